@@ -1,0 +1,207 @@
+"""`pointnet2._ext` for MI355X: the reference's nine-function operator surface
+(lib/pointnet2/_ext_src/src/bindings.cpp:6-19) bound to libbqhip.so through ctypes.
+
+What the reference's C++ wrappers do on the host is done here: dtype / contiguity / device checks
+(include/utils.h:5-25), output allocation (zero-filled where the kernel accumulates), and turning
+a non-zero status into a Python exception (the reference prints and exit(-1)s instead).
+There is NO CPU path: like the reference ("CPU not supported", sampling.cpp:34) a host tensor
+raises, and a missing library raises at import time.
+"""
+import ctypes
+import os
+
+import torch  # must be imported first: libbqhip.so resolves libamdhip64.so.7 to torch's copy
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libbqhip.so")
+
+if not os.path.exists(_LIB_PATH):
+    raise ImportError(
+        "bridgeqa_amd: %s is missing -- build it with `python -m bridgeqa_amd.build` "
+        "(hipcc --offload-arch=gfx950). There is no CPU fallback." % _LIB_PATH)
+
+_lib = ctypes.CDLL(_LIB_PATH)
+_lib.bq_last_error.restype = ctypes.c_char_p
+_lib.bq_abi_version.restype = ctypes.c_int
+if _lib.bq_abi_version() != 1:
+    raise ImportError("bridgeqa_amd: libbqhip.so ABI %d != 1" % _lib.bq_abi_version())
+
+_vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+_SIGS = {
+    "bq_opt_n_threads": [_i],
+    "bq_furthest_point_sampling": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "bq_gather_points": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "bq_gather_points_grad": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "bq_ball_query": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
+    "bq_group_points": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "bq_group_points_grad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "bq_three_nn": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "bq_three_interpolate": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "bq_three_interpolate_grad": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "bq_group_concat": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "bq_group_concat_grad": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
+}
+for _name, _args in _SIGS.items():
+    getattr(_lib, _name).argtypes = _args
+    getattr(_lib, _name).restype = ctypes.c_int
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def _check(status, what):
+    if status != 0:
+        raise RuntimeError("%s failed (status %d): %s" % (what, status, _lib.bq_last_error().decode()))
+
+
+def _req(t, dtype, name):
+    if not t.is_cuda:
+        raise RuntimeError("%s: CPU not supported (bridgeqa_amd has no CPU path)" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be a contiguous tensor" % name)
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be a %s tensor" % (name, "float" if dtype == torch.float32 else "int"))
+
+
+def _same_device(*ts):
+    d = ts[0].device
+    for t in ts[1:]:
+        if t.device != d:
+            raise RuntimeError("all tensors must be on the same device")
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def opt_n_threads(n):
+    return _lib.bq_opt_n_threads(int(n))
+
+
+def furthest_point_sampling(points, nsamples):
+    _req(points, torch.float32, "points")
+    B, N, _ = points.shape
+    with torch.cuda.device(points.device):
+        out = torch.zeros(B, nsamples, dtype=torch.int32, device=points.device)
+        tmp = torch.empty(B, N, dtype=torch.float32, device=points.device) if N > 24576 else None
+        _check(_lib.bq_furthest_point_sampling(_p(points), _p(tmp), _p(out), B, N, int(nsamples), _stream()),
+               "furthest_point_sampling")
+    return out
+
+
+def gather_points(points, idx):
+    _req(points, torch.float32, "points"); _req(idx, torch.int32, "idx"); _same_device(points, idx)
+    B, C, N = points.shape
+    M = idx.shape[1]
+    with torch.cuda.device(points.device):
+        out = torch.empty(B, C, M, dtype=torch.float32, device=points.device)
+        _check(_lib.bq_gather_points(_p(points), _p(idx), _p(out), B, C, N, M, _stream()), "gather_points")
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    _req(grad_out, torch.float32, "grad_out"); _req(idx, torch.int32, "idx"); _same_device(grad_out, idx)
+    B, C, M = grad_out.shape
+    with torch.cuda.device(grad_out.device):
+        out = torch.zeros(B, C, n, dtype=torch.float32, device=grad_out.device)
+        _check(_lib.bq_gather_points_grad(_p(grad_out), _p(idx), _p(out), B, C, int(n), M, _stream()),
+               "gather_points_grad")
+    return out
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    _req(new_xyz, torch.float32, "new_xyz"); _req(xyz, torch.float32, "xyz"); _same_device(new_xyz, xyz)
+    B, M, _ = new_xyz.shape
+    N = xyz.shape[1]
+    with torch.cuda.device(xyz.device):
+        idx = torch.empty(B, M, nsample, dtype=torch.int32, device=xyz.device)
+        _check(_lib.bq_ball_query(_p(new_xyz), _p(xyz), _p(idx), B, N, M, float(radius), int(nsample), _stream()),
+               "ball_query")
+    return idx
+
+
+def group_points(points, idx):
+    _req(points, torch.float32, "points"); _req(idx, torch.int32, "idx"); _same_device(points, idx)
+    B, C, N = points.shape
+    _, M, S = idx.shape
+    with torch.cuda.device(points.device):
+        out = torch.empty(B, C, M, S, dtype=torch.float32, device=points.device)
+        _check(_lib.bq_group_points(_p(points), _p(idx), _p(out), B, C, N, M, S, _stream()), "group_points")
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    _req(grad_out, torch.float32, "grad_out"); _req(idx, torch.int32, "idx"); _same_device(grad_out, idx)
+    B, C, M, S = grad_out.shape
+    with torch.cuda.device(grad_out.device):
+        out = torch.zeros(B, C, n, dtype=torch.float32, device=grad_out.device)
+        _check(_lib.bq_group_points_grad(_p(grad_out), _p(idx), _p(out), B, C, int(n), M, S, _stream()),
+               "group_points_grad")
+    return out
+
+
+def three_nn(unknowns, knows):
+    _req(unknowns, torch.float32, "unknowns"); _req(knows, torch.float32, "knows"); _same_device(unknowns, knows)
+    B, n, _ = unknowns.shape
+    m = knows.shape[1]
+    with torch.cuda.device(unknowns.device):
+        dist2 = torch.empty(B, n, 3, dtype=torch.float32, device=unknowns.device)
+        idx = torch.empty(B, n, 3, dtype=torch.int32, device=unknowns.device)
+        _check(_lib.bq_three_nn(_p(unknowns), _p(knows), _p(dist2), _p(idx), B, n, m, _stream()), "three_nn")
+    return [dist2, idx]
+
+
+def three_interpolate(points, idx, weight):
+    _req(points, torch.float32, "points"); _req(idx, torch.int32, "idx"); _req(weight, torch.float32, "weight")
+    _same_device(points, idx, weight)
+    B, C, m = points.shape
+    n = idx.shape[1]
+    with torch.cuda.device(points.device):
+        out = torch.empty(B, C, n, dtype=torch.float32, device=points.device)
+        _check(_lib.bq_three_interpolate(_p(points), _p(idx), _p(weight), _p(out), B, C, m, n, _stream()),
+               "three_interpolate")
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    _req(grad_out, torch.float32, "grad_out"); _req(idx, torch.int32, "idx"); _req(weight, torch.float32, "weight")
+    _same_device(grad_out, idx, weight)
+    B, C, n = grad_out.shape
+    with torch.cuda.device(grad_out.device):
+        out = torch.zeros(B, C, m, dtype=torch.float32, device=grad_out.device)
+        _check(_lib.bq_three_interpolate_grad(_p(grad_out), _p(idx), _p(weight), _p(out), B, C, n, int(m), _stream()),
+               "three_interpolate_grad")
+    return out
+
+
+# ---- fused forms (include/bqhip.h) ---------------------------------------------------------------
+def group_concat(xyz, new_xyz, features, idx, radius, normalize):
+    _req(xyz, torch.float32, "xyz"); _req(new_xyz, torch.float32, "new_xyz"); _req(idx, torch.int32, "idx")
+    if features is not None:
+        _req(features, torch.float32, "features")
+    B, N, _ = xyz.shape
+    _, M, S = idx.shape
+    C = features.shape[1] if features is not None else 0
+    with torch.cuda.device(xyz.device):
+        out = torch.empty(B, C + 3, M, S, dtype=torch.float32, device=xyz.device)
+        _check(_lib.bq_group_concat(_p(xyz), _p(new_xyz), _p(features), _p(idx), _p(out), B, C, N, M, S,
+                                    float(radius), int(bool(normalize)), _stream()), "group_concat")
+    return out
+
+
+def group_concat_grad(grad_out, idx, n, radius, normalize, need_features, need_xyz, need_new_xyz):
+    _req(grad_out, torch.float32, "grad_out"); _req(idx, torch.int32, "idx")
+    B, CT, M, S = grad_out.shape
+    C = CT - 3
+    dev = grad_out.device
+    with torch.cuda.device(dev):
+        gf = torch.zeros(B, C, n, dtype=torch.float32, device=dev) if (need_features and C > 0) else None
+        gx = torch.zeros(B, n, 3, dtype=torch.float32, device=dev) if need_xyz else None
+        gn = torch.zeros(B, M, 3, dtype=torch.float32, device=dev) if need_new_xyz else None
+        _check(_lib.bq_group_concat_grad(_p(grad_out), _p(idx), _p(gf), _p(gx), _p(gn), B, C, int(n), M, S,
+                                         float(radius), int(bool(normalize)), _stream()), "group_concat_grad")
+    return gf, gx, gn

@@ -1,0 +1,54 @@
+"""Pointnet2Backbone -- mirror of the reference's models/backbone_module.py:11-131.
+
+4 set-abstraction levels (2048/0.2/64, 1024/0.4/32, 512/0.8/16, 256/1.2/16) + 2 feature
+propagation levels; writes sa{1..4}_{xyz,features}, sa1_inds, sa2_inds, fp2_{features,xyz,inds}
+into data_dict.  State-dict names: sa{i}.mlp_module.layer{j}.{conv.weight,bn.bn.*}, fp{i}.mlp.layer{j}...
+"""
+import torch.nn as nn
+
+from .pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
+
+# (npoint, radius, nsample) per level -- backbone_module.py:28-66
+SA_LEVELS = ((2048, 0.2, 64), (1024, 0.4, 32), (512, 0.8, 16), (256, 1.2, 16))
+
+
+class Pointnet2Backbone(nn.Module):
+    def __init__(self, input_feature_dim=0, width=1, depth=2, seed_feat_dim=256):
+        super().__init__()
+        self.input_feature_dim = input_feature_dim
+        w = width
+        chans = (
+            [input_feature_dim] + [64 * w] * depth + [128 * w],
+            [128 * w] + [128 * w] * depth + [256 * w],
+            [256 * w] + [128 * w] * depth + [256 * w],
+            [256 * w] + [128 * w] * depth + [256 * w],
+        )
+        for i, ((npoint, radius, nsample), mlp) in enumerate(zip(SA_LEVELS, chans), start=1):
+            setattr(self, "sa%d" % i, PointnetSAModuleVotes(npoint=npoint, radius=radius, nsample=nsample, mlp=mlp,
+                                                            use_xyz=True, normalize_xyz=True))
+        self.fp1 = PointnetFPModule(mlp=[256 * w + 256 * w, 256 * w, 256 * w])
+        self.fp2 = PointnetFPModule(mlp=[256 * w + 256 * w, 256 * w, seed_feat_dim])
+
+    def _break_up_pc(self, pc):
+        xyz = pc[..., :3].contiguous()
+        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
+        return xyz, features
+
+    def forward(self, data_dict):
+        """data_dict["point_clouds"]: (B, N, 3 + input_feature_dim) f32, xyz first."""
+        xyz, features = self._break_up_pc(data_dict["point_clouds"])
+        for i in (1, 2, 3, 4):
+            xyz, features, inds = getattr(self, "sa%d" % i)(xyz, features)
+            if i <= 2:
+                data_dict["sa%d_inds" % i] = inds
+            data_dict["sa%d_xyz" % i] = xyz
+            data_dict["sa%d_features" % i] = features
+        features = self.fp1(data_dict["sa3_xyz"], data_dict["sa4_xyz"], data_dict["sa3_features"],
+                            data_dict["sa4_features"])
+        features = self.fp2(data_dict["sa2_xyz"], data_dict["sa3_xyz"], data_dict["sa2_features"], features)
+        data_dict["fp2_features"] = features
+        data_dict["fp2_xyz"] = data_dict["sa2_xyz"]
+        num_seed = data_dict["fp2_xyz"].shape[1]
+        # seeds are the first num_seed FPS picks of level 1 (FPS prefix property, backbone_module.py:130)
+        data_dict["fp2_inds"] = data_dict["sa1_inds"][:, 0:num_seed]
+        return data_dict

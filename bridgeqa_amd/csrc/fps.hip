@@ -1,0 +1,190 @@
+// Furthest point sampling for gfx950 -- replaces furthest_point_sampling_kernel
+// (reference lib/pointnet2/_ext_src/src/sampling_gpu.cu:69-173).
+//
+// Semantics reproduced exactly (see include/bqhip.h): every round picks the point maximising
+// the running minimum squared distance; the reference's block-size dependent tie order is
+// folded into a TOTAL ORDER key  (d desc, bitrev_{log2 bs}(k mod bs) asc, k asc)  so the result
+// does not depend on how points are assigned to lanes or on the shape of the reduction.
+//
+// MI355X design: one workgroup per scene (rounds are strictly serial; a cross-CU hand-off per
+// round costs more than the round itself).  The scene's coordinates and running minima live in
+// REGISTERS for the whole kernel (PPT points per lane), the per-round arg-max is a wave64 DPP
+// reduction plus one LDS exchange and ONE barrier per round; HBM is touched once (12 B/point in,
+// 4 B/sample out).  Scenes too large for the register file use the streaming kernel at the bottom.
+#include "bq_common.h"
+
+namespace bq {
+
+__device__ __forceinline__ unsigned tie_key(int k, int log2bs) {
+  // smaller is better: bitrev_{log2bs}(k mod bs) in the high bits, k in the low 22
+  const unsigned cls = log2bs ? (__brev((unsigned)k & ((1u << log2bs) - 1u)) >> (32 - log2bs)) : 0u;
+  return (cls << 22) | (unsigned)k;
+}
+
+// Block-wide arg-max of (best, key) -> winning point id (uniform).  One barrier.
+template <int T>
+__device__ __forceinline__ int block_argmax(float best, int bestk, int log2bs, float *s_d, unsigned *s_k, int buf) {
+  constexpr int NW = T / 64;
+  const float wmax = wave_max_f32(best);
+  const unsigned key = (best == wmax) ? tie_key(bestk, log2bs) : 0xFFFFFFFFu;
+  const unsigned wkey = wave_min_u32(key);
+  if constexpr (NW == 1) {
+    return wmax < 0.0f ? 0 : (int)(wkey & 0x3FFFFFu);
+  } else {
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+      s_d[buf * 16 + wid] = wmax;
+      s_k[buf * 16 + wid] = wkey;
+    }
+    __syncthreads();
+    float d = lane < NW ? s_d[buf * 16 + lane] : -2.0f;
+    unsigned kk = lane < NW ? s_k[buf * 16 + lane] : 0xFFFFFFFFu;
+    const float gmax = row0_max_f32(d);
+    kk = (d == gmax) ? kk : 0xFFFFFFFFu;
+    const unsigned gkey = row0_min_u32(kk);
+    return gmax < 0.0f ? 0 : (int)(gkey & 0x3FFFFFu);
+  }
+}
+
+// ---- register-resident kernel ------------------------------------------------------------------
+// T threads (multiple of bs so that a lane's points share one tie class), PPT points per lane,
+// lane t owns k = t + i*T.  XYZ_LDS: also keep an LDS copy of xyz for the winner broadcast.
+template <int T, int PPT, bool XYZ_LDS>
+__global__ __launch_bounds__(T) void fps_reg_kernel(const float *__restrict__ xyz, int32_t *__restrict__ idx,
+                                                    int N, int m, int log2bs) {
+  extern __shared__ float s_xyz[];
+  __shared__ float s_d[32];
+  __shared__ unsigned s_k[32];
+  const int t = threadIdx.x;
+  const float *P = xyz + (size_t)blockIdx.x * N * 3;
+  int32_t *out = idx + (size_t)blockIdx.x * m;
+
+  float x[PPT], y[PPT], z[PPT], md[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = t + i * T;
+    if (k < N) {
+      x[i] = P[k * 3 + 0];
+      y[i] = P[k * 3 + 1];
+      z[i] = P[k * 3 + 2];
+      // reference: `if (mag <= 1e-3) continue;` with mag promoted to double.  float(1e-3) > 1e-3,
+      // so (double)mag <= 1e-3  <=>  mag < 0.001f.
+      md[i] = (sqnorm(x[i], y[i], z[i]) < 0.001f) ? -1.0f : 1e10f;
+    } else {
+      x[i] = y[i] = z[i] = 0.0f;
+      md[i] = -1.0f;  // never a candidate: fminf(-1, d>=0) stays -1 and -1 > best(-1) is false
+    }
+    if constexpr (XYZ_LDS) {
+      if (k < N) {
+        s_xyz[k * 3 + 0] = x[i];
+        s_xyz[k * 3 + 1] = y[i];
+        s_xyz[k * 3 + 2] = z[i];
+      }
+    }
+  }
+  if (t == 0) out[0] = 0;
+  if constexpr (XYZ_LDS) __syncthreads();
+
+  int old = 0;
+  for (int j = 1; j < m; ++j) {
+    float px, py, pz;
+    if constexpr (XYZ_LDS) {
+      px = s_xyz[old * 3 + 0]; py = s_xyz[old * 3 + 1]; pz = s_xyz[old * 3 + 2];
+    } else {
+      px = P[old * 3 + 0]; py = P[old * 3 + 1]; pz = P[old * 3 + 2];
+    }
+    float best = -1.0f;
+    int bestk = 0;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const float d = sqdist(x[i], y[i], z[i], px, py, pz);
+      md[i] = fminf(md[i], d);
+      const bool gt = md[i] > best;
+      bestk = gt ? (t + i * T) : bestk;
+      best = gt ? md[i] : best;
+    }
+    old = block_argmax<T>(best, bestk, log2bs, s_d, s_k, j & 1);
+    if (t == 0) out[j] = old;
+  }
+}
+
+// ---- streaming kernel (any N): running minima in `temp` (global, L2-resident), like the
+// reference but with the same total-order reduction.  Placeholder for scenes beyond the
+// register file until the bucketed kernel lands.
+template <int T>
+__global__ __launch_bounds__(T) void fps_stream_kernel(const float *__restrict__ xyz, float *__restrict__ temp,
+                                                       int32_t *__restrict__ idx, int N, int m, int log2bs) {
+  __shared__ float s_d[32];
+  __shared__ unsigned s_k[32];
+  const int t = threadIdx.x;
+  const float *P = xyz + (size_t)blockIdx.x * N * 3;
+  float *md = temp + (size_t)blockIdx.x * N;
+  int32_t *out = idx + (size_t)blockIdx.x * m;
+  for (int k = t; k < N; k += T) md[k] = (sqnorm(P[k * 3], P[k * 3 + 1], P[k * 3 + 2]) < 0.001f) ? -1.0f : 1e10f;
+  if (t == 0) out[0] = 0;
+  int old = 0;
+  for (int j = 1; j < m; ++j) {
+    const float px = P[old * 3 + 0], py = P[old * 3 + 1], pz = P[old * 3 + 2];
+    float best = -1.0f;
+    int bestk = 0;
+    for (int k = t; k < N; k += T) {  // each lane revisits only its own k: no cross-lane hazard on md
+      const float d = sqdist(P[k * 3 + 0], P[k * 3 + 1], P[k * 3 + 2], px, py, pz);
+      const float v = fminf(md[k], d);
+      md[k] = v;
+      const bool gt = v > best;
+      bestk = gt ? k : bestk;
+      best = gt ? v : best;
+    }
+    old = block_argmax<T>(best, bestk, log2bs, s_d, s_k, j & 1);
+    if (t == 0) out[j] = old;
+  }
+}
+
+template <int T, int PPT>
+static void launch_reg(const float *xyz, int32_t *idx, int B, int N, int m, int log2bs, hipStream_t st) {
+  const size_t lds_bytes = (size_t)N * 12;
+  if (lds_bytes <= 96 * 1024) {
+    hipLaunchKernelGGL((fps_reg_kernel<T, PPT, true>), dim3(B), dim3(T), lds_bytes, st, xyz, idx, N, m, log2bs);
+  } else {
+    hipLaunchKernelGGL((fps_reg_kernel<T, PPT, false>), dim3(B), dim3(T), 0, st, xyz, idx, N, m, log2bs);
+  }
+}
+
+}  // namespace bq
+
+extern "C" int bq_opt_n_threads(int work_size) {
+  // cuda_utils.h:15-19, evaluated in double exactly as written there
+  const int pow_2 = (int)(log((double)work_size) / log(2.0));
+  int t = 1 << pow_2;
+  if (t > 512) t = 512;
+  if (t < 1) t = 1;
+  return t;
+}
+
+extern "C" int bq_furthest_point_sampling(const float *xyz, float *temp, int32_t *idx, int B, int N, int m,
+                                          void *stream) {
+  using namespace bq;
+  BQ_REQUIRE(B >= 0 && N >= 1 && m >= 0, BQ_EINVAL, "fps: bad extents B=%d N=%d m=%d", B, N, m);
+  BQ_REQUIRE(N < (1 << 22), BQ_ELIMIT, "fps: N=%d exceeds 2^22-1", N);
+  if (B == 0 || m == 0) return BQ_OK;  // sampling_gpu.cu:73
+  BQ_REQUIRE(xyz && idx, BQ_EINVAL, "fps: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int bs = bq_opt_n_threads(N);
+  int log2bs = 0;
+  while ((1 << log2bs) < bs) ++log2bs;
+  // T must be a multiple of bs (bs <= 256 when N < 512, else 512)
+  if (N <= 256)        launch_reg<256, 1>(xyz, idx, B, N, m, log2bs, st);
+  else if (N < 512)    launch_reg<256, 2>(xyz, idx, B, N, m, log2bs, st);
+  else if (N <= 512)   launch_reg<512, 1>(xyz, idx, B, N, m, log2bs, st);
+  else if (N <= 1024)  launch_reg<512, 2>(xyz, idx, B, N, m, log2bs, st);
+  else if (N <= 2048)  launch_reg<512, 4>(xyz, idx, B, N, m, log2bs, st);
+  else if (N <= 4096)  launch_reg<1024, 4>(xyz, idx, B, N, m, log2bs, st);
+  else if (N <= 8192)  launch_reg<1024, 8>(xyz, idx, B, N, m, log2bs, st);
+  else if (N <= 16384) launch_reg<1024, 16>(xyz, idx, B, N, m, log2bs, st);
+  else if (N <= 24576) launch_reg<1024, 24>(xyz, idx, B, N, m, log2bs, st);
+  else {
+    BQ_REQUIRE(temp, BQ_EINVAL, "fps: temp scratch required for N=%d", N);
+    hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(B), dim3(1024), 0, st, xyz, temp, idx, N, m, log2bs);
+  }
+  return check_launch("furthest_point_sampling");
+}

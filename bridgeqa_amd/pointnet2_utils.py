@@ -1,0 +1,194 @@
+"""Autograd operators over the HIP library -- mirror of the reference's
+lib/pointnet2/pointnet2_utils.py:51-376 (same names, argument order and autograd contract:
+FPS / ball-query outputs non-differentiable, three_nn has no backward, gather / group /
+interpolate backward call the `_grad` operator on a contiguous grad_out).
+
+`_ext` is the operator backend (bridgeqa_amd._ext -> libbqhip.so).  Tests may substitute another
+module with the same nine functions via `set_backend` (the CPU oracle, for host-logic tests on a
+machine without a GPU); the product never does.
+"""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import _ext as _hip_ext
+
+_ext = _hip_ext
+
+
+def set_backend(module):
+    """TEST HOOK: swap the operator backend (returns the previous one)."""
+    global _ext
+    prev, _ext = _ext, module
+    return prev
+
+
+def backend():
+    return _ext
+
+
+class FurthestPointSampling(Function):
+    """xyz (B,N,3) f32, npoint -> (B,npoint) i32   [pointnet2_utils.py:51-80]"""
+
+    @staticmethod
+    def forward(ctx, xyz, npoint):
+        inds = _ext.furthest_point_sampling(xyz, npoint)
+        ctx.mark_non_differentiable(inds)
+        return inds
+
+    @staticmethod
+    def backward(ctx, grad=None):
+        return None, None
+
+
+furthest_point_sample = FurthestPointSampling.apply
+
+
+class GatherOperation(Function):
+    """features (B,C,N), idx (B,npoint) -> (B,C,npoint)   [pointnet2_utils.py:83-117]"""
+
+    @staticmethod
+    def forward(ctx, features, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = features.size(2)
+        return _ext.gather_points(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        return _ext.gather_points_grad(grad_out.contiguous(), idx, ctx.n), None
+
+
+gather_operation = GatherOperation.apply
+
+
+class ThreeNN(Function):
+    """unknown (B,n,3), known (B,m,3) -> (dist (B,n,3) = sqrt(d2), idx (B,n,3))   [:120-149]"""
+
+    @staticmethod
+    def forward(ctx, unknown, known):
+        dist2, idx = _ext.three_nn(unknown, known)
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    """features (B,c,m), idx (B,n,3), weight (B,n,3) -> (B,c,n)   [:152-206]"""
+
+    @staticmethod
+    def forward(ctx, features, idx, weight):
+        ctx.save_for_backward(idx, weight)
+        ctx.m = features.size(2)
+        return _ext.three_interpolate(features, idx, weight)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        return _ext.three_interpolate_grad(grad_out.contiguous(), idx, weight, ctx.m), None, None
+
+
+three_interpolate = ThreeInterpolate.apply
+
+
+class GroupingOperation(Function):
+    """features (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample)   [:209-257]"""
+
+    @staticmethod
+    def forward(ctx, features, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = features.size(2)
+        return _ext.group_points(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        return _ext.group_points_grad(grad_out.contiguous(), idx, ctx.n), None
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class BallQuery(Function):
+    """(radius, nsample, xyz (B,N,3), new_xyz (B,npoint,3)) -> (B,npoint,nsample) i32   [:260-291]
+    NB the operator takes (new_xyz, xyz, radius, nsample)."""
+
+    @staticmethod
+    def forward(ctx, radius, nsample, xyz, new_xyz):
+        inds = _ext.ball_query(new_xyz, xyz, radius, nsample)
+        ctx.mark_non_differentiable(inds)
+        return inds
+
+    @staticmethod
+    def backward(ctx, grad=None):
+        return None, None, None, None
+
+
+ball_query = BallQuery.apply
+
+
+class _GroupConcat(Function):
+    """Fused tail of QueryAndGroup (pointnet2_utils.py:348-359): one kernel writes
+    cat([(xyz[idx]-centre)/radius, features[idx]], dim=1) instead of 2 gathers + sub + div + cat."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, features, idx, radius, normalize):
+        ctx.save_for_backward(idx)
+        ctx.n, ctx.radius, ctx.normalize = xyz.size(1), radius, normalize
+        ctx.has_features = features is not None
+        return _ext.group_concat(xyz, new_xyz, features, idx, radius, normalize)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        gf, gx, gn = _ext.group_concat_grad(grad_out.contiguous(), idx, ctx.n, ctx.radius, ctx.normalize,
+                                            ctx.has_features and need[2], need[0], need[1])
+        return gx, gn, gf, None, None, None
+
+
+class QueryAndGroup(nn.Module):
+    """Ball query + neighbourhood gather   [pointnet2_utils.py:294-376].
+
+    Only the live configuration of the reference is supported (sample_uniformly=False,
+    ret_unique_cnt=False; SURVEY.md §2.1 "live vs dead code").  Returns new_features
+    (B, 3+C, npoint, nsample) and, with ret_grouped_xyz, the centred/normalised grouped_xyz
+    (B, 3, npoint, nsample) -- a view of the first three channels, as the reference's in-place
+    ops make it the same values.
+    """
+
+    def __init__(self, radius, nsample, use_xyz=True, ret_grouped_xyz=False, normalize_xyz=False,
+                 sample_uniformly=False, ret_unique_cnt=False):
+        super().__init__()
+        if sample_uniformly or ret_unique_cnt:
+            raise NotImplementedError("sample_uniformly / ret_unique_cnt have no caller in BridgeQA")
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+        self.ret_grouped_xyz = ret_grouped_xyz
+        self.normalize_xyz = normalize_xyz
+
+    def forward(self, xyz, new_xyz, features=None):
+        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        fused = hasattr(_ext, "group_concat") and self.nsample % 4 == 0
+        if fused and (self.use_xyz or features is None):
+            new_features = _GroupConcat.apply(xyz, new_xyz, features, idx, self.radius, self.normalize_xyz)
+            grouped_xyz = new_features[:, :3]
+        else:
+            grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)
+            grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+            if self.normalize_xyz:
+                grouped_xyz = grouped_xyz / self.radius
+            if features is not None:
+                grouped_features = grouping_operation(features, idx)
+                new_features = torch.cat([grouped_xyz, grouped_features], dim=1) if self.use_xyz else grouped_features
+            else:
+                assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+                new_features = grouped_xyz
+        if self.ret_grouped_xyz:
+            return new_features, grouped_xyz
+        return new_features

@@ -1,0 +1,85 @@
+"""SharedMLP (1x1 conv -> BatchNorm -> ReLU stacks) and the BN-momentum scheduler -- mirror of
+the live part of the reference's lib/pointnet2/pytorch_utils.py:11-36,76-225,294-335.
+
+State-dict layout is part of the drop-in contract (SURVEY.md §5 "Checkpoint / resume"):
+`layer{i}.conv.weight` (Cout,Cin,1,1), `layer{i}.bn.bn.{weight,bias,running_mean,running_var,
+num_batches_tracked}`.  Conv bias is dropped when bn=True (pytorch_utils.py:124), conv weights are
+kaiming-normal, BN weight 1 / bias 0 (:78-83,133-135).
+"""
+import torch
+import torch.nn as nn
+
+
+class _BN(nn.Sequential):
+    """`bn.bn` nesting of the reference (_BNBase, pytorch_utils.py:76-83)."""
+
+    def __init__(self, num_features, kind):
+        super().__init__()
+        self.add_module("bn", kind(num_features))
+        nn.init.constant_(self[0].weight, 1.0)
+        nn.init.constant_(self[0].bias, 0.0)
+
+
+class BatchNorm1d(_BN):
+    def __init__(self, in_size, *, name=""):
+        super().__init__(in_size, nn.BatchNorm1d)
+
+
+class BatchNorm2d(_BN):
+    def __init__(self, in_size, name=""):
+        super().__init__(in_size, nn.BatchNorm2d)
+
+
+class Conv2d(nn.Sequential):
+    """conv(1x1) [-> bn] [-> activation]; children named conv / bn / activation (:104-157, :195-225)."""
+
+    def __init__(self, in_size, out_size, *, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0),
+                 activation=nn.ReLU(inplace=True), bn=False, init=nn.init.kaiming_normal_, bias=True,
+                 preact=False, name=""):
+        super().__init__()
+        if preact:
+            raise NotImplementedError("preact SharedMLP has no caller in BridgeQA")
+        bias = bias and (not bn)
+        conv = nn.Conv2d(in_size, out_size, kernel_size=kernel_size, stride=stride, padding=padding, bias=bias)
+        init(conv.weight)
+        if bias:
+            nn.init.constant_(conv.bias, 0)
+        self.add_module(name + "conv", conv)
+        if bn:
+            self.add_module(name + "bn", BatchNorm2d(out_size))
+        if activation is not None:
+            self.add_module(name + "activation", activation)
+
+
+class SharedMLP(nn.Sequential):
+    """args=[C0,C1,...,Ck] -> k layers named layer0..layer{k-1} (pytorch_utils.py:11-36)."""
+
+    def __init__(self, args, *, bn=False, activation=nn.ReLU(inplace=True), preact=False, first=False, name=""):
+        super().__init__()
+        for i in range(len(args) - 1):
+            self.add_module(name + "layer{}".format(i),
+                            Conv2d(args[i], args[i + 1], bn=bn, activation=activation, preact=preact))
+
+
+def set_bn_momentum_default(bn_momentum):
+    def fn(m):
+        if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
+            m.momentum = bn_momentum
+    return fn
+
+
+class BNMomentumScheduler(object):
+    """Used by the reference's solver (lib/solver.py:24,271-277); pytorch_utils.py:303-335."""
+
+    def __init__(self, model, bn_lambda, last_epoch=-1, setter=set_bn_momentum_default):
+        if not isinstance(model, nn.Module):
+            raise RuntimeError("Class '{}' is not a PyTorch nn Module".format(type(model).__name__))
+        self.model, self.setter, self.lmbd = model, setter, bn_lambda
+        self.step(last_epoch + 1)
+        self.last_epoch = last_epoch
+
+    def step(self, epoch=None):
+        if epoch is None:
+            epoch = self.last_epoch + 1
+        self.last_epoch = epoch
+        self.model.apply(self.setter(self.lmbd(epoch)))

@@ -1,0 +1,163 @@
+"""PARITY TESTS PROPER: the HIP operators (through the C ABI) against the CPU oracle on the same
+seeded inputs, against the committed golden vectors, and -- at BASELINE.json's full sizes --
+against size-independent properties.  Index work is compared bit-exactly; fp32 copies bit-exactly;
+atomics-based gradients with a stated tolerance."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import scene
+from test_modules_cpu import run_ops_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ext():
+    from bridgeqa_amd import _ext
+    return _ext
+
+
+def test_single_hip_runtime_loaded(ext, dev):
+    torch.zeros(1, device=dev)
+    libs = {l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l}
+    assert len(libs) == 1, libs  # libbqhip.so must share torch's HIP runtime (streams are passed across)
+    assert any("libbqhip.so" in l for l in open("/proc/self/maps"))
+
+
+FPS_CASES = [(1, 1, 1), (1, 2, 2), (2, 7, 7), (2, 63, 20), (2, 64, 64), (2, 65, 33), (3, 100, 100), (2, 255, 64),
+             (2, 256, 100), (2, 257, 100), (2, 511, 128), (2, 512, 256), (2, 513, 256), (2, 1000, 300),
+             (2, 1024, 512), (2, 2048, 1024), (2, 3000, 500), (2, 4096, 1024), (1, 8192, 700), (1, 10000, 512),
+             (1, 16384, 300), (1, 20000, 256), (1, 24576, 200), (1, 24577, 200), (1, 30000, 128)]
+
+
+@pytest.mark.parametrize("B,N,m", FPS_CASES)
+def test_fps_index_exact_vs_oracle(ext, oracle, dev, B, N, m):
+    xyz = scene(B, N, 0, seed=N * 7 + m)
+    got = ext.furthest_point_sampling(xyz.to(dev), m).cpu()
+    assert torch.equal(got, oracle.furthest_point_sampling(xyz, m))
+
+
+def test_fps_edge_cases_vs_oracle(ext, oracle, dev):
+    # exact ties on a lattice (tie order = bit-reversed reference-thread id, then k), several block sizes
+    for nx, ny, nz in ((4, 4, 2), (8, 8, 4), (16, 8, 5), (16, 16, 8)):
+        g = np.stack(np.meshgrid(np.arange(nx) * 0.5, np.arange(ny) * 0.5, np.arange(nz) * 0.5, indexing="ij"), -1)
+        xyz = torch.tensor(g.reshape(1, -1, 3) + 1.0, dtype=torch.float32).contiguous()
+        m = xyz.shape[1]
+        assert torch.equal(ext.furthest_point_sampling(xyz.to(dev), m).cpu(), oracle.furthest_point_sampling(xyz, m))
+    # duplicates + origin-ball points + m > number of distinct points
+    xyz = scene(2, 700, 0, 3)
+    xyz[0, 100:140] = xyz[0, 5]
+    xyz[0, 0] = 0.0
+    xyz[0, 9] = torch.tensor([0.03, 0.0, 0.0])
+    xyz[0, 10] = torch.tensor([0.0316, 0.0, 0.0])
+    xyz[0, 11] = torch.tensor([0.03163, 0.0, 0.0])
+    xyz[1, :] = xyz[1, :1]  # every point identical
+    assert torch.equal(ext.furthest_point_sampling(xyz.to(dev), 700).cpu(), oracle.furthest_point_sampling(xyz, 700))
+    z = torch.zeros(1, 50, 3)  # everything inside the skip ball
+    assert ext.furthest_point_sampling(z.to(dev), 8).cpu().tolist() == [[0] * 8]
+    tiny = scene(1, 5, 0, 12)  # m > N
+    assert torch.equal(ext.furthest_point_sampling(tiny.to(dev), 9).cpu(), oracle.furthest_point_sampling(tiny, 9))
+    assert ext.furthest_point_sampling(torch.zeros(0, 4, 3, device=dev), 2).shape == (0, 2)
+
+
+@pytest.mark.parametrize("B,N,M,r,S", [(2, 50, 10, 0.5, 4), (2, 1000, 64, 0.4, 16), (2, 1000, 257, 3.0, 32),
+                                       (1, 4096, 512, 0.2, 64), (2, 300, 300, 0.05, 8), (1, 130, 3, 100.0, 64),
+                                       (1, 64, 64, 1.0, 5), (1, 5000, 100, 1.2, 16)])
+def test_ball_query_index_exact_vs_oracle(ext, oracle, dev, B, N, M, r, S):
+    xyz = scene(B, N, 0, seed=N + M)
+    new_xyz = xyz[:, torch.randperm(N, generator=torch.Generator().manual_seed(1))[:M]].contiguous()
+    if r < 0.1:
+        new_xyz[:, M // 2:] += 50.0  # empty balls -> all-zero rows
+    got = ext.ball_query(new_xyz.to(dev), xyz.to(dev), r, S).cpu()
+    assert torch.equal(got, oracle.ball_query(new_xyz, xyz, r, S))
+
+
+def test_gather_group_interp_vs_oracle(ext, oracle, dev):
+    g = torch.Generator().manual_seed(0)
+    for (B, C, N, M, S) in ((2, 5, 300, 40, 8), (1, 131, 2048, 1024, 32), (2, 3, 777, 33, 5), (1, 1, 64, 64, 64)):
+        pts = torch.randn(B, C, N, generator=g)
+        idx = torch.randint(0, N, (B, M, S), generator=g, dtype=torch.int32)
+        idx[:, :, S // 2:] = idx[:, :, :1]  # padded neighbourhoods: repeated ids
+        assert torch.equal(ext.group_points(pts.to(dev), idx.to(dev)).cpu(), oracle.group_points(pts, idx))
+        go = torch.randn(B, C, M, S, generator=g)
+        torch.testing.assert_close(ext.group_points_grad(go.to(dev), idx.to(dev), N).cpu(),
+                                   oracle.group_points_grad(go, idx, N), rtol=1e-4, atol=1e-4)  # fp32 atomics: order
+        gi = torch.randint(0, N, (B, M), generator=g, dtype=torch.int32)
+        assert torch.equal(ext.gather_points(pts.to(dev), gi.to(dev)).cpu(), oracle.gather_points(pts, gi))
+        gg = torch.randn(B, C, M, generator=g)
+        torch.testing.assert_close(ext.gather_points_grad(gg.to(dev), gi.to(dev), N).cpu(),
+                                   oracle.gather_points_grad(gg, gi, N), rtol=1e-5, atol=1e-5)
+    for (B, n, m, C) in ((2, 120, 40, 6), (1, 1024, 512, 256), (2, 300, 2, 4), (1, 2500, 1500, 3)):
+        unknown, known = scene(B, n, 0, 1), scene(B, m, 0, 2)
+        k = min(5, m)
+        known[:, :k] = unknown[:, :k]
+        d2, idx = ext.three_nn(unknown.to(dev), known.to(dev))
+        od2, oidx = oracle.three_nn(unknown, known)
+        assert torch.equal(idx.cpu(), oidx) and torch.equal(d2.cpu(), od2)
+        w = torch.rand(B, n, 3, generator=g)
+        feats = torch.randn(B, C, m, generator=g)
+        assert torch.equal(ext.three_interpolate(feats.to(dev), idx, w.to(dev)).cpu(),
+                           oracle.three_interpolate(feats, oidx, w))  # same op order, no contraction => exact
+        go = torch.randn(B, C, n, generator=g)
+        torch.testing.assert_close(ext.three_interpolate_grad(go.to(dev), idx, w.to(dev), m).cpu(),
+                                   oracle.three_interpolate_grad(go, oidx, w, m), rtol=1e-4, atol=1e-4)
+
+
+def test_group_concat_equals_reference_composition(ext, oracle, dev):
+    g = torch.Generator().manual_seed(3)
+    for (B, C, N, M, S, r, norm) in ((2, 5, 512, 64, 16, 0.9, True), (1, 0, 300, 20, 8, 0.3, True),
+                                     (1, 128, 2048, 1024, 32, 0.4, True), (2, 4, 100, 10, 4, 0.2, False)):
+        xyz = scene(B, N, 0, 5)
+        new_xyz = xyz[:, :M].contiguous()
+        idx = oracle.ball_query(new_xyz, xyz, r, S)
+        feats = torch.randn(B, C, N, generator=g) if C else None
+        # reference composition (pointnet2_utils.py:348-359) on CPU
+        gx = oracle.group_points(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if norm:
+            gx = gx / r
+        want = torch.cat([gx, oracle.group_points(feats, idx)], 1) if C else gx
+        got = ext.group_concat(xyz.to(dev), new_xyz.to(dev), feats.to(dev) if C else None, idx.to(dev), r, norm)
+        assert torch.equal(got.cpu(), want)
+        go = torch.randn(B, C + 3, M, S, generator=g)
+        gf, gxyz, gnew = ext.group_concat_grad(go.to(dev), idx.to(dev), N, r, norm, True, True, True)
+        s = go[:, :3] / r if norm else go[:, :3]
+        want_xyz = oracle.group_points_grad(s.contiguous(), idx, N).transpose(1, 2)
+        torch.testing.assert_close(gxyz.cpu(), want_xyz, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(gnew.cpu(), -s.sum(-1).transpose(1, 2), rtol=1e-4, atol=1e-4)
+        if C:
+            torch.testing.assert_close(gf.cpu(), oracle.group_points_grad(go[:, 3:].contiguous(), idx, N),
+                                       rtol=1e-4, atol=1e-4)
+
+
+def test_autograd_ops_vs_reference_golden_on_gpu(ext, golden, dev):
+    from bridgeqa_amd import pointnet2_utils as pu
+    assert pu.backend() is ext  # the HIP backend, not a substitute
+    run_ops_golden(golden("pn2_ops.npz"), pu, lambda a: torch.from_numpy(a).to(dev))
+
+
+def test_full_size_c2_properties_and_oracle_spot_check(ext, oracle, dev):
+    """BASELINE config 2 sizes: B=16, N=40000 -> 2048 centres, r=0.2, S=64."""
+    B, N, M = 16, 40000, 2048
+    xyz = scene(B, N, 0, seed=42)
+    dxyz = xyz.to(dev)
+    inds = ext.furthest_point_sampling(dxyz, M)
+    ci = inds.cpu()
+    assert (ci[:, 0] == 0).all() and ((ci >= 0) & (ci < N)).all()
+    assert all(len(set(r.tolist())) == M for r in ci)  # distinct points -> unique ids
+    assert torch.equal(ext.furthest_point_sampling(dxyz, 256).cpu(), ci[:, :256])  # prefix property
+    # permuting scenes permutes results (no cross-scene state)
+    perm = torch.tensor([3, 0, 15, 7])
+    assert torch.equal(ext.furthest_point_sampling(dxyz[perm.to(dev)].contiguous(), 512).cpu(), ci[perm, :512])
+    assert torch.equal(ci[:2], oracle.furthest_point_sampling(xyz[:2].contiguous(), M))  # full size, 2 scenes
+    new_xyz = ext.gather_points(dxyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+    assert torch.equal(new_xyz.cpu(), torch.gather(xyz, 1, ci.long()[..., None].expand(-1, -1, 3)))
+    idx = ext.ball_query(new_xyz, dxyz, 0.2, 64).cpu()
+    assert (idx == ci[..., None]).any(-1).all()  # a centre is inside its own ball (d=0) and balls hold < 64 points here
+    # ids ascending up to the pad, pads repeat the first hit
+    d = idx[:, :, 1:] - idx[:, :, :-1]
+    assert ((d > 0) | (idx[:, :, 1:] == idx[:, :, :1])).all()
+    assert torch.equal(idx[:2], oracle.ball_query(new_xyz[:2].cpu().contiguous(), xyz[:2].contiguous(), 0.2, 64))
+    # SA2-level FPS on the FPS-ordered set is the identity prefix (backbone_module.py:111)
+    inds2 = ext.furthest_point_sampling(new_xyz, 1024).cpu()
+    assert torch.equal(inds2, torch.arange(1024, dtype=torch.int32).expand(B, -1))

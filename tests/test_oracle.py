@@ -1,0 +1,181 @@
+"""The oracle against (a) independent brute-force definitions, (b) the properties the reference's
+callers rely on, (c) the committed golden vectors (which were produced through the reference's own
+Python wrappers).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import scene
+
+
+def bitrev(v, bits):
+    r = 0
+    for _ in range(bits):
+        r = (r << 1) | (v & 1)
+        v >>= 1
+    return r
+
+
+def fps_definition(xyz, m, bs):
+    """FPS by its definition with the total-order tie key (d desc, bitrev(k mod bs) asc, k asc)."""
+    n = xyz.shape[0]
+    x = xyz.astype(np.float32)
+    mag = (x[:, 0] * x[:, 0] + x[:, 1] * x[:, 1]) + x[:, 2] * x[:, 2]
+    valid = ~(mag.astype(np.float64) <= 1e-3)
+    md = np.full(n, 1e10, np.float32)
+    bits = int(np.log2(bs))
+    tie = np.array([(bitrev(k % bs, bits) << 22) | k for k in range(n)], dtype=np.int64)
+    out = [0]
+    old = 0
+    for _ in range(1, m):
+        d = x - x[old]
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        md[valid] = np.minimum(md[valid], d2[valid])
+        cand = np.where(valid, md, -1.0).astype(np.float32)
+        best = cand.max()
+        if best < 0:
+            old = 0
+        else:
+            ks = np.nonzero(cand == best)[0]
+            old = int(ks[np.argmin(tie[ks])])
+        out.append(old)
+    return np.array(out, np.int32)
+
+
+@pytest.mark.parametrize("n,m,seed", [(1, 1, 0), (2, 2, 1), (7, 7, 2), (64, 32, 3), (100, 100, 4), (513, 64, 5),
+                                      (1000, 200, 6), (2048, 256, 7)])
+def test_fps_matches_definition(oracle, n, m, seed):
+    xyz = scene(1, n, 0, seed)
+    got = oracle.furthest_point_sampling(xyz, m)[0].numpy()
+    want = fps_definition(xyz[0].numpy(), m, oracle.opt_n_threads(n))
+    np.testing.assert_array_equal(got, want)
+
+
+def test_fps_ties_and_origin_ball(oracle):
+    # lattice => many exact ties; bs=8 tie order is bit-reversed-tid-major
+    g = np.stack(np.meshgrid(np.arange(4.0), np.arange(4.0), np.arange(2.0), indexing="ij"), -1).reshape(-1, 3) + 1.0
+    xyz = torch.tensor(g, dtype=torch.float32)[None].contiguous()
+    got = oracle.furthest_point_sampling(xyz, 32)[0].numpy()
+    np.testing.assert_array_equal(got, fps_definition(g, 32, oracle.opt_n_threads(32)))
+    # points inside the 1e-3 ball are never picked (except the forced first index)
+    xyz = scene(1, 300, 0, 9)
+    xyz[0, 0] = 0.0
+    xyz[0, 5] = torch.tensor([0.03, 0.0, 0.0])      # mag 9.0e-4 -> skipped
+    xyz[0, 6] = torch.tensor([0.0316, 0.0, 0.0])    # mag 9.9856e-4 -> skipped
+    xyz[0, 7] = torch.tensor([0.03163, 0.0, 0.0])   # mag 1.00046e-3 -> kept
+    got = oracle.furthest_point_sampling(xyz, 300)[0].numpy()
+    assert got[0] == 0 and 5 not in got and 6 not in got and 7 in got
+    # all points skipped -> index 0 forever
+    z = torch.zeros(1, 10, 3)
+    assert oracle.furthest_point_sampling(z, 5)[0].tolist() == [0] * 5
+
+
+def test_fps_properties(oracle):
+    xyz = scene(2, 1500, 0, 11)
+    inds = oracle.furthest_point_sampling(xyz, 300)
+    assert (inds[:, 0] == 0).all()
+    for b in range(2):
+        assert len(set(inds[b].tolist())) == 300  # distinct points => unique ids
+    # prefix property used at backbone_module.py:130
+    np.testing.assert_array_equal(oracle.furthest_point_sampling(xyz, 100).numpy(), inds[:, :100].numpy())
+    # FPS of an FPS-ordered set is the identity prefix (backbone_module.py:111 comment)
+    sel = torch.gather(xyz, 1, inds.long()[..., None].expand(-1, -1, 3)).contiguous()
+    np.testing.assert_array_equal(oracle.furthest_point_sampling(sel, 128).numpy(),
+                                  np.tile(np.arange(128, dtype=np.int32), (2, 1)))
+    # m > N: once every distance is 0 the arg-max falls back deterministically
+    tiny = scene(1, 5, 0, 12)
+    out = oracle.furthest_point_sampling(tiny, 9)[0].tolist()
+    assert sorted(out[:5]) == [0, 1, 2, 3, 4] and len(out) == 9
+
+
+def ball_query_definition(new_xyz, xyz, r, S):
+    r2 = np.float32(r) * np.float32(r)
+    M = new_xyz.shape[0]
+    out = np.zeros((M, S), np.int32)
+    for j in range(M):
+        d = (new_xyz[j] - xyz).astype(np.float32)
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        hits = np.nonzero(d2 < r2)[0][:S]
+        if len(hits):
+            out[j, :] = hits[0]
+            out[j, :len(hits)] = hits
+    return out
+
+
+@pytest.mark.parametrize("n,m,r,S", [(50, 10, 0.5, 4), (1000, 64, 0.4, 16), (1000, 64, 3.0, 32), (300, 300, 0.05, 8)])
+def test_ball_query_matches_definition(oracle, n, m, r, S):
+    xyz = scene(2, n, 0, n + m)
+    new_xyz = xyz[:, :m].clone().contiguous()
+    new_xyz[:, m // 2:] += 50.0 if r < 0.1 else 0.0  # far-away centres -> empty balls
+    got = oracle.ball_query(new_xyz, xyz, r, S).numpy()
+    for b in range(2):
+        np.testing.assert_array_equal(got[b], ball_query_definition(new_xyz[b].numpy(), xyz[b].numpy(), r, S))
+    if r < 0.1:
+        assert (got[:, m // 2:] == 0).all()  # empty ball -> zeros (ball_query.cpp:19-21)
+
+
+def test_three_nn_and_interpolate_definitions(oracle):
+    unknown, known = scene(2, 120, 0, 1), scene(2, 40, 0, 2)
+    known[:, :5] = unknown[:, :5]  # exact zero distances
+    known[0, 7] = known[0, 6]      # duplicate known point -> lowest index first
+    d2, idx = oracle.three_nn(unknown, known)
+    for b in range(2):
+        diff = (unknown[b, :, None, :] - known[b, None, :, :]).numpy().astype(np.float32)
+        full = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
+        order = np.argsort(full, axis=1, kind="stable")[:, :3]
+        np.testing.assert_array_equal(idx[b].numpy(), order.astype(np.int32))
+        np.testing.assert_array_equal(d2[b].numpy(), np.take_along_axis(full, order, 1))
+    # m < 3 leaves +inf / index 0 in the unfilled slots (1e40 stored to float)
+    d2s, idxs = oracle.three_nn(unknown, known[:, :2].contiguous())
+    assert torch.isinf(d2s[..., 2]).all() and (idxs[..., 2] == 0).all()
+    w = torch.rand(2, 120, 3)
+    feats = torch.randn(2, 6, 40)
+    out = oracle.three_interpolate(feats, idx, w)
+    ref = sum(torch.gather(feats, 2, idx[:, None, :, t].long().expand(-1, 6, -1)) * w[:, None, :, t] for t in range(3))
+    torch.testing.assert_close(out, ref, rtol=1e-6, atol=1e-6)
+    go = torch.randn(2, 6, 120)
+    grad = oracle.three_interpolate_grad(go, idx, w, 40)
+    ref = torch.zeros(2, 6, 40)
+    for t in range(3):
+        ref.scatter_add_(2, idx[:, None, :, t].long().expand(-1, 6, -1), go * w[:, None, :, t])
+    torch.testing.assert_close(grad, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_gather_group_definitions(oracle):
+    pts = torch.randn(2, 5, 300)
+    idx = torch.randint(0, 300, (2, 40, 8), dtype=torch.int32)
+    out = oracle.group_points(pts, idx)
+    ref = torch.gather(pts[:, :, None, :].expand(-1, -1, 40, -1), 3, idx[:, None].long().expand(-1, 5, -1, -1))
+    assert torch.equal(out, ref)
+    go = torch.randn(2, 5, 40, 8)
+    grad = oracle.group_points_grad(go, idx, 300)
+    ref = torch.zeros(2, 5, 300).scatter_add_(2, idx.reshape(2, 1, -1).long().expand(-1, 5, -1), go.reshape(2, 5, -1))
+    torch.testing.assert_close(grad, ref, rtol=1e-5, atol=1e-5)
+    gi = torch.randint(0, 300, (2, 50), dtype=torch.int32)
+    assert torch.equal(oracle.gather_points(pts, gi), torch.gather(pts, 2, gi[:, None].long().expand(-1, 5, -1)))
+    gg = oracle.gather_points_grad(torch.ones(2, 5, 50), gi, 300)
+    assert gg.sum().item() == 2 * 5 * 50
+    # empty / degenerate extents
+    assert oracle.ball_query(torch.zeros(1, 0, 3), torch.zeros(1, 4, 3), 1.0, 4).shape == (1, 0, 4)
+    assert oracle.furthest_point_sampling(torch.zeros(0, 4, 3), 2).shape == (0, 2)
+
+
+def test_oracle_reproduces_golden_ops(oracle, golden):
+    """Drift guard: the goldens were written by the reference's Python wrappers over this oracle."""
+    g = golden("pn2_ops.npz")
+    for tag in ("n64", "n1000", "n4096"):
+        xyz = torch.from_numpy(g["fps_%s_xyz" % tag])
+        inds = oracle.furthest_point_sampling(xyz, int(g["fps_%s_m" % tag]))
+        np.testing.assert_array_equal(inds.numpy(), g["fps_%s_inds" % tag])
+        new_xyz = torch.from_numpy(g["gather_%s_out" % tag])
+        for key in [k for k in g if k.startswith("bq_%s_" % tag)]:
+            r, S = key.split("_")[2:]
+            got = oracle.ball_query(new_xyz, xyz, float(r[1:]), int(S[1:]))
+            np.testing.assert_array_equal(got.numpy(), g[key])
+
+
+def test_opt_n_threads(oracle):
+    # cuda_utils.h:15-19 including the log()/log(2) truncation it really performs
+    for n in list(range(1, 70)) + [127, 128, 129, 255, 256, 257, 511, 512, 513, 1000, 1024, 4096, 40000, 80000]:
+        want = max(min(1 << int(np.log(float(n)) / np.log(2.0)), 512), 1)
+        assert oracle.opt_n_threads(n) == want

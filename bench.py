@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on synthetic data.
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload c2|c3] [--cin 132]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one training pass (forward + backward + AdamW step) of the hot path over one synthetic
+batch that is already resident in HBM: B=16 scenes x 40000 points (xyz + C_in features), and for
+workload c3 additionally one 512x512 view + question/answer ids per scene.  One process per GPU;
+each rank owns its own B=16 batch (weak scaling), gradients are all-reduced over RCCL.
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` for the dominant
+kernel and `cpu_baseline` (the CPU oracle port timed on a bounded sample; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("BQ_WORKLOAD", "auto"), choices=["auto", "c2", "c3"])
+    ap.add_argument("--cin", type=int, default=132, help="per-point feature channels (README recipe: 128+3+1)")
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--points", type=int, default=40000)
+    ap.add_argument("--image", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-scenes", type=int, default=2, help="scenes in the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def synth_batch(B, N, cin, seed, device):
+    """SURVEY.md §8d synthetic inputs: xyz ~ U([0,8]x[0,8]x[0,3]) m, features ~ N(0,1), seed 42."""
+    g = torch.Generator().manual_seed(seed)
+    xyz = torch.rand(B, N, 3, generator=g) * torch.tensor([8.0, 8.0, 3.0])
+    feats = torch.randn(B, N, cin, generator=g)
+    return torch.cat([xyz, feats], -1).contiguous().to(device)
+
+
+class DetPath(torch.nn.Module):
+    """The DET-stage slice of ScanQA.forward (models/qa_module.py:438-459): backbone -> voting ->
+    L2-normalise -> vote clustering + proposal head."""
+
+    def __init__(self, cin):
+        super().__init__()
+        import numpy as np
+        from bridgeqa_amd.backbone_module import Pointnet2Backbone
+        from bridgeqa_amd.proposal_module import ProposalModule
+        from bridgeqa_amd.voting_module import VotingModule
+        self.detection_backbone = Pointnet2Backbone(input_feature_dim=cin)
+        self.voting_net = VotingModule(1, 256)
+        self.proposal_net = ProposalModule(18, 1, 18, np.ones((18, 3)), 256, "vote_fps")
+
+    def forward(self, data_dict):
+        dd = self.detection_backbone(data_dict)
+        xyz, features = self.voting_net(dd["fp2_xyz"], dd["fp2_features"])
+        features = features.div(torch.norm(features, p=2, dim=1).unsqueeze(1))
+        dd["vote_xyz"], dd["vote_features"] = xyz, features
+        return self.proposal_net(xyz, features, dd)
+
+
+def det_loss(dd):
+    """Stand-in scalar with gradients into every head (the reference's losses are SURVEY §8f 'next')."""
+    return (dd["objectness_scores"].square().mean() + dd["center"].square().mean() * 1e-2 +
+            dd["size_residuals_normalized"].square().mean() + dd["sem_cls_scores"].square().mean() +
+            (dd["vote_xyz"] - dd["fp2_xyz"]).abs().mean())
+
+
+class OpTimer(object):
+    """HIP-event timing of the native operators on the stream they are launched on."""
+
+    def __init__(self):
+        self.records = []
+
+    def wrap(self, ext, names):
+        self._orig = {n: getattr(ext, n) for n in names}
+        for n in names:
+            def timed(*a, _n=n, **k):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = self._orig[_n](*a, **k)
+                e.record()
+                self.records.append((_n, tuple(a[0].shape), s, e))
+                return out
+            setattr(ext, n, timed)
+        self._ext = ext
+
+    def unwrap(self):
+        for n, f in self._orig.items():
+            setattr(self._ext, n, f)
+
+    def summary(self):
+        agg = {}
+        for n, shape, s, e in self.records:
+            agg.setdefault((n, shape), []).append(s.elapsed_time(e))
+        return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+
+
+def cpu_baseline(args):
+    """The hot path on the host cores: bridgeqa_amd's Python layers over the CPU oracle backend
+    (oracle/ -- allowed here as the reported baseline only) + torch-CPU fp32 for the dense layers."""
+    from bridgeqa_amd import pointnet2_utils
+    from oracle import pn2_oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    prev = pointnet2_utils.set_backend(pn2_oracle)
+    try:
+        torch.manual_seed(0)
+        model = DetPath(args.cin)
+        opt = torch.optim.AdamW(model.parameters(), lr=5e-4)
+        B = args.cpu_scenes
+        pc = synth_batch(B, args.points, args.cin, 42, "cpu")
+        times = []
+        for it in range(2):
+            t0 = time.time()
+            opt.zero_grad(set_to_none=True)
+            loss = det_loss(model({"point_clouds": pc}))
+            loss.backward()
+            opt.step()
+            times.append(time.time() - t0)
+        dt = min(times)
+    finally:
+        pointnet2_utils.set_backend(prev)
+    return {"value": round(B / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "DET slice fwd+bwd+AdamW, %d scenes x %d pts, C_in=%d, fp32, best of 2 steps "
+                      "(oracle ops with OpenMP + torch-CPU)" % (B, args.points, args.cin)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://")
+    workload = "c2" if args.workload == "auto" else args.workload
+    if workload == "c3":
+        raise SystemExit("workload c3 (fusion) is not wired into bench.py yet")
+
+    from bridgeqa_amd import _ext
+    torch.manual_seed(0)
+    model = DetPath(args.cin).to(dev)
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local])
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-5)
+    pc = synth_batch(args.batch, args.points, args.cin, 42 + rank, dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = det_loss(model({"point_clouds": pc}))
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    timer = OpTimer()
+    timer.wrap(_ext, ["furthest_point_sampling", "ball_query", "group_concat", "group_concat_grad"])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    timer.unwrap()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    assert torch.isfinite(loss).item()
+
+    if rank == 0:
+        ops = timer.summary()
+        # dominant native kernel: SA1 furthest point sampling; algorithmic bytes 20*N*(m-1) per scene
+        key = ("furthest_point_sampling", (args.batch, args.points, 3))
+        fps_ms, _ = ops.get(key, (float("nan"), 0))
+        alg = 20.0 * args.points * (2048 - 1) * args.batch
+        achieved = alg / (fps_ms * 1e-3) / 1e9
+        out = {
+            "metric": "train samples/s (40k-pt scene + 512^2 view, bs16)",
+            "value": round(args.batch * world * args.steps / dt, 3),
+            "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "c2: DET-stage slice (VoteNet backbone + voting + vote-cluster/proposal), "
+                                   "fwd+bwd+AdamW, stand-in loss; fusion (c3) not yet in this bench",
+                       "global_batch": args.batch * world, "points": args.points, "c_in": args.cin,
+                       "parallelism": "dp%d" % world},
+            "roofline": {"kernel": "fps (SA1 40000->2048)", "bound": "hbm", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None, "ms_per_launch": round(fps_ms, 4),
+                         "algorithmic_bytes_per_launch": alg},
+            "op_ms": {"%s%s" % (k[0], list(k[1])): round(v[0], 4) for k, v in sorted(ops.items())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -35,6 +35,7 @@ _SIGS = {
     "bq_group_points": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "bq_group_points_grad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "bq_three_nn": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "bq_three_nn_dist": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "bq_three_interpolate": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "bq_three_interpolate_grad": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "bq_group_concat": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
@@ -153,6 +154,18 @@ def three_nn(unknowns, knows):
         idx = torch.empty(B, n, 3, dtype=torch.int32, device=unknowns.device)
         _check(_lib.bq_three_nn(_p(unknowns), _p(knows), _p(dist2), _p(idx), B, n, m, _stream()), "three_nn")
     return [dist2, idx]
+
+
+def three_nn_dist(unknowns, knows):
+    """three_nn + sqrt in one kernel (IEEE-correct sqrt, unlike the device sqrt torch uses)."""
+    _req(unknowns, torch.float32, "unknowns"); _req(knows, torch.float32, "knows"); _same_device(unknowns, knows)
+    B, n, _ = unknowns.shape
+    m = knows.shape[1]
+    with torch.cuda.device(unknowns.device):
+        dist = torch.empty(B, n, 3, dtype=torch.float32, device=unknowns.device)
+        idx = torch.empty(B, n, 3, dtype=torch.int32, device=unknowns.device)
+        _check(_lib.bq_three_nn_dist(_p(unknowns), _p(knows), _p(dist), _p(idx), B, n, m, _stream()), "three_nn_dist")
+    return [dist, idx]
 
 
 def three_interpolate(points, idx, weight):

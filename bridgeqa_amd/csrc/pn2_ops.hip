@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256) void group_concat_grad_kernel(const float *__r
 // running bests are compared exactly as the reference does (float candidate against a best
 // that is either a float value or the 1e40 sentinel -- held here as +inf, same ordering).
 // ---------------------------------------------------------------------------------------------
+template <bool SQRT>
 __global__ __launch_bounds__(256) void three_nn_kernel(const float *__restrict__ unknown,
                                                        const float *__restrict__ known, float *__restrict__ dist2,
                                                        int32_t *__restrict__ idx, int n, int m) {
@@ -263,6 +264,9 @@ __global__ __launch_bounds__(256) void three_nn_kernel(const float *__restrict__
   if (j < n) {
     float *od = dist2 + ((size_t)b * n + j) * 3;
     int32_t *oi = idx + ((size_t)b * n + j) * 3;
+    if constexpr (SQRT) {  // correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt)
+      b1 = sqrtf(b1); b2 = sqrtf(b2); b3 = sqrtf(b3);
+    }
     od[0] = b1; od[1] = b2; od[2] = b3;
     oi[0] = i1; oi[1] = i2; oi[2] = i3;
   }
@@ -434,9 +438,20 @@ extern "C" int bq_three_nn(const float *unknown, const float *known, float *dist
   if (B == 0 || n == 0) return BQ_OK;
   BQ_REQUIRE(unknown && dist2 && idx && (known || m == 0), BQ_EINVAL, "three_nn: null pointer");
   BQ_REQUIRE(B <= 65535, BQ_ELIMIT, "three_nn: B > 65535");
-  hipLaunchKernelGGL(three_nn_kernel, dim3(cdiv(n, 256), B), dim3(256), 0, (hipStream_t)stream, unknown, known, dist2,
-                     idx, n, m);
+  hipLaunchKernelGGL(three_nn_kernel<false>, dim3(cdiv(n, 256), B), dim3(256), 0, (hipStream_t)stream, unknown, known,
+                     dist2, idx, n, m);
   return check_launch("three_nn");
+}
+
+extern "C" int bq_three_nn_dist(const float *unknown, const float *known, float *dist, int32_t *idx, int B, int n,
+                                int m, void *stream) {
+  BQ_REQUIRE(B >= 0 && n >= 0 && m >= 0, BQ_EINVAL, "three_nn_dist: bad extents");
+  if (B == 0 || n == 0) return BQ_OK;
+  BQ_REQUIRE(unknown && dist && idx && (known || m == 0), BQ_EINVAL, "three_nn_dist: null pointer");
+  BQ_REQUIRE(B <= 65535, BQ_ELIMIT, "three_nn_dist: B > 65535");
+  hipLaunchKernelGGL(three_nn_kernel<true>, dim3(cdiv(n, 256), B), dim3(256), 0, (hipStream_t)stream, unknown, known,
+                     dist, idx, n, m);
+  return check_launch("three_nn_dist");
 }
 
 extern "C" int bq_three_interpolate(const float *points, const int32_t *idx, const float *weight, float *out, int B,

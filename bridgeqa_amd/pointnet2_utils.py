@@ -67,9 +67,13 @@ class ThreeNN(Function):
 
     @staticmethod
     def forward(ctx, unknown, known):
-        dist2, idx = _ext.three_nn(unknown, known)
+        if hasattr(_ext, "three_nn_dist"):
+            dist, idx = _ext.three_nn_dist(unknown, known)
+        else:
+            dist2, idx = _ext.three_nn(unknown, known)
+            dist = torch.sqrt(dist2)
         ctx.mark_non_differentiable(idx)
-        return torch.sqrt(dist2), idx
+        return dist, idx
 
     @staticmethod
     def backward(ctx, a=None, b=None):

@@ -105,6 +105,11 @@ BQ_API int bq_three_interpolate_grad(const float *grad_out, const int32_t *idx, 
 /* ---- fused forms (no reference counterpart as a single op; each equals the composition
  *      the reference's Python performs, cited per function) ------------------------------ */
 
+/* ThreeNN.forward (pointnet2_utils.py:140-142): bq_three_nn followed by a correctly rounded sqrt;
+ *   dist (B,n,3) f32 = sqrt(dist2). */
+BQ_API int bq_three_nn_dist(const float *unknown, const float *known, float *dist, int32_t *idx, int B,
+                     int n, int m, void *stream);
+
 /* QueryAndGroup.forward body after ball_query (pointnet2_utils.py:348-359):
  *   out[b, 0:3, j, k] = (xyz[b, idx[b,j,k], :] - new_xyz[b,j,:]) / radius   (if normalize)
  *   out[b, 3:3+C, j, k] = features[b, :, idx[b,j,k]]

@@ -1,0 +1,90 @@
+"""Dense operators of the 2D-3D fusion path (ViT / MED-BERT twin encoder / LM decoder).
+
+One narrow surface -- linear (+bias, +GELU), layer_norm (+residual), attention (additive mask,
+optional probabilities), lm_loss -- so the modules in vit.py / med.py / blip_vqa_3d.py never
+touch a kernel directly and every op has exactly one place where its MI355X implementation lives.
+
+Precision policy ("bf16-in / fp32-accumulate allowed"): parameters stay fp32 (the
+reference trains in fp32 and the state dict must round-trip); with `set_compute_dtype(bfloat16)`
+GEMM operands are cast to bf16 and accumulate in fp32, softmax / LayerNorm statistics and the
+residual stream stay fp32.  `float32` reproduces the reference arithmetic and is what the CPU
+parity tests use.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+_COMPUTE_DTYPE = torch.float32
+
+
+def set_compute_dtype(dtype):
+    global _COMPUTE_DTYPE
+    prev, _COMPUTE_DTYPE = _COMPUTE_DTYPE, dtype
+    return prev
+
+
+def compute_dtype():
+    return _COMPUTE_DTYPE
+
+
+def _c(t):
+    return t if t.dtype == _COMPUTE_DTYPE else t.to(_COMPUTE_DTYPE)
+
+
+def linear(x, weight, bias=None, act=None):
+    """y = act(x @ weight^T + bias); weight (out,in) as nn.Linear stores it.  Output in the compute dtype."""
+    y = F.linear(_c(x), _c(weight), _c(bias) if bias is not None else None)
+    if act == "gelu":
+        y = F.gelu(y)  # exact (erf) GELU: vit.py act_layer=nn.GELU, med_config hidden_act "gelu"
+    elif act is not None:
+        raise ValueError(act)
+    return y
+
+
+def layer_norm(x, ln, residual=None):
+    """LayerNorm(x [+ residual]) with fp32 statistics; output in the compute dtype."""
+    if residual is not None:
+        x = x.float() + residual.float()
+    y = F.layer_norm(x.float(), ln.normalized_shape, ln.weight, ln.bias, ln.eps)
+    return _c(y)
+
+
+def attention(q, k, v, mask, scale, return_probs=False, dropout_p=0.0):
+    """softmax(q k^T * scale + mask) v.
+
+    q (B,Lq,H,D), k/v (B,Lk,H,D) (any strides); mask None or additive fp32 broadcastable to
+    (B,1,Lq,Lk).  Returns ctx (B,Lq,H,D) [compute dtype] and probs (B,H,Lq,Lk) fp32 or None.
+    Order of operations follows med.py:179-217 (scores/sqrt(d) then + mask) and vit.py:75-83.
+    """
+    qh, kh, vh = _c(q).permute(0, 2, 1, 3), _c(k).permute(0, 2, 1, 3), _c(v).permute(0, 2, 1, 3)
+    scores = torch.matmul(qh, kh.transpose(-1, -2)).float() * scale
+    if mask is not None:
+        scores = scores + mask
+    probs = torch.softmax(scores, dim=-1)
+    p = probs
+    if dropout_p > 0.0:
+        p = F.dropout(p, dropout_p, training=True)
+    ctx = torch.matmul(p.to(vh.dtype), vh).permute(0, 2, 1, 3)
+    return ctx, (probs if return_probs else None)
+
+
+def lm_loss(hidden, decoder_weight, decoder_bias, labels, label_smoothing=0.1):
+    """Tied LM head + shifted label-smoothed cross entropy, summed per sequence (med.py:1417-1432).
+
+    hidden (B,L,D) = output of the prediction-head transform; labels (B,L) with -100 = ignore.
+    Returns (logits (B,L,V) or None, loss (B,)).
+    """
+    logits = linear(hidden, decoder_weight, decoder_bias).float()
+    B, L, V = logits.shape
+    shifted = logits[:, :-1, :].reshape(-1, V)
+    tgt = labels[:, 1:].reshape(-1)
+    loss = F.cross_entropy(shifted, tgt, reduction="none", label_smoothing=label_smoothing)
+    return logits, loss.view(B, -1).sum(1)
+
+
+def gelu(x):
+    return F.gelu(x)
+
+
+SQRT_HEAD = math.sqrt

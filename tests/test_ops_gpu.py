@@ -95,6 +95,9 @@ def test_gather_group_interp_vs_oracle(ext, oracle, dev):
         d2, idx = ext.three_nn(unknown.to(dev), known.to(dev))
         od2, oidx = oracle.three_nn(unknown, known)
         assert torch.equal(idx.cpu(), oidx) and torch.equal(d2.cpu(), od2)
+        dist, idx_b = ext.three_nn_dist(unknown.to(dev), known.to(dev))  # fused correctly-rounded sqrt
+        assert torch.equal(idx_b.cpu(), oidx)
+        np.testing.assert_array_equal(dist.cpu().numpy(), np.sqrt(od2.numpy()))
         w = torch.rand(B, n, 3, generator=g)
         feats = torch.randn(B, C, m, generator=g)
         assert torch.equal(ext.three_interpolate(feats.to(dev), idx, w.to(dev)).cpu(),

@@ -24,6 +24,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+WORKLOADS = {
+    "c2": "c2: DET-stage hot path (VoteNet backbone + voting + vote-cluster/proposal), fwd+bwd+AdamW, "
+          "stand-in detector loss",
+    "c3": "c3: VQA-stage hot path (c2 + ViT-B/16 on one 512x512 view + paralleltwin MED fusion + shared LM "
+          "answer decoder on both streams), fwd+bwd+AdamW, LM answer loss + stand-in detector loss",
+}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -50,33 +56,42 @@ def synth_batch(B, N, cin, seed, device):
     return torch.cat([xyz, feats], -1).contiguous().to(device)
 
 
-class DetPath(torch.nn.Module):
-    """The DET-stage slice of ScanQA.forward (models/qa_module.py:438-459): backbone -> voting ->
-    L2-normalise -> vote clustering + proposal head."""
+def build_model(workload, cin, image):
+    from bridgeqa_amd.hotpath import ScanQAHotPath
+    if workload == "c2":
+        return ScanQAHotPath(input_feature_dim=cin, use_blip=False)
+    return ScanQAHotPath(input_feature_dim=cin, use_blip=True, blip_kwargs=dict(image_size=image))
 
-    def __init__(self, cin):
-        super().__init__()
-        import numpy as np
-        from bridgeqa_amd.backbone_module import Pointnet2Backbone
-        from bridgeqa_amd.proposal_module import ProposalModule
-        from bridgeqa_amd.voting_module import VotingModule
-        self.detection_backbone = Pointnet2Backbone(input_feature_dim=cin)
-        self.voting_net = VotingModule(1, 256)
-        self.proposal_net = ProposalModule(18, 1, 18, np.ones((18, 3)), 256, "vote_fps")
 
-    def forward(self, data_dict):
-        dd = self.detection_backbone(data_dict)
-        xyz, features = self.voting_net(dd["fp2_xyz"], dd["fp2_features"])
-        features = features.div(torch.norm(features, p=2, dim=1).unsqueeze(1))
-        dd["vote_xyz"], dd["vote_features"] = xyz, features
-        return self.proposal_net(xyz, features, dd)
+def synth_text(B, L, La, seed, device):
+    """SURVEY §8d: question ids (B,L) ~ U{1000..30521}, [ENC] at 0 (set by the model), 0-6 trailing pads;
+    answers (B,La)."""
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randint(1000, 30522, (B, L), generator=g)
+    qm = torch.ones(B, L, dtype=torch.long)
+    for b in range(B):
+        pad = int(torch.randint(0, 7, (1,), generator=g))
+        if pad:
+            q[b, L - pad:] = 0
+            qm[b, L - pad:] = 0
+    a = torch.randint(1000, 30522, (B, La), generator=g)
+    am = torch.ones(B, La, dtype=torch.long)
+    return ({"input_ids": q.to(device), "attention_mask": qm.to(device)},
+            {"input_ids": a.to(device), "attention_mask": am.to(device)})
 
 
 def det_loss(dd):
-    """Stand-in scalar with gradients into every head (the reference's losses are SURVEY §8f 'next')."""
+    """Stand-in scalar with gradients into every detector head (the reference's losses are SURVEY §8f 'next')."""
     return (dd["objectness_scores"].square().mean() + dd["center"].square().mean() * 1e-2 +
             dd["size_residuals_normalized"].square().mean() + dd["sem_cls_scores"].square().mean() +
             (dd["vote_xyz"] - dd["fp2_xyz"]).abs().mean())
+
+
+def total_loss(dd):
+    loss = det_loss(dd)
+    if "blip_loss" in dd:
+        loss = loss + dd["blip_loss"]  # LM answer loss of both streams (blip_vqa_3d.py:305-343)
+    return loss
 
 
 class OpTimer(object):
@@ -109,34 +124,47 @@ class OpTimer(object):
         return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
 
 
-def cpu_baseline(args):
+def make_batch(args, workload, B, seed, device):
+    batch = {"point_clouds": synth_batch(B, args.points, args.cin, seed, device), "phase": "train"}
+    if workload == "c3":
+        g = torch.Generator().manual_seed(seed + 1)
+        batch["images"] = torch.randn(B, 1, 3, args.image, args.image, generator=g).to(device)
+        batch["question"], batch["answer"] = synth_text(B, 20, 5, seed + 2, device)
+    return batch
+
+
+def cpu_baseline(args, workload):
     """The hot path on the host cores: bridgeqa_amd's Python layers over the CPU oracle backend
     (oracle/ -- allowed here as the reported baseline only) + torch-CPU fp32 for the dense layers."""
     from bridgeqa_amd import pointnet2_utils
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 32)))
     from oracle import pn2_oracle
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)  # beyond ~32 threads this workload only adds contention
     torch.set_num_threads(cores)
     prev = pointnet2_utils.set_backend(pn2_oracle)
     try:
+        from bridgeqa_amd import fusion_ops
+        prev_dt = fusion_ops.set_compute_dtype(torch.float32)
         torch.manual_seed(0)
-        model = DetPath(args.cin)
+        model = build_model(workload, args.cin, args.image)
         opt = torch.optim.AdamW(model.parameters(), lr=5e-4)
         B = args.cpu_scenes
-        pc = synth_batch(B, args.points, args.cin, 42, "cpu")
+        batch = make_batch(args, workload, B, 42, "cpu")
         times = []
         for it in range(2):
             t0 = time.time()
             opt.zero_grad(set_to_none=True)
-            loss = det_loss(model({"point_clouds": pc}))
+            loss = total_loss(model(dict(batch)))
             loss.backward()
             opt.step()
             times.append(time.time() - t0)
         dt = min(times)
+        fusion_ops.set_compute_dtype(prev_dt)
     finally:
         pointnet2_utils.set_backend(prev)
     return {"value": round(B / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "DET slice fwd+bwd+AdamW, %d scenes x %d pts, C_in=%d, fp32, best of 2 steps "
-                      "(oracle ops with OpenMP + torch-CPU)" % (B, args.points, args.cin)}
+            "sample": "%s hot path fwd+bwd+AdamW, %d scenes x %d pts, C_in=%d, fp32, best of 2 steps "
+                      "(oracle ops with OpenMP + torch-CPU dense layers)" % (workload, B, args.points, args.cin)}
 
 
 def main():
@@ -151,21 +179,21 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", init_method="env://")
-    workload = "c2" if args.workload == "auto" else args.workload
-    if workload == "c3":
-        raise SystemExit("workload c3 (fusion) is not wired into bench.py yet")
+    workload = "c3" if args.workload == "auto" else args.workload
 
-    from bridgeqa_amd import _ext
+    from bridgeqa_amd import _ext, fusion_ops
+    if workload == "c3":
+        fusion_ops.set_compute_dtype(torch.bfloat16)
     torch.manual_seed(0)
-    model = DetPath(args.cin).to(dev)
+    model = build_model(workload, args.cin, args.image).to(dev)
     if world > 1:
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local])
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=True)
     opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-5)
-    pc = synth_batch(args.batch, args.points, args.cin, 42 + rank, dev)
+    batch = make_batch(args, workload, args.batch, 42 + rank, dev)
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = det_loss(model({"point_clouds": pc}))
+        loss = total_loss(model(dict(batch)))
         loss.backward()
         opt.step()
         return loss
@@ -205,10 +233,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "c2: DET-stage slice (VoteNet backbone + voting + vote-cluster/proposal), "
-                                   "fwd+bwd+AdamW, stand-in loss; fusion (c3) not yet in this bench",
-                       "global_batch": args.batch * world, "points": args.points, "c_in": args.cin,
+            "dtype": "bf16" if workload == "c3" else "f32", "data": "synthetic",
+            "config": {"workload": WORKLOADS[workload], "global_batch": args.batch * world, "points": args.points,
+                       "c_in": args.cin, "image": args.image if workload == "c3" else None,
                        "parallelism": "dp%d" % world},
             "roofline": {"kernel": "fps (SA1 40000->2048)", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -217,7 +244,7 @@ def main():
             "op_ms": {"%s%s" % (k[0], list(k[1])): round(v[0], 4) for k, v in sorted(ops.items())},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args, workload)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -1,0 +1,63 @@
+"""The slice of `ScanQA.forward` that IS the hot path (reference models/qa_module.py:438-479 for the
+detector branch and :611-668 for the BLIP branch), with the reference's attribute names so its
+state-dict keys are a subset of ScanQA's: detection_backbone.*, voting_net.*, proposal_net.*,
+object_feat_linear.*, blip_model.*.  The rest of ScanQA (language/MCAN heads, losses, reference
+head) is the caller on either side of the path -- SURVEY.md §8f rank 1, not built here.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .backbone_module import Pointnet2Backbone
+from .proposal_module import ProposalModule
+from .voting_module import VotingModule
+
+
+class ScanQAHotPath(nn.Module):
+    def __init__(self, input_feature_dim=132, num_proposal=256, vote_factor=1, seed_feat_dim=256, proposal_size=128,
+                 vote_radius=0.3, vote_nsample=16, hidden_size=256, num_class=18, num_heading_bin=1,
+                 num_size_cluster=18, mean_size_arr=None, use_blip=True, blip_kwargs=None):
+        super().__init__()
+        if mean_size_arr is None:
+            mean_size_arr = np.ones((num_size_cluster, 3))
+        self.detection_backbone = Pointnet2Backbone(input_feature_dim=input_feature_dim, seed_feat_dim=seed_feat_dim)
+        self.voting_net = VotingModule(vote_factor, seed_feat_dim)
+        self.proposal_net = ProposalModule(num_class, num_heading_bin, num_size_cluster, mean_size_arr, num_proposal,
+                                           "vote_fps", seed_feat_dim=seed_feat_dim, proposal_size=proposal_size,
+                                           radius=vote_radius, nsample=vote_nsample)
+        self.object_feat_linear = nn.Sequential(nn.Linear(proposal_size, hidden_size), nn.GELU())  # qa_module.py:219-221
+        self.use_blip = use_blip
+        if use_blip:
+            from .blip_vqa_3d import BLIP_VQA3D
+            kw = dict(num_answers=10, use_text_decoder=True, share_decoder=True, scene_size=hidden_size,
+                      scene_feature_position="paralleltwin")
+            kw.update(blip_kwargs or {})
+            self.blip_model = BLIP_VQA3D(**kw)
+
+    def detect(self, data_dict):
+        data_dict = self.detection_backbone(data_dict)
+        xyz, features = data_dict["fp2_xyz"], data_dict["fp2_features"]
+        data_dict["seed_inds"], data_dict["seed_xyz"], data_dict["seed_features"] = data_dict["fp2_inds"], xyz, features
+        xyz, features = self.voting_net(xyz, features)
+        features = features.div(torch.norm(features, p=2, dim=1).unsqueeze(1))
+        data_dict["vote_xyz"], data_dict["vote_features"] = xyz, features
+        return self.proposal_net(xyz, features, data_dict)
+
+    def forward(self, data_dict):
+        """data_dict: point_clouds (B,N,3+C); with use_blip also images (B,V,3,H,W), question / answer
+        (token dicts or strings).  Adds the detector outputs and, with BLIP, `blip_loss`, `fused_feat`."""
+        data_dict = self.detect(data_dict)
+        object_feat = self.object_feat_linear(data_dict["aggregated_vote_features"])
+        object_mask = ~data_dict["bbox_mask"].bool().detach()  # True = not an object
+        data_dict["object_feat"] = object_feat
+        if not self.use_blip:
+            return data_dict
+        train = data_dict.get("phase", "train") == "train"
+        out = self.blip_model(data_dict["images"][:, 0], data_dict["question"],
+                              scene_object_embeds=object_feat.clone(), scene_object_mask=~object_mask,
+                              answer=data_dict["answer"], train=train, k_test=256, data_dict=data_dict)
+        if train:
+            data_dict["blip_loss"], data_dict["fused_feat"], data_dict["fused_mask"] = out
+        else:
+            data_dict["fused_feat"], data_dict["answer_scores"], data_dict["fused_mask"] = out
+        return data_dict

@@ -49,7 +49,9 @@ class PointnetSAModuleVotes(nn.Module):
             .transpose(1, 2).contiguous()
         grouped_features, _grouped_xyz = self.grouper(xyz, new_xyz, features)  # (B, 3+C, npoint, nsample)
         new_features = self.mlp_module(grouped_features)
-        new_features = F.max_pool2d(new_features, kernel_size=[1, new_features.size(3)]).squeeze(-1)
+        # == F.max_pool2d(kernel=[1, nsample]).squeeze(-1) (pointnet2_modules.py:259-262, 272); a row reduction
+        # instead of the generic NCHW pooling kernel.  Tie routing in backward is immaterial.
+        new_features = new_features.max(dim=3)[0]
         return new_xyz, new_features, inds
 
 

@@ -28,7 +28,8 @@ if _lib.bq_abi_version() != 1:
 _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 _SIGS = {
     "bq_opt_n_threads": [_i],
-    "bq_furthest_point_sampling": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "bq_furthest_point_sampling": [_vp, _vp, ctypes.c_size_t, _vp, _i, _i, _i, _vp],
+    "bq_furthest_point_sampling_bruteforce": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "bq_gather_points": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "bq_gather_points_grad": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "bq_ball_query": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
@@ -44,6 +45,8 @@ _SIGS = {
 for _name, _args in _SIGS.items():
     getattr(_lib, _name).argtypes = _args
     getattr(_lib, _name).restype = ctypes.c_int
+_lib.bq_fps_workspace_bytes.argtypes = [_i, _i]
+_lib.bq_fps_workspace_bytes.restype = ctypes.c_size_t
 
 
 def library_path():
@@ -88,9 +91,22 @@ def furthest_point_sampling(points, nsamples):
     B, N, _ = points.shape
     with torch.cuda.device(points.device):
         out = torch.zeros(B, nsamples, dtype=torch.int32, device=points.device)
-        tmp = torch.empty(B, N, dtype=torch.float32, device=points.device) if N > 24576 else None
-        _check(_lib.bq_furthest_point_sampling(_p(points), _p(tmp), _p(out), B, N, int(nsamples), _stream()),
+        nbytes = _lib.bq_fps_workspace_bytes(B, N)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=points.device) if nbytes else None
+        _check(_lib.bq_furthest_point_sampling(_p(points), _p(ws), nbytes, _p(out), B, N, int(nsamples), _stream()),
                "furthest_point_sampling")
+    return out
+
+
+def furthest_point_sampling_bruteforce(points, nsamples):
+    """Unpruned kernels (A/B timing, independent cross-check of the bucketed kernel)."""
+    _req(points, torch.float32, "points")
+    B, N, _ = points.shape
+    with torch.cuda.device(points.device):
+        out = torch.zeros(B, nsamples, dtype=torch.int32, device=points.device)
+        tmp = torch.empty(B, N, dtype=torch.float32, device=points.device) if N > 24576 else None
+        _check(_lib.bq_furthest_point_sampling_bruteforce(_p(points), _p(tmp), _p(out), B, N, int(nsamples),
+                                                          _stream()), "furthest_point_sampling_bruteforce")
     return out
 
 

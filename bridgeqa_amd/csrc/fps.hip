@@ -161,8 +161,13 @@ extern "C" int bq_opt_n_threads(int work_size) {
   return t;
 }
 
-extern "C" int bq_furthest_point_sampling(const float *xyz, float *temp, int32_t *idx, int B, int N, int m,
-                                          void *stream) {
+namespace bq {
+int launch_fps_bucket(const float *xyz, void *workspace, size_t workspace_bytes, int32_t *idx, int B, int N, int m,
+                      int log2bs, hipStream_t st);
+}
+
+extern "C" int bq_furthest_point_sampling(const float *xyz, void *workspace, size_t workspace_bytes, int32_t *idx,
+                                          int B, int N, int m, void *stream) {
   using namespace bq;
   BQ_REQUIRE(B >= 0 && N >= 1 && m >= 0, BQ_EINVAL, "fps: bad extents B=%d N=%d m=%d", B, N, m);
   BQ_REQUIRE(N < (1 << 22), BQ_ELIMIT, "fps: N=%d exceeds 2^22-1", N);
@@ -179,12 +184,30 @@ extern "C" int bq_furthest_point_sampling(const float *xyz, float *temp, int32_t
   else if (N <= 1024)  launch_reg<512, 2>(xyz, idx, B, N, m, log2bs, st);
   else if (N <= 2048)  launch_reg<512, 4>(xyz, idx, B, N, m, log2bs, st);
   else if (N <= 4096)  launch_reg<1024, 4>(xyz, idx, B, N, m, log2bs, st);
-  else if (N <= 8192)  launch_reg<1024, 8>(xyz, idx, B, N, m, log2bs, st);
+  else return launch_fps_bucket(xyz, workspace, workspace_bytes, idx, B, N, m, log2bs, st);
+  return check_launch("furthest_point_sampling");
+}
+
+// Brute-force (unpruned) kernels, any N: for A/B timing against the bucketed kernel and as an independent on-GPU
+// cross-check of it.  temp: (B,N) f32 scratch, needed when N > 24576.
+extern "C" int bq_furthest_point_sampling_bruteforce(const float *xyz, float *temp, int32_t *idx, int B, int N,
+                                                     int m, void *stream) {
+  using namespace bq;
+  BQ_REQUIRE(B >= 0 && N >= 1 && m >= 0, BQ_EINVAL, "fps: bad extents B=%d N=%d m=%d", B, N, m);
+  BQ_REQUIRE(N < (1 << 22), BQ_ELIMIT, "fps: N=%d exceeds 2^22-1", N);
+  if (B == 0 || m == 0) return BQ_OK;
+  BQ_REQUIRE(xyz && idx, BQ_EINVAL, "fps: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int bs = bq_opt_n_threads(N);
+  int log2bs = 0;
+  while ((1 << log2bs) < bs) ++log2bs;
+  if (N <= 4096) return bq_furthest_point_sampling(xyz, nullptr, 0, idx, B, N, m, stream);
+  if (N <= 8192)       launch_reg<1024, 8>(xyz, idx, B, N, m, log2bs, st);
   else if (N <= 16384) launch_reg<1024, 16>(xyz, idx, B, N, m, log2bs, st);
   else if (N <= 24576) launch_reg<1024, 24>(xyz, idx, B, N, m, log2bs, st);
   else {
     BQ_REQUIRE(temp, BQ_EINVAL, "fps: temp scratch required for N=%d", N);
     hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(B), dim3(1024), 0, st, xyz, temp, idx, N, m, log2bs);
   }
-  return check_launch("furthest_point_sampling");
+  return check_launch("furthest_point_sampling(bruteforce)");
 }

@@ -22,6 +22,7 @@
 #ifndef BQHIP_H
 #define BQHIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -48,14 +49,20 @@ BQ_API const char *bq_last_error(void);
 BQ_API int bq_opt_n_threads(int work_size);
 
 /* furthest_point_sampling  (sampling.cpp:66-87, sampling_gpu.cu:69-229)
- *   xyz  (B,N,3) f32   idx (B,m) i32 out   temp (B,N) f32 scratch (contents ignored on entry;
- *   the reference fills it with 1e10 -- this implementation keeps the running minimum
- *   distances on chip and only uses `temp` when N exceeds its on-chip capacity).
+ *   xyz (B,N,3) f32 -> idx (B,m) i32.  `workspace` is device scratch of at least
+ *   bq_fps_workspace_bytes(B,N) bytes (0 for small scenes: pass NULL); it plays the role of the
+ *   reference's `temp (B,N)` tensor but holds the spatially sorted scene (contents ignored on entry).
  *   Result is index-exact w.r.t. the reference kernel: idx[:,0]=0; points with
  *   x*x+y*y+z*z <= 1e-3 are never selected; exact distance ties resolve by
  *   (bitrev_{log2 bs}(k mod bs), k) ascending, bs = bq_opt_n_threads(N).  Requires N < 2^22. */
-BQ_API int bq_furthest_point_sampling(const float *xyz, float *temp, int32_t *idx, int B, int N, int m,
-                               void *stream);
+BQ_API size_t bq_fps_workspace_bytes(int B, int N);
+BQ_API int bq_furthest_point_sampling(const float *xyz, void *workspace, size_t workspace_bytes,
+                               int32_t *idx, int B, int N, int m, void *stream);
+
+/* Same result by the unpruned (every point, every round) kernels; temp (B,N) f32 scratch for
+ * N > 24576.  Kept for A/B measurement and as an independent on-GPU cross-check. */
+BQ_API int bq_furthest_point_sampling_bruteforce(const float *xyz, float *temp, int32_t *idx, int B,
+                                          int N, int m, void *stream);
 
 /* gather_points  (sampling.cpp:15-38, sampling_gpu.cu:8-30)   out[b,c,j] = points[b,c,idx[b,j]]
  *   points (B,C,N) f32, idx (B,M) i32, out (B,C,M) f32 */

@@ -38,6 +38,45 @@ def test_fps_index_exact_vs_oracle(ext, oracle, dev, B, N, m):
     assert torch.equal(got, oracle.furthest_point_sampling(xyz, m))
 
 
+def test_fps_bucketed_kernel_edge_cases(ext, oracle, dev):
+    """The pruned kernel (N > 4096) on inputs built to break a pruning or tie rule."""
+    g = torch.Generator().manual_seed(5)
+    cases = {}
+    # exact ties everywhere: lattice of 32x16x10 = 5120 points
+    lat = np.stack(np.meshgrid(np.arange(32) * 0.25, np.arange(16) * 0.25, np.arange(10) * 0.25, indexing="ij"), -1)
+    cases["lattice"] = (torch.tensor(lat.reshape(1, -1, 3) + 0.5, dtype=torch.float32), 600)
+    # every point identical / two clusters of duplicates
+    same = torch.full((1, 5000, 3), 1.25)
+    cases["identical"] = (same, 40)
+    dup = scene(1, 6000, 0, 1)
+    dup[0, 1000:3000] = dup[0, 7]
+    dup[0, 3000:5000] = dup[0, 11]
+    cases["duplicates"] = (dup, 4200)  # m beyond the number of distinct points
+    # dense blob + far outliers (degenerate grid), and a scene far from the origin
+    blob = torch.randn(1, 9000, 3, generator=g) * 0.01 + 3.0
+    blob[0, ::1000] += 100.0
+    cases["blob+outliers"] = (blob, 300)
+    cases["translated"] = (scene(1, 7000, 0, 2) + 1000.0, 300)
+    # many points inside the origin skip ball, first point among them
+    ob = scene(2, 5000, 0, 3)
+    ob[:, :2500] *= 0.002
+    cases["origin ball"] = (ob, 2600)
+    cases["all skipped"] = (torch.zeros(1, 4500, 3), 10)
+    # flat (z constant) and line-like scenes
+    flat = scene(1, 8000, 0, 4); flat[..., 2] = 1.0
+    cases["flat"] = (flat, 400)
+    line = scene(1, 8000, 0, 5); line[..., 1:] = 2.0
+    cases["line"] = (line, 400)
+    # minima kept outside LDS (N > 40448) and two rows per lane (N > 65536)
+    cases["N=41000"] = (scene(1, 41000, 0, 6), 300)
+    cases["N=80000"] = (scene(2, 80000, 0, 7), 256)
+    for name, (xyz, m) in cases.items():
+        xyz = xyz.contiguous()
+        got = ext.furthest_point_sampling(xyz.to(dev), m).cpu()
+        assert torch.equal(got, oracle.furthest_point_sampling(xyz, m)), name
+        assert torch.equal(got, ext.furthest_point_sampling_bruteforce(xyz.to(dev), m).cpu()), name
+
+
 def test_fps_edge_cases_vs_oracle(ext, oracle, dev):
     # exact ties on a lattice (tie order = bit-reversed reference-thread id, then k), several block sizes
     for nx, ny, nz in ((4, 4, 2), (8, 8, 4), (16, 8, 5), (16, 16, 8)):

@@ -45,11 +45,12 @@ def test_bad_extents_return_status_not_exit():
     from bridgeqa_amd import _ext
     lib = _ext._lib
     # negative extents / null pointers are rejected before any launch
-    assert lib.bq_furthest_point_sampling(None, None, None, 1, 0, 4, None) == -1
-    assert lib.bq_furthest_point_sampling(None, None, None, 1, 1 << 23, 4, None) == -2
+    assert lib.bq_furthest_point_sampling(None, None, 0, None, 1, 0, 4, None) == -1
+    assert lib.bq_furthest_point_sampling(None, None, 0, None, 1, 1 << 23, 4, None) == -2
     assert b"fps" in lib.bq_last_error()
     assert lib.bq_ball_query(None, None, None, -1, 4, 4, 0.5, 4, None) == -1
     assert lib.bq_group_concat(None, None, None, None, None, 1, 0, 4, 4, 6, 0.5, 1, None) == -1
     # empty work is a no-op success, as in the reference (`if (m <= 0) return`)
-    assert lib.bq_furthest_point_sampling(None, None, None, 0, 8, 4, None) == 0
+    assert lib.bq_furthest_point_sampling(None, None, 0, None, 0, 8, 4, None) == 0
+    assert lib.bq_fps_workspace_bytes(16, 40000) == 16 * 40000 * 20 and lib.bq_fps_workspace_bytes(16, 2048) == 0
     assert lib.bq_opt_n_threads(40000) == 512 and lib.bq_opt_n_threads(300) == 256

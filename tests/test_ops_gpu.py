@@ -200,6 +200,9 @@ def test_full_size_c2_properties_and_oracle_spot_check(ext, oracle, dev):
     d = idx[:, :, 1:] - idx[:, :, :-1]
     assert ((d > 0) | (idx[:, :, 1:] == idx[:, :, :1])).all()
     assert torch.equal(idx[:2], oracle.ball_query(new_xyz[:2].cpu().contiguous(), xyz[:2].contiguous(), 0.2, 64))
-    # SA2-level FPS on the FPS-ordered set is the identity prefix (backbone_module.py:111)
+    # SA2-level FPS on the FPS-ordered set is the identity prefix (backbone_module.py:111) EXCEPT where two
+    # candidates tie exactly in fp32 (then the index-dependent tie rule differs between the two orderings; the
+    # oracle shows the same 2 swapped ids in scene 1 of this seed) => exact vs oracle, near-identity as a property
     inds2 = ext.furthest_point_sampling(new_xyz, 1024).cpu()
-    assert torch.equal(inds2, torch.arange(1024, dtype=torch.int32).expand(B, -1))
+    assert torch.equal(inds2, oracle.furthest_point_sampling(new_xyz.cpu().contiguous(), 1024))
+    assert (inds2 == torch.arange(1024, dtype=torch.int32).expand(B, -1)).float().mean() > 0.999

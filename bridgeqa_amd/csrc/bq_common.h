@@ -85,6 +85,58 @@ __device__ __forceinline__ unsigned row0_min_u32(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 15);
 }
 
+// ---- single-instruction DPP reduction steps (inline asm) -----------------------------------------
+// hipcc expands update_dpp + max into mov / s_nop / mov_dpp / canonicalise / max (5 instructions per step);
+// the serial arg-max chain of furthest point sampling is made of these steps, so they are written as the
+// one VOP2-DPP instruction the hardware has.  `s_nop 1` = the 2 wait states a DPP read needs after a VALU
+// write of the same VGPR.  Lanes without a DPP source (row start, masked rows) are not written: they keep v.
+#define BQ_DPP_STEP(op, ctrl) "s_nop 1\n\t" op " %0, %0, %0 " ctrl "\n\t"
+#define BQ_DPP_ROW(op)                                       \
+  BQ_DPP_STEP(op, "row_shr:1 row_mask:0xf bank_mask:0xf")    \
+  BQ_DPP_STEP(op, "row_shr:2 row_mask:0xf bank_mask:0xf")    \
+  BQ_DPP_STEP(op, "row_shr:4 row_mask:0xf bank_mask:0xf")    \
+  BQ_DPP_STEP(op, "row_shr:8 row_mask:0xf bank_mask:0xf")
+#define BQ_DPP_WAVE(op)                                      \
+  BQ_DPP_ROW(op)                                             \
+  BQ_DPP_STEP(op, "row_bcast:15 row_mask:0xa bank_mask:0xf") \
+  BQ_DPP_STEP(op, "row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
+
+// signed-int max over the wave; used on float BITS: for d in {-1} U [0, +inf) the int order is the float order
+__device__ __forceinline__ int wave_max_i32(int v) {
+  asm volatile(BQ_DPP_WAVE("v_max_i32_dpp") : "+v"(v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ unsigned wave_min_u32_fast(unsigned v) {
+  asm volatile(BQ_DPP_WAVE("v_min_u32_dpp") : "+v"(v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Wave-wide arg-max on the total order (d desc, key asc): returns the winning lane; *dmax_bits / *kmin get the
+// winner's distance bits and key (wave-uniform).  The key reduction only runs on an exact tie in d.
+__device__ __forceinline__ int wave_argmax(float d, unsigned key, int *dmax_bits, unsigned *kmin) {
+  const int bits = __float_as_int(d);
+  const int mx = wave_max_i32(bits);
+  const unsigned long long tied = __ballot(bits == mx);
+  int L;
+  if (__builtin_popcountll(tied) == 1) {
+    L = __builtin_ctzll(tied);
+    *kmin = (unsigned)__builtin_amdgcn_readlane((int)key, L);
+  } else {
+    const unsigned mine = (bits == mx) ? key : 0xFFFFFFFFu;
+    const unsigned k = wave_min_u32_fast(mine);
+    L = __builtin_ctzll(__ballot(mine == k));
+    *kmin = k;
+  }
+  *dmax_bits = mx;
+  return L;
+}
+
+// (d, key) -> one u64 whose unsigned order is (d desc, key asc); d < 0 ("no candidate") maps below everything
+__device__ __forceinline__ unsigned long long pack_best(int dbits, unsigned key) {
+  const unsigned hi = dbits < 0 ? 0u : (unsigned)dbits + 1u;
+  return ((unsigned long long)hi << 32) | (unsigned long long)(~key);
+}
+
 __device__ __forceinline__ unsigned lane_id() { return __lane_id(); }
 
 }  // namespace bq

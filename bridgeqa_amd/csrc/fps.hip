@@ -21,28 +21,25 @@ __device__ __forceinline__ unsigned tie_key(int k, int log2bs) {
   return (cls << 22) | (unsigned)k;
 }
 
-// Block-wide arg-max of (best, key) -> winning point id (uniform).  One barrier.
+// Block-wide arg-max of (best, bestk) on the total order -> winning point id (uniform).  One barrier:
+// each wave reduces with DPP, lane 0 folds the wave's packed (d, key) into a triple-buffered LDS slot with a
+// 64-bit ds_max, everyone reads the slot back after the barrier.  `rot` cycles 0,1,2 (round j uses slot j%3;
+// slot (j+2)%3 is cleared after the barrier: its readers finished before this barrier and its next writers
+// cannot start before the next one).
 template <int T>
-__device__ __forceinline__ int block_argmax(float best, int bestk, int log2bs, float *s_d, unsigned *s_k, int buf) {
+__device__ __forceinline__ int block_argmax(float best, int bestk, int log2bs, unsigned long long *s_best, int rot) {
   constexpr int NW = T / 64;
-  const float wmax = wave_max_f32(best);
-  const unsigned key = (best == wmax) ? tie_key(bestk, log2bs) : 0xFFFFFFFFu;
-  const unsigned wkey = wave_min_u32(key);
+  int dbits;
+  unsigned wkey;
+  wave_argmax(best, tie_key(bestk, log2bs), &dbits, &wkey);
   if constexpr (NW == 1) {
-    return wmax < 0.0f ? 0 : (int)(wkey & 0x3FFFFFu);
+    return dbits < 0 ? 0 : (int)(wkey & 0x3FFFFFu);
   } else {
-    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) {
-      s_d[buf * 16 + wid] = wmax;
-      s_k[buf * 16 + wid] = wkey;
-    }
+    if ((threadIdx.x & 63) == 0) atomicMax(&s_best[rot], pack_best(dbits, wkey));
     __syncthreads();
-    float d = lane < NW ? s_d[buf * 16 + lane] : -2.0f;
-    unsigned kk = lane < NW ? s_k[buf * 16 + lane] : 0xFFFFFFFFu;
-    const float gmax = row0_max_f32(d);
-    kk = (d == gmax) ? kk : 0xFFFFFFFFu;
-    const unsigned gkey = row0_min_u32(kk);
-    return gmax < 0.0f ? 0 : (int)(gkey & 0x3FFFFFu);
+    const unsigned long long win = s_best[rot];
+    if (threadIdx.x == 0) s_best[rot == 0 ? 2 : rot - 1] = 0ull;  // (rot+2)%3
+    return (win >> 32) == 0ull ? 0 : (int)((~(unsigned)win) & 0x3FFFFFu);
   }
 }
 
@@ -53,11 +50,11 @@ template <int T, int PPT, bool XYZ_LDS>
 __global__ __launch_bounds__(T) void fps_reg_kernel(const float *__restrict__ xyz, int32_t *__restrict__ idx,
                                                     int N, int m, int log2bs) {
   extern __shared__ float s_xyz[];
-  __shared__ float s_d[32];
-  __shared__ unsigned s_k[32];
+  __shared__ unsigned long long s_best[3];
   const int t = threadIdx.x;
   const float *P = xyz + (size_t)blockIdx.x * N * 3;
   int32_t *out = idx + (size_t)blockIdx.x * m;
+  if (t < 3) s_best[t] = 0ull;
 
   float x[PPT], y[PPT], z[PPT], md[PPT];
 #pragma unroll
@@ -83,9 +80,9 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(const float *__restrict__ xy
     }
   }
   if (t == 0) out[0] = 0;
-  if constexpr (XYZ_LDS) __syncthreads();
+  __syncthreads();
 
-  int old = 0;
+  int old = 0, rot = 0;
   for (int j = 1; j < m; ++j) {
     float px, py, pz;
     if constexpr (XYZ_LDS) {
@@ -103,7 +100,8 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(const float *__restrict__ xy
       bestk = gt ? (t + i * T) : bestk;
       best = gt ? md[i] : best;
     }
-    old = block_argmax<T>(best, bestk, log2bs, s_d, s_k, j & 1);
+    old = block_argmax<T>(best, bestk, log2bs, s_best, rot);
+    rot = rot == 2 ? 0 : rot + 1;
     if (t == 0) out[j] = old;
   }
 }
@@ -114,15 +112,16 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(const float *__restrict__ xy
 template <int T>
 __global__ __launch_bounds__(T) void fps_stream_kernel(const float *__restrict__ xyz, float *__restrict__ temp,
                                                        int32_t *__restrict__ idx, int N, int m, int log2bs) {
-  __shared__ float s_d[32];
-  __shared__ unsigned s_k[32];
+  __shared__ unsigned long long s_best[3];
   const int t = threadIdx.x;
   const float *P = xyz + (size_t)blockIdx.x * N * 3;
   float *md = temp + (size_t)blockIdx.x * N;
   int32_t *out = idx + (size_t)blockIdx.x * m;
+  if (t < 3) s_best[t] = 0ull;
   for (int k = t; k < N; k += T) md[k] = (sqnorm(P[k * 3], P[k * 3 + 1], P[k * 3 + 2]) < 0.001f) ? -1.0f : 1e10f;
   if (t == 0) out[0] = 0;
-  int old = 0;
+  __syncthreads();
+  int old = 0, rot = 0;
   for (int j = 1; j < m; ++j) {
     const float px = P[old * 3 + 0], py = P[old * 3 + 1], pz = P[old * 3 + 2];
     float best = -1.0f;
@@ -135,7 +134,8 @@ __global__ __launch_bounds__(T) void fps_stream_kernel(const float *__restrict__
       bestk = gt ? k : bestk;
       best = gt ? v : best;
     }
-    old = block_argmax<T>(best, bestk, log2bs, s_d, s_k, j & 1);
+    old = block_argmax<T>(best, bestk, log2bs, s_best, rot);
+    rot = rot == 2 ? 0 : rot + 1;
     if (t == 0) out[j] = old;
   }
 }

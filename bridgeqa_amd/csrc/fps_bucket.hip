@@ -94,6 +94,9 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(const float *__rest
   extern __shared__ __align__(16) unsigned char s_dyn[];
   __shared__ float s_red[2][NW][8];
   __shared__ float s_box[6];
+  struct alignas(8) Entry { unsigned long long packed; float x, y, z, pad; };
+  __shared__ Entry s_tab[2][NW];
+  __shared__ unsigned long long s_best[3];
 
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const float *P = xyz + (size_t)blockIdx.x * N * 3;
@@ -215,8 +218,12 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(const float *__rest
   // ---------------- phase 2: the sampling rounds -----------------------------------------------------
   float px = P[0], py = P[1], pz = P[2];
   if (t == 0) out[0] = 0;
-  float wmax = -1.0f, wbx = 0.f, wby = 0.f, wbz = 0.f;  // this wave's cached best record (uniform)
+  if (t < 3) s_best[t] = 0ull;
+  __syncthreads();
+  int wbits = __float_as_int(-1.0f);  // this wave's cached best record (wave-uniform)
   unsigned wkey = 0xFFFFFFFFu;
+  float wbx = 0.f, wby = 0.f, wbz = 0.f;
+  int rot = 0;
   for (int j = 1; j < m; ++j) {
     bool changed = false;
 #pragma unroll
@@ -225,33 +232,38 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(const float *__rest
       unsigned long long mask = __ballot(lb < rmax[q]);
       changed |= mask != 0ull;
       while (mask) {
-        const int s = __builtin_ctzll(mask);
+        // two rows per trip so their loads and reduction chains overlap; with one row left the second slot
+        // repeats the first (min/max are idempotent, the record is rewritten with the same values)
+        const int s0 = __builtin_ctzll(mask);
         mask &= mask - 1ull;
-        const int pos = ((q * 64 + s) * NW + wid) * 64 + lane;
-        const float x = sx[pos], y = sy[pos], z = sz[pos];
-        const int kk = sk[pos];
-        const float nm = fminf(mdg[pos], sqdist(x, y, z, px, py, pz));
-        mdg[pos] = nm;
-        const float rm = wave_max_f32(nm);
-        const unsigned long long tied = __ballot(nm == rm);
-        int L;
-        unsigned key;
-        if (__builtin_popcountll(tied) == 1) {
-          L = __builtin_ctzll(tied);
-          key = tie_key2(__builtin_amdgcn_readlane(kk, L), log2bs);
-        } else {
-          const unsigned mine = (nm == rm) ? tie_key2(kk, log2bs) : 0xFFFFFFFFu;
-          key = wave_min_u32(mine);
-          L = __builtin_ctzll(__ballot(mine == key));
-        }
-        rmax[q] = wrlane(rm, s, rmax[q]);
-        rkey[q] = wrlane_u(key, s, rkey[q]);
-        rbx[q] = wrlane(rdlane(x, L), s, rbx[q]);
-        rby[q] = wrlane(rdlane(y, L), s, rby[q]);
-        rbz[q] = wrlane(rdlane(z, L), s, rbz[q]);
+        const int s1 = mask ? __builtin_ctzll(mask) : s0;
+        mask &= mask - 1ull;  // no-op when mask is already 0
+        const int p0 = ((q * 64 + s0) * NW + wid) * 64 + lane;
+        const int p1 = ((q * 64 + s1) * NW + wid) * 64 + lane;
+        const float x0 = sx[p0], y0 = sy[p0], z0 = sz[p0];
+        const float x1 = sx[p1], y1 = sy[p1], z1 = sz[p1];
+        const int k0 = sk[p0], k1 = sk[p1];
+        const float n0 = fminf(mdg[p0], sqdist(x0, y0, z0, px, py, pz));
+        const float n1 = fminf(mdg[p1], sqdist(x1, y1, z1, px, py, pz));
+        mdg[p0] = n0;
+        mdg[p1] = n1;
+        int b0, b1;
+        unsigned key0, key1;
+        const int L0 = wave_argmax(n0, tie_key2(k0, log2bs), &b0, &key0);
+        const int L1 = wave_argmax(n1, tie_key2(k1, log2bs), &b1, &key1);
+        rmax[q] = wrlane(__int_as_float(b0), s0, rmax[q]);
+        rkey[q] = wrlane_u(key0, s0, rkey[q]);
+        rbx[q] = wrlane(rdlane(x0, L0), s0, rbx[q]);
+        rby[q] = wrlane(rdlane(y0, L0), s0, rby[q]);
+        rbz[q] = wrlane(rdlane(z0, L0), s0, rbz[q]);
+        rmax[q] = wrlane(__int_as_float(b1), s1, rmax[q]);
+        rkey[q] = wrlane_u(key1, s1, rkey[q]);
+        rbx[q] = wrlane(rdlane(x1, L1), s1, rbx[q]);
+        rby[q] = wrlane(rdlane(y1, L1), s1, rby[q]);
+        rbz[q] = wrlane(rdlane(z1, L1), s1, rbz[q]);
       }
     }
-    if (changed) {  // uniform: refresh the wave's best over its row records
+    if (changed) {  // wave-uniform: refresh the wave's best over its row records
       float v = rmax[0];
       unsigned kq = rkey[0];
       float bx = rbx[0], by = rby[0], bz = rbz[0];
@@ -261,41 +273,31 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(const float *__rest
         v = better ? rmax[q] : v; kq = better ? rkey[q] : kq;
         bx = better ? rbx[q] : bx; by = better ? rby[q] : by; bz = better ? rbz[q] : bz;
       }
-      // an un-refreshed BIG marker only exists before round 1 finishes; every such row was just processed
-      wmax = wave_max_f32(v);
-      const unsigned mine = (v == wmax) ? kq : 0xFFFFFFFFu;
-      wkey = wave_min_u32(mine);
-      const int L = __builtin_ctzll(__ballot(mine == wkey) | (1ull << 63));
+      const int L = wave_argmax(v, kq, &wbits, &wkey);
       wbx = rdlane(bx, L); wby = rdlane(by, L); wbz = rdlane(bz, L);
     }
     const int buf = j & 1;
+    const unsigned long long mine = pack_best(wbits, wkey);
     if (lane == 0) {
-      s_red[buf][wid][0] = wmax; s_red[buf][wid][1] = __int_as_float((int)wkey);
-      s_red[buf][wid][2] = wbx; s_red[buf][wid][3] = wby; s_red[buf][wid][4] = wbz;
+      s_tab[buf][wid].packed = mine;
+      s_tab[buf][wid].x = wbx; s_tab[buf][wid].y = wby; s_tab[buf][wid].z = wbz;
+      atomicMax(&s_best[rot], mine);
     }
     __syncthreads();
     {
-      const int src = lane < NW ? lane : 0;
-      float d = s_red[buf][src][0];
-      unsigned kq = (unsigned)__float_as_int(s_red[buf][src][1]);
-      const float ex = s_red[buf][src][2], ey = s_red[buf][src][3], ez = s_red[buf][src][4];
-      if (lane >= NW) { d = -2.0f; kq = 0xFFFFFFFFu; }
-      float gmax;
-      unsigned gkey;
-      if constexpr (NW <= 16) {
-        gmax = row0_max_f32(d);
-        gkey = row0_min_u32(d == gmax ? kq : 0xFFFFFFFFu);
-      } else {
-        gmax = wave_max_f32(d);
-        gkey = wave_min_u32(d == gmax ? kq : 0xFFFFFFFFu);
-      }
+      const unsigned long long win = s_best[rot];
+      if (t == 0) s_best[rot == 0 ? 2 : rot - 1] = 0ull;
+      rot = rot == 2 ? 0 : rot + 1;
       int old;
-      if (gmax < 0.0f) {  // no candidate anywhere: the reference's (-1, 0) fallback
+      if ((win >> 32) == 0ull) {  // no candidate anywhere: the reference's (-1, 0) fallback
         old = 0;
         px = P[0]; py = P[1]; pz = P[2];
       } else {
-        const int L = __builtin_ctzll(__ballot(lane < NW && d == gmax && kq == gkey) | (1ull << 63));
-        old = (int)(gkey & 0x3FFFFFu);
+        const int src = lane < NW ? lane : 0;
+        const unsigned long long e = s_tab[buf][src].packed;
+        const float ex = s_tab[buf][src].x, ey = s_tab[buf][src].y, ez = s_tab[buf][src].z;
+        const int L = __builtin_ctzll(__ballot(lane < NW && e == win) | (1ull << 63));
+        old = (int)((~(unsigned)win) & 0x3FFFFFu);
         px = rdlane(ex, L); py = rdlane(ey, L); pz = rdlane(ez, L);
       }
       if (t == 0) out[j] = old;

@@ -137,6 +137,29 @@ __device__ __forceinline__ unsigned long long pack_best(int dbits, unsigned key)
   return ((unsigned long long)hi << 32) | (unsigned long long)(~key);
 }
 
+// Workgroup barrier that waits for LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would make
+// every sampling round wait for the previous round's global store to be acknowledged (~0.3 us).  Legal where
+// no wave reads global memory another wave wrote since the last full __syncthreads().
+__device__ __forceinline__ void barrier_lds_only() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Sample ids are produced one per round by every lane (wave-uniform value).  Wave 0 parks id j in lane j%64 and
+// flushes 64 ids with one coalesced store, so no round has a global store in flight at its barrier.
+struct IdSink {
+  int32_t *out;
+  int acc;
+  __device__ __forceinline__ void push(int j, int id, int m) {
+    if (threadIdx.x < 64) {
+      if ((int)threadIdx.x == (j & 63)) acc = id;
+      if ((j & 63) == 63 || j == m - 1) {
+        const int base = j & ~63;
+        if (base + (int)threadIdx.x <= j) out[base + threadIdx.x] = acc;
+      }
+    }
+  }
+};
+
 __device__ __forceinline__ unsigned lane_id() { return __lane_id(); }
 
 }  // namespace bq

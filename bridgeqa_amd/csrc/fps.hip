@@ -36,7 +36,7 @@ __device__ __forceinline__ int block_argmax(float best, int bestk, int log2bs, u
     return dbits < 0 ? 0 : (int)(wkey & 0x3FFFFFu);
   } else {
     if ((threadIdx.x & 63) == 0) atomicMax(&s_best[rot], pack_best(dbits, wkey));
-    __syncthreads();
+    barrier_lds_only();
     const unsigned long long win = s_best[rot];
     if (threadIdx.x == 0) s_best[rot == 0 ? 2 : rot - 1] = 0ull;  // (rot+2)%3
     return (win >> 32) == 0ull ? 0 : (int)((~(unsigned)win) & 0x3FFFFFu);
@@ -79,7 +79,8 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(const float *__restrict__ xy
       }
     }
   }
-  if (t == 0) out[0] = 0;
+  IdSink sink{out, 0};
+  sink.push(0, 0, m);
   __syncthreads();
 
   int old = 0, rot = 0;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(const float *__restrict__ xy
     }
     old = block_argmax<T>(best, bestk, log2bs, s_best, rot);
     rot = rot == 2 ? 0 : rot + 1;
-    if (t == 0) out[j] = old;
+    sink.push(j, old, m);
   }
 }
 
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(T) void fps_stream_kernel(const float *__restrict__
   int32_t *out = idx + (size_t)blockIdx.x * m;
   if (t < 3) s_best[t] = 0ull;
   for (int k = t; k < N; k += T) md[k] = (sqnorm(P[k * 3], P[k * 3 + 1], P[k * 3 + 2]) < 0.001f) ? -1.0f : 1e10f;
-  if (t == 0) out[0] = 0;
+  IdSink sink{out, 0};
+  sink.push(0, 0, m);
   __syncthreads();
   int old = 0, rot = 0;
   for (int j = 1; j < m; ++j) {
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(T) void fps_stream_kernel(const float *__restrict__
     }
     old = block_argmax<T>(best, bestk, log2bs, s_best, rot);
     rot = rot == 2 ? 0 : rot + 1;
-    if (t == 0) out[j] = old;
+    sink.push(j, old, m);
   }
 }
 

@@ -217,7 +217,8 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(const float *__rest
 
   // ---------------- phase 2: the sampling rounds -----------------------------------------------------
   float px = P[0], py = P[1], pz = P[2];
-  if (t == 0) out[0] = 0;
+  IdSink sink{out, 0};
+  sink.push(0, 0, m);
   if (t < 3) s_best[t] = 0ull;
   __syncthreads();
   int wbits = __float_as_int(-1.0f);  // this wave's cached best record (wave-uniform)
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(const float *__rest
       s_tab[buf][wid].x = wbx; s_tab[buf][wid].y = wby; s_tab[buf][wid].z = wbz;
       atomicMax(&s_best[rot], mine);
     }
-    __syncthreads();
+    barrier_lds_only();  // global traffic of a round (row loads / minima) is private to the issuing lane
     {
       const unsigned long long win = s_best[rot];
       if (t == 0) s_best[rot == 0 ? 2 : rot - 1] = 0ull;
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(const float *__rest
         old = (int)((~(unsigned)win) & 0x3FFFFFu);
         px = rdlane(ex, L); py = rdlane(ey, L); pz = rdlane(ez, L);
       }
-      if (t == 0) out[j] = old;
+      sink.push(j, old, m);
     }
   }
 }

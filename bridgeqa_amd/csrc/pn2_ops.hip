@@ -477,3 +477,24 @@ extern "C" int bq_three_interpolate_grad(const float *grad_out, const int32_t *i
                      grad_out, idx, weight, grad_points, C, n, m);
   return check_launch("three_interpolate_grad");
 }
+
+// ---- diagnostics -------------------------------------------------------------------------------
+// Shader clock seen by a resident wave: d(s_memtime) / d(s_memrealtime) * 100 MHz (MI355X_MICROARCH.md,
+// 'DVFS give-back' item 6).  out[0] = MHz measured by block 0 after `iters` dependent FMAs per lane.
+__global__ void debug_clock_kernel(float *out, int iters) {
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  float v = (float)threadIdx.x;
+  for (int i = 0; i < iters; ++i) v = v * 1.0000001f + 0.5f;
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    out[0] = (float)((double)(c1 - c0) / (double)(r1 - r0) * 100.0);
+    out[1] = v;
+    out[2] = (float)(c1 - c0);
+  }
+}
+
+extern "C" __attribute__((visibility("default"))) int bq_debug_clock_mhz(float *out, int blocks, int iters,
+                                                                         void *stream) {
+  hipLaunchKernelGGL(debug_clock_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters);
+  return bq::check_launch("debug_clock");
+}

@@ -45,6 +45,9 @@ _SIGS = {
 for _name, _args in _SIGS.items():
     getattr(_lib, _name).argtypes = _args
     getattr(_lib, _name).restype = ctypes.c_int
+_l = ctypes.c_long
+_lib.bq_attn_fwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i] + [_l] * 9 + [_f, _vp]
+_lib.bq_attn_fwd.restype = ctypes.c_int
 _lib.bq_fps_workspace_bytes.argtypes = [_i, _i]
 _lib.bq_fps_workspace_bytes.restype = ctypes.c_size_t
 
@@ -234,3 +237,37 @@ def group_concat_grad(grad_out, idx, n, radius, normalize, need_features, need_x
         _check(_lib.bq_group_concat_grad(_p(grad_out), _p(idx), _p(gf), _p(gx), _p(gn), B, C, int(n), M, S,
                                          float(radius), int(bool(normalize)), _stream()), "group_concat_grad")
     return gf, gx, gn
+
+
+# ---- fused attention (csrc/attn.hip) ---------------------------------------------------------------
+def _bhd_strides(t):
+    """(B, L, H, 64) view with a contiguous last dim -> element strides (batch, token, head)."""
+    if t.dtype != torch.bfloat16 or t.stride(3) != 1 or t.shape[3] != 64:
+        raise RuntimeError("attention operands must be bf16 (B, L, H, 64) views with a contiguous head dim")
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+def transpose_v(v, Lp):
+    """(B, L, H, 64) -> zero padded (B, H, 64, Lp), key-contiguous: the V^T operand of attn_fwd."""
+    B, L, H, D = v.shape
+    vt = torch.zeros(B, H, D, Lp, dtype=v.dtype, device=v.device)
+    vt[..., :L] = v.permute(0, 2, 3, 1)
+    return vt
+
+
+def attn_fwd(q, k, v, scale):
+    """softmax(q k^T * scale) v without materialising the scores.  q, k, v: bf16 (B, L, H, 64) views.
+    Returns out (B, L, H, 64) bf16 contiguous and lse (B, H, L) f32 (log2 domain)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        if not t.is_cuda:
+            raise RuntimeError("%s: CPU not supported" % n)
+    B, L, H, D = q.shape
+    Lp = (L + 63) // 64 * 64
+    with torch.cuda.device(q.device):
+        vt = transpose_v(v, Lp)
+        out = torch.empty(B, L, H, D, dtype=torch.bfloat16, device=q.device)
+        lse = torch.empty(B, H, L, dtype=torch.float32, device=q.device)
+        qs, ks, os_ = _bhd_strides(q), _bhd_strides(k), _bhd_strides(out)
+        _check(_lib.bq_attn_fwd(_p(q), _p(k), _p(vt), _p(out), _p(lse), B, H, L, Lp, *qs, *ks, *os_, float(scale),
+                                _stream()), "attn_fwd")
+    return out, lse

@@ -1,0 +1,194 @@
+// Fused (non-materialising) multi-head attention for gfx950, head_dim 64, bf16 in / fp32 accumulate.
+// Replaces the  q@k^T -> *scale -> softmax -> @v  chain of the reference's ViT attention
+// (models/vit.py:75-83), which writes a (B,12,P,P) fp32 probability tensor per layer (807 MB at
+// 512x512).  Forward here; the backward kernels live below it.
+//
+// MFMA mapping (v_mfma_f32_32x32x16_bf16; operand maps from cdna_hip_programming.md §3):
+//   S^T[key][q] = K . Q^T       A = K rows from LDS (ds_read_b128), B = Q fragments held in registers.
+//                               Result: lane = one query column, its 16 registers = 16 keys of the block,
+//                               so the softmax max/sum are in-lane loops + ONE permlane32_swap.
+//   O^T[d][q]  += V^T . P^T     B = the probabilities straight from the S^T accumulator registers (converted
+//                               to bf16, no lane movement); A = V^T rows from an LDS image of the
+//                               pre-transposed V ([d][key], key-contiguous) read in the k-order the
+//                               accumulator registers have (16s + 8(j>>2) + 4h + (j&3)).
+//                               Result: lane = query column again, so the online-softmax rescale of O is a
+//                               per-lane scalar multiply.
+// Workgroup = 4 waves = 128 query rows of one (batch, head); K / V^T tiles of 64 keys are staged through
+// LDS once per workgroup (XOR-swizzled 16-B chunks), the next tile's global loads are in flight while the
+// current one is consumed.
+#include "bq_common.h"
+
+namespace bq {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short u16;
+
+constexpr int AT_D = 64;      // head dim
+constexpr int AT_QW = 32;     // query rows per wave
+constexpr int AT_NW = 4;      // waves per workgroup
+constexpr int AT_QB = AT_QW * AT_NW;  // 128 query rows per workgroup
+constexpr int AT_KB = 64;     // keys per LDS tile
+
+__device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ float xhalf_max(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+  return fmaxf(__int_as_float(r[0]), __int_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+  return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+
+// byte offset of 16-B chunk `ch` (0..7) of row `row` in a [rows][64 x bf16] LDS image
+__device__ __forceinline__ int swz(int row, int ch) { return row * 128 + ((ch ^ (row & 7)) << 4); }
+
+struct AttnDims {
+  int B, H, L, Lp;                  // L = real length, Lp = padded length of the transposed operands
+  long q_bs, q_rs, q_hs;            // element strides: batch, row (token), head
+  long k_bs, k_rs, k_hs;
+  long o_bs, o_rs, o_hs;
+};
+
+// Staging of one 64 x 64 bf16 tile (source rows of 64 contiguous elements) into a swizzled LDS image via
+// registers: 512 chunks of 16 B, two per thread.  Loads are issued one tile ahead of their LDS commit.
+__device__ __forceinline__ uint4 stage_load(const __bf16 *base, long row_stride, int row0, int nrows_valid, int c) {
+  const int row = c >> 3, ch = c & 7;
+  const int gr = min(row0 + row, nrows_valid - 1);  // clamp: rows past the end repeat the last one (masked later)
+  return *reinterpret_cast<const uint4 *>(base + (long)gr * row_stride + ch * 8);
+}
+__device__ __forceinline__ void stage_store(unsigned char *lds, int c, uint4 v) {
+  *reinterpret_cast<uint4 *>(lds + swz(c >> 3, c & 7)) = v;
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+                                                       const __bf16 *__restrict__ Vt, __bf16 *__restrict__ O,
+                                                       float *__restrict__ LSE, AttnDims dm, float scale_log2e) {
+  __shared__ __align__(16) unsigned char s_k[AT_KB * 128];
+  __shared__ __align__(16) unsigned char s_v[AT_D * 128];
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
+  const int q0 = blockIdx.x * AT_QB + wid * AT_QW;  // first query row of this wave
+  const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
+  const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
+  const __bf16 *Vb = Vt + (long)bh * AT_D * dm.Lp;
+
+  // Q fragments (B operand of S^T = K.Q^T): lane (q = r, h) holds Q[q][16*step + 8h + j]
+  bf16x8 qf[4];
+  {
+    const int qr = min(q0 + r, dm.L - 1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8 *>(Qb + (long)qr * dm.q_rs + 16 * s + 8 * h);
+  }
+  f32x16 o0 = {0}, o1 = {0};
+  float m = -INFINITY, lsum = 0.0f;
+  const int nkt = (dm.L + AT_KB - 1) / AT_KB;
+  uint4 ka = stage_load(Kb, dm.k_rs, 0, dm.L, t), kb = stage_load(Kb, dm.k_rs, 0, dm.L, t + 256);
+  uint4 va = stage_load(Vb, dm.Lp, 0, AT_D, t), vb = stage_load(Vb, dm.Lp, 0, AT_D, t + 256);  // rows = d
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();  // everyone finished reading the previous tile
+    stage_store(s_k, t, ka); stage_store(s_k, t + 256, kb);
+    stage_store(s_v, t, va); stage_store(s_v, t + 256, vb);
+    __syncthreads();
+    {
+      const int nt = min(kt + 1, nkt - 1);  // the tile after the last is a harmless re-load of the last
+      ka = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.L, t); kb = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.L, t + 256);
+      va = stage_load(Vb + nt * AT_KB, dm.Lp, 0, AT_D, t); vb = stage_load(Vb + nt * AT_KB, dm.Lp, 0, AT_D, t + 256);
+    }
+    const bool last = kt == nkt - 1;
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+      f32x16 acc = {0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(s_k + swz(kb2 * 32 + r, 2 * s + h));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], acc, 0, 0, 0);
+      }
+      float sc[16];
+      float mloc = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        sc[i] = acc[i] * scale_log2e;
+        if (last && kt * AT_KB + kb2 * 32 + crow(i, h) >= dm.L) sc[i] = -INFINITY;
+        mloc = fmaxf(mloc, sc[i]);
+      }
+      mloc = xhalf_max(mloc);
+      const float mnew = fmaxf(m, mloc);
+      const float alpha = __builtin_amdgcn_exp2f(m - mnew);  // m = -inf on the first block -> 0
+      m = mnew;
+      float psum = 0.0f;
+      bf16x8 pb0, pb1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float p = __builtin_amdgcn_exp2f(sc[i] - mnew);
+        const float p2 = __builtin_amdgcn_exp2f(sc[8 + i] - mnew);
+        psum += p + p2;
+        pb0[i] = (__bf16)p;
+        pb1[i] = (__bf16)p2;
+      }
+      lsum = lsum * alpha + psum;
+      if (__ballot(alpha != 1.0f)) {  // wave-uniform: skip the rescale once the running max has settled
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int ch = 4 * kb2 + 2 * s2;
+        bf16x8 v0, v1;
+        {
+          const unsigned char *p0 = s_v + swz(r, ch) + h * 8, *p1 = s_v + swz(r, ch + 1) + h * 8;
+          const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(p0), hi = *reinterpret_cast<const bf16x4 *>(p1);
+          v0 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          const unsigned char *p2 = s_v + swz(32 + r, ch) + h * 8, *p3 = s_v + swz(32 + r, ch + 1) + h * 8;
+          const bf16x4 lo1 = *reinterpret_cast<const bf16x4 *>(p2), hi1 = *reinterpret_cast<const bf16x4 *>(p3);
+          v1 = __builtin_shufflevector(lo1, hi1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        const bf16x8 pb = s2 == 0 ? pb0 : pb1;
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, o1, 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: O[q][d] = O^T[d][q] / l ; LSE[q] = m + log2(l)   (log2 domain, scale folded in)
+  const float l = xhalf_sum(lsum);
+  const float inv = 1.0f / l;
+  const int q = q0 + r;
+  if (q < dm.L) {
+    __bf16 *Orow = O + b * dm.o_bs + hd * dm.o_hs + (long)q * dm.o_rs;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 w0, w1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        w0[j] = (__bf16)(o0[4 * g + j] * inv);
+        w1[j] = (__bf16)(o1[4 * g + j] * inv);
+      }
+      *reinterpret_cast<bf16x4 *>(Orow + 8 * g + 4 * h) = w0;
+      *reinterpret_cast<bf16x4 *>(Orow + 32 + 8 * g + 4 * h) = w1;
+    }
+    if (h == 0) LSE[(long)bh * dm.L + q] = m + __builtin_amdgcn_logf(l);  // v_log_f32 = log2
+  }
+}
+
+}  // namespace bq
+
+using namespace bq;
+
+// Q, K: bf16 with element strides (batch, token, head), 64 contiguous elements per (token, head);
+// Vt: bf16 [B*H][64][Lp] (V transposed, key-contiguous, zero padded to Lp, Lp % 64 == 0);
+// O: bf16 strided like Q; LSE: f32 [B*H][L], log2-domain log-sum-exp of the scaled scores.
+extern "C" __attribute__((visibility("default"))) int bq_attn_fwd(
+    const void *Q, const void *K, const void *Vt, void *O, float *LSE, int B, int H, int L, int Lp, long q_bs,
+    long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long o_bs, long o_rs, long o_hs, float scale, void *stream) {
+  BQ_REQUIRE(B > 0 && H > 0 && L > 0 && Lp >= L && Lp % 64 == 0, BQ_EINVAL, "attn_fwd: bad extents");
+  BQ_REQUIRE(Q && K && Vt && O && LSE, BQ_EINVAL, "attn_fwd: null pointer");
+  BQ_REQUIRE((q_rs % 8) == 0 && (k_rs % 8) == 0 && (o_rs % 4) == 0 && (q_hs % 8) == 0 && (k_hs % 8) == 0, BQ_EINVAL,
+             "attn_fwd: rows must be 16-byte aligned");
+  AttnDims dm{B, H, L, Lp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, o_bs, o_rs, o_hs};
+  const dim3 grid((L + AT_QB - 1) / AT_QB, B * H);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Q, (const __bf16 *)K,
+                     (const __bf16 *)Vt, (__bf16 *)O, LSE, dm, scale * 1.4426950408889634f);
+  return check_launch("attn_fwd");
+}

@@ -28,8 +28,25 @@ def compute_dtype():
     return _COMPUTE_DTYPE
 
 
+_PARAM_CACHE = {}
+
+
 def _c(t):
-    return t if t.dtype == _COMPUTE_DTYPE else t.to(_COMPUTE_DTYPE)
+    """Cast to the compute dtype.  Parameters are cast once per optimizer step: the cached copy is keyed by the
+    parameter's in-place version counter, so any optimizer update (or load_state_dict) invalidates it; the cast
+    stays in the autograd graph, so gradients still reach the fp32 master weight."""
+    if t.dtype == _COMPUTE_DTYPE:
+        return t
+    if isinstance(t, torch.nn.Parameter):
+        key = id(t)
+        hit = _PARAM_CACHE.get(key)
+        if hit is not None and hit[0] == t._version and hit[1].dtype == _COMPUTE_DTYPE \
+                and hit[1].requires_grad == (t.requires_grad and torch.is_grad_enabled()):
+            return hit[1]
+        c = t.to(_COMPUTE_DTYPE)
+        _PARAM_CACHE[key] = (t._version, c)
+        return c
+    return t.to(_COMPUTE_DTYPE)
 
 
 def linear(x, weight, bias=None, act=None):

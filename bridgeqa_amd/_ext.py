@@ -48,6 +48,8 @@ for _name, _args in _SIGS.items():
 _l = ctypes.c_long
 _lib.bq_attn_fwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i] + [_l] * 9 + [_f, _vp]
 _lib.bq_attn_fwd.restype = ctypes.c_int
+_lib.bq_attn_bwd.argtypes = [_vp] * 12 + [_i, _i, _i, _i] + [_l] * 9 + [_f, _vp]
+_lib.bq_attn_bwd.restype = ctypes.c_int
 _lib.bq_fps_workspace_bytes.argtypes = [_i, _i]
 _lib.bq_fps_workspace_bytes.restype = ctypes.c_size_t
 
@@ -253,6 +255,24 @@ def transpose_v(v, Lp):
     vt = torch.zeros(B, H, D, Lp, dtype=v.dtype, device=v.device)
     vt[..., :L] = v.permute(0, 2, 3, 1)
     return vt
+
+
+def attn_bwd(q, k, v, out, lse, grad_out, scale, dq, dk, dv):
+    """Backward of attn_fwd.  q, k, v, grad_out: bf16 (B, L, H, 64) views (k and v with equal strides);
+    out / lse from the forward; dq, dk, dv: preallocated bf16 views (dq strided like q, dk/dv like k)."""
+    B, L, H, D = q.shape
+    Lp = (L + 63) // 64 * 64
+    if k.stride() != v.stride() or dq.stride() != q.stride() or dk.stride() != k.stride() or dv.stride() != k.stride():
+        raise RuntimeError("attn_bwd: stride contract violated")
+    with torch.cuda.device(q.device):
+        if grad_out.stride(3) != 1:
+            grad_out = grad_out.contiguous()
+        delta = (grad_out.float() * out.float()).sum(-1).permute(0, 2, 1).contiguous()  # (B, H, L)
+        qt, kt, gt = transpose_v(q, Lp), transpose_v(k, Lp), transpose_v(grad_out, Lp)
+        qs, ks, gs = _bhd_strides(q), _bhd_strides(k), _bhd_strides(grad_out)
+        _check(_lib.bq_attn_bwd(_p(q), _p(k), _p(v), _p(qt), _p(kt), _p(grad_out), _p(gt), _p(lse), _p(delta),
+                                _p(dq), _p(dk), _p(dv), B, H, L, Lp, *qs, *ks, *gs, float(scale), _stream()),
+               "attn_bwd")
 
 
 def attn_fwd(q, k, v, scale):

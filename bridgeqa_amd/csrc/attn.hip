@@ -172,6 +172,235 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __bf16 *__restrict_
   }
 }
 
+
+// =====================================================================================================
+// Backward.  With P = softmax(S), S = scale * Q K^T, delta[q] = rowsum(dO o O):
+//   dV = P^T dO      dP = dO V^T      dS = P o (dP - delta) * scale      dQ = dS K      dK = dS^T Q
+// P is recomputed from Q, K and the forward's log-sum-exp (no (L x L) tensor is ever stored).  Two kernels
+// with the forward's operand maps, so every product keeps "one lane = one column":
+//   attn_bwd_dq : lane = query.  S^T = K.Q^T and dP^T = V.dO^T (A from LDS rows, B = register fragments of Q
+//                 and dO), then dQ^T[d][q] += K^T[d][key] . dS^T[key][q] (A = LDS image of the pre-transposed
+//                 K, B = dS straight from the accumulator registers).
+//   attn_bwd_dkv: lane = key.    S = Q.K^T and dP = dO.V^T (A = Q / dO rows from LDS, B = register fragments
+//                 of K and V), then dV^T[d][key] += dO^T[d][q] . P[q][key] and dK^T[d][key] += Q^T[d][q] . dS[q][key]
+//                 (A = LDS images of the pre-transposed dO and Q).
+// =====================================================================================================
+
+// 16 contiguous-in-groups-of-4 floats for the register rows of lane half h: v[rr] = src[32*blk + crow(rr, h)]
+__device__ __forceinline__ void load_rowvals(const float *src, int blk, int h, float *v) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 x = *reinterpret_cast<const float4 *>(src + 32 * blk + 8 * g + 4 * h);
+    v[4 * g + 0] = x.x; v[4 * g + 1] = x.y; v[4 * g + 2] = x.z; v[4 * g + 3] = x.w;
+  }
+}
+
+// A fragment (8 x bf16) of a TRANSPOSED image [row][k]: elements k = 16*s2 + 8*(j>>2) + 4*h + (j&3) of row `row`
+__device__ __forceinline__ bf16x8 tfrag(const unsigned char *img, int row, int kchunk, int h) {
+  const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(img + swz(row, kchunk) + h * 8);
+  const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(img + swz(row, kchunk + 1) + h * 8);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// store a transposed accumulator pair (T[d][col], lane = col) as row `Xrow`[0..63] of a bf16 matrix
+__device__ __forceinline__ void store_T(__bf16 *Xrow, const f32x16 &a0, const f32x16 &a1, int h, float mul) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    bf16x4 w0, w1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w0[j] = (__bf16)(a0[4 * g + j] * mul);
+      w1[j] = (__bf16)(a1[4 * g + j] * mul);
+    }
+    *reinterpret_cast<bf16x4 *>(Xrow + 8 * g + 4 * h) = w0;
+    *reinterpret_cast<bf16x4 *>(Xrow + 32 + 8 * g + 4 * h) = w1;
+  }
+}
+
+struct BwdDims {
+  int B, H, L, Lp;
+  long q_bs, q_rs, q_hs;    // Q / dQ
+  long k_bs, k_rs, k_hs;    // K, V / dK, dV
+  long g_bs, g_rs, g_hs;    // dO
+};
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+                                                          const __bf16 *__restrict__ V, const __bf16 *__restrict__ Kt,
+                                                          const __bf16 *__restrict__ dO, const float *__restrict__ LSE,
+                                                          const float *__restrict__ DELTA, __bf16 *__restrict__ dQ,
+                                                          BwdDims dm, float scale) {
+  __shared__ __align__(16) unsigned char s_k[AT_KB * 128];
+  __shared__ __align__(16) unsigned char s_v[AT_KB * 128];
+  __shared__ __align__(16) unsigned char s_kt[AT_D * 128];
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
+  const int q0 = blockIdx.x * AT_QB + wid * AT_QW;
+  const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
+  const __bf16 *Gb = dO + b * dm.g_bs + hd * dm.g_hs;
+  const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
+  const __bf16 *Vb = V + b * dm.k_bs + hd * dm.k_hs;
+  const __bf16 *Ktb = Kt + (long)bh * AT_D * dm.Lp;
+  const float c = scale * 1.4426950408889634f;
+
+  bf16x8 qf[4], gf[4];
+  const int qr = min(q0 + r, dm.L - 1);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    qf[s] = *reinterpret_cast<const bf16x8 *>(Qb + (long)qr * dm.q_rs + 16 * s + 8 * h);
+    gf[s] = *reinterpret_cast<const bf16x8 *>(Gb + (long)qr * dm.g_rs + 16 * s + 8 * h);
+  }
+  const float lse = LSE[(long)bh * dm.L + qr], delta = DELTA[(long)bh * dm.L + qr];
+  f32x16 a0 = {0}, a1 = {0};
+  const int nkt = (dm.L + AT_KB - 1) / AT_KB;
+  uint4 ka = stage_load(Kb, dm.k_rs, 0, dm.L, t), kb = stage_load(Kb, dm.k_rs, 0, dm.L, t + 256);
+  uint4 va = stage_load(Vb, dm.k_rs, 0, dm.L, t), vb = stage_load(Vb, dm.k_rs, 0, dm.L, t + 256);
+  uint4 ta = stage_load(Ktb, dm.Lp, 0, AT_D, t), tb = stage_load(Ktb, dm.Lp, 0, AT_D, t + 256);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    stage_store(s_k, t, ka); stage_store(s_k, t + 256, kb);
+    stage_store(s_v, t, va); stage_store(s_v, t + 256, vb);
+    stage_store(s_kt, t, ta); stage_store(s_kt, t + 256, tb);
+    __syncthreads();
+    {
+      const int nt = min(kt + 1, nkt - 1);
+      ka = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.L, t); kb = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.L, t + 256);
+      va = stage_load(Vb, dm.k_rs, nt * AT_KB, dm.L, t); vb = stage_load(Vb, dm.k_rs, nt * AT_KB, dm.L, t + 256);
+      ta = stage_load(Ktb + nt * AT_KB, dm.Lp, 0, AT_D, t); tb = stage_load(Ktb + nt * AT_KB, dm.Lp, 0, AT_D, t + 256);
+    }
+    const bool last = kt == nkt - 1;
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+      f32x16 sacc = {0}, pacc = {0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 ak = *reinterpret_cast<const bf16x8 *>(s_k + swz(kb2 * 32 + r, 2 * s + h));
+        const bf16x8 av = *reinterpret_cast<const bf16x8 *>(s_v + swz(kb2 * 32 + r, 2 * s + h));
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, qf[s], sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, gf[s], pacc, 0, 0, 0);
+      }
+      bf16x8 d0, d1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float p = __builtin_amdgcn_exp2f(sacc[i] * c - lse), p2 = __builtin_amdgcn_exp2f(sacc[8 + i] * c - lse);
+        if (last) {
+          if (kt * AT_KB + kb2 * 32 + crow(i, h) >= dm.L) p = 0.0f;
+          if (kt * AT_KB + kb2 * 32 + crow(8 + i, h) >= dm.L) p2 = 0.0f;
+        }
+        d0[i] = (__bf16)(p * (pacc[i] - delta) * scale);
+        d1[i] = (__bf16)(p2 * (pacc[8 + i] - delta) * scale);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int ch = 4 * kb2 + 2 * s2;
+        const bf16x8 ds = s2 == 0 ? d0 : d1;
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(s_kt, r, ch, h), ds, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(s_kt, 32 + r, ch, h), ds, a1, 0, 0, 0);
+      }
+    }
+  }
+  if (q0 + r < dm.L) store_T(dQ + b * dm.q_bs + hd * dm.q_hs + (long)(q0 + r) * dm.q_rs, a0, a1, h, 1.0f);
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+                                                           const __bf16 *__restrict__ V, const __bf16 *__restrict__ Qt,
+                                                           const __bf16 *__restrict__ dO, const __bf16 *__restrict__ dOt,
+                                                           const float *__restrict__ LSE, const float *__restrict__ DELTA,
+                                                           __bf16 *__restrict__ dK, __bf16 *__restrict__ dV, BwdDims dm,
+                                                           float scale) {
+  __shared__ __align__(16) unsigned char s_q[AT_KB * 128];
+  __shared__ __align__(16) unsigned char s_g[AT_KB * 128];
+  __shared__ __align__(16) unsigned char s_qt[AT_D * 128];
+  __shared__ __align__(16) unsigned char s_gt[AT_D * 128];
+  __shared__ __align__(16) float s_lse[AT_KB];
+  __shared__ __align__(16) float s_del[AT_KB];
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
+  const int k0 = blockIdx.x * AT_QB + wid * AT_QW;  // first key of this wave
+  const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
+  const __bf16 *Gb = dO + b * dm.g_bs + hd * dm.g_hs;
+  const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
+  const __bf16 *Vb = V + b * dm.k_bs + hd * dm.k_hs;
+  const __bf16 *Qtb = Qt + (long)bh * AT_D * dm.Lp;
+  const __bf16 *Gtb = dOt + (long)bh * AT_D * dm.Lp;
+  const float *lseb = LSE + (long)bh * dm.L, *delb = DELTA + (long)bh * dm.L;
+  const float c = scale * 1.4426950408889634f;
+
+  bf16x8 kf[4], vf[4];
+  const int kr = min(k0 + r, dm.L - 1);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    kf[s] = *reinterpret_cast<const bf16x8 *>(Kb + (long)kr * dm.k_rs + 16 * s + 8 * h);
+    vf[s] = *reinterpret_cast<const bf16x8 *>(Vb + (long)kr * dm.k_rs + 16 * s + 8 * h);
+  }
+  f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
+  const int nqt = (dm.L + AT_KB - 1) / AT_KB;
+  uint4 qa = stage_load(Qb, dm.q_rs, 0, dm.L, t), qb = stage_load(Qb, dm.q_rs, 0, dm.L, t + 256);
+  uint4 ga = stage_load(Gb, dm.g_rs, 0, dm.L, t), gb = stage_load(Gb, dm.g_rs, 0, dm.L, t + 256);
+  uint4 qta = stage_load(Qtb, dm.Lp, 0, AT_D, t), qtb = stage_load(Qtb, dm.Lp, 0, AT_D, t + 256);
+  uint4 gta = stage_load(Gtb, dm.Lp, 0, AT_D, t), gtb = stage_load(Gtb, dm.Lp, 0, AT_D, t + 256);
+  float rl = 0.f, rd = 0.f;
+  if (t < AT_KB) { rl = lseb[min(t, dm.L - 1)]; rd = delb[min(t, dm.L - 1)]; }
+  for (int qt = 0; qt < nqt; ++qt) {
+    __syncthreads();
+    stage_store(s_q, t, qa); stage_store(s_q, t + 256, qb);
+    stage_store(s_g, t, ga); stage_store(s_g, t + 256, gb);
+    stage_store(s_qt, t, qta); stage_store(s_qt, t + 256, qtb);
+    stage_store(s_gt, t, gta); stage_store(s_gt, t + 256, gtb);
+    if (t < AT_KB) { s_lse[t] = rl; s_del[t] = rd; }
+    __syncthreads();
+    {
+      const int nt = min(qt + 1, nqt - 1);
+      qa = stage_load(Qb, dm.q_rs, nt * AT_KB, dm.L, t); qb = stage_load(Qb, dm.q_rs, nt * AT_KB, dm.L, t + 256);
+      ga = stage_load(Gb, dm.g_rs, nt * AT_KB, dm.L, t); gb = stage_load(Gb, dm.g_rs, nt * AT_KB, dm.L, t + 256);
+      qta = stage_load(Qtb + nt * AT_KB, dm.Lp, 0, AT_D, t); qtb = stage_load(Qtb + nt * AT_KB, dm.Lp, 0, AT_D, t + 256);
+      gta = stage_load(Gtb + nt * AT_KB, dm.Lp, 0, AT_D, t); gtb = stage_load(Gtb + nt * AT_KB, dm.Lp, 0, AT_D, t + 256);
+      if (t < AT_KB) { rl = lseb[min(nt * AT_KB + t, dm.L - 1)]; rd = delb[min(nt * AT_KB + t, dm.L - 1)]; }
+    }
+    const bool last = qt == nqt - 1;
+#pragma unroll
+    for (int qb2 = 0; qb2 < 2; ++qb2) {
+      f32x16 sacc = {0}, pacc = {0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 aq = *reinterpret_cast<const bf16x8 *>(s_q + swz(qb2 * 32 + r, 2 * s + h));
+        const bf16x8 ag = *reinterpret_cast<const bf16x8 *>(s_g + swz(qb2 * 32 + r, 2 * s + h));
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf[s], sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, vf[s], pacc, 0, 0, 0);
+      }
+      float lv[16], dl[16];
+      load_rowvals(s_lse, qb2, h, lv);
+      load_rowvals(s_del, qb2, h, dl);
+      bf16x8 p0, p1, d0, d1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float p = __builtin_amdgcn_exp2f(sacc[i] * c - lv[i]), p2 = __builtin_amdgcn_exp2f(sacc[8 + i] * c - lv[8 + i]);
+        if (last) {  // query rows past the end were staged as copies of the last row: drop them
+          if (qt * AT_KB + qb2 * 32 + crow(i, h) >= dm.L) p = 0.0f;
+          if (qt * AT_KB + qb2 * 32 + crow(8 + i, h) >= dm.L) p2 = 0.0f;
+        }
+        p0[i] = (__bf16)p;
+        p1[i] = (__bf16)p2;
+        d0[i] = (__bf16)(p * (pacc[i] - dl[i]) * scale);
+        d1[i] = (__bf16)(p2 * (pacc[8 + i] - dl[8 + i]) * scale);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int ch = 4 * qb2 + 2 * s2;
+        const bf16x8 pp = s2 == 0 ? p0 : p1, ds = s2 == 0 ? d0 : d1;
+        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(s_gt, r, ch, h), pp, dv0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(s_gt, 32 + r, ch, h), pp, dv1, 0, 0, 0);
+        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(s_qt, r, ch, h), ds, dk0, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(s_qt, 32 + r, ch, h), ds, dk1, 0, 0, 0);
+      }
+    }
+  }
+  if (k0 + r < dm.L) {
+    const long off = b * dm.k_bs + hd * dm.k_hs + (long)(k0 + r) * dm.k_rs;
+    store_T(dK + off, dk0, dk1, h, 1.0f);
+    store_T(dV + off, dv0, dv1, h, 1.0f);
+  }
+}
+
 }  // namespace bq
 
 using namespace bq;
@@ -191,4 +420,30 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_fwd(
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Q, (const __bf16 *)K,
                      (const __bf16 *)Vt, (__bf16 *)O, LSE, dm, scale * 1.4426950408889634f);
   return check_launch("attn_fwd");
+}
+
+// Backward of bq_attn_fwd.  Q, K, V, dO, dQ, dK, dV: bf16 strided (batch, token, head) with 64 contiguous
+// elements; dQ shares Q's strides, dK/dV share K's (V must be strided like K).  Kt, Qt, dOt: bf16
+// [B*H][64][Lp] zero-padded transposes.  LSE (from the forward) and DELTA = rowsum(dO*O): f32 [B*H][L].
+extern "C" __attribute__((visibility("default"))) int bq_attn_bwd(
+    const void *Q, const void *K, const void *V, const void *Qt, const void *Kt, const void *dO, const void *dOt,
+    const float *LSE, const float *DELTA, void *dQ, void *dK, void *dV, int B, int H, int L, int Lp, long q_bs,
+    long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long g_bs, long g_rs, long g_hs, float scale,
+    void *stream) {
+  BQ_REQUIRE(B > 0 && H > 0 && L > 0 && Lp >= L && Lp % 64 == 0, BQ_EINVAL, "attn_bwd: bad extents");
+  BQ_REQUIRE(Q && K && V && Qt && Kt && dO && dOt && LSE && DELTA && dQ && dK && dV, BQ_EINVAL,
+             "attn_bwd: null pointer");
+  BQ_REQUIRE((q_rs % 8) == 0 && (k_rs % 8) == 0 && (g_rs % 8) == 0 && (q_hs % 8) == 0 && (k_hs % 8) == 0 &&
+                 (g_hs % 8) == 0, BQ_EINVAL, "attn_bwd: rows must be 16-byte aligned");
+  BwdDims dm{B, H, L, Lp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, g_bs, g_rs, g_hs};
+  const dim3 grid((L + AT_QB - 1) / AT_QB, B * H);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, (const __bf16 *)Q, (const __bf16 *)K,
+                     (const __bf16 *)V, (const __bf16 *)Kt, (const __bf16 *)dO, LSE, DELTA, (__bf16 *)dQ, dm, scale);
+  int rc = check_launch("attn_bwd_dq");
+  if (rc) return rc;
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, (const __bf16 *)Q, (const __bf16 *)K,
+                     (const __bf16 *)V, (const __bf16 *)Qt, (const __bf16 *)dO, (const __bf16 *)dOt, LSE, DELTA,
+                     (__bf16 *)dK, (__bf16 *)dV, dm, scale);
+  return check_launch("attn_bwd_dkv");
 }

@@ -86,6 +86,39 @@ def attention(q, k, v, mask, scale, return_probs=False, dropout_p=0.0):
     return ctx, (probs if return_probs else None)
 
 
+class _PackedAttention(torch.autograd.Function):
+    """softmax(q k^T * scale) v on a fused-QKV tensor (B, L, 3, H, 64) through the MFMA kernels of
+    csrc/attn.hip: no (L x L) tensor in HBM, forward or backward; the gradient comes back packed the same
+    way, so the QKV projection's backward needs no concat."""
+
+    @staticmethod
+    def forward(ctx, qkv, scale):
+        from . import _ext
+        out, lse = _ext.attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], scale)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import _ext
+        qkv, out, lse = ctx.saved_tensors
+        dqkv = torch.empty_like(qkv)
+        _ext.attn_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out, lse, grad_out, ctx.scale,
+                      dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2])
+        return dqkv, None
+
+
+def attention_packed(qkv, scale, dropout_p=0.0):
+    """Self-attention on the output of a fused QKV projection, qkv (B, L, 3, H, D) -> (B, L, H, D).
+    bf16 / D=64 / CUDA goes to the fused kernels; anything else to the reference composition."""
+    if qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.shape[-1] == 64 and dropout_p == 0.0 \
+            and qkv.is_contiguous():
+        return _PackedAttention.apply(qkv, scale)
+    ctx, _ = attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], None, scale, dropout_p=dropout_p)
+    return ctx
+
+
 def lm_loss(hidden, decoder_weight, decoder_bias, labels, label_smoothing=0.1):
     """Tied LM head + shifted label-smoothed cross entropy, summed per sequence (med.py:1417-1432).
 

@@ -106,14 +106,15 @@ class Attention(nn.Module):
         B, N, C = x.shape
         H = self.num_heads
         qkv = ops.linear(x, self.qkv.weight, self.qkv.bias).reshape(B, N, 3, H, C // H)
-        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]  # (B,N,H,D) views, no permute copies
-        want_probs = register_hook or (self.attn_drop.p > 0 and self.training)
-        ctx, probs = ops.attention(q, k, v, None, self.scale, return_probs=want_probs,
-                                   dropout_p=self.attn_drop.p if self.training else 0.0)
-        if register_hook:
+        drop = self.attn_drop.p if self.training else 0.0
+        if register_hook:  # Grad-CAM style hooks need the probabilities: reference composition
+            ctx, probs = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], None, self.scale, return_probs=True,
+                                       dropout_p=drop)
             self.save_attention_map(probs)
             if probs.requires_grad:
                 probs.register_hook(self.save_attn_gradients)
+        else:
+            ctx = ops.attention_packed(qkv, self.scale, dropout_p=drop)
         x = ops.linear(ctx.reshape(B, N, C), self.proj.weight, self.proj.bias)
         return self.proj_drop(x)
 

@@ -44,3 +44,38 @@ def test_attn_fwd_rescale_branch(dev):
     want, want_lse = ref_attention(q, k, v, 0.125)
     assert (out.float() - want).norm() / want.norm() < 2e-2
     assert (lse - want_lse).abs().max() < 2e-3
+
+
+@pytest.mark.parametrize("B,H,L", [(1, 1, 32), (2, 3, 64), (1, 2, 77), (2, 4, 197), (1, 2, 1025), (1, 1, 130)])
+def test_attn_bwd_vs_torch_autograd_fp32(dev, B, H, L):
+    """dQ, dK, dV of the fused kernels vs autograd through the fp32 reference composition on the same
+    bf16-rounded inputs; tolerance 3e-2 relative-L2 (bf16 P / dS operands, fp32 accumulation)."""
+    from bridgeqa_amd import fusion_ops
+    g = torch.Generator().manual_seed(L + 1)
+    qkv = (torch.randn(B, L, 3, H, 64, generator=g)).to(dev).to(torch.bfloat16).requires_grad_(True)
+    go = torch.randn(B, L, H, 64, generator=g).to(dev).to(torch.bfloat16)
+    out = fusion_ops.attention_packed(qkv, 0.125)
+    out.backward(go)
+    got = qkv.grad.float()
+    ref_in = qkv.detach().float().requires_grad_(True)
+    want, _ = ref_attention(ref_in[:, :, 0], ref_in[:, :, 1], ref_in[:, :, 2], 0.125)
+    want.backward(go.float())
+    for i, name in enumerate(("dq", "dk", "dv")):
+        err = (got[:, :, i] - ref_in.grad[:, :, i]).norm() / ref_in.grad[:, :, i].norm()
+        assert err < 3e-2, (name, err)
+
+
+def test_vit_block_bf16_fused_vs_fp32_composition(dev):
+    """A ViT block through the fused path (bf16) against the same block in fp32 reference composition."""
+    from bridgeqa_amd import fusion_ops, vit
+    torch.manual_seed(0)
+    blk = vit.Block(dim=768, num_heads=12, qkv_bias=True).to(dev).eval()
+    x = torch.randn(2, 197, 768, device=dev)
+    prev = fusion_ops.set_compute_dtype(torch.float32)
+    try:
+        want = blk(x)
+        fusion_ops.set_compute_dtype(torch.bfloat16)
+        got = blk(x)
+    finally:
+        fusion_ops.set_compute_dtype(prev)
+    assert (got.float() - want).norm() / want.norm() < 2e-2

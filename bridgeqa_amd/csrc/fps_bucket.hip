@@ -343,9 +343,13 @@ int launch_fps_bucket(const float *xyz, void *workspace, size_t workspace_bytes,
 #define BQ_LAUNCH_BUCKET(RPL, MDL)                                                                              \
   do {                                                                                                          \
     auto kern = fps_bucket_kernel<BUCKET_NW, RPL, MDL>;                                                         \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                    \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                   \
-    if (e != hipSuccess) { set_error("fps: cannot reserve %zu B of LDS: %s", dyn, hipGetErrorString(e)); return (int)e; } \
+    static bool lds_reserved = false; /* once per instantiation: keeps the launch path free of driver calls */  \
+    if (!lds_reserved) {                                                                                        \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                  \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET);          \
+      if (e != hipSuccess) { set_error("fps: cannot reserve LDS: %s", hipGetErrorString(e)); return (int)e; }   \
+      lds_reserved = true;                                                                                      \
+    }                                                                                                           \
     hipLaunchKernelGGL(kern, dim3(B), dim3(BUCKET_NW * 64), dyn, st, xyz, ws, idx, N, m, log2bs, nrows, stride); \
   } while (0)
   if (rpl == 1) { if (md_lds) BQ_LAUNCH_BUCKET(1, true); else BQ_LAUNCH_BUCKET(1, false); }

@@ -44,7 +44,9 @@ def parse():
     ap.add_argument("--points", type=int, default=40000)
     ap.add_argument("--image", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a HIP graph")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the whole train step from one HIP graph (auto: c2 only -- ending the capture of the "
+                         "c3 step segfaults inside hipStreamEndCapture on ROCm 7.0/7.2, so c3 runs eagerly)")
     ap.add_argument("--cpu-scenes", type=int, default=2, help="scenes in the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -189,7 +191,7 @@ def main():
     model = build_model(workload, args.cin, args.image).to(dev)
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=True)
-    use_graph = (not args.no_graph) and world == 1
+    use_graph = world == 1 and (args.graph == "on" or (args.graph == "auto" and workload == "c2"))
     opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-5, capturable=use_graph)
     batch = make_batch(args, workload, args.batch, 42 + rank, dev)
 

@@ -1,0 +1,71 @@
+"""Multi-process data parallelism of the hot path on CPU: world_size 2, gloo, 127.0.0.1.  Each rank runs the
+DET-stage hot path (bridgeqa_amd layers over the CPU oracle backend -- host-logic test) on its OWN batch;
+after backward the gradients must be the mean over ranks and a step must leave both replicas identical."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bridgeqa_amd import pointnet2_utils
+        from bridgeqa_amd.hotpath import ScanQAHotPath
+        from oracle import pn2_oracle
+        pointnet2_utils.set_backend(pn2_oracle)
+        import bench
+        torch.manual_seed(0)  # identical replicas
+        model = ScanQAHotPath(input_feature_dim=1, use_blip=False)
+        ddp = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=True)
+        opt = torch.optim.AdamW(ddp.parameters(), lr=1e-3)
+        pc = bench.synth_batch(2, 2500, 1, 42 + rank, "cpu")  # each rank its own scenes (DistributedSampler-like)
+        loss = bench.det_loss(ddp({"point_clouds": pc}))
+        loss.backward()
+        g = model.detection_backbone.sa1.mlp_module.layer0.conv.weight.grad.clone()
+        # reference: the same two batches on one replica, gradients averaged by hand
+        torch.manual_seed(0)
+        solo = ScanQAHotPath(input_feature_dim=1, use_blip=False)
+        gs = []
+        for r in range(world):
+            solo.zero_grad()
+            bench.det_loss(solo({"point_clouds": bench.synth_batch(2, 2500, 1, 42 + r, "cpu")})).backward()
+            gs.append(solo.detection_backbone.sa1.mlp_module.layer0.conv.weight.grad.clone())
+        want = sum(gs) / world
+        opt.step()
+        w = model.voting_net.conv3.weight.detach().clone()
+        ws = [torch.zeros_like(w) for _ in range(world)]
+        dist.all_gather(ws, w)
+        out.put((rank, float((g - want).abs().max()), float(want.abs().max()), float((ws[0] - ws[1]).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_ddp_world2_gloo_grads_are_rank_means_and_replicas_stay_equal(oracle):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, scale, drift in res:
+        assert err <= 1e-5 * max(scale, 1.0), (rank, err, scale)
+        assert drift == 0.0, (rank, drift)

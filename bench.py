@@ -45,8 +45,8 @@ def parse():
     ap.add_argument("--image", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
-                    help="replay the whole train step from one HIP graph (auto: c2 only -- ending the capture of the "
-                         "c3 step segfaults inside hipStreamEndCapture on ROCm 7.0/7.2, so c3 runs eagerly)")
+                    help="replay the whole train step (forward + backward + fused AdamW) from one HIP graph; "
+                         "auto = on for a single GPU")
     ap.add_argument("--cpu-scenes", type=int, default=2, help="scenes in the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -191,12 +191,19 @@ def main():
     model = build_model(workload, args.cin, args.image).to(dev)
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=True)
-    use_graph = world == 1 and (args.graph == "on" or (args.graph == "auto" and workload == "c2"))
-    opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-5, capturable=use_graph)
+    use_graph = world == 1 and args.graph in ("on", "auto")
+    # fused multi-tensor AdamW; NB the foreach implementation under capture makes hipStreamEndCapture segfault
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-5, fused=True, capturable=use_graph)
+    params = [p for p in model.parameters() if p.requires_grad]
     batch = make_batch(args, workload, args.batch, 42 + rank, dev)
 
     def eager_step():
-        opt.zero_grad(set_to_none=not use_graph)
+        if use_graph:
+            for p in params:  # static gradient buffers: zero in place
+                if p.grad is not None:
+                    p.grad.zero_()
+        else:
+            opt.zero_grad(set_to_none=True)
         loss = total_loss(model(dict(batch)))
         loss.backward()
         opt.step()

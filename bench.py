@@ -210,34 +210,33 @@ def main():
         return loss
 
     step = eager_step
-    for _ in range(max(args.warmup, 3 if use_graph else 0)):
-        eager_step()
     graphed = False
+    side = torch.cuda.Stream() if use_graph else None
     if use_graph:
-        # The step is launch-bound in places (thousands of short kernels): capture forward + backward +
-        # optimizer ONCE into a HIP graph on a side stream and replay it.  Inputs are static device buffers.
-        try:
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
+        # The step is launch-bound in places (thousands of short kernels): capture forward + backward + AdamW
+        # ONCE into a HIP graph and replay it.  Inputs are static device buffers.  Every eager step before the
+        # capture runs on the SAME side stream: autograd's AccumulateGrad nodes remember the stream they were
+        # created on, and nodes born on the default stream make hipStreamEndCapture segfault (ROCm 7.0/7.2).
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(args.warmup, 3)):
                 eager_step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            with torch.cuda.graph(g):
-                static_loss = eager_step()
-            torch.cuda.synchronize()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            static_loss = eager_step()
+        torch.cuda.synchronize()
 
-            def step():
-                g.replay()
-                return static_loss
-            graphed = True
-            for _ in range(2):
-                step()
-        except Exception as ex:  # fall back loudly, never silently
-            sys.stderr.write("bench: HIP-graph capture failed (%s: %s); running eagerly\n" % (type(ex).__name__, ex))
-            step = eager_step
+        def step():
+            g.replay()
+            return static_loss
+        graphed = True
+        for _ in range(2):
+            step()
+    else:
+        for _ in range(args.warmup):
+            eager_step()
     timer = OpTimer()
     timer.wrap(_ext, ["furthest_point_sampling", "ball_query", "group_concat", "group_concat_grad"])
     torch.cuda.synchronize()
@@ -253,8 +252,9 @@ def main():
     if graphed:
         # a replayed graph runs no Python, so the per-kernel HIP events are taken on an eager re-run of the same
         # step (same kernels, same stream) right after the timed region; it is not part of `value`
-        for _ in range(min(args.steps, 3)):
-            eager_step()
+        with torch.cuda.stream(side):
+            for _ in range(min(args.steps, 3)):
+                eager_step()
         torch.cuda.synchronize()
     timer.unwrap()
     if world > 1:

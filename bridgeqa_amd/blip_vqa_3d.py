@@ -218,6 +218,16 @@ class BLIP_VQA3D(nn.Module):
             answer = _tokens(answer, self.tokenizer, dev, padding="longest")
             answer.input_ids[:, 0] = self.tokenizer.bos_token_id
             targets = answer.input_ids.masked_fill(answer.input_ids == self.tokenizer.pad_token_id, -100)
+            if self.share_decoder and not self.use_scene_classifier:
+                # the 2D and 3D answer losses use the SAME decoder (blip_vqa_3d.py:119-122,323-343): one pass over
+                # the two streams stacked along the batch gives loss2d + loss3d with half the launches
+                two = lambda t: torch.cat((t, t), dim=0)
+                out = self.text_decoder(two(answer.input_ids), attention_mask=two(answer.attention_mask),
+                                        encoder_hidden_states=torch.cat((q2d.last_hidden_state,
+                                                                         q3d.last_hidden_state), dim=0),
+                                        encoder_attention_mask=two(q_mask), labels=two(targets), return_dict=True,
+                                        reduction="none")
+                return out.loss.sum() / B, self.fuse_2d3d(q2d, q3d), q_mask
             out = self.text_decoder(answer.input_ids, attention_mask=answer.attention_mask,
                                     encoder_hidden_states=q2d.last_hidden_state, encoder_attention_mask=q_mask,
                                     labels=targets, return_dict=True, reduction="none")

@@ -49,8 +49,83 @@ def _c(t):
     return t.to(_COMPUTE_DTYPE)
 
 
+_SHADOW = {}
+_MM_OUT_DTYPE = [None]  # does torch.mm accept out_dtype on this build? (probed on first use)
+
+
+def _shadow(t):
+    """bf16 copy of an fp32 parameter made OUTSIDE autograd, once per optimizer step (keyed by the in-place
+    version counter).  _LinearFn routes the gradient to the fp32 parameter itself, in fp32."""
+    if t.dtype == _COMPUTE_DTYPE:
+        return t.detach()
+    hit = _SHADOW.get(id(t))
+    if hit is not None and hit[0]() is t and hit[1] == t._version and hit[2].dtype == _COMPUTE_DTYPE:
+        return hit[2]
+    import weakref
+    with torch.no_grad():
+        c = t.detach().to(_COMPUTE_DTYPE)
+    _SHADOW[id(t)] = (weakref.ref(t), t._version, c)
+    return c
+
+
+def _mm_f32(a, b):
+    """a @ b for bf16 operands with an fp32 result (weight gradients are accumulated and applied in fp32)."""
+    if _MM_OUT_DTYPE[0] is None:
+        try:
+            torch.mm(a[:1], b[:, :1], out_dtype=torch.float32)
+            _MM_OUT_DTYPE[0] = True
+        except Exception:
+            _MM_OUT_DTYPE[0] = False
+    if _MM_OUT_DTYPE[0]:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    return torch.mm(a, b).float()
+
+
+class _LinearFn(torch.autograd.Function):
+    """bf16-operand linear with fp32 master weights: the forward reads the bf16 shadow of W / b, the backward
+    produces dW and db directly in fp32 (no per-parameter cast kernels in either direction)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gelu):
+        wb = _shadow(weight)
+        bb = _shadow(bias) if bias is not None else None
+        xb = x if x.dtype == _COMPUTE_DTYPE else x.to(_COMPUTE_DTYPE)
+        y = F.linear(xb, wb, bb)
+        ctx.gelu = gelu
+        ctx.has_bias = bias is not None
+        ctx.x_dtype = x.dtype
+        if gelu:
+            ctx.save_for_backward(xb, wb, y)
+            return F.gelu(y)
+        ctx.save_for_backward(xb, wb)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.gelu:
+            xb, wb, y = ctx.saved_tensors
+            g = torch.ops.aten.gelu_backward(g, y)
+        else:
+            xb, wb = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        x2 = xb.reshape(-1, xb.shape[-1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(g2, wb).view(xb.shape).to(ctx.x_dtype)
+        if ctx.needs_input_grad[1]:
+            dw = _mm_f32(g2.t(), x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = g2.sum(0, dtype=torch.float32)
+        return dx, dw, db, None
+
+
 def linear(x, weight, bias=None, act=None):
     """y = act(x @ weight^T + bias); weight (out,in) as nn.Linear stores it.  Output in the compute dtype."""
+    if act not in (None, "gelu"):
+        raise ValueError(act)
+    if (_COMPUTE_DTYPE != torch.float32 and x.is_cuda and isinstance(weight, torch.nn.Parameter)
+            and weight.dtype == torch.float32 and (bias is None or isinstance(bias, torch.nn.Parameter))):
+        return _LinearFn.apply(x, weight, bias, act == "gelu")
     y = F.linear(_c(x), _c(weight), _c(bias) if bias is not None else None)
     if act == "gelu":
         y = F.gelu(y)  # exact (erf) GELU: vit.py act_layer=nn.GELU, med_config hidden_act "gelu"

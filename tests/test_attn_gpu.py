@@ -79,3 +79,29 @@ def test_vit_block_bf16_fused_vs_fp32_composition(dev):
     finally:
         fusion_ops.set_compute_dtype(prev)
     assert (got.float() - want).norm() / want.norm() < 2e-2
+
+
+@pytest.mark.parametrize("act", [None, "gelu"])
+def test_bf16_linear_with_fp32_master_weights(dev, act):
+    """fusion_ops.linear in bf16 mode: output and fp32 gradients vs the fp32 composition (tolerance = bf16 operands)."""
+    from bridgeqa_amd import fusion_ops
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(96, 160).to(dev)
+    x = torch.randn(4, 33, 96, device=dev, requires_grad=True)
+    prev = fusion_ops.set_compute_dtype(torch.bfloat16)
+    try:
+        y = fusion_ops.linear(x, lin.weight, lin.bias, act=act)
+        assert y.dtype == torch.bfloat16
+        y.float().square().sum().backward()
+    finally:
+        fusion_ops.set_compute_dtype(prev)
+    gw, gb, gx = lin.weight.grad.clone(), lin.bias.grad.clone(), x.grad.clone()
+    assert gw.dtype == torch.float32 and gb.dtype == torch.float32
+    lin.zero_grad(); x.grad = None
+    yr = torch.nn.functional.linear(x, lin.weight, lin.bias)
+    if act == "gelu":
+        yr = torch.nn.functional.gelu(yr)
+    yr.square().sum().backward()
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    assert rel(y.float(), yr) < 1e-2 and rel(gw, lin.weight.grad) < 2e-2 and rel(gb, lin.bias.grad) < 2e-2
+    assert rel(gx, x.grad) < 2e-2

@@ -53,35 +53,13 @@ class Conv2d(nn.Sequential):
 
 class SharedMLP(nn.Sequential):
     """args=[C0,C1,...,Ck] -> k layers named layer0..layer{k-1} (pytorch_utils.py:11-36).
-
-    The layers are 1x1 convolutions on (B,C,M,S): each is evaluated as the batched GEMM
-    W[Cout,Cin] @ X[b][Cin, M*S] directly on the channel-major layout (no MIOpen convolution, hence no
-    NCHW<->NHWC transposes and no find-mode tuning runs on a fresh machine); BatchNorm + ReLU follow."""
+"""
 
     def __init__(self, args, *, bn=False, activation=nn.ReLU(inplace=True), preact=False, first=False, name=""):
         super().__init__()
         for i in range(len(args) - 1):
             self.add_module(name + "layer{}".format(i),
                             Conv2d(args[i], args[i + 1], bn=bn, activation=activation, preact=preact))
-
-    def forward(self, x):
-        shape = x.shape
-        x = x.flatten(2)  # (B, C, positions)
-        for layer in self:
-            conv = layer.conv
-            x = torch.matmul(conv.weight.flatten(1), x)
-            if conv.bias is not None:
-                x = x + conv.bias[None, :, None]
-            if hasattr(layer, "bn"):
-                bn = layer.bn.bn
-                if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-                    bn.num_batches_tracked.add_(1)
-                x = nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias,
-                                             bn.training or not bn.track_running_stats,
-                                             bn.momentum if bn.momentum is not None else 0.0, bn.eps)
-            if hasattr(layer, "activation"):
-                x = nn.functional.relu(x, inplace=True)
-        return x.view(shape[0], x.shape[1], *shape[2:])
 
 
 def set_bn_momentum_default(bn_momentum):

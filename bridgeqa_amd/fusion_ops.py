@@ -17,6 +17,61 @@ import torch.nn.functional as F
 
 _COMPUTE_DTYPE = torch.float32
 
+# ---- stream-level concurrency --------------------------------------------------------------------
+# Large parts of the step are chains of short, latency-bound kernels that use a fraction of the 256 CUs
+# (furthest point sampling runs on B workgroups; the text streams work on 320 tokens).  Independent chains are
+# therefore issued on separate HIP streams -- detector branch || image encoder, 2D text stream || 3D text stream --
+# and joined with events; under HIP-graph capture the forks become parallel branches of the graph.
+_OVERLAP = [True]
+_SIDE_STREAMS = {}
+
+
+def set_overlap(flag):
+    prev, _OVERLAP[0] = _OVERLAP[0], bool(flag)
+    return prev
+
+
+def overlap_enabled(t):
+    return _OVERLAP[0] and t.is_cuda
+
+
+def side_stream(name, device):
+    key = (name, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+class fork(object):
+    """with fork("name", tensor) as s: ... runs the body on a side stream that first waits for the current one.
+    Call .join(*tensors) afterwards: the current stream waits for the side stream and the tensors produced on it
+    are marked as used by the current stream (allocator safety)."""
+
+    def __init__(self, name, like):
+        self.main = torch.cuda.current_stream(like.device)
+        self.side = side_stream(name, like.device)
+        self.ctx = torch.cuda.stream(self.side)
+
+    def __enter__(self):
+        self.side.wait_stream(self.main)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        return self.ctx.__exit__(*a)
+
+    def uses(self, *tensors):
+        """tensors made on the main stream that the side stream reads"""
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.side)
+
+    def join(self, *tensors):
+        self.main.wait_stream(self.side)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.main)
+
 
 def set_compute_dtype(dtype):
     global _COMPUTE_DTYPE

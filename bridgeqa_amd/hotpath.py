@@ -46,14 +46,28 @@ class ScanQAHotPath(nn.Module):
     def forward(self, data_dict):
         """data_dict: point_clouds (B,N,3+C); with use_blip also images (B,V,3,H,W), question / answer
         (token dicts or strings).  Adds the detector outputs and, with BLIP, `blip_loss`, `fused_feat`."""
-        data_dict = self.detect(data_dict)
+        image_embeds = None
+        if self.use_blip and "images" in data_dict:
+            from . import fusion_ops as ops
+            image = data_dict["images"][:, 0]
+            if ops.overlap_enabled(image):
+                # image encoder || detector branch: FPS / ball query occupy B workgroups, the ViT wants the rest
+                with ops.fork("image", image) as f:
+                    f.uses(image)
+                    image_embeds = self.blip_model.visual_encoder(image)
+                data_dict = self.detect(data_dict)
+                f.join(image_embeds)
+            else:
+                data_dict = self.detect(data_dict)
+        else:
+            data_dict = self.detect(data_dict)
         object_feat = self.object_feat_linear(data_dict["aggregated_vote_features"])
         object_mask = ~data_dict["bbox_mask"].bool().detach()  # True = not an object
         data_dict["object_feat"] = object_feat
         if not self.use_blip:
             return data_dict
         train = data_dict.get("phase", "train") == "train"
-        out = self.blip_model(data_dict["images"][:, 0], data_dict["question"],
+        out = self.blip_model(data_dict["images"][:, 0], data_dict["question"], image_embeds=image_embeds,
                               scene_object_embeds=object_feat.clone(), scene_object_mask=~object_mask,
                               answer=data_dict["answer"], train=train, k_test=256, data_dict=data_dict)
         if train:

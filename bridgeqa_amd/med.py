@@ -334,12 +334,23 @@ class BertEncoderTwin(BertEncoder):
             twin = self.layer_twin[i] if i < self.num_hidden_layers_twin else None
             mix2d = torch.cat((enc2d, ops._c(hidden_states_twin)), dim=1)
             mix3d = torch.cat((enc3d, ops._c(hidden_states)), dim=1)
-            out2d = self.layer[i](hidden_states, attention_mask, None, mix2d, encoder_attention_mask, None, want,
-                                  mode=mode, layernorm_idx=layernorm_idx)
-            if twin is not None:
-                out3d = twin(hidden_states_twin, attention_mask, None, mix3d, encoder_attention_mask_twin, None,
-                             want, mode=mode, layernorm_idx=layernorm_idx)
+            if twin is not None and ops.overlap_enabled(hidden_states):
+                # the two streams of a layer only depend on each other's PREVIOUS state: run them side by side
+                with ops.fork("twin", hidden_states) as f:
+                    f.uses(hidden_states_twin, mix3d, attention_mask, encoder_attention_mask_twin)
+                    out3d = twin(hidden_states_twin, attention_mask, None, mix3d, encoder_attention_mask_twin, None,
+                                 want, mode=mode, layernorm_idx=layernorm_idx)
+                out2d = self.layer[i](hidden_states, attention_mask, None, mix2d, encoder_attention_mask, None, want,
+                                      mode=mode, layernorm_idx=layernorm_idx)
+                f.join(*[t for t in out3d if isinstance(t, torch.Tensor)])
                 hidden_states_twin = out3d[0]
+            else:
+                out2d = self.layer[i](hidden_states, attention_mask, None, mix2d, encoder_attention_mask, None, want,
+                                      mode=mode, layernorm_idx=layernorm_idx)
+                if twin is not None:
+                    out3d = twin(hidden_states_twin, attention_mask, None, mix3d, encoder_attention_mask_twin, None,
+                                 want, mode=mode, layernorm_idx=layernorm_idx)
+                    hidden_states_twin = out3d[0]
             hidden_states = out2d[0]
             if want:
                 self_att, cross_att = (out2d[1],), (out2d[-2],)

@@ -105,3 +105,41 @@ def test_bf16_linear_with_fp32_master_weights(dev, act):
     rel = lambda a, b: ((a - b).norm() / b.norm()).item()
     assert rel(y.float(), yr) < 1e-2 and rel(gw, lin.weight.grad) < 2e-2 and rel(gb, lin.bias.grad) < 2e-2
     assert rel(gx, x.grad) < 2e-2
+
+
+def test_stream_overlap_is_value_neutral(dev):
+    """Side-stream execution (image encoder || detector, 2D || 3D text stream) must not change any value:
+    the eval-mode hot path with overlap on equals the one with overlap off, repeatedly (race check)."""
+    import bench
+    from bridgeqa_amd import fusion_ops
+    from bridgeqa_amd.blip_vqa_3d import SyntheticTokenizer
+    from bridgeqa_amd.hotpath import ScanQAHotPath
+    from bridgeqa_amd.med import BertConfig
+    torch.manual_seed(0)
+    cfg = BertConfig(num_hidden_layers=3, vocab_size=200, max_position_embeddings=64)
+    model = ScanQAHotPath(input_feature_dim=3, blip_kwargs=dict(
+        med_config=cfg, image_size=64, tokenizer=SyntheticTokenizer(0, 102, 198, 199))).to(dev).eval()
+    g = torch.Generator().manual_seed(1)
+    B = 4
+    batch = {"point_clouds": bench.synth_batch(B, 5000, 3, 7, dev), "phase": "train",
+             "images": torch.randn(B, 1, 3, 64, 64, generator=g).to(dev),
+             "question": {"input_ids": torch.randint(5, 190, (B, 9), generator=g).to(dev),
+                          "attention_mask": torch.ones(B, 9, dtype=torch.long, device=dev)},
+             "answer": {"input_ids": torch.randint(5, 190, (B, 4), generator=g).to(dev),
+                        "attention_mask": torch.ones(B, 4, dtype=torch.long, device=dev)}}
+    prev_dt = fusion_ops.set_compute_dtype(torch.bfloat16)
+    try:
+        outs = []
+        for flag in (False, True, True, True, False):
+            prev = fusion_ops.set_overlap(flag)
+            with torch.no_grad():
+                dd = model(dict(batch))
+            torch.cuda.synchronize()
+            fusion_ops.set_overlap(prev)
+            outs.append((dd["blip_loss"].float().clone(), dd["fused_feat"].float().clone(),
+                         dd["2d_cross_attention"].float().clone()))
+        for o in outs[1:]:
+            for a, b in zip(outs[0], o):
+                assert torch.equal(a, b)
+    finally:
+        fusion_ops.set_compute_dtype(prev_dt)

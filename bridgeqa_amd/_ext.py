@@ -46,9 +46,10 @@ for _name, _args in _SIGS.items():
     getattr(_lib, _name).argtypes = _args
     getattr(_lib, _name).restype = ctypes.c_int
 _l = ctypes.c_long
-_lib.bq_attn_fwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i] + [_l] * 9 + [_f, _vp]
+_u = ctypes.c_uint
+_lib.bq_attn_fwd.argtypes = [_vp] * 6 + [_i] * 5 + [_l] * 9 + [_f, _f, _u, _vp, _vp]
 _lib.bq_attn_fwd.restype = ctypes.c_int
-_lib.bq_attn_bwd.argtypes = [_vp] * 12 + [_i, _i, _i, _i] + [_l] * 9 + [_f, _vp]
+_lib.bq_attn_bwd.argtypes = [_vp] * 13 + [_i] * 6 + [_l] * 9 + [_f, _f, _u, _vp, _vp]
 _lib.bq_attn_bwd.restype = ctypes.c_int
 _lib.bq_fps_workspace_bytes.argtypes = [_i, _i]
 _lib.bq_fps_workspace_bytes.restype = ctypes.c_size_t
@@ -257,37 +258,58 @@ def transpose_v(v, Lp):
     return vt
 
 
-def attn_bwd(q, k, v, out, lse, grad_out, scale, dq, dk, dv):
-    """Backward of attn_fwd.  q, k, v, grad_out: bf16 (B, L, H, 64) views (k and v with equal strides);
-    out / lse from the forward; dq, dk, dv: preallocated bf16 views (dq strided like q, dk/dv like k)."""
-    B, L, H, D = q.shape
-    Lp = (L + 63) // 64 * 64
+LOG2E = 1.4426950408889634
+
+
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+def key_mask_log2(mask, B, Lk):
+    """additive key mask broadcastable to (B,1,1,Lk) -> f32 (B, Lkp), multiplied by log2(e), zero in the padding"""
+    if mask is None:
+        return None
+    m = torch.zeros(B, _pad64(Lk), dtype=torch.float32, device=mask.device)
+    m[:, :Lk] = mask.reshape(-1, Lk).expand(B, Lk).float() * LOG2E
+    return m
+
+
+def attn_fwd(q, k, v, scale, mask_log2=None, p_drop=0.0, seed=0, seed_tensor=None):
+    """softmax(q k^T * scale + mask) v without materialising the scores.  q: bf16 (B, Lq, H, 64) view, k / v:
+    (B, Lk, H, 64) views; mask_log2 from key_mask_log2.  Returns out (B, Lq, H, 64) bf16 contiguous and
+    lse (B, H, Lq) f32 (log2 domain)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        if not t.is_cuda:
+            raise RuntimeError("%s: CPU not supported" % n)
+    B, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    Lkp = _pad64(Lk)
+    with torch.cuda.device(q.device):
+        vt = transpose_v(v, Lkp)
+        out = torch.empty(B, Lq, H, D, dtype=torch.bfloat16, device=q.device)
+        lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
+        qs, ks, os_ = _bhd_strides(q), _bhd_strides(k), _bhd_strides(out)
+        _check(_lib.bq_attn_fwd(_p(q), _p(k), _p(vt), _p(out), _p(lse), _p(mask_log2), B, H, Lq, Lk, Lkp, *qs, *ks,
+                                *os_, float(scale), float(p_drop), int(seed) & 0xFFFFFFFF, _p(seed_tensor),
+                                _stream()), "attn_fwd")
+    return out, lse
+
+
+def attn_bwd(q, k, v, out, lse, grad_out, scale, dq, dk, dv, mask_log2=None, p_drop=0.0, seed=0, seed_tensor=None):
+    """Backward of attn_fwd (same mask / dropout arguments).  dq, dk, dv: preallocated bf16 views (dq strided like
+    q, dk/dv like k; k and v with equal strides)."""
+    B, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    Lqp, Lkp = _pad64(Lq), _pad64(Lk)
     if k.stride() != v.stride() or dq.stride() != q.stride() or dk.stride() != k.stride() or dv.stride() != k.stride():
         raise RuntimeError("attn_bwd: stride contract violated")
     with torch.cuda.device(q.device):
         if grad_out.stride(3) != 1:
             grad_out = grad_out.contiguous()
-        delta = (grad_out.float() * out.float()).sum(-1).permute(0, 2, 1).contiguous()  # (B, H, L)
-        qt, kt, gt = transpose_v(q, Lp), transpose_v(k, Lp), transpose_v(grad_out, Lp)
+        delta = (grad_out.float() * out.float()).sum(-1).permute(0, 2, 1).contiguous()  # (B, H, Lq)
+        qt, kt, gt = transpose_v(q, Lqp), transpose_v(k, Lkp), transpose_v(grad_out, Lqp)
         qs, ks, gs = _bhd_strides(q), _bhd_strides(k), _bhd_strides(grad_out)
         _check(_lib.bq_attn_bwd(_p(q), _p(k), _p(v), _p(qt), _p(kt), _p(grad_out), _p(gt), _p(lse), _p(delta),
-                                _p(dq), _p(dk), _p(dv), B, H, L, Lp, *qs, *ks, *gs, float(scale), _stream()),
+                                _p(mask_log2), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, Lqp, Lkp, *qs, *ks, *gs,
+                                float(scale), float(p_drop), int(seed) & 0xFFFFFFFF, _p(seed_tensor), _stream()),
                "attn_bwd")
-
-
-def attn_fwd(q, k, v, scale):
-    """softmax(q k^T * scale) v without materialising the scores.  q, k, v: bf16 (B, L, H, 64) views.
-    Returns out (B, L, H, 64) bf16 contiguous and lse (B, H, L) f32 (log2 domain)."""
-    for t, n in ((q, "q"), (k, "k"), (v, "v")):
-        if not t.is_cuda:
-            raise RuntimeError("%s: CPU not supported" % n)
-    B, L, H, D = q.shape
-    Lp = (L + 63) // 64 * 64
-    with torch.cuda.device(q.device):
-        vt = transpose_v(v, Lp)
-        out = torch.empty(B, L, H, D, dtype=torch.bfloat16, device=q.device)
-        lse = torch.empty(B, H, L, dtype=torch.float32, device=q.device)
-        qs, ks, os_ = _bhd_strides(q), _bhd_strides(k), _bhd_strides(out)
-        _check(_lib.bq_attn_fwd(_p(q), _p(k), _p(vt), _p(out), _p(lse), B, H, L, Lp, *qs, *ks, *os_, float(scale),
-                                _stream()), "attn_fwd")
-    return out, lse

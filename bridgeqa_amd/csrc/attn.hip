@@ -46,11 +46,38 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 __device__ __forceinline__ int swz(int row, int ch) { return row * 128 + ((ch ^ (row & 7)) << 4); }
 
 struct AttnDims {
-  int B, H, L, Lp;                  // L = real length, Lp = padded length of the transposed operands
-  long q_bs, q_rs, q_hs;            // element strides: batch, row (token), head
-  long k_bs, k_rs, k_hs;
-  long o_bs, o_rs, o_hs;
+  int B, H, Lq, Lk, Lqp, Lkp;       // real lengths; padded lengths (multiples of 64) of the transposed operands / mask
+  long q_bs, q_rs, q_hs;            // element strides: batch, row (token), head   (Q, dQ)
+  long k_bs, k_rs, k_hs;            // K, V, dK, dV
+  long o_bs, o_rs, o_hs;            // O (forward) / dO (backward)
+  const float *mask;                // optional additive key mask [B][Lkp], ALREADY multiplied by log2(e); or null
+  float scale;                      // softmax scale (natural units)
+  float inv_keep;                   // 1/(1-p) of the attention-probability dropout, 1 when off
+  unsigned drop_thresh;             // p * 2^32 (0 = no dropout)
+  unsigned seed;                    // per-call offset ...
+  const unsigned *seed_ptr;         // ... combined with a per-step device counter (graph-replay safe), may be null
 };
+
+__device__ __forceinline__ unsigned eff_seed(const AttnDims &dm) {
+  return dm.seed_ptr ? dm.seed_ptr[0] * 2654435761u + dm.seed : dm.seed;
+}
+
+// keep-decision of the attention dropout: a stateless hash of (seed, batch*head, query, key), so forward and
+// backward regenerate the same mask and nothing is stored
+__device__ __forceinline__ bool drop_keep(unsigned seed, int bh, int q, int key, unsigned thresh) {
+  unsigned x = seed ^ ((unsigned)bh * 0x9E3779B1u) ^ ((unsigned)q * 0x85EBCA77u) ^ ((unsigned)key * 0xC2B2AE3Du);
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x >= thresh;
+}
+
+// 16 contiguous-in-groups-of-4 floats for the register rows of lane half h: v[rr] = src[32*blk + crow(rr, h)]
+__device__ __forceinline__ void load_rowvals(const float *src, int blk, int h, float *v) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 x = *reinterpret_cast<const float4 *>(src + 32 * blk + 8 * g + 4 * h);
+    v[4 * g + 0] = x.x; v[4 * g + 1] = x.y; v[4 * g + 2] = x.z; v[4 * g + 3] = x.w;
+  }
+}
 
 // Staging of one 64 x 64 bf16 tile (source rows of 64 contiguous elements) into a swizzled LDS image via
 // registers: 512 chunks of 16 B, two per thread.  Loads are issued one tile ahead of their LDS commit.
@@ -65,28 +92,31 @@ __device__ __forceinline__ void stage_store(unsigned char *lds, int c, uint4 v) 
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
                                                        const __bf16 *__restrict__ Vt, __bf16 *__restrict__ O,
-                                                       float *__restrict__ LSE, AttnDims dm, float scale_log2e) {
+                                                       float *__restrict__ LSE, AttnDims dm) {
   __shared__ __align__(16) unsigned char s_k[AT_KB * 128];
   __shared__ __align__(16) unsigned char s_v[AT_D * 128];
+  const float scale_log2e = dm.scale * 1.4426950408889634f;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
+  const unsigned seed = eff_seed(dm);
   const int q0 = blockIdx.x * AT_QB + wid * AT_QW;  // first query row of this wave
   const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
   const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
-  const __bf16 *Vb = Vt + (long)bh * AT_D * dm.Lp;
+  const __bf16 *Vb = Vt + (long)bh * AT_D * dm.Lkp;
+  const float *mrow = dm.mask ? dm.mask + (long)b * dm.Lkp : nullptr;
 
   // Q fragments (B operand of S^T = K.Q^T): lane (q = r, h) holds Q[q][16*step + 8h + j]
   bf16x8 qf[4];
   {
-    const int qr = min(q0 + r, dm.L - 1);
+    const int qr = min(q0 + r, dm.Lq - 1);
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8 *>(Qb + (long)qr * dm.q_rs + 16 * s + 8 * h);
   }
   f32x16 o0 = {0}, o1 = {0};
   float m = -INFINITY, lsum = 0.0f;
-  const int nkt = (dm.L + AT_KB - 1) / AT_KB;
-  uint4 ka = stage_load(Kb, dm.k_rs, 0, dm.L, t), kb = stage_load(Kb, dm.k_rs, 0, dm.L, t + 256);
-  uint4 va = stage_load(Vb, dm.Lp, 0, AT_D, t), vb = stage_load(Vb, dm.Lp, 0, AT_D, t + 256);  // rows = d
+  const int nkt = (dm.Lk + AT_KB - 1) / AT_KB;
+  uint4 ka = stage_load(Kb, dm.k_rs, 0, dm.Lk, t), kb = stage_load(Kb, dm.k_rs, 0, dm.Lk, t + 256);
+  uint4 va = stage_load(Vb, dm.Lkp, 0, AT_D, t), vb = stage_load(Vb, dm.Lkp, 0, AT_D, t + 256);  // rows = d
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();  // everyone finished reading the previous tile
     stage_store(s_k, t, ka); stage_store(s_k, t + 256, kb);
@@ -94,8 +124,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __bf16 *__restrict_
     __syncthreads();
     {
       const int nt = min(kt + 1, nkt - 1);  // the tile after the last is a harmless re-load of the last
-      ka = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.L, t); kb = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.L, t + 256);
-      va = stage_load(Vb + nt * AT_KB, dm.Lp, 0, AT_D, t); vb = stage_load(Vb + nt * AT_KB, dm.Lp, 0, AT_D, t + 256);
+      ka = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.Lk, t); kb = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.Lk, t + 256);
+      va = stage_load(Vb + nt * AT_KB, dm.Lkp, 0, AT_D, t); vb = stage_load(Vb + nt * AT_KB, dm.Lkp, 0, AT_D, t + 256);
     }
     const bool last = kt == nkt - 1;
 #pragma unroll
@@ -108,10 +138,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __bf16 *__restrict_
       }
       float sc[16];
       float mloc = -INFINITY;
+      const int kbase = kt * AT_KB + kb2 * 32;
+      if (mrow) {
+        float mk[16];
+        load_rowvals(mrow + kbase, 0, h, mk);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sc[i] = acc[i] * scale_log2e + mk[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sc[i] = acc[i] * scale_log2e;
+      }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        sc[i] = acc[i] * scale_log2e;
-        if (last && kt * AT_KB + kb2 * 32 + crow(i, h) >= dm.L) sc[i] = -INFINITY;
+        if (last && kbase + crow(i, h) >= dm.Lk) sc[i] = -INFINITY;
         mloc = fmaxf(mloc, sc[i]);
       }
       mloc = xhalf_max(mloc);
@@ -122,9 +161,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __bf16 *__restrict_
       bf16x8 pb0, pb1;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const float p = __builtin_amdgcn_exp2f(sc[i] - mnew);
-        const float p2 = __builtin_amdgcn_exp2f(sc[8 + i] - mnew);
-        psum += p + p2;
+        float p = __builtin_amdgcn_exp2f(sc[i] - mnew);
+        float p2 = __builtin_amdgcn_exp2f(sc[8 + i] - mnew);
+        psum += p + p2;  // the softmax denominator uses the un-dropped probabilities
+        if (dm.drop_thresh) {
+          p = drop_keep(seed, bh, q0 + r, kbase + crow(i, h), dm.drop_thresh) ? p * dm.inv_keep : 0.0f;
+          p2 = drop_keep(seed, bh, q0 + r, kbase + crow(8 + i, h), dm.drop_thresh) ? p2 * dm.inv_keep : 0.0f;
+        }
         pb0[i] = (__bf16)p;
         pb1[i] = (__bf16)p2;
       }
@@ -155,7 +198,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __bf16 *__restrict_
   const float l = xhalf_sum(lsum);
   const float inv = 1.0f / l;
   const int q = q0 + r;
-  if (q < dm.L) {
+  if (q < dm.Lq) {
     __bf16 *Orow = O + b * dm.o_bs + hd * dm.o_hs + (long)q * dm.o_rs;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -168,7 +211,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __bf16 *__restrict_
       *reinterpret_cast<bf16x4 *>(Orow + 8 * g + 4 * h) = w0;
       *reinterpret_cast<bf16x4 *>(Orow + 32 + 8 * g + 4 * h) = w1;
     }
-    if (h == 0) LSE[(long)bh * dm.L + q] = m + __builtin_amdgcn_logf(l);  // v_log_f32 = log2
+    if (h == 0) LSE[(long)bh * dm.Lq + q] = m + __builtin_amdgcn_logf(l);  // v_log_f32 = log2
   }
 }
 
@@ -185,15 +228,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __bf16 *__restrict_
 //                 of K and V), then dV^T[d][key] += dO^T[d][q] . P[q][key] and dK^T[d][key] += Q^T[d][q] . dS[q][key]
 //                 (A = LDS images of the pre-transposed dO and Q).
 // =====================================================================================================
-
-// 16 contiguous-in-groups-of-4 floats for the register rows of lane half h: v[rr] = src[32*blk + crow(rr, h)]
-__device__ __forceinline__ void load_rowvals(const float *src, int blk, int h, float *v) {
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float4 x = *reinterpret_cast<const float4 *>(src + 32 * blk + 8 * g + 4 * h);
-    v[4 * g + 0] = x.x; v[4 * g + 1] = x.y; v[4 * g + 2] = x.z; v[4 * g + 3] = x.w;
-  }
-}
 
 // A fragment (8 x bf16) of a TRANSPOSED image [row][k]: elements k = 16*s2 + 8*(j>>2) + 4*h + (j&3) of row `row`
 __device__ __forceinline__ bf16x8 tfrag(const unsigned char *img, int row, int kchunk, int h) {
@@ -217,44 +251,42 @@ __device__ __forceinline__ void store_T(__bf16 *Xrow, const f32x16 &a0, const f3
   }
 }
 
-struct BwdDims {
-  int B, H, L, Lp;
-  long q_bs, q_rs, q_hs;    // Q / dQ
-  long k_bs, k_rs, k_hs;    // K, V / dK, dV
-  long g_bs, g_rs, g_hs;    // dO
-};
+typedef AttnDims BwdDims;  // o_* strides describe dO
 
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
                                                           const __bf16 *__restrict__ V, const __bf16 *__restrict__ Kt,
                                                           const __bf16 *__restrict__ dO, const float *__restrict__ LSE,
                                                           const float *__restrict__ DELTA, __bf16 *__restrict__ dQ,
-                                                          BwdDims dm, float scale) {
+                                                          BwdDims dm) {
   __shared__ __align__(16) unsigned char s_k[AT_KB * 128];
   __shared__ __align__(16) unsigned char s_v[AT_KB * 128];
   __shared__ __align__(16) unsigned char s_kt[AT_D * 128];
+  const float scale = dm.scale;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
+  const unsigned seed = eff_seed(dm);
   const int q0 = blockIdx.x * AT_QB + wid * AT_QW;
   const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
-  const __bf16 *Gb = dO + b * dm.g_bs + hd * dm.g_hs;
+  const __bf16 *Gb = dO + b * dm.o_bs + hd * dm.o_hs;
   const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
   const __bf16 *Vb = V + b * dm.k_bs + hd * dm.k_hs;
-  const __bf16 *Ktb = Kt + (long)bh * AT_D * dm.Lp;
+  const __bf16 *Ktb = Kt + (long)bh * AT_D * dm.Lkp;
+  const float *mrow = dm.mask ? dm.mask + (long)b * dm.Lkp : nullptr;
   const float c = scale * 1.4426950408889634f;
 
   bf16x8 qf[4], gf[4];
-  const int qr = min(q0 + r, dm.L - 1);
+  const int qr = min(q0 + r, dm.Lq - 1);
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     qf[s] = *reinterpret_cast<const bf16x8 *>(Qb + (long)qr * dm.q_rs + 16 * s + 8 * h);
-    gf[s] = *reinterpret_cast<const bf16x8 *>(Gb + (long)qr * dm.g_rs + 16 * s + 8 * h);
+    gf[s] = *reinterpret_cast<const bf16x8 *>(Gb + (long)qr * dm.o_rs + 16 * s + 8 * h);
   }
-  const float lse = LSE[(long)bh * dm.L + qr], delta = DELTA[(long)bh * dm.L + qr];
+  const float lse = LSE[(long)bh * dm.Lq + qr], delta = DELTA[(long)bh * dm.Lq + qr];
   f32x16 a0 = {0}, a1 = {0};
-  const int nkt = (dm.L + AT_KB - 1) / AT_KB;
-  uint4 ka = stage_load(Kb, dm.k_rs, 0, dm.L, t), kb = stage_load(Kb, dm.k_rs, 0, dm.L, t + 256);
-  uint4 va = stage_load(Vb, dm.k_rs, 0, dm.L, t), vb = stage_load(Vb, dm.k_rs, 0, dm.L, t + 256);
-  uint4 ta = stage_load(Ktb, dm.Lp, 0, AT_D, t), tb = stage_load(Ktb, dm.Lp, 0, AT_D, t + 256);
+  const int nkt = (dm.Lk + AT_KB - 1) / AT_KB;
+  uint4 ka = stage_load(Kb, dm.k_rs, 0, dm.Lk, t), kb = stage_load(Kb, dm.k_rs, 0, dm.Lk, t + 256);
+  uint4 va = stage_load(Vb, dm.k_rs, 0, dm.Lk, t), vb = stage_load(Vb, dm.k_rs, 0, dm.Lk, t + 256);
+  uint4 ta = stage_load(Ktb, dm.Lkp, 0, AT_D, t), tb = stage_load(Ktb, dm.Lkp, 0, AT_D, t + 256);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
     stage_store(s_k, t, ka); stage_store(s_k, t + 256, kb);
@@ -263,9 +295,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const __bf16 *__restri
     __syncthreads();
     {
       const int nt = min(kt + 1, nkt - 1);
-      ka = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.L, t); kb = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.L, t + 256);
-      va = stage_load(Vb, dm.k_rs, nt * AT_KB, dm.L, t); vb = stage_load(Vb, dm.k_rs, nt * AT_KB, dm.L, t + 256);
-      ta = stage_load(Ktb + nt * AT_KB, dm.Lp, 0, AT_D, t); tb = stage_load(Ktb + nt * AT_KB, dm.Lp, 0, AT_D, t + 256);
+      ka = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.Lk, t); kb = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.Lk, t + 256);
+      va = stage_load(Vb, dm.k_rs, nt * AT_KB, dm.Lk, t); vb = stage_load(Vb, dm.k_rs, nt * AT_KB, dm.Lk, t + 256);
+      ta = stage_load(Ktb + nt * AT_KB, dm.Lkp, 0, AT_D, t); tb = stage_load(Ktb + nt * AT_KB, dm.Lkp, 0, AT_D, t + 256);
     }
     const bool last = kt == nkt - 1;
 #pragma unroll
@@ -279,15 +311,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const __bf16 *__restri
         pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, gf[s], pacc, 0, 0, 0);
       }
       bf16x8 d0, d1;
+      const int kbase = kt * AT_KB + kb2 * 32;
+      float mk[16];
+      if (mrow) load_rowvals(mrow + kbase, 0, h, mk);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        float p = __builtin_amdgcn_exp2f(sacc[i] * c - lse), p2 = __builtin_amdgcn_exp2f(sacc[8 + i] * c - lse);
+        float p = __builtin_amdgcn_exp2f(sacc[i] * c + (mrow ? mk[i] : 0.0f) - lse);
+        float p2 = __builtin_amdgcn_exp2f(sacc[8 + i] * c + (mrow ? mk[8 + i] : 0.0f) - lse);
         if (last) {
-          if (kt * AT_KB + kb2 * 32 + crow(i, h) >= dm.L) p = 0.0f;
-          if (kt * AT_KB + kb2 * 32 + crow(8 + i, h) >= dm.L) p2 = 0.0f;
+          if (kbase + crow(i, h) >= dm.Lk) p = 0.0f;
+          if (kbase + crow(8 + i, h) >= dm.Lk) p2 = 0.0f;
         }
-        d0[i] = (__bf16)(p * (pacc[i] - delta) * scale);
-        d1[i] = (__bf16)(p2 * (pacc[8 + i] - delta) * scale);
+        float g1 = pacc[i], g2 = pacc[8 + i];
+        if (dm.drop_thresh) {
+          g1 = drop_keep(seed, bh, q0 + r, kbase + crow(i, h), dm.drop_thresh) ? g1 * dm.inv_keep : 0.0f;
+          g2 = drop_keep(seed, bh, q0 + r, kbase + crow(8 + i, h), dm.drop_thresh) ? g2 * dm.inv_keep : 0.0f;
+        }
+        d0[i] = (__bf16)(p * (g1 - delta) * scale);
+        d1[i] = (__bf16)(p2 * (g2 - delta) * scale);
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -298,15 +339,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const __bf16 *__restri
       }
     }
   }
-  if (q0 + r < dm.L) store_T(dQ + b * dm.q_bs + hd * dm.q_hs + (long)(q0 + r) * dm.q_rs, a0, a1, h, 1.0f);
+  if (q0 + r < dm.Lq) store_T(dQ + b * dm.q_bs + hd * dm.q_hs + (long)(q0 + r) * dm.q_rs, a0, a1, h, 1.0f);
 }
 
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
                                                            const __bf16 *__restrict__ V, const __bf16 *__restrict__ Qt,
                                                            const __bf16 *__restrict__ dO, const __bf16 *__restrict__ dOt,
                                                            const float *__restrict__ LSE, const float *__restrict__ DELTA,
-                                                           __bf16 *__restrict__ dK, __bf16 *__restrict__ dV, BwdDims dm,
-                                                           float scale) {
+                                                           __bf16 *__restrict__ dK, __bf16 *__restrict__ dV, BwdDims dm) {
   __shared__ __align__(16) unsigned char s_q[AT_KB * 128];
   __shared__ __align__(16) unsigned char s_g[AT_KB * 128];
   __shared__ __align__(16) unsigned char s_qt[AT_D * 128];
@@ -315,31 +355,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const __bf16 *__restr
   __shared__ __align__(16) float s_del[AT_KB];
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
+  const unsigned seed = eff_seed(dm);
   const int k0 = blockIdx.x * AT_QB + wid * AT_QW;  // first key of this wave
   const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
-  const __bf16 *Gb = dO + b * dm.g_bs + hd * dm.g_hs;
+  const __bf16 *Gb = dO + b * dm.o_bs + hd * dm.o_hs;
   const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
   const __bf16 *Vb = V + b * dm.k_bs + hd * dm.k_hs;
-  const __bf16 *Qtb = Qt + (long)bh * AT_D * dm.Lp;
-  const __bf16 *Gtb = dOt + (long)bh * AT_D * dm.Lp;
-  const float *lseb = LSE + (long)bh * dm.L, *delb = DELTA + (long)bh * dm.L;
+  const __bf16 *Qtb = Qt + (long)bh * AT_D * dm.Lqp;
+  const __bf16 *Gtb = dOt + (long)bh * AT_D * dm.Lqp;
+  const float *lseb = LSE + (long)bh * dm.Lq, *delb = DELTA + (long)bh * dm.Lq;
+  const float scale = dm.scale;
   const float c = scale * 1.4426950408889634f;
 
   bf16x8 kf[4], vf[4];
-  const int kr = min(k0 + r, dm.L - 1);
+  const int kr = min(k0 + r, dm.Lk - 1);
+  const float mkey = dm.mask ? dm.mask[(long)b * dm.Lkp + kr] : 0.0f;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     kf[s] = *reinterpret_cast<const bf16x8 *>(Kb + (long)kr * dm.k_rs + 16 * s + 8 * h);
     vf[s] = *reinterpret_cast<const bf16x8 *>(Vb + (long)kr * dm.k_rs + 16 * s + 8 * h);
   }
   f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
-  const int nqt = (dm.L + AT_KB - 1) / AT_KB;
-  uint4 qa = stage_load(Qb, dm.q_rs, 0, dm.L, t), qb = stage_load(Qb, dm.q_rs, 0, dm.L, t + 256);
-  uint4 ga = stage_load(Gb, dm.g_rs, 0, dm.L, t), gb = stage_load(Gb, dm.g_rs, 0, dm.L, t + 256);
-  uint4 qta = stage_load(Qtb, dm.Lp, 0, AT_D, t), qtb = stage_load(Qtb, dm.Lp, 0, AT_D, t + 256);
-  uint4 gta = stage_load(Gtb, dm.Lp, 0, AT_D, t), gtb = stage_load(Gtb, dm.Lp, 0, AT_D, t + 256);
+  const int nqt = (dm.Lq + AT_KB - 1) / AT_KB;
+  uint4 qa = stage_load(Qb, dm.q_rs, 0, dm.Lq, t), qb = stage_load(Qb, dm.q_rs, 0, dm.Lq, t + 256);
+  uint4 ga = stage_load(Gb, dm.o_rs, 0, dm.Lq, t), gb = stage_load(Gb, dm.o_rs, 0, dm.Lq, t + 256);
+  uint4 qta = stage_load(Qtb, dm.Lqp, 0, AT_D, t), qtb = stage_load(Qtb, dm.Lqp, 0, AT_D, t + 256);
+  uint4 gta = stage_load(Gtb, dm.Lqp, 0, AT_D, t), gtb = stage_load(Gtb, dm.Lqp, 0, AT_D, t + 256);
   float rl = 0.f, rd = 0.f;
-  if (t < AT_KB) { rl = lseb[min(t, dm.L - 1)]; rd = delb[min(t, dm.L - 1)]; }
+  if (t < AT_KB) { rl = lseb[min(t, dm.Lq - 1)]; rd = delb[min(t, dm.Lq - 1)]; }
   for (int qt = 0; qt < nqt; ++qt) {
     __syncthreads();
     stage_store(s_q, t, qa); stage_store(s_q, t + 256, qb);
@@ -350,11 +393,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const __bf16 *__restr
     __syncthreads();
     {
       const int nt = min(qt + 1, nqt - 1);
-      qa = stage_load(Qb, dm.q_rs, nt * AT_KB, dm.L, t); qb = stage_load(Qb, dm.q_rs, nt * AT_KB, dm.L, t + 256);
-      ga = stage_load(Gb, dm.g_rs, nt * AT_KB, dm.L, t); gb = stage_load(Gb, dm.g_rs, nt * AT_KB, dm.L, t + 256);
-      qta = stage_load(Qtb + nt * AT_KB, dm.Lp, 0, AT_D, t); qtb = stage_load(Qtb + nt * AT_KB, dm.Lp, 0, AT_D, t + 256);
-      gta = stage_load(Gtb + nt * AT_KB, dm.Lp, 0, AT_D, t); gtb = stage_load(Gtb + nt * AT_KB, dm.Lp, 0, AT_D, t + 256);
-      if (t < AT_KB) { rl = lseb[min(nt * AT_KB + t, dm.L - 1)]; rd = delb[min(nt * AT_KB + t, dm.L - 1)]; }
+      qa = stage_load(Qb, dm.q_rs, nt * AT_KB, dm.Lq, t); qb = stage_load(Qb, dm.q_rs, nt * AT_KB, dm.Lq, t + 256);
+      ga = stage_load(Gb, dm.o_rs, nt * AT_KB, dm.Lq, t); gb = stage_load(Gb, dm.o_rs, nt * AT_KB, dm.Lq, t + 256);
+      qta = stage_load(Qtb + nt * AT_KB, dm.Lqp, 0, AT_D, t); qtb = stage_load(Qtb + nt * AT_KB, dm.Lqp, 0, AT_D, t + 256);
+      gta = stage_load(Gtb + nt * AT_KB, dm.Lqp, 0, AT_D, t); gtb = stage_load(Gtb + nt * AT_KB, dm.Lqp, 0, AT_D, t + 256);
+      if (t < AT_KB) { rl = lseb[min(nt * AT_KB + t, dm.Lq - 1)]; rd = delb[min(nt * AT_KB + t, dm.Lq - 1)]; }
     }
     const bool last = qt == nqt - 1;
 #pragma unroll
@@ -371,17 +414,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const __bf16 *__restr
       load_rowvals(s_lse, qb2, h, lv);
       load_rowvals(s_del, qb2, h, dl);
       bf16x8 p0, p1, d0, d1;
+      const int qbase = qt * AT_KB + qb2 * 32;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        float p = __builtin_amdgcn_exp2f(sacc[i] * c - lv[i]), p2 = __builtin_amdgcn_exp2f(sacc[8 + i] * c - lv[8 + i]);
+        float p = __builtin_amdgcn_exp2f(sacc[i] * c + mkey - lv[i]);
+        float p2 = __builtin_amdgcn_exp2f(sacc[8 + i] * c + mkey - lv[8 + i]);
         if (last) {  // query rows past the end were staged as copies of the last row: drop them
-          if (qt * AT_KB + qb2 * 32 + crow(i, h) >= dm.L) p = 0.0f;
-          if (qt * AT_KB + qb2 * 32 + crow(8 + i, h) >= dm.L) p2 = 0.0f;
+          if (qbase + crow(i, h) >= dm.Lq) p = 0.0f;
+          if (qbase + crow(8 + i, h) >= dm.Lq) p2 = 0.0f;
         }
-        p0[i] = (__bf16)p;
-        p1[i] = (__bf16)p2;
-        d0[i] = (__bf16)(p * (pacc[i] - dl[i]) * scale);
-        d1[i] = (__bf16)(p2 * (pacc[8 + i] - dl[8 + i]) * scale);
+        float g1 = pacc[i], g2 = pacc[8 + i], pd = p, pd2 = p2;
+        if (dm.drop_thresh) {
+          const bool k1 = drop_keep(seed, bh, qbase + crow(i, h), k0 + r, dm.drop_thresh);
+          const bool k2 = drop_keep(seed, bh, qbase + crow(8 + i, h), k0 + r, dm.drop_thresh);
+          g1 = k1 ? g1 * dm.inv_keep : 0.0f; pd = k1 ? p * dm.inv_keep : 0.0f;
+          g2 = k2 ? g2 * dm.inv_keep : 0.0f; pd2 = k2 ? p2 * dm.inv_keep : 0.0f;
+        }
+        p0[i] = (__bf16)pd;
+        p1[i] = (__bf16)pd2;
+        d0[i] = (__bf16)(p * (g1 - dl[i]) * scale);
+        d1[i] = (__bf16)(p2 * (g2 - dl[8 + i]) * scale);
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -394,7 +446,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const __bf16 *__restr
       }
     }
   }
-  if (k0 + r < dm.L) {
+  if (k0 + r < dm.Lk) {
     const long off = b * dm.k_bs + hd * dm.k_hs + (long)(k0 + r) * dm.k_rs;
     store_T(dK + off, dk0, dk1, h, 1.0f);
     store_T(dV + off, dv0, dv1, h, 1.0f);
@@ -405,45 +457,54 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const __bf16 *__restr
 
 using namespace bq;
 
-// Q, K: bf16 with element strides (batch, token, head), 64 contiguous elements per (token, head);
-// Vt: bf16 [B*H][64][Lp] (V transposed, key-contiguous, zero padded to Lp, Lp % 64 == 0);
-// O: bf16 strided like Q; LSE: f32 [B*H][L], log2-domain log-sum-exp of the scaled scores.
+// Q: bf16 (B, Lq, H, 64) / K, V: (B, Lk, H, 64) given by element strides (batch, token, head), 64 contiguous
+// elements per (token, head).  Vt: bf16 [B*H][64][Lkp] (V transposed, key-contiguous, zero padded, Lkp % 64 == 0).
+// O: bf16 strided like Q's shape; LSE: f32 [B*H][Lq], log2-domain log-sum-exp of the scaled (+masked) scores.
+// mask: optional f32 [B][Lkp] additive key mask ALREADY multiplied by log2(e) (0 in the padding); p_drop / seed:
+// dropout on the attention probabilities (stateless hash, regenerated by the backward); the effective seed is
+// seed_ptr[0] * 2654435761 + seed when seed_ptr (a device counter the caller bumps once per step) is given.
 extern "C" __attribute__((visibility("default"))) int bq_attn_fwd(
-    const void *Q, const void *K, const void *Vt, void *O, float *LSE, int B, int H, int L, int Lp, long q_bs,
-    long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long o_bs, long o_rs, long o_hs, float scale, void *stream) {
-  BQ_REQUIRE(B > 0 && H > 0 && L > 0 && Lp >= L && Lp % 64 == 0, BQ_EINVAL, "attn_fwd: bad extents");
+    const void *Q, const void *K, const void *Vt, void *O, float *LSE, const float *mask, int B, int H, int Lq, int Lk,
+    int Lkp, long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long o_bs, long o_rs, long o_hs,
+    float scale, float p_drop, unsigned seed, const unsigned *seed_ptr, void *stream) {
+  BQ_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && Lkp >= Lk && Lkp % 64 == 0, BQ_EINVAL, "attn_fwd: bad extents");
   BQ_REQUIRE(Q && K && Vt && O && LSE, BQ_EINVAL, "attn_fwd: null pointer");
   BQ_REQUIRE((q_rs % 8) == 0 && (k_rs % 8) == 0 && (o_rs % 4) == 0 && (q_hs % 8) == 0 && (k_hs % 8) == 0, BQ_EINVAL,
              "attn_fwd: rows must be 16-byte aligned");
-  AttnDims dm{B, H, L, Lp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, o_bs, o_rs, o_hs};
-  const dim3 grid((L + AT_QB - 1) / AT_QB, B * H);
+  BQ_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, BQ_EINVAL, "attn_fwd: bad dropout probability");
+  AttnDims dm{B, H, Lq, Lk, 0, Lkp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, o_bs, o_rs, o_hs, mask, scale,
+              1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr};
+  const dim3 grid((Lq + AT_QB - 1) / AT_QB, B * H);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Q, (const __bf16 *)K,
-                     (const __bf16 *)Vt, (__bf16 *)O, LSE, dm, scale * 1.4426950408889634f);
+                     (const __bf16 *)Vt, (__bf16 *)O, LSE, dm);
   return check_launch("attn_fwd");
 }
 
-// Backward of bq_attn_fwd.  Q, K, V, dO, dQ, dK, dV: bf16 strided (batch, token, head) with 64 contiguous
-// elements; dQ shares Q's strides, dK/dV share K's (V must be strided like K).  Kt, Qt, dOt: bf16
-// [B*H][64][Lp] zero-padded transposes.  LSE (from the forward) and DELTA = rowsum(dO*O): f32 [B*H][L].
+// Backward of bq_attn_fwd.  dQ shares Q's strides, dK/dV share K's (V must be strided like K), dO has its own.
+// Kt: [B*H][64][Lkp]; Qt, dOt: [B*H][64][Lqp] zero-padded transposes.  LSE from the forward, DELTA = rowsum(dO*O):
+// f32 [B*H][Lq].  mask / p_drop / seed exactly as given to the forward.
 extern "C" __attribute__((visibility("default"))) int bq_attn_bwd(
     const void *Q, const void *K, const void *V, const void *Qt, const void *Kt, const void *dO, const void *dOt,
-    const float *LSE, const float *DELTA, void *dQ, void *dK, void *dV, int B, int H, int L, int Lp, long q_bs,
-    long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long g_bs, long g_rs, long g_hs, float scale,
-    void *stream) {
-  BQ_REQUIRE(B > 0 && H > 0 && L > 0 && Lp >= L && Lp % 64 == 0, BQ_EINVAL, "attn_bwd: bad extents");
+    const float *LSE, const float *DELTA, const float *mask, void *dQ, void *dK, void *dV, int B, int H, int Lq, int Lk,
+    int Lqp, int Lkp, long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long g_bs, long g_rs, long g_hs,
+    float scale, float p_drop, unsigned seed, const unsigned *seed_ptr, void *stream) {
+  BQ_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && Lkp >= Lk && Lkp % 64 == 0 && Lqp >= Lq && Lqp % 64 == 0, BQ_EINVAL,
+             "attn_bwd: bad extents");
   BQ_REQUIRE(Q && K && V && Qt && Kt && dO && dOt && LSE && DELTA && dQ && dK && dV, BQ_EINVAL,
              "attn_bwd: null pointer");
   BQ_REQUIRE((q_rs % 8) == 0 && (k_rs % 8) == 0 && (g_rs % 8) == 0 && (q_hs % 8) == 0 && (k_hs % 8) == 0 &&
                  (g_hs % 8) == 0, BQ_EINVAL, "attn_bwd: rows must be 16-byte aligned");
-  BwdDims dm{B, H, L, Lp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, g_bs, g_rs, g_hs};
-  const dim3 grid((L + AT_QB - 1) / AT_QB, B * H);
+  BQ_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, BQ_EINVAL, "attn_bwd: bad dropout probability");
+  BwdDims dm{B, H, Lq, Lk, Lqp, Lkp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, g_bs, g_rs, g_hs, mask, scale,
+             1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr};
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, (const __bf16 *)Q, (const __bf16 *)K,
-                     (const __bf16 *)V, (const __bf16 *)Kt, (const __bf16 *)dO, LSE, DELTA, (__bf16 *)dQ, dm, scale);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Lq + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, st, (const __bf16 *)Q,
+                     (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)Kt, (const __bf16 *)dO, LSE, DELTA,
+                     (__bf16 *)dQ, dm);
   int rc = check_launch("attn_bwd_dq");
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, (const __bf16 *)Q, (const __bf16 *)K,
-                     (const __bf16 *)V, (const __bf16 *)Qt, (const __bf16 *)dO, (const __bf16 *)dOt, LSE, DELTA,
-                     (__bf16 *)dK, (__bf16 *)dV, dm, scale);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Lk + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, st, (const __bf16 *)Q,
+                     (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)Qt, (const __bf16 *)dO, (const __bf16 *)dOt,
+                     LSE, DELTA, (__bf16 *)dK, (__bf16 *)dV, dm);
   return check_launch("attn_bwd_dkv");
 }

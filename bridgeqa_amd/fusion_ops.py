@@ -204,6 +204,10 @@ def attention(q, k, v, mask, scale, return_probs=False, dropout_p=0.0):
     (B,1,Lq,Lk).  Returns ctx (B,Lq,H,D) [compute dtype] and probs (B,H,Lq,Lk) fp32 or None.
     Order of operations follows med.py:179-217 (scores/sqrt(d) then + mask) and vit.py:75-83.
     """
+    if _COMPUTE_DTYPE == torch.bfloat16 and _kernel_attention_ok(_c(q), _c(k), mask, return_probs):
+        from . import _ext
+        ml2 = _ext.key_mask_log2(mask, q.shape[0], k.shape[1]) if mask is not None else None
+        return _MaskedAttention.apply(_c(q), _c(k), _c(v), ml2, scale, float(dropout_p)), None
     qh, kh, vh = _c(q).permute(0, 2, 1, 3), _c(k).permute(0, 2, 1, 3), _c(v).permute(0, 2, 1, 3)
     scores = torch.matmul(qh, kh.transpose(-1, -2)).float() * scale
     if mask is not None:
@@ -237,6 +241,63 @@ class _PackedAttention(torch.autograd.Function):
         _ext.attn_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out, lse, grad_out, ctx.scale,
                       dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2])
         return dqkv, None
+
+
+_STEP_SEED = {}
+_CALL_SEED = [0]
+
+
+def step_seed(device):
+    """Device-resident step counter feeding the attention-dropout hash: bump it once per training step with
+    new_step(); the increment is an ordinary kernel, so a replayed HIP graph draws fresh masks every replay."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _STEP_SEED:
+        _STEP_SEED[key] = torch.full((1,), torch.initial_seed() & 0x7FFFFFFF, dtype=torch.int32, device=device)
+    return _STEP_SEED[key]
+
+
+def new_step(device):
+    step_seed(device).add_(1)
+    _CALL_SEED[0] = 0
+
+
+class _MaskedAttention(torch.autograd.Function):
+    """softmax(q k^T * scale + key_mask) v with dropout on the probabilities, through csrc/attn.hip;
+    q (B,Lq,H,64), k/v (B,Lk,H,64) bf16 (any strides with a contiguous head dim)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask_log2, scale, p_drop):
+        from . import _ext
+        _CALL_SEED[0] += 1
+        seed, st = _CALL_SEED[0] * 7919, (step_seed(q.device) if p_drop > 0 else None)
+        out, lse = _ext.attn_fwd(q, k, v, scale, mask_log2, p_drop, seed, st)
+        ctx.save_for_backward(q, k, v, out, lse, mask_log2 if mask_log2 is not None else q.new_empty(0), 
+                              st if st is not None else q.new_empty(0))
+        ctx.cfg = (scale, p_drop, seed, mask_log2 is not None, st is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import _ext
+        q, k, v, out, lse, mask_log2, st = ctx.saved_tensors
+        scale, p_drop, seed, has_mask, has_st = ctx.cfg
+        dq = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+        dkv = torch.empty((2,) + tuple(k.shape), dtype=k.dtype, device=k.device)
+        kc, vc = (k, v) if k.stride() == v.stride() else (k.contiguous(), v.contiguous())
+        if kc.stride() != dkv[0].stride():
+            kc, vc = kc.contiguous(), vc.contiguous()
+        qc = q if q.stride() == dq.stride() else q.contiguous()
+        _ext.attn_bwd(qc, kc, vc, out, lse, grad_out, scale, dq, dkv[0], dkv[1], mask_log2 if has_mask else None,
+                      p_drop, seed, st if has_st else None)
+        return dq, dkv[0], dkv[1], None, None, None
+
+
+def _kernel_attention_ok(q, k, mask, return_probs):
+    if return_probs or not q.is_cuda or q.dtype != torch.bfloat16 or q.shape[-1] != 64:
+        return False
+    if q.stride(-1) != 1 or k.stride(-1) != 1:
+        return False
+    return mask is None or (mask.dim() == 4 and mask.shape[1] == 1 and mask.shape[2] == 1)
 
 
 def attention_packed(qkv, scale, dropout_p=0.0):

@@ -49,6 +49,8 @@ class ScanQAHotPath(nn.Module):
         image_embeds = None
         if self.use_blip and "images" in data_dict:
             from . import fusion_ops as ops
+            if data_dict["images"].is_cuda and self.training:
+                ops.new_step(data_dict["images"].device)  # fresh attention-dropout masks for this step
             image = data_dict["images"][:, 0]
             if ops.overlap_enabled(image):
                 # image encoder || detector branch: FPS / ball query occupy B workgroups, the ViT wants the rest

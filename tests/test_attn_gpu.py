@@ -143,3 +143,69 @@ def test_stream_overlap_is_value_neutral(dev):
                 assert torch.equal(a, b)
     finally:
         fusion_ops.set_compute_dtype(prev_dt)
+
+
+def _keep_mask(seed, B, H, Lq, Lk, p, dev):
+    """The kernel's stateless dropout hash (csrc/attn.hip drop_keep), restated with 64-bit integer tensors."""
+    M = 0xFFFFFFFF
+    bh = torch.arange(B * H, device=dev, dtype=torch.int64).view(B, H, 1, 1)
+    q = torch.arange(Lq, device=dev, dtype=torch.int64).view(1, 1, Lq, 1)
+    k = torch.arange(Lk, device=dev, dtype=torch.int64).view(1, 1, 1, Lk)
+    x = (seed & M) ^ ((bh * 0x9E3779B1) & M) ^ ((q * 0x85EBCA77) & M) ^ ((k * 0xC2B2AE3D) & M)
+    x = x ^ (x >> 16); x = (x * 0x7feb352d) & M; x = x ^ (x >> 15); x = (x * 0x846ca68b) & M; x = x ^ (x >> 16)
+    return x >= int(p * 4294967296.0)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,p", [(2, 3, 20, 1045, 0.0), (2, 12, 20, 276, 0.1), (3, 2, 5, 20, 0.1),
+                                         (1, 2, 20, 20, 0.25), (2, 2, 150, 70, 0.1)])
+def test_masked_cross_attention_with_dropout_fwd_bwd(dev, B, H, Lq, Lk, p):
+    """Lq != Lk, additive key mask (-10000 / -1e9 conventions of med.py) and hash dropout: forward and all three
+    gradients vs the fp32 composition that uses the SAME keep mask."""
+    from bridgeqa_amd import _ext
+    g = torch.Generator().manual_seed(Lq * 7 + Lk)
+    q = torch.randn(B, Lq, H, 64, generator=g).to(dev).to(torch.bfloat16)
+    k = torch.randn(B, Lk, H, 64, generator=g).to(dev).to(torch.bfloat16)
+    v = torch.randn(B, Lk, H, 64, generator=g).to(dev).to(torch.bfloat16)
+    go = torch.randn(B, Lq, H, 64, generator=g).to(dev).to(torch.bfloat16)
+    valid = torch.ones(B, Lk, device=dev)
+    valid[0, Lk // 2:] = 0
+    valid[-1, -3:] = 0
+    mask = ((1.0 - valid) * (-10000.0 if Lk == 20 else -1e9)).view(B, 1, 1, Lk)
+    seed = 12345
+    ml2 = _ext.key_mask_log2(mask, B, Lk)
+    out, lse = _ext.attn_fwd(q, k, v, 0.125, ml2, p, seed, None)
+    dq = torch.empty_like(q); dk = torch.empty_like(k); dv = torch.empty_like(v)
+    _ext.attn_bwd(q, k, v, out, lse, go, 0.125, dq, dk, dv, ml2, p, seed, None)
+    qf, kf, vf = (t.float().permute(0, 2, 1, 3).detach().requires_grad_(True) for t in (q, k, v))
+    s = torch.matmul(qf, kf.transpose(-1, -2)) * 0.125 + mask
+    pr = torch.softmax(s, dim=-1)
+    if p > 0:
+        pr = pr * _keep_mask(seed, B, H, Lq, Lk, p, dev) / (1.0 - p)
+    want = torch.matmul(pr, vf)
+    want.backward(go.float().permute(0, 2, 1, 3))
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    assert rel(out.float().permute(0, 2, 1, 3), want) < 2e-2
+    assert rel(dq.float().permute(0, 2, 1, 3), qf.grad) < 3e-2
+    assert rel(dk.float().permute(0, 2, 1, 3), kf.grad) < 3e-2
+    assert rel(dv.float().permute(0, 2, 1, 3), vf.grad) < 3e-2
+    if p > 0:  # the kept fraction is what it should be
+        frac = _keep_mask(seed, B, H, Lq, Lk, p, dev).float().mean().item()
+        assert abs(frac - (1 - p)) < 0.02
+
+
+def test_text_attention_routes_to_kernel_and_matches_composition(dev):
+    """fusion_ops.attention in bf16 mode with a key mask == the fp32 composition (eval: no dropout)."""
+    from bridgeqa_amd import fusion_ops
+    g = torch.Generator().manual_seed(3)
+    B, H, Lq, Lk = 2, 12, 20, 1045
+    q = torch.randn(B, Lq, H, 64, generator=g).to(dev); k = torch.randn(B, Lk, H, 64, generator=g).to(dev)
+    v = torch.randn(B, Lk, H, 64, generator=g).to(dev)
+    m = torch.zeros(B, 1, 1, Lk, device=dev); m[1, ..., 1000:] = -1e9
+    want, _ = fusion_ops.attention(q, k, v, m, 0.125)
+    prev = fusion_ops.set_compute_dtype(torch.bfloat16)
+    try:
+        got, probs = fusion_ops.attention(q, k, v, m, 0.125)
+    finally:
+        fusion_ops.set_compute_dtype(prev)
+    assert probs is None and got.dtype == torch.bfloat16
+    assert ((got.float() - want).norm() / want.norm()).item() < 2e-2

@@ -49,8 +49,14 @@ _l = ctypes.c_long
 _u = ctypes.c_uint
 _lib.bq_attn_fwd.argtypes = [_vp] * 6 + [_i] * 5 + [_l] * 9 + [_f, _f, _u, _vp, _vp]
 _lib.bq_attn_fwd.restype = ctypes.c_int
-_lib.bq_attn_bwd.argtypes = [_vp] * 13 + [_i] * 6 + [_l] * 9 + [_f, _f, _u, _vp, _vp]
+_lib.bq_attn_bwd.argtypes = [_vp] * 14 + [_i] * 6 + [_l] * 9 + [_f, _f, _u, _vp, _vp]
 _lib.bq_attn_bwd.restype = ctypes.c_int
+_lib.bq_transpose_pad.argtypes = [_vp, _vp, _i, _i, _i, _i, _l, _l, _l, _vp]
+_lib.bq_transpose_pad.restype = ctypes.c_int
+_lib.bq_drop_add_ln_fwd.argtypes = [_vp] * 7 + [_i, _i, _f, _f, _u, _vp, _vp]
+_lib.bq_drop_add_ln_fwd.restype = ctypes.c_int
+_lib.bq_drop_add_ln_bwd.argtypes = [_vp] * 10 + [_i, _i, _f, _f, _u, _vp, _vp]
+_lib.bq_drop_add_ln_bwd.restype = ctypes.c_int
 _lib.bq_fps_workspace_bytes.argtypes = [_i, _i]
 _lib.bq_fps_workspace_bytes.restype = ctypes.c_size_t
 
@@ -251,10 +257,11 @@ def _bhd_strides(t):
 
 
 def transpose_v(v, Lp):
-    """(B, L, H, 64) -> zero padded (B, H, 64, Lp), key-contiguous: the V^T operand of attn_fwd."""
+    """(B, L, H, 64) -> zero padded (B, H, 64, Lp), token-contiguous: the transposed operands of the attention
+    kernels, in one launch."""
     B, L, H, D = v.shape
-    vt = torch.zeros(B, H, D, Lp, dtype=v.dtype, device=v.device)
-    vt[..., :L] = v.permute(0, 2, 3, 1)
+    vt = torch.empty(B, H, D, Lp, dtype=v.dtype, device=v.device)
+    _check(_lib.bq_transpose_pad(_p(v), _p(vt), B, H, L, Lp, *_bhd_strides(v), _stream()), "transpose_pad")
     return vt
 
 
@@ -306,10 +313,39 @@ def attn_bwd(q, k, v, out, lse, grad_out, scale, dq, dk, dv, mask_log2=None, p_d
     with torch.cuda.device(q.device):
         if grad_out.stride(3) != 1:
             grad_out = grad_out.contiguous()
-        delta = (grad_out.float() * out.float()).sum(-1).permute(0, 2, 1).contiguous()  # (B, H, Lq)
+        if not out.is_contiguous():
+            raise RuntimeError("attn_bwd: the forward output must be contiguous")
+        delta = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)  # filled by the dQ kernel
         qt, kt, gt = transpose_v(q, Lqp), transpose_v(k, Lkp), transpose_v(grad_out, Lqp)
         qs, ks, gs = _bhd_strides(q), _bhd_strides(k), _bhd_strides(grad_out)
-        _check(_lib.bq_attn_bwd(_p(q), _p(k), _p(v), _p(qt), _p(kt), _p(grad_out), _p(gt), _p(lse), _p(delta),
-                                _p(mask_log2), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, Lqp, Lkp, *qs, *ks, *gs,
+        _check(_lib.bq_attn_bwd(_p(q), _p(k), _p(v), _p(qt), _p(kt), _p(grad_out), _p(gt), _p(lse), _p(out),
+                                _p(delta), _p(mask_log2), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, Lqp, Lkp, *qs, *ks, *gs,
                                 float(scale), float(p_drop), int(seed) & 0xFFFFFFFF, _p(seed_tensor), _stream()),
                "attn_bwd")
+
+
+# ---- fused dropout + residual + LayerNorm (csrc/ln.hip) ---------------------------------------------
+def drop_add_ln_fwd(x, residual, gamma, beta, eps, p_drop, seed, seed_tensor):
+    """y = LayerNorm(dropout(x) + residual); x, residual bf16 (..., H) contiguous.  Returns y, mean, rstd."""
+    H = x.shape[-1]
+    M = x.numel() // H
+    with torch.cuda.device(x.device):
+        y = torch.empty_like(x)
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+        _check(_lib.bq_drop_add_ln_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, H,
+                                       float(eps), float(p_drop), int(seed) & 0xFFFFFFFF, _p(seed_tensor), _stream()),
+               "drop_add_ln_fwd")
+    return y, mean, rstd
+
+
+def drop_add_ln_bwd(x, residual, gamma, dy, mean, rstd, eps, p_drop, seed, seed_tensor):
+    H = x.shape[-1]
+    M = x.numel() // H
+    with torch.cuda.device(x.device):
+        dx, dres = torch.empty_like(x), torch.empty_like(x)
+        dgb = torch.zeros(2, H, dtype=torch.float32, device=x.device)
+        _check(_lib.bq_drop_add_ln_bwd(_p(x), _p(residual), _p(gamma), _p(dy), _p(mean), _p(rstd), _p(dx), _p(dres),
+                                       _p(dgb[0]), _p(dgb[1]), M, H, float(eps), float(p_drop),
+                                       int(seed) & 0xFFFFFFFF, _p(seed_tensor), _stream()), "drop_add_ln_bwd")
+    return dx, dres, dgb[0], dgb[1]

@@ -256,8 +256,8 @@ typedef AttnDims BwdDims;  // o_* strides describe dO
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
                                                           const __bf16 *__restrict__ V, const __bf16 *__restrict__ Kt,
                                                           const __bf16 *__restrict__ dO, const float *__restrict__ LSE,
-                                                          const float *__restrict__ DELTA, __bf16 *__restrict__ dQ,
-                                                          BwdDims dm) {
+                                                          const __bf16 *__restrict__ O, float *__restrict__ DELTA,
+                                                          __bf16 *__restrict__ dQ, BwdDims dm) {
   __shared__ __align__(16) unsigned char s_k[AT_KB * 128];
   __shared__ __align__(16) unsigned char s_v[AT_KB * 128];
   __shared__ __align__(16) unsigned char s_kt[AT_D * 128];
@@ -281,7 +281,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const __bf16 *__restri
     qf[s] = *reinterpret_cast<const bf16x8 *>(Qb + (long)qr * dm.q_rs + 16 * s + 8 * h);
     gf[s] = *reinterpret_cast<const bf16x8 *>(Gb + (long)qr * dm.o_rs + 16 * s + 8 * h);
   }
-  const float lse = LSE[(long)bh * dm.Lq + qr], delta = DELTA[(long)bh * dm.Lq + qr];
+  const float lse = LSE[(long)bh * dm.Lq + qr];
+  // delta[q] = rowsum(dO o O), computed here (O is the forward's contiguous (B, Lq, H, 64) output) and published
+  // for the dK/dV kernel that follows on the same stream
+  float delta = 0.0f;
+  {
+    const __bf16 *Orow = O + (((long)b * dm.Lq + qr) * dm.H + hd) * AT_D;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 ov = *reinterpret_cast<const bf16x8 *>(Orow + 16 * s + 8 * h);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) delta += (float)ov[j] * (float)gf[s][j];
+    }
+    delta = xhalf_sum(delta);
+    if (h == 0 && q0 + r < dm.Lq) DELTA[(long)bh * dm.Lq + q0 + r] = delta;
+  }
   f32x16 a0 = {0}, a1 = {0};
   const int nkt = (dm.Lk + AT_KB - 1) / AT_KB;
   uint4 ka = stage_load(Kb, dm.k_rs, 0, dm.Lk, t), kb = stage_load(Kb, dm.k_rs, 0, dm.Lk, t + 256);
@@ -481,16 +495,17 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_fwd(
 }
 
 // Backward of bq_attn_fwd.  dQ shares Q's strides, dK/dV share K's (V must be strided like K), dO has its own.
-// Kt: [B*H][64][Lkp]; Qt, dOt: [B*H][64][Lqp] zero-padded transposes.  LSE from the forward, DELTA = rowsum(dO*O):
-// f32 [B*H][Lq].  mask / p_drop / seed exactly as given to the forward.
+// Kt: [B*H][64][Lkp]; Qt, dOt: [B*H][64][Lqp] zero-padded transposes.  LSE and O (contiguous (B,Lq,H,64)) from the
+// forward; DELTA: f32 [B*H][Lq] scratch (rowsum(dO*O), produced by the dQ kernel, consumed by the dK/dV kernel).  mask / p_drop / seed exactly as given to the forward.
 extern "C" __attribute__((visibility("default"))) int bq_attn_bwd(
     const void *Q, const void *K, const void *V, const void *Qt, const void *Kt, const void *dO, const void *dOt,
-    const float *LSE, const float *DELTA, const float *mask, void *dQ, void *dK, void *dV, int B, int H, int Lq, int Lk,
+    const float *LSE, const void *O, float *DELTA, const float *mask, void *dQ, void *dK, void *dV, int B, int H, int Lq,
+    int Lk,
     int Lqp, int Lkp, long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long g_bs, long g_rs, long g_hs,
     float scale, float p_drop, unsigned seed, const unsigned *seed_ptr, void *stream) {
   BQ_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && Lkp >= Lk && Lkp % 64 == 0 && Lqp >= Lq && Lqp % 64 == 0, BQ_EINVAL,
              "attn_bwd: bad extents");
-  BQ_REQUIRE(Q && K && V && Qt && Kt && dO && dOt && LSE && DELTA && dQ && dK && dV, BQ_EINVAL,
+  BQ_REQUIRE(Q && K && V && Qt && Kt && dO && dOt && LSE && O && DELTA && dQ && dK && dV, BQ_EINVAL,
              "attn_bwd: null pointer");
   BQ_REQUIRE((q_rs % 8) == 0 && (k_rs % 8) == 0 && (g_rs % 8) == 0 && (q_hs % 8) == 0 && (k_hs % 8) == 0 &&
                  (g_hs % 8) == 0, BQ_EINVAL, "attn_bwd: rows must be 16-byte aligned");
@@ -499,8 +514,8 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_bwd(
              1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr};
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Lq + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, st, (const __bf16 *)Q,
-                     (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)Kt, (const __bf16 *)dO, LSE, DELTA,
-                     (__bf16 *)dQ, dm);
+                     (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)Kt, (const __bf16 *)dO, LSE,
+                     (const __bf16 *)O, DELTA, (__bf16 *)dQ, dm);
   int rc = check_launch("attn_bwd_dq");
   if (rc) return rc;
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Lk + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, st, (const __bf16 *)Q,

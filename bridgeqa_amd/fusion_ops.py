@@ -205,9 +205,8 @@ def attention(q, k, v, mask, scale, return_probs=False, dropout_p=0.0):
     Order of operations follows med.py:179-217 (scores/sqrt(d) then + mask) and vit.py:75-83.
     """
     if _COMPUTE_DTYPE == torch.bfloat16 and _kernel_attention_ok(_c(q), _c(k), mask, return_probs):
-        from . import _ext
-        ml2 = _ext.key_mask_log2(mask, q.shape[0], k.shape[1]) if mask is not None else None
-        return _MaskedAttention.apply(_c(q), _c(k), _c(v), ml2, scale, float(dropout_p)), None
+        return _MaskedAttention.apply(_c(q), _c(k), _c(v), _mask_log2(mask, q.shape[0], k.shape[1]), scale,
+                                      float(dropout_p)), None
     qh, kh, vh = _c(q).permute(0, 2, 1, 3), _c(k).permute(0, 2, 1, 3), _c(v).permute(0, 2, 1, 3)
     scores = torch.matmul(qh, kh.transpose(-1, -2)).float() * scale
     if mask is not None:
@@ -290,6 +289,59 @@ class _MaskedAttention(torch.autograd.Function):
         _ext.attn_bwd(qc, kc, vc, out, lse, grad_out, scale, dq, dkv[0], dkv[1], mask_log2 if has_mask else None,
                       p_drop, seed, st if has_st else None)
         return dq, dkv[0], dkv[1], None, None, None
+
+
+class _DropAddLN(torch.autograd.Function):
+    """LayerNorm(dropout(x) + residual) in one kernel each way (csrc/ln.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, eps, p_drop):
+        from . import _ext
+        _CALL_SEED[0] += 1
+        seed, st = _CALL_SEED[0] * 104729, (step_seed(x.device) if p_drop > 0 else None)
+        y, mean, rstd = _ext.drop_add_ln_fwd(x, residual, weight, bias, eps, p_drop, seed, st)
+        ctx.save_for_backward(x, residual, weight, mean, rstd, st if st is not None else x.new_empty(0))
+        ctx.cfg = (eps, p_drop, seed, st is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _ext
+        x, residual, weight, mean, rstd, st = ctx.saved_tensors
+        eps, p_drop, seed, has_st = ctx.cfg
+        dx, dres, dg, db = _ext.drop_add_ln_bwd(x, residual, weight, dy.contiguous(), mean, rstd, eps, p_drop, seed,
+                                                st if has_st else None)
+        return dx, dres, dg, db, None, None
+
+
+def dropout_add_layer_norm(x, residual, ln, p_drop, training):
+    """LayerNorm(dropout(x) + residual): BertSelfOutput / BertOutput tail (med.py:236-239, 313-317)."""
+    p = float(p_drop) if training else 0.0
+    if (_COMPUTE_DTYPE == torch.bfloat16 and x.is_cuda and x.dtype == torch.bfloat16 and residual.dtype == torch.bfloat16
+            and x.shape[-1] % 256 == 0 and x.shape[-1] <= 1024 and x.is_contiguous() and residual.is_contiguous()
+            and ln.weight.dtype == torch.float32):
+        return _DropAddLN.apply(x, residual, ln.weight, ln.bias, ln.eps, p)
+    h = F.dropout(x, p, training=True) if p > 0 else x
+    return layer_norm(h, ln, residual=residual)
+
+
+_MASK_CACHE = {}
+
+
+def _mask_log2(mask, B, Lk):
+    """kernel-format key mask, converted once per mask tensor (the same extended mask serves all 12 layers)"""
+    if mask is None:
+        return None
+    import weakref
+    hit = _MASK_CACHE.get(id(mask))
+    if hit is not None and hit[0]() is mask and hit[1] == mask._version:
+        return hit[2]
+    from . import _ext
+    if len(_MASK_CACHE) > 64:
+        _MASK_CACHE.clear()
+    m = _ext.key_mask_log2(mask, B, Lk)
+    _MASK_CACHE[id(mask)] = (weakref.ref(mask), mask._version, m)
+    return m
 
 
 def _kernel_attention_ok(q, k, mask, return_probs):

@@ -165,8 +165,8 @@ class BertSelfOutput(nn.Module):
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
 
     def forward(self, hidden_states, input_tensor):
-        h = self.dropout(ops.linear(hidden_states, self.dense.weight, self.dense.bias))
-        return ops.layer_norm(h, self.LayerNorm, residual=input_tensor)
+        h = ops.linear(hidden_states, self.dense.weight, self.dense.bias)
+        return ops.dropout_add_layer_norm(h, input_tensor, self.LayerNorm, self.dropout.p, self.training)
 
 
 class BertAttention(nn.Module):
@@ -204,8 +204,8 @@ class BertOutput(nn.Module):
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
 
     def forward(self, hidden_states, input_tensor):
-        h = self.dropout(ops.linear(hidden_states, self.dense.weight, self.dense.bias))
-        return ops.layer_norm(h, self.LayerNorm, residual=input_tensor)
+        h = ops.linear(hidden_states, self.dense.weight, self.dense.bias)
+        return ops.dropout_add_layer_norm(h, input_tensor, self.LayerNorm, self.dropout.p, self.training)
 
 
 class BertOutputParallel(BertOutput):
@@ -218,9 +218,9 @@ class BertOutputParallel(BertOutput):
                                          for _ in range(1)])
 
     def forward(self, hidden_states, input_tensor, layernorm_idx=0):
-        h = self.dropout(ops.linear(hidden_states, self.dense.weight, self.dense.bias))
+        h = ops.linear(hidden_states, self.dense.weight, self.dense.bias)
         ln = self.LayerNorm if layernorm_idx == 0 else self.LayerNorms[layernorm_idx - 1]
-        return ops.layer_norm(h, ln, residual=input_tensor)
+        return ops.dropout_add_layer_norm(h, input_tensor, ln, self.dropout.p, self.training)
 
 
 class BertLayer(nn.Module):

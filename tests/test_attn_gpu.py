@@ -209,3 +209,32 @@ def test_text_attention_routes_to_kernel_and_matches_composition(dev):
         fusion_ops.set_compute_dtype(prev)
     assert probs is None and got.dtype == torch.bfloat16
     assert ((got.float() - want).norm() / want.norm()).item() < 2e-2
+
+
+@pytest.mark.parametrize("M,H,p", [(320, 768, 0.0), (320, 768, 0.1), (37, 256, 0.1), (5000, 768, 0.1), (3, 1024, 0.5)])
+def test_fused_dropout_add_layernorm_fwd_bwd(dev, M, H, p):
+    """csrc/ln.hip vs the reference composition LayerNorm(dropout(x) + residual) with the SAME keep mask."""
+    from bridgeqa_amd import _ext
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, H, generator=g).to(dev).to(torch.bfloat16)
+    res = torch.randn(M, H, generator=g).to(dev).to(torch.bfloat16)
+    gamma = (torch.rand(H, generator=g) + 0.5).to(dev); beta = (torch.randn(H, generator=g) * 0.1).to(dev)
+    dy = torch.randn(M, H, generator=g).to(dev).to(torch.bfloat16)
+    seed = 777
+    y, mean, rstd = _ext.drop_add_ln_fwd(x, res, gamma, beta, 1e-12, p, seed, None)
+    dx, dres, dg, db = _ext.drop_add_ln_bwd(x, res, gamma, dy, mean, rstd, 1e-12, p, seed, None)
+    # reference with the same hash
+    Mk = 0xFFFFFFFF
+    r = torch.arange(M, device=dev, dtype=torch.int64).view(M, 1); c = torch.arange(H, device=dev, dtype=torch.int64).view(1, H)
+    h = (seed & Mk) ^ ((r * 0x85EBCA77) & Mk) ^ ((c * 0xC2B2AE3D) & Mk)
+    h = h ^ (h >> 16); h = (h * 0x7feb352d) & Mk; h = h ^ (h >> 15); h = (h * 0x846ca68b) & Mk; h = h ^ (h >> 16)
+    keep = (h >= int(p * 4294967296.0)).float()
+    xf, rf = x.float().requires_grad_(True), res.float().requires_grad_(True)
+    gf, bf = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z = xf * keep / (1.0 - p) + rf
+    want = torch.nn.functional.layer_norm(z, (H,), gf, bf, 1e-12)
+    want.backward(dy.float())
+    rel = lambda a, b: ((a.float() - b).norm() / b.norm()).item()
+    assert rel(y, want) < 1e-2
+    assert rel(dx, xf.grad) < 2e-2 and rel(dres, rf.grad) < 2e-2
+    assert rel(dg, gf.grad) < 2e-2 and rel(db, bf.grad) < 2e-2

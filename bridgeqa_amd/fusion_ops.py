@@ -344,6 +344,16 @@ def _mask_log2(mask, B, Lk):
     return m
 
 
+def prime_masks(*masks):
+    """Convert key masks to kernel format NOW, on the current stream.  Called before any fork so that side
+    streams (which wait for the current stream when they fork) never see a half-written cached mask."""
+    if _COMPUTE_DTYPE != torch.bfloat16:
+        return
+    for m in masks:
+        if m is not None and m.is_cuda and m.dim() == 4 and m.shape[1] == 1 and m.shape[2] == 1:
+            _mask_log2(m, m.shape[0], m.shape[3])
+
+
 def _kernel_attention_ok(q, k, mask, return_probs):
     if return_probs or not q.is_cuda or q.dtype != torch.bfloat16 or q.shape[-1] != 64:
         return False

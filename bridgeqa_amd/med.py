@@ -325,6 +325,7 @@ class BertEncoderTwin(BertEncoder):
         all_cross_attentions = () if output_attentions and self.config.add_cross_attention else None
         layers = [i for i in range(self.config.num_hidden_layers) if forward_layers is None or i in forward_layers]
         hidden_states_twin = hidden_states.clone()
+        ops.prime_masks(attention_mask, encoder_attention_mask, encoder_attention_mask_twin)
         enc2d = ops._c(encoder_hidden_states)
         enc3d = ops._c(encoder_hidden_states_twin)
         for i in layers:

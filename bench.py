@@ -94,6 +94,9 @@ def total_loss(dd):
     loss = det_loss(dd)
     if "blip_loss" in dd:
         loss = loss + dd["blip_loss"]  # LM answer loss of both streams (blip_vqa_3d.py:305-343)
+        # the fused 2D/3D states feed the reference's downstream heads (qa_module.py:735-754): keep their
+        # backward (lowrank projections + bilinear fuse) in the timed step
+        loss = loss + dd["fused_feat"].float().square().mean() * 1e-3
     return loss
 
 
@@ -198,12 +201,9 @@ def main():
     batch = make_batch(args, workload, args.batch, 42 + rank, dev)
 
     def eager_step():
-        if use_graph:
-            for p in params:  # static gradient buffers: zero in place
-                if p.grad is not None:
-                    p.grad.zero_()
-        else:
-            opt.zero_grad(set_to_none=True)
+        # grads start as None: autograd then hands each gradient tensor over without a zero-fill + add per
+        # parameter (under capture the buffers come from the graph's private pool at fixed addresses)
+        opt.zero_grad(set_to_none=True)
         loss = total_loss(model(dict(batch)))
         loss.backward()
         opt.step()

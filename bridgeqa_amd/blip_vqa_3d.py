@@ -291,7 +291,15 @@ class BLIP_VQA3D(nn.Module):
         """Low-rank bilinear + mean (blip_vqa_3d.py:502-507)."""
         h2d = question_output.last_hidden_state.float()
         h3d = question_output_scene.last_hidden_state.float()
-        return self.bilinear_fusion(self.lowrank_2d(h2d), self.lowrank_3d(h3d)) + (h2d + h3d) / 2.0
+        a, b = self.lowrank_2d(h2d), self.lowrank_3d(h3d)  # (B, L, r)
+        # nn.Bilinear as two dense contractions: out[.,o] = sum_ij a_i W[o,i,j] b_j + bias_o.  (torch's bilinear
+        # runs one small GEMM pair PER OUTPUT FEATURE on the GPU -- 768 x 3 launches per call.)
+        W = self.bilinear_fusion.weight  # (out, r, r)
+        t = torch.matmul(a, W.permute(1, 0, 2).reshape(W.shape[1], -1))          # (B, L, out * r)
+        out = (t.view(*a.shape[:-1], W.shape[0], W.shape[2]) * b.unsqueeze(-2)).sum(-1)
+        if self.bilinear_fusion.bias is not None:
+            out = out + self.bilinear_fusion.bias
+        return out + (h2d + h3d) / 2.0
 
     def rank_answer(self, question_states, question_atts, answer_ids, answer_atts, k, use_scene=False):
         """Top-k answers by first-token probability, then exact sequence log-likelihood (:509-566)."""

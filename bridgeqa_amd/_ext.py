@@ -41,6 +41,8 @@ _SIGS = {
     "bq_three_interpolate_grad": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "bq_group_concat": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "bq_group_concat_grad": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "bq_group_concat_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "bq_group_concat_grad_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
 }
 for _name, _args in _SIGS.items():
     getattr(_lib, _name).argtypes = _args
@@ -220,7 +222,7 @@ def three_interpolate_grad(grad_out, idx, weight, m):
 
 
 # ---- fused forms (include/bqhip.h) ---------------------------------------------------------------
-def group_concat(xyz, new_xyz, features, idx, radius, normalize):
+def group_concat(xyz, new_xyz, features, idx, radius, normalize, out_dtype=torch.float32):
     _req(xyz, torch.float32, "xyz"); _req(new_xyz, torch.float32, "new_xyz"); _req(idx, torch.int32, "idx")
     if features is not None:
         _req(features, torch.float32, "features")
@@ -228,14 +230,16 @@ def group_concat(xyz, new_xyz, features, idx, radius, normalize):
     _, M, S = idx.shape
     C = features.shape[1] if features is not None else 0
     with torch.cuda.device(xyz.device):
-        out = torch.empty(B, C + 3, M, S, dtype=torch.float32, device=xyz.device)
-        _check(_lib.bq_group_concat(_p(xyz), _p(new_xyz), _p(features), _p(idx), _p(out), B, C, N, M, S,
-                                    float(radius), int(bool(normalize)), _stream()), "group_concat")
+        out = torch.empty(B, C + 3, M, S, dtype=out_dtype, device=xyz.device)
+        fn = _lib.bq_group_concat_bf16 if out_dtype == torch.bfloat16 else _lib.bq_group_concat
+        _check(fn(_p(xyz), _p(new_xyz), _p(features), _p(idx), _p(out), B, C, N, M, S,
+                  float(radius), int(bool(normalize)), _stream()), "group_concat")
     return out
 
 
 def group_concat_grad(grad_out, idx, n, radius, normalize, need_features, need_xyz, need_new_xyz):
-    _req(grad_out, torch.float32, "grad_out"); _req(idx, torch.int32, "idx")
+    _req(grad_out, grad_out.dtype if grad_out.dtype == torch.bfloat16 else torch.float32, "grad_out")
+    _req(idx, torch.int32, "idx")
     B, CT, M, S = grad_out.shape
     C = CT - 3
     dev = grad_out.device
@@ -243,8 +247,9 @@ def group_concat_grad(grad_out, idx, n, radius, normalize, need_features, need_x
         gf = torch.zeros(B, C, n, dtype=torch.float32, device=dev) if (need_features and C > 0) else None
         gx = torch.zeros(B, n, 3, dtype=torch.float32, device=dev) if need_xyz else None
         gn = torch.zeros(B, M, 3, dtype=torch.float32, device=dev) if need_new_xyz else None
-        _check(_lib.bq_group_concat_grad(_p(grad_out), _p(idx), _p(gf), _p(gx), _p(gn), B, C, int(n), M, S,
-                                         float(radius), int(bool(normalize)), _stream()), "group_concat_grad")
+        fn = _lib.bq_group_concat_grad_bf16 if grad_out.dtype == torch.bfloat16 else _lib.bq_group_concat_grad
+        _check(fn(_p(grad_out), _p(idx), _p(gf), _p(gx), _p(gn), B, C, int(n), M, S,
+                  float(radius), int(bool(normalize)), _stream()), "group_concat_grad")
     return gf, gx, gn
 
 

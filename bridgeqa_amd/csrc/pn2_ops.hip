@@ -147,14 +147,28 @@ __global__ __launch_bounds__(256) void group_points_grad_kernel(const float *__r
   }
 }
 
+typedef __bf16 bq_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ void store4(__bf16 *p, float4 v) {
+  bq_bf16x4 w;
+  w[0] = (__bf16)v.x; w[1] = (__bf16)v.y; w[2] = (__bf16)v.z; w[3] = (__bf16)v.w;
+  *reinterpret_cast<bq_bf16x4 *>(p) = w;
+}
+__device__ __forceinline__ float4 load4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 load4(const __bf16 *p) {
+  const bq_bf16x4 w = *reinterpret_cast<const bq_bf16x4 *>(p);
+  return make_float4((float)w[0], (float)w[1], (float)w[2], (float)w[3]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // fused QueryAndGroup tail (pointnet2_utils.py:348-359): rows 0..2 = (xyz[idx]-centre)/radius,
 // rows 3.. = features[idx]; written once, straight into the SharedMLP's input layout.
 // ---------------------------------------------------------------------------------------------
+template <typename OT>  // OT = float (reference precision) or __bf16 (input of the bf16 SharedMLP GEMMs)
 __global__ __launch_bounds__(256) void group_concat_kernel(const float *__restrict__ xyz,
                                                            const float *__restrict__ new_xyz,
                                                            const float *__restrict__ features,
-                                                           const int32_t *__restrict__ idx, float *__restrict__ out,
+                                                           const int32_t *__restrict__ idx, OT *__restrict__ out,
                                                            int C, int N, int M, int S, float radius, int normalize) {
   const int b = blockIdx.z;
   const int MS = M * S;
@@ -172,18 +186,19 @@ __global__ __launch_bounds__(256) void group_concat_kernel(const float *__restri
       float4 v;
       v.x = P[id.x * 3 + c] - qc; v.y = P[id.y * 3 + c] - qc; v.z = P[id.z * 3 + c] - qc; v.w = P[id.w * 3 + c] - qc;
       if (normalize) { v.x /= radius; v.y /= radius; v.z /= radius; v.w /= radius; }
-      *reinterpret_cast<float4 *>(out + ((size_t)b * CT + c) * MS + e) = v;
+      store4(out + ((size_t)b * CT + c) * MS + e, v);
     }
   }
   for (int c = blockIdx.y; c < C; c += gridDim.y) {
     const float *p = features + ((size_t)b * C + c) * N;
     float4 v;
     v.x = p[id.x]; v.y = p[id.y]; v.z = p[id.z]; v.w = p[id.w];
-    *reinterpret_cast<float4 *>(out + ((size_t)b * CT + c + 3) * MS + e) = v;
+    store4(out + ((size_t)b * CT + c + 3) * MS + e, v);
   }
 }
 
-__global__ __launch_bounds__(256) void group_concat_grad_kernel(const float *__restrict__ grad_out,
+template <typename OT>
+__global__ __launch_bounds__(256) void group_concat_grad_kernel(const OT *__restrict__ grad_out,
                                                                 const int32_t *__restrict__ idx,
                                                                 float *__restrict__ grad_features,
                                                                 float *__restrict__ grad_xyz,
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(256) void group_concat_grad_kernel(const float *__r
     const int j = e / S;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      float4 v = *reinterpret_cast<const float4 *>(grad_out + ((size_t)b * CT + c) * MS + e);
+      float4 v = load4(grad_out + ((size_t)b * CT + c) * MS + e);
       if (normalize) { v.x /= radius; v.y /= radius; v.z /= radius; v.w /= radius; }
       const float g[4] = {v.x, v.y, v.z, v.w};
       if (grad_xyz) {
@@ -213,7 +228,7 @@ __global__ __launch_bounds__(256) void group_concat_grad_kernel(const float *__r
   if (!grad_features) return;
   for (int c = blockIdx.y; c < C; c += gridDim.y) {
     float *g = grad_features + ((size_t)b * C + c) * N;
-    const float4 v = *reinterpret_cast<const float4 *>(grad_out + ((size_t)b * CT + c + 3) * MS + e);
+    const float4 v = load4(grad_out + ((size_t)b * CT + c + 3) * MS + e);
     float acc = v.x;
     if (id[1] == id[0]) acc += v.y; else { atomicAdd(g + id[0], acc); acc = v.y; }
     if (id[2] == id[1]) acc += v.z; else { atomicAdd(g + id[1], acc); acc = v.z; }
@@ -402,9 +417,9 @@ extern "C" int bq_group_points_grad(const float *grad_out, const int32_t *idx, f
   return check_launch("group_points_grad");
 }
 
-extern "C" int bq_group_concat(const float *xyz, const float *new_xyz, const float *features, const int32_t *idx,
-                               float *out, int B, int C, int N, int M, int S, float radius, int normalize,
-                               void *stream) {
+static int group_concat_impl(const float *xyz, const float *new_xyz, const float *features, const int32_t *idx,
+                             void *out, int out_bf16, int B, int C, int N, int M, int S, float radius, int normalize,
+                             void *stream) {
   BQ_REQUIRE(B >= 0 && C >= 0 && N >= 0 && M >= 0 && S >= 0, BQ_EINVAL, "group_concat: bad extents");
   if (B == 0 || M == 0 || S == 0) return BQ_OK;
   BQ_REQUIRE(xyz && new_xyz && idx && out && (features || C == 0), BQ_EINVAL, "group_concat: null pointer");
@@ -412,14 +427,31 @@ extern "C" int bq_group_concat(const float *xyz, const float *new_xyz, const flo
   BQ_REQUIRE(B <= 65535 && (long)M * S < (1L << 31), BQ_ELIMIT, "group_concat: extent too large");
   const int xb = cdiv(M * S / 4, 256);
   const int yb = C ? cgrid(C, xb, B) : 1;
-  hipLaunchKernelGGL(group_concat_kernel, dim3(xb, yb, B), dim3(256), 0, (hipStream_t)stream, xyz, new_xyz, features,
-                     idx, out, C, N, M, S, radius, normalize);
+  if (out_bf16)
+    hipLaunchKernelGGL(group_concat_kernel<__bf16>, dim3(xb, yb, B), dim3(256), 0, (hipStream_t)stream, xyz, new_xyz,
+                       features, idx, (__bf16 *)out, C, N, M, S, radius, normalize);
+  else
+    hipLaunchKernelGGL(group_concat_kernel<float>, dim3(xb, yb, B), dim3(256), 0, (hipStream_t)stream, xyz, new_xyz,
+                       features, idx, (float *)out, C, N, M, S, radius, normalize);
   return check_launch("group_concat");
 }
 
-extern "C" int bq_group_concat_grad(const float *grad_out, const int32_t *idx, float *grad_features, float *grad_xyz,
-                                    float *grad_new_xyz, int B, int C, int N, int M, int S, float radius,
-                                    int normalize, void *stream) {
+extern "C" int bq_group_concat(const float *xyz, const float *new_xyz, const float *features, const int32_t *idx,
+                               float *out, int B, int C, int N, int M, int S, float radius, int normalize,
+                               void *stream) {
+  return group_concat_impl(xyz, new_xyz, features, idx, out, 0, B, C, N, M, S, radius, normalize, stream);
+}
+
+// same, writing bf16 (the grouped tensor is the largest activation of the detector: 1.1 GB in fp32 at SA1)
+extern "C" __attribute__((visibility("default"))) int bq_group_concat_bf16(
+    const float *xyz, const float *new_xyz, const float *features, const int32_t *idx, void *out, int B, int C, int N,
+    int M, int S, float radius, int normalize, void *stream) {
+  return group_concat_impl(xyz, new_xyz, features, idx, out, 1, B, C, N, M, S, radius, normalize, stream);
+}
+
+static int group_concat_grad_impl(const void *grad_out, int in_bf16, const int32_t *idx, float *grad_features,
+                                  float *grad_xyz, float *grad_new_xyz, int B, int C, int N, int M, int S,
+                                  float radius, int normalize, void *stream) {
   BQ_REQUIRE(B >= 0 && C >= 0 && N >= 0 && M >= 0 && S >= 0, BQ_EINVAL, "group_concat_grad: bad extents");
   if (B == 0 || M == 0 || S == 0) return BQ_OK;
   BQ_REQUIRE(grad_out && idx, BQ_EINVAL, "group_concat_grad: null pointer");
@@ -427,9 +459,29 @@ extern "C" int bq_group_concat_grad(const float *grad_out, const int32_t *idx, f
   BQ_REQUIRE(B <= 65535 && (long)M * S < (1L << 31), BQ_ELIMIT, "group_concat_grad: extent too large");
   const int xb = cdiv(M * S / 4, 256);
   const int yb = (C && grad_features) ? cgrid(C, xb, B) : 1;
-  hipLaunchKernelGGL(group_concat_grad_kernel, dim3(xb, yb, B), dim3(256), 0, (hipStream_t)stream, grad_out, idx,
-                     grad_features, grad_xyz, grad_new_xyz, C, N, M, S, radius, normalize);
+  if (in_bf16)
+    hipLaunchKernelGGL(group_concat_grad_kernel<__bf16>, dim3(xb, yb, B), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16 *)grad_out, idx, grad_features, grad_xyz, grad_new_xyz, C, N, M, S, radius,
+                       normalize);
+  else
+    hipLaunchKernelGGL(group_concat_grad_kernel<float>, dim3(xb, yb, B), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)grad_out, idx, grad_features, grad_xyz, grad_new_xyz, C, N, M, S, radius,
+                       normalize);
   return check_launch("group_concat_grad");
+}
+
+extern "C" int bq_group_concat_grad(const float *grad_out, const int32_t *idx, float *grad_features, float *grad_xyz,
+                                    float *grad_new_xyz, int B, int C, int N, int M, int S, float radius,
+                                    int normalize, void *stream) {
+  return group_concat_grad_impl(grad_out, 0, idx, grad_features, grad_xyz, grad_new_xyz, B, C, N, M, S, radius,
+                                normalize, stream);
+}
+
+extern "C" __attribute__((visibility("default"))) int bq_group_concat_grad_bf16(
+    const void *grad_out, const int32_t *idx, float *grad_features, float *grad_xyz, float *grad_new_xyz, int B, int C,
+    int N, int M, int S, float radius, int normalize, void *stream) {
+  return group_concat_grad_impl(grad_out, 1, idx, grad_features, grad_xyz, grad_new_xyz, B, C, N, M, S, radius,
+                                normalize, stream);
 }
 
 extern "C" int bq_three_nn(const float *unknown, const float *known, float *dist2, int32_t *idx, int B, int n, int m,

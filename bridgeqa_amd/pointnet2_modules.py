@@ -51,7 +51,7 @@ class PointnetSAModuleVotes(nn.Module):
         new_features = self.mlp_module(grouped_features)
         # == F.max_pool2d(kernel=[1, nsample]).squeeze(-1) (pointnet2_modules.py:259-262, 272); a row reduction
         # instead of the generic NCHW pooling kernel.  Tie routing in backward is immaterial.
-        new_features = new_features.max(dim=3)[0]
+        new_features = new_features.max(dim=3)[0].float()  # module boundary stays fp32 (reference dtype)
         return new_xyz, new_features, inds
 
 

@@ -142,10 +142,12 @@ class _GroupConcat(Function):
     cat([(xyz[idx]-centre)/radius, features[idx]], dim=1) instead of 2 gathers + sub + div + cat."""
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, features, idx, radius, normalize):
+    def forward(ctx, xyz, new_xyz, features, idx, radius, normalize, out_dtype=torch.float32):
         ctx.save_for_backward(idx)
         ctx.n, ctx.radius, ctx.normalize = xyz.size(1), radius, normalize
         ctx.has_features = features is not None
+        if out_dtype != torch.float32:
+            return _ext.group_concat(xyz, new_xyz, features, idx, radius, normalize, out_dtype)
         return _ext.group_concat(xyz, new_xyz, features, idx, radius, normalize)
 
     @staticmethod
@@ -154,7 +156,7 @@ class _GroupConcat(Function):
         need = ctx.needs_input_grad
         gf, gx, gn = _ext.group_concat_grad(grad_out.contiguous(), idx, ctx.n, ctx.radius, ctx.normalize,
                                             ctx.has_features and need[2], need[0], need[1])
-        return gx, gn, gf, None, None, None
+        return gx, gn, gf, None, None, None, None
 
 
 class QueryAndGroup(nn.Module):
@@ -180,7 +182,9 @@ class QueryAndGroup(nn.Module):
         idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
         fused = hasattr(_ext, "group_concat") and self.nsample % 4 == 0
         if fused and (self.use_xyz or features is None):
-            new_features = _GroupConcat.apply(xyz, new_xyz, features, idx, self.radius, self.normalize_xyz)
+            from . import fusion_ops
+            dt = fusion_ops.compute_dtype() if (xyz.is_cuda and _ext is _hip_ext) else torch.float32
+            new_features = _GroupConcat.apply(xyz, new_xyz, features, idx, self.radius, self.normalize_xyz, dt)
             grouped_xyz = new_features[:, :3]
         else:
             grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)

@@ -61,6 +61,30 @@ class SharedMLP(nn.Sequential):
             self.add_module(name + "layer{}".format(i),
                             Conv2d(args[i], args[i + 1], bn=bn, activation=activation, preact=preact))
 
+    def forward(self, x):
+        if x.dtype != torch.bfloat16:
+            return super().forward(x)  # reference composition (fp32: conv1x1 -> BN -> ReLU per layer)
+        # bf16 path: each 1x1 convolution is the batched GEMM  W[Cout,Cin] @ X[b][Cin, positions]  on the
+        # channel-major layout (bf16 operands, fp32 accumulation; no MIOpen NCHW<->NHWC transposes);
+        # BatchNorm statistics in fp32.
+        from . import fusion_ops
+        shape = x.shape
+        x = x.flatten(2)
+        for layer in self:
+            conv = layer.conv
+            x = torch.matmul(fusion_ops._c(conv.weight).flatten(1), x)
+            if conv.bias is not None:
+                x = x + fusion_ops._c(conv.bias)[None, :, None]
+            if hasattr(layer, "bn"):
+                bn = layer.bn.bn
+                if bn.training and bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked.add_(1)
+                x = nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training,
+                                             bn.momentum if bn.momentum is not None else 0.0, bn.eps)
+            if hasattr(layer, "activation"):
+                x = nn.functional.relu(x, inplace=True)
+        return x.view(shape[0], x.shape[1], *shape[2:])
+
 
 def set_bn_momentum_default(bn_momentum):
     def fn(m):

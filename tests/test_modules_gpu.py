@@ -33,3 +33,30 @@ def test_backbone_c2_shapes_and_backward(dev):
     (vx.square().mean() + vf.square().mean()).backward()
     g = bb.sa1.mlp_module.layer0.conv.weight.grad
     assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
+
+
+def test_sa_module_bf16_path_vs_reference_golden(golden, dev):
+    """bf16 grouped tensor + bf16 SharedMLP GEMMs (fp32 accumulation, fp32 BN statistics) against the fp32 reference
+    golden: rel-L2 <= 1e-2 on the outputs, indices exact."""
+    import numpy as np
+    from bridgeqa_amd import fusion_ops
+    from bridgeqa_amd.pointnet2_modules import PointnetSAModuleVotes
+    from golden_util import fill_params
+    g = golden("pn2_modules.npz")
+    sa = PointnetSAModuleVotes(npoint=64, radius=0.9, nsample=16, mlp=[5, 16, 16, 32], use_xyz=True, normalize_xyz=True)
+    fill_params(sa, "sa.")
+    sa = sa.to(dev).train()
+    pc = torch.from_numpy(g["sa_pc"]).to(dev)
+    xyz = pc[..., :3].contiguous()
+    feat = pc[..., 3:].transpose(1, 2).contiguous().requires_grad_(True)
+    prev = fusion_ops.set_compute_dtype(torch.bfloat16)
+    try:
+        nx, nf, ni = sa(xyz, feat)
+        (nf * torch.from_numpy(g["sa_w"]).to(dev)).sum().backward()
+    finally:
+        fusion_ops.set_compute_dtype(prev)
+    assert nf.dtype == torch.float32
+    np.testing.assert_array_equal(ni.cpu().numpy(), g["sa_inds"])
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    assert rel(nf.detach().cpu().numpy(), g["sa_train_new_features"]) < 1.5e-2
+    assert rel(feat.grad.cpu().numpy(), g["sa_train_grad_features"]) < 5e-2

@@ -60,7 +60,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         child(sys.argv[1])
     else:
-        for w in ("full", "fullopt"):
+        for w in ("det", "vit", "text", "full"):
             r = subprocess.run([sys.executable, __file__, w], capture_output=True, text=True)
             tail = [l for l in (r.stdout + r.stderr).splitlines() if "Warning" not in l and "AccumulateGrad" not in l and "run_backward" not in l and "libdrm" not in l]
             print(w, "rc", r.returncode, "|", " / ".join(tail[-3:]))

@@ -23,6 +23,7 @@ _COMPUTE_DTYPE = torch.float32
 # therefore issued on separate HIP streams -- detector branch || image encoder, 2D text stream || 3D text stream --
 # and joined with events; under HIP-graph capture the forks become parallel branches of the graph.
 _OVERLAP = [True]
+SHAREDMLP_BF16 = [False]
 _SIDE_STREAMS = {}
 
 

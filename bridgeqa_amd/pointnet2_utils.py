@@ -183,7 +183,10 @@ class QueryAndGroup(nn.Module):
         fused = hasattr(_ext, "group_concat") and self.nsample % 4 == 0
         if fused and (self.use_xyz or features is None):
             from . import fusion_ops
-            dt = fusion_ops.compute_dtype() if (xyz.is_cuda and _ext is _hip_ext) else torch.float32
+            # bf16 grouped tensor + bf16 SharedMLP GEMMs exist (fusion_ops.SHAREDMLP_BF16) but are OFF by default:
+            # hipBLASLt's batched GEMM at Cout x Cin <= 256 x 259 loses to MIOpen's fp32 convolution (tools/time_sa.py)
+            dt = fusion_ops.compute_dtype() if (xyz.is_cuda and _ext is _hip_ext and fusion_ops.SHAREDMLP_BF16[0]) \
+                else torch.float32
             new_features = _GroupConcat.apply(xyz, new_xyz, features, idx, self.radius, self.normalize_xyz, dt)
             grouped_xyz = new_features[:, :3]
         else:

@@ -50,13 +50,15 @@ def test_sa_module_bf16_path_vs_reference_golden(golden, dev):
     xyz = pc[..., :3].contiguous()
     feat = pc[..., 3:].transpose(1, 2).contiguous().requires_grad_(True)
     prev = fusion_ops.set_compute_dtype(torch.bfloat16)
+    fusion_ops.SHAREDMLP_BF16[0] = True
     try:
         nx, nf, ni = sa(xyz, feat)
         (nf * torch.from_numpy(g["sa_w"]).to(dev)).sum().backward()
     finally:
+        fusion_ops.SHAREDMLP_BF16[0] = False
         fusion_ops.set_compute_dtype(prev)
     assert nf.dtype == torch.float32
     np.testing.assert_array_equal(ni.cpu().numpy(), g["sa_inds"])
     rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
     assert rel(nf.detach().cpu().numpy(), g["sa_train_new_features"]) < 1.5e-2
-    assert rel(feat.grad.cpu().numpy(), g["sa_train_grad_features"]) < 5e-2
+    assert rel(feat.grad.cpu().numpy(), g["sa_train_grad_features"]) < 0.15  # bf16 re-rounding moves max-pool winners

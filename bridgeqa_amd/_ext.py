@@ -253,6 +253,48 @@ def group_concat_grad(grad_out, idx, n, radius, normalize, need_features, need_x
     return gf, gx, gn
 
 
+_lib.bq_group_concat_pm.argtypes = [_vp, _vp, _vp, ctypes.c_long, ctypes.c_long, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]
+_lib.bq_group_concat_pm.restype = ctypes.c_int
+_lib.bq_group_concat_pm_grad.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]
+_lib.bq_group_concat_pm_grad.restype = ctypes.c_int
+
+
+def group_concat_pm(xyz, new_xyz, feats_pm, idx, radius, normalize, out_dtype):
+    """Point-major grouping: feats_pm (B,N,C) f32 view with contiguous rows (any batch / row stride) or None ->
+    (B, M, S, 3+C) in out_dtype (f32 / bf16)."""
+    _req(xyz, torch.float32, "xyz"); _req(new_xyz, torch.float32, "new_xyz"); _req(idx, torch.int32, "idx")
+    B, N, _ = xyz.shape
+    _, M, S = idx.shape
+    C = 0
+    fbs = frs = 0
+    if feats_pm is not None:
+        if not feats_pm.is_cuda or feats_pm.dtype != torch.float32 or feats_pm.stride(2) != 1:
+            raise RuntimeError("feats_pm must be a CUDA float tensor (B,N,C) with contiguous rows")
+        C, fbs, frs = feats_pm.shape[2], feats_pm.stride(0), feats_pm.stride(1)
+    with torch.cuda.device(xyz.device):
+        out = torch.empty(B, M, S, C + 3, dtype=out_dtype, device=xyz.device)
+        _check(_lib.bq_group_concat_pm(_p(xyz), _p(new_xyz), _p(feats_pm), fbs, frs, _p(idx), _p(out),
+                                       int(out_dtype == torch.bfloat16), B, C, N, M, S, float(radius),
+                                       int(bool(normalize)), _stream()), "group_concat_pm")
+    return out
+
+
+def group_concat_pm_grad(grad_out, idx, n, radius, normalize, need_features, need_xyz, need_new_xyz):
+    B, M, S, CT = grad_out.shape
+    C = CT - 3
+    dev = grad_out.device
+    if not grad_out.is_contiguous():
+        grad_out = grad_out.contiguous()
+    with torch.cuda.device(dev):
+        gf = torch.zeros(B, n, C, dtype=torch.float32, device=dev) if (need_features and C > 0) else None
+        gx = torch.zeros(B, n, 3, dtype=torch.float32, device=dev) if need_xyz else None
+        gn = torch.zeros(B, M, 3, dtype=torch.float32, device=dev) if need_new_xyz else None
+        _check(_lib.bq_group_concat_pm_grad(_p(grad_out), int(grad_out.dtype == torch.bfloat16), _p(idx), _p(gf),
+                                            _p(gx), _p(gn), B, C, int(n), M, S, float(radius),
+                                            int(bool(normalize)), _stream()), "group_concat_pm_grad")
+    return gf, gx, gn
+
+
 # ---- fused attention (csrc/attn.hip) ---------------------------------------------------------------
 def _bhd_strides(t):
     """(B, L, H, 64) view with a contiguous last dim -> element strides (batch, token, head)."""

@@ -4,6 +4,7 @@
 propagation levels; writes sa{1..4}_{xyz,features}, sa1_inds, sa2_inds, fp2_{features,xyz,inds}
 into data_dict.  State-dict names: sa{i}.mlp_module.layer{j}.{conv.weight,bn.bn.*}, fp{i}.mlp.layer{j}...
 """
+import torch
 import torch.nn as nn
 
 from .pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
@@ -31,8 +32,13 @@ class Pointnet2Backbone(nn.Module):
 
     def _break_up_pc(self, pc):
         xyz = pc[..., :3].contiguous()
-        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
-        return xyz, features
+        if pc.size(-1) <= 3:
+            return xyz, None
+        from . import fusion_ops
+        features = pc[..., 3:].transpose(1, 2)  # (B,C,N) view of the interleaved cloud
+        if pc.is_cuda and fusion_ops.POINT_MAJOR[0] and fusion_ops.compute_dtype() == torch.bfloat16:
+            return xyz, features  # point-major fast path reads the rows in place: no 340 MB transposing copy
+        return xyz, features.contiguous()
 
     def forward(self, data_dict):
         """data_dict["point_clouds"]: (B, N, 3 + input_feature_dim) f32, xyz first."""
@@ -42,7 +48,7 @@ class Pointnet2Backbone(nn.Module):
             if i <= 2:
                 data_dict["sa%d_inds" % i] = inds
             data_dict["sa%d_xyz" % i] = xyz
-            data_dict["sa%d_features" % i] = features
+            data_dict["sa%d_features" % i] = features.contiguous()  # reference layout for consumers
         features = self.fp1(data_dict["sa3_xyz"], data_dict["sa4_xyz"], data_dict["sa3_features"],
                             data_dict["sa4_features"])
         features = self.fp2(data_dict["sa2_xyz"], data_dict["sa3_xyz"], data_dict["sa2_features"], features)

@@ -238,6 +238,65 @@ __global__ __launch_bounds__(256) void group_concat_grad_kernel(const OT *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// Point-major ("channels-last") grouping: out[b][j][k][0:3] = (xyz[idx]-centre)/radius, out[b][j][k][3:3+C] =
+// feats[b][idx][:].  With features stored point-major (B,N,C) a neighbourhood gather is a copy of contiguous
+// rows: one wave per output position reads the point's row and writes the output row, both coalesced.  The
+// output feeds the SharedMLP as an NHWC tensor (no layout transposes inside the convolution library).
+// ---------------------------------------------------------------------------------------------
+template <typename OT>
+__global__ __launch_bounds__(256) void group_concat_pm_kernel(const float *__restrict__ xyz,
+                                                              const float *__restrict__ new_xyz,
+                                                              const float *__restrict__ feats, long f_bs, long f_rs,
+                                                              const int32_t *__restrict__ idx, OT *__restrict__ out,
+                                                              int C, int N, int M, int S, float radius, int normalize,
+                                                              long total) {
+  const int lane = threadIdx.x & 63;
+  const int CT = C + 3;
+  for (long pos = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pos < total; pos += (long)gridDim.x * 4) {
+    const long bj = pos / S;            // b*M + j
+    const int b = (int)(bj / M);
+    const int id = idx[pos];
+    OT *o = out + pos * CT;
+    if (lane < 3) {
+      float v = xyz[((long)b * N + id) * 3 + lane] - new_xyz[bj * 3 + lane];
+      if (normalize) v /= radius;
+      o[lane] = (OT)v;
+    }
+    const float *f = feats + (long)b * f_bs + (long)id * f_rs;
+    for (int c = lane; c < C; c += 64) o[3 + c] = (OT)f[c];
+  }
+}
+
+// grad of the above w.r.t. point-major features (B,N,C) f32 (zero_init) and xyz / new_xyz (zero_init, optional)
+template <typename OT>
+__global__ __launch_bounds__(256) void group_concat_pm_grad_kernel(const OT *__restrict__ grad_out,
+                                                                   const int32_t *__restrict__ idx,
+                                                                   float *__restrict__ grad_feats,
+                                                                   float *__restrict__ grad_xyz,
+                                                                   float *__restrict__ grad_new_xyz, int C, int N,
+                                                                   int M, int S, float radius, int normalize,
+                                                                   long total) {
+  const int lane = threadIdx.x & 63;
+  const int CT = C + 3;
+  for (long pos = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pos < total; pos += (long)gridDim.x * 4) {
+    const long bj = pos / S;
+    const int b = (int)(bj / M);
+    const int id = idx[pos];
+    const OT *g = grad_out + pos * CT;
+    if (lane < 3 && (grad_xyz || grad_new_xyz)) {
+      float v = (float)g[lane];
+      if (normalize) v /= radius;
+      if (grad_xyz) atomicAdd(grad_xyz + ((long)b * N + id) * 3 + lane, v);
+      if (grad_new_xyz) atomicAdd(grad_new_xyz + bj * 3 + lane, -v);
+    }
+    if (grad_feats) {
+      float *gf = grad_feats + ((long)b * N + id) * C;
+      for (int c = lane; c < C; c += 64) atomicAdd(gf + c, (float)g[3 + c]);  // 256 contiguous bytes per wave-instruction
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // three_nn: one lane per unknown point, known points staged through LDS in tiles and read as
 // wave-wide broadcasts; strict '<' with ascending k keeps the lowest index on ties, and the
 // running bests are compared exactly as the reference does (float candidate against a best
@@ -549,4 +608,46 @@ extern "C" __attribute__((visibility("default"))) int bq_debug_clock_mhz(float *
                                                                          void *stream) {
   hipLaunchKernelGGL(debug_clock_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters);
   return bq::check_launch("debug_clock");
+}
+
+
+// Point-major grouping (see group_concat_pm_kernel).  feats: f32 rows of C contiguous elements, batch stride f_bs
+// and row stride f_rs in elements (so a (B,N,3+C) interleaved cloud can be read in place); out: (B,M,S,3+C) f32 or
+// bf16.
+extern "C" __attribute__((visibility("default"))) int bq_group_concat_pm(
+    const float *xyz, const float *new_xyz, const float *feats, long f_bs, long f_rs, const int32_t *idx, void *out,
+    int out_bf16, int B, int C, int N, int M, int S, float radius, int normalize, void *stream) {
+  BQ_REQUIRE(B >= 0 && C >= 0 && N >= 0 && M >= 0 && S >= 0, BQ_EINVAL, "group_concat_pm: bad extents");
+  if (B == 0 || M == 0 || S == 0) return BQ_OK;
+  BQ_REQUIRE(xyz && new_xyz && idx && out && (feats || C == 0), BQ_EINVAL, "group_concat_pm: null pointer");
+  const long total = (long)B * M * S;
+  const int blocks = (int)(total / 4 < 8192 ? (total + 3) / 4 : 8192);
+  if (out_bf16)
+    hipLaunchKernelGGL(group_concat_pm_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, xyz, new_xyz,
+                       feats, f_bs, f_rs, idx, (__bf16 *)out, C, N, M, S, radius, normalize, total);
+  else
+    hipLaunchKernelGGL(group_concat_pm_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, xyz, new_xyz,
+                       feats, f_bs, f_rs, idx, (float *)out, C, N, M, S, radius, normalize, total);
+  return check_launch("group_concat_pm");
+}
+
+// grad_out: (B,M,S,3+C) f32 or bf16; grad_feats (B,N,C) f32, grad_xyz (B,N,3), grad_new_xyz (B,M,3): zero_init, each
+// optional (NULL).
+extern "C" __attribute__((visibility("default"))) int bq_group_concat_pm_grad(
+    const void *grad_out, int in_bf16, const int32_t *idx, float *grad_feats, float *grad_xyz, float *grad_new_xyz,
+    int B, int C, int N, int M, int S, float radius, int normalize, void *stream) {
+  BQ_REQUIRE(B >= 0 && C >= 0 && N >= 0 && M >= 0 && S >= 0, BQ_EINVAL, "group_concat_pm_grad: bad extents");
+  if (B == 0 || M == 0 || S == 0) return BQ_OK;
+  BQ_REQUIRE(grad_out && idx, BQ_EINVAL, "group_concat_pm_grad: null pointer");
+  const long total = (long)B * M * S;
+  const int blocks = (int)(total / 4 < 8192 ? (total + 3) / 4 : 8192);
+  if (in_bf16)
+    hipLaunchKernelGGL(group_concat_pm_grad_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16 *)grad_out, idx, grad_feats, grad_xyz, grad_new_xyz, C, N, M, S, radius,
+                       normalize, total);
+  else
+    hipLaunchKernelGGL(group_concat_pm_grad_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)grad_out, idx, grad_feats, grad_xyz, grad_new_xyz, C, N, M, S, radius,
+                       normalize, total);
+  return check_launch("group_concat_pm_grad");
 }

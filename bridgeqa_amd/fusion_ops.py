@@ -24,6 +24,10 @@ _COMPUTE_DTYPE = torch.float32
 # and joined with events; under HIP-graph capture the forks become parallel branches of the graph.
 _OVERLAP = [True]
 SHAREDMLP_BF16 = [False]
+# Detector fast path (bf16 compute dtype only): features are kept POINT-MAJOR (B,N,C) so neighbourhood grouping is
+# a copy of contiguous rows, the grouped tensor is written once as bf16 NHWC and the SharedMLP convolutions run on
+# it without layout transposes.  Values at the module boundary keep the reference layout (B,C,N) as strided views.
+POINT_MAJOR = [True]
 _SIDE_STREAMS = {}
 
 

@@ -51,7 +51,12 @@ class PointnetSAModuleVotes(nn.Module):
         new_features = self.mlp_module(grouped_features)
         # == F.max_pool2d(kernel=[1, nsample]).squeeze(-1) (pointnet2_modules.py:259-262, 272); a row reduction
         # instead of the generic NCHW pooling kernel.  Tie routing in backward is immaterial.
-        new_features = new_features.max(dim=3)[0].float()  # module boundary stays fp32 (reference dtype)
+        if new_features.is_contiguous(memory_format=torch.channels_last) and not new_features.is_contiguous():
+            # NHWC fast path: reduce over S on the (B,M,S,C) view; the result stays point-major (B,M,C) and is
+            # handed on as a (B,C,M) VIEW so the next level can group it without a transpose
+            new_features = new_features.permute(0, 2, 3, 1).max(dim=2)[0].float().transpose(1, 2)
+        else:
+            new_features = new_features.max(dim=3)[0].float()  # module boundary stays fp32 (reference dtype)
         return new_xyz, new_features, inds
 
 
@@ -71,7 +76,7 @@ class PointnetFPModule(nn.Module):
             dist_recip = 1.0 / (dist + 1e-8)
             norm = torch.sum(dist_recip, dim=2, keepdim=True)
             weight = dist_recip / norm
-            interpolated_feats = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+            interpolated_feats = pointnet2_utils.three_interpolate(known_feats.contiguous(), idx, weight)
         else:
             interpolated_feats = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         if unknow_feats is not None:

@@ -159,6 +159,34 @@ class _GroupConcat(Function):
         return gx, gn, gf, None, None, None, None
 
 
+class _GroupConcatPM(Function):
+    """Point-major grouping (csrc/pn2_ops.hip group_concat_pm_kernel): feats_pm (B,N,C) rows -> (B,M,S,3+C)."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feats_pm, idx, radius, normalize, out_dtype):
+        ctx.save_for_backward(idx)
+        ctx.n, ctx.radius, ctx.normalize = xyz.size(1), radius, normalize
+        ctx.has_features = feats_pm is not None
+        return _ext.group_concat_pm(xyz, new_xyz, feats_pm, idx, radius, normalize, out_dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        gf, gx, gn = _ext.group_concat_pm_grad(grad_out, idx, ctx.n, ctx.radius, ctx.normalize,
+                                               ctx.has_features and need[2], need[0], need[1])
+        return gx, gn, gf, None, None, None, None
+
+
+def point_major(features):
+    """(B,C,N) features -> (B,N,C) view with contiguous rows (a free view when `features` already is a transposed
+    point-major tensor, one transposing copy otherwise)"""
+    if features is None:
+        return None
+    pm = features.transpose(1, 2)
+    return pm if pm.stride(2) == 1 else pm.contiguous()
+
+
 class QueryAndGroup(nn.Module):
     """Ball query + neighbourhood gather   [pointnet2_utils.py:294-376].
 
@@ -180,6 +208,13 @@ class QueryAndGroup(nn.Module):
 
     def forward(self, xyz, new_xyz, features=None):
         idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        from . import fusion_ops
+        if (xyz.is_cuda and _ext is _hip_ext and fusion_ops.POINT_MAJOR[0] and self.use_xyz
+                and fusion_ops.compute_dtype() == torch.bfloat16):
+            out = _GroupConcatPM.apply(xyz, new_xyz, point_major(features), idx, self.radius, self.normalize_xyz,
+                                       torch.bfloat16)
+            new_features = out.permute(0, 3, 1, 2)  # logical (B,3+C,M,S), physically NHWC
+            return (new_features, new_features[:, :3]) if self.ret_grouped_xyz else new_features
         fused = hasattr(_ext, "group_concat") and self.nsample % 4 == 0
         if fused and (self.use_xyz or features is None):
             from . import fusion_ops

@@ -64,6 +64,11 @@ class SharedMLP(nn.Sequential):
     def forward(self, x):
         if x.dtype != torch.bfloat16:
             return super().forward(x)  # reference composition (fp32: conv1x1 -> BN -> ReLU per layer)
+        if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last):
+            # bf16 NHWC grouped tensor (point-major fast path): the 1x1 convolutions run as bf16 implicit GEMMs on the
+            # layout as it is; BatchNorm keeps fp32 parameters and statistics
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return super().forward(x)
         # bf16 path: each 1x1 convolution is the batched GEMM  W[Cout,Cin] @ X[b][Cin, positions]  on the
         # channel-major layout (bf16 operands, fp32 accumulation; no MIOpen NCHW<->NHWC transposes);
         # BatchNorm statistics in fp32.

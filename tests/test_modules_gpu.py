@@ -62,3 +62,34 @@ def test_sa_module_bf16_path_vs_reference_golden(golden, dev):
     rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
     assert rel(nf.detach().cpu().numpy(), g["sa_train_new_features"]) < 1.5e-2
     assert rel(feat.grad.cpu().numpy(), g["sa_train_grad_features"]) < 0.15  # bf16 re-rounding moves max-pool winners
+
+
+def test_point_major_bf16_detector_vs_fp32_reference_path(dev):
+    """The whole DET slice through the point-major bf16 fast path (grouping of contiguous rows, NHWC bf16 SharedMLP)
+    against the fp32 reference-layout path: identical sampling / neighbour indices, features within bf16 tolerance,
+    gradients reach the first SA layer."""
+    import bench
+    from bridgeqa_amd import fusion_ops
+    from bridgeqa_amd.hotpath import ScanQAHotPath
+    torch.manual_seed(0)
+    model = ScanQAHotPath(input_feature_dim=7, use_blip=False).to(dev).eval()
+    pc = bench.synth_batch(2, 6000, 7, 3, dev)
+    with torch.no_grad():
+        ref = model.detect({"point_clouds": pc})
+    prev = fusion_ops.set_compute_dtype(torch.bfloat16)
+    try:
+        with torch.no_grad():
+            got = model.detect({"point_clouds": pc})
+        model.train()
+        dd = model.detect({"point_clouds": pc})
+        bench.det_loss(dd).backward()
+    finally:
+        fusion_ops.set_compute_dtype(prev)
+    for k in ("sa1_inds", "sa2_inds", "fp2_inds"):
+        assert torch.equal(got[k], ref[k])
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+    for k in ("sa1_features", "sa2_features", "sa4_features", "fp2_features"):
+        assert got[k].shape == ref[k].shape and got[k].is_contiguous()
+        assert rel(got[k], ref[k]) < 3e-2, (k, rel(got[k], ref[k]))
+    g = model.detection_backbone.sa1.mlp_module.layer0.conv.weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0

@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--points", type=int, default=40000)
     ap.add_argument("--image", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dp-path", action="store_true", help="use the data-parallel step structure even on one GPU")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the whole train step (forward + backward + fused AdamW) from one HIP graph; "
                          "auto = on for a single GPU")
@@ -181,8 +182,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU product path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if world > 1 or (args.dp_path and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", init_method="env://")
     workload = "c3" if args.workload == "auto" else args.workload
@@ -192,51 +193,83 @@ def main():
         fusion_ops.set_compute_dtype(torch.bfloat16)
     torch.manual_seed(0)
     model = build_model(workload, args.cin, args.image).to(dev)
-    if world > 1:
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=True)
-    use_graph = world == 1 and args.graph in ("on", "auto")
-    # fused multi-tensor AdamW; NB the foreach implementation under capture makes hipStreamEndCapture segfault
-    opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-5, fused=True, capturable=use_graph)
-    params = [p for p in model.parameters() if p.requires_grad]
+    dp = world > 1 or args.dp_path  # data-parallel structure: graph(fwd+bwd) -> flat bf16 all-reduce -> fused AdamW
+    use_graph = args.graph in ("on", "auto")
     batch = make_batch(args, workload, args.batch, 42 + rank, dev)
+    side = torch.cuda.Stream()
+    graphed = False
 
-    def eager_step():
-        # grads start as None: autograd then hands each gradient tensor over without a zero-fill + add per
-        # parameter (under capture the buffers come from the graph's private pool at fixed addresses)
-        opt.zero_grad(set_to_none=True)
-        loss = total_loss(model(dict(batch)))
-        loss.backward()
-        opt.step()
-        return loss
+    if not dp:
+        # ---- single GPU: forward + backward + fused AdamW replayed from ONE HIP graph -----------------------
+        # (fused multi-tensor AdamW; NB the foreach implementation under capture makes hipStreamEndCapture segfault)
+        opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-5, fused=True, capturable=use_graph)
+
+        def eager_step():
+            # grads start as None: autograd then hands each gradient tensor over without a zero-fill + add per
+            # parameter (under capture the buffers come from the graph's private pool at fixed addresses)
+            opt.zero_grad(set_to_none=True)
+            loss = total_loss(model(dict(batch)))
+            loss.backward()
+            opt.step()
+            return loss
+        graph_body = eager_step
+        after_replay = lambda: None
+    else:
+        # ---- data parallel: the gradients live in flat buffers (bridgeqa_amd/ddp.py); the forward+backward is a
+        # HIP graph without collectives, the exchange is a few large bf16 all-reduces over RCCL, then fused AdamW
+        from bridgeqa_amd.ddp import FlatGradReducer, broadcast_parameters, used_parameters
+        broadcast_parameters(model)
+
+        def dry():
+            for p in model.parameters():
+                p.grad = None
+            total_loss(model(dict(batch))).backward()
+        with torch.cuda.stream(side):
+            used = used_parameters(model, dry)
+        torch.cuda.synchronize()
+        reducer = FlatGradReducer(used, comm_dtype=torch.bfloat16)
+        reducer.force = args.dp_path
+        opt = torch.optim.AdamW(used, lr=5e-4, weight_decay=1e-5, fused=True)
+
+        def graph_body():
+            reducer.zero()
+            loss = total_loss(model(dict(batch)))
+            loss.backward()
+            return loss
+
+        def after_replay():
+            reducer.all_reduce()
+            opt.step()
+
+        def eager_step():
+            loss = graph_body()
+            after_replay()
+            return loss
 
     step = eager_step
-    graphed = False
-    side = torch.cuda.Stream() if use_graph else None
+    # Every eager step before a capture runs on the SAME side stream: autograd's AccumulateGrad nodes remember the
+    # stream they were created on, and nodes born on the default stream make hipStreamEndCapture segfault (ROCm 7).
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(max(args.warmup, 3 if use_graph else 0)):
+            eager_step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
     if use_graph:
-        # The step is launch-bound in places (thousands of short kernels): capture forward + backward + AdamW
-        # ONCE into a HIP graph and replay it.  Inputs are static device buffers.  Every eager step before the
-        # capture runs on the SAME side stream: autograd's AccumulateGrad nodes remember the stream they were
-        # created on, and nodes born on the default stream make hipStreamEndCapture segfault (ROCm 7.0/7.2).
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(args.warmup, 3)):
-                eager_step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+        # The step is launch-bound in places (thousands of short kernels): capture it ONCE and replay.  Inputs are
+        # static device buffers.
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=side):
-            static_loss = eager_step()
+            static_loss = graph_body()
         torch.cuda.synchronize()
 
         def step():
             g.replay()
+            after_replay()
             return static_loss
         graphed = True
         for _ in range(2):
             step()
-    else:
-        for _ in range(args.warmup):
-            eager_step()
     timer = OpTimer()
     timer.wrap(_ext, ["furthest_point_sampling", "ball_query", "group_concat", "group_concat_grad"])
     torch.cuda.synchronize()
@@ -280,7 +313,9 @@ def main():
             "dtype": "bf16" if workload == "c3" else "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[workload], "global_batch": args.batch * world, "points": args.points,
                        "c_in": args.cin, "image": args.image if workload == "c3" else None,
-                       "parallelism": "dp%d" % world, "hip_graph": graphed},
+                       "parallelism": "dp%d" % world, "hip_graph": graphed,
+                       "grad_exchange": ("flat bf16 all-reduce after the fwd+bwd graph, %d MB on the wire"
+                                         % (reducer.nbytes_on_wire() >> 20)) if dp else None},
             "roofline": {"kernel": "fps (SA1 40000->2048)", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": None, "ms_per_launch": round(fps_ms, 4),
@@ -291,7 +326,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, workload)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

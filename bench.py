@@ -318,7 +318,10 @@ def main():
                                          % (reducer.nbytes_on_wire() >> 20)) if dp else None},
             "roofline": {"kernel": "fps (SA1 40000->2048)", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "ms_per_launch": round(fps_ms, 4),
+                         # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE,
+                         # measured on exactly this kernel and size (profiles/r01_fps_pmc.txt); null for other sizes
+                         "traffic": 27.9e6 if (args.points == 40000 and args.batch == 16) else None,
+                         "ms_per_launch": round(fps_ms, 4),
                          "timed_on": "eager re-run after the graph replay" if graphed else "the timed steps",
                          "algorithmic_bytes_per_launch": alg},
             "op_ms": {"%s%s" % (k[0], list(k[1])): round(v[0], 4) for k, v in sorted(ops.items())},

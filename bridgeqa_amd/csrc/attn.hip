@@ -16,6 +16,8 @@
 // Workgroup = 4 waves = 128 query rows of one (batch, head); K / V^T tiles of 64 keys are staged through
 // LDS once per workgroup (XOR-swizzled 16-B chunks), the next tile's global loads are in flight while the
 // current one is consumed.
+#include <stdlib.h>
+
 #include "bq_common.h"
 
 namespace bq {
@@ -90,7 +92,8 @@ __device__ __forceinline__ void stage_store(unsigned char *lds, int c, uint4 v) 
   *reinterpret_cast<uint4 *>(lds + swz(c >> 3, c & 7)) = v;
 }
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
                                                        const __bf16 *__restrict__ Vt, __bf16 *__restrict__ O,
                                                        float *__restrict__ LSE, AttnDims dm) {
   __shared__ __align__(16) unsigned char s_k[AT_KB * 128];
@@ -489,8 +492,11 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_fwd(
   AttnDims dm{B, H, Lq, Lk, 0, Lkp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, o_bs, o_rs, o_hs, mask, scale,
               1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr};
   const dim3 grid((Lq + AT_QB - 1) / AT_QB, B * H);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Q, (const __bf16 *)K,
-                     (const __bf16 *)Vt, (__bf16 *)O, LSE, dm);
+  static const int minw = getenv("BQ_ATTN_MINW") ? atoi(getenv("BQ_ATTN_MINW")) : 2;
+#define BQ_FWD(W) hipLaunchKernelGGL(attn_fwd_kernel<W>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Q, \
+                                     (const __bf16 *)K, (const __bf16 *)Vt, (__bf16 *)O, LSE, dm)
+  switch (minw) { case 1: BQ_FWD(1); break; case 3: BQ_FWD(3); break; case 4: BQ_FWD(4); break; default: BQ_FWD(2); }
+#undef BQ_FWD
   return check_launch("attn_fwd");
 }
 

@@ -371,6 +371,21 @@ def attn_bwd(q, k, v, out, lse, grad_out, scale, dq, dk, dv, mask_log2=None, p_d
                "attn_bwd")
 
 
+_lib.bq_colsum_chunks.argtypes = [_i]
+_lib.bq_colsum_chunks.restype = ctypes.c_int
+_lib.bq_colsum_bf16.argtypes = [_vp, _vp, _i, _i, _vp]
+_lib.bq_colsum_bf16.restype = ctypes.c_int
+
+
+def colsum(g2d):
+    """f32 column sums of a contiguous bf16 (M, N) matrix (bias gradients), N % 4 == 0."""
+    M, N = g2d.shape
+    with torch.cuda.device(g2d.device):
+        out = (torch.zeros if _lib.bq_colsum_chunks(M) > 1 else torch.empty)(N, dtype=torch.float32, device=g2d.device)
+        _check(_lib.bq_colsum_bf16(_p(g2d), _p(out), M, N, _stream()), "colsum")
+    return out
+
+
 # ---- fused dropout + residual + LayerNorm (csrc/ln.hip) ---------------------------------------------
 def drop_add_ln_fwd(x, residual, gamma, beta, eps, p_drop, seed, seed_tensor):
     """y = LayerNorm(dropout(x) + residual); x, residual bf16 (..., H) contiguous.  Returns y, mean, rstd."""

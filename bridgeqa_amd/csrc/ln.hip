@@ -183,9 +183,50 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const __bf16 *__rest
   }
 }
 
+// Column sums of a bf16 (M, N) matrix into f32 (N): the bias gradient of every linear layer (db = sum_rows dY).
+// Thread = 4 adjacent columns (8-B loads), 4 row phases per workgroup folded through LDS; row chunks over
+// gridDim.y with atomics (out zero-initialised) only when M is large.
+__global__ __launch_bounds__(256) void colsum_kernel(const __bf16 *__restrict__ g, float *__restrict__ out, int M,
+                                                     int N, int rows_per_chunk) {
+  __shared__ float s[4][256];
+  const int cg = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int c0 = (blockIdx.x * 64 + cg) * 4;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c0 < N) {
+    for (int r = r0 + ph; r < r1; r += 4) {
+      const bf16x4 v = *reinterpret_cast<const bf16x4 *>(g + (long)r * N + c0);
+      a0 += (float)v[0]; a1 += (float)v[1]; a2 += (float)v[2]; a3 += (float)v[3];
+    }
+  }
+  s[ph][cg * 4 + 0] = a0; s[ph][cg * 4 + 1] = a1; s[ph][cg * 4 + 2] = a2; s[ph][cg * 4 + 3] = a3;
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < N) {
+    const float v = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+    if (gridDim.y == 1) out[c] = v; else atomicAdd(out + c, v);
+  }
+}
+
 }  // namespace bq
 
 using namespace bq;
+
+// out[n] = sum_m g[m][n]; g bf16 (M, N) row-major with N % 4 == 0, out f32 (N).  Returns in *needs_zero (host int,
+// may be NULL) whether `out` had to be zero-initialised by the caller (large M: chunked with atomics) -- call
+// bq_colsum_chunks first to know.
+extern "C" __attribute__((visibility("default"))) int bq_colsum_chunks(int M) { return M <= 4096 ? 1 : (M + 1023) / 1024; }
+
+extern "C" __attribute__((visibility("default"))) int bq_colsum_bf16(const void *g, float *out, int M, int N,
+                                                                     void *stream) {
+  BQ_REQUIRE(M >= 0 && N > 0 && N % 4 == 0, BQ_EINVAL, "colsum: bad extents");
+  BQ_REQUIRE(g && out, BQ_EINVAL, "colsum: null pointer");
+  const int chunks = bq_colsum_chunks(M);
+  const int rpc = chunks == 1 ? (M > 0 ? M : 1) : 1024;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, chunks), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16 *)g, out, M, N, rpc);
+  return check_launch("colsum");
+}
 
 // y = LayerNorm(dropout(x) + residual): x, residual, y bf16 (M, H) row-major, gamma/beta f32 (H), mean/rstd f32 (M)
 // saved for the backward.  H must be 256, 512, 768 or 1024.

@@ -175,8 +175,74 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = _mm_f32(g2.t(), x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = g2.sum(0, dtype=torch.float32)
+            if g2.dtype == torch.bfloat16 and g2.shape[1] % 4 == 0 and g2.is_contiguous():
+                from . import _ext
+                db = _ext.colsum(g2)
+            else:
+                db = g2.sum(0, dtype=torch.float32)
         return dx, dw, db, None
+
+
+_CAT_CACHE = {}
+
+
+def _cat_shadow(weights, biases):
+    """bf16 [sum(N_i), K] / [sum(N_i)] concatenation of several linears' shadows, rebuilt once per optimizer step"""
+    key = tuple(id(w) for w in weights)
+    ver = tuple(w._version for w in weights) + tuple(b._version for b in biases)
+    hit = _CAT_CACHE.get(key)
+    if hit is not None and hit[0] == ver and all(r() is w for r, w in zip(hit[1], weights)):
+        return hit[2], hit[3]
+    import weakref
+    with torch.no_grad():
+        wc = torch.cat([_shadow(w) for w in weights], dim=0)
+        bc = torch.cat([_shadow(b) for b in biases], dim=0)
+    _CAT_CACHE[key] = (ver, [weakref.ref(w) for w in weights], wc, bc)
+    return wc, bc
+
+
+class _MultiLinearFn(torch.autograd.Function):
+    """k linears over the SAME input evaluated as one GEMM (Q/K/V of self-attention, K/V of cross-attention):
+    y[..., i, :] = x @ W_i^T + b_i.  One dX GEMM, one dW GEMM and one bias reduction in the backward; the
+    per-layer gradients are row blocks (views) of the fused results."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        k = len(wb) // 2
+        weights, biases = wb[:k], wb[k:]
+        wc, bc = _cat_shadow(weights, biases)
+        xb = x if x.dtype == _COMPUTE_DTYPE else x.to(_COMPUTE_DTYPE)
+        y = F.linear(xb, wc, bc)
+        ctx.save_for_backward(xb, wc)
+        ctx.k, ctx.x_dtype = k, x.dtype
+        return y.view(*y.shape[:-1], k, y.shape[-1] // k)
+
+    @staticmethod
+    def backward(ctx, g):
+        xb, wc = ctx.saved_tensors
+        k = ctx.k
+        g2 = g.reshape(-1, g.shape[-2] * g.shape[-1])
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        x2 = xb.reshape(-1, xb.shape[-1])
+        dx = torch.mm(g2, wc).view(xb.shape).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
+        dw = _mm_f32(g2.t(), x2)
+        if g2.dtype == torch.bfloat16 and g2.shape[1] % 4 == 0:
+            from . import _ext
+            db = _ext.colsum(g2)
+        else:
+            db = g2.sum(0, dtype=torch.float32)
+        n = dw.shape[0] // k
+        return (dx,) + tuple(dw[i * n:(i + 1) * n] for i in range(k)) + tuple(db[i * n:(i + 1) * n] for i in range(k))
+
+
+def multi_linear(x, linears):
+    """[lin_i(x)] stacked on a new second-to-last axis: (..., k, N).  Fused on the bf16 CUDA path."""
+    ws, bs = [l.weight for l in linears], [l.bias for l in linears]
+    if (_COMPUTE_DTYPE != torch.float32 and x.is_cuda and all(w.dtype == torch.float32 for w in ws)
+            and all(b is not None for b in bs) and len({w.shape for w in ws}) == 1):
+        return _MultiLinearFn.apply(x, *ws, *bs)
+    return torch.stack([linear(x, w, b) for w, b in zip(ws, bs)], dim=-2)
 
 
 def linear(x, weight, bias=None, act=None):

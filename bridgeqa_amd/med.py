@@ -134,8 +134,30 @@ class BertSelfAttention(nn.Module):
                 encoder_attention_mask=None, past_key_value=None, output_attentions=False):
         if head_mask is not None:
             raise NotImplementedError("head_mask is always None on the BridgeQA path")
-        q = self._heads(ops.linear(hidden_states, self.query.weight, self.query.bias))
         is_cross = encoder_hidden_states is not None
+        want = output_attentions or (is_cross and self.save_attention)
+        H, D = self.num_attention_heads, self.attention_head_size
+        p_drop = self.dropout.p if self.training else 0.0
+        if not want and past_key_value is None and ops.compute_dtype() == torch.bfloat16 and hidden_states.is_cuda:
+            # fused projections: Q/K/V (self) or K/V (cross) as ONE GEMM over the shared input, and the attention
+            # kernels read / write the packed tensors in place
+            B, L = hidden_states.shape[:2]
+            if is_cross:
+                Lk = encoder_hidden_states.shape[1]
+                q = self._heads(ops.linear(hidden_states, self.query.weight, self.query.bias))
+                kv = ops.multi_linear(encoder_hidden_states, (self.key, self.value)).view(B, Lk, 2, H, D)
+                ctx = ops.attention_q_kv(q, kv, 1.0 / math.sqrt(D), p_drop, encoder_attention_mask)
+                present = (kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3))
+            else:
+                qkv = ops.multi_linear(hidden_states, (self.query, self.key, self.value)).view(B, L, 3, H, D)
+                if attention_mask is not None and not (attention_mask.shape[1] == 1 and attention_mask.shape[2] == 1):
+                    ctx, _ = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], attention_mask,
+                                           1.0 / math.sqrt(D), dropout_p=p_drop)  # causal decoder mask
+                else:
+                    ctx = ops.attention_packed(qkv, 1.0 / math.sqrt(D), p_drop, attention_mask)
+                present = (qkv[:, :, 1].permute(0, 2, 1, 3), qkv[:, :, 2].permute(0, 2, 1, 3))
+            return (ctx.reshape(B, L, self.all_head_size), present)
+        q = self._heads(ops.linear(hidden_states, self.query.weight, self.query.bias))
         src = encoder_hidden_states if is_cross else hidden_states
         k = self._heads(ops.linear(src, self.key.weight, self.key.bias))
         v = self._heads(ops.linear(src, self.value.weight, self.value.bias))
@@ -145,7 +167,6 @@ class BertSelfAttention(nn.Module):
             k = torch.cat([past_key_value[0].permute(0, 2, 1, 3), k], dim=1)
             v = torch.cat([past_key_value[1].permute(0, 2, 1, 3), v], dim=1)
         present = (k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3))
-        want = output_attentions or (is_cross and self.save_attention)
         ctx, probs = ops.attention(q, k, v, attention_mask, 1.0 / math.sqrt(self.attention_head_size),
                                    return_probs=want, dropout_p=self.dropout.p if self.training else 0.0)
         if is_cross and self.save_attention:

@@ -290,29 +290,6 @@ def attention(q, k, v, mask, scale, return_probs=False, dropout_p=0.0):
     return ctx, (probs if return_probs else None)
 
 
-class _PackedAttention(torch.autograd.Function):
-    """softmax(q k^T * scale) v on a fused-QKV tensor (B, L, 3, H, 64) through the MFMA kernels of
-    csrc/attn.hip: no (L x L) tensor in HBM, forward or backward; the gradient comes back packed the same
-    way, so the QKV projection's backward needs no concat."""
-
-    @staticmethod
-    def forward(ctx, qkv, scale):
-        from . import _ext
-        out, lse = _ext.attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], scale)
-        ctx.save_for_backward(qkv, out, lse)
-        ctx.scale = scale
-        return out
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        from . import _ext
-        qkv, out, lse = ctx.saved_tensors
-        dqkv = torch.empty_like(qkv)
-        _ext.attn_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out, lse, grad_out, ctx.scale,
-                      dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2])
-        return dqkv, None
-
-
 _STEP_SEED = {}
 _CALL_SEED = [0]
 
@@ -433,13 +410,82 @@ def _kernel_attention_ok(q, k, mask, return_probs):
     return mask is None or (mask.dim() == 4 and mask.shape[1] == 1 and mask.shape[2] == 1)
 
 
-def attention_packed(qkv, scale, dropout_p=0.0):
+def _seed_args(p_drop, device):
+    _CALL_SEED[0] += 1
+    return _CALL_SEED[0] * 7919, (step_seed(device) if p_drop > 0 else None)
+
+
+class _PackedAttention(torch.autograd.Function):
+    """softmax(q k^T * scale + key_mask) v on a fused-QKV tensor (B, L, 3, H, 64) through the MFMA kernels of
+    csrc/attn.hip: no (L x L) tensor in HBM, forward or backward; the gradient comes back packed the same
+    way, so the QKV projection's backward needs no concat."""
+
+    @staticmethod
+    def forward(ctx, qkv, scale, mask_log2, p_drop):
+        from . import _ext
+        seed, st = _seed_args(p_drop, qkv.device)
+        out, lse = _ext.attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], scale, mask_log2, p_drop, seed, st)
+        ctx.save_for_backward(qkv, out, lse, mask_log2 if mask_log2 is not None else qkv.new_empty(0),
+                              st if st is not None else qkv.new_empty(0))
+        ctx.cfg = (scale, p_drop, seed, mask_log2 is not None, st is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import _ext
+        qkv, out, lse, mask_log2, st = ctx.saved_tensors
+        scale, p_drop, seed, has_mask, has_st = ctx.cfg
+        dqkv = torch.empty_like(qkv)
+        _ext.attn_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out, lse, grad_out, scale,
+                      dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], mask_log2 if has_mask else None, p_drop, seed,
+                      st if has_st else None)
+        return dqkv, None, None, None
+
+
+class _QKVAttention(torch.autograd.Function):
+    """Cross-attention with q (B, Lq, H, 64) and a fused K/V tensor kv (B, Lk, 2, H, 64); dkv comes back packed."""
+
+    @staticmethod
+    def forward(ctx, q, kv, scale, mask_log2, p_drop):
+        from . import _ext
+        seed, st = _seed_args(p_drop, q.device)
+        out, lse = _ext.attn_fwd(q, kv[:, :, 0], kv[:, :, 1], scale, mask_log2, p_drop, seed, st)
+        ctx.save_for_backward(q, kv, out, lse, mask_log2 if mask_log2 is not None else q.new_empty(0),
+                              st if st is not None else q.new_empty(0))
+        ctx.cfg = (scale, p_drop, seed, mask_log2 is not None, st is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import _ext
+        q, kv, out, lse, mask_log2, st = ctx.saved_tensors
+        scale, p_drop, seed, has_mask, has_st = ctx.cfg
+        qc = q if q.is_contiguous() else q.contiguous()
+        dq, dkv = torch.empty_like(qc), torch.empty_like(kv)
+        _ext.attn_bwd(qc, kv[:, :, 0], kv[:, :, 1], out, lse, grad_out, scale, dq, dkv[:, :, 0], dkv[:, :, 1],
+                      mask_log2 if has_mask else None, p_drop, seed, st if has_st else None)
+        return dq, dkv, None, None, None
+
+
+def _packed_ok(t, mask):
+    return (t.is_cuda and t.dtype == torch.bfloat16 and t.shape[-1] == 64 and t.is_contiguous()
+            and (mask is None or (mask.dim() == 4 and mask.shape[1] == 1 and mask.shape[2] == 1)))
+
+
+def attention_packed(qkv, scale, dropout_p=0.0, mask=None):
     """Self-attention on the output of a fused QKV projection, qkv (B, L, 3, H, D) -> (B, L, H, D).
     bf16 / D=64 / CUDA goes to the fused kernels; anything else to the reference composition."""
-    if qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.shape[-1] == 64 and dropout_p == 0.0 \
-            and qkv.is_contiguous():
-        return _PackedAttention.apply(qkv, scale)
-    ctx, _ = attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], None, scale, dropout_p=dropout_p)
+    if _packed_ok(qkv, mask):
+        return _PackedAttention.apply(qkv, scale, _mask_log2(mask, qkv.shape[0], qkv.shape[1]), float(dropout_p))
+    ctx, _ = attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], mask, scale, dropout_p=dropout_p)
+    return ctx
+
+
+def attention_q_kv(q, kv, scale, dropout_p=0.0, mask=None):
+    """Cross-attention: q (B, Lq, H, D), kv (B, Lk, 2, H, D) from a fused K/V projection -> (B, Lq, H, D)."""
+    if _packed_ok(kv, mask) and q.is_cuda and q.dtype == torch.bfloat16 and q.stride(-1) == 1:
+        return _QKVAttention.apply(q, kv, scale, _mask_log2(mask, kv.shape[0], kv.shape[1]), float(dropout_p))
+    ctx, _ = attention(q, kv[:, :, 0], kv[:, :, 1], mask, scale, dropout_p=dropout_p)
     return ctx
 
 

@@ -276,8 +276,15 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
+    host_ms = 0.0
+    host_each = []
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         loss = step()
+        if os.environ.get("BQ_SYNC_EACH_STEP") == "1":
+            torch.cuda.synchronize()
+        host_each.append((time.perf_counter() - h0) * 1e3)
+        host_ms += host_each[-1]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -295,6 +302,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     assert torch.isfinite(loss).item()
+    if rank == 0:
+        print("host-side launch time per step: %.2f ms  [%s]" % (host_ms / args.steps, " ".join("%.1f" % h for h in host_each)), file=sys.stderr)
 
     if rank == 0:
         ops = timer.summary()

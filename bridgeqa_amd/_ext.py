@@ -55,9 +55,9 @@ _lib.bq_attn_bwd.argtypes = [_vp] * 14 + [_i] * 6 + [_l] * 9 + [_f, _f, _u, _vp,
 _lib.bq_attn_bwd.restype = ctypes.c_int
 _lib.bq_transpose_pad.argtypes = [_vp, _vp, _i, _i, _i, _i, _l, _l, _l, _vp]
 _lib.bq_transpose_pad.restype = ctypes.c_int
-_lib.bq_drop_add_ln_fwd.argtypes = [_vp] * 7 + [_i, _i, _f, _f, _u, _vp, _vp]
+_lib.bq_drop_add_ln_fwd.argtypes = [_vp] * 8 + [_i, _i, _f, _f, _u, _vp, _vp]
 _lib.bq_drop_add_ln_fwd.restype = ctypes.c_int
-_lib.bq_drop_add_ln_bwd.argtypes = [_vp] * 10 + [_i, _i, _f, _f, _u, _vp, _vp]
+_lib.bq_drop_add_ln_bwd.argtypes = [_vp] * 11 + [_i, _i, _f, _f, _u, _vp, _vp]
 _lib.bq_drop_add_ln_bwd.restype = ctypes.c_int
 _lib.bq_fps_workspace_bytes.argtypes = [_i, _i]
 _lib.bq_fps_workspace_bytes.restype = ctypes.c_size_t
@@ -312,6 +312,22 @@ def transpose_v(v, Lp):
     return vt
 
 
+_lib.bq_transpose_pad3.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]
+_lib.bq_transpose_pad3.restype = ctypes.c_int
+
+
+def transpose3(ts, Lps):
+    """three transpose_v in one launch: ts = three (B, L_i, H, 64) views (same B, H) -> three (B, H, 64, Lp_i)"""
+    B, _, H, D = ts[0].shape
+    outs = [torch.empty(B, H, D, Lp, dtype=t.dtype, device=t.device) for t, Lp in zip(ts, Lps)]
+    vp3, i3, l3 = ctypes.c_void_p * 3, ctypes.c_int * 3, ctypes.c_long * 3
+    _check(_lib.bq_transpose_pad3(vp3(*[t.data_ptr() for t in ts]), vp3(*[o.data_ptr() for o in outs]),
+                                  i3(*[t.shape[1] for t in ts]), i3(*Lps), l3(*[t.stride(0) for t in ts]),
+                                  l3(*[t.stride(1) for t in ts]), l3(*[t.stride(2) for t in ts]), B, H, _stream()),
+           "transpose_pad3")
+    return outs
+
+
 LOG2E = 1.4426950408889634
 
 
@@ -363,7 +379,7 @@ def attn_bwd(q, k, v, out, lse, grad_out, scale, dq, dk, dv, mask_log2=None, p_d
         if not out.is_contiguous():
             raise RuntimeError("attn_bwd: the forward output must be contiguous")
         delta = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)  # filled by the dQ kernel
-        qt, kt, gt = transpose_v(q, Lqp), transpose_v(k, Lkp), transpose_v(grad_out, Lqp)
+        qt, kt, gt = transpose3((q, k, grad_out), (Lqp, Lkp, Lqp))
         qs, ks, gs = _bhd_strides(q), _bhd_strides(k), _bhd_strides(grad_out)
         _check(_lib.bq_attn_bwd(_p(q), _p(k), _p(v), _p(qt), _p(kt), _p(grad_out), _p(gt), _p(lse), _p(out),
                                 _p(delta), _p(mask_log2), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, Lqp, Lkp, *qs, *ks, *gs,
@@ -373,41 +389,67 @@ def attn_bwd(q, k, v, out, lse, grad_out, scale, dq, dk, dv, mask_log2=None, p_d
 
 _lib.bq_colsum_chunks.argtypes = [_i]
 _lib.bq_colsum_chunks.restype = ctypes.c_int
-_lib.bq_colsum_bf16.argtypes = [_vp, _vp, _i, _i, _vp]
+_lib.bq_colsum_bf16.argtypes = [_vp, _vp, _i, _i, _vp, _vp, _vp]
 _lib.bq_colsum_bf16.restype = ctypes.c_int
+
+_COLSUM_SLOTS = 1 << 16
+_colsum_counters = {}
+_colsum_next = [0]
+
+
+def _colsum_counter(device, n):
+    """n zeroed, self-resetting completion counters that no other in-flight colsum launch uses (rotating slots)"""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    pool = _colsum_counters.get(key)
+    if pool is None:
+        pool = _colsum_counters[key] = torch.zeros(_COLSUM_SLOTS, dtype=torch.int32, device=device)
+    if _colsum_next[0] + n > _COLSUM_SLOTS:
+        _colsum_next[0] = 0
+    base = _colsum_next[0]
+    _colsum_next[0] += n
+    return pool.data_ptr() + 4 * base
 
 
 def colsum(g2d):
-    """f32 column sums of a contiguous bf16 (M, N) matrix (bias gradients), N % 4 == 0."""
+    """f32 column sums of a contiguous bf16 (M, N) matrix (bias gradients), N % 4 == 0.  One launch."""
     M, N = g2d.shape
     with torch.cuda.device(g2d.device):
-        out = (torch.zeros if _lib.bq_colsum_chunks(M) > 1 else torch.empty)(N, dtype=torch.float32, device=g2d.device)
-        _check(_lib.bq_colsum_bf16(_p(g2d), _p(out), M, N, _stream()), "colsum")
+        out = torch.empty(N, dtype=torch.float32, device=g2d.device)
+        chunks = _lib.bq_colsum_chunks(M)
+        part = cnt = None
+        if chunks > 1:
+            part = torch.empty(chunks * N, dtype=torch.float32, device=g2d.device)
+            cnt = _colsum_counter(g2d.device, (N + 255) // 256)
+        _check(_lib.bq_colsum_bf16(_p(g2d), _p(out), M, N, _p(part), cnt, _stream()), "colsum")
     return out
 
 
 # ---- fused dropout + residual + LayerNorm (csrc/ln.hip) ---------------------------------------------
-def drop_add_ln_fwd(x, residual, gamma, beta, eps, p_drop, seed, seed_tensor):
-    """y = LayerNorm(dropout(x) + residual); x, residual bf16 (..., H) contiguous.  Returns y, mean, rstd."""
+def drop_add_ln_fwd(x, residual, gamma, beta, eps, p_drop, seed, seed_tensor, want_sum=False):
+    """y = LayerNorm(dropout(x) + residual); x, residual bf16 (..., H) contiguous, residual may be None.
+    Returns y, sum (dropout(x) + residual in bf16, or None unless want_sum), mean, rstd."""
     H = x.shape[-1]
     M = x.numel() // H
     with torch.cuda.device(x.device):
         y = torch.empty_like(x)
+        s = torch.empty_like(x) if want_sum else None
         mean = torch.empty(M, dtype=torch.float32, device=x.device)
         rstd = torch.empty(M, dtype=torch.float32, device=x.device)
-        _check(_lib.bq_drop_add_ln_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, H,
-                                       float(eps), float(p_drop), int(seed) & 0xFFFFFFFF, _p(seed_tensor), _stream()),
-               "drop_add_ln_fwd")
-    return y, mean, rstd
+        _check(_lib.bq_drop_add_ln_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(y), _p(s), _p(mean), _p(rstd), M,
+                                       H, float(eps), float(p_drop), int(seed) & 0xFFFFFFFF, _p(seed_tensor),
+                                       _stream()), "drop_add_ln_fwd")
+    return y, s, mean, rstd
 
 
-def drop_add_ln_bwd(x, residual, gamma, dy, mean, rstd, eps, p_drop, seed, seed_tensor):
+def drop_add_ln_bwd(x, residual, gamma, dy, mean, rstd, eps, p_drop, seed, seed_tensor, dsum=None):
+    """-> dx, dresidual (None when residual is None), dgamma, dbeta; dsum = gradient of the `sum` output"""
     H = x.shape[-1]
     M = x.numel() // H
     with torch.cuda.device(x.device):
-        dx, dres = torch.empty_like(x), torch.empty_like(x)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if residual is not None else None
         dgb = torch.zeros(2, H, dtype=torch.float32, device=x.device)
-        _check(_lib.bq_drop_add_ln_bwd(_p(x), _p(residual), _p(gamma), _p(dy), _p(mean), _p(rstd), _p(dx), _p(dres),
-                                       _p(dgb[0]), _p(dgb[1]), M, H, float(eps), float(p_drop),
+        _check(_lib.bq_drop_add_ln_bwd(_p(x), _p(residual), _p(gamma), _p(dy), _p(dsum), _p(mean), _p(rstd), _p(dx),
+                                       _p(dres), _p(dgb[0]), _p(dgb[1]), M, H, float(eps), float(p_drop),
                                        int(seed) & 0xFFFFFFFF, _p(seed_tensor), _stream()), "drop_add_ln_bwd")
     return dx, dres, dgb[0], dgb[1]

@@ -4,6 +4,7 @@
 // One wave per row (hidden size = 64 * 4 * NCH, 768 -> NCH = 3), values stay in registers, statistics by
 // DPP wave sums; the dropout mask is a stateless hash (regenerated in the backward, nothing stored).
 // Also here: the padded transpose the attention kernels want (one launch instead of zeros + strided copy).
+#include <cstdint>
 #include "bq_common.h"
 
 namespace bq {
@@ -40,7 +41,8 @@ __device__ __forceinline__ void load_z(const __bf16 *x, const __bf16 *res, long 
   for (int ch = 0; ch < NCH; ++ch) {
     const int c0 = ch * 256 + lane * 4;
     const bf16x4 xv = *reinterpret_cast<const bf16x4 *>(x + rowoff + c0);
-    const bf16x4 rv = *reinterpret_cast<const bf16x4 *>(res + rowoff + c0);
+    bf16x4 rv = {(__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f};
+    if (res) rv = *reinterpret_cast<const bf16x4 *>(res + rowoff + c0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float v = (float)xv[j];
@@ -55,6 +57,7 @@ __global__ __launch_bounds__(256) void drop_add_ln_fwd_kernel(const __bf16 *__re
                                                               const __bf16 *__restrict__ res,
                                                               const float *__restrict__ gamma,
                                                               const float *__restrict__ beta, __bf16 *__restrict__ y,
+                                                              __bf16 *__restrict__ sum_out,
                                                               float *__restrict__ mean_out,
                                                               float *__restrict__ rstd_out, LnArgs a) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -82,6 +85,11 @@ __global__ __launch_bounds__(256) void drop_add_ln_fwd_kernel(const __bf16 *__re
     o[2] = (__bf16)((z[ch * 4 + 2] - mean) * rstd * g.z + bt.z);
     o[3] = (__bf16)((z[ch * 4 + 3] - mean) * rstd * g.w + bt.w);
     *reinterpret_cast<bf16x4 *>(y + rowoff + c0) = o;
+    if (sum_out) {  // the residual stream itself (pre-LN blocks carry it on)
+      bf16x4 zs;
+      zs[0] = (__bf16)z[ch * 4 + 0]; zs[1] = (__bf16)z[ch * 4 + 1]; zs[2] = (__bf16)z[ch * 4 + 2]; zs[3] = (__bf16)z[ch * 4 + 3];
+      *reinterpret_cast<bf16x4 *>(sum_out + rowoff + c0) = zs;
+    }
   }
   if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
@@ -93,6 +101,7 @@ __global__ __launch_bounds__(256) void drop_add_ln_bwd_kernel(const __bf16 *__re
                                                               const __bf16 *__restrict__ res,
                                                               const float *__restrict__ gamma,
                                                               const __bf16 *__restrict__ dy,
+                                                              const __bf16 *__restrict__ dsum,
                                                               const float *__restrict__ mean_in,
                                                               const float *__restrict__ rstd_in,
                                                               __bf16 *__restrict__ dx, __bf16 *__restrict__ dres,
@@ -137,17 +146,19 @@ __global__ __launch_bounds__(256) void drop_add_ln_bwd_kernel(const __bf16 *__re
     for (int ch = 0; ch < NCH; ++ch) {
       const int c0 = ch * 256 + lane * 4;
       bf16x4 ox, orr;
+      bf16x4 ds = {(__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f};
+      if (dsum) ds = *reinterpret_cast<const bf16x4 *>(dsum + rowoff + c0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int i = ch * 4 + j;
-        const float dz = rstd * (g[i] - s1 - z[i] * s2);
+        const float dz = rstd * (g[i] - s1 - z[i] * s2) + (float)ds[j];
         orr[j] = (__bf16)dz;
         float dxv = dz;
         if (a.thresh) dxv = ln_keep(seed, row, c0 + j, a.thresh) ? dz * a.inv_keep : 0.0f;
         ox[j] = (__bf16)dxv;
       }
       *reinterpret_cast<bf16x4 *>(dx + rowoff + c0) = ox;
-      *reinterpret_cast<bf16x4 *>(dres + rowoff + c0) = orr;
+      if (dres) *reinterpret_cast<bf16x4 *>(dres + rowoff + c0) = orr;
     }
   }
 #pragma unroll
@@ -164,97 +175,191 @@ __global__ __launch_bounds__(256) void drop_add_ln_bwd_kernel(const __bf16 *__re
   }
 }
 
-// out[bh][d][l] = in[b][l][h][d] for l < L, 0 for L <= l < Lp   (bf16; in given by element strides)
-__global__ __launch_bounds__(256) void transpose_pad_kernel(const __bf16 *__restrict__ in, __bf16 *__restrict__ out,
-                                                            int H, int L, int Lp, long bs, long rs, long hs) {
-  __shared__ __bf16 tile[64][66];
-  const int bh = blockIdx.y, b = bh / H, hd = bh % H;
+// out[bh][d][l] = in[b][l][h][d] for l < L, 0 for L <= l < Lp   (bf16; in given by element strides, d-contiguous
+// and 8-B aligned rows).  Up to three tensors per launch (blockIdx.z): the backward wants q^T, k^T and dO^T at once.
+struct TransposeJob {
+  const __bf16 *in;
+  __bf16 *out;
+  int L, Lp;
+  long bs, rs, hs;
+};
+struct TransposeJobs {
+  TransposeJob j[3];
+};
+
+__global__ __launch_bounds__(256) void transpose_pad_kernel(TransposeJobs jobs, int H) {
+  __shared__ __bf16 tile[64][68];
+  const TransposeJob &J = jobs.j[blockIdx.z];
   const int l0 = blockIdx.x * 64;
-  const __bf16 *src = in + b * bs + hd * hs;
-  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-    const int l = i >> 6, d = i & 63;
-    tile[l][d] = (l0 + l < L) ? src[(long)(l0 + l) * rs + d] : (__bf16)0.0f;
+  if (l0 >= J.Lp) return;
+  const int bh = blockIdx.y, b = bh / H, hd = bh % H;
+  const __bf16 *src = J.in + b * J.bs + hd * J.hs;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int i = threadIdx.x + it * 256, l = i >> 4, d = (i & 15) * 4;
+    bf16x4 v = {(__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f};
+    if (l0 + l < J.L) v = *reinterpret_cast<const bf16x4 *>(src + (long)(l0 + l) * J.rs + d);
+    *reinterpret_cast<bf16x4 *>(&tile[l][d]) = v;
   }
   __syncthreads();
-  __bf16 *dst = out + (long)bh * 64 * Lp + l0;
-  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-    const int d = i >> 6, l = i & 63;
-    dst[(long)d * Lp + l] = tile[l][d];
+  __bf16 *dst = J.out + (long)bh * 64 * J.Lp + l0;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int i = threadIdx.x + it * 256, d = i >> 4, l = (i & 15) * 4;
+    bf16x4 v;
+    v[0] = tile[l][d]; v[1] = tile[l + 1][d]; v[2] = tile[l + 2][d]; v[3] = tile[l + 3][d];
+    *reinterpret_cast<bf16x4 *>(dst + (long)d * J.Lp + l) = v;
   }
 }
 
 // Column sums of a bf16 (M, N) matrix into f32 (N): the bias gradient of every linear layer (db = sum_rows dY).
-// Thread = 4 adjacent columns (8-B loads), 4 row phases per workgroup folded through LDS; row chunks over
-// gridDim.y with atomics (out zero-initialised) only when M is large.
-__global__ __launch_bounds__(256) void colsum_kernel(const __bf16 *__restrict__ g, float *__restrict__ out, int M,
-                                                     int N, int rows_per_chunk) {
-  __shared__ float s[4][256];
-  const int cg = threadIdx.x & 63, ph = threadIdx.x >> 6;
-  const int c0 = (blockIdx.x * 64 + cg) * 4;
+// Workgroup = 256 columns x one chunk of rows; a lane owns VEC adjacent columns (16-B loads when VEC = 8) and the
+// 256 / (256 / VEC) row phases are folded through LDS.  With more than one row chunk each workgroup stores its
+// partial row to `partial` [chunks][N]; then either (counter != NULL, few workgroups) the LAST workgroup of a
+// column block to finish (device-scope counter, reset to 0 on exit so the slot can be reused) adds the partials in
+// chunk order -- one launch -- or (counter == NULL, large M: a release fence per workgroup means an L2 write-back
+// on this multi-XCD part, measured 10x slower than the read itself) colsum_fold_kernel does it as a second launch.
+// No zero-fill, no float atomics, bit-reproducible either way.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int VEC>
+__global__ __launch_bounds__(256) void colsum_kernel(const __bf16 *__restrict__ g, float *__restrict__ out,
+                                                     float *partial, unsigned *counter, int M, int N,
+                                                     int rows_per_chunk) {
+  constexpr int LANES = 256 / VEC, PH = 256 / LANES;
+  typedef __bf16 vec_t __attribute__((ext_vector_type(VEC)));
+  __shared__ float s[PH][256];
+  __shared__ int last;
+  const int cg = threadIdx.x % LANES, ph = threadIdx.x / LANES;
+  const int c0 = blockIdx.x * 256 + cg * VEC;
   const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
   if (c0 < N) {
-    for (int r = r0 + ph; r < r1; r += 4) {
-      const bf16x4 v = *reinterpret_cast<const bf16x4 *>(g + (long)r * N + c0);
-      a0 += (float)v[0]; a1 += (float)v[1]; a2 += (float)v[2]; a3 += (float)v[3];
+    const __bf16 *p = g + (long)(r0 + ph) * N + c0;
+    const long step = (long)PH * N;
+    int r = r0 + ph;
+    for (; r + 3 * PH < r1; r += 4 * PH, p += 4 * step) {
+      const vec_t v0 = *reinterpret_cast<const vec_t *>(p), v1 = *reinterpret_cast<const vec_t *>(p + step),
+                  v2 = *reinterpret_cast<const vec_t *>(p + 2 * step), v3 = *reinterpret_cast<const vec_t *>(p + 3 * step);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += ((float)v0[i] + (float)v1[i]) + ((float)v2[i] + (float)v3[i]);
+    }
+    for (; r < r1; r += PH, p += step) {
+      const vec_t v = *reinterpret_cast<const vec_t *>(p);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += (float)v[i];
     }
   }
-  s[ph][cg * 4 + 0] = a0; s[ph][cg * 4 + 1] = a1; s[ph][cg * 4 + 2] = a2; s[ph][cg * 4 + 3] = a3;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[ph][cg * VEC + i] = acc[i];
   __syncthreads();
   const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c < N) {
-    const float v = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
-    if (gridDim.y == 1) out[c] = v; else atomicAdd(out + c, v);
+  float v = 0.f;
+#pragma unroll
+  for (int q = 0; q < PH; ++q) v += s[q][threadIdx.x];
+  if (gridDim.y == 1) {
+    if (c < N) out[c] = v;
+    return;
   }
+  if (c < N) partial[(long)blockIdx.y * N + c] = v;
+  if (!counter) return;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(counter + blockIdx.x, 1u) == gridDim.y - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (c < N) {
+    float t = 0.f;
+    for (int y = 0; y < (int)gridDim.y; ++y) t += __builtin_nontemporal_load(partial + (long)y * N + c);
+    out[c] = t;
+  }
+  if (threadIdx.x == 0) counter[blockIdx.x] = 0u;
+}
+
+// out[c] = sum_y partial[y][c] in a fixed order: 64 columns x 4 chunk phases per workgroup
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float *__restrict__ partial, float *__restrict__ out,
+                                                          int chunks, int N) {
+  __shared__ float s[4][64];
+  const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float t0 = 0.f, t1 = 0.f;
+  if (c < N) {
+    int y = ph;
+    for (; y + 4 < chunks; y += 8) { t0 += partial[(long)y * N + c]; t1 += partial[(long)(y + 4) * N + c]; }
+    if (y < chunks) t0 += partial[(long)y * N + c];
+  }
+  s[ph][cl] = t0 + t1;
+  __syncthreads();
+  if (ph == 0 && c < N) out[c] = (s[0][cl] + s[1][cl]) + (s[2][cl] + s[3][cl]);
 }
 
 }  // namespace bq
-
 using namespace bq;
 
-// out[n] = sum_m g[m][n]; g bf16 (M, N) row-major with N % 4 == 0, out f32 (N).  Returns in *needs_zero (host int,
-// may be NULL) whether `out` had to be zero-initialised by the caller (large M: chunked with atomics) -- call
-// bq_colsum_chunks first to know.
-extern "C" __attribute__((visibility("default"))) int bq_colsum_chunks(int M) { return M <= 4096 ? 1 : (M + 1023) / 1024; }
+// out[n] = sum_m g[m][n]; g bf16 (M, N) row-major with N % 4 == 0, out f32 (N), every element written.
+// bq_colsum_chunks(M) = C row chunks: when C > 1 the caller passes `partial` (C * N floats, uninitialised), and for
+// M <= BQ_COLSUM_ONE_LAUNCH_ROWS also `counter` ((N + 255) / 256 unsigned ints that are ZERO on entry; the kernel
+// leaves them zero) -- counters of launches that may run concurrently must not alias.  Larger M: two launches.
+#define BQ_COLSUM_ONE_LAUNCH_ROWS 2048
+extern "C" __attribute__((visibility("default"))) int bq_colsum_chunks(int M) {
+  const int rpc = M <= BQ_COLSUM_ONE_LAUNCH_ROWS ? 32 : 128;
+  return M <= rpc ? 1 : (M + rpc - 1) / rpc;
+}
 
 extern "C" __attribute__((visibility("default"))) int bq_colsum_bf16(const void *g, float *out, int M, int N,
-                                                                     void *stream) {
+                                                                     float *partial, unsigned *counter, void *stream) {
   BQ_REQUIRE(M >= 0 && N > 0 && N % 4 == 0, BQ_EINVAL, "colsum: bad extents");
-  BQ_REQUIRE(g && out, BQ_EINVAL, "colsum: null pointer");
+  BQ_REQUIRE((g || M == 0) && out, BQ_EINVAL, "colsum: null pointer");
   const int chunks = bq_colsum_chunks(M);
-  const int rpc = chunks == 1 ? (M > 0 ? M : 1) : 1024;
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, chunks), dim3(256), 0, (hipStream_t)stream,
-                     (const __bf16 *)g, out, M, N, rpc);
+  const bool one_launch = M <= BQ_COLSUM_ONE_LAUNCH_ROWS;
+  BQ_REQUIRE(chunks == 1 || (partial && (counter || !one_launch)), BQ_EINVAL, "colsum: workspace missing for %d chunks",
+             chunks);
+  const int rpc = chunks == 1 ? (M > 0 ? M : 1) : (one_launch ? 32 : 128);
+  const dim3 grid((N + 255) / 256, chunks);
+  unsigned *cnt = one_launch ? counter : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  if (N % 8 == 0)
+    hipLaunchKernelGGL(colsum_kernel<8>, grid, dim3(256), 0, st, (const __bf16 *)g, out, partial, cnt, M, N, rpc);
+  else
+    hipLaunchKernelGGL(colsum_kernel<4>, grid, dim3(256), 0, st, (const __bf16 *)g, out, partial, cnt, M, N, rpc);
+  if (chunks > 1 && !one_launch)
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 63) / 64), dim3(256), 0, st, partial, out, chunks, N);
   return check_launch("colsum");
 }
 
 // y = LayerNorm(dropout(x) + residual): x, residual, y bf16 (M, H) row-major, gamma/beta f32 (H), mean/rstd f32 (M)
-// saved for the backward.  H must be 256, 512, 768 or 1024.
+// saved for the backward.  H must be 256, 512, 768 or 1024.  residual may be NULL (plain LayerNorm(dropout(x)));
+// sum_out (bf16 (M, H)) may be NULL, else it receives dropout(x) + residual -- the carried residual stream of a
+// pre-LN block (reference models/vit.py:106-109).
 extern "C" __attribute__((visibility("default"))) int bq_drop_add_ln_fwd(
-    const void *x, const void *residual, const float *gamma, const float *beta, void *y, float *mean, float *rstd,
-    int M, int H, float eps, float p_drop, unsigned seed, const unsigned *seed_ptr, void *stream) {
+    const void *x, const void *residual, const float *gamma, const float *beta, void *y, void *sum_out, float *mean,
+    float *rstd, int M, int H, float eps, float p_drop, unsigned seed, const unsigned *seed_ptr, void *stream) {
   BQ_REQUIRE(M >= 0 && H > 0 && H % 256 == 0 && H <= 1024, BQ_ELIMIT, "drop_add_ln: H=%d unsupported", H);
   if (M == 0) return BQ_OK;
-  BQ_REQUIRE(x && residual && gamma && beta && y && mean && rstd, BQ_EINVAL, "drop_add_ln: null pointer");
+  BQ_REQUIRE(x && gamma && beta && y && mean && rstd, BQ_EINVAL, "drop_add_ln: null pointer");
   LnArgs a{M, H, eps, 1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr};
   const dim3 grid((M + 3) / 4);
   hipStream_t st = (hipStream_t)stream;
 #define BQ_LN_FWD(N)                                                                                           \
   hipLaunchKernelGGL(drop_add_ln_fwd_kernel<N>, grid, dim3(256), 0, st, (const __bf16 *)x, (const __bf16 *)residual, \
-                     gamma, beta, (__bf16 *)y, mean, rstd, a)
+                     gamma, beta, (__bf16 *)y, (__bf16 *)sum_out, mean, rstd, a)
   switch (H / 256) { case 1: BQ_LN_FWD(1); break; case 2: BQ_LN_FWD(2); break; case 3: BQ_LN_FWD(3); break; default: BQ_LN_FWD(4); }
 #undef BQ_LN_FWD
   return check_launch("drop_add_ln_fwd");
 }
 
-// dgamma / dbeta (f32, H) MUST be zero-initialised; dx, dresidual bf16 (M, H).
+// dgamma / dbeta (f32, H) MUST be zero-initialised; dx, dresidual bf16 (M, H).  residual / dresidual NULL together
+// for the plain form; dsum (bf16 (M, H), may be NULL) is the gradient that reached sum_out and is added to both.
 extern "C" __attribute__((visibility("default"))) int bq_drop_add_ln_bwd(
-    const void *x, const void *residual, const float *gamma, const void *dy, const float *mean, const float *rstd,
-    void *dx, void *dresidual, float *dgamma, float *dbeta, int M, int H, float eps, float p_drop, unsigned seed,
-    const unsigned *seed_ptr, void *stream) {
+    const void *x, const void *residual, const float *gamma, const void *dy, const void *dsum, const float *mean,
+    const float *rstd, void *dx, void *dresidual, float *dgamma, float *dbeta, int M, int H, float eps, float p_drop,
+    unsigned seed, const unsigned *seed_ptr, void *stream) {
   BQ_REQUIRE(M >= 0 && H > 0 && H % 256 == 0 && H <= 1024, BQ_ELIMIT, "drop_add_ln: H=%d unsupported", H);
   if (M == 0) return BQ_OK;
-  BQ_REQUIRE(x && residual && gamma && dy && mean && rstd && dx && dresidual && dgamma && dbeta, BQ_EINVAL,
+  BQ_REQUIRE(x && gamma && dy && mean && rstd && dx && dgamma && dbeta && (!residual == !dresidual), BQ_EINVAL,
              "drop_add_ln_bwd: null pointer");
   LnArgs a{M, H, eps, 1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr};
   int blocks = (M + 3) / 4;
@@ -262,7 +367,8 @@ extern "C" __attribute__((visibility("default"))) int bq_drop_add_ln_bwd(
   hipStream_t st = (hipStream_t)stream;
 #define BQ_LN_BWD(N)                                                                                            \
   hipLaunchKernelGGL(drop_add_ln_bwd_kernel<N>, dim3(blocks), dim3(256), 0, st, (const __bf16 *)x,               \
-                     (const __bf16 *)residual, gamma, (const __bf16 *)dy, mean, rstd, (__bf16 *)dx,              \
+                     (const __bf16 *)residual, gamma, (const __bf16 *)dy, (const __bf16 *)dsum, mean, rstd,      \
+                     (__bf16 *)dx,                                                                              \
                      (__bf16 *)dresidual, dgamma, dbeta, a)
   switch (H / 256) { case 1: BQ_LN_BWD(1); break; case 2: BQ_LN_BWD(2); break; case 3: BQ_LN_BWD(3); break; default: BQ_LN_BWD(4); }
 #undef BQ_LN_BWD
@@ -270,12 +376,34 @@ extern "C" __attribute__((visibility("default"))) int bq_drop_add_ln_bwd(
 }
 
 // in: bf16 (B, L, H, 64) by element strides -> out: bf16 [B*H][64][Lp], zero padded (Lp % 64 == 0)
+static int transpose_job_ok(const TransposeJob &j) {
+  return j.in && j.out && j.L > 0 && j.Lp >= j.L && j.Lp % 64 == 0 && j.rs % 4 == 0 && j.bs % 4 == 0 && j.hs % 4 == 0 &&
+         ((uintptr_t)j.in & 7) == 0 && ((uintptr_t)j.out & 7) == 0;
+}
+
 extern "C" __attribute__((visibility("default"))) int bq_transpose_pad(const void *in, void *out, int B, int H, int L,
                                                                        int Lp, long bs, long rs, long hs,
                                                                        void *stream) {
-  BQ_REQUIRE(B > 0 && H > 0 && L > 0 && Lp >= L && Lp % 64 == 0, BQ_EINVAL, "transpose_pad: bad extents");
-  BQ_REQUIRE(in && out, BQ_EINVAL, "transpose_pad: null pointer");
-  hipLaunchKernelGGL(transpose_pad_kernel, dim3(Lp / 64, B * H), dim3(256), 0, (hipStream_t)stream,
-                     (const __bf16 *)in, (__bf16 *)out, H, L, Lp, bs, rs, hs);
+  TransposeJobs jobs{};
+  jobs.j[0] = TransposeJob{(const __bf16 *)in, (__bf16 *)out, L, Lp, bs, rs, hs};
+  BQ_REQUIRE(B > 0 && H > 0 && transpose_job_ok(jobs.j[0]), BQ_EINVAL, "transpose_pad: bad extents / alignment");
+  hipLaunchKernelGGL(transpose_pad_kernel, dim3(Lp / 64, B * H, 1), dim3(256), 0, (hipStream_t)stream, jobs, H);
   return check_launch("transpose_pad");
+}
+
+// Three transposes in one launch: in[i] (B, L[i], H, 64) by strides (bs[i], rs[i], hs[i]) -> out[i] [B*H][64][Lp[i]].
+extern "C" __attribute__((visibility("default"))) int bq_transpose_pad3(const void *const *in, void *const *out,
+                                                                        const int *L, const int *Lp, const long *bs,
+                                                                        const long *rs, const long *hs, int B, int H,
+                                                                        void *stream) {
+  BQ_REQUIRE(in && out && L && Lp && bs && rs && hs && B > 0 && H > 0, BQ_EINVAL, "transpose_pad3: bad arguments");
+  TransposeJobs jobs{};
+  int maxLp = 0;
+  for (int i = 0; i < 3; ++i) {
+    jobs.j[i] = TransposeJob{(const __bf16 *)in[i], (__bf16 *)out[i], L[i], Lp[i], bs[i], rs[i], hs[i]};
+    BQ_REQUIRE(transpose_job_ok(jobs.j[i]), BQ_EINVAL, "transpose_pad3: tensor %d bad extents / alignment", i);
+    if (Lp[i] > maxLp) maxLp = Lp[i];
+  }
+  hipLaunchKernelGGL(transpose_pad_kernel, dim3(maxLp / 64, B * H, 3), dim3(256), 0, (hipStream_t)stream, jobs, H);
+  return check_launch("transpose_pad3");
 }

@@ -262,6 +262,8 @@ def linear(x, weight, bias=None, act=None):
 
 def layer_norm(x, ln, residual=None):
     """LayerNorm(x [+ residual]) with fp32 statistics; output in the compute dtype."""
+    if residual is None and _ln_kernel_ok(x, ln):
+        return _DropAddLN.apply(x, None, ln.weight, ln.bias, ln.eps, 0.0, False)
     if residual is not None:
         x = x.float() + residual.float()
     y = F.layer_norm(x.float(), ln.normalized_shape, ln.weight, ln.bias, ln.eps)
@@ -340,37 +342,58 @@ class _MaskedAttention(torch.autograd.Function):
 
 
 class _DropAddLN(torch.autograd.Function):
-    """LayerNorm(dropout(x) + residual) in one kernel each way (csrc/ln.hip)."""
+    """y = LayerNorm(dropout(x) + residual) in one kernel each way (csrc/ln.hip).  residual may be None (plain
+    LayerNorm); with want_sum the bf16 sum dropout(x) + residual is a second output (the residual stream a pre-LN
+    block carries on), and its gradient is folded into the same backward launch."""
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, eps, p_drop):
+    def forward(ctx, x, residual, weight, bias, eps, p_drop, want_sum):
         from . import _ext
         _CALL_SEED[0] += 1
         seed, st = _CALL_SEED[0] * 104729, (step_seed(x.device) if p_drop > 0 else None)
-        y, mean, rstd = _ext.drop_add_ln_fwd(x, residual, weight, bias, eps, p_drop, seed, st)
-        ctx.save_for_backward(x, residual, weight, mean, rstd, st if st is not None else x.new_empty(0))
-        ctx.cfg = (eps, p_drop, seed, st is not None)
+        y, s, mean, rstd = _ext.drop_add_ln_fwd(x, residual, weight, bias, eps, p_drop, seed, st, want_sum)
+        ctx.save_for_backward(x, residual if residual is not None else x.new_empty(0), weight, mean, rstd,
+                              st if st is not None else x.new_empty(0))
+        ctx.cfg = (eps, p_drop, seed, st is not None, residual is not None)
+        if want_sum:
+            return y, s
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dsum=None):
         from . import _ext
         x, residual, weight, mean, rstd, st = ctx.saved_tensors
-        eps, p_drop, seed, has_st = ctx.cfg
-        dx, dres, dg, db = _ext.drop_add_ln_bwd(x, residual, weight, dy.contiguous(), mean, rstd, eps, p_drop, seed,
-                                                st if has_st else None)
-        return dx, dres, dg, db, None, None
+        eps, p_drop, seed, has_st, has_res = ctx.cfg
+        if dsum is not None and not dsum.is_contiguous():
+            dsum = dsum.contiguous()
+        dx, dres, dg, db = _ext.drop_add_ln_bwd(x, residual if has_res else None, weight, dy.contiguous(), mean, rstd,
+                                                eps, p_drop, seed, st if has_st else None, dsum)
+        return dx, dres, dg, db, None, None, None
+
+
+def _ln_kernel_ok(x, ln):
+    return (_COMPUTE_DTYPE == torch.bfloat16 and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 256 == 0
+            and x.shape[-1] <= 1024 and x.is_contiguous() and ln.weight.dtype == torch.float32
+            and tuple(ln.normalized_shape) == (x.shape[-1],))
 
 
 def dropout_add_layer_norm(x, residual, ln, p_drop, training):
     """LayerNorm(dropout(x) + residual): BertSelfOutput / BertOutput tail (med.py:236-239, 313-317)."""
     p = float(p_drop) if training else 0.0
-    if (_COMPUTE_DTYPE == torch.bfloat16 and x.is_cuda and x.dtype == torch.bfloat16 and residual.dtype == torch.bfloat16
-            and x.shape[-1] % 256 == 0 and x.shape[-1] <= 1024 and x.is_contiguous() and residual.is_contiguous()
-            and ln.weight.dtype == torch.float32):
-        return _DropAddLN.apply(x, residual, ln.weight, ln.bias, ln.eps, p)
+    if _ln_kernel_ok(x, ln) and residual.dtype == torch.bfloat16 and residual.is_contiguous():
+        return _DropAddLN.apply(x, residual, ln.weight, ln.bias, ln.eps, p, False)
     h = F.dropout(x, p, training=True) if p > 0 else x
     return layer_norm(h, ln, residual=residual)
+
+
+def add_layer_norm(x, residual, ln):
+    """(s, LayerNorm(s)) with s = x + residual: the residual update of one pre-LN sub-block fused with the next
+    sub-block's norm (vit.py:106-109 `x = x + f(norm(x))` followed by the next `norm(x)`)."""
+    if _ln_kernel_ok(x, ln) and residual.dtype == torch.bfloat16 and residual.is_contiguous():
+        y, s = _DropAddLN.apply(x, residual, ln.weight, ln.bias, ln.eps, 0.0, True)
+        return s, y
+    s = x + residual
+    return s, layer_norm(s, ln)
 
 
 _MASK_CACHE = {}

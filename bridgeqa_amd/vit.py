@@ -149,6 +149,17 @@ class Block(nn.Module):
         x = x + self.drop_path(self._mlp(x))
         return x
 
+    def fusable(self, register_hook=False):
+        """plain residual adds (no stochastic depth, no checkpointing, no hooks): the block can run as
+        forward_fused with each residual add folded into the following LayerNorm"""
+        return (isinstance(self.drop_path, nn.Identity) and not register_hook
+                and not (self.use_grad_checkpointing and self.training))
+
+    def forward_fused(self, x, n1, next_norm):
+        """x: residual stream, n1 = norm1(x) (already computed).  Returns (x_out, next_norm(x_out))."""
+        x, n2 = ops.add_layer_norm(self.attn(n1), x, self.norm2)
+        return ops.add_layer_norm(self.mlp(n2), x, next_norm)
+
 
 class VisionTransformer(nn.Module):
     """vit.py:113-196.  forward(x (B,3,H,W)) -> (B, 1 + H*W/256, embed_dim)."""
@@ -196,6 +207,13 @@ class VisionTransformer(nn.Module):
         x = torch.cat((self.cls_token.expand(B, -1, -1).to(x.dtype), x), dim=1)
         x = x + self.pos_embed[:, :x.size(1), :].to(x.dtype)
         x = self.pos_drop(x)
+        last = len(self.blocks) - 1
+        if return_fm == -1 and all(blk.fusable(register_blk == i) for i, blk in enumerate(self.blocks)):
+            # same arithmetic, 2 launches per block instead of 2 adds + 2 norms (+ casts)
+            n = ops.layer_norm(x, self.blocks[0].norm1)
+            for i, blk in enumerate(self.blocks):
+                x, n = blk.forward_fused(x, n, self.blocks[i + 1].norm1 if i < last else self.norm)
+            return n
         for i, blk in enumerate(self.blocks):
             x = blk(x, register_blk == i)
             if len(self.blocks) + return_fm == i:

@@ -221,7 +221,7 @@ def test_fused_dropout_add_layernorm_fwd_bwd(dev, M, H, p):
     gamma = (torch.rand(H, generator=g) + 0.5).to(dev); beta = (torch.randn(H, generator=g) * 0.1).to(dev)
     dy = torch.randn(M, H, generator=g).to(dev).to(torch.bfloat16)
     seed = 777
-    y, mean, rstd = _ext.drop_add_ln_fwd(x, res, gamma, beta, 1e-12, p, seed, None)
+    y, _, mean, rstd = _ext.drop_add_ln_fwd(x, res, gamma, beta, 1e-12, p, seed, None)
     dx, dres, dg, db = _ext.drop_add_ln_bwd(x, res, gamma, dy, mean, rstd, 1e-12, p, seed, None)
     # reference with the same hash
     Mk = 0xFFFFFFFF
@@ -238,6 +238,46 @@ def test_fused_dropout_add_layernorm_fwd_bwd(dev, M, H, p):
     assert rel(y, want) < 1e-2
     assert rel(dx, xf.grad) < 2e-2 and rel(dres, rf.grad) < 2e-2
     assert rel(dg, gf.grad) < 2e-2 and rel(db, bf.grad) < 2e-2
+
+
+@pytest.mark.parametrize("M,H,with_res", [(300, 768, True), (300, 768, False), (4105, 768, True), (9, 512, False)])
+def test_add_layernorm_with_sum_output_and_plain_form(dev, M, H, with_res):
+    """pre-LN form of csrc/ln.hip: (s, LayerNorm(s)) with s = x + residual, gradients arriving at BOTH outputs;
+    and the plain LayerNorm(x) form (residual NULL) -- vs the fp32 composition through ops (vit.py:106-109)."""
+    from bridgeqa_amd import fusion_ops as ops
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        g = torch.Generator().manual_seed(M + H)
+        ln = torch.nn.LayerNorm(H, eps=1e-6).to(dev)
+        with torch.no_grad():
+            ln.weight.copy_(torch.rand(H, generator=g) + 0.5); ln.bias.copy_(torch.randn(H, generator=g) * 0.1)
+        x = torch.randn(M, H, generator=g).to(dev).to(torch.bfloat16).requires_grad_(True)
+        res = torch.randn(M, H, generator=g).to(dev).to(torch.bfloat16).requires_grad_(True)
+        dy = torch.randn(M, H, generator=g).to(dev).to(torch.bfloat16)
+        ds = torch.randn(M, H, generator=g).to(dev).to(torch.bfloat16)
+        xf, rf = x.detach().float().requires_grad_(True), res.detach().float().requires_grad_(True)
+        if with_res:
+            s, y = ops.add_layer_norm(x, res, ln)
+            assert s.dtype == torch.bfloat16 and y.dtype == torch.bfloat16
+            (y.float() * dy.float()).sum().add((s.float() * ds.float()).sum()).backward()
+            g_w, g_b = ln.weight.grad.clone(), ln.bias.grad.clone(); ln.zero_grad()
+            sf = xf + rf
+            yf = torch.nn.functional.layer_norm(sf, (H,), ln.weight, ln.bias, 1e-6)
+            ((yf * dy.float()).sum() + (sf * ds.float()).sum()).backward()
+        else:
+            y = ops.layer_norm(x, ln)
+            (y.float() * dy.float()).sum().backward()
+            g_w, g_b = ln.weight.grad.clone(), ln.bias.grad.clone(); ln.zero_grad()
+            yf = torch.nn.functional.layer_norm(xf, (H,), ln.weight, ln.bias, 1e-6)
+            (yf * dy.float()).sum().backward()
+        rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+        assert rel(y, yf) < 1e-2
+        assert rel(x.grad, xf.grad) < 2e-2
+        if with_res:
+            assert rel(s, sf) < 1e-2 and rel(res.grad, rf.grad) < 2e-2 and torch.equal(x.grad, res.grad)
+        assert rel(g_w, ln.weight.grad) < 2e-2 and rel(g_b, ln.bias.grad) < 2e-2
+    finally:
+        ops.set_compute_dtype(torch.float32)
 
 
 def test_twin_encoder_and_decoder_bf16_fused_path_vs_fp32(dev):
@@ -287,3 +327,28 @@ def test_twin_encoder_and_decoder_bf16_fused_path_vs_fp32(dev):
             continue
         assert p.grad is not None and torch.isfinite(p.grad).all(), name
     assert twin.encoder.layer_twin[0].crossattention.self.value.weight.grad.abs().sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N", [(0, 256), (1, 256), (31, 768), (32, 768), (33, 772), (560, 768), (577, 2304), (2049, 260),
+                                 (9232, 3072), (16 * 1025, 768)])
+def test_colsum_single_launch_matches_fp64_and_is_reproducible(dev, M, N):
+    """bias gradients: f32 column sums of a bf16 matrix, one launch, chunk partials folded by the last workgroup."""
+    from bridgeqa_amd import _ext
+    torch.manual_seed(M * 7 + N)
+    g = torch.randn(M, N, device=dev).to(torch.bfloat16)
+    ref = g.double().sum(0)
+    outs = [_ext.colsum(g) for _ in range(3)]
+    assert outs[0].shape == (N,) and outs[0].dtype == torch.float32
+    tol = 2e-6 * max(M, 1) ** 0.5 * 4 + 1e-6  # f32 accumulation of O(1) terms
+    assert (outs[0].double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])  # fixed summation order
+    # many launches in flight on two streams: the rotating completion counters must not collide
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    res = []
+    for i in range(20):
+        with torch.cuda.stream(s1 if i % 2 else s2):
+            res.append(_ext.colsum(g))
+    torch.cuda.synchronize()
+    assert all(torch.equal(r, outs[0]) for r in res)

@@ -49,15 +49,15 @@ for _name, _args in _SIGS.items():
     getattr(_lib, _name).restype = ctypes.c_int
 _l = ctypes.c_long
 _u = ctypes.c_uint
-_lib.bq_attn_fwd.argtypes = [_vp] * 6 + [_i] * 5 + [_l] * 9 + [_f, _f, _u, _vp, _vp]
+_lib.bq_attn_fwd.argtypes = [_vp] * 6 + [_i] * 5 + [_l] * 9 + [_f, _f, _u, _vp, _i, _vp]
 _lib.bq_attn_fwd.restype = ctypes.c_int
-_lib.bq_attn_bwd.argtypes = [_vp] * 14 + [_i] * 6 + [_l] * 9 + [_f, _f, _u, _vp, _vp]
+_lib.bq_attn_bwd.argtypes = [_vp] * 14 + [_i] * 6 + [_l] * 9 + [_f, _f, _u, _vp, _i, _vp]
 _lib.bq_attn_bwd.restype = ctypes.c_int
 _lib.bq_transpose_pad.argtypes = [_vp, _vp, _i, _i, _i, _i, _l, _l, _l, _vp]
 _lib.bq_transpose_pad.restype = ctypes.c_int
-_lib.bq_drop_add_ln_fwd.argtypes = [_vp] * 8 + [_i, _i, _f, _f, _u, _vp, _vp]
+_lib.bq_drop_add_ln_fwd.argtypes = [_vp] * 9 + [_i, _i, _f, _f, _f, _i, _u, _vp, _vp]
 _lib.bq_drop_add_ln_fwd.restype = ctypes.c_int
-_lib.bq_drop_add_ln_bwd.argtypes = [_vp] * 11 + [_i, _i, _f, _f, _u, _vp, _vp]
+_lib.bq_drop_add_ln_bwd.argtypes = [_vp] * 10 + [_i, _i, _f, _f, _f, _i, _u, _vp, _vp]
 _lib.bq_drop_add_ln_bwd.restype = ctypes.c_int
 _lib.bq_fps_workspace_bytes.argtypes = [_i, _i]
 _lib.bq_fps_workspace_bytes.restype = ctypes.c_size_t
@@ -344,7 +344,7 @@ def key_mask_log2(mask, B, Lk):
     return m
 
 
-def attn_fwd(q, k, v, scale, mask_log2=None, p_drop=0.0, seed=0, seed_tensor=None):
+def attn_fwd(q, k, v, scale, mask_log2=None, p_drop=0.0, seed=0, seed_tensor=None, causal=False):
     """softmax(q k^T * scale + mask) v without materialising the scores.  q: bf16 (B, Lq, H, 64) view, k / v:
     (B, Lk, H, 64) views; mask_log2 from key_mask_log2.  Returns out (B, Lq, H, 64) bf16 contiguous and
     lse (B, H, Lq) f32 (log2 domain)."""
@@ -361,11 +361,12 @@ def attn_fwd(q, k, v, scale, mask_log2=None, p_drop=0.0, seed=0, seed_tensor=Non
         qs, ks, os_ = _bhd_strides(q), _bhd_strides(k), _bhd_strides(out)
         _check(_lib.bq_attn_fwd(_p(q), _p(k), _p(vt), _p(out), _p(lse), _p(mask_log2), B, H, Lq, Lk, Lkp, *qs, *ks,
                                 *os_, float(scale), float(p_drop), int(seed) & 0xFFFFFFFF, _p(seed_tensor),
-                                _stream()), "attn_fwd")
+                                int(bool(causal)), _stream()), "attn_fwd")
     return out, lse
 
 
-def attn_bwd(q, k, v, out, lse, grad_out, scale, dq, dk, dv, mask_log2=None, p_drop=0.0, seed=0, seed_tensor=None):
+def attn_bwd(q, k, v, out, lse, grad_out, scale, dq, dk, dv, mask_log2=None, p_drop=0.0, seed=0, seed_tensor=None,
+             causal=False):
     """Backward of attn_fwd (same mask / dropout arguments).  dq, dk, dv: preallocated bf16 views (dq strided like
     q, dk/dv like k; k and v with equal strides)."""
     B, Lq, H, D = q.shape
@@ -383,8 +384,8 @@ def attn_bwd(q, k, v, out, lse, grad_out, scale, dq, dk, dv, mask_log2=None, p_d
         qs, ks, gs = _bhd_strides(q), _bhd_strides(k), _bhd_strides(grad_out)
         _check(_lib.bq_attn_bwd(_p(q), _p(k), _p(v), _p(qt), _p(kt), _p(grad_out), _p(gt), _p(lse), _p(out),
                                 _p(delta), _p(mask_log2), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, Lqp, Lkp, *qs, *ks, *gs,
-                                float(scale), float(p_drop), int(seed) & 0xFFFFFFFF, _p(seed_tensor), _stream()),
-               "attn_bwd")
+                                float(scale), float(p_drop), int(seed) & 0xFFFFFFFF, _p(seed_tensor),
+                                int(bool(causal)), _stream()), "attn_bwd")
 
 
 _lib.bq_colsum_chunks.argtypes = [_i]
@@ -425,9 +426,12 @@ def colsum(g2d):
 
 
 # ---- fused dropout + residual + LayerNorm (csrc/ln.hip) ---------------------------------------------
-def drop_add_ln_fwd(x, residual, gamma, beta, eps, p_drop, seed, seed_tensor, want_sum=False):
-    """y = LayerNorm(dropout(x) + residual); x, residual bf16 (..., H) contiguous, residual may be None.
-    Returns y, sum (dropout(x) + residual in bf16, or None unless want_sum), mean, rstd."""
+def drop_add_ln_fwd(x, residual, gamma, beta, eps, p_drop, seed, seed_tensor, want_sum=False, p_path=0.0,
+                    rows_per_sample=0, want_dgb=False):
+    """y = LayerNorm(path(dropout(x)) + residual); x, residual bf16 (..., H) contiguous, residual may be None;
+    path = stochastic depth per sample of rows_per_sample rows (p_path = 0: identity).
+    Returns y, sum (the bf16 pre-norm sum, or None unless want_sum), mean, rstd, dgb (zeroed f32 (2, H) accumulator
+    for drop_add_ln_bwd, or None unless want_dgb)."""
     H = x.shape[-1]
     M = x.numel() // H
     with torch.cuda.device(x.device):
@@ -435,21 +439,26 @@ def drop_add_ln_fwd(x, residual, gamma, beta, eps, p_drop, seed, seed_tensor, wa
         s = torch.empty_like(x) if want_sum else None
         mean = torch.empty(M, dtype=torch.float32, device=x.device)
         rstd = torch.empty(M, dtype=torch.float32, device=x.device)
-        _check(_lib.bq_drop_add_ln_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(y), _p(s), _p(mean), _p(rstd), M,
-                                       H, float(eps), float(p_drop), int(seed) & 0xFFFFFFFF, _p(seed_tensor),
-                                       _stream()), "drop_add_ln_fwd")
-    return y, s, mean, rstd
+        dgb = torch.empty(2, H, dtype=torch.float32, device=x.device) if want_dgb else None
+        _check(_lib.bq_drop_add_ln_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(y), _p(s), _p(mean), _p(rstd),
+                                       _p(dgb), M, H, float(eps), float(p_drop), float(p_path), int(rows_per_sample),
+                                       int(seed) & 0xFFFFFFFF, _p(seed_tensor), _stream()), "drop_add_ln_fwd")
+    return y, s, mean, rstd, dgb
 
 
-def drop_add_ln_bwd(x, residual, gamma, dy, mean, rstd, eps, p_drop, seed, seed_tensor, dsum=None):
-    """-> dx, dresidual (None when residual is None), dgamma, dbeta; dsum = gradient of the `sum` output"""
+def drop_add_ln_bwd(x, residual, gamma, dy, mean, rstd, eps, p_drop, seed, seed_tensor, dsum=None, p_path=0.0,
+                    rows_per_sample=0, dgb=None):
+    """-> dx, dresidual (None when residual is None), dgamma, dbeta; dsum = gradient of the `sum` output; dgb = the
+    zeroed accumulator the forward handed out (a fresh zeros(2, H) when None)"""
     H = x.shape[-1]
     M = x.numel() // H
     with torch.cuda.device(x.device):
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if residual is not None else None
-        dgb = torch.zeros(2, H, dtype=torch.float32, device=x.device)
+        if dgb is None:
+            dgb = torch.zeros(2, H, dtype=torch.float32, device=x.device)
         _check(_lib.bq_drop_add_ln_bwd(_p(x), _p(residual), _p(gamma), _p(dy), _p(dsum), _p(mean), _p(rstd), _p(dx),
-                                       _p(dres), _p(dgb[0]), _p(dgb[1]), M, H, float(eps), float(p_drop),
-                                       int(seed) & 0xFFFFFFFF, _p(seed_tensor), _stream()), "drop_add_ln_bwd")
+                                       _p(dres), _p(dgb), M, H, float(eps), float(p_drop), float(p_path),
+                                       int(rows_per_sample), int(seed) & 0xFFFFFFFF, _p(seed_tensor), _stream()),
+               "drop_add_ln_bwd")
     return dx, dres, dgb[0], dgb[1]

@@ -58,6 +58,8 @@ struct AttnDims {
   unsigned drop_thresh;             // p * 2^32 (0 = no dropout)
   unsigned seed;                    // per-call offset ...
   const unsigned *seed_ptr;         // ... combined with a per-step device counter (graph-replay safe), may be null
+  int causal;                       // 1: key j is visible to query i only when j <= i (decoder self-attention,
+                                    // reference med.py:640-672 causal_mask), on top of the key mask
 };
 
 __device__ __forceinline__ unsigned eff_seed(const AttnDims &dm) {
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__res
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         if (last && kbase + crow(i, h) >= dm.Lk) sc[i] = -INFINITY;
+        if (dm.causal && kbase + crow(i, h) > q0 + r) sc[i] = -INFINITY;
         mloc = fmaxf(mloc, sc[i]);
       }
       mloc = xhalf_max(mloc);
@@ -339,6 +342,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const __bf16 *__restri
           if (kbase + crow(i, h) >= dm.Lk) p = 0.0f;
           if (kbase + crow(8 + i, h) >= dm.Lk) p2 = 0.0f;
         }
+        if (dm.causal) {
+          if (kbase + crow(i, h) > q0 + r) p = 0.0f;
+          if (kbase + crow(8 + i, h) > q0 + r) p2 = 0.0f;
+        }
         float g1 = pacc[i], g2 = pacc[8 + i];
         if (dm.drop_thresh) {
           g1 = drop_keep(seed, bh, q0 + r, kbase + crow(i, h), dm.drop_thresh) ? g1 * dm.inv_keep : 0.0f;
@@ -440,6 +447,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const __bf16 *__restr
           if (qbase + crow(i, h) >= dm.Lq) p = 0.0f;
           if (qbase + crow(8 + i, h) >= dm.Lq) p2 = 0.0f;
         }
+        if (dm.causal) {
+          if (qbase + crow(i, h) < k0 + r) p = 0.0f;
+          if (qbase + crow(8 + i, h) < k0 + r) p2 = 0.0f;
+        }
         float g1 = pacc[i], g2 = pacc[8 + i], pd = p, pd2 = p2;
         if (dm.drop_thresh) {
           const bool k1 = drop_keep(seed, bh, qbase + crow(i, h), k0 + r, dm.drop_thresh);
@@ -480,17 +491,19 @@ using namespace bq;
 // mask: optional f32 [B][Lkp] additive key mask ALREADY multiplied by log2(e) (0 in the padding); p_drop / seed:
 // dropout on the attention probabilities (stateless hash, regenerated by the backward); the effective seed is
 // seed_ptr[0] * 2654435761 + seed when seed_ptr (a device counter the caller bumps once per step) is given.
+// causal != 0 (Lq == Lk): keys after the query are masked as well.
 extern "C" __attribute__((visibility("default"))) int bq_attn_fwd(
     const void *Q, const void *K, const void *Vt, void *O, float *LSE, const float *mask, int B, int H, int Lq, int Lk,
     int Lkp, long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long o_bs, long o_rs, long o_hs,
-    float scale, float p_drop, unsigned seed, const unsigned *seed_ptr, void *stream) {
+    float scale, float p_drop, unsigned seed, const unsigned *seed_ptr, int causal, void *stream) {
   BQ_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && Lkp >= Lk && Lkp % 64 == 0, BQ_EINVAL, "attn_fwd: bad extents");
+  BQ_REQUIRE(!causal || Lq == Lk, BQ_EINVAL, "attn_fwd: causal needs Lq == Lk");
   BQ_REQUIRE(Q && K && Vt && O && LSE, BQ_EINVAL, "attn_fwd: null pointer");
   BQ_REQUIRE((q_rs % 8) == 0 && (k_rs % 8) == 0 && (o_rs % 4) == 0 && (q_hs % 8) == 0 && (k_hs % 8) == 0, BQ_EINVAL,
              "attn_fwd: rows must be 16-byte aligned");
   BQ_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, BQ_EINVAL, "attn_fwd: bad dropout probability");
   AttnDims dm{B, H, Lq, Lk, 0, Lkp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, o_bs, o_rs, o_hs, mask, scale,
-              1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr};
+              1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr, causal ? 1 : 0};
   const dim3 grid((Lq + AT_QB - 1) / AT_QB, B * H);
   static const int minw = getenv("BQ_ATTN_MINW") ? atoi(getenv("BQ_ATTN_MINW")) : 3;  // 3 waves/SIMD measured best (158 VGPRs, no spill)
 #define BQ_FWD(W) hipLaunchKernelGGL(attn_fwd_kernel<W>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Q, \
@@ -508,16 +521,17 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_bwd(
     const float *LSE, const void *O, float *DELTA, const float *mask, void *dQ, void *dK, void *dV, int B, int H, int Lq,
     int Lk,
     int Lqp, int Lkp, long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long g_bs, long g_rs, long g_hs,
-    float scale, float p_drop, unsigned seed, const unsigned *seed_ptr, void *stream) {
+    float scale, float p_drop, unsigned seed, const unsigned *seed_ptr, int causal, void *stream) {
   BQ_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && Lkp >= Lk && Lkp % 64 == 0 && Lqp >= Lq && Lqp % 64 == 0, BQ_EINVAL,
              "attn_bwd: bad extents");
+  BQ_REQUIRE(!causal || Lq == Lk, BQ_EINVAL, "attn_bwd: causal needs Lq == Lk");
   BQ_REQUIRE(Q && K && V && Qt && Kt && dO && dOt && LSE && O && DELTA && dQ && dK && dV, BQ_EINVAL,
              "attn_bwd: null pointer");
   BQ_REQUIRE((q_rs % 8) == 0 && (k_rs % 8) == 0 && (g_rs % 8) == 0 && (q_hs % 8) == 0 && (k_hs % 8) == 0 &&
                  (g_hs % 8) == 0, BQ_EINVAL, "attn_bwd: rows must be 16-byte aligned");
   BQ_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, BQ_EINVAL, "attn_bwd: bad dropout probability");
   BwdDims dm{B, H, Lq, Lk, Lqp, Lkp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, g_bs, g_rs, g_hs, mask, scale,
-             1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr};
+             1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr, causal ? 1 : 0};
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Lq + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, st, (const __bf16 *)Q,
                      (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)Kt, (const __bf16 *)dO, LSE,

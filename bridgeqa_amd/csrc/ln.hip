@@ -27,7 +27,17 @@ struct LnArgs {
   float eps, inv_keep;
   unsigned thresh, seed;
   const unsigned *seed_ptr;
+  // stochastic depth (timm DropPath, reference models/vit.py:107-108): the whole x row of sample row / rows_per_sample
+  // is dropped with probability path_thresh / 2^32 and scaled by path_inv_keep otherwise
+  unsigned path_thresh;
+  float path_inv_keep;
+  int rows_per_sample;
 };
+
+__device__ __forceinline__ float ln_path_scale(const LnArgs &a, unsigned seed, int row) {
+  if (!a.path_thresh) return 1.0f;
+  return ln_keep(seed ^ 0x5bd1e995u, row / a.rows_per_sample, 0x3039, a.path_thresh) ? a.path_inv_keep : 0.0f;
+}
 
 __device__ __forceinline__ unsigned ln_seed(const LnArgs &a) {
   return a.seed_ptr ? a.seed_ptr[0] * 2654435761u + a.seed : a.seed;
@@ -37,6 +47,7 @@ __device__ __forceinline__ unsigned ln_seed(const LnArgs &a) {
 template <int NCH>
 __device__ __forceinline__ void load_z(const __bf16 *x, const __bf16 *res, long rowoff, int row, int lane,
                                        const LnArgs &a, unsigned seed, float *z) {
+  const float ps = ln_path_scale(a, seed, row);
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     const int c0 = ch * 256 + lane * 4;
@@ -47,7 +58,7 @@ __device__ __forceinline__ void load_z(const __bf16 *x, const __bf16 *res, long 
     for (int j = 0; j < 4; ++j) {
       float v = (float)xv[j];
       if (a.thresh) v = ln_keep(seed, row, c0 + j, a.thresh) ? v * a.inv_keep : 0.0f;
-      z[ch * 4 + j] = v + (float)rv[j];
+      z[ch * 4 + j] = v * ps + (float)rv[j];
     }
   }
 }
@@ -59,8 +70,11 @@ __global__ __launch_bounds__(256) void drop_add_ln_fwd_kernel(const __bf16 *__re
                                                               const float *__restrict__ beta, __bf16 *__restrict__ y,
                                                               __bf16 *__restrict__ sum_out,
                                                               float *__restrict__ mean_out,
-                                                              float *__restrict__ rstd_out, LnArgs a) {
+                                                              float *__restrict__ rstd_out,
+                                                              float *__restrict__ zero_out, LnArgs a) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (zero_out && blockIdx.x == 0)  // the backward's dgamma / dbeta accumulators, cleared here for free
+    for (int c = threadIdx.x; c < 2 * a.H; c += 256) zero_out[c] = 0.0f;
   const int row = blockIdx.x * 4 + wid;
   if (row >= a.M) return;
   const unsigned seed = ln_seed(a);
@@ -95,7 +109,9 @@ __global__ __launch_bounds__(256) void drop_add_ln_fwd_kernel(const __bf16 *__re
 }
 
 // backward: rows are strided over the grid so every wave folds its rows' dgamma / dbeta in registers; one LDS
-// reduction over the 4 waves and one atomicAdd per column per workgroup at the end
+// reduction over the 4 waves and one atomicAdd per column per workgroup at the end into dgb (2, H), which the
+// FORWARD launch of the same site zeroed (zero_out).  (A last-workgroup fold behind a release fence was measured
+// 8x slower here: the fence has to write back the dx / dresidual lines this kernel just dirtied in L2.)
 template <int NCH>
 __global__ __launch_bounds__(256) void drop_add_ln_bwd_kernel(const __bf16 *__restrict__ x,
                                                               const __bf16 *__restrict__ res,
@@ -105,8 +121,7 @@ __global__ __launch_bounds__(256) void drop_add_ln_bwd_kernel(const __bf16 *__re
                                                               const float *__restrict__ mean_in,
                                                               const float *__restrict__ rstd_in,
                                                               __bf16 *__restrict__ dx, __bf16 *__restrict__ dres,
-                                                              float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                              LnArgs a) {
+                                                              float *__restrict__ dgb, LnArgs a) {
   __shared__ float s_g[4][256 * NCH], s_b[4][256 * NCH];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const unsigned seed = ln_seed(a);
@@ -124,6 +139,7 @@ __global__ __launch_bounds__(256) void drop_add_ln_bwd_kernel(const __bf16 *__re
     float z[4 * NCH], g[4 * NCH];
     load_z<NCH>(x, res, rowoff, row, lane, a, seed, z);
     const float mean = mean_in[row], rstd = rstd_in[row];
+    const float ps = ln_path_scale(a, seed, row);
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
@@ -153,8 +169,8 @@ __global__ __launch_bounds__(256) void drop_add_ln_bwd_kernel(const __bf16 *__re
         const int i = ch * 4 + j;
         const float dz = rstd * (g[i] - s1 - z[i] * s2) + (float)ds[j];
         orr[j] = (__bf16)dz;
-        float dxv = dz;
-        if (a.thresh) dxv = ln_keep(seed, row, c0 + j, a.thresh) ? dz * a.inv_keep : 0.0f;
+        float dxv = dz * ps;
+        if (a.thresh) dxv = ln_keep(seed, row, c0 + j, a.thresh) ? dxv * a.inv_keep : 0.0f;
         ox[j] = (__bf16)dxv;
       }
       *reinterpret_cast<bf16x4 *>(dx + rowoff + c0) = ox;
@@ -169,9 +185,10 @@ __global__ __launch_bounds__(256) void drop_add_ln_bwd_kernel(const __bf16 *__re
       s_b[wid][ch * 256 + lane * 4 + j] = ab[ch * 4 + j];
     }
   __syncthreads();
-  for (int c = threadIdx.x; c < 256 * NCH; c += 256) {
-    atomicAdd(dgamma + c, (s_g[0][c] + s_g[1][c]) + (s_g[2][c] + s_g[3][c]));
-    atomicAdd(dbeta + c, (s_b[0][c] + s_b[1][c]) + (s_b[2][c] + s_b[3][c]));
+  constexpr int H = 256 * NCH;
+  for (int c = threadIdx.x; c < H; c += 256) {
+    atomicAdd(dgb + c, (s_g[0][c] + s_g[1][c]) + (s_g[2][c] + s_g[3][c]));
+    atomicAdd(dgb + H + c, (s_b[0][c] + s_b[1][c]) + (s_b[2][c] + s_b[3][c]));
   }
 }
 
@@ -333,49 +350,57 @@ extern "C" __attribute__((visibility("default"))) int bq_colsum_bf16(const void 
 // y = LayerNorm(dropout(x) + residual): x, residual, y bf16 (M, H) row-major, gamma/beta f32 (H), mean/rstd f32 (M)
 // saved for the backward.  H must be 256, 512, 768 or 1024.  residual may be NULL (plain LayerNorm(dropout(x)));
 // sum_out (bf16 (M, H)) may be NULL, else it receives dropout(x) + residual -- the carried residual stream of a
-// pre-LN block (reference models/vit.py:106-109).
+// pre-LN block (reference models/vit.py:106-109).  zero_out (f32 (2, H), may be NULL) is set to 0: pass the buffer
+// that bq_drop_add_ln_bwd of this site will accumulate dgamma / dbeta into.
 extern "C" __attribute__((visibility("default"))) int bq_drop_add_ln_fwd(
     const void *x, const void *residual, const float *gamma, const float *beta, void *y, void *sum_out, float *mean,
-    float *rstd, int M, int H, float eps, float p_drop, unsigned seed, const unsigned *seed_ptr, void *stream) {
+    float *rstd, float *zero_out, int M, int H, float eps, float p_drop, float p_path, int rows_per_sample,
+    unsigned seed, const unsigned *seed_ptr, void *stream) {
   BQ_REQUIRE(M >= 0 && H > 0 && H % 256 == 0 && H <= 1024, BQ_ELIMIT, "drop_add_ln: H=%d unsupported", H);
-  if (M == 0) return BQ_OK;
+  if (M == 0) {
+    if (zero_out) (void)hipMemsetAsync(zero_out, 0, sizeof(float) * 2 * H, (hipStream_t)stream);
+    return check_launch("drop_add_ln_fwd");
+  }
   BQ_REQUIRE(x && gamma && beta && y && mean && rstd, BQ_EINVAL, "drop_add_ln: null pointer");
-  LnArgs a{M, H, eps, 1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr};
+  BQ_REQUIRE(p_path == 0.0f || rows_per_sample > 0, BQ_EINVAL, "drop_add_ln: rows_per_sample");
+  LnArgs a{M, H, eps, 1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr,
+           (unsigned)((double)p_path * 4294967296.0), 1.0f / (1.0f - p_path), rows_per_sample};
   const dim3 grid((M + 3) / 4);
   hipStream_t st = (hipStream_t)stream;
 #define BQ_LN_FWD(N)                                                                                           \
   hipLaunchKernelGGL(drop_add_ln_fwd_kernel<N>, grid, dim3(256), 0, st, (const __bf16 *)x, (const __bf16 *)residual, \
-                     gamma, beta, (__bf16 *)y, (__bf16 *)sum_out, mean, rstd, a)
+                     gamma, beta, (__bf16 *)y, (__bf16 *)sum_out, mean, rstd, zero_out, a)
   switch (H / 256) { case 1: BQ_LN_FWD(1); break; case 2: BQ_LN_FWD(2); break; case 3: BQ_LN_FWD(3); break; default: BQ_LN_FWD(4); }
 #undef BQ_LN_FWD
   return check_launch("drop_add_ln_fwd");
 }
 
-// dgamma / dbeta (f32, H) MUST be zero-initialised; dx, dresidual bf16 (M, H).  residual / dresidual NULL together
-// for the plain form; dsum (bf16 (M, H), may be NULL) is the gradient that reached sum_out and is added to both.
+// dgb: f32 (2, H) = dgamma then dbeta, ACCUMULATED into (float atomics): it must hold zeros on entry -- the
+// forward's zero_out does that.  dx, dresidual bf16 (M, H).  residual / dresidual NULL together for the plain
+// form; dsum (bf16 (M, H), may be NULL) is the gradient that reached sum_out and is added to both.
 extern "C" __attribute__((visibility("default"))) int bq_drop_add_ln_bwd(
     const void *x, const void *residual, const float *gamma, const void *dy, const void *dsum, const float *mean,
-    const float *rstd, void *dx, void *dresidual, float *dgamma, float *dbeta, int M, int H, float eps, float p_drop,
-    unsigned seed, const unsigned *seed_ptr, void *stream) {
+    const float *rstd, void *dx, void *dresidual, float *dgb, int M, int H, float eps, float p_drop, float p_path,
+    int rows_per_sample, unsigned seed, const unsigned *seed_ptr, void *stream) {
   BQ_REQUIRE(M >= 0 && H > 0 && H % 256 == 0 && H <= 1024, BQ_ELIMIT, "drop_add_ln: H=%d unsupported", H);
   if (M == 0) return BQ_OK;
-  BQ_REQUIRE(x && gamma && dy && mean && rstd && dx && dgamma && dbeta && (!residual == !dresidual), BQ_EINVAL,
+  BQ_REQUIRE(x && gamma && dy && mean && rstd && dx && dgb && (!residual == !dresidual), BQ_EINVAL,
              "drop_add_ln_bwd: null pointer");
-  LnArgs a{M, H, eps, 1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr};
+  BQ_REQUIRE(p_path == 0.0f || rows_per_sample > 0, BQ_EINVAL, "drop_add_ln_bwd: rows_per_sample");
+  LnArgs a{M, H, eps, 1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr,
+           (unsigned)((double)p_path * 4294967296.0), 1.0f / (1.0f - p_path), rows_per_sample};
   int blocks = (M + 3) / 4;
   if (blocks > 512) blocks = 512;
   hipStream_t st = (hipStream_t)stream;
 #define BQ_LN_BWD(N)                                                                                            \
   hipLaunchKernelGGL(drop_add_ln_bwd_kernel<N>, dim3(blocks), dim3(256), 0, st, (const __bf16 *)x,               \
                      (const __bf16 *)residual, gamma, (const __bf16 *)dy, (const __bf16 *)dsum, mean, rstd,      \
-                     (__bf16 *)dx,                                                                              \
-                     (__bf16 *)dresidual, dgamma, dbeta, a)
+                     (__bf16 *)dx, (__bf16 *)dresidual, dgb, a)
   switch (H / 256) { case 1: BQ_LN_BWD(1); break; case 2: BQ_LN_BWD(2); break; case 3: BQ_LN_BWD(3); break; default: BQ_LN_BWD(4); }
 #undef BQ_LN_BWD
   return check_launch("drop_add_ln_bwd");
 }
 
-// in: bf16 (B, L, H, 64) by element strides -> out: bf16 [B*H][64][Lp], zero padded (Lp % 64 == 0)
 static int transpose_job_ok(const TransposeJob &j) {
   return j.in && j.out && j.L > 0 && j.Lp >= j.L && j.Lp % 64 == 0 && j.rs % 4 == 0 && j.bs % 4 == 0 && j.hs % 4 == 0 &&
          ((uintptr_t)j.in & 7) == 0 && ((uintptr_t)j.out & 7) == 0;

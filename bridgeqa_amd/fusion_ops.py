@@ -347,14 +347,18 @@ class _DropAddLN(torch.autograd.Function):
     block carries on), and its gradient is folded into the same backward launch."""
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, eps, p_drop, want_sum):
+    def forward(ctx, x, residual, weight, bias, eps, p_drop, want_sum, p_path=0.0):
         from . import _ext
         _CALL_SEED[0] += 1
-        seed, st = _CALL_SEED[0] * 104729, (step_seed(x.device) if p_drop > 0 else None)
-        y, s, mean, rstd = _ext.drop_add_ln_fwd(x, residual, weight, bias, eps, p_drop, seed, st, want_sum)
+        seed, st = _CALL_SEED[0] * 104729, (step_seed(x.device) if (p_drop > 0 or p_path > 0) else None)
+        rps = x.shape[-2] if x.dim() >= 3 else 1  # stochastic depth drops whole samples (B, L, H)
+        need_grad = any(ctx.needs_input_grad[:4])
+        y, s, mean, rstd, dgb = _ext.drop_add_ln_fwd(x, residual, weight, bias, eps, p_drop, seed, st, want_sum, p_path,
+                                                     rps, need_grad)
         ctx.save_for_backward(x, residual if residual is not None else x.new_empty(0), weight, mean, rstd,
                               st if st is not None else x.new_empty(0))
-        ctx.cfg = (eps, p_drop, seed, st is not None, residual is not None)
+        ctx.cfg = (eps, p_drop, seed, st is not None, residual is not None, p_path, rps)
+        ctx.dgb = dgb  # dgamma / dbeta accumulator, zeroed by the forward launch; consumed by the first backward
         if want_sum:
             return y, s
         return y
@@ -363,12 +367,13 @@ class _DropAddLN(torch.autograd.Function):
     def backward(ctx, dy, dsum=None):
         from . import _ext
         x, residual, weight, mean, rstd, st = ctx.saved_tensors
-        eps, p_drop, seed, has_st, has_res = ctx.cfg
+        eps, p_drop, seed, has_st, has_res, p_path, rps = ctx.cfg
         if dsum is not None and not dsum.is_contiguous():
             dsum = dsum.contiguous()
+        dgb, ctx.dgb = ctx.dgb, None
         dx, dres, dg, db = _ext.drop_add_ln_bwd(x, residual if has_res else None, weight, dy.contiguous(), mean, rstd,
-                                                eps, p_drop, seed, st if has_st else None, dsum)
-        return dx, dres, dg, db, None, None, None
+                                                eps, p_drop, seed, st if has_st else None, dsum, p_path, rps, dgb)
+        return dx, dres, dg, db, None, None, None, None
 
 
 def _ln_kernel_ok(x, ln):
@@ -386,12 +391,16 @@ def dropout_add_layer_norm(x, residual, ln, p_drop, training):
     return layer_norm(h, ln, residual=residual)
 
 
-def add_layer_norm(x, residual, ln):
-    """(s, LayerNorm(s)) with s = x + residual: the residual update of one pre-LN sub-block fused with the next
-    sub-block's norm (vit.py:106-109 `x = x + f(norm(x))` followed by the next `norm(x)`)."""
+def add_layer_norm(x, residual, ln, drop_path=0.0):
+    """(s, LayerNorm(s)) with s = drop_path(x) + residual: the residual update of one pre-LN sub-block fused with
+    the next sub-block's norm (vit.py:106-109 `x = x + drop_path(f(norm(x)))` followed by the next `norm(x)`).
+    drop_path = per-sample stochastic depth probability (0 in eval)."""
     if _ln_kernel_ok(x, ln) and residual.dtype == torch.bfloat16 and residual.is_contiguous():
-        y, s = _DropAddLN.apply(x, residual, ln.weight, ln.bias, ln.eps, 0.0, True)
+        y, s = _DropAddLN.apply(x, residual, ln.weight, ln.bias, ln.eps, 0.0, True, float(drop_path))
         return s, y
+    if drop_path > 0.0:
+        keep = 1.0 - drop_path
+        x = x.div(keep) * x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
     s = x + residual
     return s, layer_norm(s, ln)
 
@@ -444,25 +453,25 @@ class _PackedAttention(torch.autograd.Function):
     way, so the QKV projection's backward needs no concat."""
 
     @staticmethod
-    def forward(ctx, qkv, scale, mask_log2, p_drop):
+    def forward(ctx, qkv, scale, mask_log2, p_drop, causal=False):
         from . import _ext
         seed, st = _seed_args(p_drop, qkv.device)
-        out, lse = _ext.attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], scale, mask_log2, p_drop, seed, st)
+        out, lse = _ext.attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], scale, mask_log2, p_drop, seed, st, causal)
         ctx.save_for_backward(qkv, out, lse, mask_log2 if mask_log2 is not None else qkv.new_empty(0),
                               st if st is not None else qkv.new_empty(0))
-        ctx.cfg = (scale, p_drop, seed, mask_log2 is not None, st is not None)
+        ctx.cfg = (scale, p_drop, seed, mask_log2 is not None, st is not None, causal)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         from . import _ext
         qkv, out, lse, mask_log2, st = ctx.saved_tensors
-        scale, p_drop, seed, has_mask, has_st = ctx.cfg
+        scale, p_drop, seed, has_mask, has_st, causal = ctx.cfg
         dqkv = torch.empty_like(qkv)
         _ext.attn_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out, lse, grad_out, scale,
                       dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], mask_log2 if has_mask else None, p_drop, seed,
-                      st if has_st else None)
-        return dqkv, None, None, None
+                      st if has_st else None, causal)
+        return dqkv, None, None, None, None
 
 
 class _QKVAttention(torch.autograd.Function):
@@ -495,11 +504,21 @@ def _packed_ok(t, mask):
             and (mask is None or (mask.dim() == 4 and mask.shape[1] == 1 and mask.shape[2] == 1)))
 
 
-def attention_packed(qkv, scale, dropout_p=0.0, mask=None):
+def packed_kernel_ok(qkv, key_mask):
+    """True when attention_packed(qkv, ..., key_mask) runs on the fused kernels (needed by callers that can only
+    hand over a causal mask in factored form: key mask + causal flag)"""
+    return _packed_ok(qkv, key_mask)
+
+
+def attention_packed(qkv, scale, dropout_p=0.0, mask=None, causal=False):
     """Self-attention on the output of a fused QKV projection, qkv (B, L, 3, H, D) -> (B, L, H, D).
-    bf16 / D=64 / CUDA goes to the fused kernels; anything else to the reference composition."""
+    bf16 / D=64 / CUDA goes to the fused kernels; anything else to the reference composition.  causal=True (kernel
+    path only, see packed_kernel_ok): `mask` is the (B,1,1,L) key mask and keys after the query are hidden too."""
     if _packed_ok(qkv, mask):
-        return _PackedAttention.apply(qkv, scale, _mask_log2(mask, qkv.shape[0], qkv.shape[1]), float(dropout_p))
+        return _PackedAttention.apply(qkv, scale, _mask_log2(mask, qkv.shape[0], qkv.shape[1]), float(dropout_p),
+                                      bool(causal))
+    if causal:
+        raise RuntimeError("attention_packed(causal=True) needs the kernel path; pass the full (B,1,L,L) mask instead")
     ctx, _ = attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], mask, scale, dropout_p=dropout_p)
     return ctx
 

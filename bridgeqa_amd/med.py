@@ -150,7 +150,11 @@ class BertSelfAttention(nn.Module):
                 present = (kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3))
             else:
                 qkv = ops.multi_linear(hidden_states, (self.query, self.key, self.value)).view(B, L, 3, H, D)
-                if attention_mask is not None and not (attention_mask.shape[1] == 1 and attention_mask.shape[2] == 1):
+                key_mask = getattr(attention_mask, "_bq_causal_key_mask", None)
+                if key_mask is not None and ops.packed_kernel_ok(qkv, key_mask):
+                    # decoder: the (B,1,L,L) mask is causal AND key padding -- the kernels take it factored
+                    ctx = ops.attention_packed(qkv, 1.0 / math.sqrt(D), p_drop, key_mask, causal=True)
+                elif attention_mask is not None and not (attention_mask.shape[1] == 1 and attention_mask.shape[2] == 1):
                     ctx, _ = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], attention_mask,
                                            1.0 / math.sqrt(D), dropout_p=p_drop)  # causal decoder mask
                 else:
@@ -480,7 +484,11 @@ class BertPreTrainedModel(nn.Module):
         else:
             raise ValueError("Wrong shape for input_ids (shape {}) or attention_mask (shape {})".format(
                 input_shape, attention_mask.shape))
-        return (1.0 - ext.to(torch.float32)) * -10000.0
+        out = (1.0 - ext.to(torch.float32)) * -10000.0
+        if is_decoder and attention_mask.dim() == 2 and attention_mask.shape[1] == input_shape[1]:
+            # the same mask in factored form (key padding x lower triangle) for the fused attention kernels
+            out._bq_causal_key_mask = (1.0 - attention_mask[:, None, None, :].to(torch.float32)) * -10000.0
+        return out
 
     def invert_attention_mask(self, encoder_attention_mask):
         """HF invert_attention_mask (v4.15 era): (1 - m) * -1e9 for fp32/bf16 -- not in the reference tree.

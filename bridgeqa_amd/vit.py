@@ -150,15 +150,15 @@ class Block(nn.Module):
         return x
 
     def fusable(self, register_hook=False):
-        """plain residual adds (no stochastic depth, no checkpointing, no hooks): the block can run as
-        forward_fused with each residual add folded into the following LayerNorm"""
-        return (isinstance(self.drop_path, nn.Identity) and not register_hook
-                and not (self.use_grad_checkpointing and self.training))
+        """no checkpointing, no hooks: the block can run as forward_fused with each residual add (and its
+        stochastic depth) folded into the following LayerNorm"""
+        return not register_hook and not (self.use_grad_checkpointing and self.training)
 
     def forward_fused(self, x, n1, next_norm):
         """x: residual stream, n1 = norm1(x) (already computed).  Returns (x_out, next_norm(x_out))."""
-        x, n2 = ops.add_layer_norm(self.attn(n1), x, self.norm2)
-        return ops.add_layer_norm(self.mlp(n2), x, next_norm)
+        dp = self.drop_path.drop_prob if (self.training and isinstance(self.drop_path, DropPath)) else 0.0
+        x, n2 = ops.add_layer_norm(self.attn(n1), x, self.norm2, drop_path=dp)
+        return ops.add_layer_norm(self.mlp(n2), x, next_norm, drop_path=dp)
 
 
 class VisionTransformer(nn.Module):

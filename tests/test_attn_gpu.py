@@ -211,6 +211,35 @@ def test_text_attention_routes_to_kernel_and_matches_composition(dev):
     assert ((got.float() - want).norm() / want.norm()).item() < 2e-2
 
 
+@pytest.mark.parametrize("B,H,L", [(3, 12, 5), (2, 4, 33), (1, 2, 64), (2, 3, 130)])
+def test_causal_decoder_self_attention_fwd_bwd(dev, B, H, L):
+    """decoder self-attention (med.py:771-830 causal AND padding mask) through the kernels in factored form
+    (key mask + causal flag) == fp32 composition with the full (B,1,L,L) additive mask, values and gradients."""
+    from bridgeqa_amd import fusion_ops as ops
+    g = torch.Generator().manual_seed(L)
+    qkv = torch.randn(B, L, 3, H, 64, generator=g).to(dev)
+    am = torch.ones(B, L, device=dev); am[0, L - 1:] = 0  # one padded key in sample 0
+    ids = torch.arange(L, device=dev)
+    causal = (ids[None, None, :] <= ids[None, :, None]).float().expand(B, L, L)
+    full = (1.0 - causal[:, None] * am[:, None, None, :]) * -10000.0
+    key = (1.0 - am[:, None, None, :]) * -10000.0
+    go = torch.randn(B, L, H, 64, generator=g).to(dev)
+    q32 = qkv.clone().requires_grad_(True)
+    want, _ = ops.attention(q32[:, :, 0], q32[:, :, 1], q32[:, :, 2], full, 0.125)
+    want.backward(go)
+    prev = ops.set_compute_dtype(torch.bfloat16)
+    try:
+        qb = qkv.to(torch.bfloat16).requires_grad_(True)
+        assert ops.packed_kernel_ok(qb, key)
+        got = ops.attention_packed(qb, 0.125, 0.0, key, causal=True)
+        got.backward(go.to(torch.bfloat16))
+    finally:
+        ops.set_compute_dtype(prev)
+    rel = lambda a, b: ((a.float() - b).norm() / b.norm()).item()
+    assert rel(got, want) < 2e-2
+    assert rel(qb.grad, q32.grad) < 3e-2
+
+
 @pytest.mark.parametrize("M,H,p", [(320, 768, 0.0), (320, 768, 0.1), (37, 256, 0.1), (5000, 768, 0.1), (3, 1024, 0.5)])
 def test_fused_dropout_add_layernorm_fwd_bwd(dev, M, H, p):
     """csrc/ln.hip vs the reference composition LayerNorm(dropout(x) + residual) with the SAME keep mask."""
@@ -221,7 +250,7 @@ def test_fused_dropout_add_layernorm_fwd_bwd(dev, M, H, p):
     gamma = (torch.rand(H, generator=g) + 0.5).to(dev); beta = (torch.randn(H, generator=g) * 0.1).to(dev)
     dy = torch.randn(M, H, generator=g).to(dev).to(torch.bfloat16)
     seed = 777
-    y, _, mean, rstd = _ext.drop_add_ln_fwd(x, res, gamma, beta, 1e-12, p, seed, None)
+    y, _, mean, rstd, _ = _ext.drop_add_ln_fwd(x, res, gamma, beta, 1e-12, p, seed, None)
     dx, dres, dg, db = _ext.drop_add_ln_bwd(x, res, gamma, dy, mean, rstd, 1e-12, p, seed, None)
     # reference with the same hash
     Mk = 0xFFFFFFFF
@@ -278,6 +307,31 @@ def test_add_layernorm_with_sum_output_and_plain_form(dev, M, H, with_res):
         assert rel(g_w, ln.weight.grad) < 2e-2 and rel(g_b, ln.bias.grad) < 2e-2
     finally:
         ops.set_compute_dtype(torch.float32)
+
+
+def test_add_layernorm_stochastic_depth_drops_whole_samples(dev):
+    """vit.py:107-108 x + drop_path(f): with p_path > 0 a sample's branch rows are either all dropped (sum == residual)
+    or all scaled by 1 / keep; the backward sends the same scale to dx and an unscaled gradient to the residual."""
+    from bridgeqa_amd import _ext
+    B, L, H, p = 64, 7, 768, 0.3
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, L, H, generator=g).to(dev).to(torch.bfloat16)
+    res = torch.randn(B, L, H, generator=g).to(dev).to(torch.bfloat16)
+    gamma, beta = torch.ones(H, device=dev), torch.zeros(H, device=dev)
+    y, s, mean, rstd, _ = _ext.drop_add_ln_fwd(x, res, gamma, beta, 1e-6, 0.0, 99, None, True, p, L)
+    d = (s.float() - res.float())
+    dropped = d.abs().amax(dim=(1, 2)) == 0
+    assert 5 <= int(dropped.sum()) <= 35  # ~ Binomial(64, 0.3)
+    kept = ~dropped
+    want = x.float() / (1 - p) + res.float()
+    assert ((s.float() - want)[kept].abs().max() <= 0.04 * want[kept].abs().max()).item()
+    dy = torch.zeros_like(x); dsum = torch.ones_like(x)
+    dx, dres, _, _ = _ext.drop_add_ln_bwd(x, res, gamma, dy, mean, rstd, 1e-6, 0.0, 99, None, dsum, p, L)
+    assert torch.all(dres.float() == 1)
+    assert torch.all(dx[dropped].float() == 0) and torch.allclose(dx[kept].float(), torch.tensor(1 / (1 - p), device=dev), rtol=1e-2)
+    # in LayerNorm terms: y is the norm of s
+    ref = torch.nn.functional.layer_norm(s.float(), (H,), gamma, beta, 1e-6)
+    assert ((y.float() - ref).norm() / ref.norm()).item() < 1e-2
 
 
 def test_twin_encoder_and_decoder_bf16_fused_path_vs_fp32(dev):

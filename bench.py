@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the whole train step (forward + backward + fused AdamW) from one HIP graph; "
                          "auto = on for a single GPU")
+    ap.add_argument("--schedule", choices=["auto", "phased", "single"], default=os.environ.get("BQ_SCHEDULE", "auto"),
+                    help="phased: one HIP graph per phase on two streams (bridgeqa_amd/pipeline.py); single: the "
+                         "whole step in one multi-stream graph; auto = phased for c3")
     ap.add_argument("--cpu-scenes", type=int, default=2, help="scenes in the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -91,13 +94,16 @@ def det_loss(dd):
             (dd["vote_xyz"] - dd["fp2_xyz"]).abs().mean())
 
 
+def fusion_loss(dd):
+    # LM answer loss of both streams (blip_vqa_3d.py:305-343); the fused 2D/3D states feed the reference's downstream
+    # heads (qa_module.py:735-754): keep their backward (lowrank projections + bilinear fuse) in the timed step
+    return dd["blip_loss"] + dd["fused_feat"].float().square().mean() * 1e-3
+
+
 def total_loss(dd):
     loss = det_loss(dd)
     if "blip_loss" in dd:
-        loss = loss + dd["blip_loss"]  # LM answer loss of both streams (blip_vqa_3d.py:305-343)
-        # the fused 2D/3D states feed the reference's downstream heads (qa_module.py:735-754): keep their
-        # backward (lowrank projections + bilinear fuse) in the timed step
-        loss = loss + dd["fused_feat"].float().square().mean() * 1e-3
+        loss = loss + fusion_loss(dd)
     return loss
 
 
@@ -199,7 +205,17 @@ def main():
     side = torch.cuda.Stream()
     graphed = False
 
-    if not dp:
+    phased = (not dp) and workload == "c3" and args.schedule in ("auto", "phased")
+    pipe = None
+    if phased:
+        # ---- single GPU, c3: one HIP graph per phase, image / fusion chain on one stream, detector on a second,
+        # high-priority one (bridgeqa_amd/pipeline.py) -------------------------------------------------------
+        from bridgeqa_amd.pipeline import PhasedTrainStep
+        opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-5, fused=True, capturable=use_graph)
+        pipe = PhasedTrainStep(model, batch, det_loss, fusion_loss, opt, use_graphs=use_graph,
+                               det_priority=int(os.environ.get("BQ_DET_PRIORITY", "-1")))
+        eager_step = pipe.eager_step
+    elif not dp:
         # ---- single GPU: forward + backward + fused AdamW replayed from ONE HIP graph -----------------------
         # (fused multi-tensor AdamW; NB the foreach implementation under capture makes hipStreamEndCapture segfault)
         opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-5, fused=True, capturable=use_graph)
@@ -246,14 +262,25 @@ def main():
             after_replay()
             return loss
 
-    step = eager_step
+    if phased:
+        pipe.capture(warmup=max(args.warmup, 3 if use_graph else 0))
+        graphed = use_graph
+
+        def step():
+            return pipe.step()
+        for _ in range(2):
+            step()
+        use_graph = False  # (the single-graph capture below is the other schedule)
+    else:
+        step = eager_step
     # Every eager step before a capture runs on the SAME side stream: autograd's AccumulateGrad nodes remember the
     # stream they were created on, and nodes born on the default stream make hipStreamEndCapture segfault (ROCm 7).
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(max(args.warmup, 3 if use_graph else 0)):
-            eager_step()
-    torch.cuda.current_stream().wait_stream(side)
+    if not phased:
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(args.warmup, 3 if use_graph else 0)):
+                eager_step()
+        torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     if use_graph:
         # The step is launch-bound in places (thousands of short kernels): capture it ONCE and replay.  Inputs are
@@ -292,9 +319,13 @@ def main():
     if graphed:
         # a replayed graph runs no Python, so the per-kernel HIP events are taken on an eager re-run of the same
         # step (same kernels, same stream) right after the timed region; it is not part of `value`
-        with torch.cuda.stream(side):
+        if phased:
             for _ in range(min(args.steps, 3)):
                 eager_step()
+        else:
+            with torch.cuda.stream(side):
+                for _ in range(min(args.steps, 3)):
+                    eager_step()
         torch.cuda.synchronize()
     timer.unwrap()
     if world > 1:
@@ -323,6 +354,7 @@ def main():
             "config": {"workload": WORKLOADS[workload], "global_batch": args.batch * world, "points": args.points,
                        "c_in": args.cin, "image": args.image if workload == "c3" else None,
                        "parallelism": "dp%d" % world, "hip_graph": graphed,
+                       "schedule": "phased: 6 graphs on 2 streams" if phased else "single graph",
                        "grad_exchange": ("flat bf16 all-reduce after the fwd+bwd graph, %d MB on the wire"
                                          % (reducer.nbytes_on_wire() >> 20)) if dp else None},
             "roofline": {"kernel": "fps (SA1 40000->2048)", "bound": "hbm", "achieved": round(achieved, 1),

@@ -43,6 +43,32 @@ class ScanQAHotPath(nn.Module):
         data_dict["vote_xyz"], data_dict["vote_features"] = xyz, features
         return self.proposal_net(xyz, features, data_dict)
 
+    # ---- the three stages of the path; forward() chains them, pipeline.PhasedTrainStep schedules them ----------
+    def encode_image(self, data_dict):
+        """ViT over view 0 of `images` (qa_module.py:611-620 -> blip_vqa_3d visual_encoder)"""
+        return self.blip_model.visual_encoder(data_dict["images"][:, 0])
+
+    def detect_objects(self, data_dict):
+        """detector + the proposal-feature projection the fusion consumes (qa_module.py:438-479, 219-221)"""
+        data_dict = self.detect(data_dict)
+        data_dict["object_feat"] = self.object_feat_linear(data_dict["aggregated_vote_features"])
+        return data_dict
+
+    def fuse(self, data_dict, image_embeds, object_feat=None):
+        """twin 2D/3D cross-attention encoder + answer decoder over the detector's proposals and the image tokens"""
+        if object_feat is None:
+            object_feat = data_dict["object_feat"]
+        object_mask = ~data_dict["bbox_mask"].bool().detach()  # True = not an object
+        train = data_dict.get("phase", "train") == "train"
+        out = self.blip_model(data_dict["images"][:, 0], data_dict["question"], image_embeds=image_embeds,
+                              scene_object_embeds=object_feat.clone(), scene_object_mask=~object_mask,
+                              answer=data_dict["answer"], train=train, k_test=256, data_dict=data_dict)
+        if train:
+            data_dict["blip_loss"], data_dict["fused_feat"], data_dict["fused_mask"] = out
+        else:
+            data_dict["fused_feat"], data_dict["answer_scores"], data_dict["fused_mask"] = out
+        return data_dict
+
     def forward(self, data_dict):
         """data_dict: point_clouds (B,N,3+C); with use_blip also images (B,V,3,H,W), question / answer
         (token dicts or strings).  Adds the detector outputs and, with BLIP, `blip_loss`, `fused_feat`."""
@@ -56,24 +82,13 @@ class ScanQAHotPath(nn.Module):
                 # image encoder || detector branch: FPS / ball query occupy B workgroups, the ViT wants the rest
                 with ops.fork("image", image) as f:
                     f.uses(image)
-                    image_embeds = self.blip_model.visual_encoder(image)
-                data_dict = self.detect(data_dict)
+                    image_embeds = self.encode_image(data_dict)
+                data_dict = self.detect_objects(data_dict)
                 f.join(image_embeds)
             else:
-                data_dict = self.detect(data_dict)
+                data_dict = self.detect_objects(data_dict)
         else:
-            data_dict = self.detect(data_dict)
-        object_feat = self.object_feat_linear(data_dict["aggregated_vote_features"])
-        object_mask = ~data_dict["bbox_mask"].bool().detach()  # True = not an object
-        data_dict["object_feat"] = object_feat
+            data_dict = self.detect_objects(data_dict)
         if not self.use_blip:
             return data_dict
-        train = data_dict.get("phase", "train") == "train"
-        out = self.blip_model(data_dict["images"][:, 0], data_dict["question"], image_embeds=image_embeds,
-                              scene_object_embeds=object_feat.clone(), scene_object_mask=~object_mask,
-                              answer=data_dict["answer"], train=train, k_test=256, data_dict=data_dict)
-        if train:
-            data_dict["blip_loss"], data_dict["fused_feat"], data_dict["fused_mask"] = out
-        else:
-            data_dict["fused_feat"], data_dict["answer_scores"], data_dict["fused_mask"] = out
-        return data_dict
+        return self.fuse(data_dict, image_embeds)

@@ -1,0 +1,160 @@
+"""One training step of ScanQAHotPath scheduled as phases on two HIP streams.
+
+The step has two independent heavy branches -- the image encoder (GPU-filling GEMMs) and the point-cloud detector
+(FPS / ball query / small convolutions: latency-bound, a few workgroups at a time) -- joined by the twin
+cross-attention fusion.  Measured on MI355X (profiles/r01_*): captured as ONE multi-stream HIP graph the two
+branches barely overlap (the runtime enqueues the graph's streams one list after the other, and the detector's
+kernels starve behind the encoder's on an equal-priority queue).  Here every phase is its own graph, replayed on an
+explicit stream with explicit events:
+
+    main stream (normal priority):  image fwd ............. fusion fwd+bwd -> image bwd ........ optimizer
+    det  stream (HIGH  priority):   detector fwd -> (event) ..............-> detector bwd -> (event)
+
+Autograd is cut at the two tensors that cross streams (image_embeds, object_feat): the fusion phase differentiates
+w.r.t. detached leaves and the branch backward phases are seeded with those leaf gradients -- the same gradients as
+one backward over the whole graph (chain rule), asserted in tests/test_pipeline_*.
+
+Reference: the work of one iteration of scripts/train.py -> lib/solver.py:_forward/_backward (models/qa_module.py
+forward) restricted to the hot path; the optimizer is the caller's.
+"""
+import torch
+
+from . import fusion_ops as ops
+
+
+class PhasedTrainStep(object):
+    def __init__(self, model, batch, det_loss, fusion_loss, optimizer=None, use_graphs=True, det_priority=-1,
+                 grad_hook=None):
+        """model: ScanQAHotPath (use_blip=True, train mode); batch: static device tensors (replayed in place);
+        det_loss(data_dict) -> scalar over detector outputs; fusion_loss(data_dict) -> scalar over blip_loss /
+        fused_feat; optimizer: stepped at the end of the step (None: the caller steps);
+        grad_hook: optional callable run on the main stream after both backward phases and before the optimizer
+        (data-parallel gradient exchange)."""
+        self.model, self.batch, self.det_loss, self.fusion_loss = model, batch, det_loss, fusion_loss
+        self.opt, self.grad_hook = optimizer, grad_hook
+        dev = batch["point_clouds"].device
+        self.dev = dev
+        self.s_main = torch.cuda.Stream(device=dev)
+        self.s_det = torch.cuda.Stream(device=dev, priority=det_priority)
+        self.e_det_fwd, self.e_fused, self.e_det_bwd, self.e_done = (torch.cuda.Event() for _ in range(4))
+        self.use_graphs = use_graphs
+        self.graphs = None
+        self.loss = None
+        self._state = {}
+
+    # ---- phases (each runs entirely on one stream) -----------------------------------------------------------
+    def _image_fwd(self):
+        ops.new_step(self.dev)
+        self._state["img"] = self.model.encode_image(self.batch)
+
+    def _det_fwd(self):
+        dd = self.model.detect_objects(dict(self.batch))
+        self._state["dd"] = dd
+        self._state["det_loss"] = self.det_loss(dd)
+
+    def _fusion(self):
+        st = self._state
+        img_leaf = st["img"].detach().requires_grad_(True)
+        obj_leaf = st["dd"]["object_feat"].detach().requires_grad_(True)
+        dd = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in st["dd"].items()}
+        dd = self.model.fuse(dd, img_leaf, obj_leaf)
+        loss = self.fusion_loss(dd)
+        loss.backward()
+        st["img_grad"], st["obj_grad"] = img_leaf.grad, obj_leaf.grad
+        st["fusion_loss"] = loss.detach()
+
+    def _image_bwd(self):
+        self._state["img"].backward(self._state["img_grad"])
+
+    def _det_bwd(self):
+        st = self._state
+        torch.autograd.backward([st["det_loss"], st["dd"]["object_feat"]], [None, st["obj_grad"]])
+
+    def _finish(self):
+        if self.grad_hook is not None:
+            self.grad_hook()
+        if self.opt is not None:
+            self.opt.step()
+        st = self._state
+        self.loss = st["det_loss"].detach() + st["fusion_loss"]
+
+    _ORDER = (("image_fwd", "main"), ("det_fwd", "det"), ("fusion", "main"), ("det_bwd", "det"),
+              ("image_bwd", "main"), ("finish", "main"))
+
+    def _stream(self, which):
+        return self.s_main if which == "main" else self.s_det
+
+    def _run(self, name, eager):
+        if eager:
+            getattr(self, "_" + name)()
+        else:
+            self.graphs[name].replay()
+
+    def _schedule(self, eager):
+        """launch the six phases with their cross-stream dependencies (host returns immediately)"""
+        sm, sd = self.s_main, self.s_det
+        sd.wait_event(self.e_done)  # parameters of the previous step's optimizer
+        with torch.cuda.stream(sm):
+            self._run("image_fwd", eager)
+        with torch.cuda.stream(sd):
+            self._run("det_fwd", eager)
+            self.e_det_fwd.record(sd)
+        sm.wait_event(self.e_det_fwd)
+        with torch.cuda.stream(sm):
+            self._run("fusion", eager)
+            self.e_fused.record(sm)
+        sd.wait_event(self.e_fused)
+        with torch.cuda.stream(sd):
+            self._run("det_bwd", eager)
+            self.e_det_bwd.record(sd)
+        with torch.cuda.stream(sm):
+            self._run("image_bwd", eager)
+            sm.wait_event(self.e_det_bwd)
+            self._run("finish", eager)
+            self.e_done.record(sm)
+
+    def zero_grad(self):
+        for p in self.model.parameters():
+            p.grad = None
+
+    def eager_step(self):
+        self.zero_grad()
+        self._schedule(eager=True)
+        return self.loss
+
+    def capture(self, warmup=3):
+        """`warmup` eager steps on the phase streams (autograd's AccumulateGrad nodes remember the stream they were
+        created on -- they must be born on the stream that is later captured), then one graph per phase.  Graphs of
+        one stream share a memory pool (they always replay in capture order); the two streams' pools are separate
+        because their graphs run concurrently."""
+        cur = torch.cuda.current_stream(self.dev)
+        self.s_main.wait_stream(cur)
+        self.s_det.wait_stream(cur)
+        self.e_done.record(self.s_main)
+        for _ in range(warmup):
+            self.eager_step()
+        torch.cuda.synchronize(self.dev)
+        if not self.use_graphs:
+            return self
+        self.zero_grad()
+        self._state = {}
+        pools = {"main": torch.cuda.graph_pool_handle(), "det": torch.cuda.graph_pool_handle()}
+        self.graphs = {}
+        for name, which in self._ORDER:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pools[which], stream=self._stream(which)):
+                getattr(self, "_" + name)()
+            self.graphs[name] = g
+            torch.cuda.synchronize(self.dev)
+        self.e_done.record(self.s_main)
+        return self
+
+    def step(self):
+        """one optimisation step; returns the (device) loss of this step without synchronising"""
+        if self.graphs is None:
+            return self.eager_step()
+        self._schedule(eager=False)
+        return self.loss
+
+    def wait(self):
+        torch.cuda.current_stream(self.dev).wait_event(self.e_done)

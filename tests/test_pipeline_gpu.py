@@ -1,0 +1,73 @@
+"""bridgeqa_amd/pipeline.py: the phased two-stream schedule computes the same step as one forward + one backward.
+fp32 compute, dropout off (eval-mode dropout via p=0 is not available for BatchNorm, so the model stays in train()
+and the stochastic pieces are disabled by construction: hidden/attention dropout p=0, drop_path 0)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _small_model(dev):
+    from bridgeqa_amd.hotpath import ScanQAHotPath
+    torch.manual_seed(0)
+    m = ScanQAHotPath(input_feature_dim=4, use_blip=True, blip_kwargs=dict(image_size=64)).to(dev)
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if hasattr(mod, "drop_prob"):
+            mod.drop_prob = 0.0
+    return m
+
+
+def _batch(dev, B=2, N=4096):
+    import bench
+    class A(object):
+        points, cin, image = N, 4, 64
+    return bench.make_batch(A, "c3", B, 7, dev)
+
+
+def test_phased_step_gradients_equal_single_backward(dev):
+    import bench
+    from bridgeqa_amd.pipeline import PhasedTrainStep
+    model = _small_model(dev)
+    batch = _batch(dev)
+    for p in model.parameters():
+        p.grad = None
+    loss = bench.total_loss(model(dict(batch)))
+    loss.backward()
+    want = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    pipe = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, optimizer=None, use_graphs=False)
+    pipe.capture(warmup=0)
+    got_loss = pipe.eager_step()
+    torch.cuda.synchronize()
+    assert abs(got_loss.item() - loss.item()) <= 1e-4 * abs(loss.item())
+    got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == set(want)
+    worst = max(((got[n] - want[n]).norm() / (want[n].norm() + 1e-12)).item() for n in want)
+    assert worst < 2e-3, worst  # fp32 atomics in the detector backward (three_interpolate / group grads)
+
+
+def test_phased_step_graph_replay_trains(dev):
+    """six captured graphs on two streams: replays are finite, the loss moves, parameters change every step"""
+    import bench
+    from bridgeqa_amd import fusion_ops as ops
+    from bridgeqa_amd.pipeline import PhasedTrainStep
+    prev = ops.set_compute_dtype(torch.bfloat16)
+    try:
+        model = _small_model(dev)
+        batch = _batch(dev)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True, capturable=True)
+        pipe = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, opt, use_graphs=True).capture(warmup=3)
+        w = model.blip_model.visual_encoder.blocks[0].attn.qkv.weight
+        w0 = w.detach().clone()
+        losses = []
+        for _ in range(4):
+            l = pipe.step()
+            pipe.wait()
+            torch.cuda.synchronize()
+            losses.append(l.item())
+        assert all(x == x and abs(x) < 1e6 for x in losses), losses
+        assert len(set(losses)) > 1 and not torch.equal(w0, w.detach())
+    finally:
+        ops.set_compute_dtype(prev)

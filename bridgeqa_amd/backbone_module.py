@@ -40,18 +40,41 @@ class Pointnet2Backbone(nn.Module):
             return xyz, features  # point-major fast path reads the rows in place: no 340 MB transposing copy
         return xyz, features.contiguous()
 
+    def precompute_geometry(self, point_clouds):
+        """Everything in forward() that depends on coordinates only -- FPS picks, sampled centres and ball-query
+        groups of the four SA levels, three-NN of the two FP levels -- as a flat dict of tensors.  No parameters
+        are involved, so a training loop can compute it for the NEXT batch while the current step is busy elsewhere
+        (pipeline.PhasedTrainStep) and hand it back as data_dict["geometry"]; values are identical to what
+        forward() would compute itself."""
+        from . import pointnet2_utils
+        geo = {}
+        xyz = point_clouds[..., :3].contiguous()
+        level_xyz = {}
+        with torch.no_grad():
+            for i in (1, 2, 3, 4):
+                inds, xyz, idx = getattr(self, "sa%d" % i).sample_and_query(xyz)
+                geo["sa%d_inds" % i], geo["sa%d_xyz" % i], geo["sa%d_group_idx" % i] = inds, xyz, idx
+                level_xyz[i] = xyz
+            geo["fp1_dist"], geo["fp1_idx"] = pointnet2_utils.three_nn(level_xyz[3], level_xyz[4])
+            geo["fp2_dist"], geo["fp2_idx"] = pointnet2_utils.three_nn(level_xyz[2], level_xyz[3])
+        return geo
+
     def forward(self, data_dict):
-        """data_dict["point_clouds"]: (B, N, 3 + input_feature_dim) f32, xyz first."""
+        """data_dict["point_clouds"]: (B, N, 3 + input_feature_dim) f32, xyz first; optional data_dict["geometry"]
+        from precompute_geometry(point_clouds)."""
         xyz, features = self._break_up_pc(data_dict["point_clouds"])
+        geo = data_dict.get("geometry")
         for i in (1, 2, 3, 4):
-            xyz, features, inds = getattr(self, "sa%d" % i)(xyz, features)
+            g = (geo["sa%d_inds" % i], geo["sa%d_xyz" % i], geo["sa%d_group_idx" % i]) if geo is not None else None
+            xyz, features, inds = getattr(self, "sa%d" % i)(xyz, features, geometry=g)
             if i <= 2:
                 data_dict["sa%d_inds" % i] = inds
             data_dict["sa%d_xyz" % i] = xyz
             data_dict["sa%d_features" % i] = features.contiguous()  # reference layout for consumers
         features = self.fp1(data_dict["sa3_xyz"], data_dict["sa4_xyz"], data_dict["sa3_features"],
-                            data_dict["sa4_features"])
-        features = self.fp2(data_dict["sa2_xyz"], data_dict["sa3_xyz"], data_dict["sa2_features"], features)
+                            data_dict["sa4_features"], nn=(geo["fp1_dist"], geo["fp1_idx"]) if geo is not None else None)
+        features = self.fp2(data_dict["sa2_xyz"], data_dict["sa3_xyz"], data_dict["sa2_features"], features,
+                            nn=(geo["fp2_dist"], geo["fp2_idx"]) if geo is not None else None)
         data_dict["fp2_features"] = features
         data_dict["fp2_xyz"] = data_dict["sa2_xyz"]
         num_seed = data_dict["fp2_xyz"].shape[1]

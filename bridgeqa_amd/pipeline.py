@@ -7,8 +7,13 @@ branches barely overlap (the runtime enqueues the graph's streams one list after
 kernels starve behind the encoder's on an equal-priority queue).  Here every phase is its own graph, replayed on an
 explicit stream with explicit events:
 
-    main stream (normal priority):  image fwd ............. fusion fwd+bwd -> image bwd ........ optimizer
-    det  stream (HIGH  priority):   detector fwd -> (event) ..............-> detector bwd -> (event)
+    main stream:  image fwd ............. fusion fwd+bwd ..........-> image bwd ........ optimizer
+    det  stream:  detector fwd -> (event) geometry of the NEXT batch -> detector bwd -> (event)
+
+The fusion phase is ~2000 short kernels that leave most of the 256 CUs idle, and FPS / ball query / three-NN depend
+on coordinates only (no parameters): the sampling and grouping indices of the next batch are computed under it
+(4 ms per step hidden, measured) and handed to the next detector forward through a copy, so the backward of the
+current step still reads the indices it was built with.
 
 Autograd is cut at the two tensors that cross streams (image_embeds, object_feat): the fusion phase differentiates
 w.r.t. detached leaves and the branch backward phases are seeded with those leaf gradients -- the same gradients as
@@ -23,15 +28,19 @@ from . import fusion_ops as ops
 
 
 class PhasedTrainStep(object):
-    def __init__(self, model, batch, det_loss, fusion_loss, optimizer=None, use_graphs=True, det_priority=-1,
-                 grad_hook=None):
+    def __init__(self, model, batch, det_loss, fusion_loss, optimizer=None, use_graphs=True, det_priority=0,
+                 grad_hook=None, next_batch=None, prefetch_geometry=True):
         """model: ScanQAHotPath (use_blip=True, train mode); batch: static device tensors (replayed in place);
         det_loss(data_dict) -> scalar over detector outputs; fusion_loss(data_dict) -> scalar over blip_loss /
         fused_feat; optimizer: stepped at the end of the step (None: the caller steps);
         grad_hook: optional callable run on the main stream after both backward phases and before the optimizer
-        (data-parallel gradient exchange)."""
+        (data-parallel gradient exchange); next_batch: where the loader puts the FOLLOWING step's inputs (only its
+        point_clouds are read, by the geometry prefetch; default: the same static buffers as `batch`)."""
         self.model, self.batch, self.det_loss, self.fusion_loss = model, batch, det_loss, fusion_loss
         self.opt, self.grad_hook = optimizer, grad_hook
+        self.next_batch = next_batch if next_batch is not None else batch
+        self.prefetch = prefetch_geometry
+        self._geo_next, self._geo_cur = None, None
         dev = batch["point_clouds"].device
         self.dev = dev
         self.s_main = torch.cuda.Stream(device=dev)
@@ -47,8 +56,26 @@ class PhasedTrainStep(object):
         ops.new_step(self.dev)
         self._state["img"] = self.model.encode_image(self.batch)
 
+    def _geometry(self):
+        """sampling / grouping indices of the next batch, into the persistent `next` buffers"""
+        geo = self.model.detection_backbone.precompute_geometry(self.next_batch["point_clouds"])
+        if self._geo_next is None:
+            self._geo_next = {k: v.clone() for k, v in geo.items()}
+        else:
+            for k, v in geo.items():
+                self._geo_next[k].copy_(v)
+
     def _det_fwd(self):
-        dd = self.model.detect_objects(dict(self.batch))
+        dd = dict(self.batch)
+        if self.prefetch:
+            # next -> cur: the backward of this step keeps reading `cur` while the prefetch refills `next`
+            if self._geo_cur is None:
+                self._geo_cur = {k: v.clone() for k, v in self._geo_next.items()}
+            else:
+                for k, v in self._geo_next.items():
+                    self._geo_cur[k].copy_(v)
+            dd["geometry"] = self._geo_cur
+        dd = self.model.detect_objects(dd)
         self._state["dd"] = dd
         self._state["det_loss"] = self.det_loss(dd)
 
@@ -78,7 +105,7 @@ class PhasedTrainStep(object):
         st = self._state
         self.loss = st["det_loss"].detach() + st["fusion_loss"]
 
-    _ORDER = (("image_fwd", "main"), ("det_fwd", "det"), ("fusion", "main"), ("det_bwd", "det"),
+    _ORDER = (("image_fwd", "main"), ("det_fwd", "det"), ("geometry", "det"), ("fusion", "main"), ("det_bwd", "det"),
               ("image_bwd", "main"), ("finish", "main"))
 
     def _stream(self, which):
@@ -103,6 +130,9 @@ class PhasedTrainStep(object):
         with torch.cuda.stream(sm):
             self._run("fusion", eager)
             self.e_fused.record(sm)
+        if self.prefetch:
+            with torch.cuda.stream(sd):
+                self._run("geometry", eager)
         sd.wait_event(self.e_fused)
         with torch.cuda.stream(sd):
             self._run("det_bwd", eager)
@@ -131,6 +161,9 @@ class PhasedTrainStep(object):
         self.s_main.wait_stream(cur)
         self.s_det.wait_stream(cur)
         self.e_done.record(self.s_main)
+        if self.prefetch:
+            with torch.cuda.stream(self.s_det):
+                self._geometry()  # the first step's own geometry
         for _ in range(warmup):
             self.eager_step()
         torch.cuda.synchronize(self.dev)
@@ -141,6 +174,8 @@ class PhasedTrainStep(object):
         pools = {"main": torch.cuda.graph_pool_handle(), "det": torch.cuda.graph_pool_handle()}
         self.graphs = {}
         for name, which in self._ORDER:
+            if name == "geometry" and not self.prefetch:
+                continue
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pools[which], stream=self._stream(which)):
                 getattr(self, "_" + name)()

@@ -40,14 +40,29 @@ class PointnetSAModuleVotes(nn.Module):
             mlp_spec[0] += 3
         self.mlp_module = pt_utils.SharedMLP(mlp_spec, bn=bn)
 
-    def forward(self, xyz, features=None, inds=None):
-        if inds is None:
+    def sample_and_query(self, xyz):
+        """the parameter-free part of forward: (inds, new_xyz, group_idx) for coordinates xyz (B, N, 3)"""
+        with torch.no_grad():
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
-        else:
+            new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds) \
+                .transpose(1, 2).contiguous()
+            idx = pointnet2_utils.ball_query(self.grouper.radius, self.grouper.nsample, xyz, new_xyz)
+        return inds, new_xyz, idx
+
+    def forward(self, xyz, features=None, inds=None, geometry=None):
+        """geometry: optional (inds, new_xyz, group_idx) from sample_and_query(xyz), computed ahead of time"""
+        group_idx = None
+        if geometry is not None:
+            inds, new_xyz, group_idx = geometry
             assert inds.shape[1] == self.npoint
-        new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds) \
-            .transpose(1, 2).contiguous()
-        grouped_features, _grouped_xyz = self.grouper(xyz, new_xyz, features)  # (B, 3+C, npoint, nsample)
+        else:
+            if inds is None:
+                inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+            else:
+                assert inds.shape[1] == self.npoint
+            new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds) \
+                .transpose(1, 2).contiguous()
+        grouped_features, _grouped_xyz = self.grouper(xyz, new_xyz, features, idx=group_idx)  # (B, 3+C, npoint, nsample)
         new_features = self.mlp_module(grouped_features)
         # == F.max_pool2d(kernel=[1, nsample]).squeeze(-1) (pointnet2_modules.py:259-262, 272); a row reduction
         # instead of the generic NCHW pooling kernel.  Tie routing in backward is immaterial (SURVEY §7).
@@ -70,9 +85,10 @@ class PointnetFPModule(nn.Module):
         super().__init__()
         self.mlp = pt_utils.SharedMLP(mlp, bn=bn)
 
-    def forward(self, unknown, known, unknow_feats, known_feats):
+    def forward(self, unknown, known, unknow_feats, known_feats, nn=None):
+        """nn: optional precomputed three_nn(unknown, known) = (dist, idx)"""
         if known is not None:
-            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            dist, idx = nn if nn is not None else pointnet2_utils.three_nn(unknown, known)
             dist_recip = 1.0 / (dist + 1e-8)
             norm = torch.sum(dist_recip, dim=2, keepdim=True)
             weight = dist_recip / norm

@@ -206,8 +206,11 @@ class QueryAndGroup(nn.Module):
         self.ret_grouped_xyz = ret_grouped_xyz
         self.normalize_xyz = normalize_xyz
 
-    def forward(self, xyz, new_xyz, features=None):
-        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+    def forward(self, xyz, new_xyz, features=None, idx=None):
+        """idx: optional precomputed ball_query(radius, nsample, xyz, new_xyz) (geometry prefetch: the indices depend
+        on coordinates only, not on parameters -- Pointnet2Backbone.precompute_geometry)"""
+        if idx is None:
+            idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
         from . import fusion_ops
         if (xyz.is_cuda and _ext is _hip_ext and fusion_ops.POINT_MAJOR[0] and self.use_xyz
                 and fusion_ops.compute_dtype() == torch.bfloat16):

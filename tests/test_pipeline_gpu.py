@@ -71,3 +71,19 @@ def test_phased_step_graph_replay_trains(dev):
         assert len(set(losses)) > 1 and not torch.equal(w0, w.detach())
     finally:
         ops.set_compute_dtype(prev)
+
+
+def test_precomputed_geometry_is_value_neutral(dev):
+    """Pointnet2Backbone.precompute_geometry + data_dict["geometry"] == the backbone computing its own FPS / ball
+    query / three-NN: bit-identical features and indices (the indices are a pure function of the coordinates)."""
+    from bridgeqa_amd.backbone_module import Pointnet2Backbone
+    from conftest import scene
+    torch.manual_seed(0)
+    bb = Pointnet2Backbone(input_feature_dim=3).to(dev).eval()
+    pc = scene(2, 5000, 3, 11).to(dev)
+    with torch.no_grad():
+        a = bb({"point_clouds": pc})
+        geo = bb.precompute_geometry(pc)
+        b = bb({"point_clouds": pc, "geometry": geo})
+    for k in ("sa1_inds", "sa2_inds", "fp2_inds", "sa4_xyz", "sa1_features", "sa4_features", "fp2_features"):
+        assert torch.equal(a[k], b[k]), k

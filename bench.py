@@ -270,6 +270,8 @@ def main():
             return pipe.step()
         for _ in range(2):
             step()
+        if os.environ.get("BQ_PIPE_TRACE") == "1":
+            pipe.host_times = {}
         use_graph = False  # (the single-graph capture below is the other schedule)
     else:
         step = eager_step
@@ -333,6 +335,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     assert torch.isfinite(loss).item()
+    if rank == 0 and pipe is not None and pipe.host_times:
+        print("host ms per graph launch: " + "  ".join("%s %.1f" % (k, sum(v) / len(v)) for k, v in pipe.host_times.items()),
+              file=sys.stderr)
     if rank == 0:
         print("host-side launch time per step: %.2f ms  [%s]" % (host_ms / args.steps, " ".join("%.1f" % h for h in host_each)), file=sys.stderr)
 

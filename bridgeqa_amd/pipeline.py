@@ -15,6 +15,14 @@ on coordinates only (no parameters): the sampling and grouping indices of the ne
 (4 ms per step hidden, measured) and handed to the next detector forward through a copy, so the backward of the
 current step still reads the indices it was built with.
 
+What overlaps and what does not (rocprofv3 traces, profiles/r01_*): short kernels overlap short kernels (the twin
+branches of the fusion; the geometry prefetch under the fusion), and a kernel that is already resident keeps its CUs
+(FPS under the image encoder); but while a stream of GPU-filling kernels runs (image encoder forward / backward) the
+other stream's kernels are only dispatched at its kernel boundaries, so detector and encoder phases execute almost
+back to back in launch order whatever the priorities -- CU masking would fix that at the price of taking the CUs
+away from the encoder for the whole step.  The schedule therefore puts the detector's parameter-free work where it
+overlaps and accepts the rest.
+
 Autograd is cut at the two tensors that cross streams (image_embeds, object_feat): the fusion phase differentiates
 w.r.t. detached leaves and the branch backward phases are seeded with those leaf gradients -- the same gradients as
 one backward over the whole graph (chain rule), asserted in tests/test_pipeline_*.
@@ -41,6 +49,7 @@ class PhasedTrainStep(object):
         self.next_batch = next_batch if next_batch is not None else batch
         self.prefetch = prefetch_geometry
         self._geo_next, self._geo_cur = None, None
+        self.host_times = None  # set to {} to record the host time of every graph launch (ms, per phase)
         dev = batch["point_clouds"].device
         self.dev = dev
         self.s_main = torch.cuda.Stream(device=dev)
@@ -105,7 +114,7 @@ class PhasedTrainStep(object):
         st = self._state
         self.loss = st["det_loss"].detach() + st["fusion_loss"]
 
-    _ORDER = (("image_fwd", "main"), ("det_fwd", "det"), ("geometry", "det"), ("fusion", "main"), ("det_bwd", "det"),
+    _ORDER = (("det_fwd", "det"), ("geometry", "det"), ("image_fwd", "main"), ("fusion", "main"), ("det_bwd", "det"),
               ("image_bwd", "main"), ("finish", "main"))
 
     def _stream(self, which):
@@ -114,25 +123,31 @@ class PhasedTrainStep(object):
     def _run(self, name, eager):
         if eager:
             getattr(self, "_" + name)()
+        elif self.host_times is not None:
+            import time
+            t0 = time.perf_counter()
+            self.graphs[name].replay()
+            self.host_times.setdefault(name, []).append((time.perf_counter() - t0) * 1e3)
         else:
             self.graphs[name].replay()
 
     def _schedule(self, eager):
-        """launch the six phases with their cross-stream dependencies (host returns immediately)"""
+        """Launch the phases with their cross-stream dependencies (the host returns without waiting for the GPU).
+        Host ORDER matters: a graph launch blocks the host while its stream's hardware queue is full, so at every
+        point the detector stream's launches (short, its queue is usually empty) are issued before the main
+        stream's -- otherwise the detector only gets its packets once the main stream has drained (measured)."""
         sm, sd = self.s_main, self.s_det
         sd.wait_event(self.e_done)  # parameters of the previous step's optimizer
-        with torch.cuda.stream(sm):
-            self._run("image_fwd", eager)
         with torch.cuda.stream(sd):
             self._run("det_fwd", eager)
             self.e_det_fwd.record(sd)
-        sm.wait_event(self.e_det_fwd)
+            if self.prefetch:
+                self._run("geometry", eager)
         with torch.cuda.stream(sm):
+            self._run("image_fwd", eager)
+            sm.wait_event(self.e_det_fwd)
             self._run("fusion", eager)
             self.e_fused.record(sm)
-        if self.prefetch:
-            with torch.cuda.stream(sd):
-                self._run("geometry", eager)
         sd.wait_event(self.e_fused)
         with torch.cuda.stream(sd):
             self._run("det_bwd", eager)

@@ -37,17 +37,20 @@ from . import fusion_ops as ops
 
 class PhasedTrainStep(object):
     def __init__(self, model, batch, det_loss, fusion_loss, optimizer=None, use_graphs=True, det_priority=0,
-                 grad_hook=None, next_batch=None, prefetch_geometry=True):
+                 grad_hook=None, next_batch=None, prefetch_geometry=True, eager_phases=()):
         """model: ScanQAHotPath (use_blip=True, train mode); batch: static device tensors (replayed in place);
         det_loss(data_dict) -> scalar over detector outputs; fusion_loss(data_dict) -> scalar over blip_loss /
         fused_feat; optimizer: stepped at the end of the step (None: the caller steps);
         grad_hook: optional callable run on the main stream after both backward phases and before the optimizer
         (data-parallel gradient exchange); next_batch: where the loader puts the FOLLOWING step's inputs (only its
-        point_clouds are read, by the geometry prefetch; default: the same static buffers as `batch`)."""
+        point_clouds are read, by the geometry prefetch; default: the same static buffers as `batch`);
+        eager_phases: names of phases launched kernel by kernel even when the rest replays from graphs (bench.py keeps
+        "geometry" eager so that HIP events can bracket the FPS launch inside the timed steps; ~60 launches)."""
         self.model, self.batch, self.det_loss, self.fusion_loss = model, batch, det_loss, fusion_loss
         self.opt, self.grad_hook = optimizer, grad_hook
         self.next_batch = next_batch if next_batch is not None else batch
         self.prefetch = prefetch_geometry
+        self.eager_phases = tuple(eager_phases)
         self._geo_next, self._geo_cur = None, None
         self.host_times = None  # set to {} to record the host time of every graph launch (ms, per phase)
         dev = batch["point_clouds"].device
@@ -121,7 +124,7 @@ class PhasedTrainStep(object):
         return self.s_main if which == "main" else self.s_det
 
     def _run(self, name, eager):
-        if eager:
+        if eager or name in self.eager_phases:
             getattr(self, "_" + name)()
         elif self.host_times is not None:
             import time
@@ -189,7 +192,7 @@ class PhasedTrainStep(object):
         pools = {"main": torch.cuda.graph_pool_handle(), "det": torch.cuda.graph_pool_handle()}
         self.graphs = {}
         for name, which in self._ORDER:
-            if name == "geometry" and not self.prefetch:
+            if (name == "geometry" and not self.prefetch) or name in self.eager_phases:
                 continue
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pools[which], stream=self._stream(which)):

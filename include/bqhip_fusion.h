@@ -1,0 +1,96 @@
+/* bqhip_fusion.h -- C ABI of the MI355X (gfx950) kernels behind the BLIP 2D-3D fusion half of the hot path and the
+ * bf16 / point-major forms of the grouping operator.  Same conventions as bqhip.h (raw device pointers, extents,
+ * strides in ELEMENTS, a hipStream_t passed as void*, int status, bq_last_error()).
+ *
+ * The reference has no native code here: these entry points replace COMPOSITIONS of torch operators in the
+ * reference's Python, cited per function.  bridgeqa_amd/fusion_ops.py is the only caller in this repo; the
+ * reference-side binding a maintainer would add is in INTEGRATION.md §3.
+ *
+ * Test infrastructure never links this file's library into the oracle; see oracle/README in DESIGN.md §2. */
+#ifndef BQHIP_FUSION_H
+#define BQHIP_FUSION_H
+#include "bqhip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- multi-head attention, head dim 64, bf16 operands, fp32 accumulation (csrc/attn.hip) -------------------
+ * Replaces  attn = (q @ k^T) * scale [+ mask]; attn = softmax(attn); attn = dropout(attn); out = attn @ v
+ *   models/vit.py:75-83 (Attention.forward), models/med.py:179-217 (BertSelfAttention.forward).
+ * Q (B,Lq,H,64), K/V (B,Lk,H,64) by strides (q_bs,q_rs,q_hs = batch, token, head; 64 contiguous elements);
+ * Vt = V transposed [B*H][64][Lkp], zero padded, Lkp % 64 == 0 (bq_transpose_pad);  O (B,Lq,H,64) by strides;
+ * LSE f32 [B*H][Lq] (log2 domain).  mask: NULL or f32 [B][Lkp] additive key mask ALREADY multiplied by log2(e).
+ * p_drop / seed / seed_ptr: dropout on the probabilities as a stateless hash of (seed_ptr[0]*2654435761 + seed,
+ * b*H+h, query, key) -- nothing stored, the backward regenerates it.  causal != 0 (Lq == Lk): key j visible to
+ * query i only if j <= i (med.py:771-830 decoder mask). */
+BQ_API int bq_attn_fwd(const void *Q, const void *K, const void *Vt, void *O, float *LSE, const float *mask, int B,
+                       int H, int Lq, int Lk, int Lkp, long q_bs, long q_rs, long q_hs, long k_bs, long k_rs,
+                       long k_hs, long o_bs, long o_rs, long o_hs, float scale, float p_drop, unsigned seed,
+                       const unsigned *seed_ptr, int causal, void *stream);
+
+/* Backward of bq_attn_fwd (what autograd derives from the composition above).  dQ strided like Q, dK/dV like K
+ * (V strided like K); Qt, dOt [B*H][64][Lqp], Kt [B*H][64][Lkp] zero-padded transposes; O contiguous
+ * (B,Lq,H,64) and LSE from the forward; DELTA f32 [B*H][Lq] scratch. */
+BQ_API int bq_attn_bwd(const void *Q, const void *K, const void *V, const void *Qt, const void *Kt, const void *dO,
+                       const void *dOt, const float *LSE, const void *O, float *DELTA, const float *mask, void *dQ,
+                       void *dK, void *dV, int B, int H, int Lq, int Lk, int Lqp, int Lkp, long q_bs, long q_rs,
+                       long q_hs, long k_bs, long k_rs, long k_hs, long g_bs, long g_rs, long g_hs, float scale,
+                       float p_drop, unsigned seed, const unsigned *seed_ptr, int causal, void *stream);
+
+/* in (B,L,H,64) bf16 by strides -> out [B*H][64][Lp], zero padded (replaces zeros + permute + copy_) */
+BQ_API int bq_transpose_pad(const void *in, void *out, int B, int H, int L, int Lp, long bs, long rs, long hs,
+                            void *stream);
+/* three of them in one launch (arrays of 3) */
+BQ_API int bq_transpose_pad3(const void *const *in, void *const *out, const int *L, const int *Lp, const long *bs,
+                             const long *rs, const long *hs, int B, int H, void *stream);
+
+/* ---- y = LayerNorm(path(dropout(x)) + residual) (csrc/ln.hip) -----------------------------------------------
+ * Replaces  hidden = dense(x); hidden = dropout(hidden); hidden = LayerNorm(hidden + input)
+ *   models/med.py:236-239 (BertSelfOutput), :313-317 (BertOutput)   [residual != NULL, p_drop]
+ * and       x = x + drop_path(f(norm(x)))  followed by the next norm(x)
+ *   models/vit.py:106-109 (Block.forward)                            [sum_out != NULL, p_path, rows_per_sample]
+ * and plain LayerNorm (residual NULL).  x, residual, y, sum_out bf16 (M,H) row-major, H in {256,512,768,1024};
+ * gamma/beta f32 (H); mean/rstd f32 (M) saved for the backward; zero_out: f32 (2,H) cleared by this launch (the
+ * backward's dgamma/dbeta accumulator) or NULL. */
+BQ_API int bq_drop_add_ln_fwd(const void *x, const void *residual, const float *gamma, const float *beta, void *y,
+                              void *sum_out, float *mean, float *rstd, float *zero_out, int M, int H, float eps,
+                              float p_drop, float p_path, int rows_per_sample, unsigned seed,
+                              const unsigned *seed_ptr, void *stream);
+/* dgb f32 (2,H) = dgamma, dbeta ACCUMULATED (must be zero on entry: the forward's zero_out); dsum = gradient that
+ * reached sum_out (or NULL); dresidual NULL iff residual NULL. */
+BQ_API int bq_drop_add_ln_bwd(const void *x, const void *residual, const float *gamma, const void *dy,
+                              const void *dsum, const float *mean, const float *rstd, void *dx, void *dresidual,
+                              float *dgb, int M, int H, float eps, float p_drop, float p_path, int rows_per_sample,
+                              unsigned seed, const unsigned *seed_ptr, void *stream);
+
+/* ---- bias gradient: out[n] = sum_m g[m][n], g bf16 (M,N), out f32 (N) (csrc/ln.hip) -------------------------
+ * Replaces grad_output.sum(0) of torch's LinearBackward (every nn.Linear of vit.py / med.py).
+ * C = bq_colsum_chunks(M) row chunks; C > 1 needs partial (C*N floats) and, for M <= 2048, counter ((N+255)/256
+ * zeroed unsigned ints, left zero; not shared with a concurrent launch).  Fixed summation order. */
+BQ_API int bq_colsum_chunks(int M);
+BQ_API int bq_colsum_bf16(const void *g, float *out, int M, int N, float *partial, unsigned *counter, void *stream);
+
+/* ---- grouping operator, bf16 / point-major forms (csrc/pn2_ops.hip) -----------------------------------------
+ * bq_group_concat with a bf16 (B,3+C,M,S) result / bf16 incoming gradient */
+BQ_API int bq_group_concat_bf16(const float *xyz, const float *new_xyz, const float *features, const int32_t *idx,
+                                void *out, int B, int C, int N, int M, int S, float radius, int normalize,
+                                void *stream);
+BQ_API int bq_group_concat_grad_bf16(const void *grad_out, const int32_t *idx, float *grad_features, float *grad_xyz,
+                                     float *grad_new_xyz, int B, int C, int N, int M, int S, float radius,
+                                     int normalize, void *stream);
+/* point-major: feats rows (b, n) of C floats at feats + b*f_bs + n*f_rs; out (B,M,S,3+C) f32 or bf16 (the
+ * channels-last layout MIOpen's NHWC convolutions and the next level's grouping read without a transpose);
+ * same values as bq_group_concat (pointnet2_utils.py:348-359). */
+BQ_API int bq_group_concat_pm(const float *xyz, const float *new_xyz, const float *feats, long f_bs, long f_rs,
+                              const int32_t *idx, void *out, int out_bf16, int B, int C, int N, int M, int S,
+                              float radius, int normalize, void *stream);
+/* grad_feats (B,N,C) point-major, zero_init (or NULL); grad_xyz / grad_new_xyz as bq_group_concat_grad */
+BQ_API int bq_group_concat_pm_grad(const void *grad_out, int in_bf16, const int32_t *idx, float *grad_feats,
+                                   float *grad_xyz, float *grad_new_xyz, int B, int C, int N, int M, int S,
+                                   float radius, int normalize, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BQHIP_FUSION_H */

@@ -11,8 +11,21 @@ from conftest import ROOT
 
 
 def declared_symbols():
-    hdr = open(os.path.join(ROOT, "include", "bqhip.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("bqhip.h", "bqhip_fusion.h"))
     return sorted(set(re.findall(r"BQ_API\s+(?:const\s+)?\w+\s*\*?\s*(bq_\w+)\s*\(", hdr)))
+
+
+def test_headers_compile_as_c_and_cover_the_fusion_kernels():
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        open(src, "w").write('#include "bqhip_fusion.h"\nint main(void) { return BQHIP_ABI_VERSION - 1; }\n')
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", src,
+                               "-o", os.path.join(d, "t.o")])
+    syms = declared_symbols()
+    for s in ("bq_attn_fwd", "bq_attn_bwd", "bq_drop_add_ln_fwd", "bq_drop_add_ln_bwd", "bq_colsum_bf16",
+              "bq_transpose_pad3", "bq_group_concat_pm", "bq_group_concat_pm_grad"):
+        assert s in syms
 
 
 def test_header_declares_the_nine_reference_operators():

@@ -205,7 +205,7 @@ def main():
     side = torch.cuda.Stream()
     graphed = False
 
-    phased = (not dp) and workload == "c3" and args.schedule in ("auto", "phased")
+    phased = workload == "c3" and args.schedule in ("auto", "phased")
     pipe = None
     if phased:
         # ---- single GPU, c3: one HIP graph per phase, image / fusion chain on one stream, detector on a second,
@@ -217,6 +217,18 @@ def main():
         pipe = PhasedTrainStep(model, batch, det_loss, fusion_loss, opt, use_graphs=use_graph,
                                eager_phases=("geometry",))
         eager_step = pipe.eager_step
+        reducers = {}
+        if dp:
+            # data parallel: each phase's gradients are packed to bf16, all-reduced over RCCL on a communication
+            # stream as soon as that phase's backward has finished, unpacked, and the optimizer waits for all three
+            from bridgeqa_amd.ddp import PackedGradReducer, broadcast_parameters
+            broadcast_parameters(model)
+
+            def make_reducer(ps):
+                r = PackedGradReducer(ps, comm_dtype=torch.bfloat16)
+                r.force = args.dp_path
+                return r
+            reducers = pipe.attach_reducers(make_reducer)
     elif not dp:
         # ---- single GPU: forward + backward + fused AdamW replayed from ONE HIP graph -----------------------
         # (fused multi-tensor AdamW; NB the foreach implementation under capture makes hipStreamEndCapture segfault)
@@ -361,8 +373,10 @@ def main():
                        "c_in": args.cin, "image": args.image if workload == "c3" else None,
                        "parallelism": "dp%d" % world, "hip_graph": graphed,
                        "schedule": "phased: 6 graphs on 2 streams" if phased else "single graph",
-                       "grad_exchange": ("flat bf16 all-reduce after the fwd+bwd graph, %d MB on the wire"
-                                         % (reducer.nbytes_on_wire() >> 20)) if dp else None},
+                       "grad_exchange": (("per-phase packed bf16 all-reduce on a comm stream, %d MB on the wire"
+                                          % (sum(r.nbytes_on_wire() for r in reducers.values()) >> 20)) if phased
+                                         else ("flat bf16 all-reduce after the fwd+bwd graph, %d MB on the wire"
+                                               % (reducer.nbytes_on_wire() >> 20))) if dp else None},
             "roofline": {"kernel": "fps (SA1 40000->2048)", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE,

@@ -69,6 +69,45 @@ class FlatGradReducer(object):
                    for f, c in self.buckets)
 
 
+class PackedGradReducer(object):
+    """Gradient exchange for ONE group of parameters whose gradients become ready together (one phase of
+    pipeline.PhasedTrainStep): the .grad tensors stay wherever autograd put them (so a captured backward keeps its
+    "first gradient is an assignment" form -- no zero-fill, no accumulate kernel per parameter), and the exchange is
+
+        pack  (multi-tensor fp32 -> bf16 copy into one flat wire buffer)
+        all-reduce of the flat buffer (RCCL, one large message per group)
+        unpack (multi-tensor bf16 -> fp32 copy back) and scale by 1 / world
+
+    issued on whatever stream is current (PhasedTrainStep uses a communication stream, so the exchange of the
+    fusion gradients runs under the image / detector backward)."""
+
+    def __init__(self, params, comm_dtype=torch.bfloat16, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.force = False  # run the collective even for a single rank (exercises the RCCL path on a 1-GPU box)
+        self.params = [p for p in params]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.comm = torch.empty(n, dtype=comm_dtype, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.comm[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def all_reduce(self):
+        if self.world == 1 and not (self.force and dist.is_initialized()):
+            return
+        grads = [p.grad for p in self.params]
+        torch._foreach_copy_(self.views, grads)
+        dist.all_reduce(self.comm, op=dist.ReduceOp.SUM, group=self.group)
+        torch._foreach_copy_(grads, self.views)
+        if self.world > 1:
+            torch._foreach_mul_(grads, 1.0 / self.world)
+
+    def nbytes_on_wire(self):
+        return self.comm.numel() * self.comm.element_size()
+
+
 def used_parameters(model, run_backward):
     """Dry run: `run_backward()` must do zero_grad(set_to_none=True) + forward + backward; returns the parameters
     that ended up with a gradient (same set on every rank: same model, same path)."""

@@ -37,7 +37,7 @@ from . import fusion_ops as ops
 
 class PhasedTrainStep(object):
     def __init__(self, model, batch, det_loss, fusion_loss, optimizer=None, use_graphs=True, det_priority=0,
-                 grad_hook=None, next_batch=None, prefetch_geometry=True, eager_phases=()):
+                 grad_hook=None, next_batch=None, prefetch_geometry=True, eager_phases=(), reducers=None):
         """model: ScanQAHotPath (use_blip=True, train mode); batch: static device tensors (replayed in place);
         det_loss(data_dict) -> scalar over detector outputs; fusion_loss(data_dict) -> scalar over blip_loss /
         fused_feat; optimizer: stepped at the end of the step (None: the caller steps);
@@ -45,12 +45,20 @@ class PhasedTrainStep(object):
         (data-parallel gradient exchange); next_batch: where the loader puts the FOLLOWING step's inputs (only its
         point_clouds are read, by the geometry prefetch; default: the same static buffers as `batch`);
         eager_phases: names of phases launched kernel by kernel even when the rest replays from graphs (bench.py keeps
-        "geometry" eager so that HIP events can bracket the FPS launch inside the timed steps; ~60 launches)."""
+        "geometry" eager so that HIP events can bracket the FPS launch inside the timed steps; ~60 launches);
+        reducers: data parallel -- {"fusion" | "image" | "det": ddp.PackedGradReducer over the parameters whose
+        gradients that phase produces}: each group is exchanged on a communication stream as soon as its backward
+        phase has finished (the fusion group, 3/4 of the bytes, travels under the image and detector backward) and
+        the optimizer waits for all of them."""
         self.model, self.batch, self.det_loss, self.fusion_loss = model, batch, det_loss, fusion_loss
         self.opt, self.grad_hook = optimizer, grad_hook
         self.next_batch = next_batch if next_batch is not None else batch
         self.prefetch = prefetch_geometry
         self.eager_phases = tuple(eager_phases)
+        self.reducers = dict(reducers or {})
+        self.s_comm = torch.cuda.Stream(device=batch["point_clouds"].device) if self.reducers else None
+        self.e_img_bwd = torch.cuda.Event()
+        self._comm_events = []
         self._geo_next, self._geo_cur = None, None
         self.host_times = None  # set to {} to record the host time of every graph launch (ms, per phase)
         dev = batch["point_clouds"].device
@@ -134,6 +142,18 @@ class PhasedTrainStep(object):
         else:
             self.graphs[name].replay()
 
+    def _reduce(self, group, after_event):
+        """exchange one gradient group on the communication stream once `after_event` (its backward) has passed"""
+        r = self.reducers.get(group)
+        if r is None:
+            return
+        self.s_comm.wait_event(after_event)
+        with torch.cuda.stream(self.s_comm):
+            r.all_reduce()
+            ev = torch.cuda.Event()
+            ev.record(self.s_comm)
+        self._comm_events.append(ev)
+
     def _schedule(self, eager):
         """Launch the phases with their cross-stream dependencies (the host returns without waiting for the GPU).
         Host ORDER matters: a graph launch blocks the host while its stream's hardware queue is full, so at every
@@ -151,15 +171,53 @@ class PhasedTrainStep(object):
             sm.wait_event(self.e_det_fwd)
             self._run("fusion", eager)
             self.e_fused.record(sm)
+        self._reduce("fusion", self.e_fused)
         sd.wait_event(self.e_fused)
         with torch.cuda.stream(sd):
             self._run("det_bwd", eager)
             self.e_det_bwd.record(sd)
+        self._reduce("det", self.e_det_bwd)
         with torch.cuda.stream(sm):
             self._run("image_bwd", eager)
+            self.e_img_bwd.record(sm)
+        self._reduce("image", self.e_img_bwd)
+        with torch.cuda.stream(sm):
             sm.wait_event(self.e_det_bwd)
+            for ev in self._comm_events:
+                sm.wait_event(ev)
+            del self._comm_events[:]
             self._run("finish", eager)
             self.e_done.record(sm)
+
+    def attach_reducers(self, make_reducer):
+        """Data parallel: one eager step to see which parameters receive a gradient in which phase, then
+        self.reducers[group] = make_reducer(list_of_parameters) for the groups "fusion", "image", "det".
+        (Parameters that get no gradient on this path -- unused BLIP heads -- are left out, as DDP's
+        find_unused_parameters would discover every step.)"""
+        cur = torch.cuda.current_stream(self.dev)
+        for s_ in (self.s_main, self.s_det):
+            s_.wait_stream(cur)
+        self.e_done.record(self.s_main)
+        if self.prefetch and self._geo_next is None:
+            with torch.cuda.stream(self.s_det):
+                self._geometry()
+        opt, self.opt = self.opt, None  # a dry step: no parameter update (replicas must not diverge)
+        self.eager_step()
+        self.opt = opt
+        torch.cuda.synchronize(self.dev)
+        groups = {"fusion": [], "image": [], "det": []}
+        for name, p in self.model.named_parameters():
+            if p.grad is None:
+                continue
+            if name.startswith("blip_model.visual_encoder."):
+                groups["image"].append(p)
+            elif name.startswith("blip_model."):
+                groups["fusion"].append(p)
+            else:
+                groups["det"].append(p)
+        self.reducers = {g: make_reducer(ps) for g, ps in groups.items() if ps}
+        self.s_comm = torch.cuda.Stream(device=self.dev)
+        return self.reducers
 
     def zero_grad(self):
         for p in self.model.parameters():

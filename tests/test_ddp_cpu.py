@@ -121,3 +121,50 @@ def test_flat_grad_reducer_world2_gloo():
         assert p.exitcode == 0
     for rank, err, drift, dead_none in res:
         assert err < 1e-6 and drift == 0.0 and dead_none
+
+
+def _worker_packed(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bridgeqa_amd.ddp import PackedGradReducer, broadcast_parameters
+        torch.manual_seed(rank)
+        net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+        broadcast_parameters(net)
+        x = torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + rank))
+        # two groups exchanged separately, as the phases of pipeline.PhasedTrainStep do
+        groups = [list(net[0].parameters()), list(net[2].parameters())]
+        reds = [PackedGradReducer(g, comm_dtype=torch.float32) for g in groups]
+        net.zero_grad(set_to_none=True)
+        net(x).square().mean().backward()       # .grad tensors are whatever autograd allocated
+        ptrs = [p.grad.data_ptr() for p in net.parameters()]
+        local = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        for r in reversed(reds):                # backward order: last layer's group first
+            r.all_reduce()
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        want = sum(gathered) / world
+        got = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        same_storage = ptrs == [p.grad.data_ptr() for p in net.parameters()]
+        bf = PackedGradReducer(groups[0], comm_dtype=torch.bfloat16)  # wire format used on the GPUs
+        out.put((rank, float((got - want).abs().max()), same_storage, bf.nbytes_on_wire() == 2 * (8 * 16 + 16)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_packed_grad_reducer_world2_gloo():
+    """per-phase exchange: gradients stay in autograd's own tensors, pack -> all-reduce -> unpack gives the rank mean"""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_packed, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=200) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, same_storage, wire_ok in res:
+        assert err < 1e-6 and same_storage and wire_ok

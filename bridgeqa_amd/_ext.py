@@ -425,6 +425,49 @@ def colsum(g2d):
     return out
 
 
+# ---- training-mode BatchNorm + ReLU (+ max over nsample) on point-major bf16 rows (csrc/bn.hip) -------
+_lib.bq_bn_chunks.argtypes = [_l, _i, _i]
+_lib.bq_bn_chunks.restype = ctypes.c_int
+_lib.bq_bn_stats.argtypes = [_vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]
+_lib.bq_bn_stats.restype = ctypes.c_int
+_lib.bq_bn_apply.argtypes = [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp]
+_lib.bq_bn_apply.restype = ctypes.c_int
+_lib.bq_bn_backward.argtypes = [_vp] * 9 + [_l, _i, _i, _i, _i, _vp]
+_lib.bq_bn_backward.restype = ctypes.c_int
+
+
+def bn_relu_fwd(x, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, S, relu, pool):
+    """x: bf16 (R, C) contiguous rows (point-major activations).  Batch statistics (running buffers updated in
+    place), then y = relu?(bn(x)) as bf16 (R, C), or (R // S, C) = max over every run of S rows when pool.
+    Returns y and the saved statistics (scale, shift, mean, rstd: one f32 (4, C) tensor)."""
+    if not x.is_cuda:
+        raise RuntimeError("x: CPU not supported")
+    R, C = x.shape
+    with torch.cuda.device(x.device):
+        stats = torch.empty(4, C, dtype=torch.float32, device=x.device)
+        part = torch.empty(_lib.bq_bn_chunks(R, 0, 0) * 2 * C, dtype=torch.float32, device=x.device)
+        _check(_lib.bq_bn_stats(_p(x), R, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                _p(num_batches_tracked), float(eps), float(momentum), _p(part), _p(stats[0]),
+                                _p(stats[1]), _p(stats[2]), _p(stats[3]), _stream()), "bn_stats")
+        y = torch.empty(R // S if pool else R, C, dtype=torch.bfloat16, device=x.device)
+        _check(_lib.bq_bn_apply(_p(x), _p(stats[0]), _p(stats[1]), _p(y), R, C, int(S), int(bool(relu)),
+                                int(bool(pool)), _stream()), "bn_apply")
+    return y, stats
+
+
+def bn_relu_bwd(dy, x, stats, S, relu, pool):
+    """-> dx bf16 (R, C), dgamma f32 (C), dbeta f32 (C)"""
+    R, C = x.shape
+    with torch.cuda.device(x.device):
+        dx = torch.empty_like(x)
+        dgb = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        part = torch.empty(_lib.bq_bn_chunks(R, int(S), int(bool(pool))) * 2 * C, dtype=torch.float32, device=x.device)
+        _check(_lib.bq_bn_backward(_p(dy), _p(x), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), _p(part),
+                                   _p(dgb), _p(dx), R, C, int(S), int(bool(relu)), int(bool(pool)), _stream()),
+               "bn_backward")
+    return dx, dgb[1], dgb[0]
+
+
 # ---- fused dropout + residual + LayerNorm (csrc/ln.hip) ---------------------------------------------
 def drop_add_ln_fwd(x, residual, gamma, beta, eps, p_drop, seed, seed_tensor, want_sum=False, p_path=0.0,
                     rows_per_sample=0, want_dgb=False):

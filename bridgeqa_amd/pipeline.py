@@ -100,6 +100,16 @@ class PhasedTrainStep(object):
         self._state["det_loss"] = self.det_loss(dd)
 
     def _fusion(self):
+        import os
+        if os.environ.get("BQ_FUSION_NO_FORK") == "1":
+            prev = ops.set_overlap(False)
+            try:
+                return self._fusion_body()
+            finally:
+                ops.set_overlap(prev)
+        return self._fusion_body()
+
+    def _fusion_body(self):
         st = self._state
         img_leaf = st["img"].detach().requires_grad_(True)
         obj_leaf = st["dd"]["object_feat"].detach().requires_grad_(True)

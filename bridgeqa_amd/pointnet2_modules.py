@@ -63,14 +63,15 @@ class PointnetSAModuleVotes(nn.Module):
             new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds) \
                 .transpose(1, 2).contiguous()
         grouped_features, _grouped_xyz = self.grouper(xyz, new_xyz, features, idx=group_idx)  # (B, 3+C, npoint, nsample)
-        new_features = self.mlp_module(grouped_features)
-        # == F.max_pool2d(kernel=[1, nsample]).squeeze(-1) (pointnet2_modules.py:259-262, 272); a row reduction
-        # instead of the generic NCHW pooling kernel.  Tie routing in backward is immaterial.
-        if new_features.is_contiguous(memory_format=torch.channels_last) and not new_features.is_contiguous():
-            # NHWC fast path: reduce over S on the (B,M,S,C) view; the result stays point-major (B,M,C) and is
-            # handed on as a (B,C,M) VIEW so the next level can group it without a transpose
-            new_features = new_features.permute(0, 2, 3, 1).max(dim=2)[0].float().transpose(1, 2)
+        # max over nsample == F.max_pool2d(kernel=[1, nsample]).squeeze(-1) (pointnet2_modules.py:259-262, 272); a row
+        # reduction instead of the generic NCHW pooling kernel.  Tie routing in backward is immaterial.
+        if (grouped_features.dtype == torch.bfloat16 and grouped_features.is_contiguous(memory_format=torch.channels_last)
+                and not grouped_features.is_contiguous()):
+            # NHWC fast path: the last layer's BatchNorm+ReLU kernel also reduces over S; the result stays
+            # point-major (B,M,C) and is handed on as a (B,C,M) VIEW so the next level can group it without a transpose
+            new_features = self.mlp_module(grouped_features, pool=True).float().transpose(1, 2)
         else:
+            new_features = self.mlp_module(grouped_features)
             new_features = new_features.max(dim=3)[0].float()  # module boundary stays fp32 (reference dtype)
         return new_xyz, new_features, inds
 

@@ -27,6 +27,10 @@ def backend():
     return _ext
 
 
+def backend_is_hip():
+    return _ext is _hip_ext
+
+
 class FurthestPointSampling(Function):
     """xyz (B,N,3) f32, npoint -> (B,npoint) i32   [pointnet2_utils.py:51-80]"""
 

@@ -96,3 +96,41 @@ def test_point_major_bf16_detector_vs_fp32_reference_path(dev):
         assert rel(got[k], ref[k]) < tol, (k, rel(got[k], ref[k]))
     g = model.detection_backbone.sa1.mlp_module.layer0.conv.weight.grad
     assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
+
+
+@pytest.mark.parametrize("B,C,M,S,relu,pool", [(2, 64, 37, 16, True, False), (2, 128, 50, 32, True, True),
+                                               (1, 256, 9, 16, False, False), (3, 64, 700, 64, True, True),
+                                               (2, 8, 5, 4, True, True)])
+def test_fused_batchnorm_relu_maxpool_point_major(dev, B, C, M, S, relu, pool):
+    """csrc/bn.hip vs the reference composition BatchNorm2d(train) -> ReLU -> max over nsample (pytorch_utils.py:104-157,
+    pointnet2_modules.py:259-262) in fp32 on the same bf16-rounded input: outputs, running statistics,
+    num_batches_tracked, and the gradients w.r.t. input, gamma, beta."""
+    from bridgeqa_amd.pytorch_utils import _BNReLUPointMajor
+    g = torch.Generator().manual_seed(B * 1000 + C + S)
+    x = (torch.randn(B, C, M, S, generator=g) * 1.5 + 0.3).to(dev).to(torch.bfloat16)
+    x = x.contiguous(memory_format=torch.channels_last)
+    bn = torch.nn.BatchNorm2d(C, momentum=0.1).to(dev).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5); bn.bias.copy_(torch.randn(C, generator=g) * 0.2)
+    ref_bn = torch.nn.BatchNorm2d(C, momentum=0.1).to(dev).train()
+    ref_bn.load_state_dict(bn.state_dict())
+    xa = x.clone().requires_grad_(True)
+    y = _BNReLUPointMajor.apply(xa, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                bn.eps, bn.momentum, relu, pool)
+    xr = x.float().requires_grad_(True)
+    z = ref_bn(xr)
+    if relu:
+        z = torch.relu(z)
+    if pool:
+        z = z.max(dim=3)[0].transpose(1, 2)  # (B, M, C)
+    assert y.shape == z.shape and y.dtype == torch.bfloat16
+    dy = torch.randn(z.shape, generator=g).to(dev)
+    y.backward(dy.to(torch.bfloat16))
+    z.backward(dy.to(torch.bfloat16).float())
+    rel = lambda a, b: ((a.float() - b.float()).norm() / (b.float().norm() + 1e-12)).item()
+    assert rel(y, z) < 6e-3
+    assert rel(bn.running_mean, ref_bn.running_mean) < 1e-4 and rel(bn.running_var, ref_bn.running_var) < 1e-4
+    assert int(bn.num_batches_tracked) == 1
+    assert rel(xa.grad, xr.grad) < 2e-2
+    assert rel(bn.weight.grad, ref_bn.weight.grad) < 1e-2 and rel(bn.bias.grad, ref_bn.bias.grad) < 1e-2
+    assert xa.grad.is_contiguous(memory_format=torch.channels_last)

@@ -23,7 +23,8 @@ namespace bq {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#define BN_CHUNK_ROWS 1024
+// rows per partial: 1024, or 4096 once that still leaves >= 256 chunks (fewer partials to fold)
+__host__ __device__ inline int bn_chunk_rows(long R) { return R >= (1L << 20) ? 4096 : 1024; }
 
 // thread = 8 adjacent channels; TPR = C / 8 threads per row, 256 / TPR rows per sweep
 __global__ __launch_bounds__(256) void bn_stats_kernel(const __bf16 *__restrict__ x, float *__restrict__ partial,
@@ -31,7 +32,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const __bf16 *__restrict_
   __shared__ float s_sum[256 * 8], s_sq[256 * 8];
   const int tpr = C >> 3, rps = 256 / tpr;
   const int cg = threadIdx.x % tpr, rp = threadIdx.x / tpr;
-  const long r0 = (long)blockIdx.x * BN_CHUNK_ROWS, r1 = min(R, r0 + BN_CHUNK_ROWS);
+  const int cr = bn_chunk_rows(R);
+  const long r0 = (long)blockIdx.x * cr, r1 = min(R, r0 + cr);
   float a[8], q[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { a[i] = 0.f; q[i] = 0.f; }
@@ -54,14 +56,20 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const __bf16 *__restrict_
   }
 }
 
-// out[j] = sum over chunks of partial[chunk][j], j < W, fixed order; 64 columns x 4 chunk phases per workgroup
+// out[j] = sum over chunks of partial[chunk][j], j < W, fixed order; 64 columns x 4 chunk phases per workgroup,
+// 8 independent loads in flight per thread (the loads are L2 hits: latency, not bandwidth, is the cost)
 __device__ __forceinline__ float fold_column(const float *partial, int chunks, int W, int j, int ph, float (*s)[64],
                                              int cl) {
-  float t0 = 0.f, t1 = 0.f;
+  float t[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) t[u] = 0.f;
   int y = ph;
-  for (; y + 4 < chunks; y += 8) { t0 += partial[(long)y * W + j]; t1 += partial[(long)(y + 4) * W + j]; }
-  if (y < chunks) t0 += partial[(long)y * W + j];
-  s[ph][cl] = t0 + t1;
+  for (; y + 28 < chunks; y += 32) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] += partial[(long)(y + 4 * u) * W + j];
+  }
+  for (; y < chunks; y += 4) t[0] += partial[(long)y * W + j];
+  s[ph][cl] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
   __syncthreads();
   const float v = (s[0][cl] + s[1][cl]) + (s[2][cl] + s[3][cl]);
   __syncthreads();
@@ -177,7 +185,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const __bf16 *__rest
   }
   if (rp < rps) {
     if (!POOL) {
-      const long r0 = (long)blockIdx.x * BN_CHUNK_ROWS, r1 = min(R, r0 + BN_CHUNK_ROWS);
+      const int cr = bn_chunk_rows(R);
+      const long r0 = (long)blockIdx.x * cr, r1 = min(R, r0 + cr);
       for (long r = r0 + rp; r < r1; r += rps) {
         const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + r * C + cg * 8);
         const bf16x8 d = *reinterpret_cast<const bf16x8 *>(dy + r * C + cg * 8);
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const __bf16 *__rest
         }
       }
     } else {
-      const long G = R / S, gpc = BN_CHUNK_ROWS / S > 0 ? BN_CHUNK_ROWS / S : 1;
+      const long G = R / S, gpc = bn_chunk_rows(R) / S > 0 ? bn_chunk_rows(R) / S : 1;
       const long g0 = (long)blockIdx.x * gpc, g1 = min(G, g0 + gpc);
       for (long gi = g0 + rp; gi < g1; gi += rps) {
         const bf16x8 d = *reinterpret_cast<const bf16x8 *>(dy + gi * C + cg * 8);
@@ -297,16 +306,16 @@ using namespace bq;
 
 static bool bn_extents_ok(long R, int C, int S, int pool) {
   return R >= 0 && (C == 8 || C == 16 || C == 32 || C == 64 || C == 128 || C == 256 || C == 512 || C == 1024 || C == 2048) &&
-         (!pool || (S > 0 && R % S == 0 && (BN_CHUNK_ROWS % S == 0 || S > BN_CHUNK_ROWS)));
+         (!pool || (S > 0 && R % S == 0 && (1024 % S == 0 || S > 4096)));
 }
 
 extern "C" __attribute__((visibility("default"))) int bq_bn_chunks(long R, int S, int pool) {
   if (R <= 0) return 0;
   if (pool && S > 0) {
-    const long G = R / S, gpc = BN_CHUNK_ROWS / S > 0 ? BN_CHUNK_ROWS / S : 1;
+    const long G = R / S, gpc = bn_chunk_rows(R) / S > 0 ? bn_chunk_rows(R) / S : 1;
     return (int)((G + gpc - 1) / gpc);
   }
-  return (int)((R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS);
+  return (int)((R + bn_chunk_rows(R) - 1) / bn_chunk_rows(R));
 }
 
 // Training-mode statistics of x bf16 (R, C): scale/shift/mean/rstd f32 (C) out; running_mean/var (f32 C) and

@@ -296,19 +296,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16 *__restrict__ 
   if (threadIdx.x == 0) counter[blockIdx.x] = 0u;
 }
 
-// out[c] = sum_y partial[y][c] in a fixed order: 64 columns x 4 chunk phases per workgroup
+// out[c] = sum_y partial[y][c] in a fixed order: 64 columns x 4 chunk phases per workgroup, 8 independent loads in
+// flight per thread (L2 hits: latency-bound)
 __global__ __launch_bounds__(256) void colsum_fold_kernel(const float *__restrict__ partial, float *__restrict__ out,
                                                           int chunks, int N) {
   __shared__ float s[4][64];
   const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
-  float t0 = 0.f, t1 = 0.f;
+  float t[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) t[u] = 0.f;
   if (c < N) {
     int y = ph;
-    for (; y + 4 < chunks; y += 8) { t0 += partial[(long)y * N + c]; t1 += partial[(long)(y + 4) * N + c]; }
-    if (y < chunks) t0 += partial[(long)y * N + c];
+    for (; y + 28 < chunks; y += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] += partial[(long)(y + 4 * u) * N + c];
+    }
+    for (; y < chunks; y += 4) t[0] += partial[(long)y * N + c];
   }
-  s[ph][cl] = t0 + t1;
+  s[ph][cl] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
   __syncthreads();
   if (ph == 0 && c < N) out[c] = (s[0][cl] + s[1][cl]) + (s[2][cl] + s[3][cl]);
 }

@@ -259,7 +259,8 @@ __device__ __forceinline__ void store_T(__bf16 *Xrow, const f32x16 &a0, const f3
 
 typedef AttnDims BwdDims;  // o_* strides describe dO
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
                                                           const __bf16 *__restrict__ V, const __bf16 *__restrict__ Kt,
                                                           const __bf16 *__restrict__ dO, const float *__restrict__ LSE,
                                                           const __bf16 *__restrict__ O, float *__restrict__ DELTA,
@@ -366,7 +367,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const __bf16 *__restri
   if (q0 + r < dm.Lq) store_T(dQ + b * dm.q_bs + hd * dm.q_hs + (long)(q0 + r) * dm.q_rs, a0, a1, h, 1.0f);
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
                                                            const __bf16 *__restrict__ V, const __bf16 *__restrict__ Qt,
                                                            const __bf16 *__restrict__ dO, const __bf16 *__restrict__ dOt,
                                                            const float *__restrict__ LSE, const float *__restrict__ DELTA,
@@ -533,13 +535,19 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_bwd(
   BwdDims dm{B, H, Lq, Lk, Lqp, Lkp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, g_bs, g_rs, g_hs, mask, scale,
              1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr, causal ? 1 : 0};
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Lq + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, st, (const __bf16 *)Q,
-                     (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)Kt, (const __bf16 *)dO, LSE,
-                     (const __bf16 *)O, DELTA, (__bf16 *)dQ, dm);
+  static const int dq_w = getenv("BQ_ATTN_DQ_MINW") ? atoi(getenv("BQ_ATTN_DQ_MINW")) : 2;
+  static const int dkv_w = getenv("BQ_ATTN_DKV_MINW") ? atoi(getenv("BQ_ATTN_DKV_MINW")) : 2;  // 242 VGPRs, 2 waves/SIMD: 0.64 -> 0.50 ms per ViT layer (tools/attn_sweep.sh)
+#define BQ_DQ(W) hipLaunchKernelGGL(attn_bwd_dq_kernel<W>, dim3((Lq + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, st, \
+                                    (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)Kt,      \
+                                    (const __bf16 *)dO, LSE, (const __bf16 *)O, DELTA, (__bf16 *)dQ, dm)
+  switch (dq_w) { case 1: BQ_DQ(1); break; case 3: BQ_DQ(3); break; default: BQ_DQ(2); }
+#undef BQ_DQ
   int rc = check_launch("attn_bwd_dq");
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Lk + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, st, (const __bf16 *)Q,
-                     (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)Qt, (const __bf16 *)dO, (const __bf16 *)dOt,
-                     LSE, DELTA, (__bf16 *)dK, (__bf16 *)dV, dm);
+#define BQ_DKV(W) hipLaunchKernelGGL(attn_bwd_dkv_kernel<W>, dim3((Lk + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, st, \
+                                     (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)Qt,      \
+                                     (const __bf16 *)dO, (const __bf16 *)dOt, LSE, DELTA, (__bf16 *)dK, (__bf16 *)dV, dm)
+  switch (dkv_w) { case 1: BQ_DKV(1); break; default: BQ_DKV(2); }
+#undef BQ_DKV
   return check_launch("attn_bwd_dkv");
 }

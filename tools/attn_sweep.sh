@@ -1,0 +1,1 @@
+for dq in 1 2 3; do for dkv in 1 2; do echo "dq=$dq dkv=$dkv"; BQ_ATTN_DQ_MINW=$dq BQ_ATTN_DKV_MINW=$dkv timeout 120 python tools/bench_attn.py 2>&1 | grep "L=1025" | cut -c1-120; done; done

@@ -296,6 +296,49 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16 *__restrict__ 
   if (threadIdx.x == 0) counter[blockIdx.x] = 0u;
 }
 
+// Small M (the text side: 160-1024 rows): one 1024-thread workgroup per 256 columns, 32 row phases, every load of a
+// thread issued before the first add -- one launch, no partials, no fence (4 us instead of 9.6)
+template <int VEC>
+__global__ __launch_bounds__(1024) void colsum_tall_kernel(const __bf16 *__restrict__ g, float *__restrict__ out, int M,
+                                                           int N) {
+  constexpr int LANES = 256 / VEC, PH = 1024 / LANES;
+  typedef __bf16 vec_t __attribute__((ext_vector_type(VEC)));
+  __shared__ float s[PH][256 + 1];
+  const int cg = threadIdx.x % LANES, ph = threadIdx.x / LANES;
+  const int c0 = blockIdx.x * 256 + cg * VEC;
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  if (c0 < N) {
+    const __bf16 *p = g + (long)ph * N + c0;
+    const long step = (long)PH * N;
+    int r = ph;
+    for (; r + 3 * PH < M; r += 4 * PH, p += 4 * step) {
+      const vec_t v0 = *reinterpret_cast<const vec_t *>(p), v1 = *reinterpret_cast<const vec_t *>(p + step),
+                  v2 = *reinterpret_cast<const vec_t *>(p + 2 * step), v3 = *reinterpret_cast<const vec_t *>(p + 3 * step);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += ((float)v0[i] + (float)v1[i]) + ((float)v2[i] + (float)v3[i]);
+    }
+    for (; r < M; r += PH, p += step) {
+      const vec_t v = *reinterpret_cast<const vec_t *>(p);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += (float)v[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[ph][cg * VEC + i] = acc[i];
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+    for (int q = 0; q < PH; q += 4) {
+      t0 += s[q][threadIdx.x]; t1 += s[q + 1][threadIdx.x]; t2 += s[q + 2][threadIdx.x]; t3 += s[q + 3][threadIdx.x];
+    }
+    if (c < N) out[c] = (t0 + t1) + (t2 + t3);
+  }
+}
+
 // out[c] = sum_y partial[y][c] in a fixed order: 64 columns x 4 chunk phases per workgroup, 8 independent loads in
 // flight per thread (L2 hits: latency-bound)
 __global__ __launch_bounds__(256) void colsum_fold_kernel(const float *__restrict__ partial, float *__restrict__ out,
@@ -327,7 +370,9 @@ using namespace bq;
 // M <= BQ_COLSUM_ONE_LAUNCH_ROWS also `counter` ((N + 255) / 256 unsigned ints that are ZERO on entry; the kernel
 // leaves them zero) -- counters of launches that may run concurrently must not alias.  Larger M: two launches.
 #define BQ_COLSUM_ONE_LAUNCH_ROWS 2048
+#define BQ_COLSUM_TALL_ROWS 1024
 extern "C" __attribute__((visibility("default"))) int bq_colsum_chunks(int M) {
+  if (M <= BQ_COLSUM_TALL_ROWS) return 1;
   const int rpc = M <= BQ_COLSUM_ONE_LAUNCH_ROWS ? 32 : 128;
   return M <= rpc ? 1 : (M + rpc - 1) / rpc;
 }
@@ -336,6 +381,15 @@ extern "C" __attribute__((visibility("default"))) int bq_colsum_bf16(const void 
                                                                      float *partial, unsigned *counter, void *stream) {
   BQ_REQUIRE(M >= 0 && N > 0 && N % 4 == 0, BQ_EINVAL, "colsum: bad extents");
   BQ_REQUIRE((g || M == 0) && out, BQ_EINVAL, "colsum: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (M <= BQ_COLSUM_TALL_ROWS) {
+    const dim3 grid((N + 255) / 256);
+    if (N % 8 == 0)
+      hipLaunchKernelGGL(colsum_tall_kernel<8>, grid, dim3(1024), 0, st, (const __bf16 *)g, out, M, N);
+    else
+      hipLaunchKernelGGL(colsum_tall_kernel<4>, grid, dim3(1024), 0, st, (const __bf16 *)g, out, M, N);
+    return check_launch("colsum");
+  }
   const int chunks = bq_colsum_chunks(M);
   const bool one_launch = M <= BQ_COLSUM_ONE_LAUNCH_ROWS;
   BQ_REQUIRE(chunks == 1 || (partial && (counter || !one_launch)), BQ_EINVAL, "colsum: workspace missing for %d chunks",
@@ -343,7 +397,6 @@ extern "C" __attribute__((visibility("default"))) int bq_colsum_bf16(const void 
   const int rpc = chunks == 1 ? (M > 0 ? M : 1) : (one_launch ? 32 : 128);
   const dim3 grid((N + 255) / 256, chunks);
   unsigned *cnt = one_launch ? counter : nullptr;
-  hipStream_t st = (hipStream_t)stream;
   if (N % 8 == 0)
     hipLaunchKernelGGL(colsum_kernel<8>, grid, dim3(256), 0, st, (const __bf16 *)g, out, partial, cnt, M, N, rpc);
   else

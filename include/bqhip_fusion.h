@@ -90,6 +90,26 @@ BQ_API int bq_group_concat_pm_grad(const void *grad_out, int in_bf16, const int3
                                    float *grad_xyz, float *grad_new_xyz, int B, int C, int N, int M, int S,
                                    float radius, int normalize, void *stream);
 
+/* ---- training-mode BatchNorm2d + ReLU (+ max over nsample) on point-major rows (csrc/bn.hip) ------------------
+ * Replaces conv -> BatchNorm2d -> ReLU of one SharedMLP layer (lib/pointnet2/pytorch_utils.py:104-157) and, for the
+ * last layer of a set-abstraction module, F.max_pool2d(kernel=[1, nsample]) (pointnet2_modules.py:259-262).
+ * x: bf16 (R, C), rows = (b, m, s) = the NHWC convolution output, C a power of two in [8, 2048].
+ * bq_bn_stats: batch statistics -> scale = gamma*rstd, shift = beta - mean*scale, mean, rstd (f32 C each);
+ *   running_mean / running_var (momentum, unbiased variance) and num_batches_tracked (int64) updated when non-NULL;
+ *   partial = bq_bn_chunks(R, 0, 0) * 2C floats of scratch.
+ * bq_bn_apply: y = relu?(x*scale + shift), bf16 (R, C); pool != 0: y bf16 (R/S, C) = max over each run of S rows.
+ * bq_bn_backward: dy as y; dgb f32 (2, C) = dbeta | dgamma; dx bf16 (R, C); pooled gradients go to the first row
+ *   attaining the maximum; partial = bq_bn_chunks(R, S, pool) * 2C floats. */
+BQ_API int bq_bn_chunks(long R, int S, int pool);
+BQ_API int bq_bn_stats(const void *x, long R, int C, const float *gamma, const float *beta, float *running_mean,
+                       float *running_var, long long *num_batches_tracked, float eps, float momentum, float *partial,
+                       float *scale, float *shift, float *mean, float *rstd, void *stream);
+BQ_API int bq_bn_apply(const void *x, const float *scale, const float *shift, void *y, long R, int C, int S, int relu,
+                       int pool, void *stream);
+BQ_API int bq_bn_backward(const void *dy, const void *x, const float *scale, const float *shift, const float *mean,
+                          const float *rstd, float *partial, float *dgb, void *dx, long R, int C, int S, int relu,
+                          int pool, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

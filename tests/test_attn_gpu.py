@@ -384,7 +384,7 @@ def test_twin_encoder_and_decoder_bf16_fused_path_vs_fp32(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N", [(0, 256), (1, 256), (31, 768), (32, 768), (33, 772), (560, 768), (577, 2304), (2049, 260),
+@pytest.mark.parametrize("M,N", [(0, 256), (1, 256), (31, 768), (32, 768), (33, 772), (560, 768), (577, 2304), (1024, 3072), (1500, 768), (2049, 260),
                                  (9232, 3072), (16 * 1025, 768)])
 def test_colsum_single_launch_matches_fp64_and_is_reproducible(dev, M, N):
     """bias gradients: f32 column sums of a bf16 matrix, one launch, chunk partials folded by the last workgroup."""

@@ -159,6 +159,59 @@ def _mm_f32(a, b):
     return torch.mm(a, b).float()
 
 
+_WGRAD = [False]
+_WGRAD_MAX_ROWS = 4096
+
+
+def set_wgrad_overlap(flag):
+    """While on, the backward of a (multi_)linear over <= 4096 rows computes dW and db on a side stream ("wgrad"):
+    only dX is on the critical path of a backward pass made of hundreds of 5-10 us kernels, and short kernels of
+    different streams do overlap on this GPU.  The caller MUST call join_wgrad() before anything reads the parameter
+    gradients (pipeline.PhasedTrainStep does, at the end of the fusion phase).  Returns the previous setting."""
+    prev, _WGRAD[0] = _WGRAD[0], bool(flag)
+    return prev
+
+
+def _wgrad_stream(g2, x2):
+    """the side stream for this backward's dW / db (ordered after the current stream), or None"""
+    if not (_WGRAD[0] and _OVERLAP[0] and g2.is_cuda and g2.shape[0] <= _WGRAD_MAX_ROWS):
+        return None
+    cur = torch.cuda.current_stream(g2.device)
+    side = side_stream("wgrad", g2.device)
+    side.wait_stream(cur)
+    g2.record_stream(side)
+    x2.record_stream(side)
+    return side
+
+
+def join_wgrad(device):
+    """the current stream waits for every weight / bias gradient issued on the wgrad stream so far"""
+    key = ("wgrad", device.index if device.index is not None else torch.cuda.current_device())
+    if key in _SIDE_STREAMS:
+        torch.cuda.current_stream(device).wait_stream(_SIDE_STREAMS[key])
+
+
+def _dw_db(g2, x2, need_dw, need_db):
+    dw = db = None
+    if need_dw:
+        dw = _dw_f32(g2, x2)
+    if need_db:
+        if g2.dtype == torch.bfloat16 and g2.shape[1] % 4 == 0 and g2.is_contiguous():
+            from . import _ext
+            db = _ext.colsum(g2)
+        else:
+            db = g2.sum(0, dtype=torch.float32)
+    return dw, db
+
+
+def _dw_db_maybe_forked(g2, x2, need_dw, need_db):
+    side = _wgrad_stream(g2, x2) if (need_dw or need_db) else None
+    if side is None:
+        return _dw_db(g2, x2, need_dw, need_db)
+    with torch.cuda.stream(side):
+        return _dw_db(g2, x2, need_dw, need_db)
+
+
 class _LinearFn(torch.autograd.Function):
     """bf16-operand linear with fp32 master weights: the forward reads the bf16 shadow of W / b, the backward
     produces dW and db directly in fp32 (no per-parameter cast kernels in either direction)."""
@@ -187,17 +240,10 @@ class _LinearFn(torch.autograd.Function):
             xb, wb = ctx.saved_tensors
         g2 = g.reshape(-1, g.shape[-1])
         x2 = xb.reshape(-1, xb.shape[-1])
-        dx = dw = db = None
+        dw, db = _dw_db_maybe_forked(g2, x2, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.mm(g2, wb).view(xb.shape).to(ctx.x_dtype)
-        if ctx.needs_input_grad[1]:
-            dw = _dw_f32(g2, x2)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            if g2.dtype == torch.bfloat16 and g2.shape[1] % 4 == 0 and g2.is_contiguous():
-                from . import _ext
-                db = _ext.colsum(g2)
-            else:
-                db = g2.sum(0, dtype=torch.float32)
         return dx, dw, db, None
 
 
@@ -243,13 +289,8 @@ class _MultiLinearFn(torch.autograd.Function):
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         x2 = xb.reshape(-1, xb.shape[-1])
+        dw, db = _dw_db_maybe_forked(g2, x2, True, True)
         dx = torch.mm(g2, wc).view(xb.shape).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
-        dw = _dw_f32(g2, x2)
-        if g2.dtype == torch.bfloat16 and g2.shape[1] % 4 == 0:
-            from . import _ext
-            db = _ext.colsum(g2)
-        else:
-            db = g2.sum(0, dtype=torch.float32)
         n = dw.shape[0] // k
         return (dx,) + tuple(dw[i * n:(i + 1) * n] for i in range(k)) + tuple(db[i * n:(i + 1) * n] for i in range(k))
 

@@ -55,6 +55,10 @@ class PhasedTrainStep(object):
         self.next_batch = next_batch if next_batch is not None else batch
         self.prefetch = prefetch_geometry
         self.eager_phases = tuple(eager_phases)
+        # dW / db of the small linears on a side stream (fusion_ops.set_wgrad_overlap): value-neutral, but MEASURED
+        # SLOWER on ROCm 7.2 (53.5 -> 61.3 ms/step): every fork is an event record + wait pair in a multi-stream
+        # graph, and ~300 of them cost more than the kernels they take off the critical path.  Off.
+        self.wgrad_overlap = False
         self.reducers = dict(reducers or {})
         self.s_comm = torch.cuda.Stream(device=batch["point_clouds"].device) if self.reducers else None
         self.e_img_bwd = torch.cuda.Event()
@@ -116,7 +120,12 @@ class PhasedTrainStep(object):
         dd = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in st["dd"].items()}
         dd = self.model.fuse(dd, img_leaf, obj_leaf)
         loss = self.fusion_loss(dd)
-        loss.backward()
+        prev = ops.set_wgrad_overlap(self.wgrad_overlap)
+        try:
+            loss.backward()
+        finally:
+            ops.set_wgrad_overlap(prev)
+            ops.join_wgrad(self.dev)
         st["img_grad"], st["obj_grad"] = img_leaf.grad, obj_leaf.grad
         st["fusion_loss"] = loss.detach()
 

@@ -406,3 +406,34 @@ def test_colsum_single_launch_matches_fp64_and_is_reproducible(dev, M, N):
             res.append(_ext.colsum(g))
     torch.cuda.synchronize()
     assert all(torch.equal(r, outs[0]) for r in res)
+
+
+def test_weight_gradients_on_side_stream_are_value_neutral(dev):
+    """fusion_ops.set_wgrad_overlap: dW / db of the small linears computed on the "wgrad" stream == computed inline,
+    bit for bit (same kernels, other stream), once join_wgrad() has been called."""
+    from bridgeqa_amd import fusion_ops as ops
+    prev_dt = ops.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(0)
+        lin = torch.nn.Linear(768, 3072).to(dev)
+        trio = [torch.nn.Linear(768, 768).to(dev) for _ in range(3)]
+        x = torch.randn(16, 20, 768, device=dev).to(torch.bfloat16)
+
+        def run(flag):
+            for m in [lin] + trio:
+                m.zero_grad(set_to_none=True)
+            xa = x.clone().requires_grad_(True)
+            prev = ops.set_wgrad_overlap(flag)
+            try:
+                y = ops.linear(xa, lin.weight, lin.bias, act="gelu").float().square().mean()
+                z = ops.multi_linear(xa, trio).float().square().mean()
+                (y + z).backward()
+            finally:
+                ops.set_wgrad_overlap(prev)
+                ops.join_wgrad(dev)
+            torch.cuda.synchronize()
+            return [p.grad.clone() for m in [lin] + trio for p in m.parameters()] + [xa.grad.clone()]
+        a, b = run(False), run(True)
+        assert all(torch.equal(u, v) for u, v in zip(a, b))
+    finally:
+        ops.set_compute_dtype(prev_dt)

@@ -212,6 +212,61 @@ def _dw_db_maybe_forked(g2, x2, need_dw, need_db):
         return _dw_db(g2, x2, need_dw, need_db)
 
 
+# ---- deferred, batched weight gradients ---------------------------------------------------------------------
+_DEFER = [None]
+_DEFER_MAX_ROWS = 4096
+
+
+def begin_deferred_wgrad():
+    """From now until flush_deferred_wgrad(), the backward of every bf16 (multi_)linear over <= 4096 rows computes
+    ONLY dX and parks (dY, X, parameters): dW / db are not on the critical path of the backward pass, and parked
+    together the ~60 identical-shape products of a 12-layer stack become ONE batched GEMM + ONE reduction
+    (the text side of c3: ~700 launches of 5-10 us -> ~60)."""
+    _DEFER[0] = []
+
+
+def _accumulate_grad(p, g):
+    if p is None or not p.requires_grad:
+        return
+    if p.grad is None:
+        p.grad = g
+    else:
+        p.grad.add_(g)
+
+
+def flush_deferred_wgrad():
+    """compute the parked weight / bias gradients (current stream) and store them in the parameters' .grad"""
+    items, _DEFER[0] = _DEFER[0], None
+    if not items:
+        return
+    groups = {}
+    for it in items:
+        g2, x2, ws, bs = it
+        groups.setdefault((tuple(g2.shape), tuple(x2.shape), len(ws), bs is not None), []).append(it)
+    for (gs, xs, k, has_b), its in groups.items():
+        if len(its) == 1:
+            g2, x2, ws, bs = its[0]
+            dw, db = _dw_db(g2, x2, True, has_b)
+            dws, dbs = [dw], [db]
+        else:
+            G = torch.stack([it[0] for it in its])          # (n, M, N)
+            X = torch.stack([it[1] for it in its])          # (n, M, K)
+            dW = torch.bmm(G.transpose(1, 2), X, out_dtype=torch.float32)
+            dws = dW.unbind(0)
+            dbs = G.sum(dim=1, dtype=torch.float32).unbind(0) if has_b else [None] * len(its)
+        for (g2, x2, ws, bs), dw, db in zip(its, dws, dbs):
+            n = dw.shape[0] // k
+            for j, w in enumerate(ws):
+                _accumulate_grad(w, dw[j * n:(j + 1) * n] if k > 1 else dw)
+                if has_b:
+                    _accumulate_grad(bs[j], db[j * n:(j + 1) * n] if k > 1 else db)
+
+
+def _defer_ok(g2, x2):
+    return (_DEFER[0] is not None and g2.is_cuda and g2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
+            and g2.shape[0] <= _DEFER_MAX_ROWS and g2.is_contiguous() and x2.is_contiguous())
+
+
 class _LinearFn(torch.autograd.Function):
     """bf16-operand linear with fp32 master weights: the forward reads the bf16 shadow of W / b, the backward
     produces dW and db directly in fp32 (no per-parameter cast kernels in either direction)."""
@@ -225,6 +280,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.gelu = gelu
         ctx.has_bias = bias is not None
         ctx.x_dtype = x.dtype
+        ctx.params = (weight, bias)
         if gelu:
             ctx.save_for_backward(xb, wb, y)
             return F.gelu(y)
@@ -240,7 +296,12 @@ class _LinearFn(torch.autograd.Function):
             xb, wb = ctx.saved_tensors
         g2 = g.reshape(-1, g.shape[-1])
         x2 = xb.reshape(-1, xb.shape[-1])
-        dw, db = _dw_db_maybe_forked(g2, x2, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        if _defer_ok(g2, x2) and ctx.needs_input_grad[1]:
+            w, b = ctx.params
+            _DEFER[0].append((g2, x2, [w], [b] if ctx.has_bias else None))
+            dw = db = None
+        else:
+            dw, db = _dw_db_maybe_forked(g2, x2, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.mm(g2, wb).view(xb.shape).to(ctx.x_dtype)
@@ -279,6 +340,7 @@ class _MultiLinearFn(torch.autograd.Function):
         y = F.linear(xb, wc, bc)
         ctx.save_for_backward(xb, wc)
         ctx.k, ctx.x_dtype = k, x.dtype
+        ctx.params = (weights, biases)
         return y.view(*y.shape[:-1], k, y.shape[-1] // k)
 
     @staticmethod
@@ -289,8 +351,12 @@ class _MultiLinearFn(torch.autograd.Function):
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         x2 = xb.reshape(-1, xb.shape[-1])
-        dw, db = _dw_db_maybe_forked(g2, x2, True, True)
         dx = torch.mm(g2, wc).view(xb.shape).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
+        if _defer_ok(g2, x2):
+            ws, bs = ctx.params
+            _DEFER[0].append((g2, x2, list(ws), list(bs)))
+            return (dx,) + (None,) * (2 * k)
+        dw, db = _dw_db_maybe_forked(g2, x2, True, True)
         n = dw.shape[0] // k
         return (dx,) + tuple(dw[i * n:(i + 1) * n] for i in range(k)) + tuple(db[i * n:(i + 1) * n] for i in range(k))
 

@@ -59,6 +59,7 @@ class PhasedTrainStep(object):
         # SLOWER on ROCm 7.2 (53.5 -> 61.3 ms/step): every fork is an event record + wait pair in a multi-stream
         # graph, and ~300 of them cost more than the kernels they take off the critical path.  Off.
         self.wgrad_overlap = False
+        self.defer_wgrad = True
         self.reducers = dict(reducers or {})
         self.s_comm = torch.cuda.Stream(device=batch["point_clouds"].device) if self.reducers else None
         self.e_img_bwd = torch.cuda.Event()
@@ -121,11 +122,14 @@ class PhasedTrainStep(object):
         dd = self.model.fuse(dd, img_leaf, obj_leaf)
         loss = self.fusion_loss(dd)
         prev = ops.set_wgrad_overlap(self.wgrad_overlap)
+        if self.defer_wgrad:
+            ops.begin_deferred_wgrad()  # dW / db of the small linears: parked, then batched by shape after the chain
         try:
             loss.backward()
         finally:
             ops.set_wgrad_overlap(prev)
             ops.join_wgrad(self.dev)
+            ops.flush_deferred_wgrad()
         st["img_grad"], st["obj_grad"] = img_leaf.grad, obj_leaf.grad
         st["fusion_loss"] = loss.detach()
 

@@ -437,3 +437,40 @@ def test_weight_gradients_on_side_stream_are_value_neutral(dev):
         assert all(torch.equal(u, v) for u, v in zip(a, b))
     finally:
         ops.set_compute_dtype(prev_dt)
+
+
+def test_deferred_batched_weight_gradients_match_inline(dev):
+    """fusion_ops.begin/flush_deferred_wgrad: parked dW / db of same-shape linears computed as one batched GEMM + one
+    reduction == computed per layer inside the backward (fp32 accumulation either way; kernels differ -> 1e-3)."""
+    from bridgeqa_amd import fusion_ops as ops
+    prev_dt = ops.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(1)
+        stack = [torch.nn.Linear(768, 768).to(dev) for _ in range(5)]
+        trios = [[torch.nn.Linear(768, 768).to(dev) for _ in range(3)] for _ in range(3)]
+        lone = torch.nn.Linear(768, 256).to(dev)
+        x = torch.randn(16, 20, 768, device=dev).to(torch.bfloat16)
+        mods = stack + [m for t in trios for m in t] + [lone]
+
+        def run(defer):
+            for m in mods:
+                m.zero_grad(set_to_none=True)
+            h = x.clone().requires_grad_(True)
+            y = h
+            if defer:
+                ops.begin_deferred_wgrad()
+            for l, t in zip(stack, trios + [None, None]):
+                y = ops.linear(y, l.weight, l.bias, act="gelu")
+                if t is not None:
+                    y = y + ops.multi_linear(y, t).sum(-2)
+            (ops.linear(y, lone.weight, lone.bias).float().square().mean()).backward()
+            if defer:
+                assert all(m.weight.grad is None for m in mods)  # parked, not yet computed
+                ops.flush_deferred_wgrad()
+            torch.cuda.synchronize()
+            return [p.grad.clone() for m in mods for p in m.parameters()] + [h.grad.clone()]
+        a, b = run(False), run(True)
+        rel = lambda u, v: ((u.float() - v.float()).norm() / (v.float().norm() + 1e-20)).item()
+        assert max(rel(u, v) for u, v in zip(b, a)) < 1e-3
+    finally:
+        ops.set_compute_dtype(prev_dt)

@@ -128,6 +128,27 @@ def _shadow(t):
     return c
 
 
+def refresh_shadows():
+    """Call right after the optimizer step: every registered bf16 shadow (and, through them, the concatenated QKV / KV
+    shadows, whose row blocks ARE the per-weight shadows) is brought up to date by ONE multi-tensor cast instead of
+    ~100 separate cast / cat launches scattered over the next forward.  Shadows that are still current are skipped;
+    a shadow nobody refreshed is caught by the version check in _shadow() as before."""
+    dst, src = [], []
+    for key, (ref, ver, c) in list(_SHADOW.items()):
+        t = ref()
+        if t is None:
+            del _SHADOW[key]
+            continue
+        if ver != t._version and c.dtype == _COMPUTE_DTYPE and c.device == t.device:
+            dst.append(c)
+            src.append(t.detach())
+            _SHADOW[key] = (ref, t._version, c)
+    if dst:
+        with torch.no_grad():
+            torch._foreach_copy_(dst, src)
+    return len(dst)
+
+
 def _dw_f32(g2, x2):
     """dW = g2^T @ x2 in fp32 for bf16 (M, N), (M, K).  With a long reduction (M = batch * tokens) and a small
     (N, K) output hipBLASLt launches too few tiles to fill 256 CUs (measured 166-520 TFLOP/s); splitting M into S
@@ -312,17 +333,34 @@ _CAT_CACHE = {}
 
 
 def _cat_shadow(weights, biases):
-    """bf16 [sum(N_i), K] / [sum(N_i)] concatenation of several linears' shadows, rebuilt once per optimizer step"""
+    """bf16 [sum(N_i), K] / [sum(N_i)] concatenation of several linears' shadows.  Built once; afterwards the
+    per-parameter shadows ARE row blocks of the concatenated buffers, so refreshing them (refresh_shadows, or the
+    lazy path below) updates the fused operands in place -- no cat per step."""
     key = tuple(id(w) for w in weights)
-    ver = tuple(w._version for w in weights) + tuple(b._version for b in biases)
+    params = list(weights) + list(biases)
     hit = _CAT_CACHE.get(key)
-    if hit is not None and hit[0] == ver and all(r() is w for r, w in zip(hit[1], weights)):
-        return hit[2], hit[3]
+    if (hit is not None and all(r() is w for r, w in zip(hit[0], params)) and hit[1].dtype == _COMPUTE_DTYPE
+            and all(id(p) in _SHADOW and _SHADOW[id(p)][2].untyped_storage().data_ptr() ==
+                    (hit[1] if p.dim() > 1 else hit[2]).untyped_storage().data_ptr() for p in params)):
+        stale = [p for p in params if _SHADOW[id(p)][1] != p._version]
+        if stale:
+            with torch.no_grad():
+                torch._foreach_copy_([_SHADOW[id(p)][2] for p in stale], [p.detach() for p in stale])
+            for p in stale:
+                ent = _SHADOW[id(p)]
+                _SHADOW[id(p)] = (ent[0], p._version, ent[2])
+        return hit[1], hit[2]
     import weakref
     with torch.no_grad():
-        wc = torch.cat([_shadow(w) for w in weights], dim=0)
-        bc = torch.cat([_shadow(b) for b in biases], dim=0)
-    _CAT_CACHE[key] = (ver, [weakref.ref(w) for w in weights], wc, bc)
+        wc = torch.cat([w.detach().to(_COMPUTE_DTYPE) for w in weights], dim=0)
+        bc = torch.cat([b.detach().to(_COMPUTE_DTYPE) for b in biases], dim=0)
+    off = 0
+    for w, b in zip(weights, biases):
+        n = w.shape[0]
+        _SHADOW[id(w)] = (weakref.ref(w), w._version, wc[off:off + n])
+        _SHADOW[id(b)] = (weakref.ref(b), b._version, bc[off:off + n])
+        off += n
+    _CAT_CACHE[key] = ([weakref.ref(p) for p in params], wc, bc)
     return wc, bc
 
 

@@ -145,6 +145,7 @@ class PhasedTrainStep(object):
             self.grad_hook()
         if self.opt is not None:
             self.opt.step()
+            ops.refresh_shadows()  # bf16 operand copies of the updated weights: one multi-tensor cast
         st = self._state
         self.loss = st["det_loss"].detach() + st["fusion_loss"]
 

@@ -474,3 +474,38 @@ def test_deferred_batched_weight_gradients_match_inline(dev):
         assert max(rel(u, v) for u, v in zip(b, a)) < 1e-3
     finally:
         ops.set_compute_dtype(prev_dt)
+
+
+def test_shadow_weights_follow_the_optimizer(dev):
+    """bf16 operand copies of fp32 master weights (single and concatenated QKV form): refreshed by ONE multi-tensor
+    cast after an in-place update (refresh_shadows), and by the lazy version check when nobody refreshed them."""
+    from bridgeqa_amd import fusion_ops as ops
+    prev_dt = ops.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(2)
+        lin = torch.nn.Linear(256, 256).to(dev)
+        trio = [torch.nn.Linear(256, 256).to(dev) for _ in range(3)]
+        x = torch.randn(4, 7, 256, device=dev).to(torch.bfloat16)
+
+        def outputs():
+            with torch.no_grad():
+                return ops.linear(x, lin.weight, lin.bias).float(), ops.multi_linear(x, trio).float()
+
+        def reference():
+            with torch.no_grad():
+                f = lambda m: torch.nn.functional.linear(x, m.weight.to(torch.bfloat16), m.bias.to(torch.bfloat16)).float()
+                return f(lin), torch.stack([f(m) for m in trio], dim=-2)
+        for mode in ("first use", "refresh", "lazy"):
+            if mode != "first use":
+                with torch.no_grad():
+                    for m in [lin] + trio:
+                        m.weight.add_(torch.randn_like(m.weight) * 0.1)
+                        m.bias.add_(0.5)
+            if mode == "refresh":
+                assert ops.refresh_shadows() == 8       # 4 weights + 4 biases, one multi-tensor cast
+                assert ops.refresh_shadows() == 0
+            a, b = outputs()
+            ra, rb = reference()
+            assert torch.allclose(a, ra, atol=2e-2, rtol=2e-2) and torch.allclose(b, rb, atol=2e-2, rtol=2e-2), mode
+    finally:
+        ops.set_compute_dtype(prev_dt)

@@ -235,7 +235,8 @@ def _dw_db_maybe_forked(g2, x2, need_dw, need_db):
 
 # ---- deferred, batched weight gradients ---------------------------------------------------------------------
 _DEFER = [None]
-_DEFER_MAX_ROWS = 4096
+_DEFER_MAX_ROWS = int(__import__("os").environ.get("BQ_DEFER_MAX_ROWS", "4096"))
+_DEFER_STACK_MAX_ROWS = 4096  # larger operands are parked too, but multiplied one by one (stacking would copy GBs)
 
 
 def begin_deferred_wgrad():
@@ -265,10 +266,9 @@ def flush_deferred_wgrad():
         g2, x2, ws, bs = it
         groups.setdefault((tuple(g2.shape), tuple(x2.shape), len(ws), bs is not None), []).append(it)
     for (gs, xs, k, has_b), its in groups.items():
-        if len(its) == 1:
-            g2, x2, ws, bs = its[0]
-            dw, db = _dw_db(g2, x2, True, has_b)
-            dws, dbs = [dw], [db]
+        if len(its) == 1 or gs[0] > _DEFER_STACK_MAX_ROWS:
+            pairs = [_dw_db(it[0], it[1], True, has_b) for it in its]
+            dws, dbs = [p_[0] for p_ in pairs], [p_[1] for p_ in pairs]
         else:
             G = torch.stack([it[0] for it in its])          # (n, M, N)
             X = torch.stack([it[1] for it in its])          # (n, M, K)

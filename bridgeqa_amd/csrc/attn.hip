@@ -94,6 +94,81 @@ __device__ __forceinline__ void stage_store(unsigned char *lds, int c, uint4 v) 
   *reinterpret_cast<uint4 *>(lds + swz(c >> 3, c & 7)) = v;
 }
 
+// One 64-key tile (two 32-key blocks) of the online-softmax forward for the 32 queries of a wave: S^T = K.Q^T from
+// the LDS image s_k, mask / causal / length clamp, running max + rescale, P (with dropout) straight from the
+// accumulator registers into O^T += V^T.P^T from the LDS image s_v.  qrow = this lane's query index.
+__device__ __forceinline__ void fwd_tile(const unsigned char *s_k, const unsigned char *s_v, const bf16x8 (&qf)[4],
+                                         const AttnDims &dm, const float *mrow, float scale_log2e, unsigned seed, int bh,
+                                         int qrow, int kt, bool last, int r, int h, f32x16 &o0, f32x16 &o1, float &m,
+                                         float &lsum) {
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+      f32x16 acc = {0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(s_k + swz(kb2 * 32 + r, 2 * s + h));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], acc, 0, 0, 0);
+      }
+      float sc[16];
+      float mloc = -INFINITY;
+      const int kbase = kt * AT_KB + kb2 * 32;
+      if (mrow) {
+        float mk[16];
+        load_rowvals(mrow + kbase, 0, h, mk);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sc[i] = acc[i] * scale_log2e + mk[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sc[i] = acc[i] * scale_log2e;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (last && kbase + crow(i, h) >= dm.Lk) sc[i] = -INFINITY;
+        if (dm.causal && kbase + crow(i, h) > qrow) sc[i] = -INFINITY;
+        mloc = fmaxf(mloc, sc[i]);
+      }
+      mloc = xhalf_max(mloc);
+      const float mnew = fmaxf(m, mloc);
+      const float alpha = __builtin_amdgcn_exp2f(m - mnew);  // m = -inf on the first block -> 0
+      m = mnew;
+      float psum = 0.0f;
+      bf16x8 pb0, pb1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float p = __builtin_amdgcn_exp2f(sc[i] - mnew);
+        float p2 = __builtin_amdgcn_exp2f(sc[8 + i] - mnew);
+        psum += p + p2;  // the softmax denominator uses the un-dropped probabilities
+        if (dm.drop_thresh) {
+          p = drop_keep(seed, bh, qrow, kbase + crow(i, h), dm.drop_thresh) ? p * dm.inv_keep : 0.0f;
+          p2 = drop_keep(seed, bh, qrow, kbase + crow(8 + i, h), dm.drop_thresh) ? p2 * dm.inv_keep : 0.0f;
+        }
+        pb0[i] = (__bf16)p;
+        pb1[i] = (__bf16)p2;
+      }
+      lsum = lsum * alpha + psum;
+      if (__ballot(alpha != 1.0f)) {  // wave-uniform: skip the rescale once the running max has settled
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int ch = 4 * kb2 + 2 * s2;
+        bf16x8 v0, v1;
+        {
+          const unsigned char *p0 = s_v + swz(r, ch) + h * 8, *p1 = s_v + swz(r, ch + 1) + h * 8;
+          const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(p0), hi = *reinterpret_cast<const bf16x4 *>(p1);
+          v0 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          const unsigned char *p2 = s_v + swz(32 + r, ch) + h * 8, *p3 = s_v + swz(32 + r, ch + 1) + h * 8;
+          const bf16x4 lo1 = *reinterpret_cast<const bf16x4 *>(p2), hi1 = *reinterpret_cast<const bf16x4 *>(p3);
+          v1 = __builtin_shufflevector(lo1, hi1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        const bf16x8 pb = s2 == 0 ? pb0 : pb1;
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, o1, 0, 0, 0);
+      }
+    }
+}
+
 template <int MINW>
 __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
                                                        const __bf16 *__restrict__ Vt, __bf16 *__restrict__ O,
@@ -132,73 +207,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__res
       ka = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.Lk, t); kb = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.Lk, t + 256);
       va = stage_load(Vb + nt * AT_KB, dm.Lkp, 0, AT_D, t); vb = stage_load(Vb + nt * AT_KB, dm.Lkp, 0, AT_D, t + 256);
     }
-    const bool last = kt == nkt - 1;
-#pragma unroll
-    for (int kb2 = 0; kb2 < 2; ++kb2) {
-      f32x16 acc = {0};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(s_k + swz(kb2 * 32 + r, 2 * s + h));
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], acc, 0, 0, 0);
-      }
-      float sc[16];
-      float mloc = -INFINITY;
-      const int kbase = kt * AT_KB + kb2 * 32;
-      if (mrow) {
-        float mk[16];
-        load_rowvals(mrow + kbase, 0, h, mk);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sc[i] = acc[i] * scale_log2e + mk[i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sc[i] = acc[i] * scale_log2e;
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (last && kbase + crow(i, h) >= dm.Lk) sc[i] = -INFINITY;
-        if (dm.causal && kbase + crow(i, h) > q0 + r) sc[i] = -INFINITY;
-        mloc = fmaxf(mloc, sc[i]);
-      }
-      mloc = xhalf_max(mloc);
-      const float mnew = fmaxf(m, mloc);
-      const float alpha = __builtin_amdgcn_exp2f(m - mnew);  // m = -inf on the first block -> 0
-      m = mnew;
-      float psum = 0.0f;
-      bf16x8 pb0, pb1;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float p = __builtin_amdgcn_exp2f(sc[i] - mnew);
-        float p2 = __builtin_amdgcn_exp2f(sc[8 + i] - mnew);
-        psum += p + p2;  // the softmax denominator uses the un-dropped probabilities
-        if (dm.drop_thresh) {
-          p = drop_keep(seed, bh, q0 + r, kbase + crow(i, h), dm.drop_thresh) ? p * dm.inv_keep : 0.0f;
-          p2 = drop_keep(seed, bh, q0 + r, kbase + crow(8 + i, h), dm.drop_thresh) ? p2 * dm.inv_keep : 0.0f;
-        }
-        pb0[i] = (__bf16)p;
-        pb1[i] = (__bf16)p2;
-      }
-      lsum = lsum * alpha + psum;
-      if (__ballot(alpha != 1.0f)) {  // wave-uniform: skip the rescale once the running max has settled
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int ch = 4 * kb2 + 2 * s2;
-        bf16x8 v0, v1;
-        {
-          const unsigned char *p0 = s_v + swz(r, ch) + h * 8, *p1 = s_v + swz(r, ch + 1) + h * 8;
-          const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(p0), hi = *reinterpret_cast<const bf16x4 *>(p1);
-          v0 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          const unsigned char *p2 = s_v + swz(32 + r, ch) + h * 8, *p3 = s_v + swz(32 + r, ch + 1) + h * 8;
-          const bf16x4 lo1 = *reinterpret_cast<const bf16x4 *>(p2), hi1 = *reinterpret_cast<const bf16x4 *>(p3);
-          v1 = __builtin_shufflevector(lo1, hi1, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-        const bf16x8 pb = s2 == 0 ? pb0 : pb1;
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, o1, 0, 0, 0);
-      }
-    }
+    fwd_tile(s_k, s_v, qf, dm, mrow, scale_log2e, seed, bh, q0 + r, kt, kt == nkt - 1, r, h, o0, o1, m, lsum);
   }
   // epilogue: O[q][d] = O^T[d][q] / l ; LSE[q] = m + log2(l)   (log2 domain, scale folded in)
   const float l = xhalf_sum(lsum);
@@ -218,6 +227,87 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__res
       *reinterpret_cast<bf16x4 *>(Orow + 32 + 8 * g + 4 * h) = w1;
     }
     if (h == 0) LSE[(long)bh * dm.Lq + q] = m + __builtin_amdgcn_logf(l);  // v_log_f32 = log2
+  }
+}
+
+// Lq <= 32 (the text queries of the twin cross-attention: 20 tokens against 1045 image / 276 object keys): one
+// workgroup per (batch, head) would keep ONE wave busy for ceil(Lk / 64) serial tiles.  Here the four waves share the
+// 32 queries and take every fourth key tile each (own LDS images, own running max / sum / O^T), and the four partial
+// softmax states are merged through LDS at the end:  O = sum_w 2^(m_w - m*) O_w / sum_w 2^(m_w - m*) l_w.
+__global__ __launch_bounds__(256) void attn_fwd_narrow_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+                                                              const __bf16 *__restrict__ Vt, __bf16 *__restrict__ O,
+                                                              float *__restrict__ LSE, AttnDims dm) {
+  __shared__ __align__(16) unsigned char s_k[AT_NW][AT_KB * 128];
+  __shared__ __align__(16) unsigned char s_v[AT_NW][AT_D * 128];
+  __shared__ float s_m[AT_NW][32], s_l[AT_NW][32];
+  __shared__ float s_o[AT_NW][AT_D][33];
+  const float scale_log2e = dm.scale * 1.4426950408889634f;
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
+  const unsigned seed = eff_seed(dm);
+  const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
+  const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
+  const __bf16 *Vb = Vt + (long)bh * AT_D * dm.Lkp;
+  const float *mrow = dm.mask ? dm.mask + (long)b * dm.Lkp : nullptr;
+  bf16x8 qf[4];
+  {
+    const int qr = min(r, dm.Lq - 1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8 *>(Qb + (long)qr * dm.q_rs + 16 * s + 8 * h);
+  }
+  f32x16 o0 = {0}, o1 = {0};
+  float m = -INFINITY, lsum = 0.0f;
+  const int nkt = (dm.Lk + AT_KB - 1) / AT_KB;
+  for (int kt0 = 0; kt0 < nkt; kt0 += AT_NW) {
+    const int kt = kt0 + wid;
+    if (kt < nkt) {  // this wave stages its own tile: 512 chunks of 16 B per image, 8 per lane
+      uint4 kr[8], vr[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        kr[j] = stage_load(Kb, dm.k_rs, kt * AT_KB, dm.Lk, lane + 64 * j);
+        vr[j] = stage_load(Vb + kt * AT_KB, dm.Lkp, 0, AT_D, lane + 64 * j);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        stage_store(s_k[wid], lane + 64 * j, kr[j]);
+        stage_store(s_v[wid], lane + 64 * j, vr[j]);
+      }
+    }
+    __syncthreads();
+    if (kt < nkt)
+      fwd_tile(s_k[wid], s_v[wid], qf, dm, mrow, scale_log2e, seed, bh, r, kt, kt == nkt - 1, r, h, o0, o1, m, lsum);
+    __syncthreads();
+  }
+  const float lw = xhalf_sum(lsum);
+  if (h == 0) { s_m[wid][r] = m; s_l[wid][r] = lw; }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    s_o[wid][crow(i, h)][r] = o0[i];
+    s_o[wid][32 + crow(i, h)][r] = o1[i];
+  }
+  __syncthreads();
+  const int q = t & 31, d0 = (t >> 5) * 8;
+  float mstar = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < AT_NW; ++w) mstar = fmaxf(mstar, s_m[w][q]);
+  float wgt[AT_NW], l = 0.0f;
+#pragma unroll
+  for (int w = 0; w < AT_NW; ++w) {
+    wgt[w] = s_m[w][q] == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(s_m[w][q] - mstar);
+    l += wgt[w] * s_l[w][q];
+  }
+  if (q < dm.Lq) {
+    const float inv = 1.0f / l;
+    bf16x8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int w = 0; w < AT_NW; ++w) acc += wgt[w] * s_o[w][d0 + j][q];
+      out[j] = (__bf16)(acc * inv);
+    }
+    *reinterpret_cast<bf16x8 *>(O + b * dm.o_bs + hd * dm.o_hs + (long)q * dm.o_rs + d0) = out;
+    if (d0 == 0) LSE[(long)bh * dm.Lq + q] = mstar + __builtin_amdgcn_logf(l);
   }
 }
 
@@ -258,6 +348,56 @@ __device__ __forceinline__ void store_T(__bf16 *Xrow, const f32x16 &a0, const f3
 }
 
 typedef AttnDims BwdDims;  // o_* strides describe dO
+
+// One 64-key tile of the dQ pass for the 32 queries of a wave: P recomputed from S^T = K.Q^T and the forward's LSE,
+// dP^T = V.dO^T, dS^T = P o (dP - delta) * scale, then dQ^T += K^T.dS^T (A = LDS image of the pre-transposed K).
+__device__ __forceinline__ void dq_tile(const unsigned char *s_k, const unsigned char *s_v, const unsigned char *s_kt,
+                                        const bf16x8 (&qf)[4], const bf16x8 (&gf)[4], const BwdDims &dm,
+                                        const float *mrow, float c, float scale, float lse, float delta, unsigned seed,
+                                        int bh, int qrow, int kt, bool last, int r, int h, f32x16 &a0, f32x16 &a1) {
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+      f32x16 sacc = {0}, pacc = {0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 ak = *reinterpret_cast<const bf16x8 *>(s_k + swz(kb2 * 32 + r, 2 * s + h));
+        const bf16x8 av = *reinterpret_cast<const bf16x8 *>(s_v + swz(kb2 * 32 + r, 2 * s + h));
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, qf[s], sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, gf[s], pacc, 0, 0, 0);
+      }
+      bf16x8 d0, d1;
+      const int kbase = kt * AT_KB + kb2 * 32;
+      float mk[16];
+      if (mrow) load_rowvals(mrow + kbase, 0, h, mk);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float p = __builtin_amdgcn_exp2f(sacc[i] * c + (mrow ? mk[i] : 0.0f) - lse);
+        float p2 = __builtin_amdgcn_exp2f(sacc[8 + i] * c + (mrow ? mk[8 + i] : 0.0f) - lse);
+        if (last) {
+          if (kbase + crow(i, h) >= dm.Lk) p = 0.0f;
+          if (kbase + crow(8 + i, h) >= dm.Lk) p2 = 0.0f;
+        }
+        if (dm.causal) {
+          if (kbase + crow(i, h) > qrow) p = 0.0f;
+          if (kbase + crow(8 + i, h) > qrow) p2 = 0.0f;
+        }
+        float g1 = pacc[i], g2 = pacc[8 + i];
+        if (dm.drop_thresh) {
+          g1 = drop_keep(seed, bh, qrow, kbase + crow(i, h), dm.drop_thresh) ? g1 * dm.inv_keep : 0.0f;
+          g2 = drop_keep(seed, bh, qrow, kbase + crow(8 + i, h), dm.drop_thresh) ? g2 * dm.inv_keep : 0.0f;
+        }
+        d0[i] = (__bf16)(p * (g1 - delta) * scale);
+        d1[i] = (__bf16)(p2 * (g2 - delta) * scale);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int ch = 4 * kb2 + 2 * s2;
+        const bf16x8 ds = s2 == 0 ? d0 : d1;
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(s_kt, r, ch, h), ds, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(s_kt, 32 + r, ch, h), ds, a1, 0, 0, 0);
+      }
+    }
+}
 
 template <int MINW>
 __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
@@ -320,51 +460,92 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const __bf16 *__
       va = stage_load(Vb, dm.k_rs, nt * AT_KB, dm.Lk, t); vb = stage_load(Vb, dm.k_rs, nt * AT_KB, dm.Lk, t + 256);
       ta = stage_load(Ktb + nt * AT_KB, dm.Lkp, 0, AT_D, t); tb = stage_load(Ktb + nt * AT_KB, dm.Lkp, 0, AT_D, t + 256);
     }
-    const bool last = kt == nkt - 1;
-#pragma unroll
-    for (int kb2 = 0; kb2 < 2; ++kb2) {
-      f32x16 sacc = {0}, pacc = {0};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8 ak = *reinterpret_cast<const bf16x8 *>(s_k + swz(kb2 * 32 + r, 2 * s + h));
-        const bf16x8 av = *reinterpret_cast<const bf16x8 *>(s_v + swz(kb2 * 32 + r, 2 * s + h));
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, qf[s], sacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, gf[s], pacc, 0, 0, 0);
-      }
-      bf16x8 d0, d1;
-      const int kbase = kt * AT_KB + kb2 * 32;
-      float mk[16];
-      if (mrow) load_rowvals(mrow + kbase, 0, h, mk);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float p = __builtin_amdgcn_exp2f(sacc[i] * c + (mrow ? mk[i] : 0.0f) - lse);
-        float p2 = __builtin_amdgcn_exp2f(sacc[8 + i] * c + (mrow ? mk[8 + i] : 0.0f) - lse);
-        if (last) {
-          if (kbase + crow(i, h) >= dm.Lk) p = 0.0f;
-          if (kbase + crow(8 + i, h) >= dm.Lk) p2 = 0.0f;
-        }
-        if (dm.causal) {
-          if (kbase + crow(i, h) > q0 + r) p = 0.0f;
-          if (kbase + crow(8 + i, h) > q0 + r) p2 = 0.0f;
-        }
-        float g1 = pacc[i], g2 = pacc[8 + i];
-        if (dm.drop_thresh) {
-          g1 = drop_keep(seed, bh, q0 + r, kbase + crow(i, h), dm.drop_thresh) ? g1 * dm.inv_keep : 0.0f;
-          g2 = drop_keep(seed, bh, q0 + r, kbase + crow(8 + i, h), dm.drop_thresh) ? g2 * dm.inv_keep : 0.0f;
-        }
-        d0[i] = (__bf16)(p * (g1 - delta) * scale);
-        d1[i] = (__bf16)(p2 * (g2 - delta) * scale);
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int ch = 4 * kb2 + 2 * s2;
-        const bf16x8 ds = s2 == 0 ? d0 : d1;
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(s_kt, r, ch, h), ds, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(s_kt, 32 + r, ch, h), ds, a1, 0, 0, 0);
-      }
-    }
+    dq_tile(s_k, s_v, s_kt, qf, gf, dm, mrow, c, scale, lse, delta, seed, bh, q0 + r, kt, kt == nkt - 1, r, h, a0, a1);
   }
   if (q0 + r < dm.Lq) store_T(dQ + b * dm.q_bs + hd * dm.q_hs + (long)(q0 + r) * dm.q_rs, a0, a1, h, 1.0f);
+}
+
+// Lq <= 32: the four waves share the queries and split the key tiles (see attn_fwd_narrow_kernel); dQ^T partials are
+// summed through LDS in wave order.
+__global__ __launch_bounds__(256) void attn_bwd_dq_narrow_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+                                                                 const __bf16 *__restrict__ V, const __bf16 *__restrict__ Kt,
+                                                                 const __bf16 *__restrict__ dO, const float *__restrict__ LSE,
+                                                                 const __bf16 *__restrict__ O, float *__restrict__ DELTA,
+                                                                 __bf16 *__restrict__ dQ, BwdDims dm) {
+  __shared__ __align__(16) unsigned char s_k[AT_NW][AT_KB * 128];
+  __shared__ __align__(16) unsigned char s_v[AT_NW][AT_KB * 128];
+  __shared__ __align__(16) unsigned char s_kt[AT_NW][AT_D * 128];
+  __shared__ float s_o[AT_NW][AT_D][33];
+  const float scale = dm.scale;
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
+  const unsigned seed = eff_seed(dm);
+  const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
+  const __bf16 *Gb = dO + b * dm.o_bs + hd * dm.o_hs;
+  const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
+  const __bf16 *Vb = V + b * dm.k_bs + hd * dm.k_hs;
+  const __bf16 *Ktb = Kt + (long)bh * AT_D * dm.Lkp;
+  const float *mrow = dm.mask ? dm.mask + (long)b * dm.Lkp : nullptr;
+  const float c = scale * 1.4426950408889634f;
+  bf16x8 qf[4], gf[4];
+  const int qr = min(r, dm.Lq - 1);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    qf[s] = *reinterpret_cast<const bf16x8 *>(Qb + (long)qr * dm.q_rs + 16 * s + 8 * h);
+    gf[s] = *reinterpret_cast<const bf16x8 *>(Gb + (long)qr * dm.o_rs + 16 * s + 8 * h);
+  }
+  const float lse = LSE[(long)bh * dm.Lq + qr];
+  float delta = 0.0f;
+  {
+    const __bf16 *Orow = O + (((long)b * dm.Lq + qr) * dm.H + hd) * AT_D;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 ov = *reinterpret_cast<const bf16x8 *>(Orow + 16 * s + 8 * h);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) delta += (float)ov[j] * (float)gf[s][j];
+    }
+    delta = xhalf_sum(delta);
+    if (wid == 0 && h == 0 && r < dm.Lq) DELTA[(long)bh * dm.Lq + r] = delta;
+  }
+  f32x16 a0 = {0}, a1 = {0};
+  const int nkt = (dm.Lk + AT_KB - 1) / AT_KB;
+  for (int kt0 = 0; kt0 < nkt; kt0 += AT_NW) {
+    const int kt = kt0 + wid;
+    if (kt < nkt) {
+      uint4 kr[8], vr[8], tr[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        kr[j] = stage_load(Kb, dm.k_rs, kt * AT_KB, dm.Lk, lane + 64 * j);
+        vr[j] = stage_load(Vb, dm.k_rs, kt * AT_KB, dm.Lk, lane + 64 * j);
+        tr[j] = stage_load(Ktb + kt * AT_KB, dm.Lkp, 0, AT_D, lane + 64 * j);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        stage_store(s_k[wid], lane + 64 * j, kr[j]);
+        stage_store(s_v[wid], lane + 64 * j, vr[j]);
+        stage_store(s_kt[wid], lane + 64 * j, tr[j]);
+      }
+    }
+    __syncthreads();
+    if (kt < nkt)
+      dq_tile(s_k[wid], s_v[wid], s_kt[wid], qf, gf, dm, mrow, c, scale, lse, delta, seed, bh, r, kt, kt == nkt - 1, r, h,
+              a0, a1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    s_o[wid][crow(i, h)][r] = a0[i];
+    s_o[wid][32 + crow(i, h)][r] = a1[i];
+  }
+  __syncthreads();
+  const int q = t & 31, d0 = (t >> 5) * 8;
+  if (q < dm.Lq) {
+    bf16x8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      out[j] = (__bf16)((s_o[0][d0 + j][q] + s_o[1][d0 + j][q]) + (s_o[2][d0 + j][q] + s_o[3][d0 + j][q]));
+    *reinterpret_cast<bf16x8 *>(dQ + b * dm.q_bs + hd * dm.q_hs + (long)q * dm.q_rs + d0) = out;
+  }
 }
 
 template <int MINW>
@@ -506,6 +687,12 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_fwd(
   BQ_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, BQ_EINVAL, "attn_fwd: bad dropout probability");
   AttnDims dm{B, H, Lq, Lk, 0, Lkp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, o_bs, o_rs, o_hs, mask, scale,
               1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr, causal ? 1 : 0};
+  static const bool narrow_ok = !getenv("BQ_ATTN_NO_NARROW");
+  if (narrow_ok && Lq <= AT_QW && Lk > 2 * AT_KB && (o_rs % 8) == 0 && (o_hs % 8) == 0) {
+    hipLaunchKernelGGL(attn_fwd_narrow_kernel, dim3(1, B * H), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Q,
+                       (const __bf16 *)K, (const __bf16 *)Vt, (__bf16 *)O, LSE, dm);
+    return check_launch("attn_fwd_narrow");
+  }
   const dim3 grid((Lq + AT_QB - 1) / AT_QB, B * H);
   static const int minw = getenv("BQ_ATTN_MINW") ? atoi(getenv("BQ_ATTN_MINW")) : 3;  // 3 waves/SIMD measured best (158 VGPRs, no spill)
 #define BQ_FWD(W) hipLaunchKernelGGL(attn_fwd_kernel<W>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Q, \
@@ -540,7 +727,13 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_bwd(
 #define BQ_DQ(W) hipLaunchKernelGGL(attn_bwd_dq_kernel<W>, dim3((Lq + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, st, \
                                     (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)Kt,      \
                                     (const __bf16 *)dO, LSE, (const __bf16 *)O, DELTA, (__bf16 *)dQ, dm)
-  switch (dq_w) { case 1: BQ_DQ(1); break; case 3: BQ_DQ(3); break; default: BQ_DQ(2); }
+  static const bool narrow_ok = !getenv("BQ_ATTN_NO_NARROW");
+  if (narrow_ok && Lq <= AT_QW && Lk > 2 * AT_KB)
+    hipLaunchKernelGGL(attn_bwd_dq_narrow_kernel, dim3(1, B * H), dim3(256), 0, st, (const __bf16 *)Q, (const __bf16 *)K,
+                       (const __bf16 *)V, (const __bf16 *)Kt, (const __bf16 *)dO, LSE, (const __bf16 *)O, DELTA,
+                       (__bf16 *)dQ, dm);
+  else
+    switch (dq_w) { case 1: BQ_DQ(1); break; case 3: BQ_DQ(3); break; default: BQ_DQ(2); }
 #undef BQ_DQ
   int rc = check_launch("attn_bwd_dq");
   if (rc) return rc;

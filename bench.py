@@ -36,8 +36,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("BQ_WORKLOAD", "auto"), choices=["auto", "c2", "c3"])
     ap.add_argument("--cin", type=int, default=132, help="per-point feature channels (README recipe: 128+3+1)")
     ap.add_argument("--batch", type=int, default=16)
@@ -92,6 +92,29 @@ def det_loss(dd):
     return (dd["objectness_scores"].square().mean() + dd["center"].square().mean() * 1e-2 +
             dd["size_residuals_normalized"].square().mean() + dd["sem_cls_scores"].square().mean() +
             (dd["vote_xyz"] - dd["fp2_xyz"]).abs().mean())
+
+
+def path_roofline(args, workload):
+    """SURVEY.md §8d path-level bound: t_min = sum over ops of max(bytes / HBM peak, flops / MFMA peak), from the
+    ALGORITHMIC work of one B-sample train step (train = 3 x forward flops; FPS / ball query in their
+    streaming-equivalent bytes, grouped tensors in true bytes).  Returns (t_min_ms, detail)."""
+    B, N = args.batch, args.points
+    stages = ((N, 2048, 64), (2048, 1024, 32), (1024, 512, 16), (512, 256, 16), (1024, 256, 16))
+    chans = (args.cin, 128, 256, 256, 256)
+    fps_b = sum(20.0 * n * (m - 1) * B for n, m, _ in stages)
+    bq_b = sum(12.0 * n * m * B for n, m, _ in stages)
+    grp_b = sum(4.0 * (c + 3) * m * s_ * B for (n, m, s_), c in zip(stages, chans))
+    det_flops = 3.0 * 13.4e9 * B * (1.0 if args.cin > 1 else 11.2 / 13.4)
+    flops = det_flops
+    if workload == "c3":
+        P = (args.image // 16) ** 2 + 1
+        vit = 12 * (2 * P * 768 * 2304 + 4 * P * P * 768 + 2 * P * 768 * 768 + 4 * P * 768 * 3072) + 2 * (P - 1) * 768 * 768
+        twin, dec = 46.3e9, 2 * 1.8e9   # L = 20, La = 5 (SURVEY §8d)
+        flops += 3.0 * (vit + twin + dec) * B
+    t_bytes = (fps_b + bq_b + grp_b) / (HBM_PEAK_GBS * 1e9)
+    t_flops = flops / 2.5e15
+    return (t_bytes + t_flops) * 1e3, {"hbm_bytes": fps_b + bq_b + grp_b, "mfma_flops": flops,
+                                       "hbm_peak_GBs": HBM_PEAK_GBS, "mfma_peak_TFLOPs": 2500.0}
 
 
 def fusion_loss(dd):
@@ -405,6 +428,8 @@ def main():
                                    "frac": round(alg / (fps_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                    "note": "5 back-to-back launches after the timed region, idle GPU"}},
             "op_ms": {"%s%s" % (k[0], list(k[1])): round(v[0], 4) for k, v in sorted(ops.items())},
+            "path_roofline": (lambda tm, det: {"t_min_ms": round(tm, 3), "frac": round(tm / (dt / args.steps * 1e3), 4),
+                                               **det})(*path_roofline(args, workload)),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, workload)

@@ -5,6 +5,7 @@
 // DPP wave sums; the dropout mask is a stateless hash (regenerated in the backward, nothing stored).
 // Also here: the padded transpose the attention kernels want (one launch instead of zeros + strided copy).
 #include <cstdint>
+#include <stdlib.h>
 #include "bq_common.h"
 
 namespace bq {
@@ -75,9 +76,8 @@ __global__ __launch_bounds__(256) void drop_add_ln_fwd_kernel(const __bf16 *__re
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (zero_out && blockIdx.x == 0)  // the backward's dgamma / dbeta accumulators, cleared here for free
     for (int c = threadIdx.x; c < 2 * a.H; c += 256) zero_out[c] = 0.0f;
-  const int row = blockIdx.x * 4 + wid;
-  if (row >= a.M) return;
   const unsigned seed = ln_seed(a);
+  for (int row = blockIdx.x * 4 + wid; row < a.M; row += gridDim.x * 4) {
   const long rowoff = (long)row * a.H;
   float z[4 * NCH];
   load_z<NCH>(x, res, rowoff, row, lane, a, seed, z);
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void drop_add_ln_fwd_kernel(const __bf16 *__re
     }
   }
   if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+  }
 }
 
 // backward: rows are strided over the grid so every wave folds its rows' dgamma / dbeta in registers; one LDS
@@ -424,7 +425,8 @@ extern "C" __attribute__((visibility("default"))) int bq_drop_add_ln_fwd(
   BQ_REQUIRE(p_path == 0.0f || rows_per_sample > 0, BQ_EINVAL, "drop_add_ln: rows_per_sample");
   LnArgs a{M, H, eps, 1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr,
            (unsigned)((double)p_path * 4294967296.0), 1.0f / (1.0f - p_path), rows_per_sample};
-  const dim3 grid((M + 3) / 4);
+  static const int fwd_cap = getenv("BQ_LN_FWD_BLOCKS") ? atoi(getenv("BQ_LN_FWD_BLOCKS")) : 1024;  // rows are strided over the grid (tools/ln_sweep.sh)
+  const dim3 grid(((M + 3) / 4) < fwd_cap ? (M + 3) / 4 : fwd_cap);
   hipStream_t st = (hipStream_t)stream;
 #define BQ_LN_FWD(N)                                                                                           \
   hipLaunchKernelGGL(drop_add_ln_fwd_kernel<N>, grid, dim3(256), 0, st, (const __bf16 *)x, (const __bf16 *)residual, \
@@ -448,8 +450,9 @@ extern "C" __attribute__((visibility("default"))) int bq_drop_add_ln_bwd(
   BQ_REQUIRE(p_path == 0.0f || rows_per_sample > 0, BQ_EINVAL, "drop_add_ln_bwd: rows_per_sample");
   LnArgs a{M, H, eps, 1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr,
            (unsigned)((double)p_path * 4294967296.0), 1.0f / (1.0f - p_path), rows_per_sample};
+  static const int bwd_cap = getenv("BQ_LN_BWD_BLOCKS") ? atoi(getenv("BQ_LN_BWD_BLOCKS")) : 512;
   int blocks = (M + 3) / 4;
-  if (blocks > 512) blocks = 512;
+  if (blocks > bwd_cap) blocks = bwd_cap;
   hipStream_t st = (hipStream_t)stream;
 #define BQ_LN_BWD(N)                                                                                            \
   hipLaunchKernelGGL(drop_add_ln_bwd_kernel<N>, dim3(blocks), dim3(256), 0, st, (const __bf16 *)x,               \

@@ -17,7 +17,7 @@ def ref_attention(q, k, v, scale):
 
 
 @pytest.mark.parametrize("B,H,L", [(1, 1, 32), (2, 3, 64), (1, 2, 77), (2, 12, 197), (1, 4, 1025), (2, 2, 901),
-                                   (1, 1, 1), (1, 2, 129)])
+                                   (1, 1, 1), (1, 2, 129), (1, 2, 4097)])  # 4097 = config c5 (1024^2 view)
 def test_attn_fwd_vs_torch_fp32(dev, B, H, L):
     from bridgeqa_amd import _ext
     g = torch.Generator().manual_seed(L)
@@ -46,7 +46,8 @@ def test_attn_fwd_rescale_branch(dev):
     assert (lse - want_lse).abs().max() < 2e-3
 
 
-@pytest.mark.parametrize("B,H,L", [(1, 1, 32), (2, 3, 64), (1, 2, 77), (2, 4, 197), (1, 2, 1025), (1, 1, 130)])
+@pytest.mark.parametrize("B,H,L", [(1, 1, 32), (2, 3, 64), (1, 2, 77), (2, 4, 197), (1, 2, 1025), (1, 1, 130),
+                                   (1, 1, 4097)])
 def test_attn_bwd_vs_torch_autograd_fp32(dev, B, H, L):
     """dQ, dK, dV of the fused kernels vs autograd through the fp32 reference composition on the same
     bf16-rounded inputs; tolerance 3e-2 relative-L2 (bf16 P / dS operands, fp32 accumulation)."""

@@ -264,7 +264,6 @@ def main():
             loss = total_loss(model(dict(batch)))
             loss.backward()
             opt.step()
-            fusion_ops.refresh_shadows()
             return loss
         graph_body = eager_step
         after_replay = lambda: None

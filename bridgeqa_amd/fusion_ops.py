@@ -78,9 +78,17 @@ class fork(object):
                 t.record_stream(self.main)
 
 
+_OPT_HOOK = [None]
+
+
 def set_compute_dtype(dtype):
+    """bf16: GEMM operands are bf16 copies ("shadows") of the fp32 master parameters.  A global optimizer post-step
+    hook keeps them current (refresh_shadows), whatever optimizer the caller uses."""
     global _COMPUTE_DTYPE
     prev, _COMPUTE_DTYPE = _COMPUTE_DTYPE, dtype
+    if dtype != torch.float32 and _OPT_HOOK[0] is None:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+        _OPT_HOOK[0] = register_optimizer_step_post_hook(lambda opt, args, kwargs: refresh_shadows())
     return prev
 
 
@@ -88,24 +96,12 @@ def compute_dtype():
     return _COMPUTE_DTYPE
 
 
-_PARAM_CACHE = {}
-
-
 def _c(t):
-    """Cast to the compute dtype.  Parameters are cast once per optimizer step: the cached copy is keyed by the
-    parameter's in-place version counter, so any optimizer update (or load_state_dict) invalidates it; the cast
-    stays in the autograd graph, so gradients still reach the fp32 master weight."""
+    """Cast to the compute dtype (inside autograd: gradients reach an fp32 parameter through the cast).  No caching:
+    version counters cannot be trusted to see an optimizer update (the fused multi-tensor optimizers do not bump
+    them -- measured on torch 2.10), and the parameters on hot paths go through _shadow() / refresh_shadows()."""
     if t.dtype == _COMPUTE_DTYPE:
         return t
-    if isinstance(t, torch.nn.Parameter):
-        key = id(t)
-        hit = _PARAM_CACHE.get(key)
-        if hit is not None and hit[0] == t._version and hit[1].dtype == _COMPUTE_DTYPE \
-                and hit[1].requires_grad == (t.requires_grad and torch.is_grad_enabled()):
-            return hit[1]
-        c = t.to(_COMPUTE_DTYPE)
-        _PARAM_CACHE[key] = (t._version, c)
-        return c
     return t.to(_COMPUTE_DTYPE)
 
 
@@ -128,21 +124,26 @@ def _shadow(t):
     return c
 
 
-def refresh_shadows():
-    """Call right after the optimizer step: every registered bf16 shadow (and, through them, the concatenated QKV / KV
-    shadows, whose row blocks ARE the per-weight shadows) is brought up to date by ONE multi-tensor cast instead of
-    ~100 separate cast / cat launches scattered over the next forward.  Shadows that are still current are skipped;
-    a shadow nobody refreshed is caught by the version check in _shadow() as before."""
+def refresh_shadows(only_with_grad=True):
+    """Bring every registered bf16 shadow (and, through them, the concatenated QKV / KV operands, whose row blocks ARE
+    the per-weight shadows) up to date with ONE multi-tensor cast.  Runs as a global optimizer post-step hook
+    (set_compute_dtype); call it yourself after any other in-place parameter update.  It does NOT consult version
+    counters: torch's fused multi-tensor optimizers update parameters without bumping them (the lazy check in
+    _shadow() only catches ordinary in-place ops and load_state_dict).  only_with_grad: skip parameters that have no
+    gradient, i.e. that the optimizer did not touch."""
     dst, src = [], []
     for key, (ref, ver, c) in list(_SHADOW.items()):
         t = ref()
         if t is None:
             del _SHADOW[key]
             continue
-        if ver != t._version and c.dtype == _COMPUTE_DTYPE and c.device == t.device:
-            dst.append(c)
-            src.append(t.detach())
-            _SHADOW[key] = (ref, t._version, c)
+        if c.dtype != _COMPUTE_DTYPE or c.device != t.device:
+            continue
+        if only_with_grad and t.grad is None and ver == t._version:
+            continue
+        dst.append(c)
+        src.append(t.detach())
+        _SHADOW[key] = (ref, t._version, c)
     if dst:
         with torch.no_grad():
             torch._foreach_copy_(dst, src)

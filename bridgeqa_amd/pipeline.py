@@ -144,8 +144,7 @@ class PhasedTrainStep(object):
         if self.grad_hook is not None:
             self.grad_hook()
         if self.opt is not None:
-            self.opt.step()
-            ops.refresh_shadows()  # bf16 operand copies of the updated weights: one multi-tensor cast
+            self.opt.step()  # (fusion_ops' optimizer post-step hook refreshes the bf16 weight shadows here)
         st = self._state
         self.loss = st["det_loss"].detach() + st["fusion_loss"]
 

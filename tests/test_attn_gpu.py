@@ -510,3 +510,34 @@ def test_shadow_weights_follow_the_optimizer(dev):
             assert torch.allclose(a, ra, atol=2e-2, rtol=2e-2) and torch.allclose(b, rb, atol=2e-2, rtol=2e-2), mode
     finally:
         ops.set_compute_dtype(prev_dt)
+
+
+@pytest.mark.parametrize("capturable", [False, True])
+def test_fused_optimizer_updates_reach_the_bf16_operands(dev, capturable):
+    """torch's fused multi-tensor AdamW updates parameters WITHOUT bumping their version counters: the bf16 operand
+    copies must still follow (global optimizer post-step hook -> refresh_shadows), for single and fused-QKV linears."""
+    from bridgeqa_amd import fusion_ops as ops
+    prev_dt = ops.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(3)
+        lin = torch.nn.Linear(256, 256).to(dev)
+        trio = [torch.nn.Linear(256, 256).to(dev) for _ in range(3)]
+        params = list(lin.parameters()) + [p for m in trio for p in m.parameters()]
+        opt = torch.optim.AdamW(params, lr=5e-2, fused=True, capturable=capturable)
+        x = torch.randn(4, 7, 256, device=dev).to(torch.bfloat16)
+        for _ in range(2):
+            y = ops.linear(x, lin.weight, lin.bias).float().square().mean() + ops.multi_linear(x, trio).float().square().mean()
+            opt.zero_grad(set_to_none=True)
+            y.backward()
+            before = lin.weight.detach().clone()
+            opt.step()
+            assert not torch.equal(before, lin.weight.detach())
+            with torch.no_grad():
+                f = lambda m: torch.nn.functional.linear(x, m.weight.to(torch.bfloat16), m.bias.to(torch.bfloat16)).float()
+                got1, got3 = ops.linear(x, lin.weight, lin.bias).float(), ops.multi_linear(x, trio).float()
+                assert torch.allclose(got1, f(lin), atol=2e-2, rtol=2e-2)
+                assert torch.allclose(got3, torch.stack([f(m) for m in trio], dim=-2), atol=2e-2, rtol=2e-2)
+                stale = torch.nn.functional.linear(x, before.to(torch.bfloat16), lin.bias.to(torch.bfloat16)).float()
+                assert not torch.allclose(got1, stale, atol=1e-3, rtol=1e-3)  # lr is large enough to tell them apart
+    finally:
+        ops.set_compute_dtype(prev_dt)

@@ -90,3 +90,29 @@ def test_precomputed_geometry_is_value_neutral(dev):
         b = bb({"point_clouds": pc, "geometry": geo})
     for k in ("sa1_inds", "sa2_inds", "fp2_inds", "sa4_xyz", "sa1_features", "sa4_features", "fp2_features"):
         assert torch.equal(a[k], b[k]), k
+
+
+def test_whole_hot_path_bf16_fused_vs_fp32_reference_composition(dev):
+    """End to end: ScanQAHotPath (detector + ViT + twin fusion + decoder) with every fused bf16 kernel in play vs
+    the SAME module in fp32 through the reference composition (dropout / stochastic depth off): losses within 3 %,
+    FPS / ball-query indices identical, first-level detector features within the bf16 tolerance of SURVEY §8a (rel-L2 <= 2e-2)."""
+    import bench
+    from bridgeqa_amd import fusion_ops as ops
+    model = _small_model(dev)
+    batch = _batch(dev)
+    with torch.no_grad():
+        ref = model(dict(batch))
+        ref_loss = bench.total_loss(ref).item()
+    prev = ops.set_compute_dtype(torch.bfloat16)
+    try:
+        with torch.no_grad():
+            got = model(dict(batch))
+            got_loss = bench.total_loss(got).item()
+    finally:
+        ops.set_compute_dtype(prev)
+    assert torch.equal(ref["sa1_inds"], got["sa1_inds"]) and torch.equal(ref["fp2_inds"], got["fp2_inds"])
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+    assert rel(got["sa1_features"], ref["sa1_features"]) < 2e-2
+    # 14 bf16 conv+BatchNorm(train)+ReLU layers deep (4 SA levels + 2 FP levels), each within ~1e-2: errors compound
+    assert rel(got["fp2_features"], ref["fp2_features"]) < 1e-1
+    assert abs(got_loss - ref_loss) <= 3e-2 * abs(ref_loss), (got_loss, ref_loss)

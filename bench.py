@@ -234,7 +234,11 @@ def main():
         # ---- single GPU, c3: one HIP graph per phase, image / fusion chain on one stream, detector on a second,
         # high-priority one (bridgeqa_amd/pipeline.py) -------------------------------------------------------
         from bridgeqa_amd.pipeline import PhasedTrainStep
-        opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-5, fused=True, capturable=use_graph)
+        if os.environ.get("BQ_TORCH_ADAMW") == "1":
+            opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-5, fused=True, capturable=use_graph)
+        else:  # one HIP launch for all parameters, bf16 operand copies written in the same pass (csrc/adamw.hip)
+            from bridgeqa_amd.optim import FusedAdamW
+            opt = FusedAdamW(model.parameters(), lr=5e-4, weight_decay=1e-5)
         # the geometry phase (FPS / ball query of the next batch) stays eager so that the roofline kernel is timed
         # with HIP events INSIDE the timed steps, on the stream it is launched on
         pipe = PhasedTrainStep(model, batch, det_loss, fusion_loss, opt, use_graphs=use_graph,

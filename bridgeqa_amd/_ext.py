@@ -425,6 +425,23 @@ def colsum(g2d):
     return out
 
 
+# ---- multi-tensor AdamW that also writes the bf16 shadows (csrc/adamw.hip) -----------------------------
+_lib.bq_adamw_chunk_elems.restype = ctypes.c_int
+_lib.bq_adamw_tensor_bytes.restype = ctypes.c_int
+_lib.bq_adamw_multi.argtypes = [_vp, _vp, _i, _vp, _f, _f, _f, _vp]
+_lib.bq_adamw_multi.restype = ctypes.c_int
+ADAMW_CHUNK = _lib.bq_adamw_chunk_elems()
+ADAMW_TENSOR_BYTES = _lib.bq_adamw_tensor_bytes()
+
+
+def adamw_multi(table, chunks, step, beta1, beta2, eps):
+    """table: uint8 device tensor of packed AdamWTensor records; chunks: int32 (n, 2) device tensor; step: f32 device
+    scalar holding the 1-based count of THIS update."""
+    with torch.cuda.device(table.device):
+        _check(_lib.bq_adamw_multi(_p(table), _p(chunks), chunks.shape[0], _p(step), float(beta1), float(beta2),
+                                   float(eps), _stream()), "adamw")
+
+
 # ---- training-mode BatchNorm + ReLU (+ max over nsample) on point-major bf16 rows (csrc/bn.hip) -------
 _lib.bq_bn_chunks.argtypes = [_l, _i, _i]
 _lib.bq_bn_chunks.restype = ctypes.c_int

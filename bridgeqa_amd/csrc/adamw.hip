@@ -1,0 +1,103 @@
+// Multi-tensor AdamW for gfx950 that also writes the bf16 operand copies ("shadows") of the updated parameters.
+//
+// The optimizer step of the hot path (reference scripts/train.py:410-417: torch.optim.AdamW, betas (0.9, 0.999),
+// eps 1e-8, decoupled weight decay) is pure streaming: read p, g, m, v (16 B / parameter), write p, m, v (12 B).  The
+// bf16 GEMM path needs a bf16 copy of every updated weight for the next forward; emitting it here costs 2 B / parameter
+// instead of a second pass that re-reads p (6 B / parameter, bridgeqa_amd/fusion_ops.refresh_shadows).
+// One launch for all tensors: a chunk table maps workgroups to (tensor, offset); 4 x fp32 per lane per iteration.
+//
+// Arithmetic = torch's (single-tensor definition, torch/optim/adamw.py, amsgrad = False, maximize = False):
+//   p  <- p * (1 - lr * wd)
+//   m  <- beta1 * m + (1 - beta1) * g            v <- beta2 * v + (1 - beta2) * g * g
+//   p  <- p - (lr / (1 - beta1^t)) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+// with t read from device memory (graph-replay safe: the caller increments it on the stream before this launch).
+#include <cstdint>
+#include "bq_common.h"
+
+namespace bq {
+
+struct AdamWTensor {
+  float *p;
+  const float *g;
+  float *m;
+  float *v;
+  __bf16 *shadow;  // may be null
+  long n;
+  float lr, wd;
+};
+
+constexpr int ADAMW_CHUNK = 8192;  // elements per workgroup
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamWTensor *__restrict__ table,
+                                                    const int2 *__restrict__ chunks, const float *__restrict__ step,
+                                                    float beta1, float beta2, float eps) {
+  const int2 ck = chunks[blockIdx.x];
+  const AdamWTensor T = table[ck.x];
+  const long off = (long)ck.y * ADAMW_CHUNK;
+  const long end = min(T.n, off + ADAMW_CHUNK);
+  const float t = step[0];
+  const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
+  const float step_size = T.lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2), decay = 1.0f - T.lr * T.wd;
+  const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+  const bool vec = ((T.n & 3) == 0) && ((((uintptr_t)T.p | (uintptr_t)T.g | (uintptr_t)T.m | (uintptr_t)T.v) & 15) == 0) &&
+                   (!T.shadow || (((uintptr_t)T.shadow & 7) == 0));
+  if (vec) {
+    for (long i = off + threadIdx.x * 4; i < end; i += 256 * 4) {
+      float4 p = *reinterpret_cast<const float4 *>(T.p + i);
+      const float4 g = *reinterpret_cast<const float4 *>(T.g + i);
+      float4 m = *reinterpret_cast<const float4 *>(T.m + i), v = *reinterpret_cast<const float4 *>(T.v + i);
+      float *pp = &p.x, *mm = &m.x, *vv = &v.x;
+      const float *gg = &g.x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float q = pp[j] * decay;
+        mm[j] = beta1 * mm[j] + omb1 * gg[j];
+        vv[j] = beta2 * vv[j] + omb2 * gg[j] * gg[j];
+        const float denom = sqrtf(vv[j]) * inv_sqrt_bc2 + eps;
+        pp[j] = q - step_size * (mm[j] / denom);
+      }
+      *reinterpret_cast<float4 *>(T.p + i) = p;
+      *reinterpret_cast<float4 *>(T.m + i) = m;
+      *reinterpret_cast<float4 *>(T.v + i) = v;
+      if (T.shadow) {
+        bf16x4 s;
+        s[0] = (__bf16)p.x; s[1] = (__bf16)p.y; s[2] = (__bf16)p.z; s[3] = (__bf16)p.w;
+        *reinterpret_cast<bf16x4 *>(T.shadow + i) = s;
+      }
+    }
+  } else {
+    for (long i = off + threadIdx.x; i < end; i += 256) {
+      const float g = T.g[i];
+      const float q = T.p[i] * decay;
+      const float m = beta1 * T.m[i] + omb1 * g;
+      const float v = beta2 * T.v[i] + omb2 * g * g;
+      const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+      const float pn = q - step_size * (m / denom);
+      T.p[i] = pn; T.m[i] = m; T.v[i] = v;
+      if (T.shadow) T.shadow[i] = (__bf16)pn;
+    }
+  }
+}
+
+}  // namespace bq
+using namespace bq;
+
+extern "C" __attribute__((visibility("default"))) int bq_adamw_chunk_elems(void) { return ADAMW_CHUNK; }
+extern "C" __attribute__((visibility("default"))) int bq_adamw_tensor_bytes(void) { return (int)sizeof(AdamWTensor); }
+
+// table: n_tensors records {p, g, m, v, shadow|NULL (pointers), n (int64), lr, wd (f32)} in DEVICE memory (layout =
+// struct AdamWTensor above, bq_adamw_tensor_bytes() each); chunks: n_chunks x {tensor index, chunk index} int32 pairs
+// in device memory covering every tensor in pieces of bq_adamw_chunk_elems() elements; step: device f32, the 1-based
+// step count t of THIS update.
+extern "C" __attribute__((visibility("default"))) int bq_adamw_multi(const void *table, const void *chunks, int n_chunks,
+                                                                     const float *step, float beta1, float beta2,
+                                                                     float eps, void *stream) {
+  BQ_REQUIRE(n_chunks >= 0, BQ_EINVAL, "adamw: bad chunk count");
+  if (n_chunks == 0) return BQ_OK;
+  BQ_REQUIRE(table && chunks && step, BQ_EINVAL, "adamw: null pointer");
+  hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamWTensor *)table,
+                     (const int2 *)chunks, step, beta1, beta2, eps);
+  return check_launch("adamw");
+}

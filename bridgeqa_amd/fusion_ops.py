@@ -124,6 +124,27 @@ def _shadow(t):
     return c
 
 
+def shadow_of(param):
+    """the registered bf16 shadow tensor of a parameter (None if it has none, or not of the current compute dtype)"""
+    ent = _SHADOW.get(id(param))
+    if ent is None or ent[0]() is not param or ent[2].dtype != _COMPUTE_DTYPE or ent[2].device != param.device:
+        return None
+    return ent[2]
+
+
+_FRESH = set()
+
+
+def shadows_written(params):
+    """An optimizer that writes the shadows itself (optim.FusedAdamW) reports them here; the post-step hook's
+    refresh_shadows() then skips them."""
+    for p in params:
+        ent = _SHADOW.get(id(p))
+        if ent is not None:
+            _SHADOW[id(p)] = (ent[0], p._version, ent[2])
+            _FRESH.add(id(p))
+
+
 def refresh_shadows(only_with_grad=True):
     """Bring every registered bf16 shadow (and, through them, the concatenated QKV / KV operands, whose row blocks ARE
     the per-weight shadows) up to date with ONE multi-tensor cast.  Runs as a global optimizer post-step hook
@@ -139,11 +160,14 @@ def refresh_shadows(only_with_grad=True):
             continue
         if c.dtype != _COMPUTE_DTYPE or c.device != t.device:
             continue
+        if key in _FRESH and ver == t._version:
+            continue  # written by the optimizer kernel itself
         if only_with_grad and t.grad is None and ver == t._version:
             continue
         dst.append(c)
         src.append(t.detach())
         _SHADOW[key] = (ref, t._version, c)
+    _FRESH.clear()
     if dst:
         with torch.no_grad():
             torch._foreach_copy_(dst, src)

@@ -541,3 +541,37 @@ def test_fused_optimizer_updates_reach_the_bf16_operands(dev, capturable):
                 assert not torch.allclose(got1, stale, atol=1e-3, rtol=1e-3)  # lr is large enough to tell them apart
     finally:
         ops.set_compute_dtype(prev_dt)
+
+
+def test_fused_adamw_matches_torch_adamw_and_writes_the_shadows(dev):
+    """optim.FusedAdamW (csrc/adamw.hip) == torch.optim.AdamW over several steps (odd sizes, two parameter groups with
+    their own lr / weight decay, a parameter without gradient), and the bf16 shadows it writes are the updated weights."""
+    from bridgeqa_amd import fusion_ops as ops
+    from bridgeqa_amd.optim import FusedAdamW
+    prev_dt = ops.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(4)
+        shapes = [(768, 768), (3072,), (37, 5), (1,), (256, 259)]
+        mine = [torch.nn.Parameter(torch.randn(*s, device=dev)) for s in shapes] + [torch.nn.Parameter(torch.randn(8, device=dev))]
+        ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+        lin_w, lin_b = mine[0], mine[1][:768].detach()  # give the first weight a registered shadow
+        x = torch.randn(4, 768, device=dev).to(torch.bfloat16)
+        ops.linear(x, lin_w, None)
+        assert ops.shadow_of(lin_w) is not None
+        groups = lambda ps: [dict(params=ps[:3], lr=3e-3, weight_decay=1e-2), dict(params=ps[3:], lr=1e-2, weight_decay=0.0)]
+        o1 = FusedAdamW(groups(mine), betas=(0.9, 0.999), eps=1e-8)
+        o2 = torch.optim.AdamW(groups(ref), betas=(0.9, 0.999), eps=1e-8)
+        for step in range(5):
+            for a, b in zip(mine[:-1], ref[:-1]):  # the last parameter never gets a gradient
+                g = torch.randn_like(a)
+                a.grad, b.grad = g.clone(), g.clone()
+            o1.step(); o2.step()
+            for a, b in zip(mine, ref):
+                assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), (step, a.shape, (a - b).abs().max().item())
+            assert torch.equal(ops.shadow_of(lin_w), lin_w.detach().to(torch.bfloat16))
+            got = ops.linear(x, lin_w, None).float()
+            want = torch.nn.functional.linear(x, lin_w.detach().to(torch.bfloat16)).float()
+            assert torch.allclose(got, want, atol=2e-2, rtol=2e-2)
+        assert torch.equal(mine[-1], ref[-1])
+    finally:
+        ops.set_compute_dtype(prev_dt)

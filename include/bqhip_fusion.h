@@ -110,6 +110,17 @@ BQ_API int bq_bn_backward(const void *dy, const void *x, const float *scale, con
                           const float *rstd, float *partial, float *dgb, void *dx, long R, int C, int S, int relu,
                           int pool, void *stream);
 
+/* ---- multi-tensor AdamW that also writes the bf16 operand copies (csrc/adamw.hip) ----------------------------
+ * Replaces torch.optim.AdamW(...).step() of the reference's training step (scripts/train.py:410-417) and the
+ * per-weight fp32 -> bf16 casts of the next forward.  table: n records {p, g, m, v, shadow|NULL (device pointers),
+ * n (int64 elements), lr, weight_decay (f32)} of bq_adamw_tensor_bytes() bytes each, in device memory; chunks:
+ * n_chunks x {tensor index, chunk index} int32 pairs covering every tensor in pieces of bq_adamw_chunk_elems()
+ * elements; step: device f32 = the 1-based count of THIS update (graph-replay safe).  amsgrad / maximize: off. */
+BQ_API int bq_adamw_chunk_elems(void);
+BQ_API int bq_adamw_tensor_bytes(void);
+BQ_API int bq_adamw_multi(const void *table, const void *chunks, int n_chunks, const float *step, float beta1,
+                          float beta2, float eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

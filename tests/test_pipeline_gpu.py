@@ -48,7 +48,8 @@ def test_phased_step_gradients_equal_single_backward(dev):
     assert worst < 2e-3, worst  # fp32 atomics in the detector backward (three_interpolate / group grads)
 
 
-def test_phased_step_graph_replay_trains(dev):
+@pytest.mark.parametrize("optimizer", ["torch", "bq"])
+def test_phased_step_graph_replay_trains(dev, optimizer):
     """six captured graphs on two streams: replays are finite, the loss moves, parameters change every step"""
     import bench
     from bridgeqa_amd import fusion_ops as ops
@@ -57,7 +58,11 @@ def test_phased_step_graph_replay_trains(dev):
     try:
         model = _small_model(dev)
         batch = _batch(dev)
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True, capturable=True)
+        if optimizer == "torch":
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True, capturable=True)
+        else:
+            from bridgeqa_amd.optim import FusedAdamW
+            opt = FusedAdamW(model.parameters(), lr=1e-3)
         pipe = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, opt, use_graphs=True).capture(warmup=3)
         w = model.blip_model.visual_encoder.blocks[0].attn.qkv.weight
         w0 = w.detach().clone()

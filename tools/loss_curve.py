@@ -14,7 +14,11 @@ args = bench.parse()
 torch.manual_seed(0)
 model = bench.build_model("c3", args.cin, args.image).to(dev)
 batch = bench.make_batch(args, "c3", args.batch, 42, dev)
-opt = torch.optim.AdamW(model.parameters(), lr=float(os.environ.get("LR", "1e-4")), weight_decay=1e-5, fused=True, capturable=True)
+if os.environ.get("BQ_TORCH_ADAMW") == "1":
+    opt = torch.optim.AdamW(model.parameters(), lr=float(os.environ.get("LR", "1e-4")), weight_decay=1e-5, fused=True, capturable=True)
+else:
+    from bridgeqa_amd.optim import FusedAdamW
+    opt = FusedAdamW(model.parameters(), lr=float(os.environ.get("LR", "1e-4")), weight_decay=1e-5)
 pipe = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, opt, use_graphs=True).capture(warmup=3)
 vals = []
 for i in range(int(os.environ.get("STEPS", "60"))):

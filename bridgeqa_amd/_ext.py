@@ -425,6 +425,18 @@ def colsum(g2d):
     return out
 
 
+_lib.bq_gelu_fwd_bf16.argtypes = [_vp, _vp, _l, _vp]
+_lib.bq_gelu_fwd_bf16.restype = ctypes.c_int
+
+
+def gelu_fwd(x):
+    """exact GELU of a contiguous bf16 tensor (numel % 8 == 0)"""
+    with torch.cuda.device(x.device):
+        y = torch.empty_like(x)
+        _check(_lib.bq_gelu_fwd_bf16(_p(x), _p(y), x.numel(), _stream()), "gelu_fwd")
+    return y
+
+
 # ---- multi-tensor AdamW that also writes the bf16 shadows (csrc/adamw.hip) -----------------------------
 _lib.bq_adamw_chunk_elems.restype = ctypes.c_int
 _lib.bq_adamw_tensor_bytes.restype = ctypes.c_int

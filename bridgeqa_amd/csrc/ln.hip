@@ -363,8 +363,37 @@ __global__ __launch_bounds__(256) void colsum_fold_kernel(const float *__restric
   if (ph == 0 && c < N) out[c] = (s[0][cl] + s[1][cl]) + (s[2][cl] + s[3][cl]);
 }
 
+// exact (erf) GELU, bf16 in / out, fp32 arithmetic: y = 0.5 x (1 + erf(x / sqrt 2)) -- vit.py act_layer=nn.GELU and
+// med_config "hidden_act": "gelu".  16-B loads / stores, 4 vectors in flight per lane.
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const __bf16 *__restrict__ x, __bf16 *__restrict__ y, long n8) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + i * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = (float)v[j];
+      o[j] = (__bf16)(0.5f * f * (1.0f + erff(f * 0.70710678118654752440f)));
+    }
+    *reinterpret_cast<bf16x8 *>(y + i * 8) = o;
+  }
+}
+
 }  // namespace bq
 using namespace bq;
+
+// y = GELU(x) (exact), n bf16 elements, n % 8 == 0, 16-B aligned
+extern "C" __attribute__((visibility("default"))) int bq_gelu_fwd_bf16(const void *x, void *y, long n, void *stream) {
+  BQ_REQUIRE(n >= 0 && n % 8 == 0, BQ_EINVAL, "gelu: n must be a multiple of 8");
+  if (n == 0) return BQ_OK;
+  BQ_REQUIRE(x && y && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, BQ_EINVAL, "gelu: null / unaligned pointer");
+  const long n8 = n / 8;
+  long blocks = (n8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)x,
+                     (__bf16 *)y, n8);
+  return check_launch("gelu_fwd");
+}
 
 // out[n] = sum_m g[m][n]; g bf16 (M, N) row-major with N % 4 == 0, out f32 (N), every element written.
 // bq_colsum_chunks(M) = C row chunks: when C > 1 the caller passes `partial` (C * N floats, uninitialised), and for

@@ -110,6 +110,9 @@ BQ_API int bq_bn_backward(const void *dy, const void *x, const float *scale, con
                           const float *rstd, float *partial, float *dgb, void *dx, long R, int C, int S, int relu,
                           int pool, void *stream);
 
+/* exact (erf) GELU, bf16 (vit.py:23-41 Mlp act_layer=nn.GELU); n % 8 == 0, 16-B aligned */
+BQ_API int bq_gelu_fwd_bf16(const void *x, void *y, long n, void *stream);
+
 /* ---- multi-tensor AdamW that also writes the bf16 operand copies (csrc/adamw.hip) ----------------------------
  * Replaces torch.optim.AdamW(...).step() of the reference's training step (scripts/train.py:410-417) and the
  * per-weight fp32 -> bf16 casts of the next forward.  table: n records {p, g, m, v, shadow|NULL (device pointers),

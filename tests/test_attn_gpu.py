@@ -575,3 +575,12 @@ def test_fused_adamw_matches_torch_adamw_and_writes_the_shadows(dev):
         assert torch.equal(mine[-1], ref[-1])
     finally:
         ops.set_compute_dtype(prev_dt)
+
+
+def test_gelu_kernel_matches_torch_exact_gelu(dev):
+    from bridgeqa_amd import _ext
+    x = (torch.randn(3, 1025, 3072, device=dev) * 2).to(torch.bfloat16)
+    got = _ext.gelu_fwd(x)
+    want = torch.nn.functional.gelu(x)
+    assert got.dtype == torch.bfloat16 and (got.float() - want.float()).abs().max().item() <= 2 ** -7 * max(1.0, want.float().abs().max().item()) * 0.01 + 1e-2
+    assert ((got.float() - want.float()).norm() / want.float().norm()).item() < 2e-3

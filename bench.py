@@ -242,7 +242,7 @@ def main():
         # the geometry phase (FPS / ball query of the next batch) stays eager so that the roofline kernel is timed
         # with HIP events INSIDE the timed steps, on the stream it is launched on
         pipe = PhasedTrainStep(model, batch, det_loss, fusion_loss, opt, use_graphs=use_graph,
-                               eager_phases=("geometry",))
+                               eager_phases=("geometry",), reserve_cus=int(os.environ.get("BQ_RESERVE_CUS", "0")))
         eager_step = pipe.eager_step
         reducers = {}
         if dp:

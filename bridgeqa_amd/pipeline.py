@@ -35,9 +35,25 @@ import torch
 from . import fusion_ops as ops
 
 
+def _cu_masked_stream(device, lo, hi, total=256):
+    """a HIP stream whose kernels may only run on CUs [lo, hi) (hipExtStreamCreateWithCUMask), as a torch stream"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    words = (ctypes.c_uint32 * (total // 32))()
+    for i in range(lo, hi):
+        words[i // 32] |= (1 << (i % 32))
+    h = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), total // 32, words)
+    if rc != 0:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
 class PhasedTrainStep(object):
     def __init__(self, model, batch, det_loss, fusion_loss, optimizer=None, use_graphs=True, det_priority=0,
-                 grad_hook=None, next_batch=None, prefetch_geometry=True, eager_phases=(), reducers=None):
+                 grad_hook=None, next_batch=None, prefetch_geometry=True, eager_phases=(), reducers=None,
+                 reserve_cus=0):
         """model: ScanQAHotPath (use_blip=True, train mode); batch: static device tensors (replayed in place);
         det_loss(data_dict) -> scalar over detector outputs; fusion_loss(data_dict) -> scalar over blip_loss /
         fused_feat; optimizer: stepped at the end of the step (None: the caller steps);
@@ -49,7 +65,11 @@ class PhasedTrainStep(object):
         reducers: data parallel -- {"fusion" | "image" | "det": ddp.PackedGradReducer over the parameters whose
         gradients that phase produces}: each group is exchanged on a communication stream as soon as its backward
         phase has finished (the fusion group, 3/4 of the bytes, travels under the image and detector backward) and
-        the optimizer waits for all of them."""
+        the optimizer waits for all of them;
+        reserve_cus: N > 0 runs the two image-encoder phases on a stream masked to CUs [N, 256): its GPU-filling
+        kernels then leave N CUs to the detector stream, which otherwise only gets to dispatch at their kernel
+        boundaries (see the module docstring).  MEASURED on c3: 0 -> 50.1 ms/step, 16 -> 52.7, 32 -> 52.7, 48 -> 57.0:
+        the encoder loses more than the detector gains, so the default stays 0 (knob kept for other shapes)."""
         self.model, self.batch, self.det_loss, self.fusion_loss = model, batch, det_loss, fusion_loss
         self.opt, self.grad_hook = optimizer, grad_hook
         self.next_batch = next_batch if next_batch is not None else batch
@@ -69,6 +89,8 @@ class PhasedTrainStep(object):
         dev = batch["point_clouds"].device
         self.dev = dev
         self.s_main = torch.cuda.Stream(device=dev)
+        self.s_img = _cu_masked_stream(dev, int(reserve_cus), 256) if reserve_cus else self.s_main
+        self.e_img_fwd = torch.cuda.Event()
         self.s_det = torch.cuda.Stream(device=dev, priority=det_priority)
         self.e_det_fwd, self.e_fused, self.e_det_bwd, self.e_done = (torch.cuda.Event() for _ in range(4))
         self.use_graphs = use_graphs
@@ -148,11 +170,14 @@ class PhasedTrainStep(object):
         st = self._state
         self.loss = st["det_loss"].detach() + st["fusion_loss"]
 
-    _ORDER = (("det_fwd", "det"), ("geometry", "det"), ("image_fwd", "main"), ("fusion", "main"), ("det_bwd", "det"),
-              ("image_bwd", "main"), ("finish", "main"))
+    # (phase, stream, memory pool): the image phases may sit on their own (CU-masked) stream but still alternate
+    # strictly with the main stream's phases, so they share its pool
+    _ORDER = (("det_fwd", "det", "det"), ("geometry", "det", "det"), ("image_fwd", "img", "main"),
+              ("fusion", "main", "main"), ("det_bwd", "det", "det"), ("image_bwd", "img", "main"),
+              ("finish", "main", "main"))
 
     def _stream(self, which):
-        return self.s_main if which == "main" else self.s_det
+        return {"main": self.s_main, "det": self.s_det, "img": self.s_img}[which]
 
     def _run(self, name, eager):
         if eager or name in self.eager_phases:
@@ -182,15 +207,20 @@ class PhasedTrainStep(object):
         Host ORDER matters: a graph launch blocks the host while its stream's hardware queue is full, so at every
         point the detector stream's launches (short, its queue is usually empty) are issued before the main
         stream's -- otherwise the detector only gets its packets once the main stream has drained (measured)."""
-        sm, sd = self.s_main, self.s_det
+        sm, sd, si = self.s_main, self.s_det, self.s_img
         sd.wait_event(self.e_done)  # parameters of the previous step's optimizer
         with torch.cuda.stream(sd):
             self._run("det_fwd", eager)
             self.e_det_fwd.record(sd)
             if self.prefetch:
                 self._run("geometry", eager)
-        with torch.cuda.stream(sm):
+        if si is not sm:
+            si.wait_event(self.e_done)
+        with torch.cuda.stream(si):
             self._run("image_fwd", eager)
+            self.e_img_fwd.record(si)
+        with torch.cuda.stream(sm):
+            sm.wait_event(self.e_img_fwd)
             sm.wait_event(self.e_det_fwd)
             self._run("fusion", eager)
             self.e_fused.record(sm)
@@ -200,11 +230,13 @@ class PhasedTrainStep(object):
             self._run("det_bwd", eager)
             self.e_det_bwd.record(sd)
         self._reduce("det", self.e_det_bwd)
-        with torch.cuda.stream(sm):
+        si.wait_event(self.e_fused)
+        with torch.cuda.stream(si):
             self._run("image_bwd", eager)
-            self.e_img_bwd.record(sm)
+            self.e_img_bwd.record(si)
         self._reduce("image", self.e_img_bwd)
         with torch.cuda.stream(sm):
+            sm.wait_event(self.e_img_bwd)
             sm.wait_event(self.e_det_bwd)
             for ev in self._comm_events:
                 sm.wait_event(ev)
@@ -218,7 +250,7 @@ class PhasedTrainStep(object):
         (Parameters that get no gradient on this path -- unused BLIP heads -- are left out, as DDP's
         find_unused_parameters would discover every step.)"""
         cur = torch.cuda.current_stream(self.dev)
-        for s_ in (self.s_main, self.s_det):
+        for s_ in (self.s_main, self.s_det, self.s_img):
             s_.wait_stream(cur)
         self.e_done.record(self.s_main)
         if self.prefetch and self._geo_next is None:
@@ -257,8 +289,8 @@ class PhasedTrainStep(object):
         one stream share a memory pool (they always replay in capture order); the two streams' pools are separate
         because their graphs run concurrently."""
         cur = torch.cuda.current_stream(self.dev)
-        self.s_main.wait_stream(cur)
-        self.s_det.wait_stream(cur)
+        for s_ in (self.s_main, self.s_det, self.s_img):
+            s_.wait_stream(cur)
         self.e_done.record(self.s_main)
         if self.prefetch:
             with torch.cuda.stream(self.s_det):
@@ -272,11 +304,11 @@ class PhasedTrainStep(object):
         self._state = {}
         pools = {"main": torch.cuda.graph_pool_handle(), "det": torch.cuda.graph_pool_handle()}
         self.graphs = {}
-        for name, which in self._ORDER:
+        for name, which, pool in self._ORDER:
             if (name == "geometry" and not self.prefetch) or name in self.eager_phases:
                 continue
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pools[which], stream=self._stream(which)):
+            with torch.cuda.graph(g, pool=pools[pool], stream=self._stream(which)):
                 getattr(self, "_" + name)()
             self.graphs[name] = g
             torch.cuda.synchronize(self.dev)

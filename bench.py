@@ -26,9 +26,10 @@ if ROOT not in sys.path:
 
 WORKLOADS = {
     "c2": "c2: DET-stage hot path (VoteNet backbone + voting + vote-cluster/proposal), fwd+bwd+AdamW, "
-          "stand-in detector loss",
+          "the reference's detection loss (vote/objectness/box/sem-cls) on synthetic boxes",
     "c3": "c3: VQA-stage hot path (c2 + ViT-B/16 on one 512x512 view + paralleltwin MED fusion + shared LM "
-          "answer decoder on both streams), fwd+bwd+AdamW, LM answer loss + stand-in detector loss",
+          "answer decoder on both streams), fwd+bwd+AdamW, LM answer loss + the reference's detection loss "
+          "(vote/objectness/box/sem-cls) on synthetic boxes",
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -87,11 +88,48 @@ def synth_text(B, L, La, seed, device):
             {"input_ids": a.to(device), "attention_mask": am.to(device)})
 
 
+DET_LOSS_WEIGHTS = dict(vote_loss=1.0, objectness_loss=0.5, box_loss=1.0, sem_cls_loss=0.1)  # scripts/train.py:97-103
+NUM_GT_BOXES, MAX_NUM_OBJ = 8, 128  # SURVEY §8d synthetic labels; lib/dataset.py:31
+
+
+def det_config():
+    """the members of the reference's ScannetDatasetConfig that the losses read, at ScanQAHotPath's defaults"""
+    import types
+    import numpy as np
+    return types.SimpleNamespace(num_heading_bin=1, num_size_cluster=18, num_class=18, mean_size_arr=np.ones((18, 3)))
+
+
+def synth_labels(xyz, seed):
+    """8 random axis-aligned boxes per scene with the label fields of lib/dataset.py:553-577 (centre,
+    heading class / residual = 0, size class / residual w.r.t. mean_size_arr = 1, semantic class, box mask, padded to
+    MAX_NUM_OBJ at -100 like dataset.py:423) and per-point votes towards the centre of the box a point lies in."""
+    B, N, _ = xyz.shape
+    g = torch.Generator().manual_seed(seed)
+    centre = torch.full((B, MAX_NUM_OBJ, 3), -100.0)
+    size = torch.ones(B, MAX_NUM_OBJ, 3)
+    centre[:, :NUM_GT_BOXES] = torch.rand(B, NUM_GT_BOXES, 3, generator=g) * torch.tensor([8.0, 8.0, 3.0])
+    size[:, :NUM_GT_BOXES] = torch.rand(B, NUM_GT_BOXES, 3, generator=g) * 1.2 + 0.3
+    cls = torch.zeros(B, MAX_NUM_OBJ, dtype=torch.long)
+    cls[:, :NUM_GT_BOXES] = torch.randint(0, 18, (B, NUM_GT_BOXES), generator=g)
+    mask = torch.zeros(B, MAX_NUM_OBJ)
+    mask[:, :NUM_GT_BOXES] = 1
+    c, h = centre[:, None, :NUM_GT_BOXES], size[:, None, :NUM_GT_BOXES] / 2
+    inside = ((xyz[:, :, None] - c).abs() <= h).all(-1)                     # (B, N, 8)
+    first = inside.float().argmax(-1)                                       # first box containing the point
+    vote = torch.gather(centre[:, :NUM_GT_BOXES], 1, first[..., None].expand(-1, -1, 3)) - xyz
+    vmask = inside.any(-1)
+    vote = torch.where(vmask[..., None], vote, torch.zeros_like(vote))
+    return {"center_label": centre, "heading_class_label": torch.zeros(B, MAX_NUM_OBJ, dtype=torch.long),
+            "heading_residual_label": torch.zeros(B, MAX_NUM_OBJ), "size_class_label": cls,
+            "size_residual_label": size - 1.0, "sem_cls_label": cls.clone(), "box_label_mask": mask,
+            "vote_label": vote.repeat(1, 1, 3), "vote_label_mask": vmask.long()}
+
+
 def det_loss(dd):
-    """Stand-in scalar with gradients into every detector head (the reference's losses are SURVEY §8f 'next')."""
-    return (dd["objectness_scores"].square().mean() + dd["center"].square().mean() * 1e-2 +
-            dd["size_residuals_normalized"].square().mean() + dd["sem_cls_scores"].square().mean() +
-            (dd["vote_xyz"] - dd["fp2_xyz"]).abs().mean())
+    """the reference's detection loss (lib/loss_helper.py get_loss, detection terms: vote + objectness + box + sem-cls,
+    scripts/train.py weights, x10) through bridgeqa_amd/loss_helper.py"""
+    from bridgeqa_amd.loss_helper import get_detection_loss
+    return get_detection_loss(dd, det_config(), DET_LOSS_WEIGHTS)[0]
 
 
 def path_roofline(args, workload):
@@ -162,6 +200,7 @@ class OpTimer(object):
 
 def make_batch(args, workload, B, seed, device):
     batch = {"point_clouds": synth_batch(B, args.points, args.cin, seed, device), "phase": "train"}
+    batch.update({k: v.to(device) for k, v in synth_labels(batch["point_clouds"][..., :3].cpu(), seed + 7).items()})
     if workload == "c3":
         g = torch.Generator().manual_seed(seed + 1)
         batch["images"] = torch.randn(B, 1, 3, args.image, args.image, generator=g).to(device)

@@ -1,0 +1,141 @@
+"""Detection losses of the training step -- mirror of the reference's lib/loss_helper.py:25-193 and the detection part of
+get_loss (:355-464): vote loss, objectness loss, box (centre / heading / size) loss and semantic-class loss.  SURVEY.md
+§8f rank 1: the caller on the output side of the hot path.  Same function names, data_dict keys and arithmetic; what
+changes underneath: nothing is hard-wired to `.cuda()` (the reference's losses cannot run on any other device), the
+label / mask tensors are built by comparisons instead of boolean-mask assignment (each of those is a device-to-host
+sync through nonzero()), one-hot selections are gathers, and nn_distance broadcasts instead of tiling.
+
+Not here (they need the reference-expression and answer-classification heads, outside SURVEY §8's path):
+compute_reference_loss (numpy IoU loop), compute_lang_classification_loss, compute_answer_classification_loss."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .nn_distance import huber_loss, nn_distance
+
+FAR_THRESHOLD = 0.6
+NEAR_THRESHOLD = 0.3
+GT_VOTE_FACTOR = 3  # number of GT votes per point
+OBJECTNESS_CLS_WEIGHTS = [0.2, 0.8]  # put larger weights on positive objectness
+
+
+_CONST = {}
+
+
+def _const(key, device, make):
+    """small constant tensors live on the device once (a host->device copy per step would also break graph capture)"""
+    k = (key, str(device))
+    if k not in _CONST:
+        _CONST[k] = make().to(device)
+    return _CONST[k]
+
+
+def compute_vote_loss(data_dict):
+    """min over (predicted vote, GT vote) pairs of the L1 distance, for seeds that lie in an object (loss_helper.py:25-70)"""
+    batch_size = data_dict["seed_xyz"].shape[0]
+    num_seed = data_dict["seed_xyz"].shape[1]
+    vote_xyz = data_dict["vote_xyz"]
+    seed_inds = data_dict["seed_inds"].long()
+    seed_gt_votes_mask = torch.gather(data_dict["vote_label_mask"], 1, seed_inds)
+    seed_inds_expand = seed_inds.view(batch_size, num_seed, 1).repeat(1, 1, 3 * GT_VOTE_FACTOR)
+    seed_gt_votes = torch.gather(data_dict["vote_label"], 1, seed_inds_expand)
+    seed_gt_votes = seed_gt_votes + data_dict["seed_xyz"].repeat(1, 1, 3)
+    vote_xyz_reshape = vote_xyz.view(batch_size * num_seed, -1, 3)
+    seed_gt_votes_reshape = seed_gt_votes.view(batch_size * num_seed, GT_VOTE_FACTOR, 3)
+    _, _, dist2, _ = nn_distance(vote_xyz_reshape, seed_gt_votes_reshape, l1=True)
+    votes_dist, _ = torch.min(dist2, dim=1)
+    votes_dist = votes_dist.view(batch_size, num_seed)
+    mask = seed_gt_votes_mask.float()
+    return torch.sum(votes_dist * mask) / (torch.sum(mask) + 1e-6)
+
+
+def compute_objectness_loss(data_dict):
+    """-> objectness_loss, objectness_label (B,K) int64, objectness_mask (B,K) f32, object_assignment (B,K) int64
+    (loss_helper.py:72-115): a proposal is positive within NEAR_THRESHOLD of a GT centre, ignored in the grey zone"""
+    aggregated_vote_xyz = data_dict["aggregated_vote_xyz"]
+    gt_center = data_dict["center_label"][:, :, 0:3]
+    dist1, ind1, _, _ = nn_distance(aggregated_vote_xyz, gt_center)
+    euclidean_dist1 = torch.sqrt(dist1 + 1e-6)
+    near = euclidean_dist1 < NEAR_THRESHOLD
+    objectness_label = near.long()
+    objectness_mask = (near | (euclidean_dist1 > FAR_THRESHOLD)).float()
+    objectness_scores = data_dict["objectness_scores"]
+    weight = _const("objw", objectness_scores.device, lambda: torch.tensor(OBJECTNESS_CLS_WEIGHTS, dtype=torch.float32))
+    weight = weight.to(objectness_scores.dtype)
+    objectness_loss = F.cross_entropy(objectness_scores.transpose(2, 1), objectness_label, weight=weight, reduction="none")
+    objectness_loss = torch.sum(objectness_loss * objectness_mask) / (torch.sum(objectness_mask) + 1e-6)
+    return objectness_loss, objectness_label, objectness_mask, ind1
+
+
+def compute_box_and_sem_cls_loss(data_dict, config):
+    """-> center_loss, heading_cls_loss, heading_reg_loss, size_cls_loss, size_reg_loss, sem_cls_loss
+    (loss_helper.py:118-193); needs data_dict['object_assignment'] / ['objectness_label'] from the objectness loss"""
+    num_heading_bin = config.num_heading_bin
+    mean_size_arr = config.mean_size_arr
+    object_assignment = data_dict["object_assignment"]
+
+    pred_center = data_dict["center"]
+    gt_center = data_dict["center_label"][:, :, 0:3]
+    dist1, _, dist2, _ = nn_distance(pred_center, gt_center)
+    box_label_mask = data_dict["box_label_mask"]
+    objectness_label = data_dict["objectness_label"].float()
+    npos = torch.sum(objectness_label) + 1e-6
+    centroid_reg_loss1 = torch.sum(dist1 * objectness_label) / npos
+    centroid_reg_loss2 = torch.sum(dist2 * box_label_mask) / (torch.sum(box_label_mask) + 1e-6)
+    center_loss = centroid_reg_loss1 + centroid_reg_loss2
+
+    heading_class_label = torch.gather(data_dict["heading_class_label"], 1, object_assignment)
+    heading_class_loss = F.cross_entropy(data_dict["heading_scores"].transpose(2, 1), heading_class_label, reduction="none")
+    heading_class_loss = torch.sum(heading_class_loss * objectness_label) / npos
+    heading_residual_label = torch.gather(data_dict["heading_residual_label"], 1, object_assignment)
+    heading_residual_normalized_label = heading_residual_label / (np.pi / num_heading_bin)
+    # sum(residuals * one_hot(label)) == the residual of the labelled bin
+    picked = torch.gather(data_dict["heading_residuals_normalized"], 2, heading_class_label.unsqueeze(-1)).squeeze(-1)
+    heading_residual_normalized_loss = huber_loss(picked - heading_residual_normalized_label, delta=1.0)
+    heading_residual_normalized_loss = torch.sum(heading_residual_normalized_loss * objectness_label) / npos
+
+    size_class_label = torch.gather(data_dict["size_class_label"], 1, object_assignment)
+    size_class_loss = F.cross_entropy(data_dict["size_scores"].transpose(2, 1), size_class_label, reduction="none")
+    size_class_loss = torch.sum(size_class_loss * objectness_label) / npos
+    size_residual_label = torch.gather(data_dict["size_residual_label"], 1, object_assignment.unsqueeze(-1).repeat(1, 1, 3))
+    idx = size_class_label.view(*size_class_label.shape, 1, 1).expand(-1, -1, 1, 3)
+    predicted_size_residual_normalized = torch.gather(data_dict["size_residuals_normalized"], 2, idx).squeeze(2)
+    msa = np.ascontiguousarray(np.asarray(mean_size_arr, dtype=np.float32))
+    mean_sizes = _const(("mean_size", msa.tobytes()), pred_center.device, lambda: torch.from_numpy(msa.copy()))
+    mean_size_label = mean_sizes[size_class_label]  # (B,K,3)
+    size_residual_label_normalized = size_residual_label / mean_size_label
+    size_residual_normalized_loss = torch.mean(
+        huber_loss(predicted_size_residual_normalized - size_residual_label_normalized, delta=1.0), -1)
+    size_residual_normalized_loss = torch.sum(size_residual_normalized_loss * objectness_label) / npos
+
+    sem_cls_label = torch.gather(data_dict["sem_cls_label"], 1, object_assignment)
+    sem_cls_loss = F.cross_entropy(data_dict["sem_cls_scores"].transpose(2, 1), sem_cls_label, reduction="none")
+    sem_cls_loss = torch.sum(sem_cls_loss * objectness_label) / npos
+    return (center_loss, heading_class_loss, heading_residual_normalized_loss, size_class_loss,
+            size_residual_normalized_loss, sem_cls_loss)
+
+
+def get_detection_loss(data_dict, config, loss_weights=None, amplify=10.0):
+    """The detection terms of get_loss (loss_helper.py:355-464, `detection=True`): vote + objectness + box + sem-cls with
+    the reference's weights dict (default 1.0 each, scripts/train.py passes 1.0 / 0.5 / 1.0 / 0.1) and the x10 at the
+    end; fills the same data_dict entries.  Returns (loss, data_dict)."""
+    w = loss_weights or {}
+    vote_loss = compute_vote_loss(data_dict)
+    objectness_loss, objectness_label, objectness_mask, object_assignment = compute_objectness_loss(data_dict)
+    total = float(objectness_label.shape[0] * objectness_label.shape[1])
+    data_dict["objectness_label"] = objectness_label
+    data_dict["objectness_mask"] = objectness_mask
+    data_dict["object_assignment"] = object_assignment
+    data_dict["pos_ratio"] = torch.sum(objectness_label.float()) / total
+    data_dict["neg_ratio"] = torch.sum(objectness_mask.float()) / total - data_dict["pos_ratio"]
+    center_loss, heading_cls_loss, heading_reg_loss, size_cls_loss, size_reg_loss, sem_cls_loss = \
+        compute_box_and_sem_cls_loss(data_dict, config)
+    box_loss = center_loss + 0.1 * heading_cls_loss + heading_reg_loss + 0.1 * size_cls_loss + size_reg_loss
+    data_dict.update(vote_loss=vote_loss, objectness_loss=objectness_loss, center_loss=center_loss,
+                     heading_cls_loss=heading_cls_loss, heading_reg_loss=heading_reg_loss, size_cls_loss=size_cls_loss,
+                     size_reg_loss=size_reg_loss, sem_cls_loss=sem_cls_loss, box_loss=box_loss)
+    loss = (w.get("vote_loss", 1.0) * vote_loss + w.get("objectness_loss", 1.0) * objectness_loss
+            + w.get("box_loss", 1.0) * box_loss + w.get("sem_cls_loss", 1.0) * sem_cls_loss)
+    loss = loss * amplify
+    data_dict["detection_loss"] = loss
+    return loss, data_dict

@@ -134,3 +134,10 @@ def test_fused_batchnorm_relu_maxpool_point_major(dev, B, C, M, S, relu, pool):
     assert rel(xa.grad, xr.grad) < 2e-2
     assert rel(bn.weight.grad, ref_bn.weight.grad) < 1e-2 and rel(bn.bias.grad, ref_bn.bias.grad) < 1e-2
     assert xa.grad.is_contiguous(memory_format=torch.channels_last)
+
+
+def test_detection_losses_on_gpu_vs_reference_golden(golden, dev):
+    """the reference's losses only run with .cuda() hard-wired; the mirror runs on the GPU without a host sync and
+    matches the reference's own CPU-executed values (fp32 reductions: 1e-5)"""
+    from test_loss_cpu import run_loss_golden
+    run_loss_golden(golden, dev, 1e-5)

@@ -32,8 +32,10 @@ def _worker(rank, world, port, out):
         model = ScanQAHotPath(input_feature_dim=1, use_blip=False)
         ddp = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=True)
         opt = torch.optim.AdamW(ddp.parameters(), lr=1e-3)
-        pc = bench.synth_batch(2, 2500, 1, 42 + rank, "cpu")  # each rank its own scenes (DistributedSampler-like)
-        loss = bench.det_loss(ddp({"point_clouds": pc}))
+        def scenes(r):  # each rank its own scenes (DistributedSampler-like), with the synthetic detection labels
+            pc = bench.synth_batch(2, 2500, 1, 42 + r, "cpu")
+            return dict({"point_clouds": pc}, **bench.synth_labels(pc[..., :3], 49 + r))
+        loss = bench.det_loss(ddp(scenes(rank)))
         loss.backward()
         g = model.detection_backbone.sa1.mlp_module.layer0.conv.weight.grad.clone()
         # reference: the same two batches on one replica, gradients averaged by hand
@@ -42,7 +44,7 @@ def _worker(rank, world, port, out):
         gs = []
         for r in range(world):
             solo.zero_grad()
-            bench.det_loss(solo({"point_clouds": bench.synth_batch(2, 2500, 1, 42 + r, "cpu")})).backward()
+            bench.det_loss(solo(scenes(r))).backward()
             gs.append(solo.detection_backbone.sa1.mlp_module.layer0.conv.weight.grad.clone())
         want = sum(gs) / world
         opt.step()

@@ -81,7 +81,8 @@ def test_point_major_bf16_detector_vs_fp32_reference_path(dev):
         with torch.no_grad():
             got = model.detect({"point_clouds": pc})
         model.train()
-        dd = model.detect({"point_clouds": pc})
+        labels = {k: v.to(dev) for k, v in bench.synth_labels(pc[..., :3].cpu(), 5).items()}
+        dd = model.detect(dict({"point_clouds": pc}, **labels))
         bench.det_loss(dd).backward()
     finally:
         fusion_ops.set_compute_dtype(prev)

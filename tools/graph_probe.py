@@ -26,7 +26,7 @@ def child(which):
                               scene_object_embeds=obj, scene_object_mask=om, data_dict={})
         return loss
     def f_det():
-        return bench.det_loss(model.detect({"point_clouds": batch["point_clouds"]}))
+        return bench.det_loss(model.detect({k: v for k, v in batch.items() if k not in ("images", "question", "answer")}))
     def f_full():
         return bench.total_loss(model(dict(batch)))
     f = {"vit": f_vit, "text": f_text, "det": f_det, "full": f_full, "fullopt": f_full}[which]

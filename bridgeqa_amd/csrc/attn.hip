@@ -121,12 +121,18 @@ __device__ __forceinline__ void fwd_tile(const unsigned char *s_k, const unsigne
 #pragma unroll
         for (int i = 0; i < 16; ++i) sc[i] = acc[i] * scale_log2e;
       }
+      if (last) {  // wave-uniform: only the last tile has keys past the end
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (last && kbase + crow(i, h) >= dm.Lk) sc[i] = -INFINITY;
-        if (dm.causal && kbase + crow(i, h) > qrow) sc[i] = -INFINITY;
-        mloc = fmaxf(mloc, sc[i]);
+        for (int i = 0; i < 16; ++i)
+          if (kbase + crow(i, h) >= dm.Lk) sc[i] = -INFINITY;
       }
+      if (dm.causal) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (kbase + crow(i, h) > qrow) sc[i] = -INFINITY;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, sc[i]);
       mloc = xhalf_max(mloc);
       const float mnew = fmaxf(m, mloc);
       const float alpha = __builtin_amdgcn_exp2f(m - mnew);  // m = -inf on the first block -> 0
@@ -369,25 +375,36 @@ __device__ __forceinline__ void dq_tile(const unsigned char *s_k, const unsigned
       const int kbase = kt * AT_KB + kb2 * 32;
       float mk[16];
       if (mrow) load_rowvals(mrow + kbase, 0, h, mk);
+      float pv[16], gv[16];
+      if (mrow) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pv[i] = __builtin_amdgcn_exp2f(sacc[i] * c + mk[i] - lse);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pv[i] = __builtin_amdgcn_exp2f(sacc[i] * c - lse);
+      }
+      if (last) {  // wave-uniform special cases stay out of the common path
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (kbase + crow(i, h) >= dm.Lk) pv[i] = 0.0f;
+      }
+      if (dm.causal) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (kbase + crow(i, h) > qrow) pv[i] = 0.0f;
+      }
+      if (dm.drop_thresh) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          gv[i] = drop_keep(seed, bh, qrow, kbase + crow(i, h), dm.drop_thresh) ? pacc[i] * dm.inv_keep : 0.0f;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gv[i] = pacc[i];
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        float p = __builtin_amdgcn_exp2f(sacc[i] * c + (mrow ? mk[i] : 0.0f) - lse);
-        float p2 = __builtin_amdgcn_exp2f(sacc[8 + i] * c + (mrow ? mk[8 + i] : 0.0f) - lse);
-        if (last) {
-          if (kbase + crow(i, h) >= dm.Lk) p = 0.0f;
-          if (kbase + crow(8 + i, h) >= dm.Lk) p2 = 0.0f;
-        }
-        if (dm.causal) {
-          if (kbase + crow(i, h) > qrow) p = 0.0f;
-          if (kbase + crow(8 + i, h) > qrow) p2 = 0.0f;
-        }
-        float g1 = pacc[i], g2 = pacc[8 + i];
-        if (dm.drop_thresh) {
-          g1 = drop_keep(seed, bh, qrow, kbase + crow(i, h), dm.drop_thresh) ? g1 * dm.inv_keep : 0.0f;
-          g2 = drop_keep(seed, bh, qrow, kbase + crow(8 + i, h), dm.drop_thresh) ? g2 * dm.inv_keep : 0.0f;
-        }
-        d0[i] = (__bf16)(p * (g1 - delta) * scale);
-        d1[i] = (__bf16)(p2 * (g2 - delta) * scale);
+        d0[i] = (__bf16)(pv[i] * (gv[i] - delta) * scale);
+        d1[i] = (__bf16)(pv[8 + i] * (gv[8 + i] - delta) * scale);
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -622,29 +639,36 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *_
       load_rowvals(s_del, qb2, h, dl);
       bf16x8 p0, p1, d0, d1;
       const int qbase = qt * AT_KB + qb2 * 32;
+      float pv[16], pdv[16], gv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pv[i] = __builtin_amdgcn_exp2f(sacc[i] * c + mkey - lv[i]);
+      if (last) {  // query rows past the end were staged as copies of the last row: drop them (wave-uniform branch)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (qbase + crow(i, h) >= dm.Lq) pv[i] = 0.0f;
+      }
+      if (dm.causal) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (qbase + crow(i, h) < k0 + r) pv[i] = 0.0f;
+      }
+      if (dm.drop_thresh) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const bool keep = drop_keep(seed, bh, qbase + crow(i, h), k0 + r, dm.drop_thresh);
+          gv[i] = keep ? pacc[i] * dm.inv_keep : 0.0f;
+          pdv[i] = keep ? pv[i] * dm.inv_keep : 0.0f;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { gv[i] = pacc[i]; pdv[i] = pv[i]; }
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        float p = __builtin_amdgcn_exp2f(sacc[i] * c + mkey - lv[i]);
-        float p2 = __builtin_amdgcn_exp2f(sacc[8 + i] * c + mkey - lv[8 + i]);
-        if (last) {  // query rows past the end were staged as copies of the last row: drop them
-          if (qbase + crow(i, h) >= dm.Lq) p = 0.0f;
-          if (qbase + crow(8 + i, h) >= dm.Lq) p2 = 0.0f;
-        }
-        if (dm.causal) {
-          if (qbase + crow(i, h) < k0 + r) p = 0.0f;
-          if (qbase + crow(8 + i, h) < k0 + r) p2 = 0.0f;
-        }
-        float g1 = pacc[i], g2 = pacc[8 + i], pd = p, pd2 = p2;
-        if (dm.drop_thresh) {
-          const bool k1 = drop_keep(seed, bh, qbase + crow(i, h), k0 + r, dm.drop_thresh);
-          const bool k2 = drop_keep(seed, bh, qbase + crow(8 + i, h), k0 + r, dm.drop_thresh);
-          g1 = k1 ? g1 * dm.inv_keep : 0.0f; pd = k1 ? p * dm.inv_keep : 0.0f;
-          g2 = k2 ? g2 * dm.inv_keep : 0.0f; pd2 = k2 ? p2 * dm.inv_keep : 0.0f;
-        }
-        p0[i] = (__bf16)pd;
-        p1[i] = (__bf16)pd2;
-        d0[i] = (__bf16)(p * (g1 - dl[i]) * scale);
-        d1[i] = (__bf16)(p2 * (g2 - dl[8 + i]) * scale);
+        p0[i] = (__bf16)pdv[i];
+        p1[i] = (__bf16)pdv[8 + i];
+        d0[i] = (__bf16)(pv[i] * (gv[i] - dl[i]) * scale);
+        d1[i] = (__bf16)(pv[8 + i] * (gv[8 + i] - dl[8 + i]) * scale);
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {

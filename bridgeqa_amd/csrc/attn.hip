@@ -109,17 +109,20 @@ __device__ __forceinline__ void fwd_tile(const unsigned char *s_k, const unsigne
         const bf16x8 a = *reinterpret_cast<const bf16x8 *>(s_k + swz(kb2 * 32 + r, 2 * s + h));
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], acc, 0, 0, 0);
       }
+      // sc is kept in log2 units when there is a mask (one fma per element) and in raw dot-product units otherwise
+      // (the scale is folded into the max once and into the exp2 argument by an fma): fewer VALU ops per pair
       float sc[16];
       float mloc = -INFINITY;
       const int kbase = kt * AT_KB + kb2 * 32;
-      if (mrow) {
+      const bool masked = mrow != nullptr;
+      if (masked) {
         float mk[16];
         load_rowvals(mrow + kbase, 0, h, mk);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sc[i] = acc[i] * scale_log2e + mk[i];
+        for (int i = 0; i < 16; ++i) sc[i] = __builtin_fmaf(acc[i], scale_log2e, mk[i]);
       } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sc[i] = acc[i] * scale_log2e;
+        for (int i = 0; i < 16; ++i) sc[i] = acc[i];
       }
       if (last) {  // wave-uniform: only the last tile has keys past the end
 #pragma unroll
@@ -133,23 +136,32 @@ __device__ __forceinline__ void fwd_tile(const unsigned char *s_k, const unsigne
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, sc[i]);
+      if (!masked) mloc *= scale_log2e;  // scale > 0: max commutes with it
       mloc = xhalf_max(mloc);
       const float mnew = fmaxf(m, mloc);
       const float alpha = __builtin_amdgcn_exp2f(m - mnew);  // m = -inf on the first block -> 0
       m = mnew;
       float psum = 0.0f;
       bf16x8 pb0, pb1;
+      float pv[16];
+      if (masked) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pv[i] = __builtin_amdgcn_exp2f(sc[i] - mnew);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pv[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[i], scale_log2e, -mnew));
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) psum += pv[i];  // the softmax denominator uses the un-dropped probabilities
+      if (dm.drop_thresh) {  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          pv[i] = drop_keep(seed, bh, qrow, kbase + crow(i, h), dm.drop_thresh) ? pv[i] * dm.inv_keep : 0.0f;
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        float p = __builtin_amdgcn_exp2f(sc[i] - mnew);
-        float p2 = __builtin_amdgcn_exp2f(sc[8 + i] - mnew);
-        psum += p + p2;  // the softmax denominator uses the un-dropped probabilities
-        if (dm.drop_thresh) {
-          p = drop_keep(seed, bh, qrow, kbase + crow(i, h), dm.drop_thresh) ? p * dm.inv_keep : 0.0f;
-          p2 = drop_keep(seed, bh, qrow, kbase + crow(8 + i, h), dm.drop_thresh) ? p2 * dm.inv_keep : 0.0f;
-        }
-        pb0[i] = (__bf16)p;
-        pb1[i] = (__bf16)p2;
+        pb0[i] = (__bf16)pv[i];
+        pb1[i] = (__bf16)pv[8 + i];
       }
       lsum = lsum * alpha + psum;
       if (__ballot(alpha != 1.0f)) {  // wave-uniform: skip the rescale once the running max has settled
@@ -378,10 +390,10 @@ __device__ __forceinline__ void dq_tile(const unsigned char *s_k, const unsigned
       float pv[16], gv[16];
       if (mrow) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) pv[i] = __builtin_amdgcn_exp2f(sacc[i] * c + mk[i] - lse);
+        for (int i = 0; i < 16; ++i) pv[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[i], c, mk[i] - lse));
       } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) pv[i] = __builtin_amdgcn_exp2f(sacc[i] * c - lse);
+        for (int i = 0; i < 16; ++i) pv[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[i], c, -lse));
       }
       if (last) {  // wave-uniform special cases stay out of the common path
 #pragma unroll
@@ -403,8 +415,8 @@ __device__ __forceinline__ void dq_tile(const unsigned char *s_k, const unsigned
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        d0[i] = (__bf16)(pv[i] * (gv[i] - delta) * scale);
-        d1[i] = (__bf16)(pv[8 + i] * (gv[8 + i] - delta) * scale);
+        d0[i] = (__bf16)(pv[i] * (gv[i] - delta));  // the softmax scale is applied once, to the dQ accumulators
+        d1[i] = (__bf16)(pv[8 + i] * (gv[8 + i] - delta));
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -479,7 +491,7 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const __bf16 *__
     }
     dq_tile(s_k, s_v, s_kt, qf, gf, dm, mrow, c, scale, lse, delta, seed, bh, q0 + r, kt, kt == nkt - 1, r, h, a0, a1);
   }
-  if (q0 + r < dm.Lq) store_T(dQ + b * dm.q_bs + hd * dm.q_hs + (long)(q0 + r) * dm.q_rs, a0, a1, h, 1.0f);
+  if (q0 + r < dm.Lq) store_T(dQ + b * dm.q_bs + hd * dm.q_hs + (long)(q0 + r) * dm.q_rs, a0, a1, h, scale);
 }
 
 // Lq <= 32: the four waves share the queries and split the key tiles (see attn_fwd_narrow_kernel); dQ^T partials are
@@ -560,7 +572,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_narrow_kernel(const __bf16 *_
     bf16x8 out;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      out[j] = (__bf16)((s_o[0][d0 + j][q] + s_o[1][d0 + j][q]) + (s_o[2][d0 + j][q] + s_o[3][d0 + j][q]));
+      out[j] = (__bf16)(((s_o[0][d0 + j][q] + s_o[1][d0 + j][q]) + (s_o[2][d0 + j][q] + s_o[3][d0 + j][q])) * scale);
     *reinterpret_cast<bf16x8 *>(dQ + b * dm.q_bs + hd * dm.q_hs + (long)q * dm.q_rs + d0) = out;
   }
 }
@@ -641,7 +653,7 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *_
       const int qbase = qt * AT_KB + qb2 * 32;
       float pv[16], pdv[16], gv[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) pv[i] = __builtin_amdgcn_exp2f(sacc[i] * c + mkey - lv[i]);
+      for (int i = 0; i < 16; ++i) pv[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[i], c, mkey - lv[i]));
       if (last) {  // query rows past the end were staged as copies of the last row: drop them (wave-uniform branch)
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -667,8 +679,8 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *_
       for (int i = 0; i < 8; ++i) {
         p0[i] = (__bf16)pdv[i];
         p1[i] = (__bf16)pdv[8 + i];
-        d0[i] = (__bf16)(pv[i] * (gv[i] - dl[i]) * scale);
-        d1[i] = (__bf16)(pv[8 + i] * (gv[8 + i] - dl[8 + i]) * scale);
+        d0[i] = (__bf16)(pv[i] * (gv[i] - dl[i]));  // the softmax scale is applied once, to the dK accumulators
+        d1[i] = (__bf16)(pv[8 + i] * (gv[8 + i] - dl[8 + i]));
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -683,7 +695,7 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *_
   }
   if (k0 + r < dm.Lk) {
     const long off = b * dm.k_bs + hd * dm.k_hs + (long)(k0 + r) * dm.k_rs;
-    store_T(dK + off, dk0, dk1, h, 1.0f);
+    store_T(dK + off, dk0, dk1, h, scale);
     store_T(dV + off, dv0, dv1, h, 1.0f);
   }
 }

@@ -34,14 +34,19 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const __bf16 *__restrict_
   const int cg = threadIdx.x % tpr, rp = threadIdx.x / tpr;
   const int cr = bn_chunk_rows(R);
   const long r0 = (long)blockIdx.x * cr, r1 = min(R, r0 + cr);
-  float a[8], q[8];
+  // sums are taken of (x - pivot) with pivot = row 0 of the same channel: E[x^2] - mean^2 in fp32 loses the variance
+  // when |mean| >> std (e.g. mean 30, std 0.5 over 2 M rows); shifted by a value within a few std of the mean it does not
+  float a[8], q[8], pv[8];
+  {
+    const bf16x8 p0 = *reinterpret_cast<const bf16x8 *>(x + cg * 8);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { a[i] = 0.f; q[i] = 0.f; }
+    for (int i = 0; i < 8; ++i) { a[i] = 0.f; q[i] = 0.f; pv[i] = (float)p0[i]; }
+  }
   if (rp < rps) {
     for (long r = r0 + rp; r < r1; r += rps) {
       const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + r * C + cg * 8);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const float f = (float)v[i]; a[i] += f; q[i] += f * f; }
+      for (int i = 0; i < 8; ++i) { const float f = (float)v[i] - pv[i]; a[i] += f; q[i] += f * f; }
     }
   }
 #pragma unroll
@@ -84,7 +89,8 @@ struct BnParams {
   float eps, momentum;
 };
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ partial, int chunks, int C, long R,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ partial,
+                                                          const __bf16 *__restrict__ x, int chunks, int C, long R,
                                                           BnParams p) {
   __shared__ float s[4][64];
   const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
@@ -94,8 +100,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
   const float sq = fold_column(partial, chunks, 2 * C, C + cc, ph, s, cl);
   if (ph != 0 || c >= C) return;
   const float invR = 1.0f / (float)R;
-  const float mean = sum * invR;
-  const float var = fmaxf(sq * invR - mean * mean, 0.0f);
+  const float dmean = sum * invR;  // mean of (x - pivot)
+  const float mean = (float)x[c] + dmean;
+  const float var = fmaxf(sq * invR - dmean * dmean, 0.0f);
   const float rstd = rsqrtf(var + p.eps);
   const float sc = p.gamma[c] * rstd;
   p.scale[c] = sc;
@@ -334,7 +341,7 @@ extern "C" __attribute__((visibility("default"))) int bq_bn_stats(const void *x,
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_stats_kernel, dim3(chunks), dim3(256), 0, st, (const __bf16 *)x, partial, R, C);
   BnParams p{gamma, beta, running_mean, running_var, num_batches_tracked, scale, shift, mean, rstd, eps, momentum};
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, partial, chunks, C, R, p);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, partial, (const __bf16 *)x, chunks, C, R, p);
   return check_launch("bn_stats");
 }
 

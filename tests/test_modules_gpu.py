@@ -142,3 +142,21 @@ def test_detection_losses_on_gpu_vs_reference_golden(golden, dev):
     matches the reference's own CPU-executed values (fp32 reductions: 1e-5)"""
     from test_loss_cpu import run_loss_golden
     run_loss_golden(golden, dev, 1e-5)
+
+
+def test_fused_batchnorm_statistics_survive_a_large_mean(dev):
+    """|mean| >> std over 2 M rows: a plain fp32 E[x^2] - mean^2 would lose the variance; the pivoted sums of
+    csrc/bn.hip must not (compare with float64 statistics of the same bf16 values)."""
+    from bridgeqa_amd import _ext
+    R, C = 16 * 2048 * 64, 64
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(R, C, generator=g) * 0.5 + torch.linspace(-40, 40, C)).to(dev).to(torch.bfloat16)
+    gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    y, stats = _ext.bn_relu_fwd(x, gamma, beta, None, None, None, 1e-5, 0.1, 64, False, False)
+    xd = x.double()
+    mean, var = xd.mean(0), xd.var(0, unbiased=False)
+    assert torch.allclose(stats[2].double(), mean, rtol=1e-5, atol=1e-4)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    assert ((stats[3].double() - rstd).abs() / rstd).max().item() < 2e-3
+    want = ((xd - mean) * rstd).float()
+    assert ((y.float() - want).norm() / want.norm()).item() < 1e-2

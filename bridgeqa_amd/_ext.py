@@ -51,7 +51,7 @@ _l = ctypes.c_long
 _u = ctypes.c_uint
 _lib.bq_attn_fwd.argtypes = [_vp] * 6 + [_i] * 5 + [_l] * 9 + [_f, _f, _u, _vp, _i, _vp]
 _lib.bq_attn_fwd.restype = ctypes.c_int
-_lib.bq_attn_bwd.argtypes = [_vp] * 14 + [_i] * 6 + [_l] * 9 + [_f, _f, _u, _vp, _i, _vp]
+_lib.bq_attn_bwd.argtypes = [_vp] * 11 + [_i] * 5 + [_l] * 9 + [_f, _f, _u, _vp, _i, _vp]
 _lib.bq_attn_bwd.restype = ctypes.c_int
 _lib.bq_transpose_pad.argtypes = [_vp, _vp, _i, _i, _i, _i, _l, _l, _l, _vp]
 _lib.bq_transpose_pad.restype = ctypes.c_int
@@ -346,20 +346,21 @@ def key_mask_log2(mask, B, Lk):
 
 def attn_fwd(q, k, v, scale, mask_log2=None, p_drop=0.0, seed=0, seed_tensor=None, causal=False):
     """softmax(q k^T * scale + mask) v without materialising the scores.  q: bf16 (B, Lq, H, 64) view, k / v:
-    (B, Lk, H, 64) views; mask_log2 from key_mask_log2.  Returns out (B, Lq, H, 64) bf16 contiguous and
-    lse (B, H, Lq) f32 (log2 domain)."""
+    (B, Lk, H, 64) views with equal strides; mask_log2 from key_mask_log2.  Returns out (B, Lq, H, 64) bf16 contiguous
+    and lse (B, H, Lq) f32 (log2 domain).  No transposed copies: the kernels transpose out of LDS."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         if not t.is_cuda:
             raise RuntimeError("%s: CPU not supported" % n)
+    if k.stride() != v.stride():
+        raise RuntimeError("attn_fwd: k and v must have equal strides")
     B, Lq, H, D = q.shape
     Lk = k.shape[1]
     Lkp = _pad64(Lk)
     with torch.cuda.device(q.device):
-        vt = transpose_v(v, Lkp)
         out = torch.empty(B, Lq, H, D, dtype=torch.bfloat16, device=q.device)
         lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
         qs, ks, os_ = _bhd_strides(q), _bhd_strides(k), _bhd_strides(out)
-        _check(_lib.bq_attn_fwd(_p(q), _p(k), _p(vt), _p(out), _p(lse), _p(mask_log2), B, H, Lq, Lk, Lkp, *qs, *ks,
+        _check(_lib.bq_attn_fwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(mask_log2), B, H, Lq, Lk, Lkp, *qs, *ks,
                                 *os_, float(scale), float(p_drop), int(seed) & 0xFFFFFFFF, _p(seed_tensor),
                                 int(bool(causal)), _stream()), "attn_fwd")
     return out, lse
@@ -371,21 +372,19 @@ def attn_bwd(q, k, v, out, lse, grad_out, scale, dq, dk, dv, mask_log2=None, p_d
     q, dk/dv like k; k and v with equal strides)."""
     B, Lq, H, D = q.shape
     Lk = k.shape[1]
-    Lqp, Lkp = _pad64(Lq), _pad64(Lk)
+    Lkp = _pad64(Lk)
     if k.stride() != v.stride() or dq.stride() != q.stride() or dk.stride() != k.stride() or dv.stride() != k.stride():
         raise RuntimeError("attn_bwd: stride contract violated")
     with torch.cuda.device(q.device):
-        if grad_out.stride(3) != 1:
+        if grad_out.stride(3) != 1 or grad_out.stride(1) % 8 or grad_out.stride(2) % 8:
             grad_out = grad_out.contiguous()
         if not out.is_contiguous():
             raise RuntimeError("attn_bwd: the forward output must be contiguous")
         delta = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)  # filled by the dQ kernel
-        qt, kt, gt = transpose3((q, k, grad_out), (Lqp, Lkp, Lqp))
         qs, ks, gs = _bhd_strides(q), _bhd_strides(k), _bhd_strides(grad_out)
-        _check(_lib.bq_attn_bwd(_p(q), _p(k), _p(v), _p(qt), _p(kt), _p(grad_out), _p(gt), _p(lse), _p(out),
-                                _p(delta), _p(mask_log2), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, Lqp, Lkp, *qs, *ks, *gs,
-                                float(scale), float(p_drop), int(seed) & 0xFFFFFFFF, _p(seed_tensor),
-                                int(bool(causal)), _stream()), "attn_bwd")
+        _check(_lib.bq_attn_bwd(_p(q), _p(k), _p(v), _p(grad_out), _p(lse), _p(out), _p(delta), _p(mask_log2), _p(dq),
+                                _p(dk), _p(dv), B, H, Lq, Lk, Lkp, *qs, *ks, *gs, float(scale), float(p_drop),
+                                int(seed) & 0xFFFFFFFF, _p(seed_tensor), int(bool(causal)), _stream()), "attn_bwd")
 
 
 _lib.bq_colsum_chunks.argtypes = [_i]

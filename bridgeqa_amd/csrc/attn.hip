@@ -94,6 +94,23 @@ __device__ __forceinline__ void stage_store(unsigned char *lds, int c, uint4 v) 
   *reinterpret_cast<uint4 *>(lds + swz(c >> 3, c & 7)) = v;
 }
 
+// A-operand fragment of the TRANSPOSE of a row-major LDS image (64 rows x 64 bf16, swizzled by swz), read with gfx950's
+// ds_read_b64_tr_b16: lane (r, h) gets column d = dbase + r of rows row0 .. row0+3 (elements 0-3) and row0+8 .. row0+11
+// (elements 4-7) -- the k-order 16s + 8(j>>2) + 4h + (j&3) of the accumulator-as-B-operand maps when row0 = 32*blk +
+// 16*s + 4*h.  Per 16-lane group the instruction gathers a 4-row x 16-column block: lane 4q+p of the group supplies the
+// address of row q, columns 4p..4p+3, and lane i receives column i of the 4 rows (tools/tr_read_probe.py).  No
+// transposed copy of K / V / Q / dO exists any more, in HBM or in LDS.  EXEC must be all ones here.
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+__device__ __forceinline__ bf16x8 tfrag_tr(const unsigned char *img, int row0, int dbase, int r) {
+  const int q = (r & 15) >> 2, p = r & 3;
+  const int ch = ((dbase + 16 * (r >> 4)) >> 3) + (p >> 1);
+  const unsigned char *a0 = img + swz(row0 + q, ch) + 8 * (p & 1);
+  const unsigned char *a1 = img + swz(row0 + 8 + q, ch) + 8 * (p & 1);
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)a0);
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)a1);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 // One 64-key tile (two 32-key blocks) of the online-softmax forward for the 32 queries of a wave: S^T = K.Q^T from
 // the LDS image s_k, mask / causal / length clamp, running max + rescale, P (with dropout) straight from the
 // accumulator registers into O^T += V^T.P^T from the LDS image s_v.  qrow = this lane's query index.
@@ -170,16 +187,8 @@ __device__ __forceinline__ void fwd_tile(const unsigned char *s_k, const unsigne
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const int ch = 4 * kb2 + 2 * s2;
-        bf16x8 v0, v1;
-        {
-          const unsigned char *p0 = s_v + swz(r, ch) + h * 8, *p1 = s_v + swz(r, ch + 1) + h * 8;
-          const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(p0), hi = *reinterpret_cast<const bf16x4 *>(p1);
-          v0 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          const unsigned char *p2 = s_v + swz(32 + r, ch) + h * 8, *p3 = s_v + swz(32 + r, ch + 1) + h * 8;
-          const bf16x4 lo1 = *reinterpret_cast<const bf16x4 *>(p2), hi1 = *reinterpret_cast<const bf16x4 *>(p3);
-          v1 = __builtin_shufflevector(lo1, hi1, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
+        const int key0 = 32 * kb2 + 16 * s2 + 4 * h;  // s_v is the ROW-major V tile [key][d]
+        const bf16x8 v0 = tfrag_tr(s_v, key0, 0, r), v1 = tfrag_tr(s_v, key0, 32, r);
         const bf16x8 pb = s2 == 0 ? pb0 : pb1;
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb, o0, 0, 0, 0);
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, o1, 0, 0, 0);
@@ -189,10 +198,10 @@ __device__ __forceinline__ void fwd_tile(const unsigned char *s_k, const unsigne
 
 template <int MINW>
 __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
-                                                       const __bf16 *__restrict__ Vt, __bf16 *__restrict__ O,
+                                                       const __bf16 *__restrict__ V, __bf16 *__restrict__ O,
                                                        float *__restrict__ LSE, AttnDims dm) {
   __shared__ __align__(16) unsigned char s_k[AT_KB * 128];
-  __shared__ __align__(16) unsigned char s_v[AT_D * 128];
+  __shared__ __align__(16) unsigned char s_v[AT_KB * 128];
   const float scale_log2e = dm.scale * 1.4426950408889634f;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__res
   const int q0 = blockIdx.x * AT_QB + wid * AT_QW;  // first query row of this wave
   const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
   const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
-  const __bf16 *Vb = Vt + (long)bh * AT_D * dm.Lkp;
+  const __bf16 *Vb = V + b * dm.k_bs + hd * dm.k_hs;
   const float *mrow = dm.mask ? dm.mask + (long)b * dm.Lkp : nullptr;
 
   // Q fragments (B operand of S^T = K.Q^T): lane (q = r, h) holds Q[q][16*step + 8h + j]
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__res
   float m = -INFINITY, lsum = 0.0f;
   const int nkt = (dm.Lk + AT_KB - 1) / AT_KB;
   uint4 ka = stage_load(Kb, dm.k_rs, 0, dm.Lk, t), kb = stage_load(Kb, dm.k_rs, 0, dm.Lk, t + 256);
-  uint4 va = stage_load(Vb, dm.Lkp, 0, AT_D, t), vb = stage_load(Vb, dm.Lkp, 0, AT_D, t + 256);  // rows = d
+  uint4 va = stage_load(Vb, dm.k_rs, 0, dm.Lk, t), vb = stage_load(Vb, dm.k_rs, 0, dm.Lk, t + 256);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();  // everyone finished reading the previous tile
     stage_store(s_k, t, ka); stage_store(s_k, t + 256, kb);
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__res
     {
       const int nt = min(kt + 1, nkt - 1);  // the tile after the last is a harmless re-load of the last
       ka = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.Lk, t); kb = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.Lk, t + 256);
-      va = stage_load(Vb + nt * AT_KB, dm.Lkp, 0, AT_D, t); vb = stage_load(Vb + nt * AT_KB, dm.Lkp, 0, AT_D, t + 256);
+      va = stage_load(Vb, dm.k_rs, nt * AT_KB, dm.Lk, t); vb = stage_load(Vb, dm.k_rs, nt * AT_KB, dm.Lk, t + 256);
     }
     fwd_tile(s_k, s_v, qf, dm, mrow, scale_log2e, seed, bh, q0 + r, kt, kt == nkt - 1, r, h, o0, o1, m, lsum);
   }
@@ -253,10 +262,10 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__res
 // 32 queries and take every fourth key tile each (own LDS images, own running max / sum / O^T), and the four partial
 // softmax states are merged through LDS at the end:  O = sum_w 2^(m_w - m*) O_w / sum_w 2^(m_w - m*) l_w.
 __global__ __launch_bounds__(256) void attn_fwd_narrow_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
-                                                              const __bf16 *__restrict__ Vt, __bf16 *__restrict__ O,
+                                                              const __bf16 *__restrict__ V, __bf16 *__restrict__ O,
                                                               float *__restrict__ LSE, AttnDims dm) {
   __shared__ __align__(16) unsigned char s_k[AT_NW][AT_KB * 128];
-  __shared__ __align__(16) unsigned char s_v[AT_NW][AT_D * 128];
+  __shared__ __align__(16) unsigned char s_v[AT_NW][AT_KB * 128];
   __shared__ float s_m[AT_NW][32], s_l[AT_NW][32];
   __shared__ float s_o[AT_NW][AT_D][33];
   const float scale_log2e = dm.scale * 1.4426950408889634f;
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(256) void attn_fwd_narrow_kernel(const __bf16 *__re
   const unsigned seed = eff_seed(dm);
   const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
   const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
-  const __bf16 *Vb = Vt + (long)bh * AT_D * dm.Lkp;
+  const __bf16 *Vb = V + b * dm.k_bs + hd * dm.k_hs;
   const float *mrow = dm.mask ? dm.mask + (long)b * dm.Lkp : nullptr;
   bf16x8 qf[4];
   {
@@ -283,7 +292,7 @@ __global__ __launch_bounds__(256) void attn_fwd_narrow_kernel(const __bf16 *__re
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         kr[j] = stage_load(Kb, dm.k_rs, kt * AT_KB, dm.Lk, lane + 64 * j);
-        vr[j] = stage_load(Vb + kt * AT_KB, dm.Lkp, 0, AT_D, lane + 64 * j);
+        vr[j] = stage_load(Vb, dm.k_rs, kt * AT_KB, dm.Lk, lane + 64 * j);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -369,8 +378,7 @@ typedef AttnDims BwdDims;  // o_* strides describe dO
 
 // One 64-key tile of the dQ pass for the 32 queries of a wave: P recomputed from S^T = K.Q^T and the forward's LSE,
 // dP^T = V.dO^T, dS^T = P o (dP - delta) * scale, then dQ^T += K^T.dS^T (A = LDS image of the pre-transposed K).
-__device__ __forceinline__ void dq_tile(const unsigned char *s_k, const unsigned char *s_v, const unsigned char *s_kt,
-                                        const bf16x8 (&qf)[4], const bf16x8 (&gf)[4], const BwdDims &dm,
+__device__ __forceinline__ void dq_tile(const unsigned char *s_k, const unsigned char *s_v, const bf16x8 (&qf)[4], const bf16x8 (&gf)[4], const BwdDims &dm,
                                         const float *mrow, float c, float scale, float lse, float delta, unsigned seed,
                                         int bh, int qrow, int kt, bool last, int r, int h, f32x16 &a0, f32x16 &a1) {
 #pragma unroll
@@ -420,23 +428,22 @@ __device__ __forceinline__ void dq_tile(const unsigned char *s_k, const unsigned
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const int ch = 4 * kb2 + 2 * s2;
+        const int key0 = 32 * kb2 + 16 * s2 + 4 * h;
         const bf16x8 ds = s2 == 0 ? d0 : d1;
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(s_kt, r, ch, h), ds, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(s_kt, 32 + r, ch, h), ds, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag_tr(s_k, key0, 0, r), ds, a0, 0, 0, 0);   // K^T from the K tile
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag_tr(s_k, key0, 32, r), ds, a1, 0, 0, 0);
       }
     }
 }
 
 template <int MINW>
 __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
-                                                          const __bf16 *__restrict__ V, const __bf16 *__restrict__ Kt,
+                                                          const __bf16 *__restrict__ V,
                                                           const __bf16 *__restrict__ dO, const float *__restrict__ LSE,
                                                           const __bf16 *__restrict__ O, float *__restrict__ DELTA,
                                                           __bf16 *__restrict__ dQ, BwdDims dm) {
   __shared__ __align__(16) unsigned char s_k[AT_KB * 128];
   __shared__ __align__(16) unsigned char s_v[AT_KB * 128];
-  __shared__ __align__(16) unsigned char s_kt[AT_D * 128];
   const float scale = dm.scale;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
@@ -446,7 +453,6 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const __bf16 *__
   const __bf16 *Gb = dO + b * dm.o_bs + hd * dm.o_hs;
   const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
   const __bf16 *Vb = V + b * dm.k_bs + hd * dm.k_hs;
-  const __bf16 *Ktb = Kt + (long)bh * AT_D * dm.Lkp;
   const float *mrow = dm.mask ? dm.mask + (long)b * dm.Lkp : nullptr;
   const float c = scale * 1.4426950408889634f;
 
@@ -476,20 +482,17 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const __bf16 *__
   const int nkt = (dm.Lk + AT_KB - 1) / AT_KB;
   uint4 ka = stage_load(Kb, dm.k_rs, 0, dm.Lk, t), kb = stage_load(Kb, dm.k_rs, 0, dm.Lk, t + 256);
   uint4 va = stage_load(Vb, dm.k_rs, 0, dm.Lk, t), vb = stage_load(Vb, dm.k_rs, 0, dm.Lk, t + 256);
-  uint4 ta = stage_load(Ktb, dm.Lkp, 0, AT_D, t), tb = stage_load(Ktb, dm.Lkp, 0, AT_D, t + 256);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
     stage_store(s_k, t, ka); stage_store(s_k, t + 256, kb);
     stage_store(s_v, t, va); stage_store(s_v, t + 256, vb);
-    stage_store(s_kt, t, ta); stage_store(s_kt, t + 256, tb);
     __syncthreads();
     {
       const int nt = min(kt + 1, nkt - 1);
       ka = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.Lk, t); kb = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.Lk, t + 256);
       va = stage_load(Vb, dm.k_rs, nt * AT_KB, dm.Lk, t); vb = stage_load(Vb, dm.k_rs, nt * AT_KB, dm.Lk, t + 256);
-      ta = stage_load(Ktb + nt * AT_KB, dm.Lkp, 0, AT_D, t); tb = stage_load(Ktb + nt * AT_KB, dm.Lkp, 0, AT_D, t + 256);
     }
-    dq_tile(s_k, s_v, s_kt, qf, gf, dm, mrow, c, scale, lse, delta, seed, bh, q0 + r, kt, kt == nkt - 1, r, h, a0, a1);
+    dq_tile(s_k, s_v, qf, gf, dm, mrow, c, scale, lse, delta, seed, bh, q0 + r, kt, kt == nkt - 1, r, h, a0, a1);
   }
   if (q0 + r < dm.Lq) store_T(dQ + b * dm.q_bs + hd * dm.q_hs + (long)(q0 + r) * dm.q_rs, a0, a1, h, scale);
 }
@@ -497,13 +500,12 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const __bf16 *__
 // Lq <= 32: the four waves share the queries and split the key tiles (see attn_fwd_narrow_kernel); dQ^T partials are
 // summed through LDS in wave order.
 __global__ __launch_bounds__(256) void attn_bwd_dq_narrow_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
-                                                                 const __bf16 *__restrict__ V, const __bf16 *__restrict__ Kt,
+                                                                 const __bf16 *__restrict__ V,
                                                                  const __bf16 *__restrict__ dO, const float *__restrict__ LSE,
                                                                  const __bf16 *__restrict__ O, float *__restrict__ DELTA,
                                                                  __bf16 *__restrict__ dQ, BwdDims dm) {
   __shared__ __align__(16) unsigned char s_k[AT_NW][AT_KB * 128];
   __shared__ __align__(16) unsigned char s_v[AT_NW][AT_KB * 128];
-  __shared__ __align__(16) unsigned char s_kt[AT_NW][AT_D * 128];
   __shared__ float s_o[AT_NW][AT_D][33];
   const float scale = dm.scale;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
@@ -513,7 +515,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_narrow_kernel(const __bf16 *_
   const __bf16 *Gb = dO + b * dm.o_bs + hd * dm.o_hs;
   const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
   const __bf16 *Vb = V + b * dm.k_bs + hd * dm.k_hs;
-  const __bf16 *Ktb = Kt + (long)bh * AT_D * dm.Lkp;
   const float *mrow = dm.mask ? dm.mask + (long)b * dm.Lkp : nullptr;
   const float c = scale * 1.4426950408889634f;
   bf16x8 qf[4], gf[4];
@@ -541,23 +542,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_narrow_kernel(const __bf16 *_
   for (int kt0 = 0; kt0 < nkt; kt0 += AT_NW) {
     const int kt = kt0 + wid;
     if (kt < nkt) {
-      uint4 kr[8], vr[8], tr[8];
+      uint4 kr[8], vr[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         kr[j] = stage_load(Kb, dm.k_rs, kt * AT_KB, dm.Lk, lane + 64 * j);
         vr[j] = stage_load(Vb, dm.k_rs, kt * AT_KB, dm.Lk, lane + 64 * j);
-        tr[j] = stage_load(Ktb + kt * AT_KB, dm.Lkp, 0, AT_D, lane + 64 * j);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         stage_store(s_k[wid], lane + 64 * j, kr[j]);
         stage_store(s_v[wid], lane + 64 * j, vr[j]);
-        stage_store(s_kt[wid], lane + 64 * j, tr[j]);
       }
     }
     __syncthreads();
     if (kt < nkt)
-      dq_tile(s_k[wid], s_v[wid], s_kt[wid], qf, gf, dm, mrow, c, scale, lse, delta, seed, bh, r, kt, kt == nkt - 1, r, h,
+      dq_tile(s_k[wid], s_v[wid], qf, gf, dm, mrow, c, scale, lse, delta, seed, bh, r, kt, kt == nkt - 1, r, h,
               a0, a1);
     __syncthreads();
   }
@@ -579,14 +578,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_narrow_kernel(const __bf16 *_
 
 template <int MINW>
 __global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
-                                                           const __bf16 *__restrict__ V, const __bf16 *__restrict__ Qt,
-                                                           const __bf16 *__restrict__ dO, const __bf16 *__restrict__ dOt,
+                                                           const __bf16 *__restrict__ V,
+                                                           const __bf16 *__restrict__ dO,
                                                            const float *__restrict__ LSE, const float *__restrict__ DELTA,
                                                            __bf16 *__restrict__ dK, __bf16 *__restrict__ dV, BwdDims dm) {
   __shared__ __align__(16) unsigned char s_q[AT_KB * 128];
   __shared__ __align__(16) unsigned char s_g[AT_KB * 128];
-  __shared__ __align__(16) unsigned char s_qt[AT_D * 128];
-  __shared__ __align__(16) unsigned char s_gt[AT_D * 128];
   __shared__ __align__(16) float s_lse[AT_KB];
   __shared__ __align__(16) float s_del[AT_KB];
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
@@ -597,8 +594,6 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *_
   const __bf16 *Gb = dO + b * dm.o_bs + hd * dm.o_hs;
   const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
   const __bf16 *Vb = V + b * dm.k_bs + hd * dm.k_hs;
-  const __bf16 *Qtb = Qt + (long)bh * AT_D * dm.Lqp;
-  const __bf16 *Gtb = dOt + (long)bh * AT_D * dm.Lqp;
   const float *lseb = LSE + (long)bh * dm.Lq, *delb = DELTA + (long)bh * dm.Lq;
   const float scale = dm.scale;
   const float c = scale * 1.4426950408889634f;
@@ -615,24 +610,18 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *_
   const int nqt = (dm.Lq + AT_KB - 1) / AT_KB;
   uint4 qa = stage_load(Qb, dm.q_rs, 0, dm.Lq, t), qb = stage_load(Qb, dm.q_rs, 0, dm.Lq, t + 256);
   uint4 ga = stage_load(Gb, dm.o_rs, 0, dm.Lq, t), gb = stage_load(Gb, dm.o_rs, 0, dm.Lq, t + 256);
-  uint4 qta = stage_load(Qtb, dm.Lqp, 0, AT_D, t), qtb = stage_load(Qtb, dm.Lqp, 0, AT_D, t + 256);
-  uint4 gta = stage_load(Gtb, dm.Lqp, 0, AT_D, t), gtb = stage_load(Gtb, dm.Lqp, 0, AT_D, t + 256);
   float rl = 0.f, rd = 0.f;
   if (t < AT_KB) { rl = lseb[min(t, dm.Lq - 1)]; rd = delb[min(t, dm.Lq - 1)]; }
   for (int qt = 0; qt < nqt; ++qt) {
     __syncthreads();
     stage_store(s_q, t, qa); stage_store(s_q, t + 256, qb);
     stage_store(s_g, t, ga); stage_store(s_g, t + 256, gb);
-    stage_store(s_qt, t, qta); stage_store(s_qt, t + 256, qtb);
-    stage_store(s_gt, t, gta); stage_store(s_gt, t + 256, gtb);
     if (t < AT_KB) { s_lse[t] = rl; s_del[t] = rd; }
     __syncthreads();
     {
       const int nt = min(qt + 1, nqt - 1);
       qa = stage_load(Qb, dm.q_rs, nt * AT_KB, dm.Lq, t); qb = stage_load(Qb, dm.q_rs, nt * AT_KB, dm.Lq, t + 256);
       ga = stage_load(Gb, dm.o_rs, nt * AT_KB, dm.Lq, t); gb = stage_load(Gb, dm.o_rs, nt * AT_KB, dm.Lq, t + 256);
-      qta = stage_load(Qtb + nt * AT_KB, dm.Lqp, 0, AT_D, t); qtb = stage_load(Qtb + nt * AT_KB, dm.Lqp, 0, AT_D, t + 256);
-      gta = stage_load(Gtb + nt * AT_KB, dm.Lqp, 0, AT_D, t); gtb = stage_load(Gtb + nt * AT_KB, dm.Lqp, 0, AT_D, t + 256);
       if (t < AT_KB) { rl = lseb[min(nt * AT_KB + t, dm.Lq - 1)]; rd = delb[min(nt * AT_KB + t, dm.Lq - 1)]; }
     }
     const bool last = qt == nqt - 1;
@@ -684,12 +673,12 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *_
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const int ch = 4 * qb2 + 2 * s2;
+        const int q0r = 32 * qb2 + 16 * s2 + 4 * h;  // dO^T / Q^T fragments straight from the row-major dO / Q tiles
         const bf16x8 pp = s2 == 0 ? p0 : p1, ds = s2 == 0 ? d0 : d1;
-        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(s_gt, r, ch, h), pp, dv0, 0, 0, 0);
-        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(s_gt, 32 + r, ch, h), pp, dv1, 0, 0, 0);
-        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(s_qt, r, ch, h), ds, dk0, 0, 0, 0);
-        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(s_qt, 32 + r, ch, h), ds, dk1, 0, 0, 0);
+        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag_tr(s_g, q0r, 0, r), pp, dv0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag_tr(s_g, q0r, 32, r), pp, dv1, 0, 0, 0);
+        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag_tr(s_q, q0r, 0, r), ds, dk0, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag_tr(s_q, q0r, 32, r), ds, dk1, 0, 0, 0);
       }
     }
   }
@@ -705,19 +694,20 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *_
 using namespace bq;
 
 // Q: bf16 (B, Lq, H, 64) / K, V: (B, Lk, H, 64) given by element strides (batch, token, head), 64 contiguous
-// elements per (token, head).  Vt: bf16 [B*H][64][Lkp] (V transposed, key-contiguous, zero padded, Lkp % 64 == 0).
+// elements per (token, head); V is strided like K.  (No transposed copies: the kernels read V^T / K^T / Q^T / dO^T out of
+// the row-major LDS tiles with ds_read_b64_tr_b16.)  Lkp = row length of the mask, a multiple of 64 >= Lk.
 // O: bf16 strided like Q's shape; LSE: f32 [B*H][Lq], log2-domain log-sum-exp of the scaled (+masked) scores.
 // mask: optional f32 [B][Lkp] additive key mask ALREADY multiplied by log2(e) (0 in the padding); p_drop / seed:
 // dropout on the attention probabilities (stateless hash, regenerated by the backward); the effective seed is
 // seed_ptr[0] * 2654435761 + seed when seed_ptr (a device counter the caller bumps once per step) is given.
 // causal != 0 (Lq == Lk): keys after the query are masked as well.
 extern "C" __attribute__((visibility("default"))) int bq_attn_fwd(
-    const void *Q, const void *K, const void *Vt, void *O, float *LSE, const float *mask, int B, int H, int Lq, int Lk,
+    const void *Q, const void *K, const void *V, void *O, float *LSE, const float *mask, int B, int H, int Lq, int Lk,
     int Lkp, long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long o_bs, long o_rs, long o_hs,
     float scale, float p_drop, unsigned seed, const unsigned *seed_ptr, int causal, void *stream) {
   BQ_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && Lkp >= Lk && Lkp % 64 == 0, BQ_EINVAL, "attn_fwd: bad extents");
   BQ_REQUIRE(!causal || Lq == Lk, BQ_EINVAL, "attn_fwd: causal needs Lq == Lk");
-  BQ_REQUIRE(Q && K && Vt && O && LSE, BQ_EINVAL, "attn_fwd: null pointer");
+  BQ_REQUIRE(Q && K && V && O && LSE, BQ_EINVAL, "attn_fwd: null pointer");
   BQ_REQUIRE((q_rs % 8) == 0 && (k_rs % 8) == 0 && (o_rs % 4) == 0 && (q_hs % 8) == 0 && (k_hs % 8) == 0, BQ_EINVAL,
              "attn_fwd: rows must be 16-byte aligned");
   BQ_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, BQ_EINVAL, "attn_fwd: bad dropout probability");
@@ -726,56 +716,52 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_fwd(
   static const bool narrow_ok = !getenv("BQ_ATTN_NO_NARROW");
   if (narrow_ok && Lq <= AT_QW && Lk > 2 * AT_KB && (o_rs % 8) == 0 && (o_hs % 8) == 0) {
     hipLaunchKernelGGL(attn_fwd_narrow_kernel, dim3(1, B * H), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Q,
-                       (const __bf16 *)K, (const __bf16 *)Vt, (__bf16 *)O, LSE, dm);
+                       (const __bf16 *)K, (const __bf16 *)V, (__bf16 *)O, LSE, dm);
     return check_launch("attn_fwd_narrow");
   }
   const dim3 grid((Lq + AT_QB - 1) / AT_QB, B * H);
   static const int minw = getenv("BQ_ATTN_MINW") ? atoi(getenv("BQ_ATTN_MINW")) : 3;  // 3 waves/SIMD measured best (158 VGPRs, no spill)
 #define BQ_FWD(W) hipLaunchKernelGGL(attn_fwd_kernel<W>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Q, \
-                                     (const __bf16 *)K, (const __bf16 *)Vt, (__bf16 *)O, LSE, dm)
+                                     (const __bf16 *)K, (const __bf16 *)V, (__bf16 *)O, LSE, dm)
   switch (minw) { case 1: BQ_FWD(1); break; case 2: BQ_FWD(2); break; case 4: BQ_FWD(4); break; default: BQ_FWD(3); }
 #undef BQ_FWD
   return check_launch("attn_fwd");
 }
 
 // Backward of bq_attn_fwd.  dQ shares Q's strides, dK/dV share K's (V must be strided like K), dO has its own.
-// Kt: [B*H][64][Lkp]; Qt, dOt: [B*H][64][Lqp] zero-padded transposes.  LSE and O (contiguous (B,Lq,H,64)) from the
-// forward; DELTA: f32 [B*H][Lq] scratch (rowsum(dO*O), produced by the dQ kernel, consumed by the dK/dV kernel).  mask / p_drop / seed exactly as given to the forward.
+// LSE and O (contiguous (B,Lq,H,64)) from the forward; DELTA: f32 [B*H][Lq] scratch (rowsum(dO*O), produced by the dQ
+// kernel, consumed by the dK/dV kernel).  mask / p_drop / seed / causal exactly as given to the forward.
 extern "C" __attribute__((visibility("default"))) int bq_attn_bwd(
-    const void *Q, const void *K, const void *V, const void *Qt, const void *Kt, const void *dO, const void *dOt,
-    const float *LSE, const void *O, float *DELTA, const float *mask, void *dQ, void *dK, void *dV, int B, int H, int Lq,
-    int Lk,
-    int Lqp, int Lkp, long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long g_bs, long g_rs, long g_hs,
-    float scale, float p_drop, unsigned seed, const unsigned *seed_ptr, int causal, void *stream) {
-  BQ_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && Lkp >= Lk && Lkp % 64 == 0 && Lqp >= Lq && Lqp % 64 == 0, BQ_EINVAL,
-             "attn_bwd: bad extents");
+    const void *Q, const void *K, const void *V, const void *dO, const float *LSE, const void *O, float *DELTA,
+    const float *mask, void *dQ, void *dK, void *dV, int B, int H, int Lq, int Lk, int Lkp, long q_bs, long q_rs,
+    long q_hs, long k_bs, long k_rs, long k_hs, long g_bs, long g_rs, long g_hs, float scale, float p_drop, unsigned seed,
+    const unsigned *seed_ptr, int causal, void *stream) {
+  BQ_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && Lkp >= Lk && Lkp % 64 == 0, BQ_EINVAL, "attn_bwd: bad extents");
   BQ_REQUIRE(!causal || Lq == Lk, BQ_EINVAL, "attn_bwd: causal needs Lq == Lk");
-  BQ_REQUIRE(Q && K && V && Qt && Kt && dO && dOt && LSE && O && DELTA && dQ && dK && dV, BQ_EINVAL,
-             "attn_bwd: null pointer");
+  BQ_REQUIRE(Q && K && V && dO && LSE && O && DELTA && dQ && dK && dV, BQ_EINVAL, "attn_bwd: null pointer");
   BQ_REQUIRE((q_rs % 8) == 0 && (k_rs % 8) == 0 && (g_rs % 8) == 0 && (q_hs % 8) == 0 && (k_hs % 8) == 0 &&
                  (g_hs % 8) == 0, BQ_EINVAL, "attn_bwd: rows must be 16-byte aligned");
   BQ_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, BQ_EINVAL, "attn_bwd: bad dropout probability");
-  BwdDims dm{B, H, Lq, Lk, Lqp, Lkp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, g_bs, g_rs, g_hs, mask, scale,
+  BwdDims dm{B, H, Lq, Lk, 0, Lkp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, g_bs, g_rs, g_hs, mask, scale,
              1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr, causal ? 1 : 0};
   hipStream_t st = (hipStream_t)stream;
   static const int dq_w = getenv("BQ_ATTN_DQ_MINW") ? atoi(getenv("BQ_ATTN_DQ_MINW")) : 2;
-  static const int dkv_w = getenv("BQ_ATTN_DKV_MINW") ? atoi(getenv("BQ_ATTN_DKV_MINW")) : 2;  // 242 VGPRs, 2 waves/SIMD: 0.64 -> 0.50 ms per ViT layer (tools/attn_sweep.sh)
+  static const int dkv_w = getenv("BQ_ATTN_DKV_MINW") ? atoi(getenv("BQ_ATTN_DKV_MINW")) : 2;  // 2 waves/SIMD (tools/attn_sweep.sh)
 #define BQ_DQ(W) hipLaunchKernelGGL(attn_bwd_dq_kernel<W>, dim3((Lq + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, st, \
-                                    (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)Kt,      \
-                                    (const __bf16 *)dO, LSE, (const __bf16 *)O, DELTA, (__bf16 *)dQ, dm)
+                                    (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)dO, LSE,  \
+                                    (const __bf16 *)O, DELTA, (__bf16 *)dQ, dm)
   static const bool narrow_ok = !getenv("BQ_ATTN_NO_NARROW");
   if (narrow_ok && Lq <= AT_QW && Lk > 2 * AT_KB)
     hipLaunchKernelGGL(attn_bwd_dq_narrow_kernel, dim3(1, B * H), dim3(256), 0, st, (const __bf16 *)Q, (const __bf16 *)K,
-                       (const __bf16 *)V, (const __bf16 *)Kt, (const __bf16 *)dO, LSE, (const __bf16 *)O, DELTA,
-                       (__bf16 *)dQ, dm);
+                       (const __bf16 *)V, (const __bf16 *)dO, LSE, (const __bf16 *)O, DELTA, (__bf16 *)dQ, dm);
   else
     switch (dq_w) { case 1: BQ_DQ(1); break; case 3: BQ_DQ(3); break; default: BQ_DQ(2); }
 #undef BQ_DQ
   int rc = check_launch("attn_bwd_dq");
   if (rc) return rc;
 #define BQ_DKV(W) hipLaunchKernelGGL(attn_bwd_dkv_kernel<W>, dim3((Lk + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, st, \
-                                     (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)Qt,      \
-                                     (const __bf16 *)dO, (const __bf16 *)dOt, LSE, DELTA, (__bf16 *)dK, (__bf16 *)dV, dm)
+                                     (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)dO, LSE,   \
+                                     DELTA, (__bf16 *)dK, (__bf16 *)dV, dm)
   switch (dkv_w) { case 1: BQ_DKV(1); break; default: BQ_DKV(2); }
 #undef BQ_DKV
   return check_launch("attn_bwd_dkv");

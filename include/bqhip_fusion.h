@@ -18,25 +18,24 @@ extern "C" {
 /* ---- multi-head attention, head dim 64, bf16 operands, fp32 accumulation (csrc/attn.hip) -------------------
  * Replaces  attn = (q @ k^T) * scale [+ mask]; attn = softmax(attn); attn = dropout(attn); out = attn @ v
  *   models/vit.py:75-83 (Attention.forward), models/med.py:179-217 (BertSelfAttention.forward).
- * Q (B,Lq,H,64), K/V (B,Lk,H,64) by strides (q_bs,q_rs,q_hs = batch, token, head; 64 contiguous elements);
- * Vt = V transposed [B*H][64][Lkp], zero padded, Lkp % 64 == 0 (bq_transpose_pad);  O (B,Lq,H,64) by strides;
- * LSE f32 [B*H][Lq] (log2 domain).  mask: NULL or f32 [B][Lkp] additive key mask ALREADY multiplied by log2(e).
- * p_drop / seed / seed_ptr: dropout on the probabilities as a stateless hash of (seed_ptr[0]*2654435761 + seed,
- * b*H+h, query, key) -- nothing stored, the backward regenerates it.  causal != 0 (Lq == Lk): key j visible to
- * query i only if j <= i (med.py:771-830 decoder mask). */
-BQ_API int bq_attn_fwd(const void *Q, const void *K, const void *Vt, void *O, float *LSE, const float *mask, int B,
+ * Q (B,Lq,H,64), K / V (B,Lk,H,64) by strides (q_bs,q_rs,q_hs = batch, token, head; 64 contiguous elements; V strided
+ * like K); O (B,Lq,H,64) by strides; LSE f32 [B*H][Lq] (log2 domain).  mask: NULL or f32 [B][Lkp] additive key mask
+ * ALREADY multiplied by log2(e), Lkp a multiple of 64 >= Lk.  p_drop / seed / seed_ptr: dropout on the probabilities
+ * as a stateless hash of (seed_ptr[0]*2654435761 + seed, b*H+h, query, key) -- nothing stored, the backward
+ * regenerates it.  causal != 0 (Lq == Lk): key j visible to query i only if j <= i (med.py:771-830 decoder mask).
+ * No transposed operand copies: V^T / K^T / Q^T / dO^T are read out of the row-major LDS tiles (ds_read_b64_tr_b16). */
+BQ_API int bq_attn_fwd(const void *Q, const void *K, const void *V, void *O, float *LSE, const float *mask, int B,
                        int H, int Lq, int Lk, int Lkp, long q_bs, long q_rs, long q_hs, long k_bs, long k_rs,
                        long k_hs, long o_bs, long o_rs, long o_hs, float scale, float p_drop, unsigned seed,
                        const unsigned *seed_ptr, int causal, void *stream);
 
-/* Backward of bq_attn_fwd (what autograd derives from the composition above).  dQ strided like Q, dK/dV like K
- * (V strided like K); Qt, dOt [B*H][64][Lqp], Kt [B*H][64][Lkp] zero-padded transposes; O contiguous
- * (B,Lq,H,64) and LSE from the forward; DELTA f32 [B*H][Lq] scratch. */
-BQ_API int bq_attn_bwd(const void *Q, const void *K, const void *V, const void *Qt, const void *Kt, const void *dO,
-                       const void *dOt, const float *LSE, const void *O, float *DELTA, const float *mask, void *dQ,
-                       void *dK, void *dV, int B, int H, int Lq, int Lk, int Lqp, int Lkp, long q_bs, long q_rs,
-                       long q_hs, long k_bs, long k_rs, long k_hs, long g_bs, long g_rs, long g_hs, float scale,
-                       float p_drop, unsigned seed, const unsigned *seed_ptr, int causal, void *stream);
+/* Backward of bq_attn_fwd (what autograd derives from the composition above).  dQ strided like Q, dK/dV like K;
+ * dO by its own strides (g_*); O contiguous (B,Lq,H,64) and LSE from the forward; DELTA f32 [B*H][Lq] scratch. */
+BQ_API int bq_attn_bwd(const void *Q, const void *K, const void *V, const void *dO, const float *LSE, const void *O,
+                       float *DELTA, const float *mask, void *dQ, void *dK, void *dV, int B, int H, int Lq, int Lk,
+                       int Lkp, long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long g_bs, long g_rs,
+                       long g_hs, float scale, float p_drop, unsigned seed, const unsigned *seed_ptr, int causal,
+                       void *stream);
 
 /* in (B,L,H,64) bf16 by strides -> out [B*H][64][Lp], zero padded (replaces zeros + permute + copy_) */
 BQ_API int bq_transpose_pad(const void *in, void *out, int B, int H, int L, int Lp, long bs, long rs, long hs,

@@ -114,18 +114,38 @@ __device__ __forceinline__ bf16x8 tfrag_tr(const unsigned char *img, int row0, i
 // One 64-key tile (two 32-key blocks) of the online-softmax forward for the 32 queries of a wave: S^T = K.Q^T from
 // the LDS image s_k, mask / causal / length clamp, running max + rescale, P (with dropout) straight from the
 // accumulator registers into O^T += V^T.P^T from the LDS image s_v.  qrow = this lane's query index.
+//
+// PLAIN (compile time): no key mask, not causal, no dropout -- the ViT's case, 3/4 of the attention time of the path.
+// The wave-uniform special cases then vanish at compile time instead of being branched around, the tile becomes
+// (almost) one basic block the scheduler can interleave, and `LASTP` (compile time, the peeled last tile) replaces
+// the run-time `last`.  EARLY: both 32-key score blocks are issued to the matrix pipe before the first softmax.
+__device__ __forceinline__ f32x16 score_block(const unsigned char *s_k, const bf16x8 (&qf)[4], int kb2, int r, int h) {
+  f32x16 acc = {0};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(s_k + swz(kb2 * 32 + r, 2 * s + h));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+template <bool PLAIN = false, bool LASTP = false, bool EARLY = false>
 __device__ __forceinline__ void fwd_tile(const unsigned char *s_k, const unsigned char *s_v, const bf16x8 (&qf)[4],
-                                         const AttnDims &dm, const float *mrow, float scale_log2e, unsigned seed, int bh,
-                                         int qrow, int kt, bool last, int r, int h, f32x16 &o0, f32x16 &o1, float &m,
+                                         const AttnDims &dm, const float *mrow_, float scale_log2e, unsigned seed, int bh,
+                                         int qrow, int kt, bool last_, int r, int h, f32x16 &o0, f32x16 &o1, float &m,
                                          float &lsum) {
+    const float *mrow = PLAIN ? nullptr : mrow_;
+    const bool last = PLAIN ? LASTP : last_;
+    const bool causal = !PLAIN && dm.causal;
+    const bool drop = !PLAIN && dm.drop_thresh != 0;
+    f32x16 early[2];
+    if (EARLY) {
+      early[0] = score_block(s_k, qf, 0, r, h);
+      early[1] = score_block(s_k, qf, 1, r, h);
+    }
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2) {
-      f32x16 acc = {0};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(s_k + swz(kb2 * 32 + r, 2 * s + h));
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], acc, 0, 0, 0);
-      }
+      const f32x16 acc = EARLY ? early[kb2] : score_block(s_k, qf, kb2, r, h);
       // sc is kept in log2 units when there is a mask (one fma per element) and in raw dot-product units otherwise
       // (the scale is folded into the max once and into the exp2 argument by an fma): fewer VALU ops per pair
       float sc[16];
@@ -146,7 +166,7 @@ __device__ __forceinline__ void fwd_tile(const unsigned char *s_k, const unsigne
         for (int i = 0; i < 16; ++i)
           if (kbase + crow(i, h) >= dm.Lk) sc[i] = -INFINITY;
       }
-      if (dm.causal) {
+      if (causal) {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
           if (kbase + crow(i, h) > qrow) sc[i] = -INFINITY;
@@ -170,7 +190,7 @@ __device__ __forceinline__ void fwd_tile(const unsigned char *s_k, const unsigne
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) psum += pv[i];  // the softmax denominator uses the un-dropped probabilities
-      if (dm.drop_thresh) {  // wave-uniform
+      if (drop) {  // wave-uniform
 #pragma unroll
         for (int i = 0; i < 16; ++i)
           pv[i] = drop_keep(seed, bh, qrow, kbase + crow(i, h), dm.drop_thresh) ? pv[i] * dm.inv_keep : 0.0f;
@@ -196,12 +216,15 @@ __device__ __forceinline__ void fwd_tile(const unsigned char *s_k, const unsigne
     }
 }
 
-template <int MINW>
+// MODE 0: every option at run time; 1: PLAIN (no mask / causal / dropout), last tile peeled; 2: PLAIN + EARLY scores
+template <int MINW, int MODE = 0>
 __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
                                                        const __bf16 *__restrict__ V, __bf16 *__restrict__ O,
                                                        float *__restrict__ LSE, AttnDims dm) {
-  __shared__ __align__(16) unsigned char s_k[AT_KB * 128];
-  __shared__ __align__(16) unsigned char s_v[AT_KB * 128];
+  // two LDS images per operand: tile kt+1 is committed to the other image while tile kt is consumed => ONE barrier
+  // per tile, and the global loads of tile kt+2 have a whole tile of compute to land
+  __shared__ __align__(16) unsigned char s_k[2][AT_KB * 128];
+  __shared__ __align__(16) unsigned char s_v[2][AT_KB * 128];
   const float scale_log2e = dm.scale * 1.4426950408889634f;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
@@ -222,19 +245,41 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__res
   f32x16 o0 = {0}, o1 = {0};
   float m = -INFINITY, lsum = 0.0f;
   const int nkt = (dm.Lk + AT_KB - 1) / AT_KB;
-  uint4 ka = stage_load(Kb, dm.k_rs, 0, dm.Lk, t), kb = stage_load(Kb, dm.k_rs, 0, dm.Lk, t + 256);
-  uint4 va = stage_load(Vb, dm.k_rs, 0, dm.Lk, t), vb = stage_load(Vb, dm.k_rs, 0, dm.Lk, t + 256);
-  for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();  // everyone finished reading the previous tile
-    stage_store(s_k, t, ka); stage_store(s_k, t + 256, kb);
-    stage_store(s_v, t, va); stage_store(s_v, t + 256, vb);
-    __syncthreads();
-    {
-      const int nt = min(kt + 1, nkt - 1);  // the tile after the last is a harmless re-load of the last
-      ka = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.Lk, t); kb = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.Lk, t + 256);
-      va = stage_load(Vb, dm.k_rs, nt * AT_KB, dm.Lk, t); vb = stage_load(Vb, dm.k_rs, nt * AT_KB, dm.Lk, t + 256);
+  uint4 ka, kb, va, vb;
+  auto fetch = [&](int kt) {  // rows past the end repeat the last one (masked by the last tile)
+    ka = stage_load(Kb, dm.k_rs, kt * AT_KB, dm.Lk, t); kb = stage_load(Kb, dm.k_rs, kt * AT_KB, dm.Lk, t + 256);
+    va = stage_load(Vb, dm.k_rs, kt * AT_KB, dm.Lk, t); vb = stage_load(Vb, dm.k_rs, kt * AT_KB, dm.Lk, t + 256);
+  };
+  auto commit = [&](int buf) {
+    stage_store(s_k[buf], t, ka); stage_store(s_k[buf], t + 256, kb);
+    stage_store(s_v[buf], t, va); stage_store(s_v[buf], t + 256, vb);
+  };
+  auto advance = [&](int kt) {  // after tile kt: commit tile kt+1 (already in registers), fetch tile kt+2
+    if (kt + 1 < nkt) {
+      commit((kt + 1) & 1);
+      if (kt + 2 < nkt) fetch(kt + 2);
     }
-    fwd_tile(s_k, s_v, qf, dm, mrow, scale_log2e, seed, bh, q0 + r, kt, kt == nkt - 1, r, h, o0, o1, m, lsum);
+    __syncthreads();
+  };
+  fetch(0);
+  commit(0);
+  if (nkt > 1) fetch(1);
+  __syncthreads();
+  const bool active = q0 < dm.Lq;  // wave-uniform: a wave whose 32 queries are all past the end only helps staging
+  if (MODE == 0) {
+    for (int kt = 0; kt < nkt; ++kt) {
+      if (active)
+        fwd_tile(s_k[kt & 1], s_v[kt & 1], qf, dm, mrow, scale_log2e, seed, bh, q0 + r, kt, kt == nkt - 1, r, h, o0, o1, m, lsum);
+      advance(kt);
+    }
+  } else {
+    for (int kt = 0; kt < nkt - 1; ++kt) {
+      if (active)
+        fwd_tile<true, false, MODE == 2>(s_k[kt & 1], s_v[kt & 1], qf, dm, nullptr, scale_log2e, seed, bh, q0 + r, kt, false, r, h, o0, o1, m, lsum);
+      advance(kt);
+    }
+    if (active)
+      fwd_tile<true, true, MODE == 2>(s_k[(nkt - 1) & 1], s_v[(nkt - 1) & 1], qf, dm, nullptr, scale_log2e, seed, bh, q0 + r, nkt - 1, true, r, h, o0, o1, m, lsum);
   }
   // epilogue: O[q][d] = O^T[d][q] / l ; LSE[q] = m + log2(l)   (log2 domain, scale folded in)
   const float l = xhalf_sum(lsum);
@@ -378,9 +423,14 @@ typedef AttnDims BwdDims;  // o_* strides describe dO
 
 // One 64-key tile of the dQ pass for the 32 queries of a wave: P recomputed from S^T = K.Q^T and the forward's LSE,
 // dP^T = V.dO^T, dS^T = P o (dP - delta) * scale, then dQ^T += K^T.dS^T (A = LDS image of the pre-transposed K).
+template <bool PLAIN = false, bool LASTP = false>
 __device__ __forceinline__ void dq_tile(const unsigned char *s_k, const unsigned char *s_v, const bf16x8 (&qf)[4], const bf16x8 (&gf)[4], const BwdDims &dm,
-                                        const float *mrow, float c, float scale, float lse, float delta, unsigned seed,
-                                        int bh, int qrow, int kt, bool last, int r, int h, f32x16 &a0, f32x16 &a1) {
+                                        const float *mrow_, float c, float scale, float lse, float delta, unsigned seed,
+                                        int bh, int qrow, int kt, bool last_, int r, int h, f32x16 &a0, f32x16 &a1) {
+    const float *mrow = PLAIN ? nullptr : mrow_;  // PLAIN / LASTP: see fwd_tile
+    const bool last = PLAIN ? LASTP : last_;
+    const bool causal = !PLAIN && dm.causal;
+    const bool drop = !PLAIN && dm.drop_thresh != 0;
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2) {
       f32x16 sacc = {0}, pacc = {0};
@@ -408,12 +458,12 @@ __device__ __forceinline__ void dq_tile(const unsigned char *s_k, const unsigned
         for (int i = 0; i < 16; ++i)
           if (kbase + crow(i, h) >= dm.Lk) pv[i] = 0.0f;
       }
-      if (dm.causal) {
+      if (causal) {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
           if (kbase + crow(i, h) > qrow) pv[i] = 0.0f;
       }
-      if (dm.drop_thresh) {
+      if (drop) {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
           gv[i] = drop_keep(seed, bh, qrow, kbase + crow(i, h), dm.drop_thresh) ? pacc[i] * dm.inv_keep : 0.0f;
@@ -436,14 +486,14 @@ __device__ __forceinline__ void dq_tile(const unsigned char *s_k, const unsigned
     }
 }
 
-template <int MINW>
+template <int MINW, bool PLAIN = false>
 __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
                                                           const __bf16 *__restrict__ V,
                                                           const __bf16 *__restrict__ dO, const float *__restrict__ LSE,
                                                           const __bf16 *__restrict__ O, float *__restrict__ DELTA,
                                                           __bf16 *__restrict__ dQ, BwdDims dm) {
-  __shared__ __align__(16) unsigned char s_k[AT_KB * 128];
-  __shared__ __align__(16) unsigned char s_v[AT_KB * 128];
+  __shared__ __align__(16) unsigned char s_k[2][AT_KB * 128];  // double-buffered: see attn_fwd_kernel
+  __shared__ __align__(16) unsigned char s_v[2][AT_KB * 128];
   const float scale = dm.scale;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
@@ -480,19 +530,41 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const __bf16 *__
   }
   f32x16 a0 = {0}, a1 = {0};
   const int nkt = (dm.Lk + AT_KB - 1) / AT_KB;
-  uint4 ka = stage_load(Kb, dm.k_rs, 0, dm.Lk, t), kb = stage_load(Kb, dm.k_rs, 0, dm.Lk, t + 256);
-  uint4 va = stage_load(Vb, dm.k_rs, 0, dm.Lk, t), vb = stage_load(Vb, dm.k_rs, 0, dm.Lk, t + 256);
-  for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();
-    stage_store(s_k, t, ka); stage_store(s_k, t + 256, kb);
-    stage_store(s_v, t, va); stage_store(s_v, t + 256, vb);
-    __syncthreads();
-    {
-      const int nt = min(kt + 1, nkt - 1);
-      ka = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.Lk, t); kb = stage_load(Kb, dm.k_rs, nt * AT_KB, dm.Lk, t + 256);
-      va = stage_load(Vb, dm.k_rs, nt * AT_KB, dm.Lk, t); vb = stage_load(Vb, dm.k_rs, nt * AT_KB, dm.Lk, t + 256);
+  uint4 ka, kb, va, vb;
+  auto fetch = [&](int kt) {
+    ka = stage_load(Kb, dm.k_rs, kt * AT_KB, dm.Lk, t); kb = stage_load(Kb, dm.k_rs, kt * AT_KB, dm.Lk, t + 256);
+    va = stage_load(Vb, dm.k_rs, kt * AT_KB, dm.Lk, t); vb = stage_load(Vb, dm.k_rs, kt * AT_KB, dm.Lk, t + 256);
+  };
+  auto commit = [&](int buf) {
+    stage_store(s_k[buf], t, ka); stage_store(s_k[buf], t + 256, kb);
+    stage_store(s_v[buf], t, va); stage_store(s_v[buf], t + 256, vb);
+  };
+  auto advance = [&](int kt) {
+    if (kt + 1 < nkt) {
+      commit((kt + 1) & 1);
+      if (kt + 2 < nkt) fetch(kt + 2);
     }
-    dq_tile(s_k, s_v, qf, gf, dm, mrow, c, scale, lse, delta, seed, bh, q0 + r, kt, kt == nkt - 1, r, h, a0, a1);
+    __syncthreads();
+  };
+  fetch(0);
+  commit(0);
+  if (nkt > 1) fetch(1);
+  __syncthreads();
+  const bool active = q0 < dm.Lq;  // wave-uniform
+  if (!PLAIN) {
+    for (int kt = 0; kt < nkt; ++kt) {
+      if (active)
+        dq_tile(s_k[kt & 1], s_v[kt & 1], qf, gf, dm, mrow, c, scale, lse, delta, seed, bh, q0 + r, kt, kt == nkt - 1, r, h, a0, a1);
+      advance(kt);
+    }
+  } else {
+    for (int kt = 0; kt < nkt - 1; ++kt) {
+      if (active)
+        dq_tile<true, false>(s_k[kt & 1], s_v[kt & 1], qf, gf, dm, nullptr, c, scale, lse, delta, seed, bh, q0 + r, kt, false, r, h, a0, a1);
+      advance(kt);
+    }
+    if (active)
+      dq_tile<true, true>(s_k[(nkt - 1) & 1], s_v[(nkt - 1) & 1], qf, gf, dm, nullptr, c, scale, lse, delta, seed, bh, q0 + r, nkt - 1, true, r, h, a0, a1);
   }
   if (q0 + r < dm.Lq) store_T(dQ + b * dm.q_bs + hd * dm.q_hs + (long)(q0 + r) * dm.q_rs, a0, a1, h, scale);
 }
@@ -576,55 +648,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_narrow_kernel(const __bf16 *_
   }
 }
 
-template <int MINW>
-__global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
-                                                           const __bf16 *__restrict__ V,
-                                                           const __bf16 *__restrict__ dO,
-                                                           const float *__restrict__ LSE, const float *__restrict__ DELTA,
-                                                           __bf16 *__restrict__ dK, __bf16 *__restrict__ dV, BwdDims dm) {
-  __shared__ __align__(16) unsigned char s_q[AT_KB * 128];
-  __shared__ __align__(16) unsigned char s_g[AT_KB * 128];
-  __shared__ __align__(16) float s_lse[AT_KB];
-  __shared__ __align__(16) float s_del[AT_KB];
-  const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
-  const unsigned seed = eff_seed(dm);
-  const int k0 = blockIdx.x * AT_QB + wid * AT_QW;  // first key of this wave
-  const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
-  const __bf16 *Gb = dO + b * dm.o_bs + hd * dm.o_hs;
-  const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
-  const __bf16 *Vb = V + b * dm.k_bs + hd * dm.k_hs;
-  const float *lseb = LSE + (long)bh * dm.Lq, *delb = DELTA + (long)bh * dm.Lq;
-  const float scale = dm.scale;
-  const float c = scale * 1.4426950408889634f;
-
-  bf16x8 kf[4], vf[4];
-  const int kr = min(k0 + r, dm.Lk - 1);
-  const float mkey = dm.mask ? dm.mask[(long)b * dm.Lkp + kr] : 0.0f;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    kf[s] = *reinterpret_cast<const bf16x8 *>(Kb + (long)kr * dm.k_rs + 16 * s + 8 * h);
-    vf[s] = *reinterpret_cast<const bf16x8 *>(Vb + (long)kr * dm.k_rs + 16 * s + 8 * h);
-  }
-  f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
-  const int nqt = (dm.Lq + AT_KB - 1) / AT_KB;
-  uint4 qa = stage_load(Qb, dm.q_rs, 0, dm.Lq, t), qb = stage_load(Qb, dm.q_rs, 0, dm.Lq, t + 256);
-  uint4 ga = stage_load(Gb, dm.o_rs, 0, dm.Lq, t), gb = stage_load(Gb, dm.o_rs, 0, dm.Lq, t + 256);
-  float rl = 0.f, rd = 0.f;
-  if (t < AT_KB) { rl = lseb[min(t, dm.Lq - 1)]; rd = delb[min(t, dm.Lq - 1)]; }
-  for (int qt = 0; qt < nqt; ++qt) {
-    __syncthreads();
-    stage_store(s_q, t, qa); stage_store(s_q, t + 256, qb);
-    stage_store(s_g, t, ga); stage_store(s_g, t + 256, gb);
-    if (t < AT_KB) { s_lse[t] = rl; s_del[t] = rd; }
-    __syncthreads();
-    {
-      const int nt = min(qt + 1, nqt - 1);
-      qa = stage_load(Qb, dm.q_rs, nt * AT_KB, dm.Lq, t); qb = stage_load(Qb, dm.q_rs, nt * AT_KB, dm.Lq, t + 256);
-      ga = stage_load(Gb, dm.o_rs, nt * AT_KB, dm.Lq, t); gb = stage_load(Gb, dm.o_rs, nt * AT_KB, dm.Lq, t + 256);
-      if (t < AT_KB) { rl = lseb[min(nt * AT_KB + t, dm.Lq - 1)]; rd = delb[min(nt * AT_KB + t, dm.Lq - 1)]; }
-    }
-    const bool last = qt == nqt - 1;
+// One 64-query tile of the dK/dV pass for the 32 keys of a wave (lane = key): S = Q.K^T and dP = dO.V^T (A = Q / dO
+// rows from LDS, B = register fragments of K and V), P from the forward's LSE, then dV^T += dO^T.P and dK^T += Q^T.dS
+// with the transposed A operands read straight from the row-major tiles.  PLAIN / LASTP: see fwd_tile.
+template <bool PLAIN = false, bool LASTP = false>
+__device__ __forceinline__ void dkv_tile(const unsigned char *s_q, const unsigned char *s_g, const float *s_lse,
+                                         const float *s_del, const bf16x8 (&kf)[4], const bf16x8 (&vf)[4],
+                                         const BwdDims &dm, float c, float mkey_, unsigned seed, int bh, int kcol, int qt,
+                                         bool last_, int r, int h, f32x16 &dk0, f32x16 &dk1, f32x16 &dv0, f32x16 &dv1) {
+    const float mkey = PLAIN ? 0.0f : mkey_;
+    const bool last = PLAIN ? LASTP : last_;
+    const bool causal = !PLAIN && dm.causal;
+    const bool drop = !PLAIN && dm.drop_thresh != 0;
 #pragma unroll
     for (int qb2 = 0; qb2 < 2; ++qb2) {
       f32x16 sacc = {0}, pacc = {0};
@@ -648,15 +683,15 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *_
         for (int i = 0; i < 16; ++i)
           if (qbase + crow(i, h) >= dm.Lq) pv[i] = 0.0f;
       }
-      if (dm.causal) {
+      if (causal) {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          if (qbase + crow(i, h) < k0 + r) pv[i] = 0.0f;
+          if (qbase + crow(i, h) < kcol) pv[i] = 0.0f;
       }
-      if (dm.drop_thresh) {
+      if (drop) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const bool keep = drop_keep(seed, bh, qbase + crow(i, h), k0 + r, dm.drop_thresh);
+          const bool keep = drop_keep(seed, bh, qbase + crow(i, h), kcol, dm.drop_thresh);
           gv[i] = keep ? pacc[i] * dm.inv_keep : 0.0f;
           pdv[i] = keep ? pv[i] * dm.inv_keep : 0.0f;
         }
@@ -681,6 +716,82 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *_
         dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag_tr(s_q, q0r, 32, r), ds, dk1, 0, 0, 0);
       }
     }
+}
+
+template <int MINW, bool PLAIN = false>
+__global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+                                                           const __bf16 *__restrict__ V,
+                                                           const __bf16 *__restrict__ dO,
+                                                           const float *__restrict__ LSE, const float *__restrict__ DELTA,
+                                                           __bf16 *__restrict__ dK, __bf16 *__restrict__ dV, BwdDims dm) {
+  __shared__ __align__(16) unsigned char s_q[2][AT_KB * 128];  // double-buffered: see attn_fwd_kernel
+  __shared__ __align__(16) unsigned char s_g[2][AT_KB * 128];
+  __shared__ __align__(16) float s_lse[2][AT_KB];
+  __shared__ __align__(16) float s_del[2][AT_KB];
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
+  const unsigned seed = eff_seed(dm);
+  const int k0 = blockIdx.x * AT_QB + wid * AT_QW;  // first key of this wave
+  const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
+  const __bf16 *Gb = dO + b * dm.o_bs + hd * dm.o_hs;
+  const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
+  const __bf16 *Vb = V + b * dm.k_bs + hd * dm.k_hs;
+  const float *lseb = LSE + (long)bh * dm.Lq, *delb = DELTA + (long)bh * dm.Lq;
+  const float scale = dm.scale;
+  const float c = scale * 1.4426950408889634f;
+
+  bf16x8 kf[4], vf[4];
+  const int kr = min(k0 + r, dm.Lk - 1);
+  const float mkey = (!PLAIN && dm.mask) ? dm.mask[(long)b * dm.Lkp + kr] : 0.0f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    kf[s] = *reinterpret_cast<const bf16x8 *>(Kb + (long)kr * dm.k_rs + 16 * s + 8 * h);
+    vf[s] = *reinterpret_cast<const bf16x8 *>(Vb + (long)kr * dm.k_rs + 16 * s + 8 * h);
+  }
+  f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
+  const int nqt = (dm.Lq + AT_KB - 1) / AT_KB;
+  uint4 qa, qb, ga, gb;
+  float rl = 0.f, rd = 0.f;
+  auto fetch = [&](int qt) {
+    qa = stage_load(Qb, dm.q_rs, qt * AT_KB, dm.Lq, t); qb = stage_load(Qb, dm.q_rs, qt * AT_KB, dm.Lq, t + 256);
+    ga = stage_load(Gb, dm.o_rs, qt * AT_KB, dm.Lq, t); gb = stage_load(Gb, dm.o_rs, qt * AT_KB, dm.Lq, t + 256);
+    if (t < AT_KB) { rl = lseb[min(qt * AT_KB + t, dm.Lq - 1)]; rd = delb[min(qt * AT_KB + t, dm.Lq - 1)]; }
+  };
+  auto commit = [&](int buf) {
+    stage_store(s_q[buf], t, qa); stage_store(s_q[buf], t + 256, qb);
+    stage_store(s_g[buf], t, ga); stage_store(s_g[buf], t + 256, gb);
+    if (t < AT_KB) { s_lse[buf][t] = rl; s_del[buf][t] = rd; }
+  };
+  auto advance = [&](int qt) {
+    if (qt + 1 < nqt) {
+      commit((qt + 1) & 1);
+      if (qt + 2 < nqt) fetch(qt + 2);
+    }
+    __syncthreads();
+  };
+  fetch(0);
+  commit(0);
+  if (nqt > 1) fetch(1);
+  __syncthreads();
+  const bool active = k0 < dm.Lk;  // wave-uniform: a wave whose 32 keys are all past the end only helps staging
+  if (!PLAIN) {
+    for (int qt = 0; qt < nqt; ++qt) {
+      if (active)
+        dkv_tile(s_q[qt & 1], s_g[qt & 1], s_lse[qt & 1], s_del[qt & 1], kf, vf, dm, c, mkey, seed, bh, k0 + r, qt,
+                 qt == nqt - 1, r, h, dk0, dk1, dv0, dv1);
+      advance(qt);
+    }
+  } else {
+    for (int qt = 0; qt < nqt - 1; ++qt) {
+      if (active)
+        dkv_tile<true, false>(s_q[qt & 1], s_g[qt & 1], s_lse[qt & 1], s_del[qt & 1], kf, vf, dm, c, 0.0f, seed, bh,
+                              k0 + r, qt, false, r, h, dk0, dk1, dv0, dv1);
+      advance(qt);
+    }
+    const int lb = (nqt - 1) & 1;
+    if (active)
+      dkv_tile<true, true>(s_q[lb], s_g[lb], s_lse[lb], s_del[lb], kf, vf, dm, c, 0.0f, seed, bh, k0 + r, nqt - 1, true,
+                           r, h, dk0, dk1, dv0, dv1);
   }
   if (k0 + r < dm.Lk) {
     const long off = b * dm.k_bs + hd * dm.k_hs + (long)(k0 + r) * dm.k_rs;
@@ -720,10 +831,19 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_fwd(
     return check_launch("attn_fwd_narrow");
   }
   const dim3 grid((Lq + AT_QB - 1) / AT_QB, B * H);
-  static const int minw = getenv("BQ_ATTN_MINW") ? atoi(getenv("BQ_ATTN_MINW")) : 3;  // 3 waves/SIMD measured best (158 VGPRs, no spill)
-#define BQ_FWD(W) hipLaunchKernelGGL(attn_fwd_kernel<W>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Q, \
-                                     (const __bf16 *)K, (const __bf16 *)V, (__bf16 *)O, LSE, dm)
-  switch (minw) { case 1: BQ_FWD(1); break; case 2: BQ_FWD(2); break; case 4: BQ_FWD(4); break; default: BQ_FWD(3); }
+  static const int minw = getenv("BQ_ATTN_MINW") ? atoi(getenv("BQ_ATTN_MINW")) : 3;  // waves/SIMD (tools/attn_sweep.sh)
+  static const int plain_mode = getenv("BQ_ATTN_FWD_MODE") ? atoi(getenv("BQ_ATTN_FWD_MODE")) : 1;
+  const int mode = (!mask && !causal && dm.drop_thresh == 0) ? plain_mode : 0;
+#define BQ_FWD(W, M) hipLaunchKernelGGL((attn_fwd_kernel<W, M>), grid, dim3(256), 0, (hipStream_t)stream,           \
+                                        (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (__bf16 *)O, LSE, dm)
+  switch (mode * 10 + minw) {
+    case 2: BQ_FWD(2, 0); break;
+    case 12: BQ_FWD(2, 1); break;
+    case 13: BQ_FWD(3, 1); break;
+    case 22: BQ_FWD(2, 2); break;
+    case 23: BQ_FWD(3, 2); break;
+    default: BQ_FWD(3, 0);
+  }
 #undef BQ_FWD
   return check_launch("attn_fwd");
 }
@@ -747,22 +867,34 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_bwd(
   hipStream_t st = (hipStream_t)stream;
   static const int dq_w = getenv("BQ_ATTN_DQ_MINW") ? atoi(getenv("BQ_ATTN_DQ_MINW")) : 2;
   static const int dkv_w = getenv("BQ_ATTN_DKV_MINW") ? atoi(getenv("BQ_ATTN_DKV_MINW")) : 2;  // 2 waves/SIMD (tools/attn_sweep.sh)
-#define BQ_DQ(W) hipLaunchKernelGGL(attn_bwd_dq_kernel<W>, dim3((Lq + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, st, \
-                                    (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)dO, LSE,  \
-                                    (const __bf16 *)O, DELTA, (__bf16 *)dQ, dm)
+  static const bool plain_ok = !getenv("BQ_ATTN_NO_PLAIN");
+  const bool plain = plain_ok && !mask && !causal && dm.drop_thresh == 0;
+#define BQ_DQ(W, P) hipLaunchKernelGGL((attn_bwd_dq_kernel<W, P>), dim3((Lq + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, \
+                                       st, (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)dO, \
+                                       LSE, (const __bf16 *)O, DELTA, (__bf16 *)dQ, dm)
   static const bool narrow_ok = !getenv("BQ_ATTN_NO_NARROW");
   if (narrow_ok && Lq <= AT_QW && Lk > 2 * AT_KB)
     hipLaunchKernelGGL(attn_bwd_dq_narrow_kernel, dim3(1, B * H), dim3(256), 0, st, (const __bf16 *)Q, (const __bf16 *)K,
                        (const __bf16 *)V, (const __bf16 *)dO, LSE, (const __bf16 *)O, DELTA, (__bf16 *)dQ, dm);
   else
-    switch (dq_w) { case 1: BQ_DQ(1); break; case 3: BQ_DQ(3); break; default: BQ_DQ(2); }
+    switch (dq_w * 2 + (plain ? 1 : 0)) {
+      case 6: BQ_DQ(3, false); break;
+      case 7: BQ_DQ(3, true); break;
+      case 5: BQ_DQ(2, true); break;
+      default: BQ_DQ(2, false);
+    }
 #undef BQ_DQ
   int rc = check_launch("attn_bwd_dq");
   if (rc) return rc;
-#define BQ_DKV(W) hipLaunchKernelGGL(attn_bwd_dkv_kernel<W>, dim3((Lk + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, st, \
-                                     (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)dO, LSE,   \
-                                     DELTA, (__bf16 *)dK, (__bf16 *)dV, dm)
-  switch (dkv_w) { case 1: BQ_DKV(1); break; default: BQ_DKV(2); }
+#define BQ_DKV(W, P) hipLaunchKernelGGL((attn_bwd_dkv_kernel<W, P>), dim3((Lk + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, \
+                                        st, (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)dO,  \
+                                        LSE, DELTA, (__bf16 *)dK, (__bf16 *)dV, dm)
+  switch (dkv_w * 2 + (plain ? 1 : 0)) {
+    case 2: BQ_DKV(1, false); break;
+    case 3: BQ_DKV(1, true); break;
+    case 5: BQ_DKV(2, true); break;
+    default: BQ_DKV(2, false);
+  }
 #undef BQ_DKV
   return check_launch("attn_bwd_dkv");
 }

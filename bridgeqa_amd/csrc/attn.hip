@@ -90,6 +90,15 @@ __device__ __forceinline__ uint4 stage_load(const __bf16 *base, long row_stride,
   const int gr = min(row0 + row, nrows_valid - 1);  // clamp: rows past the end repeat the last one (masked later)
   return *reinterpret_cast<const uint4 *>(base + (long)gr * row_stride + ch * 8);
 }
+// The same load as a wave-uniform tile base (scalar registers) plus a per-thread 32-bit byte offset that is computed
+// ONCE per kernel (the clamped variant once more for the last tile): no 64-bit address arithmetic per tile (the
+// clamped re-computation cost ~6 quarter-rate integer multiplies per tile on a VALU-bound kernel, §4.3 of DESIGN.md).
+__device__ __forceinline__ unsigned stage_off(long row_stride, int row_in_tile, int c) {
+  return (unsigned)((row_in_tile * (int)row_stride + (c & 7) * 8) * 2);
+}
+__device__ __forceinline__ uint4 stage_ld(const __bf16 *tile_base, unsigned byte_off) {
+  return *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(tile_base) + byte_off);
+}
 __device__ __forceinline__ void stage_store(unsigned char *lds, int c, uint4 v) {
   *reinterpret_cast<uint4 *>(lds + swz(c >> 3, c & 7)) = v;
 }
@@ -246,9 +255,17 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__res
   float m = -INFINITY, lsum = 0.0f;
   const int nkt = (dm.Lk + AT_KB - 1) / AT_KB;
   uint4 ka, kb, va, vb;
+  const unsigned off_a = stage_off(dm.k_rs, t >> 3, t), off_b = stage_off(dm.k_rs, 32 + (t >> 3), t);
   auto fetch = [&](int kt) {  // rows past the end repeat the last one (masked by the last tile)
-    ka = stage_load(Kb, dm.k_rs, kt * AT_KB, dm.Lk, t); kb = stage_load(Kb, dm.k_rs, kt * AT_KB, dm.Lk, t + 256);
-    va = stage_load(Vb, dm.k_rs, kt * AT_KB, dm.Lk, t); vb = stage_load(Vb, dm.k_rs, kt * AT_KB, dm.Lk, t + 256);
+    const __bf16 *kbase = Kb + (long)kt * AT_KB * dm.k_rs, *vbase = Vb + (long)kt * AT_KB * dm.k_rs;
+    unsigned oa = off_a, ob = off_b;
+    if (kt == nkt - 1) {  // wave-uniform, once per kernel
+      const int lim = dm.Lk - 1 - kt * AT_KB;
+      oa = stage_off(dm.k_rs, min(t >> 3, lim), t);
+      ob = stage_off(dm.k_rs, min(32 + (t >> 3), lim), t);
+    }
+    ka = stage_ld(kbase, oa); kb = stage_ld(kbase, ob);
+    va = stage_ld(vbase, oa); vb = stage_ld(vbase, ob);
   };
   auto commit = [&](int buf) {
     stage_store(s_k[buf], t, ka); stage_store(s_k[buf], t + 256, kb);
@@ -531,9 +548,17 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const __bf16 *__
   f32x16 a0 = {0}, a1 = {0};
   const int nkt = (dm.Lk + AT_KB - 1) / AT_KB;
   uint4 ka, kb, va, vb;
+  const unsigned off_a = stage_off(dm.k_rs, t >> 3, t), off_b = stage_off(dm.k_rs, 32 + (t >> 3), t);
   auto fetch = [&](int kt) {
-    ka = stage_load(Kb, dm.k_rs, kt * AT_KB, dm.Lk, t); kb = stage_load(Kb, dm.k_rs, kt * AT_KB, dm.Lk, t + 256);
-    va = stage_load(Vb, dm.k_rs, kt * AT_KB, dm.Lk, t); vb = stage_load(Vb, dm.k_rs, kt * AT_KB, dm.Lk, t + 256);
+    const __bf16 *kbase = Kb + (long)kt * AT_KB * dm.k_rs, *vbase = Vb + (long)kt * AT_KB * dm.k_rs;
+    unsigned oa = off_a, ob = off_b;
+    if (kt == nkt - 1) {  // wave-uniform, once per kernel
+      const int lim = dm.Lk - 1 - kt * AT_KB;
+      oa = stage_off(dm.k_rs, min(t >> 3, lim), t);
+      ob = stage_off(dm.k_rs, min(32 + (t >> 3), lim), t);
+    }
+    ka = stage_ld(kbase, oa); kb = stage_ld(kbase, ob);
+    va = stage_ld(vbase, oa); vb = stage_ld(vbase, ob);
   };
   auto commit = [&](int buf) {
     stage_store(s_k[buf], t, ka); stage_store(s_k[buf], t + 256, kb);
@@ -752,9 +777,18 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *_
   const int nqt = (dm.Lq + AT_KB - 1) / AT_KB;
   uint4 qa, qb, ga, gb;
   float rl = 0.f, rd = 0.f;
+  const unsigned offq_a = stage_off(dm.q_rs, t >> 3, t), offq_b = stage_off(dm.q_rs, 32 + (t >> 3), t);
+  const unsigned offg_a = stage_off(dm.o_rs, t >> 3, t), offg_b = stage_off(dm.o_rs, 32 + (t >> 3), t);
   auto fetch = [&](int qt) {
-    qa = stage_load(Qb, dm.q_rs, qt * AT_KB, dm.Lq, t); qb = stage_load(Qb, dm.q_rs, qt * AT_KB, dm.Lq, t + 256);
-    ga = stage_load(Gb, dm.o_rs, qt * AT_KB, dm.Lq, t); gb = stage_load(Gb, dm.o_rs, qt * AT_KB, dm.Lq, t + 256);
+    const __bf16 *qbase = Qb + (long)qt * AT_KB * dm.q_rs, *gbase = Gb + (long)qt * AT_KB * dm.o_rs;
+    unsigned qoa = offq_a, qob = offq_b, goa = offg_a, gob = offg_b;
+    if (qt == nqt - 1) {  // wave-uniform, once per kernel: rows past the end repeat the last one
+      const int lim = dm.Lq - 1 - qt * AT_KB, ra = min(t >> 3, lim), rb = min(32 + (t >> 3), lim);
+      qoa = stage_off(dm.q_rs, ra, t); qob = stage_off(dm.q_rs, rb, t);
+      goa = stage_off(dm.o_rs, ra, t); gob = stage_off(dm.o_rs, rb, t);
+    }
+    qa = stage_ld(qbase, qoa); qb = stage_ld(qbase, qob);
+    ga = stage_ld(gbase, goa); gb = stage_ld(gbase, gob);
     if (t < AT_KB) { rl = lseb[min(qt * AT_KB + t, dm.Lq - 1)]; rd = delb[min(qt * AT_KB + t, dm.Lq - 1)]; }
   };
   auto commit = [&](int buf) {
@@ -822,6 +856,7 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_fwd(
   BQ_REQUIRE((q_rs % 8) == 0 && (k_rs % 8) == 0 && (o_rs % 4) == 0 && (q_hs % 8) == 0 && (k_hs % 8) == 0, BQ_EINVAL,
              "attn_fwd: rows must be 16-byte aligned");
   BQ_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, BQ_EINVAL, "attn_fwd: bad dropout probability");
+  BQ_REQUIRE(q_rs > 0 && k_rs > 0 && q_rs < (1 << 23) && k_rs < (1 << 23), BQ_EINVAL, "attn_fwd: row stride out of range");
   AttnDims dm{B, H, Lq, Lk, 0, Lkp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, o_bs, o_rs, o_hs, mask, scale,
               1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr, causal ? 1 : 0};
   static const bool narrow_ok = !getenv("BQ_ATTN_NO_NARROW");
@@ -862,6 +897,8 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_bwd(
   BQ_REQUIRE((q_rs % 8) == 0 && (k_rs % 8) == 0 && (g_rs % 8) == 0 && (q_hs % 8) == 0 && (k_hs % 8) == 0 &&
                  (g_hs % 8) == 0, BQ_EINVAL, "attn_bwd: rows must be 16-byte aligned");
   BQ_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, BQ_EINVAL, "attn_bwd: bad dropout probability");
+  BQ_REQUIRE(q_rs > 0 && k_rs > 0 && g_rs > 0 && q_rs < (1 << 23) && k_rs < (1 << 23) && g_rs < (1 << 23), BQ_EINVAL,
+             "attn_bwd: row stride out of range");
   BwdDims dm{B, H, Lq, Lk, 0, Lkp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, g_bs, g_rs, g_hs, mask, scale,
              1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr, causal ? 1 : 0};
   hipStream_t st = (hipStream_t)stream;

@@ -387,6 +387,69 @@ def attn_bwd(q, k, v, out, lse, grad_out, scale, dq, dk, dv, mask_log2=None, p_d
                                 int(seed) & 0xFFFFFFFF, _p(seed_tensor), int(bool(causal)), _stream()), "attn_bwd")
 
 
+_lib.bq_attn_fwd2.argtypes = [_vp] * 8 + [_i] * 6 + [_l] * 12 + [_f, _f, _u, _vp, _vp]
+_lib.bq_attn_fwd2.restype = ctypes.c_int
+_lib.bq_attn_bwd2.argtypes = [_vp] * 15 + [_i] * 6 + [_l] * 12 + [_f, _f, _u, _vp, _vp]
+_lib.bq_attn_bwd2.restype = ctypes.c_int
+
+
+def key_mask_log2_two(mask, B, Lk1, Lk2):
+    """additive key mask broadcastable to (B,1,1,Lk1+Lk2) over cat(segment 1, segment 2) -> f32 (B, pad64(Lk1) +
+    pad64(Lk2)) in the two-segment layout of bq_attn_fwd2 (each segment padded to a multiple of 64), times log2(e)"""
+    if mask is None:
+        return None
+    p1 = _pad64(Lk1)
+    m = torch.zeros(B, p1 + _pad64(Lk2), dtype=torch.float32, device=mask.device)
+    src = mask.reshape(-1, Lk1 + Lk2).expand(B, Lk1 + Lk2).float() * LOG2E
+    m[:, :Lk1] = src[:, :Lk1]
+    m[:, p1:p1 + Lk2] = src[:, Lk1:]
+    return m
+
+
+def attn_fwd2(q, k1, v1, k2, v2, scale, mask_log2=None, p_drop=0.0, seed=0, seed_tensor=None):
+    """attn_fwd over the keys cat(k1, k2) / values cat(v1, v2) without forming them (Lq <= 32).  k1 / v1 (B, Lk1, H, 64)
+    views with equal strides, k2 / v2 (B, Lk2, H, 64) likewise; mask_log2 from key_mask_log2_two."""
+    for t, n in ((q, "q"), (k1, "k1"), (v1, "v1"), (k2, "k2"), (v2, "v2")):
+        if not t.is_cuda:
+            raise RuntimeError("%s: CPU not supported" % n)
+    if k1.stride() != v1.stride() or k2.stride() != v2.stride():
+        raise RuntimeError("attn_fwd2: k and v of a segment must have equal strides")
+    B, Lq, H, D = q.shape
+    Lk1, Lk2 = k1.shape[1], k2.shape[1]
+    Lkp = _pad64(Lk1) + _pad64(Lk2)
+    with torch.cuda.device(q.device):
+        out = torch.empty(B, Lq, H, D, dtype=torch.bfloat16, device=q.device)
+        lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
+        _check(_lib.bq_attn_fwd2(_p(q), _p(k1), _p(v1), _p(k2), _p(v2), _p(out), _p(lse), _p(mask_log2), B, H, Lq, Lk1,
+                                 Lk2, Lkp, *_bhd_strides(q), *_bhd_strides(k1), *_bhd_strides(k2), *_bhd_strides(out),
+                                 float(scale), float(p_drop), int(seed) & 0xFFFFFFFF, _p(seed_tensor), _stream()),
+               "attn_fwd2")
+    return out, lse
+
+
+def attn_bwd2(q, k1, v1, k2, v2, out, lse, grad_out, scale, dq, dk1, dv1, dk2, dv2, mask_log2=None, p_drop=0.0, seed=0,
+              seed_tensor=None):
+    """Backward of attn_fwd2.  dq strided like q, dk1 / dv1 like k1, dk2 / dv2 like k2 (preallocated bf16 views)."""
+    B, Lq, H, D = q.shape
+    Lk1, Lk2 = k1.shape[1], k2.shape[1]
+    Lkp = _pad64(Lk1) + _pad64(Lk2)
+    if (k1.stride() != v1.stride() or k2.stride() != v2.stride() or dq.stride() != q.stride() or
+            dk1.stride() != k1.stride() or dv1.stride() != k1.stride() or dk2.stride() != k2.stride() or
+            dv2.stride() != k2.stride()):
+        raise RuntimeError("attn_bwd2: stride contract violated")
+    with torch.cuda.device(q.device):
+        if grad_out.stride(3) != 1 or grad_out.stride(1) % 8 or grad_out.stride(2) % 8:
+            grad_out = grad_out.contiguous()
+        if not out.is_contiguous():
+            raise RuntimeError("attn_bwd2: the forward output must be contiguous")
+        delta = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
+        _check(_lib.bq_attn_bwd2(_p(q), _p(k1), _p(v1), _p(k2), _p(v2), _p(grad_out), _p(lse), _p(out), _p(delta),
+                                 _p(mask_log2), _p(dq), _p(dk1), _p(dv1), _p(dk2), _p(dv2), B, H, Lq, Lk1, Lk2, Lkp,
+                                 *_bhd_strides(q), *_bhd_strides(k1), *_bhd_strides(k2), *_bhd_strides(grad_out),
+                                 float(scale), float(p_drop), int(seed) & 0xFFFFFFFF, _p(seed_tensor), _stream()),
+               "attn_bwd2")
+
+
 _lib.bq_colsum_chunks.argtypes = [_i]
 _lib.bq_colsum_chunks.restype = ctypes.c_int
 _lib.bq_colsum_bf16.argtypes = [_vp, _vp, _i, _i, _vp, _vp, _vp]

@@ -60,7 +60,32 @@ struct AttnDims {
   const unsigned *seed_ptr;         // ... combined with a per-step device counter (graph-replay safe), may be null
   int causal;                       // 1: key j is visible to query i only when j <= i (decoder self-attention,
                                     // reference med.py:640-672 causal_mask), on top of the key mask
+  // Optional SECOND key/value segment: the keys are cat(segment 1 (Lk rows of K / V), segment 2 (Lk2 rows of K2 / V2))
+  // as in the twin cross-attention over cat(image tokens, other stream's text states) (reference med.py:549-562) --
+  // without the concatenated tensor ever existing.  Tiles never straddle segments: the 64-key tile list is the
+  // nkt1 = ceil(Lk / 64) tiles of segment 1 followed by ceil(Lk2 / 64) tiles of segment 2, and the "padded key
+  // index" 64 * tile + i addresses the mask row (each segment padded to a multiple of 64 there) and the dropout hash.
+  int Lk2, nkt1;
+  long k2_bs, k2_rs, k2_hs;
+  const __bf16 *K2, *V2;
+  __bf16 *dK2, *dV2;
 };
+
+// tile kt of the two-segment key list: operand bases of this (batch, head), row stride, first row and row count of
+// its segment, whether it is that segment's last tile, and the padded key index one past the segment's last key
+struct KeyTile {
+  const __bf16 *k, *v;
+  long rs;
+  int row0, nrows;
+  bool last;
+  int kend;
+};
+__device__ __forceinline__ KeyTile key_tile(const AttnDims &dm, const __bf16 *Kb, const __bf16 *Vb, const __bf16 *K2b,
+                                            const __bf16 *V2b, int kt) {
+  if (kt < dm.nkt1) return KeyTile{Kb, Vb, dm.k_rs, kt * 64, dm.Lk, kt == dm.nkt1 - 1, dm.Lk};
+  const int t2 = kt - dm.nkt1;
+  return KeyTile{K2b, V2b, dm.k2_rs, t2 * 64, dm.Lk2, t2 == (dm.Lk2 + 63) / 64 - 1, dm.nkt1 * 64 + dm.Lk2};
+}
 
 __device__ __forceinline__ unsigned eff_seed(const AttnDims &dm) {
   return dm.seed_ptr ? dm.seed_ptr[0] * 2654435761u + dm.seed : dm.seed;
@@ -142,7 +167,8 @@ template <bool PLAIN = false, bool LASTP = false, bool EARLY = false>
 __device__ __forceinline__ void fwd_tile(const unsigned char *s_k, const unsigned char *s_v, const bf16x8 (&qf)[4],
                                          const AttnDims &dm, const float *mrow_, float scale_log2e, unsigned seed, int bh,
                                          int qrow, int kt, bool last_, int r, int h, f32x16 &o0, f32x16 &o1, float &m,
-                                         float &lsum) {
+                                         float &lsum, int kend = -1) {
+    if (kend < 0) kend = dm.Lk;  // padded key index one past the last valid key of this tile's segment
     const float *mrow = PLAIN ? nullptr : mrow_;
     const bool last = PLAIN ? LASTP : last_;
     const bool causal = !PLAIN && dm.causal;
@@ -173,7 +199,7 @@ __device__ __forceinline__ void fwd_tile(const unsigned char *s_k, const unsigne
       if (last) {  // wave-uniform: only the last tile has keys past the end
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          if (kbase + crow(i, h) >= dm.Lk) sc[i] = -INFINITY;
+          if (kbase + crow(i, h) >= kend) sc[i] = -INFINITY;
       }
       if (causal) {
 #pragma unroll
@@ -346,15 +372,18 @@ __global__ __launch_bounds__(256) void attn_fwd_narrow_kernel(const __bf16 *__re
   }
   f32x16 o0 = {0}, o1 = {0};
   float m = -INFINITY, lsum = 0.0f;
-  const int nkt = (dm.Lk + AT_KB - 1) / AT_KB;
+  const __bf16 *K2b = dm.K2 ? dm.K2 + b * dm.k2_bs + hd * dm.k2_hs : nullptr;  // second key/value segment (AttnDims)
+  const __bf16 *V2b = dm.V2 ? dm.V2 + b * dm.k2_bs + hd * dm.k2_hs : nullptr;
+  const int nkt = dm.nkt1 + (dm.Lk2 + AT_KB - 1) / AT_KB;
   for (int kt0 = 0; kt0 < nkt; kt0 += AT_NW) {
     const int kt = kt0 + wid;
+    KeyTile kt_ = key_tile(dm, Kb, Vb, K2b, V2b, min(kt, nkt - 1));
     if (kt < nkt) {  // this wave stages its own tile: 512 chunks of 16 B per image, 8 per lane
       uint4 kr[8], vr[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        kr[j] = stage_load(Kb, dm.k_rs, kt * AT_KB, dm.Lk, lane + 64 * j);
-        vr[j] = stage_load(Vb, dm.k_rs, kt * AT_KB, dm.Lk, lane + 64 * j);
+        kr[j] = stage_load(kt_.k, kt_.rs, kt_.row0, kt_.nrows, lane + 64 * j);
+        vr[j] = stage_load(kt_.v, kt_.rs, kt_.row0, kt_.nrows, lane + 64 * j);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -364,7 +393,7 @@ __global__ __launch_bounds__(256) void attn_fwd_narrow_kernel(const __bf16 *__re
     }
     __syncthreads();
     if (kt < nkt)
-      fwd_tile(s_k[wid], s_v[wid], qf, dm, mrow, scale_log2e, seed, bh, r, kt, kt == nkt - 1, r, h, o0, o1, m, lsum);
+      fwd_tile(s_k[wid], s_v[wid], qf, dm, mrow, scale_log2e, seed, bh, r, kt, kt_.last, r, h, o0, o1, m, lsum, kt_.kend);
     __syncthreads();
   }
   const float lw = xhalf_sum(lsum);
@@ -443,7 +472,9 @@ typedef AttnDims BwdDims;  // o_* strides describe dO
 template <bool PLAIN = false, bool LASTP = false>
 __device__ __forceinline__ void dq_tile(const unsigned char *s_k, const unsigned char *s_v, const bf16x8 (&qf)[4], const bf16x8 (&gf)[4], const BwdDims &dm,
                                         const float *mrow_, float c, float scale, float lse, float delta, unsigned seed,
-                                        int bh, int qrow, int kt, bool last_, int r, int h, f32x16 &a0, f32x16 &a1) {
+                                        int bh, int qrow, int kt, bool last_, int r, int h, f32x16 &a0, f32x16 &a1,
+                                        int kend = -1) {
+    if (kend < 0) kend = dm.Lk;
     const float *mrow = PLAIN ? nullptr : mrow_;  // PLAIN / LASTP: see fwd_tile
     const bool last = PLAIN ? LASTP : last_;
     const bool causal = !PLAIN && dm.causal;
@@ -473,7 +504,7 @@ __device__ __forceinline__ void dq_tile(const unsigned char *s_k, const unsigned
       if (last) {  // wave-uniform special cases stay out of the common path
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          if (kbase + crow(i, h) >= dm.Lk) pv[i] = 0.0f;
+          if (kbase + crow(i, h) >= kend) pv[i] = 0.0f;
       }
       if (causal) {
 #pragma unroll
@@ -635,15 +666,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_narrow_kernel(const __bf16 *_
     if (wid == 0 && h == 0 && r < dm.Lq) DELTA[(long)bh * dm.Lq + r] = delta;
   }
   f32x16 a0 = {0}, a1 = {0};
-  const int nkt = (dm.Lk + AT_KB - 1) / AT_KB;
+  const __bf16 *K2b = dm.K2 ? dm.K2 + b * dm.k2_bs + hd * dm.k2_hs : nullptr;  // second key/value segment (AttnDims)
+  const __bf16 *V2b = dm.V2 ? dm.V2 + b * dm.k2_bs + hd * dm.k2_hs : nullptr;
+  const int nkt = dm.nkt1 + (dm.Lk2 + AT_KB - 1) / AT_KB;
   for (int kt0 = 0; kt0 < nkt; kt0 += AT_NW) {
     const int kt = kt0 + wid;
+    KeyTile kt_ = key_tile(dm, Kb, Vb, K2b, V2b, min(kt, nkt - 1));
     if (kt < nkt) {
       uint4 kr[8], vr[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        kr[j] = stage_load(Kb, dm.k_rs, kt * AT_KB, dm.Lk, lane + 64 * j);
-        vr[j] = stage_load(Vb, dm.k_rs, kt * AT_KB, dm.Lk, lane + 64 * j);
+        kr[j] = stage_load(kt_.k, kt_.rs, kt_.row0, kt_.nrows, lane + 64 * j);
+        vr[j] = stage_load(kt_.v, kt_.rs, kt_.row0, kt_.nrows, lane + 64 * j);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -653,8 +687,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_narrow_kernel(const __bf16 *_
     }
     __syncthreads();
     if (kt < nkt)
-      dq_tile(s_k[wid], s_v[wid], qf, gf, dm, mrow, c, scale, lse, delta, seed, bh, r, kt, kt == nkt - 1, r, h,
-              a0, a1);
+      dq_tile(s_k[wid], s_v[wid], qf, gf, dm, mrow, c, scale, lse, delta, seed, bh, r, kt, kt_.last, r, h, a0, a1,
+              kt_.kend);
     __syncthreads();
   }
 #pragma unroll
@@ -756,22 +790,29 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *_
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
   const unsigned seed = eff_seed(dm);
-  const int k0 = blockIdx.x * AT_QB + wid * AT_QW;  // first key of this wave
+  // key blocks of segment 1 first, then those of the optional second segment (AttnDims): a block never straddles
+  const int nb1 = (dm.Lk + AT_QB - 1) / AT_QB;
+  const bool seg2 = !PLAIN && (int)blockIdx.x >= nb1;   // wave-uniform (PLAIN is never used with two segments)
+  const int k0 = (seg2 ? (int)blockIdx.x - nb1 : (int)blockIdx.x) * AT_QB + wid * AT_QW;  // first key of this wave, in its segment
+  const int Lks = seg2 ? dm.Lk2 : dm.Lk;               // keys in this block's segment
+  const int kpad0 = seg2 ? dm.nkt1 * 64 : 0;           // padded key index (mask row, dropout hash) of the segment's key 0
+  const long ks_rs = seg2 ? dm.k2_rs : dm.k_rs;
+  const long ks_off = seg2 ? b * dm.k2_bs + hd * dm.k2_hs : b * dm.k_bs + hd * dm.k_hs;
   const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
   const __bf16 *Gb = dO + b * dm.o_bs + hd * dm.o_hs;
-  const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
-  const __bf16 *Vb = V + b * dm.k_bs + hd * dm.k_hs;
+  const __bf16 *Kb = (seg2 ? dm.K2 : K) + ks_off;
+  const __bf16 *Vb = (seg2 ? dm.V2 : V) + ks_off;
   const float *lseb = LSE + (long)bh * dm.Lq, *delb = DELTA + (long)bh * dm.Lq;
   const float scale = dm.scale;
   const float c = scale * 1.4426950408889634f;
 
   bf16x8 kf[4], vf[4];
-  const int kr = min(k0 + r, dm.Lk - 1);
-  const float mkey = (!PLAIN && dm.mask) ? dm.mask[(long)b * dm.Lkp + kr] : 0.0f;
+  const int kr = min(k0 + r, Lks - 1);
+  const float mkey = (!PLAIN && dm.mask) ? dm.mask[(long)b * dm.Lkp + kpad0 + kr] : 0.0f;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    kf[s] = *reinterpret_cast<const bf16x8 *>(Kb + (long)kr * dm.k_rs + 16 * s + 8 * h);
-    vf[s] = *reinterpret_cast<const bf16x8 *>(Vb + (long)kr * dm.k_rs + 16 * s + 8 * h);
+    kf[s] = *reinterpret_cast<const bf16x8 *>(Kb + (long)kr * ks_rs + 16 * s + 8 * h);
+    vf[s] = *reinterpret_cast<const bf16x8 *>(Vb + (long)kr * ks_rs + 16 * s + 8 * h);
   }
   f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
   const int nqt = (dm.Lq + AT_KB - 1) / AT_KB;
@@ -807,11 +848,11 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *_
   commit(0);
   if (nqt > 1) fetch(1);
   __syncthreads();
-  const bool active = k0 < dm.Lk;  // wave-uniform: a wave whose 32 keys are all past the end only helps staging
+  const bool active = k0 < Lks;  // wave-uniform: a wave whose 32 keys are all past the end only helps staging
   if (!PLAIN) {
     for (int qt = 0; qt < nqt; ++qt) {
       if (active)
-        dkv_tile(s_q[qt & 1], s_g[qt & 1], s_lse[qt & 1], s_del[qt & 1], kf, vf, dm, c, mkey, seed, bh, k0 + r, qt,
+        dkv_tile(s_q[qt & 1], s_g[qt & 1], s_lse[qt & 1], s_del[qt & 1], kf, vf, dm, c, mkey, seed, bh, kpad0 + k0 + r, qt,
                  qt == nqt - 1, r, h, dk0, dk1, dv0, dv1);
       advance(qt);
     }
@@ -827,10 +868,10 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *_
       dkv_tile<true, true>(s_q[lb], s_g[lb], s_lse[lb], s_del[lb], kf, vf, dm, c, 0.0f, seed, bh, k0 + r, nqt - 1, true,
                            r, h, dk0, dk1, dv0, dv1);
   }
-  if (k0 + r < dm.Lk) {
-    const long off = b * dm.k_bs + hd * dm.k_hs + (long)(k0 + r) * dm.k_rs;
-    store_T(dK + off, dk0, dk1, h, scale);
-    store_T(dV + off, dv0, dv1, h, 1.0f);
+  if (k0 + r < Lks) {
+    const long off = ks_off + (long)(k0 + r) * ks_rs;
+    store_T((seg2 ? dm.dK2 : dK) + off, dk0, dk1, h, scale);
+    store_T((seg2 ? dm.dV2 : dV) + off, dv0, dv1, h, 1.0f);
   }
 }
 
@@ -859,6 +900,7 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_fwd(
   BQ_REQUIRE(q_rs > 0 && k_rs > 0 && q_rs < (1 << 23) && k_rs < (1 << 23), BQ_EINVAL, "attn_fwd: row stride out of range");
   AttnDims dm{B, H, Lq, Lk, 0, Lkp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, o_bs, o_rs, o_hs, mask, scale,
               1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr, causal ? 1 : 0};
+  dm.nkt1 = (Lk + AT_KB - 1) / AT_KB;  // single key/value segment
   static const bool narrow_ok = !getenv("BQ_ATTN_NO_NARROW");
   if (narrow_ok && Lq <= AT_QW && Lk > 2 * AT_KB && (o_rs % 8) == 0 && (o_hs % 8) == 0) {
     hipLaunchKernelGGL(attn_fwd_narrow_kernel, dim3(1, B * H), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Q,
@@ -901,6 +943,7 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_bwd(
              "attn_bwd: row stride out of range");
   BwdDims dm{B, H, Lq, Lk, 0, Lkp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, g_bs, g_rs, g_hs, mask, scale,
              1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr, causal ? 1 : 0};
+  dm.nkt1 = (Lk + AT_KB - 1) / AT_KB;  // single key/value segment
   hipStream_t st = (hipStream_t)stream;
   static const int dq_w = getenv("BQ_ATTN_DQ_MINW") ? atoi(getenv("BQ_ATTN_DQ_MINW")) : 2;
   static const int dkv_w = getenv("BQ_ATTN_DKV_MINW") ? atoi(getenv("BQ_ATTN_DKV_MINW")) : 2;  // 2 waves/SIMD (tools/attn_sweep.sh)
@@ -934,4 +977,73 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_bwd(
   }
 #undef BQ_DKV
   return check_launch("attn_bwd_dkv");
+}
+
+
+// ---- two key/value segments --------------------------------------------------------------------------------
+// Attention of Lq <= 32 queries over cat(segment 1, segment 2) along the key axis WITHOUT the concatenated
+// tensor: the twin cross-attention of the reference (med.py:549-562) attends to cat(image tokens, other stream's
+// text states); with two segments the image-token K/V of all layers can come from one hoisted projection and the
+// per-layer 25 MB concatenation (and the strided slicing of its gradient) disappears.
+// K / V: segment 1, (B, Lk, H, 64) by strides k_*; K2 / V2: segment 2, (B, Lk2, H, 64) by strides k2_*.
+// mask: optional f32 [B][Lkp], Lkp = 64 * (ceil(Lk / 64) + ceil(Lk2 / 64)): segment 1's keys at [0, Lk), segment
+// 2's at [64 * ceil(Lk / 64), ... + Lk2), already multiplied by log2(e), 0 in the padding.  Everything else as
+// bq_attn_fwd (the kernels are the narrow-query ones: the four waves split the 64-key tiles of both segments).
+extern "C" __attribute__((visibility("default"))) int bq_attn_fwd2(
+    const void *Q, const void *K, const void *V, const void *K2, const void *V2, void *O, float *LSE, const float *mask,
+    int B, int H, int Lq, int Lk, int Lk2, int Lkp, long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs,
+    long k2_bs, long k2_rs, long k2_hs, long o_bs, long o_rs, long o_hs, float scale, float p_drop, unsigned seed,
+    const unsigned *seed_ptr, void *stream) {
+  BQ_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lq <= AT_QW && Lk > 0 && Lk2 > 0, BQ_EINVAL,
+             "attn_fwd2: bad extents (needs 1 <= Lq <= 32 and two non-empty segments)");
+  const int nkt1 = (Lk + AT_KB - 1) / AT_KB, nkt2 = (Lk2 + AT_KB - 1) / AT_KB;
+  BQ_REQUIRE(Lkp == 64 * (nkt1 + nkt2), BQ_EINVAL, "attn_fwd2: mask row length must be 64 * (tiles of both segments)");
+  BQ_REQUIRE(Q && K && V && K2 && V2 && O && LSE, BQ_EINVAL, "attn_fwd2: null pointer");
+  BQ_REQUIRE((q_rs % 8) == 0 && (k_rs % 8) == 0 && (k2_rs % 8) == 0 && (o_rs % 8) == 0 && (q_hs % 8) == 0 &&
+                 (k_hs % 8) == 0 && (k2_hs % 8) == 0 && (o_hs % 8) == 0, BQ_EINVAL,
+             "attn_fwd2: rows must be 16-byte aligned");
+  BQ_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, BQ_EINVAL, "attn_fwd2: bad dropout probability");
+  AttnDims dm{B, H, Lq, Lk, 0, Lkp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, o_bs, o_rs, o_hs, mask, scale,
+              1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr, 0};
+  dm.Lk2 = Lk2; dm.nkt1 = nkt1;
+  dm.k2_bs = k2_bs; dm.k2_rs = k2_rs; dm.k2_hs = k2_hs;
+  dm.K2 = (const __bf16 *)K2; dm.V2 = (const __bf16 *)V2;
+  hipLaunchKernelGGL(attn_fwd_narrow_kernel, dim3(1, B * H), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Q,
+                     (const __bf16 *)K, (const __bf16 *)V, (__bf16 *)O, LSE, dm);
+  return check_launch("attn_fwd2");
+}
+
+// Backward of bq_attn_fwd2: dQ like Q; dK / dV strided like K (segment 1), dK2 / dV2 like K2 (segment 2).
+extern "C" __attribute__((visibility("default"))) int bq_attn_bwd2(
+    const void *Q, const void *K, const void *V, const void *K2, const void *V2, const void *dO, const float *LSE,
+    const void *O, float *DELTA, const float *mask, void *dQ, void *dK, void *dV, void *dK2, void *dV2, int B, int H,
+    int Lq, int Lk, int Lk2, int Lkp, long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long k2_bs,
+    long k2_rs, long k2_hs, long g_bs, long g_rs, long g_hs, float scale, float p_drop, unsigned seed,
+    const unsigned *seed_ptr, void *stream) {
+  BQ_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lq <= AT_QW && Lk > 0 && Lk2 > 0, BQ_EINVAL,
+             "attn_bwd2: bad extents (needs 1 <= Lq <= 32 and two non-empty segments)");
+  const int nkt1 = (Lk + AT_KB - 1) / AT_KB, nkt2 = (Lk2 + AT_KB - 1) / AT_KB;
+  BQ_REQUIRE(Lkp == 64 * (nkt1 + nkt2), BQ_EINVAL, "attn_bwd2: mask row length must be 64 * (tiles of both segments)");
+  BQ_REQUIRE(Q && K && V && K2 && V2 && dO && LSE && O && DELTA && dQ && dK && dV && dK2 && dV2, BQ_EINVAL,
+             "attn_bwd2: null pointer");
+  BQ_REQUIRE((q_rs % 8) == 0 && (k_rs % 8) == 0 && (k2_rs % 8) == 0 && (g_rs % 8) == 0 && (q_hs % 8) == 0 &&
+                 (k_hs % 8) == 0 && (k2_hs % 8) == 0 && (g_hs % 8) == 0, BQ_EINVAL,
+             "attn_bwd2: rows must be 16-byte aligned");
+  BQ_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, BQ_EINVAL, "attn_bwd2: bad dropout probability");
+  BQ_REQUIRE(q_rs < (1 << 23) && g_rs < (1 << 23), BQ_EINVAL, "attn_bwd2: row stride out of range");
+  BwdDims dm{B, H, Lq, Lk, 0, Lkp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, g_bs, g_rs, g_hs, mask, scale,
+             1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr, 0};
+  dm.Lk2 = Lk2; dm.nkt1 = nkt1;
+  dm.k2_bs = k2_bs; dm.k2_rs = k2_rs; dm.k2_hs = k2_hs;
+  dm.K2 = (const __bf16 *)K2; dm.V2 = (const __bf16 *)V2;
+  dm.dK2 = (__bf16 *)dK2; dm.dV2 = (__bf16 *)dV2;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_bwd_dq_narrow_kernel, dim3(1, B * H), dim3(256), 0, st, (const __bf16 *)Q, (const __bf16 *)K,
+                     (const __bf16 *)V, (const __bf16 *)dO, LSE, (const __bf16 *)O, DELTA, (__bf16 *)dQ, dm);
+  int rc = check_launch("attn_bwd2_dq");
+  if (rc) return rc;
+  const int nb = (Lk + AT_QB - 1) / AT_QB + (Lk2 + AT_QB - 1) / AT_QB;
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, false>), dim3(nb, B * H), dim3(256), 0, st, (const __bf16 *)Q,
+                     (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)dO, LSE, DELTA, (__bf16 *)dK, (__bf16 *)dV, dm);
+  return check_launch("attn_bwd2_dkv");
 }

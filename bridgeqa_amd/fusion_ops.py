@@ -242,7 +242,7 @@ def _dw_db(g2, x2, need_dw, need_db):
     if need_dw:
         dw = _dw_f32(g2, x2)
     if need_db:
-        if g2.dtype == torch.bfloat16 and g2.shape[1] % 4 == 0 and g2.is_contiguous():
+        if g2.is_cuda and g2.dtype == torch.bfloat16 and g2.shape[1] % 4 == 0 and g2.is_contiguous():
             from . import _ext
             db = _ext.colsum(g2)
         else:
@@ -688,6 +688,188 @@ class _QKVAttention(torch.autograd.Function):
         _ext.attn_bwd(qc, kv[:, :, 0], kv[:, :, 1], out, lse, grad_out, scale, dq, dkv[:, :, 0], dkv[:, :, 1],
                       mask_log2 if has_mask else None, p_drop, seed, st if has_st else None)
         return dq, dkv, None, None, None
+
+
+# ---- two-segment cross-attention over a hoisted K/V projection ----------------------------------------------
+# The twin encoder's layer i cross-attends to cat(image tokens, other stream's states of layer i-1) (reference
+# med.py:549-562).  The image tokens are the same in all layers, so their K/V projections for ALL layers are one GEMM
+# (HoistedKV), the attention kernels take the keys / values as two segments (bq_attn_fwd2: no concatenated tensor, no
+# strided slicing of its gradient), each layer's dK/dV for the image segment is written straight into its column block
+# of ONE gradient buffer, and the projection's backward is one dX GEMM (K = 2 * 768 * layers) + one dW GEMM.
+
+class HoistedKV(object):
+    """K/V projections of `x` (B, L1, 768) for the cross-attention of several layers at once.
+    kv(i): (B, L1, 2, H, 64) strided view for layer slot i; tail_kv(i, t): the same layer's projection of the
+    per-layer second segment t (B, L2, 768), through the same weights (their gradients join in one backward)."""
+
+    def __init__(self, x, selfattns, heads):
+        self.selfattns = list(selfattns)  # BertSelfAttention modules of the cross-attentions, in layer order
+        self.n = len(self.selfattns)
+        self.heads = heads
+        ws = [w for sa in self.selfattns for w in (sa.key.weight, sa.value.weight)]
+        bs = [b for sa in self.selfattns for b in (sa.key.bias, sa.value.bias)]
+        self.G = None          # (B, L1, n * 2 * 768) gradient of the hoisted projection, allocated by the first writer
+        self.written = set()
+        self.tails = []        # (slot, dY (M, 1536), X (M, 768)) parked by the tail projections' backward
+        self.wc, self.bc = _cat_shadow(ws, bs)
+        self.x = x
+        outs = _HoistedKVFn.apply(x, self, *ws, *bs)
+        self.y_shape = (x.shape[0], x.shape[1], self.wc.shape[0])
+        self.outs = outs
+
+    def kv(self, i):
+        return self.outs[i]
+
+    def block(self, i):
+        """rows of the concatenated weight / bias that belong to layer slot i: [key_i; value_i]"""
+        n = self.wc.shape[0] // self.n
+        return self.wc[i * n:(i + 1) * n], self.bc[i * n:(i + 1) * n]
+
+    def grad_view(self, i, like):
+        """where layer slot i's attention backward writes d(kv(i)): a view of the shared gradient buffer with the
+        strides of kv(i)"""
+        if self.G is None:
+            self.G = torch.empty(self.y_shape, dtype=like.dtype, device=like.device)
+            self.written = set()
+        self.written.add(i)
+        B, L1 = self.y_shape[:2]
+        return self.G.view(B, L1, self.n, 2, self.heads, like.shape[-1])[:, :, i]
+
+    def tail_kv(self, i, t):
+        B, L2 = t.shape[:2]
+        return _TailKVFn.apply(t, self, i).view(B, L2, 2, self.heads, -1)
+
+
+class _HoistedKVFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, hold, *wb):
+        xb = x if x.dtype == _COMPUTE_DTYPE else x.to(_COMPUTE_DTYPE)
+        y = F.linear(xb, hold.wc, hold.bc)
+        ctx.save_for_backward(xb)
+        ctx.hold, ctx.x_dtype, ctx.k = hold, x.dtype, len(wb) // 2
+        B, L1 = y.shape[:2]
+        y6 = y.view(B, L1, hold.n, 2, hold.heads, -1)
+        return tuple(y6[:, :, i] for i in range(hold.n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        hold = ctx.hold
+        (xb,) = ctx.saved_tensors
+        like = next(g for g in grads if g is not None)
+        for i, g in enumerate(grads):
+            slot = hold.grad_view(i, like) if (g is None or i not in hold.written) else None
+            if g is None:
+                slot.zero_()
+            elif slot is not None or g.data_ptr() != hold.grad_view(i, like).data_ptr():
+                hold.grad_view(i, like).copy_(g)  # the gradient did not come from attention_q_kv2's in-place writer
+        G = hold.G
+        hold.G = None
+        G2 = G.view(-1, G.shape[-1])
+        x2 = xb.reshape(-1, xb.shape[-1])
+        dx = torch.mm(G2, hold.wc).view(xb.shape).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
+        dw, db = _dw_db(G2, x2, True, True)
+        n = dw.shape[0] // hold.n
+        for slot, g2, t2 in hold.tails:  # the per-layer second segments went through the same weights
+            dw[slot * n:(slot + 1) * n].add_(_mm_f32(g2.t(), t2))
+            db[slot * n:(slot + 1) * n].add_(g2.sum(0, dtype=torch.float32))
+        hold.tails = []
+        h = n // 2
+        k = ctx.k
+        dws = tuple(dw[j * h:(j + 1) * h] for j in range(k))
+        dbs = tuple(db[j * h:(j + 1) * h] for j in range(k))
+        return (dx, None) + dws + dbs
+
+
+class _TailKVFn(torch.autograd.Function):
+    """[key_i; value_i](t) with the hoisted projection's shadows; the weight gradient is parked for _HoistedKVFn's
+    backward (which runs after every layer's backward: it needs all their gradients)."""
+
+    @staticmethod
+    def forward(ctx, t, hold, i):
+        w, b = hold.block(i)
+        tb = t if t.dtype == _COMPUTE_DTYPE else t.to(_COMPUTE_DTYPE)
+        ctx.save_for_backward(tb, w)
+        ctx.hold, ctx.i, ctx.t_dtype = hold, i, t.dtype
+        return F.linear(tb, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        tb, w = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        ctx.hold.tails.append((ctx.i, g2, tb.reshape(-1, tb.shape[-1])))
+        return torch.mm(g2, w).view(tb.shape).to(ctx.t_dtype), None, None
+
+
+_MASK2_CACHE = {}
+
+
+def _mask_log2_two(mask, B, L1, L2):
+    if mask is None:
+        return None
+    import weakref
+    key = (id(mask), L1, L2)
+    hit = _MASK2_CACHE.get(key)
+    if hit is not None and hit[0]() is mask and hit[1] == mask._version:
+        return hit[2]
+    from . import _ext
+    if len(_MASK2_CACHE) > 64:
+        _MASK2_CACHE.clear()
+    m = _ext.key_mask_log2_two(mask, B, L1, L2)
+    _MASK2_CACHE[key] = (weakref.ref(mask), mask._version, m)
+    return m
+
+
+class _QKV2Attention(torch.autograd.Function):
+    """Cross-attention of q (B, Lq <= 32, H, 64) over the keys / values cat(kv1, kv2) given as two fused K/V tensors
+    (B, L1, 2, H, 64) (may be a strided view of a hoisted projection) and (B, L2, 2, H, 64) -- never concatenated."""
+
+    @staticmethod
+    def forward(ctx, q, kv1, kv2, scale, mask_log2, p_drop, sink):
+        from . import _ext
+        seed, st = _seed_args(p_drop, q.device)
+        out, lse = _ext.attn_fwd2(q, kv1[:, :, 0], kv1[:, :, 1], kv2[:, :, 0], kv2[:, :, 1], scale, mask_log2, p_drop,
+                                  seed, st)
+        ctx.save_for_backward(q, kv1, kv2, out, lse, mask_log2 if mask_log2 is not None else q.new_empty(0),
+                              st if st is not None else q.new_empty(0))
+        ctx.cfg = (scale, p_drop, seed, mask_log2 is not None, st is not None, sink)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import _ext
+        q, kv1, kv2, out, lse, mask_log2, st = ctx.saved_tensors
+        scale, p_drop, seed, has_mask, has_st, sink = ctx.cfg
+        qc = q if q.is_contiguous() else q.contiguous()
+        dq, dkv2 = torch.empty_like(qc), torch.empty_like(kv2)
+        if sink is not None:
+            dkv1 = sink[0].grad_view(sink[1], kv1)  # this layer's column block of the hoisted projection's gradient
+        else:
+            if not kv1.is_contiguous():
+                raise RuntimeError("two-segment attention without a gradient sink needs a contiguous first segment")
+            dkv1 = torch.empty_like(kv1)
+        _ext.attn_bwd2(qc, kv1[:, :, 0], kv1[:, :, 1], kv2[:, :, 0], kv2[:, :, 1], out, lse, grad_out, scale, dq,
+                       dkv1[:, :, 0], dkv1[:, :, 1], dkv2[:, :, 0], dkv2[:, :, 1], mask_log2 if has_mask else None,
+                       p_drop, seed, st if has_st else None)
+        return dq, dkv1, dkv2, None, None, None, None
+
+
+def two_segment_ok(q, kv1, kv2, mask):
+    return (q.is_cuda and q.dtype == torch.bfloat16 and q.shape[1] <= 32 and q.shape[-1] == 64 and q.stride(-1) == 1
+            and kv1.dtype == torch.bfloat16 and kv2.dtype == torch.bfloat16 and kv2.is_contiguous()
+            and (mask is None or (mask.dim() == 4 and mask.shape[1] == 1 and mask.shape[2] == 1)))
+
+
+def attention_q_kv2(q, kv1, kv2, scale, dropout_p=0.0, mask=None, sink=None):
+    """Cross-attention over cat(kv1, kv2) along the key axis: q (B, Lq, H, D), kv1 (B, L1, 2, H, D), kv2 (B, L2, 2, H, D);
+    mask additive (B,1,1,L1+L2) or None.  sink = (HoistedKV, slot) when kv1 comes from a hoisted projection."""
+    if two_segment_ok(q, kv1, kv2, mask):
+        m = _mask_log2_two(mask, q.shape[0], kv1.shape[1], kv2.shape[1])
+        return _QKV2Attention.apply(q, kv1, kv2, scale, m, float(dropout_p), sink)
+    kv = torch.cat((kv1, kv2), dim=1)
+    ctx, _ = attention(q, kv[:, :, 0], kv[:, :, 1], mask, scale, dropout_p=dropout_p)
+    return ctx
 
 
 def _packed_ok(t, mask):

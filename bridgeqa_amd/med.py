@@ -18,6 +18,7 @@ maps (blip_vqa_3d.py:281-282), so `output_attentions="last"` is what BLIP_VQA3D 
 """
 import json
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -96,6 +97,15 @@ class BertEmbeddings(nn.Module):
         return self.dropout(ops.layer_norm(embeddings, self.LayerNorm))
 
 
+class TwoSegmentStates(object):
+    """encoder_hidden_states of a twin cross-attention in factored form: cat(fixed tokens, tail) along the sequence,
+    where the fixed tokens' K/V for this layer come from `hoisted` (ops.HoistedKV, slot `slot`) and `tail`
+    (B, L2, hidden) is the other stream's state of the previous layer (reference med.py:549-562)."""
+
+    def __init__(self, hoisted, slot, tail):
+        self.hoisted, self.slot, self.tail = hoisted, slot, tail
+
+
 class BertSelfAttention(nn.Module):
     def __init__(self, config, is_cross_attention):
         super().__init__()
@@ -138,11 +148,22 @@ class BertSelfAttention(nn.Module):
         want = output_attentions or (is_cross and self.save_attention)
         H, D = self.num_attention_heads, self.attention_head_size
         p_drop = self.dropout.p if self.training else 0.0
-        if not want and past_key_value is None and ops.compute_dtype() == torch.bfloat16 and hidden_states.is_cuda:
+        two_seg = isinstance(encoder_hidden_states, TwoSegmentStates)
+        if not want and past_key_value is None and ops.compute_dtype() == torch.bfloat16 and (hidden_states.is_cuda or two_seg):
             # fused projections: Q/K/V (self) or K/V (cross) as ONE GEMM over the shared input, and the attention
             # kernels read / write the packed tensors in place
             B, L = hidden_states.shape[:2]
-            if is_cross:
+            if is_cross and isinstance(encoder_hidden_states, TwoSegmentStates):
+                # keys / values = cat(hoisted projection of the fixed tokens, this layer's projection of the other
+                # stream's states) -- handed to the kernels as two segments, never concatenated
+                es = encoder_hidden_states
+                q = self._heads(ops.linear(hidden_states, self.query.weight, self.query.bias))
+                kv1 = es.hoisted.kv(es.slot)
+                kv2 = es.hoisted.tail_kv(es.slot, es.tail)
+                ctx = ops.attention_q_kv2(q, kv1, kv2, 1.0 / math.sqrt(D), p_drop, encoder_attention_mask,
+                                          sink=(es.hoisted, es.slot))
+                present = None
+            elif is_cross:
                 Lk = encoder_hidden_states.shape[1]
                 q = self._heads(ops.linear(hidden_states, self.query.weight, self.query.bias))
                 kv = ops.multi_linear(encoder_hidden_states, (self.key, self.value)).view(B, Lk, 2, H, D)
@@ -285,6 +306,9 @@ class BertLayer(nn.Module):
         return self.output(self.intermediate(attention_output), attention_output, layernorm_idx=layernorm_idx)
 
 
+_TWO_SEGMENT = os.environ.get("BQ_TWO_SEGMENT_KV", "0") == "1"
+
+
 def _wants(output_attentions, i, last):
     return output_attentions is True or (output_attentions == "last" and i == last)
 
@@ -353,13 +377,29 @@ class BertEncoderTwin(BertEncoder):
         ops.prime_masks(attention_mask, encoder_attention_mask, encoder_attention_mask_twin)
         enc2d = ops._c(encoder_hidden_states)
         enc3d = ops._c(encoder_hidden_states_twin)
-        for i in layers:
+        # BQ_TWO_SEGMENT_KV=1: the image / object tokens' K/V of ALL layers from one hoisted GEMM per stream, the
+        # cross-attention over two key segments (no per-layer cat, no strided slicing of its gradient)
+        hoist = (_TWO_SEGMENT and mode == "multimodal" and not output_attentions
+                 and ops.compute_dtype() == torch.bfloat16 and hidden_states.shape[1] <= 32
+                 and not ops.overlap_enabled(hidden_states)
+                 and all(i < self.num_hidden_layers_twin for i in layers)
+                 and not any(self.layer[i].crossattention.self.save_attention or
+                             self.layer_twin[i].crossattention.self.save_attention for i in layers))
+        if hoist:
+            heads = self.config.num_attention_heads
+            h2d = ops.HoistedKV(enc2d, [self.layer[i].crossattention.self for i in layers], heads)
+            h3d = ops.HoistedKV(enc3d, [self.layer_twin[i].crossattention.self for i in layers], heads)
+        for slot, i in enumerate(layers):
             if output_hidden_states:
                 all_hidden_states = all_hidden_states + (hidden_states,)
             want = _wants(output_attentions, i, layers[-1])
             twin = self.layer_twin[i] if i < self.num_hidden_layers_twin else None
-            mix2d = torch.cat((enc2d, ops._c(hidden_states_twin)), dim=1)
-            mix3d = torch.cat((enc3d, ops._c(hidden_states)), dim=1)
+            if hoist:
+                mix2d = TwoSegmentStates(h2d, slot, ops._c(hidden_states_twin))
+                mix3d = TwoSegmentStates(h3d, slot, ops._c(hidden_states))
+            else:
+                mix2d = torch.cat((enc2d, ops._c(hidden_states_twin)), dim=1)
+                mix3d = torch.cat((enc3d, ops._c(hidden_states)), dim=1)
             if twin is not None and ops.overlap_enabled(hidden_states):
                 # the two streams of a layer only depend on each other's PREVIOUS state: run them side by side
                 with ops.fork("twin", hidden_states) as f:

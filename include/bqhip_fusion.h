@@ -37,6 +37,24 @@ BQ_API int bq_attn_bwd(const void *Q, const void *K, const void *V, const void *
                        long g_hs, float scale, float p_drop, unsigned seed, const unsigned *seed_ptr, int causal,
                        void *stream);
 
+/* Attention of Lq <= 32 queries over cat(segment 1, segment 2) along the key axis without the concatenated tensor:
+ * replaces  encoder_hidden_states = torch.cat([image_embeds | object_embeds, other stream's states], dim=1)  followed
+ * by the cross-attention of models/med.py:549-562, 179-217 (BertEncoderTwin / BertSelfAttention).  K / V = segment 1
+ * (B,Lk,H,64) by strides k_*, K2 / V2 = segment 2 (B,Lk2,H,64) by strides k2_*.  mask: NULL or f32 [B][Lkp] with
+ * Lkp = 64*(ceil(Lk/64) + ceil(Lk2/64)): segment 1's keys at [0,Lk), segment 2's at [64*ceil(Lk/64), ..+Lk2), times
+ * log2(e), 0 in the padding.  No causal form.  Backward: dK/dV strided like K, dK2/dV2 like K2. */
+BQ_API int bq_attn_fwd2(const void *Q, const void *K, const void *V, const void *K2, const void *V2, void *O, float *LSE,
+                        const float *mask, int B, int H, int Lq, int Lk, int Lk2, int Lkp, long q_bs, long q_rs,
+                        long q_hs, long k_bs, long k_rs, long k_hs, long k2_bs, long k2_rs, long k2_hs, long o_bs,
+                        long o_rs, long o_hs, float scale, float p_drop, unsigned seed, const unsigned *seed_ptr,
+                        void *stream);
+BQ_API int bq_attn_bwd2(const void *Q, const void *K, const void *V, const void *K2, const void *V2, const void *dO,
+                        const float *LSE, const void *O, float *DELTA, const float *mask, void *dQ, void *dK, void *dV,
+                        void *dK2, void *dV2, int B, int H, int Lq, int Lk, int Lk2, int Lkp, long q_bs, long q_rs,
+                        long q_hs, long k_bs, long k_rs, long k_hs, long k2_bs, long k2_rs, long k2_hs, long g_bs,
+                        long g_rs, long g_hs, float scale, float p_drop, unsigned seed, const unsigned *seed_ptr,
+                        void *stream);
+
 /* in (B,L,H,64) bf16 by strides -> out [B*H][64][Lp], zero padded (replaces zeros + permute + copy_) */
 BQ_API int bq_transpose_pad(const void *in, void *out, int B, int H, int L, int Lp, long bs, long rs, long hs,
                             void *stream);

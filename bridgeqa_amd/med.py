@@ -379,24 +379,28 @@ class BertEncoderTwin(BertEncoder):
         enc3d = ops._c(encoder_hidden_states_twin)
         # BQ_TWO_SEGMENT_KV=1: the image / object tokens' K/V of ALL layers from one hoisted GEMM per stream, the
         # cross-attention over two key segments (no per-layer cat, no strided slicing of its gradient)
-        hoist = (_TWO_SEGMENT and mode == "multimodal" and not output_attentions
-                 and ops.compute_dtype() == torch.bfloat16 and hidden_states.shape[1] <= 32
-                 and not ops.overlap_enabled(hidden_states)
-                 and all(i < self.num_hidden_layers_twin for i in layers)
-                 and not any(self.layer[i].crossattention.self.save_attention or
-                             self.layer_twin[i].crossattention.self.save_attention for i in layers))
-        if hoist:
+        # Layers that must return their attention probabilities (output_attentions=True, or the last layer under
+        # "last" as BLIP_VQA3D asks) keep the concatenated wiring.
+        hoisted_layers = []
+        if (_TWO_SEGMENT and mode == "multimodal" and ops.compute_dtype() == torch.bfloat16
+                and hidden_states.shape[1] <= 32 and not ops.overlap_enabled(hidden_states)):
+            hoisted_layers = [i for i in layers if i < self.num_hidden_layers_twin
+                              and not _wants(output_attentions, i, layers[-1])
+                              and not self.layer[i].crossattention.self.save_attention
+                              and not self.layer_twin[i].crossattention.self.save_attention]
+        slot_of = {i: s_ for s_, i in enumerate(hoisted_layers)}
+        if hoisted_layers:
             heads = self.config.num_attention_heads
-            h2d = ops.HoistedKV(enc2d, [self.layer[i].crossattention.self for i in layers], heads)
-            h3d = ops.HoistedKV(enc3d, [self.layer_twin[i].crossattention.self for i in layers], heads)
-        for slot, i in enumerate(layers):
+            h2d = ops.HoistedKV(enc2d, [self.layer[i].crossattention.self for i in hoisted_layers], heads)
+            h3d = ops.HoistedKV(enc3d, [self.layer_twin[i].crossattention.self for i in hoisted_layers], heads)
+        for i in layers:
             if output_hidden_states:
                 all_hidden_states = all_hidden_states + (hidden_states,)
             want = _wants(output_attentions, i, layers[-1])
             twin = self.layer_twin[i] if i < self.num_hidden_layers_twin else None
-            if hoist:
-                mix2d = TwoSegmentStates(h2d, slot, ops._c(hidden_states_twin))
-                mix3d = TwoSegmentStates(h3d, slot, ops._c(hidden_states))
+            if i in slot_of:
+                mix2d = TwoSegmentStates(h2d, slot_of[i], ops._c(hidden_states_twin))
+                mix3d = TwoSegmentStates(h3d, slot_of[i], ops._c(hidden_states))
             else:
                 mix2d = torch.cat((enc2d, ops._c(hidden_states_twin)), dim=1)
                 mix3d = torch.cat((enc3d, ops._c(hidden_states)), dim=1)

@@ -86,9 +86,11 @@ def test_twin_encoder_hoisted_wiring_matches_concatenated_wiring():
             img, obj = img0.clone().requires_grad_(True), obj0.clone().requires_grad_(True)
             r = twin(ids, attention_mask=am, encoder_hidden_states=img,
                      encoder_attention_mask=torch.ones(B, P, dtype=torch.long), encoder_hidden_states_twin=obj,
-                     encoder_attention_mask_twin=om, return_dict=True)
+                     encoder_attention_mask_twin=om, return_dict=True, output_attentions="last")  # as BLIP_VQA3D calls it
             h2d, h3d = r.last_hidden_state
-            (h2d.float().square().sum() + h3d.float().square().sum()).backward()
+            assert len(r.cross_attentions) == 1
+            (h2d.float().square().sum() + h3d.float().square().sum()
+             + r.cross_attentions[-1][0].float().square().sum()).backward()
             grads = {n: p.grad.float().clone() for n, p in twin.named_parameters() if p.grad is not None}
             return h2d.detach().float(), h3d.detach().float(), img.grad.float(), obj.grad.float(), grads
         a = run(True)

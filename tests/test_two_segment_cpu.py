@@ -108,3 +108,21 @@ def test_twin_encoder_hoisted_wiring_matches_concatenated_wiring():
     worst = max(rel(a[4][k], b[4][k]) for k in live)
     assert max((a[4][k] - b[4][k]).norm().item() for k in a[4] if k not in live) < 1e-3
     assert worst < 6e-2, worst
+
+
+def test_two_segment_mask_layout():
+    """key_mask_log2_two: segment 1's keys at [0, L1), segment 2's at [pad64(L1), pad64(L1) + L2), zeros elsewhere,
+    values multiplied by log2(e) (the layout include/bqhip_fusion.h documents for bq_attn_fwd2)"""
+    from bridgeqa_amd import _ext
+    B, L1, L2 = 2, 70, 3
+    mask = torch.zeros(B, 1, 1, L1 + L2)
+    mask[0, 0, 0, 5] = -10000.0
+    mask[1, 0, 0, L1 + 2] = -10000.0
+    m = _ext.key_mask_log2_two(mask, B, L1, L2)
+    assert m.shape == (B, 128 + 64) and m.dtype == torch.float32
+    want = torch.zeros(B, 192)
+    want[0, 5] = -10000.0 * _ext.LOG2E
+    want[1, 128 + 2] = -10000.0 * _ext.LOG2E
+    assert torch.allclose(m, want)
+    one = _ext.key_mask_log2_two(mask[:1], B, L1, L2)  # a (1,1,1,L) mask broadcasts over the batch
+    assert torch.allclose(one[1], one[0])

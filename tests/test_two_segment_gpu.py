@@ -109,3 +109,43 @@ def test_twin_encoder_hoisted_two_segment_wiring_on_gpu(dev):
     assert len(live) > 60
     worst = max((rel(a[4][k], b[4][k]), k) for k in live)
     assert worst[0] < 6e-2, worst
+
+
+import os
+
+
+@pytest.mark.skipif(os.environ.get("BQ_TEST_TWO_SEGMENT_PIPELINE") != "1",
+                    reason="graph-replay training with the opt-in two-segment path: written when the round's GPU "
+                           "minutes were spent, not yet run -- BQ_TEST_TWO_SEGMENT_PIPELINE=1 runs it (first step of the "
+                           "next round, before BQ_TWO_SEGMENT_KV becomes the default)")
+def test_phased_pipeline_trains_with_two_segment_path(dev):
+    """tests/test_pipeline_gpu.py::test_phased_step_graph_replay_trains with med._TWO_SEGMENT on: the captured fusion
+    phase (hoisted projection, gradient sink allocated inside the capture, FusedAdamW writing the re-registered
+    concatenated shadows) must train"""
+    import bench
+    from bridgeqa_amd import fusion_ops as ops, med
+    from bridgeqa_amd.optim import FusedAdamW
+    from bridgeqa_amd.pipeline import PhasedTrainStep
+    from test_pipeline_gpu import _batch, _small_model
+    prev = ops.set_compute_dtype(torch.bfloat16)
+    flag = med._TWO_SEGMENT
+    med._TWO_SEGMENT = True
+    try:
+        model = _small_model(dev)
+        batch = _batch(dev)
+        opt = FusedAdamW(model.parameters(), lr=1e-3)
+        pipe = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, opt, use_graphs=True).capture(warmup=3)
+        w = model.blip_model.text_encoder.encoder.layer[0].crossattention.self.value.weight
+        w0 = w.detach().clone()
+        losses = []
+        for _ in range(16):
+            l = pipe.step()
+            pipe.wait()
+            torch.cuda.synchronize()
+            losses.append(l.item())
+        assert all(x == x and abs(x) < 1e6 for x in losses), losses
+        assert not torch.equal(w0, w.detach())
+        assert min(losses[-3:]) < 0.9 * losses[0], losses
+    finally:
+        med._TWO_SEGMENT = flag
+        ops.set_compute_dtype(prev)

@@ -596,3 +596,136 @@ def drop_add_ln_bwd(x, residual, gamma, dy, mean, rstd, eps, p_drop, seed, seed_
                                        int(rows_per_sample), int(seed) & 0xFFFFFFFF, _p(seed_tensor), _stream()),
                "drop_add_ln_bwd")
     return dx, dres, dgb[0], dgb[1]
+
+
+# ---- MFMA bf16 GEMM family (csrc/gemm.hip) ------------------------------------------------------------
+GEMM_P_XC, GEMM_Q_XC, GEMM_OUT_F32 = 1, 2, 4
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU = 0, 1, 2, 3
+
+
+class _GemmDesc(ctypes.Structure):
+    _fields_ = [("P", _vp), ("Q", _vp), ("out", _vp), ("bias", _vp), ("out2", _vp), ("aux", _vp), ("colsum", _vp),
+                ("ldp", _i), ("ldq", _i), ("ldo", _i), ("Ni", _i), ("Nj", _i), ("Kc", _i), ("bias_bf16", _i)]
+
+
+_lib.bq_gemm_bf16.argtypes = [ctypes.POINTER(_GemmDesc), _i, _i, _i, _i, _vp]
+_lib.bq_gemm_bf16.restype = ctypes.c_int
+_lib.bq_gemm_max_problems.restype = ctypes.c_int
+GEMM_TILE_ROWS = 1024  # problems with at least this many j rows (and i columns >= 256) run on the 256 x 256 kernel
+
+
+def _mat(t, name):
+    if not t.is_cuda:
+        raise RuntimeError("%s: CPU not supported (bridgeqa_amd has no CPU path)" % name)
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError("%s must be a 2-D tensor with a contiguous last dimension" % name)
+    return t
+
+
+def pick_tile(Ni, Nj, q_xc):
+    if Nj >= GEMM_TILE_ROWS and Ni >= 256:
+        return 256
+    if q_xc or Nj > 512:
+        return 64
+    return 32
+
+
+def gemm_grouped(problems, flags, epilogue=EPI_NONE, tile=None):
+    """One launch for a list of problems out[j][i] = epilogue(sum_kc P(i,kc) Q(j,kc)) (include/bqhip_fusion.h,
+    bq_gemm_bf16).  problems: dicts with P, Q, out (2-D tensors, contiguous last dim) and optional bias (fp32 (Ni,)),
+    out2, aux, colsum (fp32 (Ni,), accumulated).  P: (Ni, Kc), or (Kc, Ni) with GEMM_P_XC; Q likewise over j."""
+    n = len(problems)
+    arr = (_GemmDesc * n)()
+    pxc, qxc, f32 = bool(flags & GEMM_P_XC), bool(flags & GEMM_Q_XC), bool(flags & GEMM_OUT_F32)
+    t_auto = 32
+    for k, pr in enumerate(problems):
+        P, Q, out = _mat(pr["P"], "P"), _mat(pr["Q"], "Q"), _mat(pr["out"], "out")
+        if P.dtype != torch.bfloat16 or Q.dtype != torch.bfloat16:
+            raise RuntimeError("gemm: operands must be bf16")
+        if out.dtype != (torch.float32 if f32 else torch.bfloat16):
+            raise RuntimeError("gemm: out must be %s" % ("float32" if f32 else "bfloat16"))
+        Ni, Kc = (P.shape[1], P.shape[0]) if pxc else (P.shape[0], P.shape[1])
+        Nj, Kq = (Q.shape[1], Q.shape[0]) if qxc else (Q.shape[0], Q.shape[1])
+        if Kq != Kc or tuple(out.shape) != (Nj, Ni):
+            raise RuntimeError("gemm: shape mismatch P%s Q%s out%s" % (tuple(P.shape), tuple(Q.shape), tuple(out.shape)))
+        d = arr[k]
+        d.P, d.Q, d.out = P.data_ptr(), Q.data_ptr(), out.data_ptr()
+        bias, out2, aux, colsum = pr.get("bias"), pr.get("out2"), pr.get("aux"), pr.get("colsum")
+        if bias is not None and (bias.dtype not in (torch.float32, torch.bfloat16) or bias.numel() != Ni
+                                 or not bias.is_contiguous()):
+            raise RuntimeError("gemm: bias must be a contiguous fp32 or bf16 (Ni,) tensor")
+        d.bias_bf16 = int(bias is not None and bias.dtype == torch.bfloat16)
+        if colsum is not None and (colsum.dtype != torch.float32 or colsum.numel() != Ni or not colsum.is_contiguous()):
+            raise RuntimeError("gemm: colsum must be a contiguous fp32 (Ni,) tensor")
+        for t, nm in ((out2, "out2"), (aux, "aux")):
+            if t is not None and (t.dtype != torch.bfloat16 or tuple(t.shape) != (Nj, Ni) or t.stride() != out.stride()):
+                raise RuntimeError("gemm: %s must be bf16 and laid out like out" % nm)
+        d.bias, d.out2, d.aux, d.colsum = _p(bias), _p(out2), _p(aux), _p(colsum)
+        d.ldp, d.ldq, d.ldo = P.stride(0), Q.stride(0), out.stride(0)
+        d.Ni, d.Nj, d.Kc = Ni, Nj, Kc
+        t_auto = max(t_auto, pick_tile(Ni, Nj, qxc))
+    dev = problems[0]["out"].device
+    with torch.cuda.device(dev):
+        _check(_lib.bq_gemm_bf16(arr, n, int(flags), int(epilogue), int(tile or t_auto), _stream()), "gemm_bf16")
+
+
+def gemm_fwd(x, w, bias=None, gelu=False, tile=None):
+    """y = x @ w^T + bias (x (M,K), w (N,K) bf16; bias fp32 (N,)); gelu: returns (y_pre, gelu(y_pre))"""
+    _mat(x, "x"), _mat(w, "w")
+    M, N = x.shape[0], w.shape[0]
+    with torch.cuda.device(x.device):
+        y = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+        act = torch.empty_like(y) if gelu else None
+    epi = EPI_BIAS_GELU if gelu else (EPI_BIAS if bias is not None else EPI_NONE)
+    gemm_grouped([dict(P=w, Q=x, out=y, bias=bias, out2=act)], 0, epi, tile)
+    return (y, act) if gelu else y
+
+
+def gemm_dx(dy, w, pre_act=None, colsum=None, tile=None):
+    """dx = dy @ w (dy (M,N), w (N,K) bf16) [* gelu'(pre_act) (M,K)]; colsum (K,) fp32 += column sums of dx"""
+    _mat(dy, "dy"), _mat(w, "w")
+    M, K = dy.shape[0], w.shape[1]
+    with torch.cuda.device(dy.device):
+        dx = torch.empty(M, K, dtype=torch.bfloat16, device=dy.device)
+    gemm_grouped([dict(P=w, Q=dy, out=dx, aux=pre_act, colsum=colsum)], GEMM_P_XC,
+                 EPI_DGELU if pre_act is not None else EPI_NONE, tile)
+    return dx
+
+
+def gemm_dw(dy, x, tile=None):
+    """dw = dy^T @ x in fp32 (dy (M,N), x (M,K) bf16) -> (N,K)"""
+    _mat(dy, "dy"), _mat(x, "x")
+    N, K = dy.shape[1], x.shape[1]
+    with torch.cuda.device(dy.device):
+        dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+    gemm_grouped([dict(P=x, Q=dy, out=dw)], GEMM_P_XC | GEMM_Q_XC | GEMM_OUT_F32, EPI_NONE, tile)
+    return dw
+
+
+class _ColsumDesc(ctypes.Structure):
+    _fields_ = [("g", _vp), ("out", _vp), ("M", _i), ("N", _i), ("ld", _i)]
+
+
+_lib.bq_colsum_grouped_bf16.argtypes = [ctypes.POINTER(_ColsumDesc), _i, _vp]
+_lib.bq_colsum_grouped_bf16.restype = ctypes.c_int
+
+
+def colsum_grouped(mats):
+    """fp32 column sums of several bf16 (M_p, N_p) matrices (contiguous last dim) in one launch; returns a list of
+    (N_p,) views of ONE zero-initialised buffer (one memset + one kernel for all bias gradients of a backward pass)"""
+    n = len(mats)
+    dev = mats[0].device
+    with torch.cuda.device(dev):
+        flat = torch.zeros(sum(m.shape[1] for m in mats), dtype=torch.float32, device=dev)
+        arr = (_ColsumDesc * n)()
+        outs, off = [], 0
+        for k, m in enumerate(mats):
+            _mat(m, "g")
+            if m.dtype != torch.bfloat16:
+                raise RuntimeError("colsum_grouped: bf16 only")
+            o = flat[off:off + m.shape[1]]
+            off += m.shape[1]
+            outs.append(o)
+            arr[k].g, arr[k].out, arr[k].M, arr[k].N, arr[k].ld = m.data_ptr(), o.data_ptr(), m.shape[0], m.shape[1], m.stride(0)
+        _check(_lib.bq_colsum_grouped_bf16(arr, n, _stream()), "colsum_grouped")
+    return outs

@@ -1,0 +1,718 @@
+// MFMA bf16 GEMM family for gfx950 (MI355X): the dense contractions of the fusion half of the hot path --
+// ViT patch-embed / QKV / proj / FFN (reference models/vit.py:30-32,51-53,144-145) and the MED/BERT Q/K/V,
+// output and FFN projections (models/med.py:112-118,232,295,310) -- forward, input-gradient and weight-gradient
+// forms, bf16 operands, fp32 accumulation on v_mfma_f32_16x16x32_bf16.
+//
+// One formulation for all three:   out[j][i] (+)= sum_kc P(i, kc) * Q(j, kc)      (i contiguous in `out`)
+//   forward  y[m][n]  = x W^T + b : P = W  (K-contiguous, i = n),  Q = x  (K-contiguous, j = m)
+//   dX       dx[m][k] = dy W      : P = W  (contraction-major: P(i=k, kc=n) = W[n][k]),  Q = dy (K-contiguous)
+//   dW       dw[n][k] = dy^T x    : P = x  (contraction-major, i = k),  Q = dy (contraction-major, j = n), fp32 out
+// "K-contiguous" (KC) operands are staged as [rows][64 k] LDS images and read with ds_read_b128; contraction-major
+// (XC) operands as [64 kc][64 outs] images read TRANSPOSED with ds_read_b64_tr_b16 -- no transposed copy of a weight
+// or an activation exists anywhere.  P is the MFMA A operand (i on the accumulator registers: 4 consecutive i per
+// lane => 8-byte bf16 / 16-byte fp32 contiguous pieces of an output row), Q the B operand (j on the lanes).
+//
+// gemm256_kernel: 256 x 256 output tile per workgroup, 8 waves (2 along i x 4 along j, 128 x 64 per wave), K step 64,
+// LDS-DMA staging (buffer_load ... lds: bounds-checked, no VGPRs), two 64 KB LDS buffers.  The K loop is a
+// 4-phase-per-tile software pipeline in which the two wave groups (wr = 0 / 1, one wave of each per SIMD) run HALF A
+// PHASE APART: while one group issues its 16-MFMA cluster the other issues its LDS reads and the next DMA, so the
+// matrix pipe of every SIMD always has a wave feeding it (cdna_hip_programming.md §5 "8-phase template"; the schedule
+// below is this file's own and its hazard analysis is in DESIGN.md §4.4):
+//   staging unit = 64 rows x 64 k (8 KB, one DMA per wave): A0(g) A1(g) = the two 64-row halves of wave group g's
+//   P rows, B0(h) B1(h) = the first / second 32 columns of the four wave columns (h = wc >> 1);
+//   phase p of tile t reads      p0: A0,B0 -> Q00   p1: B1 -> Q01   p2: A1 -> Q11   p3: (B0 kept) -> Q10
+//   and stages (2 DMAs per wave) p0: B1(t+1)        p1: A1(t+1)     p2: A0(t+2)     p3: B0(t+2)
+//   followed by ONE s_waitcnt vmcnt(8): everything older than the last four stages has landed (a stage is consumed
+//   >= 4 phases ~ 2000 cycles after it was issued: HBM misses are covered), then barrier | MFMA | barrier.
+#include "bq_common.h"
+#include "bqhip_fusion.h"
+
+namespace bq {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_DGELU = 3 };
+enum { GF_P_XC = 1, GF_Q_XC = 2, GF_OUT_F32 = 4, GF_ACCUM = 8 };
+
+struct GemmProblem {
+  const __bf16 *P, *Q;
+  void *out;           // out[j * ldo + i]: bf16, or fp32 with GF_OUT_F32
+  const void *bias;    // over i (EPI_BIAS / EPI_BIAS_GELU) or null: fp32, or bf16 when bias_bf16
+  void *out2;          // EPI_BIAS_GELU: gelu(out) as bf16, same layout as out
+  const __bf16 *aux;   // EPI_DGELU: the pre-activation y[j][i] (ld = ldo): out = acc * gelu'(y)
+  float *colsum;       // optional fp32 [Ni]: += sum_j out[j][i] (bias gradient of the producing layer)
+  int ldp, ldq, ldo;   // leading dimensions in elements
+  int Ni, Nj, Kc;
+  int tile0, tiles_i;  // first workgroup of this problem in the launch; tiles along i
+  int bias_bf16;
+};
+
+__device__ __forceinline__ void load_bias4(const GemmProblem &pr, int i, float (&bv)[4]) {
+  if (pr.bias_bf16) {
+    const bf16x4 b = *reinterpret_cast<const bf16x4 *>(reinterpret_cast<const __bf16 *>(pr.bias) + i);
+    bv[0] = (float)b[0]; bv[1] = (float)b[1]; bv[2] = (float)b[2]; bv[3] = (float)b[3];
+  } else {
+    const float4 b = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(pr.bias) + i);
+    bv[0] = b.x; bv[1] = b.y; bv[2] = b.z; bv[3] = b.w;
+  }
+}
+
+constexpr int GEMM_MAX_PROBLEMS = 36;
+struct GemmArgs {
+  int n;
+  int total_tiles;
+  GemmProblem p[GEMM_MAX_PROBLEMS];
+};
+
+// ---- LDS images -----------------------------------------------------------------------------------------------------
+// KC unit: [64 rows][64 k] bf16, 128-B rows, 16-B chunk ch of row r at r*128 + ((ch ^ (r & 7)) << 4)
+// XC unit: [64 kc][64 outs] bf16, 128-B rows, 16-B chunk ch of row kc at kc*128 + ((ch ^ (xg(kc) << 1)) << 4)
+// both conflict-free for the fragment reads below (tools/lds_bank_sim.py)
+__device__ __forceinline__ int xg(int kc) { return ((kc >> 1) & 1) | (((kc >> 3) & 1) << 1); }
+
+// exact (erf) GELU and its derivative, fp32.  erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7: far below bf16).
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  float p = 1.061405429f;
+  p = p * t + -1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t + -0.284496736f;
+  p = p * t + 0.254829592f;
+  const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+  const float r = 1.0f - p * t * e;
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.7071067811865476f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erf_as(x * 0.7071067811865476f));
+  const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.5f * x * x * 1.4426950408889634f);
+  return cdf + x * pdf;
+}
+
+// value of the lane `n` to the left in the same 16-lane row, 0 where there is none (bound_ctrl): row-prefix sums
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32_add(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  bf16x2_t v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+template <bool XC>
+__device__ __forceinline__ bf16x8 read_frag(const unsigned char *unit, int sub16, int kk, int kc_base, const int (&xc_base)[4]) {
+  // KC: kc_base = lane term row16*128 + ((q4 ^ (row16 & 7)) << 4) for kk = 0; kk = 1 toggles bit 6
+  if (!XC) {
+    return *reinterpret_cast<const bf16x8 *>(unit + sub16 * 2048 + (kc_base ^ (kk << 6)));
+  } else {
+    // XC: xc_base[s] = (8*gq + q)*128 + ((s ^ g) << 5) + 8*p ; rows +kk*32, second read +4 rows
+    const unsigned char *a0 = unit + xc_base[sub16] + kk * 4096;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)a0);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(a0 + 512));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+
+#define BQ_BARRIER()                                        \
+  do {                                                      \
+    __builtin_amdgcn_sched_barrier(0);                      \
+    asm volatile("s_barrier" ::: "memory");                 \
+    __builtin_amdgcn_sched_barrier(0);                      \
+  } while (0)
+
+template <bool P_XC, bool Q_XC, int EPI, bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[131072];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // ---- workgroup -> (problem, tile): XCD-aware (blocks b, b+8, ... share an XCD's L2: give each XCD a contiguous run
+  // of tiles so that consecutive tiles, which share the Q row panel, hit the same L2) -----------------------------------
+  const int nwg = args.total_tiles;
+  int t;
+  {
+    const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+    t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+  }
+  int pi = 0;
+  for (int k = 1; k < args.n; ++k)
+    if (t >= args.p[k].tile0) pi = k;
+  const GemmProblem &pr = args.p[pi];
+  const int tl = t - pr.tile0;
+  const int tiles_j = (pr.Nj + 255) >> 8;
+  // ragged last j block first: it is the cheapest tile, and late-starting workgroups should be the full ones
+  const int bj = tiles_j - 1 - tl / pr.tiles_i, bi = tl % pr.tiles_i;
+  const int i0 = bi * 256, j0 = bj * 256;
+  const int Ni = pr.Ni, Nj = pr.Nj, Kc = pr.Kc;
+  const int ldp = pr.ldp, ldq = pr.ldq;
+  const int nkt = (Kc + 63) >> 6;
+
+  // ---- staging: 8 units per K tile, one LDS-DMA per wave per unit (wave w -> unit rows 8w..8w+7) -----------------
+  const unsigned p_bytes = P_XC ? (unsigned)(((long)(Kc - 1) * ldp + Ni) * 2) : (unsigned)(((long)(Ni - 1) * ldp + Kc) * 2);
+  const unsigned q_bytes = Q_XC ? (unsigned)(((long)(Kc - 1) * ldq + Nj) * 2) : (unsigned)(((long)(Nj - 1) * ldq + Kc) * 2);
+  const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void *)pr.P, 0, p_bytes, 0x00020000);
+  const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void *)pr.Q, 0, q_bytes, 0x00020000);
+  const int ur = wave * 8 + (lane >> 3);  // unit row this lane stages
+  const int cp = lane & 7;                // LDS chunk position
+  unsigned voff[8];                       // A0(0) A0(1) A1(0) A1(1) B0(0) B0(1) B1(0) B1(1)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {           // P units: rows i0 + g*128 + half*64 + r
+    const int g = u & 1, half = u >> 1;
+    if (!P_XC) {
+      const int c = cp ^ (ur & 7);
+      voff[u] = (unsigned)(((i0 + g * 128 + half * 64 + ur) * ldp + c * 8) * 2);
+    } else {
+      const int c = cp ^ (xg(ur) << 1);
+      voff[u] = (unsigned)((ur * ldp + i0 + g * 128 + half * 64 + c * 8) * 2);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {           // Q units: j0 + h*128 + (r>>5)*64 + half*32 + (r&31)
+    const int h = u & 1, half = u >> 1;
+    if (!Q_XC) {
+      const int c = cp ^ (ur & 7);
+      voff[4 + u] = (unsigned)(((j0 + h * 128 + (ur >> 5) * 64 + half * 32 + (ur & 31)) * ldq + c * 8) * 2);
+    } else {
+      const int c = cp ^ (xg(ur) << 1);
+      voff[4 + u] = (unsigned)((ur * ldq + j0 + h * 128 + (c >> 2) * 64 + half * 32 + (c & 3) * 8) * 2);
+    }
+  }
+  const unsigned p_step = P_XC ? (unsigned)(64 * ldp * 2) : 128u;
+  const unsigned q_step = Q_XC ? (unsigned)(64 * ldq * 2) : 128u;
+  const unsigned lds_w = (unsigned)(wave * 1024);
+
+  // stage the unit pair (u, u+1) of K tile `kt` into buffer kt & 1; past the last tile: out-of-range DMAs (no
+  // traffic, they keep the vmcnt bookkeeping uniform; the buffer they zero is never read again)
+  auto stage_pair = [&](int u, int kt) {
+    const bool live = kt < nkt;
+    const unsigned base = (unsigned)((kt & 1) * 65536 + u * 8192) + lds_w;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const unsigned vo = live ? voff[u + d] : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(u < 4 ? rsP : rsQ, (lds_void_t *)(smem + base + d * 8192), 16, vo, 0, 0, 0);
+      voff[u + d] += (u < 4) ? p_step : q_step;
+    }
+  };
+
+  // ---- fragment read addresses (lane-dependent parts) ------------------------------------------------------------
+  const int row16 = lane & 15, q4 = lane >> 4;
+  const int kc_base = row16 * 128 + ((q4 ^ (row16 & 7)) << 4);
+  int xc_base[4];
+  {
+    const int q = (lane & 15) >> 2, p = lane & 3, g = (q >> 1) | ((q4 & 1) << 1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xc_base[s] = (8 * q4 + q) * 128 + ((s ^ g) << 5) + 8 * p;
+  }
+  const int uA0 = wr * 8192, uA1 = (2 + wr) * 8192, uB0 = (4 + (wc >> 1)) * 8192, uB1 = (6 + (wc >> 1)) * 8192;
+  const int bsub = (wc & 1) * 2;
+
+  // which quadrants of this wave's 128 (i) x 64 (j) tile hold any valid output (ragged edge tiles skip the rest)
+  const int iw = i0 + wr * 128, jw = j0 + wc * 64;
+  const bool vA0 = iw < Ni, vA1 = iw + 64 < Ni, vB0 = jw < Nj, vB1 = jw + 32 < Nj;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: stages 0..5 = A0(0) B0(0) B1(0) A1(0) A0(1) B0(1) ------------------------------------------------
+  stage_pair(0, 0); stage_pair(4, 0); stage_pair(6, 0); stage_pair(2, 0); stage_pair(0, 1); stage_pair(4, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  BQ_BARRIER();
+  if (wr == 1) BQ_BARRIER();  // group 1 runs half a phase behind group 0
+
+  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+#define BQ_MFMA_Q(AO, FB, BO)                                                                         \
+  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int a = 0; a < 4; ++a)      \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) acc[AO + a][BO + b] =                             \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][kk], FB[b][kk], acc[AO + a][BO + b], 0, 0, 0);
+#define BQ_PHASE_SYNC_A()                                   \
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          \
+  BQ_BARRIER();                                             \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
+  __builtin_amdgcn_sched_barrier(0);                        \
+  __builtin_amdgcn_s_setprio(1);
+#define BQ_PHASE_SYNC_B()                                   \
+  __builtin_amdgcn_s_setprio(0);                            \
+  BQ_BARRIER();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const unsigned char *buf = smem + (kt & 1) * 65536;
+    // ---- p0: A0, B0 -> Q00 ; stage B1(t+1)
+    if (vA0) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag<P_XC>(buf + uA0, a, kk, kc_base, xc_base);
+    }
+    if (vB0) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fb0[b][kk] = read_frag<Q_XC>(buf + uB0, bsub + b, kk, kc_base, xc_base);
+    }
+    stage_pair(6, kt + 1);
+    BQ_PHASE_SYNC_A();
+    if (vA0 && vB0) { BQ_MFMA_Q(0, fb0, 0) }
+    BQ_PHASE_SYNC_B();
+    // ---- p1: B1 -> Q01 ; stage A1(t+1)
+    if (vB1) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fb1[b][kk] = read_frag<Q_XC>(buf + uB1, bsub + b, kk, kc_base, xc_base);
+    }
+    stage_pair(2, kt + 1);
+    BQ_PHASE_SYNC_A();
+    if (vA0 && vB1) { BQ_MFMA_Q(0, fb1, 2) }
+    BQ_PHASE_SYNC_B();
+    // ---- p2: A1 -> Q11 ; stage A0(t+2)
+    if (vA1) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag<P_XC>(buf + uA1, a, kk, kc_base, xc_base);
+    }
+    stage_pair(0, kt + 2);
+    BQ_PHASE_SYNC_A();
+    if (vA1 && vB1) { BQ_MFMA_Q(4, fb1, 2) }
+    BQ_PHASE_SYNC_B();
+    // ---- p3: (B0 kept in registers) -> Q10 ; stage B0(t+2)
+    stage_pair(4, kt + 2);
+    BQ_PHASE_SYNC_A();
+    if (vA1 && vB0) { BQ_MFMA_Q(4, fb0, 0) }
+    BQ_PHASE_SYNC_B();
+  }
+  if (wr == 0) BQ_BARRIER();  // re-align the two groups: every LDS read of the K loop is complete after this
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing out-of-range DMAs have written their zeros
+  BQ_BARRIER();
+
+  // ---- epilogue -------------------------------------------------------------------------------------------------
+  // accumulator (a, b)[r]: i = iw + a*16 + q4*4 + r, j = jw + b*16 + row16
+  const int ldo = pr.ldo;
+  if (OUT_F32) {
+    float *out = reinterpret_cast<float *>(pr.out);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int j = jw + b * 16 + row16;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const int i = iw + a * 16 + q4 * 4;
+        if (j < Nj && i < Ni) {  // Ni % 4 == 0 (checked on the host): a lane's four i are valid together
+          float4 *dst = reinterpret_cast<float4 *>(out + (long)j * ldo + i);
+          const f32x4 v = acc[a][b];
+          *dst = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    return;
+  }
+  // bf16 outputs go through LDS so that global stores are whole 256-B row pieces: wave-private [64 j][128 i] image
+  // (16 KB, 16-B chunk c of row j at j*256 + ((c ^ (j & 15)) << 4): conflict-free both ways), written as 8-B pieces,
+  // read back as 16-B pieces.
+  unsigned char *ep = smem + wave * 16384;
+  __bf16 *outb = reinterpret_cast<__bf16 *>(pr.out);
+  const int npass = (EPI == EPI_BIAS_GELU) ? 2 : 1;
+  const bool want_colsum = pr.colsum != nullptr;
+#pragma unroll 1
+  for (int pass = 0; pass < npass; ++pass) {
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int i = iw + a * 16 + q4 * 4;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && pr.bias != nullptr && i < Ni) load_bias4(pr, i, bv);
+      float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int j = jw + b * 16 + row16;
+        const bool ok = j < Nj && i < Ni;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] + bv[r];
+        if (EPI == EPI_DGELU) {  // out = acc * gelu'(y): y read with the accumulator's own map (8 B per lane)
+          bf16x4 y = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+          if (ok) y = *reinterpret_cast<const bf16x4 *>(pr.aux + (long)j * ldo + i);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= dgelu_f((float)y[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (float)(__bf16)v[r];  // what is stored (and what a backward differentiates at)
+        if (want_colsum && pass == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cs[r] += ok ? v[r] : 0.f;
+        }
+        if (EPI == EPI_BIAS_GELU && pass == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+        }
+        uint2 pk;
+        pk.x = pack_bf16x2(v[0], v[1]);
+        pk.y = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<uint2 *>(ep + (b * 16 + row16) * 256 + (((a * 2 + (q4 >> 1)) ^ row16) << 4) + (q4 & 1) * 8) = pk;
+      }
+      if (want_colsum && pass == 0) {
+        // sum over this wave's 64 j: the 16 lanes of a q4 group hold different j of the same four i
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sacc = cs[r];
+          sacc += dpp_f32_add<0x111>(sacc);
+          sacc += dpp_f32_add<0x112>(sacc);
+          sacc += dpp_f32_add<0x114>(sacc);
+          sacc += dpp_f32_add<0x118>(sacc);
+          if (row16 == 15 && i + r < Ni) atomicAdd(pr.colsum + i + r, sacc);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __bf16 *dst = (pass == 1) ? reinterpret_cast<__bf16 *>(pr.out2) : outb;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int jr = it * 4 + q4;          // row of the wave image
+      const int j = jw + jr, i = iw + row16 * 8;
+      const uint4 v = *reinterpret_cast<const uint4 *>(ep + jr * 256 + ((row16 ^ (jr & 15)) << 4));
+      if (j < Nj && i < Ni) *reinterpret_cast<uint4 *>(dst + (long)j * ldo + i) = v;  // Ni % 8 == 0 (host check)
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+}  // namespace bq
+
+// ======================================================================================================================
+// gemm64_kernel: 64 (i) x BJ (j) output tile, 4 waves (2 x 2), K step 64, three LDS stages filled by LDS-DMA.  For the
+// text side of the fusion (M = 80 .. 640 rows: latency-bound, many workgroups of little work each), the object-token
+// projections and every weight gradient with a short contraction.  Same operand formulation and LDS images as above.
+// ======================================================================================================================
+namespace bq {
+
+template <int BJ, bool P_XC, bool Q_XC, int EPI, bool OUT_F32>
+__global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
+  static_assert(BJ == 64 || (BJ == 32 && !Q_XC), "32-wide j tiles only for K-contiguous Q");
+  constexpr int QF = BJ / 32;               // 16-wide j fragments per wave
+  constexpr int Q_UNIT = BJ * 128;          // bytes of the Q image per stage
+  constexpr int STAGE = 8192 + Q_UNIT;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int t = blockIdx.x;
+  int pi = 0;
+  for (int k = 1; k < args.n; ++k)
+    if (t >= args.p[k].tile0) pi = k;
+  const GemmProblem &pr = args.p[pi];
+  const int tl = t - pr.tile0;
+  const int bj = tl / pr.tiles_i, bi = tl % pr.tiles_i;
+  const int i0 = bi * 64, j0 = bj * BJ;
+  const int Ni = pr.Ni, Nj = pr.Nj, Kc = pr.Kc;
+  const int ldp = pr.ldp, ldq = pr.ldq;
+  const int nkt = (Kc + 63) >> 6;
+
+  const unsigned p_bytes = P_XC ? (unsigned)(((long)(Kc - 1) * ldp + Ni) * 2) : (unsigned)(((long)(Ni - 1) * ldp + Kc) * 2);
+  const unsigned q_bytes = Q_XC ? (unsigned)(((long)(Kc - 1) * ldq + Nj) * 2) : (unsigned)(((long)(Nj - 1) * ldq + Kc) * 2);
+  const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void *)pr.P, 0, p_bytes, 0x00020000);
+  const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void *)pr.Q, 0, q_bytes, 0x00020000);
+  const int cp = lane & 7;
+  // P unit: 2 DMAs per wave (rows (2w+d)*8 + lane/8); Q unit: 2 (BJ = 64) or 1 (BJ = 32: rows w*8 + lane/8)
+  unsigned vp[2], vq[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const int ur = (wave * 2 + d) * 8 + (lane >> 3);
+    if (!P_XC) vp[d] = (unsigned)(((i0 + ur) * ldp + (cp ^ (ur & 7)) * 8) * 2);
+    else vp[d] = (unsigned)((ur * ldp + i0 + (cp ^ (xg(ur) << 1)) * 8) * 2);
+    const int uq = (BJ == 64) ? ur : wave * 8 + (lane >> 3);
+    if (!Q_XC) vq[d] = (unsigned)(((j0 + uq) * ldq + (cp ^ (uq & 7)) * 8) * 2);
+    else vq[d] = (unsigned)((uq * ldq + j0 + (cp ^ (xg(uq) << 1)) * 8) * 2);
+  }
+  const unsigned p_step = P_XC ? (unsigned)(64 * ldp * 2) : 128u;
+  const unsigned q_step = Q_XC ? (unsigned)(64 * ldq * 2) : 128u;
+  constexpr int NDMA = 2 + (BJ == 64 ? 2 : 1);  // LDS-DMAs per wave per stage
+
+  auto stage = [&](int kt) {
+    const bool live = kt < nkt;
+    const unsigned base = (unsigned)((kt % 3) * STAGE);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_void_t *)(smem + base + (wave * 2 + d) * 1024), 16,
+                                               live ? vp[d] : 0x80000000u, 0, 0, 0);
+      vp[d] += p_step;
+    }
+#pragma unroll
+    for (int d = 0; d < (BJ == 64 ? 2 : 1); ++d) {
+      const int blk = (BJ == 64) ? wave * 2 + d : wave;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_void_t *)(smem + base + 8192 + blk * 1024), 16,
+                                               live ? vq[d] : 0x80000000u, 0, 0, 0);
+      vq[d] += q_step;
+    }
+  };
+
+  const int row16 = lane & 15, q4 = lane >> 4;
+  const int kc_base = row16 * 128 + ((q4 ^ (row16 & 7)) << 4);
+  int xc_base[4];
+  {
+    const int q = (lane & 15) >> 2, p = lane & 3, g = (q >> 1) | ((q4 & 1) << 1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xc_base[s] = (8 * q4 + q) * 128 + ((s ^ g) << 5) + 8 * p;
+  }
+
+  f32x4 acc[2][QF];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < QF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage(0);
+  stage(1);
+  for (int kt = 0; kt < nkt; ++kt) {
+    // stage kt has landed for this wave (stage kt+1 may still be in flight); after the barrier: for every wave,
+    // and every wave has finished reading the buffer that stage kt+2 is about to overwrite
+    if (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    BQ_BARRIER();
+    stage(kt + 2);
+    const unsigned char *buf = smem + (kt % 3) * STAGE;
+    bf16x8 fa[2][2], fb[QF][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag<P_XC>(buf, wr * 2 + a, kk, kc_base, xc_base);
+#pragma unroll
+    for (int b = 0; b < QF; ++b)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fb[b][kk] = read_frag<Q_XC>(buf + 8192, wc * QF + b, kk, kc_base, xc_base);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < QF; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][kk], fb[b][kk], acc[a][b], 0, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- epilogue: straight from the accumulators (8-B bf16 / 16-B fp32 pieces of an output row) ---------------------
+  const int ldo = pr.ldo;
+  const int iw = i0 + wr * 32, jw = j0 + wc * (BJ / 2);
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int i = iw + a * 16 + q4 * 4;
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && pr.bias != nullptr && i < Ni) load_bias4(pr, i, b4);
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < QF; ++b) {
+      const int j = jw + b * 16 + row16;
+      const bool ok = j < Nj && i < Ni;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] + b4[r];
+      if (OUT_F32) {
+        if (ok) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(pr.out) + (long)j * ldo + i) = make_float4(v[0], v[1], v[2], v[3]);
+        continue;
+      }
+      if (EPI == EPI_DGELU && ok) {
+        const bf16x4 y = *reinterpret_cast<const bf16x4 *>(pr.aux + (long)j * ldo + i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= dgelu_f((float)y[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (float)(__bf16)v[r];
+      if (ok) {
+        uint2 pk;
+        pk.x = pack_bf16x2(v[0], v[1]);
+        pk.y = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<uint2 *>(reinterpret_cast<__bf16 *>(pr.out) + (long)j * ldo + i) = pk;
+        if (EPI == EPI_BIAS_GELU) {
+          pk.x = pack_bf16x2(gelu_f(v[0]), gelu_f(v[1]));
+          pk.y = pack_bf16x2(gelu_f(v[2]), gelu_f(v[3]));
+          *reinterpret_cast<uint2 *>(reinterpret_cast<__bf16 *>(pr.out2) + (long)j * ldo + i) = pk;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cs[r] += ok ? v[r] : 0.f;
+    }
+    if (!OUT_F32 && pr.colsum != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = cs[r];
+        s += dpp_f32_add<0x111>(s);
+        s += dpp_f32_add<0x112>(s);
+        s += dpp_f32_add<0x114>(s);
+        s += dpp_f32_add<0x118>(s);
+        if (row16 == 15 && i + r < Ni) atomicAdd(pr.colsum + i + r, s);
+      }
+    }
+  }
+}
+
+
+// ---- grouped column sums: out_p[n] = sum_m G_p[m][n] for a list of bf16 matrices, ONE launch -----------------------
+// (the bias gradients of every parked linear: reference autograd of nn.Linear's bias, torch `grad.sum(0)`).
+// Workgroup = 256 columns x up to 512 rows: thread = 8 columns (16-B loads) of every 8th row; the 8 row groups meet in
+// LDS, then one fp32 atomic per column (out is zeroed by the caller; a few hundred atomics per workgroup).
+struct ColsumProblem {
+  const __bf16 *g;
+  float *out;
+  int M, N, ld, wg0, cblocks;
+};
+constexpr int COLSUM_MAX_PROBLEMS = 96;
+constexpr int COLSUM_ROWS = 512;
+struct ColsumArgs {
+  int n;
+  ColsumProblem p[COLSUM_MAX_PROBLEMS];
+};
+
+__global__ __launch_bounds__(256) void colsum_grouped_kernel(const ColsumArgs args) {
+  __shared__ float red[8][256];
+  const int t = blockIdx.x;
+  int pi = 0;
+  for (int k = 1; k < args.n; ++k)
+    if (t >= args.p[k].wg0) pi = k;
+  const ColsumProblem &pr = args.p[pi];
+  const int tl = t - pr.wg0;
+  const int cb = tl % pr.cblocks, rb = tl / pr.cblocks;
+  const int tc = threadIdx.x & 31, tr = threadIdx.x >> 5;
+  const int col = cb * 256 + tc * 8;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col < pr.N) {  // N % 8 == 0
+    const int r1 = min(pr.M, (rb + 1) * COLSUM_ROWS);
+    for (int r = rb * COLSUM_ROWS + tr; r < r1; r += 8) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8 *>(pr.g + (long)r * pr.ld + col);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[tr][tc * 8 + e] = s[e];
+  __syncthreads();
+  const int c = threadIdx.x;
+  float tot = 0.f;
+#pragma unroll
+  for (int g8 = 0; g8 < 8; ++g8) tot += red[g8][c];
+  if (cb * 256 + c < pr.N) atomicAdd(pr.out + cb * 256 + c, tot);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+template <bool P_XC, bool Q_XC, int EPI, bool OUT_F32>
+static int launch_variant(const GemmArgs &ga, int tile, hipStream_t st) {
+  if (tile == 256) {
+    hipLaunchKernelGGL((gemm256_kernel<P_XC, Q_XC, EPI, OUT_F32>), dim3(ga.total_tiles), dim3(512), 0, st, ga);
+  } else if (tile == 64) {
+    hipLaunchKernelGGL((gemm64_kernel<64, P_XC, Q_XC, EPI, OUT_F32>), dim3(ga.total_tiles), dim3(256), 0, st, ga);
+  } else {
+    if constexpr (!Q_XC) {
+      hipLaunchKernelGGL((gemm64_kernel<32, P_XC, Q_XC, EPI, OUT_F32>), dim3(ga.total_tiles), dim3(256), 0, st, ga);
+    } else {
+      return -1;
+    }
+  }
+  return 0;
+}
+
+static int launch_gemm(const GemmArgs &ga, int flags, int epi, int tile, hipStream_t st) {
+  const bool pxc = flags & BQ_GEMM_P_XC, qxc = flags & BQ_GEMM_Q_XC, f32 = flags & BQ_GEMM_OUT_F32;
+  if (!pxc && !qxc && !f32) {
+    if (epi == EPI_NONE) return launch_variant<false, false, EPI_NONE, false>(ga, tile, st);
+    if (epi == EPI_BIAS) return launch_variant<false, false, EPI_BIAS, false>(ga, tile, st);
+    if (epi == EPI_BIAS_GELU) return launch_variant<false, false, EPI_BIAS_GELU, false>(ga, tile, st);
+  } else if (pxc && !qxc && !f32) {
+    if (epi == EPI_NONE) return launch_variant<true, false, EPI_NONE, false>(ga, tile, st);
+    if (epi == EPI_DGELU) return launch_variant<true, false, EPI_DGELU, false>(ga, tile, st);
+  } else if (pxc && qxc && f32) {
+    if (epi == EPI_NONE) return launch_variant<true, true, EPI_NONE, true>(ga, tile, st);
+  }
+  return -1;
+}
+
+}  // namespace bq
+
+extern "C" int bq_gemm_max_problems(void) { return bq::GEMM_MAX_PROBLEMS; }
+
+extern "C" int bq_gemm_bf16(const bq_gemm_desc *d, int n, int flags, int epilogue, int tile, void *stream) {
+  using namespace bq;
+  BQ_REQUIRE(d != nullptr && n >= 1, BQ_EINVAL, "bq_gemm_bf16: no problems");
+  BQ_REQUIRE(tile == 256 || tile == 64 || tile == 32, BQ_EINVAL, "bq_gemm_bf16: tile must be 256, 64 or 32 (got %d)", tile);
+  const bool pxc = flags & BQ_GEMM_P_XC, qxc = flags & BQ_GEMM_Q_XC, f32 = flags & BQ_GEMM_OUT_F32;
+  hipStream_t st = (hipStream_t)stream;
+  int done = 0;
+  while (done < n) {
+    GemmArgs ga;
+    ga.n = 0;
+    ga.total_tiles = 0;
+    while (done < n && ga.n < GEMM_MAX_PROBLEMS) {
+      const bq_gemm_desc &s = d[done];
+      BQ_REQUIRE(s.P && s.Q && s.out, BQ_EINVAL, "bq_gemm_bf16: null operand (problem %d)", done);
+      BQ_REQUIRE(s.Ni > 0 && s.Nj > 0 && s.Kc > 0, BQ_EINVAL, "bq_gemm_bf16: empty problem %d", done);
+      BQ_REQUIRE(s.ldp % 8 == 0 && s.ldq % 8 == 0, BQ_EINVAL, "bq_gemm_bf16: operand leading dimensions must be multiples of 8 elements");
+      BQ_REQUIRE(s.Ni % 8 == 0 && s.ldo % (f32 ? 4 : 8) == 0, BQ_EINVAL, "bq_gemm_bf16: Ni and ldo must be multiples of 8 (Ni = %d, ldo = %d)", s.Ni, s.ldo);
+      BQ_REQUIRE(!qxc || s.Nj % 8 == 0, BQ_EINVAL, "bq_gemm_bf16: a contraction-major Q needs Nj %% 8 == 0 (Nj = %d)", s.Nj);
+      BQ_REQUIRE((pxc || s.Kc % 64 == 0) && (qxc || s.Kc % 64 == 0), BQ_EINVAL,
+                 "bq_gemm_bf16: a K-contiguous operand needs Kc %% 64 == 0 (Kc = %d)", s.Kc);
+      BQ_REQUIRE(((uintptr_t)s.P % 16 == 0) && ((uintptr_t)s.Q % 16 == 0) && ((uintptr_t)s.out % 16 == 0), BQ_EINVAL,
+                 "bq_gemm_bf16: operands must be 16-byte aligned");
+      BQ_REQUIRE(epilogue != EPI_BIAS_GELU || s.out2, BQ_EINVAL, "bq_gemm_bf16: BIAS_GELU needs out2");
+      BQ_REQUIRE(epilogue != EPI_DGELU || s.aux, BQ_EINVAL, "bq_gemm_bf16: DGELU needs aux");
+      const long pb = pxc ? ((long)(s.Kc - 1) * s.ldp + s.Ni) * 2 : ((long)(s.Ni - 1) * s.ldp + s.Kc) * 2;
+      const long qb = qxc ? ((long)(s.Kc - 1) * s.ldq + s.Nj) * 2 : ((long)(s.Nj - 1) * s.ldq + s.Kc) * 2;
+      const int tj = tile == 256 ? 256 : tile, ti = tile == 256 ? 256 : 64;
+      // operand bytes (plus the rows of a ragged edge tile) must stay below the out-of-range sentinel of the DMA offsets
+      BQ_REQUIRE(pb + (long)ti * s.ldp * 2 < 0x7FFFFFFFL && qb + (long)tj * s.ldq * 2 < 0x7FFFFFFFL, BQ_EINVAL,
+                 "bq_gemm_bf16: operand larger than 2 GB (problem %d)", done);
+      GemmProblem &g = ga.p[ga.n];
+      g.P = (const __bf16 *)s.P; g.Q = (const __bf16 *)s.Q; g.out = s.out; g.bias = s.bias; g.out2 = s.out2;
+      g.aux = (const __bf16 *)s.aux; g.colsum = s.colsum;
+      g.ldp = s.ldp; g.ldq = s.ldq; g.ldo = s.ldo; g.Ni = s.Ni; g.Nj = s.Nj; g.Kc = s.Kc;
+      g.bias_bf16 = s.bias_bf16;
+      g.tiles_i = (s.Ni + ti - 1) / ti;
+      g.tile0 = ga.total_tiles;
+      ga.total_tiles += g.tiles_i * ((s.Nj + tj - 1) / tj);
+      ++ga.n;
+      ++done;
+    }
+    BQ_REQUIRE(launch_gemm(ga, flags, epilogue, tile, st) == 0, BQ_EINVAL,
+               "bq_gemm_bf16: unsupported combination flags=%d epilogue=%d tile=%d", flags, epilogue, tile);
+    int rc = check_launch("gemm_bf16");
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int bq_colsum_grouped_bf16(const bq_colsum_desc *d, int n, void *stream) {
+  using namespace bq;
+  BQ_REQUIRE(d != nullptr && n >= 1, BQ_EINVAL, "bq_colsum_grouped_bf16: no problems");
+  hipStream_t st = (hipStream_t)stream;
+  int done = 0;
+  while (done < n) {
+    ColsumArgs ca;
+    ca.n = 0;
+    int wgs = 0;
+    while (done < n && ca.n < COLSUM_MAX_PROBLEMS) {
+      const bq_colsum_desc &s = d[done];
+      BQ_REQUIRE(s.g && s.out && s.M > 0 && s.N > 0, BQ_EINVAL, "bq_colsum_grouped_bf16: bad problem %d", done);
+      BQ_REQUIRE(s.N % 8 == 0 && s.ld % 8 == 0 && ((uintptr_t)s.g % 16 == 0), BQ_EINVAL,
+                 "bq_colsum_grouped_bf16: N and ld must be multiples of 8, g 16-byte aligned");
+      ColsumProblem &c = ca.p[ca.n];
+      c.g = (const __bf16 *)s.g; c.out = s.out; c.M = s.M; c.N = s.N; c.ld = s.ld;
+      c.cblocks = (s.N + 255) / 256;
+      c.wg0 = wgs;
+      wgs += c.cblocks * ((s.M + COLSUM_ROWS - 1) / COLSUM_ROWS);
+      ++ca.n;
+      ++done;
+    }
+    hipLaunchKernelGGL(colsum_grouped_kernel, dim3(wgs), dim3(256), 0, st, ca);
+    int rc = check_launch("colsum_grouped");
+    if (rc) return rc;
+  }
+  return 0;
+}

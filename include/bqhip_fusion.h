@@ -141,6 +141,55 @@ BQ_API int bq_adamw_tensor_bytes(void);
 BQ_API int bq_adamw_multi(const void *table, const void *chunks, int n_chunks, const float *step, float beta1,
                           float beta2, float eps, void *stream);
 
+/* ---- MFMA bf16 GEMM family (csrc/gemm.hip) -----------------------------------------------------------------
+ * Replaces every nn.Linear of the fusion half and its autograd: models/vit.py:30-32 (Mlp fc1 / fc2), :51-53 (qkv /
+ * proj), timm PatchEmbed as a GEMM over 16x16x3 patches (vit.py:144-145), models/med.py:112-118 (query / key / value),
+ * :232 (BertSelfOutput.dense), :295 (BertIntermediate.dense), :310 (BertOutput.dense).
+ * One formulation:  out[j][i] = epilogue( sum_kc P(i, kc) * Q(j, kc) ),  bf16 operands, fp32 accumulation
+ * (v_mfma_f32_16x16x32_bf16), out row-major over j with i contiguous (leading dimension ldo).
+ *   P: K-contiguous  P[i*ldp + kc]  or, with BQ_GEMM_P_XC, contraction-major  P[kc*ldp + i]  (same for Q / ldq / j):
+ *     forward y = x W^T + b : P = W, Q = x            (flags 0,                  i = out feature, j = row)
+ *     dX = dY W            : P = W (P_XC), Q = dY      (BQ_GEMM_P_XC,             i = in feature,  j = row)
+ *     dW = dY^T X          : P = X (P_XC), Q = dY (Q_XC), fp32 out (P_XC|Q_XC|OUT_F32, i = in feature, j = out feature)
+ *   epilogue: BQ_GEMM_EPI_NONE; _BIAS: + bias[i] (fp32); _BIAS_GELU: out = bf16(acc + bias), out2 = gelu(out) (exact
+ *     erf GELU, vit.py act_layer=nn.GELU / med hidden_act "gelu"); _DGELU: out = acc * gelu'(aux[j][i]) (the backward
+ *     of the GELU fused into the dX GEMM of the layer after it).  colsum != NULL: colsum[i] += sum_j out[j][i] (fp32
+ *     atomics; the bias gradient of the layer that produced the operand).
+ *   tile: 256 = 256x256 tiles, 8 waves, LDS-DMA pipeline (large M); 64 / 32 = 64 x {64,32} tiles (small M; 32 needs a
+ *     K-contiguous Q).  All problems of one call run in ONE launch (grouped GEMM) and must share flags / epilogue.
+ * Requirements: 16-byte aligned operands, ldp / ldq / Ni / ldo multiples of 8 (ldo of 4 for fp32), Kc a multiple of
+ * 64 for K-contiguous operands (any Kc for contraction-major ones), operands below 2 GB. */
+#define BQ_GEMM_P_XC 1
+#define BQ_GEMM_Q_XC 2
+#define BQ_GEMM_OUT_F32 4
+#define BQ_GEMM_EPI_NONE 0
+#define BQ_GEMM_EPI_BIAS 1
+#define BQ_GEMM_EPI_BIAS_GELU 2
+#define BQ_GEMM_EPI_DGELU 3
+typedef struct bq_gemm_desc {
+  const void *P, *Q;
+  void *out;
+  const float *bias;
+  void *out2;
+  const void *aux;
+  float *colsum;
+  int ldp, ldq, ldo;
+  int Ni, Nj, Kc;
+  int bias_bf16; /* 0: bias is fp32 (a master parameter), 1: bias is bf16 (a concatenated operand copy) */
+} bq_gemm_desc;
+BQ_API int bq_gemm_max_problems(void); /* problems per launch; longer lists are split into several launches */
+BQ_API int bq_gemm_bf16(const bq_gemm_desc *problems, int n, int flags, int epilogue, int tile, void *stream);
+
+/* Column sums of a list of bf16 matrices in ONE launch: out[n] += sum_m g[m*ld + n] (fp32 atomics: out must be zeroed
+ * by the caller).  Replaces grad.sum(0), the bias gradient of nn.Linear, for every parked linear of a backward pass.
+ * N and ld multiples of 8, g 16-byte aligned. */
+typedef struct bq_colsum_desc {
+  const void *g;
+  float *out;
+  int M, N, ld;
+} bq_colsum_desc;
+BQ_API int bq_colsum_grouped_bf16(const bq_colsum_desc *problems, int n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,182 @@
+"""GPU parity of the MFMA bf16 GEMM family (csrc/gemm.hip) against a plain torch fp32 composition of the same op
+(the reference's nn.Linear and its autograd: models/vit.py:30-32,51-53; models/med.py:112-118,232,295,310).
+
+Tolerances: operands are bf16 on both sides; the kernels accumulate in fp32 and round ONCE to bf16 (fp32 for weight
+gradients), so an output differs from the fp32 reference by at most bf16 rounding: rel-L2 <= 3e-3 and
+max |err| <= 1e-2 * max |ref| for bf16 outputs, rel-L2 <= 1e-5 for fp32 outputs."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, dev, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev).to(torch.bfloat16)
+
+
+def _check(out, ref, f32=False):
+    out, ref = out.float(), ref.float()
+    assert torch.isfinite(out).all()
+    rel = ((out - ref).norm() / (ref.norm() + 1e-20)).item()
+    mx = ((out - ref).abs().max() / (ref.abs().max() + 1e-20)).item()
+    assert rel <= (1e-5 if f32 else 3e-3), (rel, mx)
+    assert mx <= (1e-4 if f32 else 1e-2), (rel, mx)
+
+
+def _gelu(x):
+    return torch.nn.functional.gelu(x)
+
+
+FWD_SHAPES = [(1000, 512, 192), (256, 256, 64), (2100, 1024, 256), (16400, 768, 768), (257, 264, 128)]
+
+
+@pytest.mark.parametrize("M,N,K", FWD_SHAPES)
+@pytest.mark.parametrize("tile", [256, 64, 32])
+def test_forward_bias(dev, M, N, K, tile):
+    from bridgeqa_amd import _ext
+    if tile != 256 and M * N > 4e6:
+        pytest.skip("small-tile kernels are for small problems")
+    x, w = _rand((M, K), dev, 1), _rand((N, K), dev, 2, 0.1)
+    b = torch.randn(N, device=dev)
+    y = _ext.gemm_fwd(x, w, b, tile=tile)
+    _check(y, x.float() @ w.float().t() + b)
+    y0 = _ext.gemm_fwd(x, w, None, tile=tile)
+    _check(y0, x.float() @ w.float().t())
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 192), (2100, 1024, 256), (320, 3072, 768)])
+@pytest.mark.parametrize("tile", [256, 64, 32])
+def test_forward_bias_gelu(dev, M, N, K, tile):
+    from bridgeqa_amd import _ext
+    x, w = _rand((M, K), dev, 3), _rand((N, K), dev, 4, 0.1)
+    b = torch.randn(N, device=dev)
+    y, act = _ext.gemm_fwd(x, w, b, gelu=True, tile=tile)
+    ref = x.float() @ w.float().t() + b
+    _check(y, ref)
+    _check(act, _gelu(y.float()))          # the activation is taken at the SAVED (bf16) pre-activation
+    _check(act, _gelu(ref))
+
+
+def test_identity_asymmetric(dev):
+    """P = I with an asymmetric Q catches a transposed or permuted output map (integer data: exact)"""
+    from bridgeqa_amd import _ext
+    N = 256
+    w = torch.eye(N, device=dev, dtype=torch.bfloat16)
+    x = (torch.arange(512 * N, device=dev).reshape(512, N) % 251).to(torch.bfloat16)
+    for tile in (256, 64, 32):
+        y = _ext.gemm_fwd(x, w, None, tile=tile)
+        assert torch.equal(y, x), tile
+        dx = _ext.gemm_dx(x, w, tile=tile)
+        assert torch.equal(dx, x), tile
+    dw = _ext.gemm_dw(torch.eye(512, device=dev, dtype=torch.bfloat16)[:, :256].contiguous(), x[:512], tile=256)
+    assert torch.equal(dw, x[:256].float())
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 384, 512), (1500, 768, 256), (16400, 768, 768), (320, 768, 3072), (80, 1536, 768)])
+@pytest.mark.parametrize("tile", [256, 64, 32])
+def test_dx(dev, M, N, K, tile):
+    """dx = dy @ W (contraction over N): P = W contraction-major (transposed LDS reads)"""
+    from bridgeqa_amd import _ext
+    if tile != 256 and M * K > 4e6:
+        pytest.skip("small-tile kernels are for small problems")
+    dy, w = _rand((M, N), dev, 5), _rand((N, K), dev, 6, 0.1)
+    dx = _ext.gemm_dx(dy, w, tile=tile)
+    _check(dx, dy.float() @ w.float())
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 384, 512), (2000, 768, 3072), (320, 768, 3072)])
+@pytest.mark.parametrize("tile", [256, 64, 32])
+def test_dx_dgelu_colsum(dev, M, N, K, tile):
+    """the fc2 input gradient with the GELU derivative and fc1's bias gradient fused in"""
+    from bridgeqa_amd import _ext
+    dy, w = _rand((M, N), dev, 7), _rand((N, K), dev, 8, 0.1)
+    pre = _rand((M, K), dev, 9, 1.5)
+    cs = torch.zeros(K, device=dev)
+    dx = _ext.gemm_dx(dy, w, pre_act=pre, colsum=cs, tile=tile)
+    p32 = pre.float().requires_grad_(True)
+    _gelu(p32).backward(dy.float() @ w.float())
+    _check(dx, p32.grad)
+    ref_cs = dx.float().sum(0)
+    assert ((cs - ref_cs).abs().max() / (ref_cs.abs().max() + 1e-20)).item() < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 768), (1024, 256, 256), (16400, 768, 768), (320, 3072, 768), (80, 768, 768), (20, 768, 1536)])
+@pytest.mark.parametrize("tile", [256, 64])
+def test_dw(dev, M, N, K, tile):
+    """dw = dy^T @ x (contraction over the M rows, any M: the ragged last K tile is zero-filled by the bounds-checked
+    LDS-DMA), fp32 out"""
+    from bridgeqa_amd import _ext
+    dy, x = _rand((M, N), dev, 10), _rand((M, K), dev, 11)
+    dw = _ext.gemm_dw(dy, x, tile=tile)
+    _check(dw, dy.float().t() @ x.float(), f32=True)
+
+
+def test_grouped_launch(dev):
+    """several problems of different sizes in ONE launch (the deferred weight gradients of a layer stack)"""
+    from bridgeqa_amd import _ext
+    probs, refs = [], []
+    for k, (M, N, K) in enumerate([(700, 768, 768), (1000, 2304, 768), (512, 768, 3072), (999, 3072, 768)] * 3):
+        dy, x = _rand((M, N), dev, 20 + k), _rand((M, K), dev, 40 + k)
+        out = torch.empty(N, K, device=dev)
+        probs.append(dict(P=x, Q=dy, out=out))
+        refs.append(dy.float().t() @ x.float())
+    for tile in (256, 64):
+        for p in probs:
+            p["out"].fill_(float("nan"))
+        _ext.gemm_grouped(probs, _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32, _ext.EPI_NONE, tile)
+        for p, r in zip(probs, refs):
+            _check(p["out"], r, f32=True)
+    # more problems than one launch holds
+    many = []
+    for k in range(_ext._lib.bq_gemm_max_problems() + 5):
+        x, w = _rand((90, 128), dev, 100 + k), _rand((64, 128), dev, 200 + k)
+        many.append(dict(P=w, Q=x, out=torch.empty(90, 64, device=dev, dtype=torch.bfloat16)))
+    _ext.gemm_grouped(many, 0, _ext.EPI_NONE, 32)
+    for p in many:
+        _check(p["out"], p["Q"].float() @ p["P"].float().t())
+
+
+def test_strided_operands(dev):
+    """operands that are column slices of wider tensors (a fused QKV output, a slice of a hoisted projection)"""
+    from bridgeqa_amd import _ext
+    big = _rand((1100, 2304), dev, 60)
+    x = big[:, 768:1536]
+    w = _rand((768, 768), dev, 61, 0.1)
+    outbig = torch.zeros(1100, 1536, device=dev, dtype=torch.bfloat16)
+    out = outbig[:, 768:]
+    _ext.gemm_grouped([dict(P=w, Q=x, out=out)], 0, _ext.EPI_NONE, 256)
+    _check(out, x.float() @ w.float().t())
+    assert outbig[:, :768].abs().max().item() == 0
+
+
+def test_repeatable_under_load(dev):
+    """The K loop keeps LDS-DMA stages in flight across barriers: a mis-placed wait shows up as rare wrong tiles.
+    Same inputs, many launches back to back (a warm and a cold L2), every output bit-identical to the first and equal
+    to the reference."""
+    from bridgeqa_amd import _ext
+    x, w = _rand((16400, 768), dev, 70), _rand((3072, 768), dev, 71, 0.1)
+    dy = _rand((16400, 3072), dev, 72)
+    ref = x.float() @ w.float().t()
+    y0 = _ext.gemm_fwd(x, w, None, tile=256)
+    _check(y0, ref)
+    dx0 = _ext.gemm_dx(dy, w, tile=256)
+    _check(dx0, dy.float() @ w.float())
+    dw0 = _ext.gemm_dw(dy, x, tile=256)
+    _check(dw0, dy.float().t() @ x.float(), f32=True)
+    junk = torch.empty(1 << 28, device=dev, dtype=torch.uint8)
+    for it in range(12):
+        if it % 3 == 0:
+            junk.fill_(it)  # evict L2 / Infinity Cache
+        assert torch.equal(_ext.gemm_fwd(x, w, None, tile=256), y0), it
+        assert torch.equal(_ext.gemm_dx(dy, w, tile=256), dx0), it
+        assert torch.equal(_ext.gemm_dw(dy, x, tile=256), dw0), it
+
+
+def test_rejects_bad_arguments(dev):
+    from bridgeqa_amd import _ext
+    x, w = _rand((64, 100), dev, 80), _rand((64, 100), dev, 81)
+    with pytest.raises(RuntimeError):
+        _ext.gemm_fwd(x, w)                       # K-contiguous operands need K % 64 == 0 (and ld % 8 == 0)
+    with pytest.raises(RuntimeError):
+        _ext.gemm_fwd(x.cpu(), w.cpu())           # no CPU path

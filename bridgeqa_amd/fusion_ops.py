@@ -106,7 +106,6 @@ def _c(t):
 
 
 _SHADOW = {}
-_MM_OUT_DTYPE = [None]  # does torch.mm accept out_dtype on this build? (probed on first use)
 
 
 def _shadow(t):
@@ -174,101 +173,72 @@ def refresh_shadows(only_with_grad=True):
     return len(dst)
 
 
-def _dw_f32(g2, x2):
-    """dW = g2^T @ x2 in fp32 for bf16 (M, N), (M, K).  With a long reduction (M = batch * tokens) and a small
-    (N, K) output hipBLASLt launches too few tiles to fill 256 CUs (measured 166-520 TFLOP/s); splitting M into S
-    batches (one bmm) and adding the S partial products restores 430-750 (tools/bench_dw.py)."""
-    M, N = g2.shape
-    K = x2.shape[1]
-    if (g2.is_cuda and g2.dtype == torch.bfloat16 and M >= 4096 and _MM_OUT_DTYPE[0] is not False
-            and g2.is_contiguous() and x2.is_contiguous()):
-        for S in ((16, 8, 4, 5, 2) if N * K <= (1 << 20) else (4, 8, 5, 2)):
-            if M % S == 0:
-                try:
-                    return torch.bmm(g2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, K),
-                                     out_dtype=torch.float32).sum(0)
-                except (TypeError, RuntimeError):
-                    break
-    return _mm_f32(g2.t(), x2)
+# ---- native GEMMs (csrc/gemm.hip through _ext.gemm_*) ------------------------------------------------------------
+# Every nn.Linear of the fusion half on the bf16 CUDA path: forward (+bias, +GELU), input gradient (+GELU derivative,
+# +bias gradient of the layer before), weight gradient (fp32).  BQ_TORCH_GEMM=1 is a MEASUREMENT knob only: it routes
+# the same call sites to torch (hipBLASLt) so that bench.py can A/B the kernels inside the whole step.
+_NATIVE_GEMM = [__import__("os").environ.get("BQ_TORCH_GEMM", "0") != "1"]
+
+
+def _rows(t):
+    """(M, K) bf16 view/copy the GEMM kernels accept: contiguous last dim, 16-B aligned rows"""
+    t2 = t.reshape(-1, t.shape[-1])
+    if t2.dtype != torch.bfloat16:
+        t2 = t2.to(torch.bfloat16)
+    if t2.stride(1) != 1 or t2.stride(0) % 8 or t2.data_ptr() % 16:
+        t2 = t2.contiguous()
+    return t2
+
+
+def _native_ok(t, N, K):
+    return _NATIVE_GEMM[0] and t.is_cuda and _COMPUTE_DTYPE == torch.bfloat16 and K % 64 == 0 and N % 8 == 0
+
+
+def _f32_bias(bias):
+    """the fp32 master bias itself when possible (no operand copy needed: the kernel adds fp32), else its shadow"""
+    if bias is None:
+        return None
+    if bias.dtype == torch.float32 and bias.is_contiguous():
+        return bias.detach()
+    return _shadow(bias)
 
 
 def _mm_f32(a, b):
-    """a @ b for bf16 operands with an fp32 result (weight gradients are accumulated and applied in fp32)."""
-    if _MM_OUT_DTYPE[0] is None:
-        try:
-            torch.mm(a[:1], b[:, :1], out_dtype=torch.float32)
-            _MM_OUT_DTYPE[0] = True
-        except Exception:
-            _MM_OUT_DTYPE[0] = False
-    if _MM_OUT_DTYPE[0]:
-        return torch.mm(a, b, out_dtype=torch.float32)
-    return torch.mm(a, b).float()
-
-
-_WGRAD = [False]
-_WGRAD_MAX_ROWS = 4096
-
-
-def set_wgrad_overlap(flag):
-    """While on, the backward of a (multi_)linear over <= 4096 rows computes dW and db on a side stream ("wgrad"):
-    only dX is on the critical path of a backward pass made of hundreds of 5-10 us kernels, and short kernels of
-    different streams do overlap on this GPU.  The caller MUST call join_wgrad() before anything reads the parameter
-    gradients (pipeline.PhasedTrainStep does, at the end of the fusion phase).  Returns the previous setting."""
-    prev, _WGRAD[0] = _WGRAD[0], bool(flag)
-    return prev
-
-
-def _wgrad_stream(g2, x2):
-    """the side stream for this backward's dW / db (ordered after the current stream), or None"""
-    if not (_WGRAD[0] and _OVERLAP[0] and g2.is_cuda and g2.shape[0] <= _WGRAD_MAX_ROWS):
-        return None
-    cur = torch.cuda.current_stream(g2.device)
-    side = side_stream("wgrad", g2.device)
-    side.wait_stream(cur)
-    g2.record_stream(side)
-    x2.record_stream(side)
-    return side
-
-
-def join_wgrad(device):
-    """the current stream waits for every weight / bias gradient issued on the wgrad stream so far"""
-    key = ("wgrad", device.index if device.index is not None else torch.cuda.current_device())
-    if key in _SIDE_STREAMS:
-        torch.cuda.current_stream(device).wait_stream(_SIDE_STREAMS[key])
+    """a @ b for bf16 operands with an fp32 result (torch fallback of the weight gradient)"""
+    return torch.mm(a.float(), b.float()) if not a.is_cuda else torch.mm(a, b, out_dtype=torch.float32)
 
 
 def _dw_db(g2, x2, need_dw, need_db):
+    """weight / bias gradient of one linear, now: dW = g2^T x2 (fp32), db = column sums of g2 (fp32)"""
     dw = db = None
+    native = g2.is_cuda and g2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and g2.shape[1] % 8 == 0 \
+        and x2.shape[1] % 8 == 0 and _NATIVE_GEMM[0]
     if need_dw:
-        dw = _dw_f32(g2, x2)
-    if need_db:
-        if g2.is_cuda and g2.dtype == torch.bfloat16 and g2.shape[1] % 4 == 0 and g2.is_contiguous():
+        if native:
             from . import _ext
-            db = _ext.colsum(g2)
+            dw = _ext.gemm_dw(_rows(g2), _rows(x2), tile=256 if g2.shape[0] >= _BIG_ROWS else 64)
+        else:
+            dw = _mm_f32(g2.t(), x2)
+    if need_db:
+        if native:
+            from . import _ext
+            db = _ext.colsum_grouped([_rows(g2)])[0]
         else:
             db = g2.sum(0, dtype=torch.float32)
     return dw, db
 
 
-def _dw_db_maybe_forked(g2, x2, need_dw, need_db):
-    side = _wgrad_stream(g2, x2) if (need_dw or need_db) else None
-    if side is None:
-        return _dw_db(g2, x2, need_dw, need_db)
-    with torch.cuda.stream(side):
-        return _dw_db(g2, x2, need_dw, need_db)
-
-
-# ---- deferred, batched weight gradients ---------------------------------------------------------------------
+# ---- deferred, grouped weight gradients ---------------------------------------------------------------------------
+# dW / db are not on the critical path of a backward pass.  Inside a begin/flush scope the backward of every bf16
+# linear computes ONLY dX and parks (dY, X, parameters); flush_deferred_wgrad() then produces ALL weight gradients
+# of the scope with ONE grouped GEMM launch per tile class (12 ViT blocks x 4 linears = 48 problems, 1296 tiles of
+# 256 x 256 with the full 16400-row contraction each -- instead of 48 launches of 27-36 tiles) and ALL bias gradients
+# with one grouped column-sum launch.  MI355X has the HBM for it: the parked dY of config c3 are 2.7 GB.
 _DEFER = [None]
-_DEFER_MAX_ROWS = int(__import__("os").environ.get("BQ_DEFER_MAX_ROWS", "4096"))
-_DEFER_STACK_MAX_ROWS = 4096  # larger operands are parked too, but multiplied one by one (stacking would copy GBs)
+_BIG_ROWS = 1024  # contractions at least this long run on the 256 x 256 kernel
 
 
 def begin_deferred_wgrad():
-    """From now until flush_deferred_wgrad(), the backward of every bf16 (multi_)linear over <= 4096 rows computes
-    ONLY dX and parks (dY, X, parameters): dW / db are not on the critical path of the backward pass, and parked
-    together the ~60 identical-shape products of a 12-layer stack become ONE batched GEMM + ONE reduction
-    (the text side of c3: ~700 launches of 5-10 us -> ~60)."""
     _DEFER[0] = []
 
 
@@ -286,75 +256,144 @@ def flush_deferred_wgrad():
     items, _DEFER[0] = _DEFER[0], None
     if not items:
         return
-    groups = {}
-    for it in items:
-        g2, x2, ws, bs = it
-        groups.setdefault((tuple(g2.shape), tuple(x2.shape), len(ws), bs is not None), []).append(it)
-    for (gs, xs, k, has_b), its in groups.items():
-        if len(its) == 1 or gs[0] > _DEFER_STACK_MAX_ROWS:
-            pairs = [_dw_db(it[0], it[1], True, has_b) for it in its]
-            dws, dbs = [p_[0] for p_ in pairs], [p_[1] for p_ in pairs]
-        else:
-            G = torch.stack([it[0] for it in its])          # (n, M, N)
-            X = torch.stack([it[1] for it in its])          # (n, M, K)
-            dW = torch.bmm(G.transpose(1, 2), X, out_dtype=torch.float32)
-            dws = dW.unbind(0)
-            dbs = G.sum(dim=1, dtype=torch.float32).unbind(0) if has_b else [None] * len(its)
-        for (g2, x2, ws, bs), dw, db in zip(its, dws, dbs):
-            n = dw.shape[0] // k
-            for j, w in enumerate(ws):
-                _accumulate_grad(w, dw[j * n:(j + 1) * n] if k > 1 else dw)
-                if has_b:
-                    _accumulate_grad(bs[j], db[j * n:(j + 1) * n] if k > 1 else db)
+    from . import _ext
+    flags = _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32
+    dws = [None] * len(items)
+    for tile, pick in ((256, lambda m: m >= _BIG_ROWS), (64, lambda m: m < _BIG_ROWS)):
+        idx = [k for k, it in enumerate(items) if pick(it[0].shape[0])]
+        if not idx:
+            continue
+        probs = []
+        for k in idx:
+            g2, x2 = items[k][0], items[k][1]
+            dws[k] = torch.empty(g2.shape[1], x2.shape[1], dtype=torch.float32, device=g2.device)
+            probs.append(dict(P=x2, Q=g2, out=dws[k]))
+        _ext.gemm_grouped(probs, flags, _ext.EPI_NONE, tile)
+    with_b = [k for k, it in enumerate(items) if it[3] is not None]
+    dbs = dict(zip(with_b, _ext.colsum_grouped([items[k][0] for k in with_b]))) if with_b else {}
+    for k, (g2, x2, ws, bs) in enumerate(items):
+        n = g2.shape[1] // len(ws)
+        for j, w in enumerate(ws):
+            _accumulate_grad(w, dws[k][j * n:(j + 1) * n] if len(ws) > 1 else dws[k].view(w.shape))
+            if bs is not None:
+                _accumulate_grad(bs[j], dbs[k][j * n:(j + 1) * n] if len(ws) > 1 else dbs[k])
 
 
 def _defer_ok(g2, x2):
-    return (_DEFER[0] is not None and g2.is_cuda and g2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
-            and g2.shape[0] <= _DEFER_MAX_ROWS and g2.is_contiguous() and x2.is_contiguous())
+    return (_DEFER[0] is not None and _NATIVE_GEMM[0] and g2.is_cuda and g2.dtype == torch.bfloat16
+            and x2.dtype == torch.bfloat16 and g2.shape[1] % 8 == 0 and x2.shape[1] % 8 == 0)
+
+
+def _park(g2, x2, ws, bs):
+    _DEFER[0].append((_rows(g2), _rows(x2), ws, bs))
 
 
 class _LinearFn(torch.autograd.Function):
-    """bf16-operand linear with fp32 master weights: the forward reads the bf16 shadow of W / b, the backward
-    produces dW and db directly in fp32 (no per-parameter cast kernels in either direction)."""
+    """bf16-operand linear with fp32 master weights: the forward reads the bf16 shadow of W and the fp32 bias itself
+    (bias / GELU in the GEMM epilogue), the backward produces dX with the same kernel family and dW / db in fp32
+    (parked inside a deferred-wgrad scope)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, gelu):
         wb = _shadow(weight)
+        if wb.dim() > 2:  # a convolution whose stride equals its kernel (ViT patch embedding): (N, C, kh, kw) = (N, K)
+            wb = wb.view(wb.shape[0], -1)
+        N, K = wb.shape
+        ctx.gelu, ctx.has_bias, ctx.x_dtype, ctx.x_shape = gelu, bias is not None, x.dtype, x.shape
+        ctx.params = (weight, bias)
+        if _native_ok(x, N, K):
+            from . import _ext
+            x2 = _rows(x)
+            out = _ext.gemm_fwd(x2, wb, _f32_bias(bias), gelu=gelu)
+            if gelu:
+                ctx.save_for_backward(x2, wb, out[0])
+                return out[1].view(*x.shape[:-1], N)
+            ctx.save_for_backward(x2, wb)
+            return out.view(*x.shape[:-1], N)
         bb = _shadow(bias) if bias is not None else None
         xb = x if x.dtype == _COMPUTE_DTYPE else x.to(_COMPUTE_DTYPE)
         y = F.linear(xb, wb, bb)
-        ctx.gelu = gelu
-        ctx.has_bias = bias is not None
-        ctx.x_dtype = x.dtype
-        ctx.params = (weight, bias)
         if gelu:
-            ctx.save_for_backward(xb, wb, y)
-            if y.is_cuda and y.dtype == torch.bfloat16 and y.is_contiguous() and y.numel() % 8 == 0 and y.numel() >= (1 << 20):
-                from . import _ext
-                return _ext.gelu_fwd(y)  # large activations (ViT fc1): 16-B vector kernel at HBM rate
+            ctx.save_for_backward(xb.reshape(-1, K), wb, y.reshape(-1, N))
             return F.gelu(y)
-        ctx.save_for_backward(xb, wb)
+        ctx.save_for_backward(xb.reshape(-1, K), wb)
         return y
 
     @staticmethod
     def backward(ctx, g):
         if ctx.gelu:
-            xb, wb, y = ctx.saved_tensors
-            g = torch.ops.aten.gelu_backward(g, y)
+            x2, wb, y = ctx.saved_tensors
+            g2 = torch.ops.aten.gelu_backward(g.reshape(-1, g.shape[-1]), y)
         else:
-            xb, wb = ctx.saved_tensors
-        g2 = g.reshape(-1, g.shape[-1])
-        x2 = xb.reshape(-1, xb.shape[-1])
+            x2, wb = ctx.saved_tensors
+            g2 = g.reshape(-1, g.shape[-1])
+        N, K = wb.shape
+        native = _native_ok(g2, N, K)
+        if native:
+            g2 = _rows(g2)
+        w, b = ctx.params
+        dw = db = None
         if _defer_ok(g2, x2) and ctx.needs_input_grad[1]:
-            w, b = ctx.params
-            _DEFER[0].append((g2, x2, [w], [b] if ctx.has_bias else None))
-            dw = db = None
+            _park(g2, x2, [w], [b] if ctx.has_bias else None)
         else:
-            dw, db = _dw_db_maybe_forked(g2, x2, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+            dw, db = _dw_db(g2, x2, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.mm(g2, wb).view(xb.shape).to(ctx.x_dtype)
-        return dx, dw, db, None
+            if native:
+                from . import _ext
+                dx = _ext.gemm_dx(g2, wb)
+            else:
+                dx = torch.mm(g2, wb)
+            dx = dx.view(ctx.x_shape).to(ctx.x_dtype)
+        return dx, (dw.view(w.shape) if dw is not None else None), db, None
+
+
+class _MlpFn(torch.autograd.Function):
+    """fc2(gelu(fc1(x))) as ONE autograd node (reference models/vit.py:23-41 Mlp; models/med.py:292-317
+    BertIntermediate + BertOutput.dense), so that the backward can fuse across the two layers:
+      forward : GEMM(+b1, GELU epilogue: pre-activation and activation written by the same launch), GEMM(+b2)
+      backward: dY1 = (dY2 W2) * gelu'(y1) and db1 = colsum(dY1) in ONE launch (dGELU + column-sum epilogue),
+                dX = dY1 W1, dW1 / dW2 / db2 parked for the grouped launch (or computed at once outside a scope)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        from . import _ext
+        w1b, w2b = _shadow(w1), _shadow(w2)
+        x2 = _rows(x)
+        y1, h = _ext.gemm_fwd(x2, w1b, _f32_bias(b1), gelu=True)
+        y2 = _ext.gemm_fwd(h, w2b, _f32_bias(b2))
+        ctx.save_for_backward(x2, y1, h, w1b, w2b)
+        ctx.params = (w1, b1, w2, b2)
+        ctx.x_dtype, ctx.x_shape = x.dtype, x.shape
+        return y2.view(*x.shape[:-1], w2b.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _ext
+        x2, y1, h, w1b, w2b = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.params
+        g2 = _rows(g)
+        db1 = torch.zeros(w1b.shape[0], dtype=torch.float32, device=g2.device) if b1 is not None else None
+        dy1 = _ext.gemm_dx(g2, w2b, pre_act=y1, colsum=db1)
+        dx = _ext.gemm_dx(dy1, w1b).view(ctx.x_shape).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
+        if _DEFER[0] is not None:
+            _park(g2, h, [w2], [b2] if b2 is not None else None)
+            _park(dy1, x2, [w1], None)
+            dw1 = dw2 = db2 = None
+        else:
+            dw2, db2 = _dw_db(g2, h, True, b2 is not None)
+            dw1, _ = _dw_db(dy1, x2, True, False)
+        return dx, dw1, db1, dw2, db2
+
+
+def mlp(x, fc1, fc2):
+    """fc2(gelu(fc1(x))) for two nn.Linear modules; one fused autograd node on the bf16 CUDA path"""
+    w1, w2 = fc1.weight, fc2.weight
+    if (_native_ok(x, w1.shape[0], w1.shape[1]) and _native_ok(x, w2.shape[0], w2.shape[1])
+            and all(isinstance(t, torch.nn.Parameter) and t.dtype == torch.float32
+                    for t in (w1, w2, fc1.bias, fc2.bias) if t is not None)):
+        return _MlpFn.apply(x, w1, fc1.bias, w2, fc2.bias)
+    return linear(linear(x, w1, fc1.bias, act="gelu"), w2, fc2.bias)
 
 
 _CAT_CACHE = {}
@@ -402,27 +441,42 @@ class _MultiLinearFn(torch.autograd.Function):
         k = len(wb) // 2
         weights, biases = wb[:k], wb[k:]
         wc, bc = _cat_shadow(weights, biases)
+        ctx.k, ctx.x_dtype, ctx.x_shape = k, x.dtype, x.shape
+        ctx.params = (weights, biases)
+        if _native_ok(x, wc.shape[0], wc.shape[1]):
+            from . import _ext
+            x2 = _rows(x)
+            y = _ext.gemm_fwd(x2, wc, bc)  # (bc is the bf16 concatenation of the k biases: bias_bf16 form)
+            ctx.save_for_backward(x2, wc)
+            return y.view(*x.shape[:-1], k, wc.shape[0] // k)
         xb = x if x.dtype == _COMPUTE_DTYPE else x.to(_COMPUTE_DTYPE)
         y = F.linear(xb, wc, bc)
-        ctx.save_for_backward(xb, wc)
-        ctx.k, ctx.x_dtype = k, x.dtype
-        ctx.params = (weights, biases)
+        ctx.save_for_backward(xb.reshape(-1, xb.shape[-1]), wc)
         return y.view(*y.shape[:-1], k, y.shape[-1] // k)
 
     @staticmethod
     def backward(ctx, g):
-        xb, wc = ctx.saved_tensors
+        x2, wc = ctx.saved_tensors
         k = ctx.k
         g2 = g.reshape(-1, g.shape[-2] * g.shape[-1])
-        if not g2.is_contiguous():
+        native = _native_ok(g2, wc.shape[0], wc.shape[1])
+        if native:
+            g2 = _rows(g2)
+        elif not g2.is_contiguous():
             g2 = g2.contiguous()
-        x2 = xb.reshape(-1, xb.shape[-1])
-        dx = torch.mm(g2, wc).view(xb.shape).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if native:
+                from . import _ext
+                dx = _ext.gemm_dx(g2, wc)
+            else:
+                dx = torch.mm(g2, wc)
+            dx = dx.view(ctx.x_shape).to(ctx.x_dtype)
         if _defer_ok(g2, x2):
             ws, bs = ctx.params
-            _DEFER[0].append((g2, x2, list(ws), list(bs)))
+            _park(g2, x2, list(ws), list(bs))
             return (dx,) + (None,) * (2 * k)
-        dw, db = _dw_db_maybe_forked(g2, x2, True, True)
+        dw, db = _dw_db(g2, x2, True, True)
         n = dw.shape[0] // k
         return (dx,) + tuple(dw[i * n:(i + 1) * n] for i in range(k)) + tuple(db[i * n:(i + 1) * n] for i in range(k))
 
@@ -443,6 +497,8 @@ def linear(x, weight, bias=None, act=None):
     if (_COMPUTE_DTYPE != torch.float32 and x.is_cuda and isinstance(weight, torch.nn.Parameter)
             and weight.dtype == torch.float32 and (bias is None or isinstance(bias, torch.nn.Parameter))):
         return _LinearFn.apply(x, weight, bias, act == "gelu")
+    if weight.dim() > 2:
+        weight = weight.reshape(weight.shape[0], -1)
     y = F.linear(_c(x), _c(weight), _c(bias) if bias is not None else None)
     if act == "gelu":
         y = F.gelu(y)  # exact (erf) GELU: vit.py act_layer=nn.GELU, med_config hidden_act "gelu"
@@ -740,11 +796,26 @@ class HoistedKV(object):
         return _TailKVFn.apply(t, self, i).view(B, L2, 2, self.heads, -1)
 
 
+def _fwd2(x2, w, b):
+    """x2 @ w^T + b for bf16 (M, K) rows and an (N, K) bf16 operand (b bf16 or fp32), native kernels when eligible"""
+    if _native_ok(x2, w.shape[0], w.shape[1]):
+        from . import _ext
+        return _ext.gemm_fwd(_rows(x2), w, b)
+    return F.linear(x2, w, b if b is None or b.dtype == x2.dtype else b.to(x2.dtype))
+
+
+def _dx2(g2, w):
+    if _native_ok(g2, w.shape[0], w.shape[1]):
+        from . import _ext
+        return _ext.gemm_dx(_rows(g2), w)
+    return torch.mm(g2, w)
+
+
 class _HoistedKVFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, hold, *wb):
         xb = x if x.dtype == _COMPUTE_DTYPE else x.to(_COMPUTE_DTYPE)
-        y = F.linear(xb, hold.wc, hold.bc)
+        y = _fwd2(xb.reshape(-1, xb.shape[-1]), hold.wc, hold.bc).view(*xb.shape[:-1], hold.wc.shape[0])
         ctx.save_for_backward(xb)
         ctx.hold, ctx.x_dtype, ctx.k = hold, x.dtype, len(wb) // 2
         B, L1 = y.shape[:2]
@@ -766,12 +837,13 @@ class _HoistedKVFn(torch.autograd.Function):
         hold.G = None
         G2 = G.view(-1, G.shape[-1])
         x2 = xb.reshape(-1, xb.shape[-1])
-        dx = torch.mm(G2, hold.wc).view(xb.shape).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
+        dx = _dx2(G2, hold.wc).view(xb.shape).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
         dw, db = _dw_db(G2, x2, True, True)
         n = dw.shape[0] // hold.n
         for slot, g2, t2 in hold.tails:  # the per-layer second segments went through the same weights
-            dw[slot * n:(slot + 1) * n].add_(_mm_f32(g2.t(), t2))
-            db[slot * n:(slot + 1) * n].add_(g2.sum(0, dtype=torch.float32))
+            dwt, dbt = _dw_db(g2, t2, True, True)
+            dw[slot * n:(slot + 1) * n].add_(dwt)
+            db[slot * n:(slot + 1) * n].add_(dbt)
         hold.tails = []
         h = n // 2
         k = ctx.k
@@ -790,7 +862,7 @@ class _TailKVFn(torch.autograd.Function):
         tb = t if t.dtype == _COMPUTE_DTYPE else t.to(_COMPUTE_DTYPE)
         ctx.save_for_backward(tb, w)
         ctx.hold, ctx.i, ctx.t_dtype = hold, i, t.dtype
-        return F.linear(tb, w, b)
+        return _fwd2(tb.reshape(-1, tb.shape[-1]), w, b).view(*tb.shape[:-1], w.shape[0])
 
     @staticmethod
     def backward(ctx, g):
@@ -799,7 +871,7 @@ class _TailKVFn(torch.autograd.Function):
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         ctx.hold.tails.append((ctx.i, g2, tb.reshape(-1, tb.shape[-1])))
-        return torch.mm(g2, w).view(tb.shape).to(ctx.t_dtype), None, None
+        return _dx2(g2, w).view(tb.shape).to(ctx.t_dtype), None, None
 
 
 _MASK2_CACHE = {}

@@ -263,8 +263,13 @@ class BertOutputParallel(BertOutput):
         self.LayerNorms = nn.ModuleList([nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
                                          for _ in range(1)])
 
-    def forward(self, hidden_states, input_tensor, layernorm_idx=0):
-        h = ops.linear(hidden_states, self.dense.weight, self.dense.bias)
+    def forward(self, hidden_states, input_tensor, layernorm_idx=0, intermediate=None):
+        """intermediate: the BertIntermediate whose dense + GELU feeds this layer; given, `hidden_states` is ITS input
+        and both linears run as one fused autograd node (ops.mlp)"""
+        if intermediate is not None:
+            h = ops.mlp(hidden_states, intermediate.dense, self.dense)
+        else:
+            h = ops.linear(hidden_states, self.dense.weight, self.dense.bias)
         ln = self.LayerNorm if layernorm_idx == 0 else self.LayerNorms[layernorm_idx - 1]
         return ops.dropout_add_layer_norm(h, input_tensor, ln, self.dropout.p, self.training)
 
@@ -303,7 +308,9 @@ class BertLayer(nn.Module):
         return (layer_output,) + outputs + (present_key_value,)
 
     def feed_forward_chunk(self, attention_output, layernorm_idx):
-        return self.output(self.intermediate(attention_output), attention_output, layernorm_idx=layernorm_idx)
+        # (BertIntermediate -> BertOutputParallel, med.py:292-330; fused: see BertOutputParallel.forward)
+        return self.output(attention_output, attention_output, layernorm_idx=layernorm_idx,
+                           intermediate=self.intermediate)
 
 
 _TWO_SEGMENT = os.environ.get("BQ_TWO_SEGMENT_KV", "0") == "1"

@@ -75,10 +75,8 @@ class PhasedTrainStep(object):
         self.next_batch = next_batch if next_batch is not None else batch
         self.prefetch = prefetch_geometry
         self.eager_phases = tuple(eager_phases)
-        # dW / db of the small linears on a side stream (fusion_ops.set_wgrad_overlap): value-neutral, but MEASURED
-        # SLOWER on ROCm 7.2 (53.5 -> 61.3 ms/step): every fork is an event record + wait pair in a multi-stream
-        # graph, and ~300 of them cost more than the kernels they take off the critical path.  Off.
-        self.wgrad_overlap = False
+        # weight / bias gradients of every linear are parked during a backward phase and produced by ONE grouped GEMM
+        # launch per tile class + one grouped column-sum launch at its end (fusion_ops.begin/flush_deferred_wgrad)
         self.defer_wgrad = True
         self.reducers = dict(reducers or {})
         self.s_comm = torch.cuda.Stream(device=batch["point_clouds"].device) if self.reducers else None
@@ -143,20 +141,22 @@ class PhasedTrainStep(object):
         dd = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in st["dd"].items()}
         dd = self.model.fuse(dd, img_leaf, obj_leaf)
         loss = self.fusion_loss(dd)
-        prev = ops.set_wgrad_overlap(self.wgrad_overlap)
         if self.defer_wgrad:
-            ops.begin_deferred_wgrad()  # dW / db of the small linears: parked, then batched by shape after the chain
+            ops.begin_deferred_wgrad()  # dW / db of the linears: parked, then one grouped launch after the chain
         try:
             loss.backward()
         finally:
-            ops.set_wgrad_overlap(prev)
-            ops.join_wgrad(self.dev)
             ops.flush_deferred_wgrad()
         st["img_grad"], st["obj_grad"] = img_leaf.grad, obj_leaf.grad
         st["fusion_loss"] = loss.detach()
 
     def _image_bwd(self):
-        self._state["img"].backward(self._state["img_grad"])
+        if self.defer_wgrad:
+            ops.begin_deferred_wgrad()  # 48 ViT weight gradients -> one grouped launch of 1296 full-contraction tiles
+        try:
+            self._state["img"].backward(self._state["img_grad"])
+        finally:
+            ops.flush_deferred_wgrad()
 
     def _det_bwd(self):
         st = self._state

@@ -38,7 +38,7 @@ class PatchEmbed(nn.Module):
         ph, pw = self.patch_size
         gh, gw = self.grid_size
         patches = x.reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * ph * pw)
-        return ops.linear(patches, self.proj.weight.reshape(self.proj.weight.shape[0], -1), self.proj.bias)
+        return ops.linear(patches, self.proj.weight, self.proj.bias)  # (N, C, kh, kw) read as the (N, C*kh*kw) GEMM operand
 
 
 class DropPath(nn.Module):
@@ -69,6 +69,8 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
+        if self.drop.p == 0.0 or not self.training:
+            return ops.mlp(x, self.fc1, self.fc2)  # one autograd node: GELU / dGELU / fc1's bias gradient in epilogues
         x = ops.linear(x, self.fc1.weight, self.fc1.bias, act="gelu")
         x = self.drop(x)
         x = ops.linear(x, self.fc2.weight, self.fc2.bias)

@@ -217,6 +217,95 @@ def main():
     out.update(bl_cand=cand["input_ids"], bl_rank_all=scores[0], bl_rank_scene=scores[1], bl_rank_2d=scores[2],
                bl_fused_eval=fused_e)
     np.savez_compressed(os.path.join(OUT, "fusion_blip.npz"), **npy(out))
+    # ---------------- kernel-shaped fixtures (round 2): head dim 64, widths the HIP kernels take ------------------
+    # (attention D = 64, LayerNorm width % 256, GEMM K % 64) so that `-m gpu` tests drive the bf16 HIP path itself
+    # against the reference's numbers -- outputs AND gradients.  A fresh generator: the files above stay bit-identical.
+    g2 = torch.Generator().manual_seed(7)
+
+    def grads_of(module, names):
+        sd = dict(module.named_parameters())
+        return {n.replace(".", "_"): sd[n].grad for n in names}
+
+    # gradients of the whole BLIP_VQA3D train-mode forward of fusion_blip.npz (eval-mode modules: no dropout)
+    model.zero_grad(set_to_none=True)
+    img_l = img.clone().requires_grad_(True)
+    obj_l = obj.clone().requires_grad_(True)
+    loss, fused, _ = model(img_l, q, a, scene_object_embeds=obj_l, scene_object_mask=om, data_dict={})
+    wf = torch.randn(fused.shape, generator=g2)
+    (loss.sum() + (fused * wf).sum()).backward()
+    out = {"bl_wf": wf, "grad_img": img_l.grad, "grad_obj": obj_l.grad}
+    out.update({"grad_" + k: v for k, v in grads_of(model, [
+        "visual_encoder.blocks.0.mlp.fc1.weight", "visual_encoder.blocks.1.attn.qkv.bias",
+        "visual_encoder.patch_embed.proj.bias", "text_encoder.encoder.layer.0.crossattention.self.value.weight",
+        "text_encoder.encoder.layer_twin.1.intermediate.dense.weight", "text_encoder.encoder.layer.1.output.dense.bias",
+        "text_decoder.bert.encoder.layer.0.crossattention.self.key.weight", "text_decoder.cls.predictions.bias",
+        "linear_scene_object.0.weight"]).items()})
+    np.savez_compressed(os.path.join(OUT, "fusion_blip_grad.npz"), **npy(out))
+
+    torch.manual_seed(0)
+    vit = rvit.VisionTransformer(img_size=64, patch_size=16, embed_dim=256, depth=2, num_heads=4, drop_path_rate=0.1)
+    out = {"vit_keys": keys_of("visual_encoder.", vit)}
+    vit.eval()
+    img = torch.randn(3, 3, 64, 64, generator=g2)
+    wout = torch.randn(3, 17, 256, generator=g2)
+    y = vit(img)
+    (y * wout).sum().backward()
+    out.update(vit_img=img, vit_out=y, vit_wout=wout)
+    out.update({"grad_" + k: v for k, v in grads_of(vit, ["patch_embed.proj.weight", "cls_token", "blocks.0.attn.qkv.weight",
+                                                          "blocks.0.attn.qkv.bias", "blocks.0.norm1.weight",
+                                                          "blocks.1.mlp.fc1.weight", "blocks.1.mlp.fc1.bias",
+                                                          "blocks.1.mlp.fc2.weight", "blocks.1.attn.proj.bias",
+                                                          "norm.bias"]).items()})
+    np.savez_compressed(os.path.join(OUT, "fusion_vit_k.npz"), **npy(out))
+
+    cfgk = rmed.BertConfig(hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=2,
+                           vocab_size=200, max_position_embeddings=64, layer_norm_eps=1e-12, hidden_act="gelu",
+                           hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, pad_token_id=0)
+    cfgk.encoder_width = 256
+    cfgk.add_cross_attention = True
+    torch.manual_seed(0)
+    twin = rmed.BertModelTwin(config=cfgk, add_pooling_layer=False)
+    out = {"twin_keys": keys_of("text_encoder.", twin)}
+    twin.eval()
+    B, L, P, O = 3, 9, 70, 13          # 70 + 9 keys: two 64-key tiles in the 2D cross-attention
+    ids = torch.randint(5, 190, (B, L), generator=g2)
+    am = torch.ones(B, L, dtype=torch.long); am[1, 6:] = 0
+    img_e = torch.randn(B, P, 256, generator=g2).requires_grad_(True)
+    obj_e = torch.randn(B, O, 256, generator=g2).requires_grad_(True)
+    om = torch.ones(B, O, dtype=torch.long); om[0, 9:] = 0
+    r = twin(ids, attention_mask=am, encoder_hidden_states=img_e,
+             encoder_attention_mask=torch.ones(B, P, dtype=torch.long), encoder_hidden_states_twin=obj_e,
+             encoder_attention_mask_twin=om, return_dict=True, output_attentions=True)
+    h2d, h3d = r.last_hidden_state
+    w2, w3 = torch.randn(B, L, 256, generator=g2), torch.randn(B, L, 256, generator=g2)
+    ((h2d * w2).sum() + (h3d * w3).sum()).backward()
+    out.update(tw_ids=ids, tw_am=am, tw_img=img_e, tw_obj=obj_e, tw_om=om, tw_h2d=h2d, tw_h3d=h3d, tw_w2=w2, tw_w3=w3,
+               tw_cross2d=r.cross_attentions[-1][0], tw_cross3d=r.cross_attentions[-1][1],
+               grad_img=img_e.grad, grad_obj=obj_e.grad)
+    out.update({"grad_" + k: v for k, v in grads_of(twin, [
+        "encoder.layer.0.attention.self.query.weight", "encoder.layer.0.crossattention.self.key.weight",
+        "encoder.layer.0.crossattention.self.value.bias", "encoder.layer_twin.0.crossattention.self.key.weight",
+        "encoder.layer.1.intermediate.dense.weight", "encoder.layer.1.intermediate.dense.bias",
+        "encoder.layer_twin.1.output.dense.weight", "encoder.layer.0.attention.output.LayerNorm.weight",
+        "embeddings.word_embeddings.weight"]).items()})
+    torch.manual_seed(0)
+    dec = rmed.BertLMHeadModel(config=cfgk)
+    out["dec_keys"] = keys_of("text_decoder.", dec)
+    dec.eval()
+    La = 6
+    aid = torch.randint(5, 190, (B, La), generator=g2); aid[:, 0] = 198
+    aam = torch.ones(B, La, dtype=torch.long); aam[0, 4:] = 0; aid[0, 4:] = 0
+    tgt = aid.masked_fill(aid == 0, -100)
+    enc = h2d.detach().clone().requires_grad_(True)
+    r = dec(aid, attention_mask=aam, encoder_hidden_states=enc, encoder_attention_mask=am, labels=tgt,
+            return_dict=True, reduction="none")
+    r.loss.sum().backward()
+    out.update(dec_ids=aid, dec_am=aam, dec_loss=r.loss, dec_logits=r.logits, grad_dec_enc=enc.grad)
+    out.update({"grad_dec_" + k: v for k, v in grads_of(dec, [
+        "bert.embeddings.word_embeddings.weight", "cls.predictions.transform.dense.weight", "cls.predictions.bias",
+        "bert.encoder.layer.0.crossattention.self.query.weight", "bert.encoder.layer.1.output.dense.bias"]).items()})
+    np.savez_compressed(os.path.join(OUT, "fusion_med_k.npz"), **npy(out))
+
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

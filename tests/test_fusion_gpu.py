@@ -1,0 +1,140 @@
+"""The fusion half (ViT / twin MED encoder / LM decoder / BLIP_VQA3D) ON THE GPU against golden vectors produced by
+the reference's own Python (oracle/gen_golden_fusion.py): rows a14-a17 of SURVEY.md §8a.
+
+  * fp32 on cuda: the mirrors' arithmetic on the device (1e-3, the same fixtures as tests/test_fusion_cpu.py).
+  * bf16 through the HIP kernels -- MFMA GEMMs with fused epilogues (csrc/gemm.hip), fused attention (csrc/attn.hip),
+    fused add + LayerNorm (csrc/ln.hip) -- on the kernel-shaped fixtures (head dim 64, widths % 256): outputs AND
+    gradients against the reference's fp32 numbers.  Tolerances ("bf16-in/fp32-acc; vs fp32
+    oracle rel-L2 <= 2e-2 on final tokens", "loss fp32, tol 1e-2 rel"): rel-L2 <= 2e-2 on outputs, 1e-2 relative on
+    losses, rel-L2 <= 5e-2 on parameter / input gradients (two bf16 roundings per layer on the way back)."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import subsample
+from test_fusion_cpu import keys_of, run_blip, run_twin_and_decoder, run_vit
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, g):
+    a = subsample(a.detach().float().cpu().numpy()).astype(np.float64).reshape(-1)
+    g = np.asarray(g, dtype=np.float64).reshape(-1)
+    assert a.shape == g.shape, (a.shape, g.shape)
+    assert np.isfinite(a).all()
+    return float(np.linalg.norm(a - g) / (np.linalg.norm(g) + 1e-30))
+
+
+def grad_of(module, key):
+    """fixture key grad_<name with . -> _> -> the parameter's gradient"""
+    for n, p in module.named_parameters():
+        if n.replace(".", "_") == key:
+            return p.grad
+    raise KeyError(key)
+
+
+@pytest.fixture()
+def bf16():
+    from bridgeqa_amd import fusion_ops as ops
+    prev = ops.set_compute_dtype(torch.bfloat16)
+    yield ops
+    ops.set_compute_dtype(prev)
+
+
+def test_fp32_on_device_vs_reference_golden(golden, dev):
+    run_vit(golden("fusion_vit.npz"), dev, 1e-3, 1e-4)
+    run_twin_and_decoder(golden("fusion_med.npz"), dev, 1e-3, 1e-4)
+    run_blip(golden("fusion_blip.npz"), dev, 1e-3, 1e-4)
+
+
+def test_vit_bf16_hip_path_vs_reference_golden(golden, dev, bf16):
+    from bridgeqa_amd import vit
+    g = golden("fusion_vit_k.npz")
+    m = vit.VisionTransformer(img_size=64, patch_size=16, embed_dim=256, depth=2, num_heads=4, drop_path_rate=0.1)
+    assert keys_of(m, "visual_encoder.") == list(g["vit_keys"])
+    m = m.to(dev).eval()
+    y = m(torch.from_numpy(g["vit_img"]).to(dev))
+    assert y.dtype == torch.bfloat16  # the kernel path ran (fp32 falls back to the torch composition)
+    assert rel_l2(y, g["vit_out"]) <= 2e-2
+    (y.float() * torch.from_numpy(g["vit_wout"]).to(dev)).sum().backward()
+    for k in [k for k in g.files if k.startswith("grad_")]:
+        e = rel_l2(grad_of(m, k[5:]), g[k])
+        assert e <= 5e-2, (k, e)
+
+
+def test_twin_and_decoder_bf16_hip_path_vs_reference_golden(golden, dev, bf16):
+    from bridgeqa_amd import med
+    g = golden("fusion_med_k.npz")
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    cfg = med.BertConfig(hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=2,
+                         vocab_size=200, max_position_embeddings=64, encoder_width=256)
+    twin = med.BertModelTwin(config=cfg, add_pooling_layer=False)
+    assert keys_of(twin, "text_encoder.") == list(g["twin_keys"])
+    twin = twin.to(dev).eval()
+    B, P = g["tw_img"].shape[:2]
+    img, obj = t("tw_img").requires_grad_(True), t("tw_obj").requires_grad_(True)
+    r = twin(t("tw_ids"), attention_mask=t("tw_am"), encoder_hidden_states=img,
+             encoder_attention_mask=torch.ones(B, P, dtype=torch.long, device=dev), encoder_hidden_states_twin=obj,
+             encoder_attention_mask_twin=t("tw_om"), return_dict=True, output_attentions="last")
+    h2d, h3d = r.last_hidden_state
+    assert h2d.dtype == torch.bfloat16
+    assert rel_l2(h2d, g["tw_h2d"]) <= 2e-2 and rel_l2(h3d, g["tw_h3d"]) <= 2e-2
+    assert rel_l2(r.cross_attentions[-1][0], g["tw_cross2d"]) <= 2e-2
+    assert rel_l2(r.cross_attentions[-1][1], g["tw_cross3d"]) <= 2e-2
+    ((h2d.float() * t("tw_w2")).sum() + (h3d.float() * t("tw_w3")).sum()).backward()
+    assert rel_l2(img.grad, g["grad_img"]) <= 5e-2 and rel_l2(obj.grad, g["grad_obj"]) <= 5e-2
+    for k in [k for k in g.files if k.startswith("grad_") and not k.startswith("grad_dec_") and k not in ("grad_img", "grad_obj")]:
+        e = rel_l2(grad_of(twin, k[5:]), g[k])
+        assert e <= 5e-2, (k, e)
+    dec = med.BertLMHeadModel(config=cfg)
+    assert keys_of(dec, "text_decoder.") == list(g["dec_keys"])
+    dec = dec.to(dev).eval()
+    aid = t("dec_ids")
+    enc = t("tw_h2d").requires_grad_(True)
+    r = dec(aid, attention_mask=t("dec_am"), encoder_hidden_states=enc, encoder_attention_mask=t("tw_am"),
+            labels=aid.masked_fill(aid == 0, -100), return_dict=True, reduction="none")
+    ref_loss = np.asarray(g["dec_loss"], dtype=np.float64)
+    assert np.abs(r.loss.detach().float().cpu().numpy() - ref_loss).max() <= 1e-2 * np.abs(ref_loss).max()
+    assert rel_l2(r.logits, g["dec_logits"]) <= 2e-2
+    r.loss.sum().backward()
+    assert rel_l2(enc.grad, g["grad_dec_enc"]) <= 5e-2
+    for k in [k for k in g.files if k.startswith("grad_dec_") and k != "grad_dec_enc"]:
+        e = rel_l2(grad_of(dec, k[9:]), g[k])
+        assert e <= 5e-2, (k, e)
+
+
+def test_blip_vqa3d_bf16_hip_path_vs_reference_golden(golden, dev, bf16):
+    """the whole BLIP_VQA3D forward of blip_vqa_3d.py:227-347 (ViT-B width, 2 + 2 layers) through the HIP path: train loss,
+    fused states, last-layer attention maps, and the gradients of the step's loss"""
+    from bridgeqa_amd.blip_vqa_3d import BLIP_VQA3D, SyntheticTokenizer
+    from bridgeqa_amd.med import BertConfig
+    g, gg, gm = golden("fusion_blip.npz"), golden("fusion_blip_grad.npz"), golden("fusion_med.npz")
+    cfg = BertConfig(num_hidden_layers=2, vocab_size=200, max_position_embeddings=64)
+    m = BLIP_VQA3D(med_config=cfg, image_size=64, num_answers=10, use_text_decoder=True, share_decoder=True,
+                   scene_size=32, tokenizer=SyntheticTokenizer(0, 102, 198, 199))
+    assert keys_of(m, "blip_model.") == list(g["blip_keys"])
+    m = m.to(dev).eval()
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    tm = lambda k: torch.from_numpy(gm[k]).to(dev)
+    q = {"input_ids": tm("tw_ids"), "attention_mask": tm("tw_am")}
+    a = {"input_ids": tm("dec_ids"), "attention_mask": tm("dec_am")}
+    img, obj = t("bl_img").requires_grad_(True), t("bl_obj").requires_grad_(True)
+    dd = {}
+    loss, fused, qmask = m(img, q, a, scene_object_embeds=obj, scene_object_mask=tm("tw_om"), data_dict=dd)
+    ref_loss = np.asarray(g["bl_loss"], dtype=np.float64)
+    assert np.abs(loss.detach().float().cpu().numpy() - ref_loss).max() <= 1e-2 * np.abs(ref_loss).max()
+    assert rel_l2(fused, g["bl_fused"]) <= 2e-2
+    assert torch.equal(qmask.cpu(), torch.from_numpy(g["bl_qmask"]))
+    assert rel_l2(dd["2d_cross_attention"], g["bl_cross2d"]) <= 2e-2
+    assert rel_l2(dd["3d_cross_attention"], g["bl_cross3d"]) <= 2e-2
+    (loss.sum() + (fused.float() * torch.from_numpy(gg["bl_wf"]).to(dev)).sum()).backward()
+    assert rel_l2(img.grad, gg["grad_img"]) <= 5e-2 and rel_l2(obj.grad, gg["grad_obj"]) <= 5e-2
+    for k in [k for k in gg.files if k.startswith("grad_") and k not in ("grad_img", "grad_obj")]:
+        e = rel_l2(grad_of(m, k[5:]), gg[k])
+        assert e <= 5e-2, (k, e)
+    cand = {"input_ids": t("bl_cand"), "attention_mask": torch.ones_like(t("bl_cand"))}
+    with torch.no_grad():
+        fused_e, scores, _ = m(t("bl_img"), q, cand, train=False, k_test=3, scene_object_embeds=t("bl_obj"),
+                               scene_object_mask=tm("tw_om"), data_dict={})
+    assert rel_l2(fused_e, g["bl_fused_eval"]) <= 2e-2
+    assert rel_l2(scores[1], g["bl_rank_scene"]) <= 2e-2 and rel_l2(scores[2], g["bl_rank_2d"]) <= 2e-2

@@ -206,3 +206,54 @@ def test_full_size_c2_properties_and_oracle_spot_check(ext, oracle, dev):
     inds2 = ext.furthest_point_sampling(new_xyz, 1024).cpu()
     assert torch.equal(inds2, oracle.furthest_point_sampling(new_xyz.cpu().contiguous(), 1024))
     assert (inds2 == torch.arange(1024, dtype=torch.int32).expand(B, -1)).float().mean() > 0.999
+
+
+def _bf16_ulp_diff(a, b):
+    """distance in bf16 units-in-the-last-place between two bf16 tensors (sign-magnitude -> ordered integers)"""
+    ia = a.contiguous().view(torch.int16).to(torch.int32)
+    ib = b.contiguous().view(torch.int16).to(torch.int32)
+    oa = torch.where(ia < 0, -(ia & 0x7FFF), ia)
+    ob = torch.where(ib < 0, -(ib & 0x7FFF), ib)
+    return (oa - ob).abs().max().item()
+
+
+def test_point_major_and_bf16_grouping_vs_oracle_composition(ext, oracle, dev):
+    """bq_group_concat_pm / bq_group_concat_pm_grad / bq_group_concat_bf16 (the forms the c3 bench runs) against the
+    reference composition (lib/pointnet2/pointnet2_utils.py:348-359) over the CPU oracle: fp32 output bit-exact (up
+    to the layout permutation), bf16 output <= 1 bf16 ulp from the rounded fp32 composition, gradients 1e-4 (atomics)."""
+    g = torch.Generator().manual_seed(11)
+    for (B, C, N, M, S, r, norm) in ((2, 5, 512, 64, 16, 0.9, True), (1, 0, 300, 20, 8, 0.3, True),
+                                     (2, 132, 4096, 256, 64, 0.4, True), (1, 128, 2048, 1024, 32, 0.4, True),
+                                     (2, 4, 100, 10, 4, 0.2, False)):
+        xyz = scene(B, N, 0, 5)
+        new_xyz = xyz[:, :M].contiguous()
+        idx = oracle.ball_query(new_xyz, xyz, r, S)
+        feats = torch.randn(B, C, N, generator=g) if C else None
+        gx = oracle.group_points(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if norm:
+            gx = gx / r
+        want = torch.cat([gx, oracle.group_points(feats, idx)], 1) if C else gx          # (B, 3+C, M, S)
+        want_pm = want.permute(0, 2, 3, 1).contiguous()                                     # (B, M, S, 3+C)
+        # point-major source rows: the interleaved (B, N, 3+C) cloud read in place (a strided view, as the bench does)
+        cloud = torch.cat([xyz, feats.transpose(1, 2)], -1).contiguous().to(dev) if C else None
+        feats_pm = cloud[:, :, 3:] if C else None
+        dxyz, dnew, didx = xyz.to(dev), new_xyz.to(dev), idx.to(dev)
+        got32 = ext.group_concat_pm(dxyz, dnew, feats_pm, didx, r, norm, torch.float32)
+        assert torch.equal(got32.cpu(), want_pm)
+        got16 = ext.group_concat_pm(dxyz, dnew, feats_pm, didx, r, norm, torch.bfloat16)
+        assert _bf16_ulp_diff(got16.cpu(), want_pm.to(torch.bfloat16)) <= 1
+        got16c = ext.group_concat(dxyz, dnew, feats.to(dev) if C else None, didx, r, norm, torch.bfloat16)
+        assert _bf16_ulp_diff(got16c.cpu(), want.to(torch.bfloat16)) <= 1
+        # gradients: point-major grad_out (B, M, S, 3+C), fp32 and bf16
+        go = torch.randn(B, M, S, C + 3, generator=g)
+        for dt, tol in ((torch.float32, 1e-4), (torch.bfloat16, 1e-4)):
+            go_d = go.to(dt)
+            go_ref = go_d.float().permute(0, 3, 1, 2).contiguous()                          # (B, 3+C, M, S)
+            gf, gxyz, gnew = ext.group_concat_pm_grad(go_d.to(dev), didx, N, r, norm, True, True, True)
+            s = go_ref[:, :3] / r if norm else go_ref[:, :3]
+            want_xyz = oracle.group_points_grad(s.contiguous(), idx, N).transpose(1, 2)
+            torch.testing.assert_close(gxyz.cpu(), want_xyz, rtol=tol, atol=tol)
+            torch.testing.assert_close(gnew.cpu(), -s.sum(-1).transpose(1, 2), rtol=tol, atol=tol)
+            if C:
+                want_f = oracle.group_points_grad(go_ref[:, 3:].contiguous(), idx, N).transpose(1, 2)  # (B, N, C)
+                torch.testing.assert_close(gf.cpu(), want_f, rtol=tol, atol=tol)

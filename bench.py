@@ -280,7 +280,9 @@ def main():
             opt = FusedAdamW(model.parameters(), lr=5e-4, weight_decay=1e-5)
         # the geometry phase (FPS / ball query of the next batch) stays eager so that the roofline kernel is timed
         # with HIP events INSIDE the timed steps, on the stream it is launched on
-        pipe = PhasedTrainStep(model, batch, det_loss, fusion_loss, opt, use_graphs=use_graph,
+        # next_batch=batch: the benchmark replays ONE static synthetic batch, so "the next step's point clouds" are the
+        # same buffers (a training loop passes the buffers its loader fills one step ahead)
+        pipe = PhasedTrainStep(model, batch, det_loss, fusion_loss, opt, use_graphs=use_graph, next_batch=batch,
                                eager_phases=("geometry",), reserve_cus=int(os.environ.get("BQ_RESERVE_CUS", "0")))
         eager_step = pipe.eager_step
         reducers = {}

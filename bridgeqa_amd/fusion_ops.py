@@ -191,7 +191,13 @@ def _rows(t):
 
 
 def _native_ok(t, N, K):
+    """forward y (M, N) = x (M, K) w^T: the contraction K is K-contiguous in both operands => K % 64"""
     return _NATIVE_GEMM[0] and t.is_cuda and _COMPUTE_DTYPE == torch.bfloat16 and K % 64 == 0 and N % 8 == 0
+
+
+def _native_dx_ok(t, N, K):
+    """input gradient dx (M, K) = dy (M, N) w: the contraction is N (K-contiguous in dy) => N % 64"""
+    return _NATIVE_GEMM[0] and t.is_cuda and _COMPUTE_DTYPE == torch.bfloat16 and N % 64 == 0 and K % 8 == 0
 
 
 def _f32_bias(bias):
@@ -328,8 +334,8 @@ class _LinearFn(torch.autograd.Function):
             x2, wb = ctx.saved_tensors
             g2 = g.reshape(-1, g.shape[-1])
         N, K = wb.shape
-        native = _native_ok(g2, N, K)
-        if native:
+        native = _native_dx_ok(g2, N, K)
+        if g2.is_cuda and g2.dtype == torch.bfloat16:
             g2 = _rows(g2)
         w, b = ctx.params
         dw = db = None
@@ -352,8 +358,10 @@ class _MlpFn(torch.autograd.Function):
     """fc2(gelu(fc1(x))) as ONE autograd node (reference models/vit.py:23-41 Mlp; models/med.py:292-317
     BertIntermediate + BertOutput.dense), so that the backward can fuse across the two layers:
       forward : GEMM(+b1, GELU epilogue: pre-activation and activation written by the same launch), GEMM(+b2)
-      backward: dY1 = (dY2 W2) * gelu'(y1) and db1 = colsum(dY1) in ONE launch (dGELU + column-sum epilogue),
-                dX = dY1 W1, dW1 / dW2 / db2 parked for the grouped launch (or computed at once outside a scope)."""
+      backward: dY1 = (dY2 W2) * gelu'(y1) in ONE launch (dGELU epilogue), dX = dY1 W1, dW1 / db1 / dW2 / db2 parked
+                for the grouped launches (or computed at once outside a scope).  (The GEMM's fused column-sum epilogue
+                for db1 was measured SLOWER in the step -- 235 vs 159 us per launch: 65 x 4 waves' fp32 atomics land on
+                the same 12 KB -- than one more matrix in the grouped column-sum launch.)"""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2):
@@ -373,16 +381,15 @@ class _MlpFn(torch.autograd.Function):
         x2, y1, h, w1b, w2b = ctx.saved_tensors
         w1, b1, w2, b2 = ctx.params
         g2 = _rows(g)
-        db1 = torch.zeros(w1b.shape[0], dtype=torch.float32, device=g2.device) if b1 is not None else None
-        dy1 = _ext.gemm_dx(g2, w2b, pre_act=y1, colsum=db1)
+        dy1 = _ext.gemm_dx(g2, w2b, pre_act=y1)
         dx = _ext.gemm_dx(dy1, w1b).view(ctx.x_shape).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
         if _DEFER[0] is not None:
             _park(g2, h, [w2], [b2] if b2 is not None else None)
-            _park(dy1, x2, [w1], None)
-            dw1 = dw2 = db2 = None
+            _park(dy1, x2, [w1], [b1] if b1 is not None else None)
+            dw1 = db1 = dw2 = db2 = None
         else:
             dw2, db2 = _dw_db(g2, h, True, b2 is not None)
-            dw1, _ = _dw_db(dy1, x2, True, False)
+            dw1, db1 = _dw_db(dy1, x2, True, b1 is not None)
         return dx, dw1, db1, dw2, db2
 
 
@@ -390,6 +397,7 @@ def mlp(x, fc1, fc2):
     """fc2(gelu(fc1(x))) for two nn.Linear modules; one fused autograd node on the bf16 CUDA path"""
     w1, w2 = fc1.weight, fc2.weight
     if (_native_ok(x, w1.shape[0], w1.shape[1]) and _native_ok(x, w2.shape[0], w2.shape[1])
+            and _native_dx_ok(x, w1.shape[0], w1.shape[1]) and _native_dx_ok(x, w2.shape[0], w2.shape[1])
             and all(isinstance(t, torch.nn.Parameter) and t.dtype == torch.float32
                     for t in (w1, w2, fc1.bias, fc2.bias) if t is not None)):
         return _MlpFn.apply(x, w1, fc1.bias, w2, fc2.bias)
@@ -459,8 +467,8 @@ class _MultiLinearFn(torch.autograd.Function):
         x2, wc = ctx.saved_tensors
         k = ctx.k
         g2 = g.reshape(-1, g.shape[-2] * g.shape[-1])
-        native = _native_ok(g2, wc.shape[0], wc.shape[1])
-        if native:
+        native = _native_dx_ok(g2, wc.shape[0], wc.shape[1])
+        if g2.is_cuda and g2.dtype == torch.bfloat16:
             g2 = _rows(g2)
         elif not g2.is_contiguous():
             g2 = g2.contiguous()
@@ -805,7 +813,7 @@ def _fwd2(x2, w, b):
 
 
 def _dx2(g2, w):
-    if _native_ok(g2, w.shape[0], w.shape[1]):
+    if _native_dx_ok(g2, w.shape[0], w.shape[1]):
         from . import _ext
         return _ext.gemm_dx(_rows(g2), w)
     return torch.mm(g2, w)

@@ -19,6 +19,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._sig = None
         self._table = self._chunks = None
         self._pinned = None
+        self._order = []   # (parameter, group) in table order: sync_hyperparams() rewrites their lr / weight_decay
 
     def _records(self):
         recs = []
@@ -29,21 +30,55 @@ class FusedAdamW(torch.optim.Optimizer):
                 if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or not p.grad.is_contiguous():
                     raise RuntimeError("FusedAdamW: parameters and gradients must be contiguous fp32 CUDA tensors")
                 st = self.state[p]
-                if not st:
+                if "exp_avg" not in st:
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                # torch.optim.AdamW's state layout ({"step", "exp_avg", "exp_avg_sq"}): checkpoints round-trip with the
+                # reference's optimizer_state_dict (lib/solver.py:687, scripts/train.py:449).  ONE device scalar counts
+                # the updates for every parameter (the kernel reads it; a replayed HIP graph increments it).
+                st["step"] = self._step(p.device)
                 sh = fusion_ops.shadow_of(p)
-                recs.append((p, p.grad, st["exp_avg"], st["exp_avg_sq"], sh, float(g["lr"]), float(g["weight_decay"])))
+                recs.append((p, p.grad, st["exp_avg"], st["exp_avg_sq"], sh, float(g["lr"]), float(g["weight_decay"]), g))
         return recs
+
+    def _step(self, device):
+        if self._step_t is None:
+            self._step_t = torch.zeros((), dtype=torch.float32, device=device)
+        return self._step_t
+
+    def load_state_dict(self, state_dict):
+        """accepts torch.optim.AdamW checkpoints: the per-parameter "step" entries collapse into the one device counter
+        (their maximum: parameters that never had a gradient sit at 0 there)"""
+        super().load_state_dict(state_dict)
+        steps = [float(st["step"]) for st in self.state.values() if "step" in st]
+        dev = next((st["exp_avg"].device for st in self.state.values() if "exp_avg" in st), None)
+        if steps and dev is not None:
+            self._step_t = None
+            self._step(dev).fill_(max(steps))
+            for st in self.state.values():
+                st["step"] = self._step_t
+        self._sig = None  # moments were re-allocated: rebuild the device table
+
+    def sync_hyperparams(self):
+        """Rewrite lr / weight_decay of every table record from param_groups into the pinned staging copy.  step() does
+        it itself; call this before REPLAYING a captured step (the graph holds the H2D copy node of the table and the
+        kernel launch, but no Python runs): LR schedulers then take effect under graph replay."""
+        if self._pinned is None:
+            return
+        tab = self._pinned.numpy()[:len(self._order) * 56].view(self._dtype)
+        for i, (_, g) in enumerate(self._order):
+            tab["lr"][i] = g["lr"]
+            tab["wd"][i] = g["weight_decay"]
 
     def _build(self, recs, device):
         from . import _ext
         assert _ext.ADAMW_TENSOR_BYTES == 56
-        dt = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("s", "<u8"), ("n", "<i8"),
-                       ("lr", "<f4"), ("wd", "<f4")])
+        dt = self._dtype = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("s", "<u8"), ("n", "<i8"),
+                                     ("lr", "<f4"), ("wd", "<f4")])
         tab = np.zeros(len(recs), dtype=dt)
         chunks = []
-        for i, (p, g, m, v, sh, lr, wd) in enumerate(recs):
+        self._order = [(r[0], r[7]) for r in recs]
+        for i, (p, g, m, v, sh, lr, wd, _) in enumerate(recs):
             tab[i] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr() if sh is not None else 0,
                       p.numel(), lr, wd)
             nchunk = (p.numel() + _ext.ADAMW_CHUNK - 1) // _ext.ADAMW_CHUNK
@@ -55,7 +90,6 @@ class FusedAdamW(torch.optim.Optimizer):
             self._pinned = torch.empty(host.size, dtype=torch.uint8).pin_memory()
             self._devbuf = torch.empty(host.size, dtype=torch.uint8, device=device)
         self._pinned.numpy()[:] = host
-        self._devbuf.copy_(self._pinned, non_blocking=True)
         nt = len(recs) * 56
         self._table = self._devbuf[:nt]
         self._chunks = self._devbuf[nt:].view(torch.int32).view(-1, 2)
@@ -72,13 +106,16 @@ class FusedAdamW(torch.optim.Optimizer):
         from . import _ext
         device = recs[0][0].device
         sig = tuple((r[0].data_ptr(), r[1].data_ptr(), r[2].data_ptr(), r[3].data_ptr(),
-                     r[4].data_ptr() if r[4] is not None else 0, r[5], r[6]) for r in recs)
+                     r[4].data_ptr() if r[4] is not None else 0) for r in recs)
         if sig != self._sig:
             self._build(recs, device)
             self._sig = sig
-        if self._step_t is None:
-            self._step_t = torch.zeros((), dtype=torch.float32, device=device)
-        self._step_t.add_(1.0)
+        else:
+            self.sync_hyperparams()
+        # the table travels to the device on EVERY step (tens of KB): a captured step therefore always contains the
+        # copy node, and lr / weight_decay written into the pinned copy reach the kernel of the next launch / replay
+        self._devbuf.copy_(self._pinned, non_blocking=True)
+        self._step(device).add_(1.0)
         beta1, beta2 = self.param_groups[0]["betas"]
         _ext.adamw_multi(self._table, self._chunks, self._step_t, beta1, beta2, self.param_groups[0]["eps"])
         fusion_ops.shadows_written([r[0] for r in recs if r[4] is not None])

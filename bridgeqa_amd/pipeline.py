@@ -52,14 +52,18 @@ def _cu_masked_stream(device, lo, hi, total=256):
 
 class PhasedTrainStep(object):
     def __init__(self, model, batch, det_loss, fusion_loss, optimizer=None, use_graphs=True, det_priority=0,
-                 grad_hook=None, next_batch=None, prefetch_geometry=True, eager_phases=(), reducers=None,
+                 grad_hook=None, next_batch=None, prefetch_geometry=None, eager_phases=(), reducers=None,
                  reserve_cus=0):
         """model: ScanQAHotPath (use_blip=True, train mode); batch: static device tensors (replayed in place);
         det_loss(data_dict) -> scalar over detector outputs; fusion_loss(data_dict) -> scalar over blip_loss /
         fused_feat; optimizer: stepped at the end of the step (None: the caller steps);
         grad_hook: optional callable run on the main stream after both backward phases and before the optimizer
         (data-parallel gradient exchange); next_batch: where the loader puts the FOLLOWING step's inputs (only its
-        point_clouds are read, by the geometry prefetch; default: the same static buffers as `batch`);
+        point_clouds are read, by the geometry prefetch).  prefetch_geometry: compute the sampling / grouping indices
+        of the next batch under this step's fusion phase -- ONLY valid when next_batch really holds the next step's
+        point clouds by the time this step's detector forward has run, so it defaults to on iff next_batch is given
+        (a static benchmark batch passes next_batch=batch); without it the indices are computed inside the detector
+        forward of the batch they belong to;
         eager_phases: names of phases launched kernel by kernel even when the rest replays from graphs (bench.py keeps
         "geometry" eager so that HIP events can bracket the FPS launch inside the timed steps; ~60 launches);
         reducers: data parallel -- {"fusion" | "image" | "det": ddp.PackedGradReducer over the parameters whose
@@ -72,8 +76,11 @@ class PhasedTrainStep(object):
         the encoder loses more than the detector gains, so the default stays 0 (knob kept for other shapes)."""
         self.model, self.batch, self.det_loss, self.fusion_loss = model, batch, det_loss, fusion_loss
         self.opt, self.grad_hook = optimizer, grad_hook
+        if prefetch_geometry and next_batch is None:
+            raise ValueError("prefetch_geometry needs next_batch: the buffers the loader fills with the FOLLOWING step's "
+                             "point clouds (pass next_batch=batch only for a static batch)")
         self.next_batch = next_batch if next_batch is not None else batch
-        self.prefetch = prefetch_geometry
+        self.prefetch = (next_batch is not None) if prefetch_geometry is None else bool(prefetch_geometry)
         self.eager_phases = tuple(eager_phases)
         # weight / bias gradients of every linear are parked during a backward phase and produced by ONE grouped GEMM
         # launch per tile class + one grouped column-sum launch at its end (fusion_ops.begin/flush_deferred_wgrad)
@@ -283,11 +290,14 @@ class PhasedTrainStep(object):
         self._schedule(eager=True)
         return self.loss
 
-    def capture(self, warmup=3):
+    def capture(self, warmup=3, keep_warmup_updates=False):
         """`warmup` eager steps on the phase streams (autograd's AccumulateGrad nodes remember the stream they were
         created on -- they must be born on the stream that is later captured), then one graph per phase.  Graphs of
         one stream share a memory pool (they always replay in capture order); the two streams' pools are separate
-        because their graphs run concurrently."""
+        because their graphs run concurrently.  The warm-up steps are real optimizer steps on the first batch (the
+        optimizer state must exist before the capture); unless keep_warmup_updates, parameters, buffers (BatchNorm
+        running statistics), moments and the step count are put back afterwards, so training starts from the state
+        the caller handed over."""
         cur = torch.cuda.current_stream(self.dev)
         for s_ in (self.s_main, self.s_det, self.s_img):
             s_.wait_stream(cur)
@@ -295,9 +305,25 @@ class PhasedTrainStep(object):
         if self.prefetch:
             with torch.cuda.stream(self.s_det):
                 self._geometry()  # the first step's own geometry
+        snapshot = None
+        if warmup and not keep_warmup_updates:
+            torch.cuda.synchronize(self.dev)
+            snapshot = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
         for _ in range(warmup):
             self.eager_step()
         torch.cuda.synchronize(self.dev)
+        if snapshot is not None:
+            with torch.no_grad():
+                for k, v in self.model.state_dict().items():
+                    v.copy_(snapshot[k])
+                if self.opt is not None:
+                    for st in self.opt.state.values():
+                        for name, t in st.items():
+                            if torch.is_tensor(t):
+                                t.zero_()
+            ops.refresh_shadows(only_with_grad=False)
+            del snapshot
+            torch.cuda.synchronize(self.dev)
         if not self.use_graphs:
             return self
         self.zero_grad()
@@ -319,6 +345,8 @@ class PhasedTrainStep(object):
         """one optimisation step; returns the (device) loss of this step without synchronising"""
         if self.graphs is None:
             return self.eager_step()
+        if self.opt is not None and hasattr(self.opt, "sync_hyperparams"):
+            self.opt.sync_hyperparams()  # LR schedulers act on param_groups; the captured step reads the pinned table
         self._schedule(eager=False)
         return self.loss
 

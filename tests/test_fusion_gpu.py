@@ -57,7 +57,7 @@ def test_vit_bf16_hip_path_vs_reference_golden(golden, dev, bf16):
     assert y.dtype == torch.bfloat16  # the kernel path ran (fp32 falls back to the torch composition)
     assert rel_l2(y, g["vit_out"]) <= 2e-2
     (y.float() * torch.from_numpy(g["vit_wout"]).to(dev)).sum().backward()
-    for k in [k for k in g.files if k.startswith("grad_")]:
+    for k in [k for k in g if k.startswith("grad_")]:
         e = rel_l2(grad_of(m, k[5:]), g[k])
         assert e <= 5e-2, (k, e)
 
@@ -83,7 +83,7 @@ def test_twin_and_decoder_bf16_hip_path_vs_reference_golden(golden, dev, bf16):
     assert rel_l2(r.cross_attentions[-1][1], g["tw_cross3d"]) <= 2e-2
     ((h2d.float() * t("tw_w2")).sum() + (h3d.float() * t("tw_w3")).sum()).backward()
     assert rel_l2(img.grad, g["grad_img"]) <= 5e-2 and rel_l2(obj.grad, g["grad_obj"]) <= 5e-2
-    for k in [k for k in g.files if k.startswith("grad_") and not k.startswith("grad_dec_") and k not in ("grad_img", "grad_obj")]:
+    for k in [k for k in g if k.startswith("grad_") and not k.startswith("grad_dec_") and k not in ("grad_img", "grad_obj")]:
         e = rel_l2(grad_of(twin, k[5:]), g[k])
         assert e <= 5e-2, (k, e)
     dec = med.BertLMHeadModel(config=cfg)
@@ -98,7 +98,7 @@ def test_twin_and_decoder_bf16_hip_path_vs_reference_golden(golden, dev, bf16):
     assert rel_l2(r.logits, g["dec_logits"]) <= 2e-2
     r.loss.sum().backward()
     assert rel_l2(enc.grad, g["grad_dec_enc"]) <= 5e-2
-    for k in [k for k in g.files if k.startswith("grad_dec_") and k != "grad_dec_enc"]:
+    for k in [k for k in g if k.startswith("grad_dec_") and k != "grad_dec_enc"]:
         e = rel_l2(grad_of(dec, k[9:]), g[k])
         assert e <= 5e-2, (k, e)
 
@@ -129,7 +129,7 @@ def test_blip_vqa3d_bf16_hip_path_vs_reference_golden(golden, dev, bf16):
     assert rel_l2(dd["3d_cross_attention"], g["bl_cross3d"]) <= 2e-2
     (loss.sum() + (fused.float() * torch.from_numpy(gg["bl_wf"]).to(dev)).sum()).backward()
     assert rel_l2(img.grad, gg["grad_img"]) <= 5e-2 and rel_l2(obj.grad, gg["grad_obj"]) <= 5e-2
-    for k in [k for k in gg.files if k.startswith("grad_") and k not in ("grad_img", "grad_obj")]:
+    for k in [k for k in gg if k.startswith("grad_") and k not in ("grad_img", "grad_obj")]:
         e = rel_l2(grad_of(m, k[5:]), gg[k])
         assert e <= 5e-2, (k, e)
     cand = {"input_ids": t("bl_cand"), "attention_mask": torch.ones_like(t("bl_cand"))}

@@ -125,3 +125,99 @@ def test_whole_hot_path_bf16_fused_vs_fp32_reference_composition(dev):
     # and labels (distance thresholds) from the bf16-perturbed geometry -- discontinuous, so only a coarse bound
     assert abs(got["vote_loss"].item() - ref["vote_loss"].item()) <= 5e-2 * abs(ref["vote_loss"].item())
     assert abs(got_det - ref_det) <= 0.35 * abs(ref_det), (got_det, ref_det)
+
+
+def test_geometry_prefetch_follows_changing_batches(dev):
+    """The geometry prefetch computes the NEXT step's sampling / grouping indices one step early from `next_batch`.
+    With batches that CHANGE every step (a loader writing the following step's point clouds into next_batch while the
+    current step runs) every step's loss must equal the loss of the same model on the same batch computed without any
+    prefetch; without an explicit next_batch the prefetch is off."""
+    import bench
+    from bridgeqa_amd.pipeline import PhasedTrainStep
+    model = _small_model(dev)
+    data = [_batch(dev, B=2, N=4096), None, None]
+    for k in (1, 2):
+        g = torch.Generator().manual_seed(100 + k)
+        data[k] = dict(data[0])
+        pc = data[0]["point_clouds"].clone()
+        pc[..., :3] = (torch.rand(pc.shape[0], pc.shape[1], 3, generator=g) * torch.tensor([8.0, 8.0, 3.0])).to(dev)
+        data[k]["point_clouds"] = pc
+    want = []
+    with torch.no_grad():
+        for k in range(3):
+            want.append(bench.total_loss(model(dict(data[k]))).item())
+    assert abs(want[0] - want[1]) > 1e-3 * abs(want[0])  # the batches really differ
+    assert PhasedTrainStep(model, data[0], bench.det_loss, bench.fusion_loss, None, use_graphs=False).prefetch is False
+    with pytest.raises(ValueError):
+        PhasedTrainStep(model, data[0], bench.det_loss, bench.fusion_loss, None, use_graphs=False, prefetch_geometry=True)
+    cur = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data[0].items()}
+    nxt = {"point_clouds": data[0]["point_clouds"].clone()}
+    pipe = PhasedTrainStep(model, cur, bench.det_loss, bench.fusion_loss, None, use_graphs=False, next_batch=nxt)
+    assert pipe.prefetch is True
+    pipe.capture(warmup=0)   # computes the geometry of the first batch (next_batch == batch 0 at this point)
+    for k in range(3):
+        # the loader: batch k is current, batch k+1 is already waiting in next_batch
+        for name, v in data[k].items():
+            if torch.is_tensor(v):
+                cur[name].copy_(v)
+        nxt["point_clouds"].copy_(data[(k + 1) % 3]["point_clouds"])
+        got = pipe.eager_step()
+        torch.cuda.synchronize()
+        assert abs(got.item() - want[k]) <= 2e-4 * abs(want[k]), (k, got.item(), want[k])
+
+
+def test_fused_adamw_checkpoint_resume_and_scheduler_under_replay(dev):
+    """(1) state_dict() carries the step count in torch.optim.AdamW's layout: a resumed FusedAdamW continues exactly
+    like an uninterrupted one, and a torch AdamW checkpoint loads (reference: lib/solver.py:687, scripts/train.py:449).
+    (2) lr written into param_groups after a HIP-graph capture reaches the replayed kernel (sync_hyperparams)."""
+    from bridgeqa_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(300, 70, device=dev)), torch.nn.Parameter(torch.randn(1000, device=dev))]
+    grads = [[torch.randn_like(p) for p in ps] for _ in range(6)]
+
+    def run(opt, steps):
+        for k in steps:
+            for p, g in zip(opt.param_groups[0]["params"], grads[k]):
+                p.grad = g.clone()
+            opt.step()
+
+    def fresh():
+        return [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    a = fresh(); oa = FusedAdamW(a, lr=1e-2, weight_decay=1e-2); run(oa, range(6))
+    b = fresh(); ob = FusedAdamW(b, lr=1e-2, weight_decay=1e-2); run(ob, range(3))
+    sd = ob.state_dict()
+    assert all(float(st["step"]) == 3.0 for st in sd["state"].values())
+    c = [torch.nn.Parameter(p.detach().clone()) for p in b]; oc = FusedAdamW(c, lr=1e-2, weight_decay=1e-2)
+    oc.load_state_dict({"state": {k: {n: (t.clone() if torch.is_tensor(t) else t) for n, t in st.items()}
+                                  for k, st in sd["state"].items()}, "param_groups": sd["param_groups"]})
+    run(oc, range(3, 6))
+    for x, y in zip(a, c):
+        assert torch.allclose(x, y, rtol=1e-6, atol=1e-7)
+    t = fresh(); ot = torch.optim.AdamW(t, lr=1e-2, weight_decay=1e-2); run(ot, range(3))
+    d = [torch.nn.Parameter(p.detach().clone()) for p in t]; od = FusedAdamW(d, lr=1e-2, weight_decay=1e-2)
+    od.load_state_dict(ot.state_dict())
+    run(ot, range(3, 6)); run(od, range(3, 6))
+    for x, y in zip(t, d):
+        assert torch.allclose(x, y, rtol=2e-5, atol=2e-6)
+    # (2) graph replay reads the lr of param_groups at replay time
+    e = fresh(); oe = FusedAdamW(e, lr=1e-2, weight_decay=0.0)
+    for p, g in zip(e, grads[0]):
+        p.grad = g.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        oe.step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=s):
+        oe.step()
+    torch.cuda.synchronize()
+    before = [p.detach().clone() for p in e]
+    gr.replay(); torch.cuda.synchronize()
+    assert all(not torch.equal(x, y) for x, y in zip(before, e))
+    oe.param_groups[0]["lr"] = 0.0
+    oe.sync_hyperparams()
+    frozen = [p.detach().clone() for p in e]
+    gr.replay(); torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(frozen, e))

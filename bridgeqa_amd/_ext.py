@@ -253,15 +253,16 @@ def group_concat_grad(grad_out, idx, n, radius, normalize, need_features, need_x
     return gf, gx, gn
 
 
-_lib.bq_group_concat_pm.argtypes = [_vp, _vp, _vp, ctypes.c_long, ctypes.c_long, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]
+_lib.bq_group_concat_pm.argtypes = [_vp, _vp, _vp, ctypes.c_long, ctypes.c_long, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]
 _lib.bq_group_concat_pm.restype = ctypes.c_int
-_lib.bq_group_concat_pm_grad.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]
+_lib.bq_group_concat_pm_grad.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]
 _lib.bq_group_concat_pm_grad.restype = ctypes.c_int
 
 
-def group_concat_pm(xyz, new_xyz, feats_pm, idx, radius, normalize, out_dtype):
+def group_concat_pm(xyz, new_xyz, feats_pm, idx, radius, normalize, out_dtype, pad_to=1):
     """Point-major grouping: feats_pm (B,N,C) f32 view with contiguous rows (any batch / row stride) or None ->
-    (B, M, S, 3+C) in out_dtype (f32 / bf16)."""
+    (B, M, S, 3+C) in out_dtype (f32 / bf16).  pad_to > 1: the rows are allocated with a stride of 3+C rounded up to a
+    multiple of pad_to (padding zeroed) and the (B, M, S, 3+C) result is a view of them."""
     _req(xyz, torch.float32, "xyz"); _req(new_xyz, torch.float32, "new_xyz"); _req(idx, torch.int32, "idx")
     B, N, _ = xyz.shape
     _, M, S = idx.shape
@@ -271,27 +272,32 @@ def group_concat_pm(xyz, new_xyz, feats_pm, idx, radius, normalize, out_dtype):
         if not feats_pm.is_cuda or feats_pm.dtype != torch.float32 or feats_pm.stride(2) != 1:
             raise RuntimeError("feats_pm must be a CUDA float tensor (B,N,C) with contiguous rows")
         C, fbs, frs = feats_pm.shape[2], feats_pm.stride(0), feats_pm.stride(1)
+    ld = (C + 3 + pad_to - 1) // pad_to * pad_to
     with torch.cuda.device(xyz.device):
-        out = torch.empty(B, M, S, C + 3, dtype=out_dtype, device=xyz.device)
+        out = torch.empty(B, M, S, ld, dtype=out_dtype, device=xyz.device)
         _check(_lib.bq_group_concat_pm(_p(xyz), _p(new_xyz), _p(feats_pm), fbs, frs, _p(idx), _p(out),
                                        int(out_dtype == torch.bfloat16), B, C, N, M, S, float(radius),
-                                       int(bool(normalize)), _stream()), "group_concat_pm")
-    return out
+                                       int(bool(normalize)), ld, _stream()), "group_concat_pm")
+    return out[..., :C + 3] if ld != C + 3 else out
 
 
 def group_concat_pm_grad(grad_out, idx, n, radius, normalize, need_features, need_xyz, need_new_xyz):
+    """grad_out (B, M, S, 3+C): contiguous, or a view of rows with a larger uniform stride (the padded rows the
+    SharedMLP's input gradient is written in)"""
     B, M, S, CT = grad_out.shape
     C = CT - 3
     dev = grad_out.device
-    if not grad_out.is_contiguous():
+    ld = grad_out.stride(2)
+    if grad_out.stride(3) != 1 or grad_out.stride(1) != S * ld or grad_out.stride(0) != M * S * ld or ld < CT:
         grad_out = grad_out.contiguous()
+        ld = CT
     with torch.cuda.device(dev):
         gf = torch.zeros(B, n, C, dtype=torch.float32, device=dev) if (need_features and C > 0) else None
         gx = torch.zeros(B, n, 3, dtype=torch.float32, device=dev) if need_xyz else None
         gn = torch.zeros(B, M, 3, dtype=torch.float32, device=dev) if need_new_xyz else None
         _check(_lib.bq_group_concat_pm_grad(_p(grad_out), int(grad_out.dtype == torch.bfloat16), _p(idx), _p(gf),
                                             _p(gx), _p(gn), B, C, int(n), M, S, float(radius),
-                                            int(bool(normalize)), _stream()), "group_concat_pm_grad")
+                                            int(bool(normalize)), ld, _stream()), "group_concat_pm_grad")
     return gf, gx, gn
 
 
@@ -605,7 +611,7 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU = 0, 1, 2, 3
 
 class _GemmDesc(ctypes.Structure):
     _fields_ = [("P", _vp), ("Q", _vp), ("out", _vp), ("bias", _vp), ("out2", _vp), ("aux", _vp), ("colsum", _vp),
-                ("ldp", _i), ("ldq", _i), ("ldo", _i), ("Ni", _i), ("Nj", _i), ("Kc", _i), ("bias_bf16", _i)]
+                ("ldp", _i), ("ldq", _i), ("ldo", _i), ("Ni", _i), ("Nj", _i), ("Kc", _i), ("bias_bf16", _i), ("p_bytes", _l), ("q_bytes", _l), ("ksplit", _i)]
 
 
 _lib.bq_gemm_bf16.argtypes = [ctypes.POINTER(_GemmDesc), _i, _i, _i, _i, _vp]
@@ -646,7 +652,7 @@ def gemm_grouped(problems, flags, epilogue=EPI_NONE, tile=None):
             raise RuntimeError("gemm: out must be %s" % ("float32" if f32 else "bfloat16"))
         Ni, Kc = (P.shape[1], P.shape[0]) if pxc else (P.shape[0], P.shape[1])
         Nj, Kq = (Q.shape[1], Q.shape[0]) if qxc else (Q.shape[0], Q.shape[1])
-        if Kq != Kc or tuple(out.shape) != (Nj, Ni):
+        if (Kq != Kc and "Kc" not in pr) or tuple(out.shape) != (Nj, Ni):
             raise RuntimeError("gemm: shape mismatch P%s Q%s out%s" % (tuple(P.shape), tuple(Q.shape), tuple(out.shape)))
         d = arr[k]
         d.P, d.Q, d.out = P.data_ptr(), Q.data_ptr(), out.data_ptr()
@@ -663,6 +669,9 @@ def gemm_grouped(problems, flags, epilogue=EPI_NONE, tile=None):
         d.bias, d.out2, d.aux, d.colsum = _p(bias), _p(out2), _p(aux), _p(colsum)
         d.ldp, d.ldq, d.ldo = P.stride(0), Q.stride(0), out.stride(0)
         d.Ni, d.Nj, d.Kc = Ni, Nj, Kc
+        d.p_bytes, d.q_bytes, d.ksplit = int(pr.get("p_bytes", 0)), int(pr.get("q_bytes", 0)), int(pr.get("ksplit", 1))
+        if "Kc" in pr:  # contraction longer than the K-contiguous operand's rows (its partner is zero-padded)
+            d.Kc = int(pr["Kc"])
         t_auto = max(t_auto, pick_tile(Ni, Nj, qxc))
     dev = problems[0]["out"].device
     with torch.cuda.device(dev):
@@ -729,3 +738,35 @@ def colsum_grouped(mats):
             arr[k].g, arr[k].out, arr[k].M, arr[k].N, arr[k].ld = m.data_ptr(), o.data_ptr(), m.shape[0], m.shape[1], m.stride(0)
         _check(_lib.bq_colsum_grouped_bf16(arr, n, _stream()), "colsum_grouped")
     return outs
+
+
+# ---- SharedMLP layer on point-major rows: 1x1 convolution + BatchNorm statistics in its epilogue (csrc/gemm.hip) ----
+_lib.bq_pwconv_records.argtypes = [_l, _i]
+_lib.bq_pwconv_records.restype = ctypes.c_int
+_lib.bq_pwconv_bn_fwd.argtypes = [_vp, _l, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp,
+                                  _vp]
+_lib.bq_pwconv_bn_fwd.restype = ctypes.c_int
+
+
+def pwconv_bn_relu_fwd(x, K, w_pad, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, S, relu,
+                       pool):
+    """x: bf16 rows (R, ldx) view with contiguous elements (ldx = x.stride(0) >= K, the first K of a row are the input
+    channels); w_pad: bf16 (N, Kc) contiguous, zero beyond K, Kc % 64 == 0.  y_raw = x @ w^T (bf16 (R, N)), its
+    training-mode BatchNorm statistics from the fp32 accumulators (running buffers updated in place), then
+    out = relu?(bn(y_raw)) as bf16 (R, N), or (R // S, N) = max over every run of S rows when pool.
+    Returns out, y_raw, stats (f32 (4, N): scale, shift, mean, rstd)."""
+    if not x.is_cuda:
+        raise RuntimeError("x: CPU not supported")
+    R, N, Kc = x.shape[0], w_pad.shape[0], w_pad.shape[1]
+    with torch.cuda.device(x.device):
+        y_raw = torch.empty(R, N, dtype=torch.bfloat16, device=x.device)
+        stats = torch.empty(4, N, dtype=torch.float32, device=x.device)
+        part = torch.empty(_lib.bq_pwconv_records(R, N) * 3 * N, dtype=torch.float32, device=x.device)
+        _check(_lib.bq_pwconv_bn_fwd(_p(x), R, int(K), x.stride(0), _p(w_pad), w_pad.stride(0), Kc, N, _p(y_raw), _p(part),
+                                     _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(num_batches_tracked),
+                                     float(eps), float(momentum), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]),
+                                     _stream()), "pwconv_bn_fwd")
+        out = torch.empty(R // S if pool else R, N, dtype=torch.bfloat16, device=x.device)
+        _check(_lib.bq_bn_apply(_p(y_raw), _p(stats[0]), _p(stats[1]), _p(out), R, N, int(S), int(bool(relu)),
+                                int(bool(pool)), _stream()), "bn_apply")
+    return out, y_raw, stats

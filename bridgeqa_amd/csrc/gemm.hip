@@ -49,6 +49,10 @@ struct GemmProblem {
   int Ni, Nj, Kc;
   int tile0, tiles_i;  // first workgroup of this problem in the launch; tiles along i
   int bias_bf16;
+  unsigned p_bytes, q_bytes;  // bounds of the operand buffers (a K-contiguous operand whose rows are shorter than Kc:
+                              // its partner is zero-padded, its own tail reads run into the next row)
+  int ksplit;          // > 1 (fp32 out, small-tile kernel): the contraction is cut into ksplit pieces, one workgroup
+                       // each, accumulated with fp32 atomics into a zero-initialised `out`
 };
 
 __device__ __forceinline__ void load_bias4(const GemmProblem &pr, int i, float (&bv)[4]) {
@@ -161,10 +165,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
   const int nkt = (Kc + 63) >> 6;
 
   // ---- staging: 8 units per K tile, one LDS-DMA per wave per unit (wave w -> unit rows 8w..8w+7) -----------------
-  const unsigned p_bytes = P_XC ? (unsigned)(((long)(Kc - 1) * ldp + Ni) * 2) : (unsigned)(((long)(Ni - 1) * ldp + Kc) * 2);
-  const unsigned q_bytes = Q_XC ? (unsigned)(((long)(Kc - 1) * ldq + Nj) * 2) : (unsigned)(((long)(Nj - 1) * ldq + Kc) * 2);
-  const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void *)pr.P, 0, p_bytes, 0x00020000);
-  const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void *)pr.Q, 0, q_bytes, 0x00020000);
+  const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void *)pr.P, 0, pr.p_bytes, 0x00020000);
+  const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void *)pr.Q, 0, pr.q_bytes, 0x00020000);
   const int ur = wave * 8 + (lane >> 3);  // unit row this lane stages
   const int cp = lane & 7;                // LDS chunk position
   unsigned voff[8];                       // A0(0) A0(1) A1(0) A1(1) B0(0) B0(1) B1(0) B1(1)
@@ -405,10 +407,11 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
   constexpr int QF = BJ / 32;               // 16-wide j fragments per wave
   constexpr int Q_UNIT = BJ * 128;          // bytes of the Q image per stage
   constexpr int STAGE = 8192 + Q_UNIT;
-  // NS LDS stages, NS - 1 K tiles in flight: these problems are latency-bound (a weight matrix is streamed from HBM
-  // once per launch by workgroups that do ~100 cycles of MFMA work per K tile), so the DMA queue must cover an HBM
-  // miss (~1 us) -- with 3 stages a K tile took 0.25 us, i.e. the loop ran at the memory latency, not the issue rate
-  constexpr int NS = 5;
+  // NS LDS stages, NS - 1 K tiles in flight.  MEASURED (profiles/r02_gemm_bench_v2.json): 5 stages instead of 3 change
+  // nothing for the forward / dX forms (a K tile costs ~0.24 us either way: the loop is bound by the ISSUE of its 3-4
+  // LDS-DMA instructions per wave, ~100 cycles each, not by memory latency) and halve the weight-gradient form
+  // (80 KB of LDS = 2 workgroups per CU for a kernel that lives on its output stores) => 3.
+  constexpr int NS = 3;
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -420,17 +423,19 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
   for (int k = 1; k < args.n; ++k)
     if (t >= args.p[k].tile0) pi = k;
   const GemmProblem &pr = args.p[pi];
-  const int tl = t - pr.tile0;
+  const int ksplit = OUT_F32 ? pr.ksplit : 1;
+  const int tl = (t - pr.tile0) / ksplit, ks = (t - pr.tile0) % ksplit;
   const int bj = tl / pr.tiles_i, bi = tl % pr.tiles_i;
   const int i0 = bi * 64, j0 = bj * BJ;
   const int Ni = pr.Ni, Nj = pr.Nj, Kc = pr.Kc;
   const int ldp = pr.ldp, ldq = pr.ldq;
-  const int nkt = (Kc + 63) >> 6;
+  const int nkt_all = (Kc + 63) >> 6;
+  const int kt_per = (nkt_all + ksplit - 1) / ksplit;
+  const int kt0 = ks * kt_per;                         // this workgroup's K tiles: [kt0, kt0 + nkt)
+  const int nkt = max(0, min(kt_per, nkt_all - kt0));
 
-  const unsigned p_bytes = P_XC ? (unsigned)(((long)(Kc - 1) * ldp + Ni) * 2) : (unsigned)(((long)(Ni - 1) * ldp + Kc) * 2);
-  const unsigned q_bytes = Q_XC ? (unsigned)(((long)(Kc - 1) * ldq + Nj) * 2) : (unsigned)(((long)(Nj - 1) * ldq + Kc) * 2);
-  const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void *)pr.P, 0, p_bytes, 0x00020000);
-  const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void *)pr.Q, 0, q_bytes, 0x00020000);
+  const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void *)pr.P, 0, pr.p_bytes, 0x00020000);
+  const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void *)pr.Q, 0, pr.q_bytes, 0x00020000);
   const int cp = lane & 7;
   // P unit: 2 DMAs per wave (rows (2w+d)*8 + lane/8); Q unit: 2 (BJ = 64) or 1 (BJ = 32: rows w*8 + lane/8)
   unsigned vp[2], vq[2];
@@ -445,6 +450,11 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
   }
   const unsigned p_step = P_XC ? (unsigned)(64 * ldp * 2) : 128u;
   const unsigned q_step = Q_XC ? (unsigned)(64 * ldq * 2) : 128u;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    vp[d] += (unsigned)kt0 * p_step;
+    vq[d] += (unsigned)kt0 * q_step;
+  }
   constexpr int NDMA = 2 + (BJ == 64 ? 2 : 1);  // LDS-DMAs per wave per stage
 
   auto stage = [&](int kt) {
@@ -485,8 +495,9 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
   for (int kt = 0; kt < nkt; ++kt) {
     // stage kt has landed for this wave (stages kt+1 .. kt+NS-2 may still be in flight); after the barrier: for every
     // wave, and every wave has finished reading the buffer that stage kt+NS-1 is about to overwrite
-    if (NDMA == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // (NS - 2) * NDMA
-    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    static_assert(NS == 3, "the counted waits below are (NS - 2) * NDMA");
+    if (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     BQ_BARRIER();
     stage(kt + NS - 1);
     const unsigned char *buf = smem + (kt % NS) * STAGE;
@@ -526,7 +537,12 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] + b4[r];
       if (OUT_F32) {
-        if (ok) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(pr.out) + (long)j * ldo + i) = make_float4(v[0], v[1], v[2], v[3]);
+        float *dst = reinterpret_cast<float *>(pr.out) + (long)j * ldo + i;
+        if (ok && ksplit == 1) *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        if (ok && ksplit > 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(dst + r, v[r]);
+        }
         continue;
       }
       if (EPI == EPI_DGELU && ok) {
@@ -564,6 +580,234 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
   }
 }
 
+
+// ======================================================================================================================
+// pwconv64_kernel: the 1x1 convolution of a SharedMLP layer on point-major rows with the BatchNorm statistics of its
+// output taken in the epilogue (reference lib/pointnet2/pytorch_utils.py:104-157 Conv2d(1x1, bias=False) ->
+// BatchNorm2d(train) of a SharedMLP, :11-36):   y[r][n] = sum_k x[r][k] W[n][k]   over R = B*npoint*nsample rows
+// (2.1 M for SA1 at config c3), K = 3+C input channels (x rows of ldx >= K elements, W zero-padded to Kc % 64 == 0),
+// N in {64, 128, 256} output channels.  A streaming problem (SA1 layer 0 moves 840 MB for 36 GFLOP): persistent
+// workgroups walk the 64-row tiles of ONE 64-channel block, so that the per-channel sums needed by BatchNorm stay in
+// registers across tiles -- taken from the fp32 accumulators, i.e. BEFORE the rounding of y to bf16 -- and leave
+// the kernel as one (pivot, sum, sum of squares) record per wave; pwconv_bn_finalize_kernel merges the records in a
+// fixed order (Chan's update: exact pairwise merging of (n, mean, M2), robust when |mean| >> std) into scale / shift /
+// mean / rstd and the running statistics.  This removes the separate statistics pass over y (268 MB for SA1 layer 0)
+// and the library convolution.  Same LDS images / DMA staging / fragment maps as gemm64_kernel.
+// ======================================================================================================================
+struct PwconvArgs {
+  const __bf16 *W;    // [Ni][ldw], zero beyond K
+  const __bf16 *X;    // [R][ldx]
+  __bf16 *Y;          // [R][Ni]
+  float *partial;     // [Gj * 2][3][Ni]: pivot | sum (y - pivot) | sum (y - pivot)^2, per (row walker, wave column)
+  int ldw, ldx, Ni, R, Kc, Gj, tiles_i;
+  unsigned w_bytes, x_bytes;
+};
+
+__global__ __launch_bounds__(256) void pwconv64_kernel(const PwconvArgs a) {
+  constexpr int STAGE = 16384, NS = 3;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int bi = blockIdx.x % a.tiles_i, gj = blockIdx.x / a.tiles_i;
+  const int i0 = bi * 64;
+  const int nkt = a.Kc >> 6;
+  const int tiles_j = (a.R + 63) >> 6;
+  const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void *)a.W, 0, a.w_bytes, 0x00020000);
+  const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void *)a.X, 0, a.x_bytes, 0x00020000);
+  const int cp = lane & 7;
+  const int row16 = lane & 15, q4 = lane >> 4;
+  const int kc_base = row16 * 128 + ((q4 ^ (row16 & 7)) << 4);
+  const int xc_dummy[4] = {0, 0, 0, 0};
+  const int iw = i0 + wr * 32;
+
+  float piv[2][4], s1[2][4], s2[2][4];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { piv[x][r] = 0.f; s1[x][r] = 0.f; s2[x][r] = 0.f; }
+  bool have_pivot = false;
+
+  for (int bj = gj; bj < tiles_j; bj += a.Gj) {
+    const int j0 = bj * 64;
+    unsigned vp[2], vq[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int ur = (wave * 2 + d) * 8 + (lane >> 3);
+      vp[d] = (unsigned)(((i0 + ur) * a.ldw + (cp ^ (ur & 7)) * 8) * 2);
+      vq[d] = (unsigned)(((long)(j0 + ur) * a.ldx + (cp ^ (ur & 7)) * 8) * 2);
+    }
+    auto stage = [&](int kt) {
+      const bool live = kt < nkt;
+      const unsigned base = (unsigned)((kt % NS) * STAGE);
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_void_t *)(smem + base + (wave * 2 + d) * 1024), 16,
+                                                 live ? vp[d] : 0x80000000u, 0, 0, 0);
+        vp[d] += 128u;
+      }
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_void_t *)(smem + base + 8192 + (wave * 2 + d) * 1024), 16,
+                                                 live ? vq[d] : 0x80000000u, 0, 0, 0);
+        vq[d] += 128u;
+      }
+    };
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[x][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    BQ_BARRIER();  // every wave has finished reading the stages of the previous tile
+    stage(0);
+    stage(1);
+    for (int kt = 0; kt < nkt; ++kt) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      BQ_BARRIER();
+      stage(kt + 2);
+      const unsigned char *buf = smem + (kt % NS) * STAGE;
+      bf16x8 fa[2][2], fb[2][2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fa[x][kk] = read_frag<false>(buf, wr * 2 + x, kk, kc_base, xc_dummy);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fb[b][kk] = read_frag<false>(buf + 8192, wc * 2 + b, kk, kc_base, xc_dummy);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[x][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[x][kk], fb[b][kk], acc[x][b], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- epilogue: y (bf16) and the statistics of the fp32 values ---------------------------------------------------
+    const int jw = j0 + wc * 32;
+    if (!have_pivot) {  // this wave's first row: the value every lane of a 16-lane group subtracts from its channels
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) piv[x][r] = __shfl(acc[x][0][r], lane & 48);
+      have_pivot = true;
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const int i = iw + x * 16 + q4 * 4;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int j = jw + b * 16 + row16;
+        const bool ok = j < a.R;
+        if (ok) {
+          uint2 pk;
+          pk.x = pack_bf16x2(acc[x][b][0], acc[x][b][1]);
+          pk.y = pack_bf16x2(acc[x][b][2], acc[x][b][3]);
+          *reinterpret_cast<uint2 *>(a.Y + (long)j * a.Ni + i) = pk;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = ok ? acc[x][b][r] - piv[x][r] : 0.f;
+          s1[x][r] += d;
+          s2[x][r] += d * d;
+        }
+      }
+    }
+  }
+  // ---- one record per (row walker gj, wave column wc): the 16 lanes of a q4 group hold different rows ---------------
+  float *rec = a.partial + (long)(gj * 2 + wc) * 3 * a.Ni;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float u = s1[x][r], v = s2[x][r];
+      u += dpp_f32_add<0x111>(u); u += dpp_f32_add<0x112>(u); u += dpp_f32_add<0x114>(u); u += dpp_f32_add<0x118>(u);
+      v += dpp_f32_add<0x111>(v); v += dpp_f32_add<0x112>(v); v += dpp_f32_add<0x114>(v); v += dpp_f32_add<0x118>(v);
+      if (row16 == 15) {
+        const int i = iw + x * 16 + q4 * 4 + r;
+        rec[i] = piv[x][r];
+        rec[a.Ni + i] = u;
+        rec[2 * a.Ni + i] = v;
+      }
+    }
+}
+
+// rows a (row walker gj, wave column wc) record covers: tiles gj, gj+Gj, ...; rows [64 t + 32 wc, +32) below R
+__device__ __forceinline__ long pwconv_record_rows(int rec, int Gj, long R) {
+  const int gj = rec >> 1, wc = rec & 1;
+  const long tiles_j = (R + 63) >> 6;
+  if (gj >= tiles_j) return 0;
+  const long nt = (tiles_j - 1 - gj) / Gj + 1;          // tiles walked
+  const long last = gj + (nt - 1) * Gj;                 // the only tile that can be ragged
+  const long r0 = last * 64 + wc * 32;
+  const long in_last = R > r0 ? (R - r0 < 32 ? R - r0 : 32) : 0;
+  return (nt - 1) * 32 + in_last;
+}
+
+struct PwconvBnParams {
+  const float *partial;
+  const float *gamma, *beta;
+  float *running_mean, *running_var;
+  long long *num_batches_tracked;
+  float *scale, *shift, *mean, *rstd;
+  float eps, momentum;
+  int C, nrec, Gj;
+  long R;
+};
+
+// 4 threads per channel: thread phase ph merges the records g = ph (mod 4) in index order, then the four partial
+// (n, mean, M2) triples are merged in phase order (Chan et al.: exact for any partition, no cancellation, and the fixed
+// order makes the statistics bit-reproducible)
+__device__ __forceinline__ void chan_merge(float &n, float &mean, float &m2, float ng, float mg, float m2g) {
+  if (ng == 0.f) return;
+  const float tot = n + ng, delta = mg - mean;
+  mean += delta * (ng / tot);
+  m2 += m2g + delta * delta * (n * ng / tot);
+  n = tot;
+}
+__global__ __launch_bounds__(256) void pwconv_bn_finalize_kernel(const PwconvBnParams p) {
+  __shared__ float sh[3][4][64];
+  const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int c = min(blockIdx.x * 64 + cl, p.C - 1);
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int g0 = ph; g0 < p.nrec; g0 += 16) {
+    float pv[4], su[4], sq[4], ng[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // four records in flight per thread
+      const int g = g0 + 4 * u;
+      const bool live = g < p.nrec;
+      const float *rec = p.partial + (long)(live ? g : 0) * 3 * p.C;
+      pv[u] = rec[c]; su[u] = rec[p.C + c]; sq[u] = rec[2 * p.C + c];
+      ng[u] = live ? (float)pwconv_record_rows(g, p.Gj, p.R) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float inv = ng[u] > 0.f ? 1.0f / ng[u] : 0.f;
+      chan_merge(n, mean, m2, ng[u], pv[u] + su[u] * inv, fmaxf(sq[u] - su[u] * su[u] * inv, 0.f));
+    }
+  }
+  sh[0][ph][cl] = n; sh[1][ph][cl] = mean; sh[2][ph][cl] = m2;
+  __syncthreads();
+  if (ph != 0 || blockIdx.x * 64 + cl >= p.C) return;
+  n = 0.f; mean = 0.f; m2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) chan_merge(n, mean, m2, sh[0][q][cl], sh[1][q][cl], sh[2][q][cl]);
+  const float var = m2 / n;
+  const float rstd = rsqrtf(var + p.eps);
+  const float sc = p.gamma[c] * rstd;
+  p.scale[c] = sc;
+  p.shift[c] = p.beta[c] - mean * sc;
+  p.mean[c] = mean;
+  p.rstd[c] = rstd;
+  if (p.running_mean) {
+    const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
+    p.running_mean[c] = (1.0f - p.momentum) * p.running_mean[c] + p.momentum * mean;
+    p.running_var[c] = (1.0f - p.momentum) * p.running_var[c] + p.momentum * unbiased;
+  }
+  if (c == 0 && p.num_batches_tracked) p.num_batches_tracked[0] += 1;
+}
 
 // ---- grouped column sums: out_p[n] = sum_m G_p[m][n] for a list of bf16 matrices, ONE launch -----------------------
 // (the bias gradients of every parked linear: reference autograd of nn.Linear's bias, torch `grad.sum(0)`).
@@ -665,8 +909,9 @@ extern "C" int bq_gemm_bf16(const bq_gemm_desc *d, int n, int flags, int epilogu
       BQ_REQUIRE(s.ldp % 8 == 0 && s.ldq % 8 == 0, BQ_EINVAL, "bq_gemm_bf16: operand leading dimensions must be multiples of 8 elements");
       BQ_REQUIRE(s.Ni % 8 == 0 && s.ldo % (f32 ? 4 : 8) == 0, BQ_EINVAL, "bq_gemm_bf16: Ni and ldo must be multiples of 8 (Ni = %d, ldo = %d)", s.Ni, s.ldo);
       BQ_REQUIRE(!qxc || s.Nj % 8 == 0, BQ_EINVAL, "bq_gemm_bf16: a contraction-major Q needs Nj %% 8 == 0 (Nj = %d)", s.Nj);
-      BQ_REQUIRE((pxc || s.Kc % 64 == 0) && (qxc || s.Kc % 64 == 0), BQ_EINVAL,
-                 "bq_gemm_bf16: a K-contiguous operand needs Kc %% 64 == 0 (Kc = %d)", s.Kc);
+      BQ_REQUIRE((pxc && qxc) || s.Kc % 64 == 0, BQ_EINVAL,
+                 "bq_gemm_bf16: a K-contiguous operand needs Kc %% 64 == 0 (Kc = %d; zero-pad the other operand and pass "
+                 "p_bytes / q_bytes when the rows are shorter)", s.Kc);
       BQ_REQUIRE(((uintptr_t)s.P % 16 == 0) && ((uintptr_t)s.Q % 16 == 0) && ((uintptr_t)s.out % 16 == 0), BQ_EINVAL,
                  "bq_gemm_bf16: operands must be 16-byte aligned");
       BQ_REQUIRE(epilogue != EPI_BIAS_GELU || s.out2, BQ_EINVAL, "bq_gemm_bf16: BIAS_GELU needs out2");
@@ -682,9 +927,13 @@ extern "C" int bq_gemm_bf16(const bq_gemm_desc *d, int n, int flags, int epilogu
       g.aux = (const __bf16 *)s.aux; g.colsum = s.colsum;
       g.ldp = s.ldp; g.ldq = s.ldq; g.ldo = s.ldo; g.Ni = s.Ni; g.Nj = s.Nj; g.Kc = s.Kc;
       g.bias_bf16 = s.bias_bf16;
+      g.p_bytes = (unsigned)(s.p_bytes > 0 ? s.p_bytes : pb);
+      g.q_bytes = (unsigned)(s.q_bytes > 0 ? s.q_bytes : qb);
+      g.ksplit = (f32 && tile != 256 && s.ksplit > 1) ? s.ksplit : 1;
+      BQ_REQUIRE(s.ksplit <= 1 || (f32 && tile != 256), BQ_EINVAL, "bq_gemm_bf16: ksplit needs fp32 out and tile 64");
       g.tiles_i = (s.Ni + ti - 1) / ti;
       g.tile0 = ga.total_tiles;
-      ga.total_tiles += g.tiles_i * ((s.Nj + tj - 1) / tj);
+      ga.total_tiles += g.tiles_i * ((s.Nj + tj - 1) / tj) * g.ksplit;
       ++ga.n;
       ++done;
     }
@@ -723,4 +972,42 @@ extern "C" int bq_colsum_grouped_bf16(const bq_colsum_desc *d, int n, void *stre
     if (rc) return rc;
   }
   return 0;
+}
+
+extern "C" int bq_pwconv_records(long R, int N) {
+  // row walkers per 64-channel block: enough workgroups to fill the chip three times over, never more than the tiles
+  const long tiles_j = (R + 63) / 64;
+  const int tiles_i = (N + 63) / 64;
+  long gj = (256 * 2 + tiles_i - 1) / tiles_i;
+  if (gj > tiles_j) gj = tiles_j;
+  if (gj < 1) gj = 1;
+  return (int)gj * 2;
+}
+
+extern "C" int bq_pwconv_bn_fwd(const void *x, long R, int K, int ldx, const void *w, int ldw, int Kc, int N, void *y,
+                                float *partial, const float *gamma, const float *beta, float *running_mean,
+                                float *running_var, long long *num_batches_tracked, float eps, float momentum,
+                                float *scale, float *shift, float *mean, float *rstd, void *stream) {
+  using namespace bq;
+  BQ_REQUIRE(x && w && y && partial && gamma && beta && scale && shift && mean && rstd, BQ_EINVAL, "pwconv_bn_fwd: null pointer");
+  BQ_REQUIRE(R > 0 && K > 0 && N > 0, BQ_EINVAL, "pwconv_bn_fwd: empty problem");
+  BQ_REQUIRE(N % 64 == 0 && Kc % 64 == 0 && Kc >= K && ldw >= Kc && ldx >= K && ldx % 8 == 0 && ldw % 8 == 0, BQ_EINVAL,
+             "pwconv_bn_fwd: need N %% 64 == 0, Kc %% 64 == 0 >= K, ldw >= Kc, ldx >= K, ld %% 8 == 0 (N=%d K=%d Kc=%d ldx=%d ldw=%d)",
+             N, K, Kc, ldx, ldw);
+  BQ_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)y % 16 == 0), BQ_EINVAL,
+             "pwconv_bn_fwd: operands must be 16-byte aligned");
+  BQ_REQUIRE(R * (long)ldx * 2 < 0x7FFFFFFFL - 64L * ldx * 2, BQ_ELIMIT, "pwconv_bn_fwd: x larger than 2 GB");
+  PwconvArgs a;
+  a.W = (const __bf16 *)w; a.X = (const __bf16 *)x; a.Y = (__bf16 *)y; a.partial = partial;
+  a.ldw = ldw; a.ldx = ldx; a.Ni = N; a.R = (int)R; a.Kc = Kc;
+  a.tiles_i = N / 64;
+  a.Gj = bq_pwconv_records(R, N) / 2;
+  a.w_bytes = (unsigned)((long)N * ldw * 2);
+  a.x_bytes = (unsigned)(R * (long)ldx * 2);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(pwconv64_kernel, dim3(a.tiles_i * a.Gj), dim3(256), 0, st, a);
+  PwconvBnParams p{partial, gamma, beta, running_mean, running_var, num_batches_tracked, scale, shift, mean, rstd,
+                   eps, momentum, N, a.Gj * 2, a.Gj, R};
+  hipLaunchKernelGGL(pwconv_bn_finalize_kernel, dim3((N + 63) / 64), dim3(256), 0, st, p);
+  return check_launch("pwconv_bn_fwd");
 }

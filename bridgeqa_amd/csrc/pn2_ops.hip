@@ -249,14 +249,15 @@ __global__ __launch_bounds__(256) void group_concat_pm_kernel(const float *__res
                                                               const float *__restrict__ feats, long f_bs, long f_rs,
                                                               const int32_t *__restrict__ idx, OT *__restrict__ out,
                                                               int C, int N, int M, int S, float radius, int normalize,
-                                                              long total) {
+                                                              long total, int ld) {
   const int lane = threadIdx.x & 63;
   const int CT = C + 3;
   for (long pos = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pos < total; pos += (long)gridDim.x * 4) {
     const long bj = pos / S;            // b*M + j
     const int b = (int)(bj / M);
     const int id = idx[pos];
-    OT *o = out + pos * CT;
+    OT *o = out + pos * ld;             // rows of ld >= 3 + C elements (padding zeroed: 16-byte aligned GEMM rows)
+    if (lane < ld - CT) o[CT + lane] = (OT)0.f;
     if (lane < 3) {
       float v = xyz[((long)b * N + id) * 3 + lane] - new_xyz[bj * 3 + lane];
       if (normalize) v /= radius;
@@ -275,14 +276,13 @@ __global__ __launch_bounds__(256) void group_concat_pm_grad_kernel(const OT *__r
                                                                    float *__restrict__ grad_xyz,
                                                                    float *__restrict__ grad_new_xyz, int C, int N,
                                                                    int M, int S, float radius, int normalize,
-                                                                   long total) {
+                                                                   long total, int ld) {
   const int lane = threadIdx.x & 63;
-  const int CT = C + 3;
   for (long pos = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pos < total; pos += (long)gridDim.x * 4) {
     const long bj = pos / S;
     const int b = (int)(bj / M);
     const int id = idx[pos];
-    const OT *g = grad_out + pos * CT;
+    const OT *g = grad_out + pos * ld;
     if (lane < 3 && (grad_xyz || grad_new_xyz)) {
       float v = (float)g[lane];
       if (normalize) v /= radius;
@@ -616,18 +616,19 @@ extern "C" __attribute__((visibility("default"))) int bq_debug_clock_mhz(float *
 // bf16.
 extern "C" __attribute__((visibility("default"))) int bq_group_concat_pm(
     const float *xyz, const float *new_xyz, const float *feats, long f_bs, long f_rs, const int32_t *idx, void *out,
-    int out_bf16, int B, int C, int N, int M, int S, float radius, int normalize, void *stream) {
+    int out_bf16, int B, int C, int N, int M, int S, float radius, int normalize, int ld, void *stream) {
   BQ_REQUIRE(B >= 0 && C >= 0 && N >= 0 && M >= 0 && S >= 0, BQ_EINVAL, "group_concat_pm: bad extents");
+  BQ_REQUIRE(ld >= C + 3 && ld - (C + 3) < 64, BQ_EINVAL, "group_concat_pm: row stride %d for %d channels", ld, C + 3);
   if (B == 0 || M == 0 || S == 0) return BQ_OK;
   BQ_REQUIRE(xyz && new_xyz && idx && out && (feats || C == 0), BQ_EINVAL, "group_concat_pm: null pointer");
   const long total = (long)B * M * S;
   const int blocks = (int)(total / 4 < 8192 ? (total + 3) / 4 : 8192);
   if (out_bf16)
     hipLaunchKernelGGL(group_concat_pm_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, xyz, new_xyz,
-                       feats, f_bs, f_rs, idx, (__bf16 *)out, C, N, M, S, radius, normalize, total);
+                       feats, f_bs, f_rs, idx, (__bf16 *)out, C, N, M, S, radius, normalize, total, ld);
   else
     hipLaunchKernelGGL(group_concat_pm_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, xyz, new_xyz,
-                       feats, f_bs, f_rs, idx, (float *)out, C, N, M, S, radius, normalize, total);
+                       feats, f_bs, f_rs, idx, (float *)out, C, N, M, S, radius, normalize, total, ld);
   return check_launch("group_concat_pm");
 }
 
@@ -635,8 +636,9 @@ extern "C" __attribute__((visibility("default"))) int bq_group_concat_pm(
 // optional (NULL).
 extern "C" __attribute__((visibility("default"))) int bq_group_concat_pm_grad(
     const void *grad_out, int in_bf16, const int32_t *idx, float *grad_feats, float *grad_xyz, float *grad_new_xyz,
-    int B, int C, int N, int M, int S, float radius, int normalize, void *stream) {
+    int B, int C, int N, int M, int S, float radius, int normalize, int ld, void *stream) {
   BQ_REQUIRE(B >= 0 && C >= 0 && N >= 0 && M >= 0 && S >= 0, BQ_EINVAL, "group_concat_pm_grad: bad extents");
+  BQ_REQUIRE(ld >= C + 3, BQ_EINVAL, "group_concat_pm_grad: row stride %d for %d channels", ld, C + 3);
   if (B == 0 || M == 0 || S == 0) return BQ_OK;
   BQ_REQUIRE(grad_out && idx, BQ_EINVAL, "group_concat_pm_grad: null pointer");
   const long total = (long)B * M * S;
@@ -644,10 +646,10 @@ extern "C" __attribute__((visibility("default"))) int bq_group_concat_pm_grad(
   if (in_bf16)
     hipLaunchKernelGGL(group_concat_pm_grad_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        (const __bf16 *)grad_out, idx, grad_feats, grad_xyz, grad_new_xyz, C, N, M, S, radius,
-                       normalize, total);
+                       normalize, total, ld);
   else
     hipLaunchKernelGGL(group_concat_pm_grad_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        (const float *)grad_out, idx, grad_feats, grad_xyz, grad_new_xyz, C, N, M, S, radius,
-                       normalize, total);
+                       normalize, total, ld);
   return check_launch("group_concat_pm_grad");
 }

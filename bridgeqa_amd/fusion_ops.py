@@ -124,11 +124,42 @@ def _shadow(t):
 
 
 def shadow_of(param):
-    """the registered bf16 shadow tensor of a parameter (None if it has none, or not of the current compute dtype)"""
+    """the registered bf16 shadow tensor of a parameter that an optimizer kernel may write element for element (None if
+    it has none, is not of the current compute dtype, or is a strided view -- those are refreshed by refresh_shadows)"""
     ent = _SHADOW.get(id(param))
-    if ent is None or ent[0]() is not param or ent[2].dtype != _COMPUTE_DTYPE or ent[2].device != param.device:
+    if (ent is None or ent[0]() is not param or ent[2].dtype != _COMPUTE_DTYPE or ent[2].device != param.device
+            or not ent[2].is_contiguous()):
         return None
     return ent[2]
+
+
+_PADDED = {}
+
+
+def padded_conv_shadow(weight):
+    """bf16 GEMM operand of a 1x1 convolution weight (N, K, 1, 1): (N, Kc) with Kc = K rounded up to 64, ZERO beyond K
+    (csrc/gemm.hip pwconv64_kernel contracts whole 64-wide K tiles; the padding multiplies whatever follows the K
+    channels of a point row).  The registered shadow of the parameter is the (N, K, 1, 1) view of that buffer, so the
+    optimizer's shadow refresh keeps it current."""
+    import weakref
+    N, K = weight.shape[0], weight.shape[1]
+    hit = _PADDED.get(id(weight))
+    if hit is not None and hit[0]() is weight and hit[1].device == weight.device:
+        ent = _SHADOW.get(id(weight))
+        if ent is not None and ent[2].untyped_storage().data_ptr() == hit[1].untyped_storage().data_ptr():
+            if ent[1] != weight._version:  # an in-place update nobody refreshed (load_state_dict, plain optimizers)
+                with torch.no_grad():
+                    ent[2].copy_(weight.detach())
+                _SHADOW[id(weight)] = (ent[0], weight._version, ent[2])
+            return hit[1]
+    Kc = (K + 63) // 64 * 64
+    with torch.no_grad():
+        buf = torch.zeros(N, Kc, dtype=torch.bfloat16, device=weight.device)
+        view = buf[:, :K].view(N, K, 1, 1) if Kc == K else buf[:, :K].unsqueeze(-1).unsqueeze(-1)
+        view.copy_(weight.detach())
+    _SHADOW[id(weight)] = (weakref.ref(weight), weight._version, view)
+    _PADDED[id(weight)] = (weakref.ref(weight), buf)
+    return buf
 
 
 _FRESH = set()

@@ -65,8 +65,10 @@ class PointnetSAModuleVotes(nn.Module):
         grouped_features, _grouped_xyz = self.grouper(xyz, new_xyz, features, idx=group_idx)  # (B, 3+C, npoint, nsample)
         # max over nsample == F.max_pool2d(kernel=[1, nsample]).squeeze(-1) (pointnet2_modules.py:259-262, 272); a row
         # reduction instead of the generic NCHW pooling kernel.  Tie routing in backward is immaterial.
-        if (grouped_features.dtype == torch.bfloat16 and grouped_features.is_contiguous(memory_format=torch.channels_last)
-                and not grouped_features.is_contiguous()):
+        if grouped_features.dtype == torch.bfloat16 and (
+                pt_utils._rows_view(grouped_features) is not None
+                or (grouped_features.is_contiguous(memory_format=torch.channels_last)
+                    and not grouped_features.is_contiguous())):
             # NHWC fast path: the last layer's BatchNorm+ReLU kernel also reduces over S; the result stays
             # point-major (B,M,C) and is handed on as a (B,C,M) VIEW so the next level can group it without a transpose
             new_features = self.mlp_module(grouped_features, pool=True).float().transpose(1, 2)

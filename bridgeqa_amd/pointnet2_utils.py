@@ -167,11 +167,11 @@ class _GroupConcatPM(Function):
     """Point-major grouping (csrc/pn2_ops.hip group_concat_pm_kernel): feats_pm (B,N,C) rows -> (B,M,S,3+C)."""
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, feats_pm, idx, radius, normalize, out_dtype):
+    def forward(ctx, xyz, new_xyz, feats_pm, idx, radius, normalize, out_dtype, pad_to=1):
         ctx.save_for_backward(idx)
         ctx.n, ctx.radius, ctx.normalize = xyz.size(1), radius, normalize
         ctx.has_features = feats_pm is not None
-        return _ext.group_concat_pm(xyz, new_xyz, feats_pm, idx, radius, normalize, out_dtype)
+        return _ext.group_concat_pm(xyz, new_xyz, feats_pm, idx, radius, normalize, out_dtype, pad_to)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -179,7 +179,7 @@ class _GroupConcatPM(Function):
         need = ctx.needs_input_grad
         gf, gx, gn = _ext.group_concat_pm_grad(grad_out, idx, ctx.n, ctx.radius, ctx.normalize,
                                                ctx.has_features and need[2], need[0], need[1])
-        return gx, gn, gf, None, None, None, None
+        return gx, gn, gf, None, None, None, None, None
 
 
 def point_major(features):
@@ -218,8 +218,9 @@ class QueryAndGroup(nn.Module):
         from . import fusion_ops
         if (xyz.is_cuda and _ext is _hip_ext and fusion_ops.POINT_MAJOR[0] and self.use_xyz
                 and fusion_ops.compute_dtype() == torch.bfloat16):
+            # rows padded to a multiple of 8 elements (16 bytes): the SharedMLP's first GEMM reads them in place
             out = _GroupConcatPM.apply(xyz, new_xyz, point_major(features), idx, self.radius, self.normalize_xyz,
-                                       torch.bfloat16)
+                                       torch.bfloat16, 8)
             new_features = out.permute(0, 3, 1, 2)  # logical (B,3+C,M,S), physically NHWC
             return (new_features, new_features[:, :3]) if self.ret_grouped_xyz else new_features
         fused = hasattr(_ext, "group_concat") and self.nsample % 4 == 0

@@ -85,6 +85,85 @@ class _BNReLUPointMajor(torch.autograd.Function):
         return dx.view(B, M, S, C).permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None, None, None
 
 
+class _ConvBNReLUPointMajor(torch.autograd.Function):
+    """One SharedMLP layer -- 1x1 convolution (bias=False) -> training-mode BatchNorm2d -> ReLU (-> max over nsample) --
+    on point-major bf16 rows, all on this repo's kernels (reference lib/pointnet2/pytorch_utils.py:104-157, 11-36;
+    pointnet2_modules.py:259-262 for the pooling):
+      forward : csrc/gemm.hip pwconv64_kernel  y = x W^T with the BatchNorm statistics taken from its fp32 accumulators
+                (no statistics pass over y, no library convolution), then csrc/bn.hip bn_apply (normalise, clamp, pool);
+      backward: csrc/bn.hip bn_backward (dgamma, dbeta, gradient w.r.t. y), then the MFMA GEMM family of csrc/gemm.hip
+                for dX = dY W (transposed LDS reads of W) and dW = dY^T X (the contraction over the millions of rows cut
+                into pieces that accumulate with fp32 atomics).
+    x: (R, ldx) rows view (contiguous elements, ldx % 8 == 0, the first K elements are the input channels)."""
+
+    @staticmethod
+    def forward(ctx, x, conv_weight, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, relu,
+                pool, S):
+        from . import _ext, fusion_ops
+        K = conv_weight.shape[1]
+        w_pad = fusion_ops.padded_conv_shadow(conv_weight)
+        out, y_raw, stats = _ext.pwconv_bn_relu_fwd(x, K, w_pad, gamma, beta, running_mean, running_var,
+                                                    num_batches_tracked, eps, momentum, S, relu, pool)
+        ctx.save_for_backward(x, w_pad, y_raw, stats)
+        ctx.cfg = (K, S, relu, pool)
+        ctx.conv_weight = conv_weight
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import _ext
+        x, w_pad, y_raw, stats = ctx.saved_tensors
+        K, S, relu, pool = ctx.cfg
+        R, ldx = x.shape[0], x.stride(0)
+        N = y_raw.shape[1]
+        dout = dout.contiguous() if not dout.is_contiguous() else dout
+        if dout.dtype != torch.bfloat16:
+            dout = dout.to(torch.bfloat16)
+        dy, dgamma, dbeta = _ext.bn_relu_bwd(dout, y_raw, stats, S, relu, pool)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # dX (R, ldx) = dY (R, N) W (N, ldx): the padding columns of W are zero, so are the padding columns of dX
+            dx_full = torch.empty(R, ldx, dtype=torch.bfloat16, device=x.device)
+            _ext.gemm_grouped([dict(P=w_pad[:, :ldx], Q=dy, out=dx_full)], _ext.GEMM_P_XC, _ext.EPI_NONE, 64)
+            dx = dx_full[:, :x.shape[1]]
+        dw = None
+        if ctx.needs_input_grad[1]:
+            xs = torch.as_strided(x, (R, ldx), (ldx, 1))  # whole padded rows (the padding is zero / zero-weighted)
+            dwf = torch.zeros(N, ldx, dtype=torch.float32, device=x.device)
+            tiles = ((ldx + 63) // 64) * (N // 64)
+            ksplit = max(1, min((R + 63) // 64, (1024 + tiles - 1) // tiles))
+            _ext.gemm_grouped([dict(P=xs, Q=dy, out=dwf, ksplit=ksplit)],
+                              _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32, _ext.EPI_NONE, 64)
+            dw = dwf[:, :K].reshape(ctx.conv_weight.shape)
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def _rows_view(x):
+    """(B, C, M, S) logical NCHW tensor that is physically point-major rows (b, m, s) of a uniform stride ld >= C with
+    contiguous channels -> the (B*M*S, C) rows view with stride (ld, 1), or None"""
+    if x.dim() != 4 or x.stride(1) != 1:
+        return None
+    B, C, M, S = x.shape
+    ld = x.stride(3)
+    if ld < C or ld % 8 or x.stride(2) != S * ld or x.stride(0) != M * S * ld or x.data_ptr() % 16:
+        return None
+    return torch.as_strided(x, (B * M * S, C), (ld, 1))
+
+
+def _native_layer_ok(layer):
+    """the native SharedMLP layer covers: conv without bias, training-mode BatchNorm2d with momentum and affine
+    parameters, ReLU or no activation, output channels a multiple of 64 and a power of two (the BN kernels)"""
+    if not hasattr(layer, "bn") or layer.conv.bias is not None:
+        return False
+    bn = layer.bn.bn
+    act = getattr(layer, "activation", None)
+    C = bn.num_features
+    return (bn.training and bn.momentum is not None and bn.track_running_stats and bn.affine
+            and (act is None or isinstance(act, nn.ReLU)) and C % 64 == 0 and (C & (C - 1)) == 0 and C <= 2048
+            and bn.weight.dtype == torch.float32 and layer.conv.weight.dtype == torch.float32
+            and tuple(layer.conv.kernel_size) == (1, 1))
+
+
 def _bn_kernel_ok(x, layer):
     """the fused BN+ReLU kernels cover: training-mode BatchNorm2d with a momentum, ReLU (or no) activation, bf16 NHWC
     activations with a power-of-two channel count"""
@@ -114,11 +193,24 @@ class SharedMLP(nn.Sequential):
         if x.dtype != torch.bfloat16:
             assert not pool
             return super().forward(x)  # reference composition (fp32: conv1x1 -> BN -> ReLU per layer)
+        from . import pointnet2_utils
+        rows = _rows_view(x) if (x.is_cuda and pointnet2_utils.backend_is_hip()) else None
+        if rows is not None and all(_native_layer_ok(layer) for layer in self):
+            # point-major rows (csrc/pn2_ops.hip group_concat_pm) all the way: every layer is one GEMM launch with the
+            # BatchNorm statistics in its epilogue + one normalise / ReLU (/ max over nsample) pass; no library
+            # convolution, no layout change, no statistics pass (see _ConvBNReLUPointMajor)
+            B, _, M, S = x.shape
+            last = len(self) - 1
+            for i, layer in enumerate(self):
+                bn = layer.bn.bn
+                rows = _ConvBNReLUPointMajor.apply(rows, layer.conv.weight, bn.weight, bn.bias, bn.running_mean,
+                                                   bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum,
+                                                   hasattr(layer, "activation"), pool and i == last, S)
+            C = rows.shape[1]
+            return rows.view(B, M, C) if pool else rows.view(B, M, S, C).permute(0, 3, 1, 2)
         if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last):
-            # bf16 NHWC grouped tensor (point-major fast path): the 1x1 convolutions run as bf16 implicit GEMMs on the
-            # layout as it is; BatchNorm (fp32 parameters and statistics) + ReLU (+ the max over nsample) are one
-            # stats pass and one apply pass over the convolution output (csrc/bn.hip)
-            from . import pointnet2_utils
+            # bf16 NHWC grouped tensor without the native layer's preconditions (eval-mode BatchNorm, odd channel
+            # counts): the 1x1 convolutions run as library bf16 implicit GEMMs; BatchNorm + ReLU (+ pool) on csrc/bn.hip
             last = len(self) - 1
             for i, layer in enumerate(self):
                 with torch.autocast("cuda", dtype=torch.bfloat16):

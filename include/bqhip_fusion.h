@@ -96,16 +96,18 @@ BQ_API int bq_group_concat_bf16(const float *xyz, const float *new_xyz, const fl
 BQ_API int bq_group_concat_grad_bf16(const void *grad_out, const int32_t *idx, float *grad_features, float *grad_xyz,
                                      float *grad_new_xyz, int B, int C, int N, int M, int S, float radius,
                                      int normalize, void *stream);
-/* point-major: feats rows (b, n) of C floats at feats + b*f_bs + n*f_rs; out (B,M,S,3+C) f32 or bf16 (the
- * channels-last layout MIOpen's NHWC convolutions and the next level's grouping read without a transpose);
+/* point-major: feats rows (b, n) of C floats at feats + b*f_bs + n*f_rs; out rows (b, m, s) of ld >= 3+C elements, f32
+ * or bf16, elements 3+C .. ld-1 zeroed (ld = 3+C rounded up to 8: 16-byte aligned rows for the SharedMLP GEMM of
+ * bq_pwconv_bn_fwd; the next level's grouping reads the same rows without a transpose);
  * same values as bq_group_concat (pointnet2_utils.py:348-359). */
 BQ_API int bq_group_concat_pm(const float *xyz, const float *new_xyz, const float *feats, long f_bs, long f_rs,
                               const int32_t *idx, void *out, int out_bf16, int B, int C, int N, int M, int S,
-                              float radius, int normalize, void *stream);
-/* grad_feats (B,N,C) point-major, zero_init (or NULL); grad_xyz / grad_new_xyz as bq_group_concat_grad */
+                              float radius, int normalize, int ld, void *stream);
+/* grad_out rows of ld elements; grad_feats (B,N,C) point-major, zero_init (or NULL); grad_xyz / grad_new_xyz as
+ * bq_group_concat_grad */
 BQ_API int bq_group_concat_pm_grad(const void *grad_out, int in_bf16, const int32_t *idx, float *grad_feats,
                                    float *grad_xyz, float *grad_new_xyz, int B, int C, int N, int M, int S,
-                                   float radius, int normalize, void *stream);
+                                   float radius, int normalize, int ld, void *stream);
 
 /* ---- training-mode BatchNorm2d + ReLU (+ max over nsample) on point-major rows (csrc/bn.hip) ------------------
  * Replaces conv -> BatchNorm2d -> ReLU of one SharedMLP layer (lib/pointnet2/pytorch_utils.py:104-157) and, for the
@@ -176,6 +178,12 @@ typedef struct bq_gemm_desc {
   int ldp, ldq, ldo;
   int Ni, Nj, Kc;
   int bias_bf16; /* 0: bias is fp32 (a master parameter), 1: bias is bf16 (a concatenated operand copy) */
+  long p_bytes, q_bytes; /* 0: derived from the extents.  Otherwise the true size of the operand buffer: a K-contiguous
+                            operand may have rows SHORTER than Kc (e.g. 136 elements of a 3+C = 135 channel point row
+                            against Kc = 192) when the other operand is zero-padded to Kc -- the tail of a row then reads
+                            the head of the next one (finite values times zeros), bounded by this size */
+  int ksplit;            /* > 1 (fp32 out, tile 64): the contraction runs in ksplit pieces accumulated with fp32 atomics
+                            into `out`, which the caller zero-fills (weight gradients over millions of rows) */
 } bq_gemm_desc;
 BQ_API int bq_gemm_max_problems(void); /* problems per launch; longer lists are split into several launches */
 BQ_API int bq_gemm_bf16(const bq_gemm_desc *problems, int n, int flags, int epilogue, int tile, void *stream);
@@ -189,6 +197,21 @@ typedef struct bq_colsum_desc {
   int M, N, ld;
 } bq_colsum_desc;
 BQ_API int bq_colsum_grouped_bf16(const bq_colsum_desc *problems, int n, void *stream);
+
+/* ---- SharedMLP layer: 1x1 convolution on point-major rows + BatchNorm statistics in its epilogue (csrc/gemm.hip) ----
+ * Replaces conv (1x1, bias=False) -> the statistics pass of BatchNorm2d(train) of one SharedMLP layer
+ * (lib/pointnet2/pytorch_utils.py:104-157, :11-36):  y[r][n] = sum_k x[r][k] w[n][k]  for bf16 x (R rows of ldx >= K
+ * elements: (b, npoint, nsample) x (3+C) point-major), bf16 w (N rows of ldw >= Kc elements, ZERO beyond K, Kc % 64
+ * == 0), y bf16 (R, N), N % 64 == 0; and from the fp32 accumulators (before the rounding of y) the training-mode
+ * statistics: scale = gamma * rstd, shift = beta - mean * scale, mean, rstd (f32 N each), running_mean / running_var
+ * (momentum, unbiased) and num_batches_tracked updated when non-NULL -- what bq_bn_stats computes from a second pass
+ * over y.  bq_bn_apply / bq_bn_backward consume scale / shift / mean / rstd unchanged.
+ * partial: bq_pwconv_records(R, N) * 3 * N floats of scratch. */
+BQ_API int bq_pwconv_records(long R, int N);
+BQ_API int bq_pwconv_bn_fwd(const void *x, long R, int K, int ldx, const void *w, int ldw, int Kc, int N, void *y,
+                            float *partial, const float *gamma, const float *beta, float *running_mean,
+                            float *running_var, long long *num_batches_tracked, float eps, float momentum,
+                            float *scale, float *shift, float *mean, float *rstd, void *stream);
 
 #ifdef __cplusplus
 }

@@ -160,3 +160,86 @@ def test_fused_batchnorm_statistics_survive_a_large_mean(dev):
     assert ((stats[3].double() - rstd).abs() / rstd).max().item() < 2e-3
     want = ((xd - mean) * rstd).float()
     assert ((y.float() - want).norm() / want.norm()).item() < 1e-2
+
+
+def test_pwconv_bn_kernel_vs_torch_fp32(dev):
+    """csrc/gemm.hip pwconv64_kernel + pwconv_bn_finalize_kernel (1x1 convolution with the BatchNorm statistics in its
+    epilogue) against torch: y = x W^T from the same bf16 operands in fp32, training-mode batch statistics of the fp32
+    y (so the kernel's statistics, taken from its fp32 accumulators, must agree to fp32 accuracy -- also when the channel
+    means are 100x the standard deviation), running buffers, then relu(bn(y)) (+ max over S) within bf16 rounding."""
+    from bridgeqa_amd import _ext
+    g = torch.Generator().manual_seed(0)
+    for (R, K, ldx, N, S, pool, offset) in ((64 * 37, 135, 136, 64, 16, True, 0.0), (4096 + 24, 64, 64, 128, 8, False, 0.0),
+                                            (65536, 131, 136, 128, 32, True, 0.0), (8192, 259, 264, 256, 16, True, 0.0),
+                                            (20000, 64, 64, 64, 16, False, 25.0)):
+        xfull = torch.zeros(R, ldx)
+        xfull[:, :K] = torch.randn(R, K, generator=g)
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        if offset:
+            xfull[:, 0] = 1.0
+            w[:, 0] = offset          # every output channel gets a mean of `offset` on a spread of ~1
+        Kc = (K + 63) // 64 * 64
+        wpad = torch.zeros(N, Kc)
+        wpad[:, :K] = w
+        x_d = xfull.to(dev).to(torch.bfloat16)
+        w_d = wpad.to(dev).to(torch.bfloat16)
+        gamma, beta = (torch.rand(N, generator=g) + 0.5).to(dev), (torch.randn(N, generator=g) * 0.1).to(dev)
+        rm, rv = torch.zeros(N, device=dev), torch.ones(N, device=dev)
+        nbt = torch.zeros((), dtype=torch.int64, device=dev)
+        rows = x_d[:, :K] if ldx != K else x_d
+        out, y_raw, stats = _ext.pwconv_bn_relu_fwd(rows, K, w_d, gamma, beta, rm, rv, nbt, 1e-5, 0.1, S, True, pool)
+        y = x_d[:, :K].float() @ w_d[:, :K].float().t()
+        mean, var = y.mean(0), y.var(0, unbiased=False)
+        rel = lambda a, b: ((a - b).norm() / (b.norm() + 1e-20)).item()
+        assert rel(y_raw.float(), y) < 3e-3
+        assert rel(stats[2], mean) < 1e-5, (R, K, N, rel(stats[2], mean))
+        assert rel(stats[3], (var + 1e-5).rsqrt()) < 1e-4, (R, K, N, rel(stats[3], (var + 1e-5).rsqrt()))
+        assert rel(rm, 0.1 * mean) < 1e-5 and rel(rv, 0.9 + 0.1 * y.var(0, unbiased=True)) < 1e-4
+        assert nbt.item() == 1
+        ref = torch.relu((y_raw.float() - mean) * (var + 1e-5).rsqrt() * gamma + beta)
+        if pool:
+            ref = ref.view(R // S, S, N).max(1)[0]
+        assert rel(out.float(), ref) < 5e-3, (R, K, N, rel(out.float(), ref))
+
+
+def test_native_sharedmlp_sa_module_vs_fp32_reference(dev):
+    """A set-abstraction module at SA2's shape through the native layers (point-major grouping with padded rows ->
+    pwconv + BN statistics -> normalise / ReLU / pool; backward through the GEMM family) against the same module in
+    fp32 (the reference composition: gather, conv2d, batch_norm, relu, max): outputs rel-L2 <= 1e-2,
+    running statistics, and the gradients of every parameter and of the input features."""
+    from bridgeqa_amd import fusion_ops
+    from bridgeqa_amd.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(3)
+    sa = PointnetSAModuleVotes(npoint=256, radius=0.5, nsample=32, mlp=[128, 128, 128, 256], use_xyz=True,
+                               normalize_xyz=True).to(dev).train()
+    g = torch.Generator().manual_seed(4)
+    xyz = (torch.rand(4, 2048, 3, generator=g) * torch.tensor([4.0, 4.0, 2.0])).to(dev)
+    feat0 = torch.randn(4, 128, 2048, generator=g).to(dev)
+    wout = torch.randn(4, 256, 256, generator=g).to(dev)
+    state = {k: v.clone() for k, v in sa.state_dict().items()}
+    res = {}
+    for mode, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        sa.load_state_dict(state)
+        sa.zero_grad(set_to_none=True)
+        feat = feat0.clone().requires_grad_(True)
+        prev = fusion_ops.set_compute_dtype(dt)
+        try:
+            nx, nf, ni = sa(xyz, feat)
+            (nf.float() * wout).sum().backward()
+        finally:
+            fusion_ops.set_compute_dtype(prev)
+        res[mode] = dict(nf=nf.detach().float().clone(), ni=ni.clone(), gfeat=feat.grad.clone(),
+                         grads={n: p.grad.detach().clone() for n, p in sa.named_parameters()},
+                         bufs={n: b.detach().clone().float() for n, b in sa.named_buffers()})
+    a, b = res["fp32"], res["bf16"]
+    rel = lambda x, y: ((x.float() - y.float()).norm() / (y.float().norm() + 1e-20)).item()
+    assert torch.equal(a["ni"], b["ni"])
+    assert rel(b["nf"], a["nf"]) <= 1e-2, rel(b["nf"], a["nf"])
+    for n in a["bufs"]:
+        if "num_batches" in n:
+            assert torch.equal(a["bufs"][n], b["bufs"][n])
+        else:
+            assert rel(b["bufs"][n], a["bufs"][n]) <= 1e-2, (n, rel(b["bufs"][n], a["bufs"][n]))
+    worst = max((rel(b["grads"][n], a["grads"][n]), n) for n in a["grads"])
+    assert worst[0] <= 5e-2, worst      # two bf16 roundings per layer on the way back; max-pool winners can move
+    assert rel(b["gfeat"], a["gfeat"]) <= 5e-2, rel(b["gfeat"], a["gfeat"])

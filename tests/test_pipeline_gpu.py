@@ -195,7 +195,7 @@ def test_fused_adamw_checkpoint_resume_and_scheduler_under_replay(dev):
         assert torch.allclose(x, y, rtol=1e-6, atol=1e-7)
     t = fresh(); ot = torch.optim.AdamW(t, lr=1e-2, weight_decay=1e-2); run(ot, range(3))
     d = [torch.nn.Parameter(p.detach().clone()) for p in t]; od = FusedAdamW(d, lr=1e-2, weight_decay=1e-2)
-    od.load_state_dict(ot.state_dict())
+    od.load_state_dict(__import__("copy").deepcopy(ot.state_dict()))  # (load_state_dict keeps device tensors by reference)
     run(ot, range(3, 6)); run(od, range(3, 6))
     for x, y in zip(t, d):
         assert torch.allclose(x, y, rtol=2e-5, atol=2e-6)

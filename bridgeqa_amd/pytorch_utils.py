@@ -208,6 +208,8 @@ class SharedMLP(nn.Sequential):
                                                    hasattr(layer, "activation"), pool and i == last, S)
             C = rows.shape[1]
             return rows.view(B, M, C) if pool else rows.view(B, M, S, C).permute(0, 3, 1, 2)
+        if rows is not None and not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)  # padded point rows -> compact NHWC for the library path
         if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last):
             # bf16 NHWC grouped tensor without the native layer's preconditions (eval-mode BatchNorm, odd channel
             # counts): the 1x1 convolutions run as library bf16 implicit GEMMs; BatchNorm + ReLU (+ pool) on csrc/bn.hip

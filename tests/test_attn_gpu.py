@@ -488,6 +488,7 @@ def test_shadow_weights_follow_the_optimizer(dev):
     cast after an in-place update (refresh_shadows), and by the lazy version check when nobody refreshed them."""
     from bridgeqa_amd import fusion_ops as ops
     prev_dt = ops.set_compute_dtype(torch.bfloat16)
+    ops._SHADOW.clear(); ops._CAT_CACHE.clear(); ops._PADDED.clear()  # (operand copies other tests' modules registered)
     try:
         torch.manual_seed(2)
         lin = torch.nn.Linear(256, 256).to(dev)

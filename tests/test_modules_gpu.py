@@ -240,6 +240,54 @@ def test_native_sharedmlp_sa_module_vs_fp32_reference(dev):
             assert torch.equal(a["bufs"][n], b["bufs"][n])
         else:
             assert rel(b["bufs"][n], a["bufs"][n]) <= 1e-2, (n, rel(b["bufs"][n], a["bufs"][n]))
-    worst = max((rel(b["grads"][n], a["grads"][n]), n) for n in a["grads"])
-    assert worst[0] <= 5e-2, worst      # two bf16 roundings per layer on the way back; max-pool winners can move
-    assert rel(b["gfeat"], a["gfeat"]) <= 5e-2, rel(b["gfeat"], a["gfeat"])
+    errs = {n: rel(b["grads"][n], a["grads"][n]) for n in a["grads"]}
+    print("native SharedMLP vs fp32: out %.4f  dfeat %.4f  " % (rel(b["nf"], a["nf"]), rel(b["gfeat"], a["gfeat"]))
+          + "  ".join("%s %.4f" % (n.replace("mlp_module.", ""), e) for n, e in errs.items()))
+    # Gradients THROUGH the max over nsample: rounding y to bf16 (3 significant digits) moves the arg-max of a pooled
+    # group to another of its 32 rows whenever the two largest values are within one bf16 step, and the whole gradient
+    # of that (point, channel) then flows to a different row -- measured 12-15 % rel-L2 on everything upstream of the
+    # pool, 0.5 % on the pooled layer's own BatchNorm parameters (the operators themselves are checked without pooling in
+    # test_native_sharedmlp_layer_backward_vs_torch below, at 2e-2).
+    for n, e in errs.items():
+        assert e <= 2e-1, (n, e)
+    assert rel(b["gfeat"], a["gfeat"]) <= 2e-1, rel(b["gfeat"], a["gfeat"])
+
+
+def test_native_sharedmlp_layer_backward_vs_torch(dev):
+    """One native SharedMLP layer (pytorch_utils._ConvBNReLUPointMajor: pwconv + BN statistics, normalise + ReLU; backward
+    = BN backward + dX / dW through the GEMM family) WITHOUT pooling against torch autograd in fp32 on the same bf16
+    operands: output 5e-3, dX / dW / dgamma / dbeta 2e-2 (bf16 rounding of y and of dY; ReLU mask flips at |y| ~ 0)."""
+    from bridgeqa_amd import fusion_ops
+    from bridgeqa_amd.pytorch_utils import _ConvBNReLUPointMajor
+    g = torch.Generator().manual_seed(5)
+    for (R, K, ldx, N, S) in ((8192, 131, 136, 128, 32), (4096, 128, 128, 256, 16), (20000, 259, 264, 64, 16)):
+        prev = fusion_ops.set_compute_dtype(torch.bfloat16)
+        try:
+            conv = torch.nn.Conv2d(K, N, 1, bias=False).to(dev)
+            bn = torch.nn.BatchNorm2d(N).to(dev)
+            with torch.no_grad():
+                bn.weight.copy_(torch.rand(N, generator=g) + 0.5); bn.bias.copy_(torch.randn(N, generator=g) * 0.2)
+            xfull = torch.zeros(R, ldx)
+            xfull[:, :K] = torch.randn(R, K, generator=g)
+            xb = xfull.to(dev).to(torch.bfloat16)
+            x_nat = xb.clone().requires_grad_(True)
+            rows = x_nat[:, :K] if ldx != K else x_nat
+            wout = torch.randn(R, N, generator=g).to(dev)
+            out = _ConvBNReLUPointMajor.apply(rows, conv.weight, bn.weight, bn.bias, None, None, None, bn.eps, 0.1, True,
+                                              False, S)
+            (out.float() * wout).sum().backward()
+            got = dict(out=out.detach().float(), dx=x_nat.grad[:, :K].float(), dw=conv.weight.grad.clone(),
+                       dg=bn.weight.grad.clone(), db=bn.bias.grad.clone())
+            conv.weight.grad = None; bn.weight.grad = None; bn.bias.grad = None
+            x_ref = xb[:, :K].float().clone().requires_grad_(True)
+            w_ref = conv.weight.detach().to(torch.bfloat16).float().view(N, K).requires_grad_(True)
+            y = x_ref @ w_ref.t()
+            yn = torch.nn.functional.batch_norm(y, None, None, bn.weight, bn.bias, True, 0.1, bn.eps)
+            ref = torch.relu(yn)
+            (ref * wout).sum().backward()
+            rel = lambda a, b: ((a.float() - b.float()).norm() / (b.float().norm() + 1e-20)).item()
+            errs = dict(out=rel(got["out"], ref), dx=rel(got["dx"], x_ref.grad), dw=rel(got["dw"].view(N, K), w_ref.grad),
+                        dg=rel(got["dg"], bn.weight.grad), db=rel(got["db"], bn.bias.grad))
+            assert errs["out"] <= 5e-3 and max(errs[k] for k in ("dx", "dw", "dg", "db")) <= 2e-2, (R, K, N, errs)
+        finally:
+            fusion_ops.set_compute_dtype(prev)

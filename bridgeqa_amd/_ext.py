@@ -508,18 +508,18 @@ def gelu_fwd(x):
 # ---- multi-tensor AdamW that also writes the bf16 shadows (csrc/adamw.hip) -----------------------------
 _lib.bq_adamw_chunk_elems.restype = ctypes.c_int
 _lib.bq_adamw_tensor_bytes.restype = ctypes.c_int
-_lib.bq_adamw_multi.argtypes = [_vp, _vp, _i, _vp, _f, _f, _f, _vp]
+_lib.bq_adamw_multi.argtypes = [_vp, _vp, _i, _vp, _f, _f, _f, _f, _vp]
 _lib.bq_adamw_multi.restype = ctypes.c_int
 ADAMW_CHUNK = _lib.bq_adamw_chunk_elems()
 ADAMW_TENSOR_BYTES = _lib.bq_adamw_tensor_bytes()
 
 
-def adamw_multi(table, chunks, step, beta1, beta2, eps):
+def adamw_multi(table, chunks, step, beta1, beta2, eps, grad_clip_value=0.0):
     """table: uint8 device tensor of packed AdamWTensor records; chunks: int32 (n, 2) device tensor; step: f32 device
-    scalar holding the 1-based count of THIS update."""
+    scalar holding the 1-based count of THIS update; grad_clip_value > 0: gradients clamped to +-value as they are read."""
     with torch.cuda.device(table.device):
         _check(_lib.bq_adamw_multi(_p(table), _p(chunks), chunks.shape[0], _p(step), float(beta1), float(beta2),
-                                   float(eps), _stream()), "adamw")
+                                   float(eps), float(grad_clip_value or 0.0), _stream()), "adamw")
 
 
 # ---- training-mode BatchNorm + ReLU (+ max over nsample) on point-major bf16 rows (csrc/bn.hip) -------

@@ -8,8 +8,12 @@ from . import fusion_ops
 
 
 class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_clip_value=None):
+        """grad_clip_value: clamp every gradient element to [-v, v] inside the update kernel -- the reference's
+        clip_grad_value_(parameters, 1.0) before optimizer.step() (lib/solver.py:407-409) at no extra pass; the stored
+        .grad tensors are left unclamped."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.grad_clip_value = grad_clip_value
         betas_set = {tuple(g["betas"]) for g in self.param_groups}
         eps_set = {g["eps"] for g in self.param_groups}
         if len(betas_set) != 1 or len(eps_set) != 1:
@@ -117,6 +121,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._devbuf.copy_(self._pinned, non_blocking=True)
         self._step(device).add_(1.0)
         beta1, beta2 = self.param_groups[0]["betas"]
-        _ext.adamw_multi(self._table, self._chunks, self._step_t, beta1, beta2, self.param_groups[0]["eps"])
+        _ext.adamw_multi(self._table, self._chunks, self._step_t, beta1, beta2, self.param_groups[0]["eps"],
+                         self.grad_clip_value)
         fusion_ops.shadows_written([r[0] for r in recs if r[4] is not None])
         return loss

@@ -137,11 +137,14 @@ BQ_API int bq_gelu_fwd_bf16(const void *x, void *y, long n, void *stream);
  * per-weight fp32 -> bf16 casts of the next forward.  table: n records {p, g, m, v, shadow|NULL (device pointers),
  * n (int64 elements), lr, weight_decay (f32)} of bq_adamw_tensor_bytes() bytes each, in device memory; chunks:
  * n_chunks x {tensor index, chunk index} int32 pairs covering every tensor in pieces of bq_adamw_chunk_elems()
- * elements; step: device f32 = the 1-based count of THIS update (graph-replay safe).  amsgrad / maximize: off. */
+ * elements; step: device f32 = the 1-based count of THIS update (graph-replay safe).  amsgrad / maximize: off.
+ * grad_clip_value > 0: every gradient element is clamped to [-c, c] as it is read -- the reference's
+ * torch.nn.utils.clip_grad_value_(parameters, 1.0) before optimizer.step() (lib/solver.py:407-409) without a pass of
+ * its own; <= 0: off. */
 BQ_API int bq_adamw_chunk_elems(void);
 BQ_API int bq_adamw_tensor_bytes(void);
 BQ_API int bq_adamw_multi(const void *table, const void *chunks, int n_chunks, const float *step, float beta1,
-                          float beta2, float eps, void *stream);
+                          float beta2, float eps, float grad_clip_value, void *stream);
 
 /* ---- MFMA bf16 GEMM family (csrc/gemm.hip) -----------------------------------------------------------------
  * Replaces every nn.Linear of the fusion half and its autograd: models/vit.py:30-32 (Mlp fc1 / fc2), :51-53 (qkv /

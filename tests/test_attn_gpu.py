@@ -582,6 +582,19 @@ def test_fused_adamw_matches_torch_adamw_and_writes_the_shadows(dev):
             want = torch.nn.functional.linear(x, lin_w.detach().to(torch.bfloat16)).float()
             assert torch.allclose(got, want, atol=2e-2, rtol=2e-2)
         assert torch.equal(mine[-1], ref[-1])
+        # gradient value clipping inside the kernel == clip_grad_value_ then AdamW (lib/solver.py:407-409)
+        mc = [torch.nn.Parameter(torch.randn(300, 7, device=dev)), torch.nn.Parameter(torch.randn(1001, device=dev))]
+        rc = [torch.nn.Parameter(p.detach().clone()) for p in mc]
+        o3, o4 = FusedAdamW(mc, lr=1e-2, grad_clip_value=1.0), torch.optim.AdamW(rc, lr=1e-2)
+        for step in range(3):
+            for a, b in zip(mc, rc):
+                g = torch.randn_like(a) * 3
+                a.grad, b.grad = g.clone(), g.clone()
+            torch.nn.utils.clip_grad_value_(rc, 1.0)
+            o3.step(); o4.step()
+            for a, b in zip(mc, rc):
+                assert torch.allclose(a, b, rtol=2e-6, atol=2e-7)
+            assert mc[0].grad.abs().max().item() > 1.0   # the stored gradients stay unclamped
     finally:
         ops.set_compute_dtype(prev_dt)
 

@@ -114,7 +114,9 @@ def test_twin_encoder_hoisted_two_segment_wiring_on_gpu(dev):
     for x, y in zip(a[:4], b[:4]):
         assert rel(x, y) < 3e-2, rel(x, y)
     assert a[4].keys() == b[4].keys()
-    live = [k for k in a[4] if b[4][k].norm().item() > 1e-2]
+    # (key biases excluded: softmax is invariant to a constant added to every score of a query, so their gradient is
+    # exactly zero in exact arithmetic and rounding noise in floating point)
+    live = [k for k in a[4] if b[4][k].norm().item() > 1e-2 and not k.endswith("key.bias")]
     assert len(live) > 60
     worst = max((rel(a[4][k], b[4][k]), k) for k in live)
     assert worst[0] < 6e-2, worst

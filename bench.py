@@ -49,9 +49,6 @@ def parse():
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the whole train step (forward + backward + fused AdamW) from one HIP graph; "
                          "auto = on for a single GPU")
-    ap.add_argument("--schedule", choices=["auto", "phased", "single"], default=os.environ.get("BQ_SCHEDULE", "auto"),
-                    help="phased: one HIP graph per phase on two streams (bridgeqa_amd/pipeline.py); single: the "
-                         "whole step in one multi-stream graph; auto = phased for c3")
     ap.add_argument("--cpu-scenes", type=int, default=2, help="scenes in the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -326,7 +323,7 @@ def main():
     side = torch.cuda.Stream()
     graphed = False
 
-    phased = workload == "c3" and args.schedule in ("auto", "phased")
+    phased = workload == "c3"  # one HIP graph per phase on two streams (bridgeqa_amd/pipeline.py); c2: one graph
     pipe = None
     if phased:
         # ---- single GPU, c3: one HIP graph per phase, image / fusion chain on one stream, detector on a second,
@@ -373,9 +370,9 @@ def main():
         graph_body = eager_step
         after_replay = lambda: None
     else:
-        # ---- data parallel: the gradients live in flat buffers (bridgeqa_amd/ddp.py); the forward+backward is a
-        # HIP graph without collectives, the exchange is a few large bf16 all-reduces over RCCL, then fused AdamW
-        from bridgeqa_amd.ddp import FlatGradReducer, broadcast_parameters, used_parameters
+        # ---- data parallel, detector-only workload: the forward+backward is one HIP graph without collectives, then ONE
+        # packed all-reduce of every used gradient over RCCL (bridgeqa_amd/ddp.py), then fused AdamW
+        from bridgeqa_amd.ddp import PackedGradReducer, broadcast_parameters, used_parameters
         broadcast_parameters(model)
 
         def dry():
@@ -385,12 +382,13 @@ def main():
         with torch.cuda.stream(side):
             used = used_parameters(model, dry)
         torch.cuda.synchronize()
-        reducer = FlatGradReducer(used, comm_dtype=torch.bfloat16)
+        reducer = PackedGradReducer(used, comm_dtype=torch.bfloat16)
         reducer.force = args.dp_path
         opt = torch.optim.AdamW(used, lr=5e-4, weight_decay=1e-5, fused=True)
 
         def graph_body():
-            reducer.zero()
+            for p in used:
+                p.grad = None
             loss = total_loss(model(dict(batch)))
             loss.backward()
             return loss
@@ -516,7 +514,7 @@ def main():
                        "schedule": "phased: 6 graphs on 2 streams" if phased else "single graph",
                        "grad_exchange": (("per-phase packed bf16 all-reduce on a comm stream, %d MB on the wire"
                                           % (sum(r.nbytes_on_wire() for r in reducers.values()) >> 20)) if phased
-                                         else ("flat bf16 all-reduce after the fwd+bwd graph, %d MB on the wire"
+                                         else ("one packed bf16 all-reduce after the fwd+bwd graph, %d MB on the wire"
                                                % (reducer.nbytes_on_wire() >> 20))) if dp else None},
             "roofline": None,      # filled below: the dominant dense kernel (MFMA GEMM)
             "roofline_fps": {"kernel": "fps (SA1 %d->2048), csrc/fps_bucket.hip" % args.points, "bound": "hbm",

@@ -53,8 +53,6 @@ _lib.bq_attn_fwd.argtypes = [_vp] * 6 + [_i] * 5 + [_l] * 9 + [_f, _f, _u, _vp, 
 _lib.bq_attn_fwd.restype = ctypes.c_int
 _lib.bq_attn_bwd.argtypes = [_vp] * 11 + [_i] * 5 + [_l] * 9 + [_f, _f, _u, _vp, _i, _vp]
 _lib.bq_attn_bwd.restype = ctypes.c_int
-_lib.bq_transpose_pad.argtypes = [_vp, _vp, _i, _i, _i, _i, _l, _l, _l, _vp]
-_lib.bq_transpose_pad.restype = ctypes.c_int
 _lib.bq_drop_add_ln_fwd.argtypes = [_vp] * 9 + [_i, _i, _f, _f, _f, _i, _u, _vp, _vp]
 _lib.bq_drop_add_ln_fwd.restype = ctypes.c_int
 _lib.bq_drop_add_ln_bwd.argtypes = [_vp] * 10 + [_i, _i, _f, _f, _f, _i, _u, _vp, _vp]
@@ -307,31 +305,6 @@ def _bhd_strides(t):
     if t.dtype != torch.bfloat16 or t.stride(3) != 1 or t.shape[3] != 64:
         raise RuntimeError("attention operands must be bf16 (B, L, H, 64) views with a contiguous head dim")
     return t.stride(0), t.stride(1), t.stride(2)
-
-
-def transpose_v(v, Lp):
-    """(B, L, H, 64) -> zero padded (B, H, 64, Lp), token-contiguous: the transposed operands of the attention
-    kernels, in one launch."""
-    B, L, H, D = v.shape
-    vt = torch.empty(B, H, D, Lp, dtype=v.dtype, device=v.device)
-    _check(_lib.bq_transpose_pad(_p(v), _p(vt), B, H, L, Lp, *_bhd_strides(v), _stream()), "transpose_pad")
-    return vt
-
-
-_lib.bq_transpose_pad3.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]
-_lib.bq_transpose_pad3.restype = ctypes.c_int
-
-
-def transpose3(ts, Lps):
-    """three transpose_v in one launch: ts = three (B, L_i, H, 64) views (same B, H) -> three (B, H, 64, Lp_i)"""
-    B, _, H, D = ts[0].shape
-    outs = [torch.empty(B, H, D, Lp, dtype=t.dtype, device=t.device) for t, Lp in zip(ts, Lps)]
-    vp3, i3, l3 = ctypes.c_void_p * 3, ctypes.c_int * 3, ctypes.c_long * 3
-    _check(_lib.bq_transpose_pad3(vp3(*[t.data_ptr() for t in ts]), vp3(*[o.data_ptr() for o in outs]),
-                                  i3(*[t.shape[1] for t in ts]), i3(*Lps), l3(*[t.stride(0) for t in ts]),
-                                  l3(*[t.stride(1) for t in ts]), l3(*[t.stride(2) for t in ts]), B, H, _stream()),
-           "transpose_pad3")
-    return outs
 
 
 LOG2E = 1.4426950408889634

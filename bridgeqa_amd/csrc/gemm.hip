@@ -757,9 +757,10 @@ struct PwconvBnParams {
   long R;
 };
 
-// 4 threads per channel: thread phase ph merges the records g = ph (mod 4) in index order, then the four partial
-// (n, mean, M2) triples are merged in phase order (Chan et al.: exact for any partition, no cancellation, and the fixed
-// order makes the statistics bit-reproducible)
+// 16 threads per channel: thread phase ph merges the records g = ph (mod 16) in index order, then the sixteen partial
+// (n, mean, M2) triples are merged in phase order (Chan et al.: exact for any partition, no cancellation; the fixed
+// order makes the statistics bit-reproducible).  (4 phases took 46 us per layer: a serial chain of ~250 dependent
+// merges per thread; 16 phases keep the chain at ~64.)
 __device__ __forceinline__ void chan_merge(float &n, float &mean, float &m2, float ng, float mg, float m2g) {
   if (ng == 0.f) return;
   const float tot = n + ng, delta = mg - mean;
@@ -767,16 +768,17 @@ __device__ __forceinline__ void chan_merge(float &n, float &mean, float &m2, flo
   m2 += m2g + delta * delta * (n * ng / tot);
   n = tot;
 }
-__global__ __launch_bounds__(256) void pwconv_bn_finalize_kernel(const PwconvBnParams p) {
-  __shared__ float sh[3][4][64];
+constexpr int PWF_PH = 16;
+__global__ __launch_bounds__(1024) void pwconv_bn_finalize_kernel(const PwconvBnParams p) {
+  __shared__ float sh[3][PWF_PH][64];
   const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int c = min(blockIdx.x * 64 + cl, p.C - 1);
   float n = 0.f, mean = 0.f, m2 = 0.f;
-  for (int g0 = ph; g0 < p.nrec; g0 += 16) {
+  for (int g0 = ph; g0 < p.nrec; g0 += 4 * PWF_PH) {
     float pv[4], su[4], sq[4], ng[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {  // four records in flight per thread
-      const int g = g0 + 4 * u;
+      const int g = g0 + PWF_PH * u;
       const bool live = g < p.nrec;
       const float *rec = p.partial + (long)(live ? g : 0) * 3 * p.C;
       pv[u] = rec[c]; su[u] = rec[p.C + c]; sq[u] = rec[2 * p.C + c];
@@ -793,7 +795,7 @@ __global__ __launch_bounds__(256) void pwconv_bn_finalize_kernel(const PwconvBnP
   if (ph != 0 || blockIdx.x * 64 + cl >= p.C) return;
   n = 0.f; mean = 0.f; m2 = 0.f;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) chan_merge(n, mean, m2, sh[0][q][cl], sh[1][q][cl], sh[2][q][cl]);
+  for (int q = 0; q < PWF_PH; ++q) chan_merge(n, mean, m2, sh[0][q][cl], sh[1][q][cl], sh[2][q][cl]);
   const float var = m2 / n;
   const float rstd = rsqrtf(var + p.eps);
   const float sc = p.gamma[c] * rstd;
@@ -1008,6 +1010,6 @@ extern "C" int bq_pwconv_bn_fwd(const void *x, long R, int K, int ldx, const voi
   hipLaunchKernelGGL(pwconv64_kernel, dim3(a.tiles_i * a.Gj), dim3(256), 0, st, a);
   PwconvBnParams p{partial, gamma, beta, running_mean, running_var, num_batches_tracked, scale, shift, mean, rstd,
                    eps, momentum, N, a.Gj * 2, a.Gj, R};
-  hipLaunchKernelGGL(pwconv_bn_finalize_kernel, dim3((N + 63) / 64), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(pwconv_bn_finalize_kernel, dim3((N + 63) / 64), dim3(1024), 0, st, p);
   return check_launch("pwconv_bn_fwd");
 }

@@ -3,7 +3,6 @@
 // reference runs as dropout (2 kernels) + add + layer_norm (+ dtype casts) per site, 144 sites per step.
 // One wave per row (hidden size = 64 * 4 * NCH, 768 -> NCH = 3), values stay in registers, statistics by
 // DPP wave sums; the dropout mask is a stateless hash (regenerated in the backward, nothing stored).
-// Also here: the padded transpose the attention kernels want (one launch instead of zeros + strided copy).
 #include <cstdint>
 #include <stdlib.h>
 #include "bq_common.h"
@@ -190,43 +189,6 @@ __global__ __launch_bounds__(256) void drop_add_ln_bwd_kernel(const __bf16 *__re
   for (int c = threadIdx.x; c < H; c += 256) {
     atomicAdd(dgb + c, (s_g[0][c] + s_g[1][c]) + (s_g[2][c] + s_g[3][c]));
     atomicAdd(dgb + H + c, (s_b[0][c] + s_b[1][c]) + (s_b[2][c] + s_b[3][c]));
-  }
-}
-
-// out[bh][d][l] = in[b][l][h][d] for l < L, 0 for L <= l < Lp   (bf16; in given by element strides, d-contiguous
-// and 8-B aligned rows).  Up to three tensors per launch (blockIdx.z): the backward wants q^T, k^T and dO^T at once.
-struct TransposeJob {
-  const __bf16 *in;
-  __bf16 *out;
-  int L, Lp;
-  long bs, rs, hs;
-};
-struct TransposeJobs {
-  TransposeJob j[3];
-};
-
-__global__ __launch_bounds__(256) void transpose_pad_kernel(TransposeJobs jobs, int H) {
-  __shared__ __bf16 tile[64][68];
-  const TransposeJob &J = jobs.j[blockIdx.z];
-  const int l0 = blockIdx.x * 64;
-  if (l0 >= J.Lp) return;
-  const int bh = blockIdx.y, b = bh / H, hd = bh % H;
-  const __bf16 *src = J.in + b * J.bs + hd * J.hs;
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int i = threadIdx.x + it * 256, l = i >> 4, d = (i & 15) * 4;
-    bf16x4 v = {(__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f};
-    if (l0 + l < J.L) v = *reinterpret_cast<const bf16x4 *>(src + (long)(l0 + l) * J.rs + d);
-    *reinterpret_cast<bf16x4 *>(&tile[l][d]) = v;
-  }
-  __syncthreads();
-  __bf16 *dst = J.out + (long)bh * 64 * J.Lp + l0;
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int i = threadIdx.x + it * 256, d = i >> 4, l = (i & 15) * 4;
-    bf16x4 v;
-    v[0] = tile[l][d]; v[1] = tile[l + 1][d]; v[2] = tile[l + 2][d]; v[3] = tile[l + 3][d];
-    *reinterpret_cast<bf16x4 *>(dst + (long)d * J.Lp + l) = v;
   }
 }
 
@@ -492,34 +454,3 @@ extern "C" __attribute__((visibility("default"))) int bq_drop_add_ln_bwd(
   return check_launch("drop_add_ln_bwd");
 }
 
-static int transpose_job_ok(const TransposeJob &j) {
-  return j.in && j.out && j.L > 0 && j.Lp >= j.L && j.Lp % 64 == 0 && j.rs % 4 == 0 && j.bs % 4 == 0 && j.hs % 4 == 0 &&
-         ((uintptr_t)j.in & 7) == 0 && ((uintptr_t)j.out & 7) == 0;
-}
-
-extern "C" __attribute__((visibility("default"))) int bq_transpose_pad(const void *in, void *out, int B, int H, int L,
-                                                                       int Lp, long bs, long rs, long hs,
-                                                                       void *stream) {
-  TransposeJobs jobs{};
-  jobs.j[0] = TransposeJob{(const __bf16 *)in, (__bf16 *)out, L, Lp, bs, rs, hs};
-  BQ_REQUIRE(B > 0 && H > 0 && transpose_job_ok(jobs.j[0]), BQ_EINVAL, "transpose_pad: bad extents / alignment");
-  hipLaunchKernelGGL(transpose_pad_kernel, dim3(Lp / 64, B * H, 1), dim3(256), 0, (hipStream_t)stream, jobs, H);
-  return check_launch("transpose_pad");
-}
-
-// Three transposes in one launch: in[i] (B, L[i], H, 64) by strides (bs[i], rs[i], hs[i]) -> out[i] [B*H][64][Lp[i]].
-extern "C" __attribute__((visibility("default"))) int bq_transpose_pad3(const void *const *in, void *const *out,
-                                                                        const int *L, const int *Lp, const long *bs,
-                                                                        const long *rs, const long *hs, int B, int H,
-                                                                        void *stream) {
-  BQ_REQUIRE(in && out && L && Lp && bs && rs && hs && B > 0 && H > 0, BQ_EINVAL, "transpose_pad3: bad arguments");
-  TransposeJobs jobs{};
-  int maxLp = 0;
-  for (int i = 0; i < 3; ++i) {
-    jobs.j[i] = TransposeJob{(const __bf16 *)in[i], (__bf16 *)out[i], L[i], Lp[i], bs[i], rs[i], hs[i]};
-    BQ_REQUIRE(transpose_job_ok(jobs.j[i]), BQ_EINVAL, "transpose_pad3: tensor %d bad extents / alignment", i);
-    if (Lp[i] > maxLp) maxLp = Lp[i];
-  }
-  hipLaunchKernelGGL(transpose_pad_kernel, dim3(maxLp / 64, B * H, 3), dim3(256), 0, (hipStream_t)stream, jobs, H);
-  return check_launch("transpose_pad3");
-}

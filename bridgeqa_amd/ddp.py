@@ -2,71 +2,18 @@
 torch.distributed (backend "nccl" is RCCL on ROCm).
 
 The reference wraps the model in DistributedDataParallel(find_unused_parameters=True) (scripts/train.py:346-347): 25 MB
-buckets, a used-parameter bitmap all-reduce and a buffer broadcast every step.  Here the gradients live in a few
-large FLAT buffers (parameters' .grad are views into them), so
+buckets, a used-parameter bitmap all-reduce and a buffer broadcast every step.  Here (PackedGradReducer)
 
-  * the forward+backward can be replayed from one HIP graph (autograd accumulates in place into fixed addresses);
-  * the exchange is a handful of large all-reduces -- xGMI is a point-to-point mesh (7 links x ~153 GB/s per GPU):
-    few, large, bf16 messages, not many 25 MB fp32 ones;
+  * the gradients stay in the tensors autograd allocated, so the backward phases replay from HIP graphs unchanged;
+  * the exchange is ONE large all-reduce per backward phase -- xGMI is a point-to-point mesh (7 links x ~153 GB/s per
+    GPU): few, large messages, not many 25 MB ones; fp32 on the wire by default (what the reference's DDP reduces
+    in), bf16 as an explicit option (half the bytes; bench.py uses it and says so in its JSON line);
   * parameters that never receive a gradient on this path (unused BLIP heads, the extra LayerNorms of
-    BertOutputParallel, ...) are found once by a dry run and left out, instead of a bitmap exchange per step.
+    BertOutputParallel, ...) are found once by a dry run and left out, instead of a bitmap exchange per step;
+    check_coverage() asserts that no parameter OUTSIDE the reducers ever shows up with a gradient.
 """
 import torch
 import torch.distributed as dist
-
-
-class FlatGradReducer(object):
-    def __init__(self, params, bucket_bytes=512 << 20, comm_dtype=torch.bfloat16, process_group=None):
-        """params: the parameters that DO receive gradients (see `used_parameters`), all on one device, fp32."""
-        self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.comm_dtype = comm_dtype
-        self.force = False  # run the collective even for a single rank (exercises the RCCL path on a 1-GPU box)
-        self.params = list(params)
-        self.buckets = []  # (flat fp32 grad buffer, comm buffer or None)
-        cur, cur_n = [], 0
-        limit = max(bucket_bytes // 4, 1)
-        groups = []
-        for p in self.params:
-            if cur and cur_n + p.numel() > limit:
-                groups.append(cur)
-                cur, cur_n = [], 0
-            cur.append(p)
-            cur_n += p.numel()
-        if cur:
-            groups.append(cur)
-        for g in groups:
-            n = sum(p.numel() for p in g)
-            flat = torch.zeros(n, dtype=torch.float32, device=g[0].device)
-            off = 0
-            for p in g:
-                p.grad = flat[off:off + p.numel()].view_as(p)  # autograd now accumulates IN PLACE at a fixed address
-                off += p.numel()
-            comm = torch.empty(n, dtype=comm_dtype, device=flat.device) if comm_dtype != torch.float32 else None
-            self.buckets.append((flat, comm))
-
-    def zero(self):
-        for flat, _ in self.buckets:
-            flat.zero_()
-
-    def all_reduce(self):
-        """Average the gradients over the ranks (in place).  A no-op for a single process."""
-        if self.world == 1 and not (self.force and dist.is_initialized()):
-            return
-        inv = 1.0 / self.world
-        for flat, comm in self.buckets:
-            if comm is None:
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-                flat.mul_(inv)
-            else:
-                torch.mul(flat, inv, out=flat)      # pre-scale in fp32, then round once to the wire format
-                comm.copy_(flat)
-                dist.all_reduce(comm, op=dist.ReduceOp.SUM, group=self.group)
-                flat.copy_(comm)
-
-    def nbytes_on_wire(self):
-        return sum((c if c is not None else f).numel() * (c if c is not None else f).element_size()
-                   for f, c in self.buckets)
 
 
 class PackedGradReducer(object):
@@ -74,14 +21,14 @@ class PackedGradReducer(object):
     pipeline.PhasedTrainStep): the .grad tensors stay wherever autograd put them (so a captured backward keeps its
     "first gradient is an assignment" form -- no zero-fill, no accumulate kernel per parameter), and the exchange is
 
-        pack  (multi-tensor fp32 -> bf16 copy into one flat wire buffer)
+        pack  (multi-tensor copy of the fp32 gradients into one flat wire buffer: fp32, or bf16 when asked for)
         all-reduce of the flat buffer (RCCL, one large message per group)
-        unpack (multi-tensor bf16 -> fp32 copy back) and scale by 1 / world
+        unpack (multi-tensor copy back) and scale by 1 / world
 
     issued on whatever stream is current (PhasedTrainStep uses a communication stream, so the exchange of the
     fusion gradients runs under the image / detector backward)."""
 
-    def __init__(self, params, comm_dtype=torch.bfloat16, process_group=None):
+    def __init__(self, params, comm_dtype=torch.float32, process_group=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.force = False  # run the collective even for a single rank (exercises the RCCL path on a 1-GPU box)
@@ -106,6 +53,16 @@ class PackedGradReducer(object):
 
     def nbytes_on_wire(self):
         return self.comm.numel() * self.comm.element_size()
+
+
+def check_coverage(model, reducers):
+    """Raise if a parameter that no reducer exchanges holds a gradient: the reduced set was fixed by one dry run, and a
+    parameter that starts receiving gradients later (a conditional path) would silently diverge between replicas."""
+    covered = {id(p) for r in reducers for p in r.params}
+    stray = [n for n, p in model.named_parameters() if p.grad is not None and id(p) not in covered]
+    if stray:
+        raise RuntimeError("data parallel: %d parameters with gradients are outside every reducer (first: %s) -- "
+                           "re-run attach_reducers / used_parameters" % (len(stray), stray[0]))
 
 
 def used_parameters(model, run_backward):

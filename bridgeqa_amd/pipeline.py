@@ -170,6 +170,9 @@ class PhasedTrainStep(object):
         torch.autograd.backward([st["det_loss"], st["dd"]["object_feat"]], [None, st["obj_grad"]])
 
     def _finish(self):
+        if self.reducers and not torch.cuda.is_current_stream_capturing():
+            from .ddp import check_coverage
+            check_coverage(self.model, self.reducers.values())  # (eager steps only: a replayed graph runs no Python)
         if self.grad_hook is not None:
             self.grad_hook()
         if self.opt is not None:

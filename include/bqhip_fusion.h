@@ -55,13 +55,6 @@ BQ_API int bq_attn_bwd2(const void *Q, const void *K, const void *V, const void 
                         long g_rs, long g_hs, float scale, float p_drop, unsigned seed, const unsigned *seed_ptr,
                         void *stream);
 
-/* in (B,L,H,64) bf16 by strides -> out [B*H][64][Lp], zero padded (replaces zeros + permute + copy_) */
-BQ_API int bq_transpose_pad(const void *in, void *out, int B, int H, int L, int Lp, long bs, long rs, long hs,
-                            void *stream);
-/* three of them in one launch (arrays of 3) */
-BQ_API int bq_transpose_pad3(const void *const *in, void *const *out, const int *L, const int *Lp, const long *bs,
-                             const long *rs, const long *hs, int B, int H, void *stream);
-
 /* ---- y = LayerNorm(path(dropout(x)) + residual) (csrc/ln.hip) -----------------------------------------------
  * Replaces  hidden = dense(x); hidden = dropout(hidden); hidden = LayerNorm(hidden + input)
  *   models/med.py:236-239 (BertSelfOutput), :313-317 (BertOutput)   [residual != NULL, p_drop]

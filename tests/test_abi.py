@@ -24,7 +24,8 @@ def test_headers_compile_as_c_and_cover_the_fusion_kernels():
                                "-o", os.path.join(d, "t.o")])
     syms = declared_symbols()
     for s in ("bq_attn_fwd", "bq_attn_bwd", "bq_drop_add_ln_fwd", "bq_drop_add_ln_bwd", "bq_colsum_bf16",
-              "bq_transpose_pad3", "bq_group_concat_pm", "bq_group_concat_pm_grad"):
+              "bq_gemm_bf16", "bq_colsum_grouped_bf16", "bq_pwconv_bn_fwd", "bq_group_concat_pm",
+              "bq_group_concat_pm_grad"):
         assert s in syms
 
 

@@ -73,58 +73,6 @@ def test_ddp_world2_gloo_grads_are_rank_means_and_replicas_stay_equal(oracle):
         assert drift == 0.0, (rank, drift)
 
 
-def _worker_flat(rank, world, port, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.set_num_threads(2)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from bridgeqa_amd.ddp import FlatGradReducer, broadcast_parameters, used_parameters
-        torch.manual_seed(rank)  # DIFFERENT initial replicas: broadcast must fix that
-        net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
-        dead = torch.nn.Linear(3, 3)  # never used: must be left out of the exchange
-        model = torch.nn.ModuleDict({"net": net, "dead": dead})
-        broadcast_parameters(model)
-        x = torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + rank))
-
-        def fb():
-            model.zero_grad(set_to_none=True)
-            net(x).square().mean().backward()
-        used = used_parameters(model, fb)
-        assert len(used) == 4 and all(p is not q for p in used for q in dead.parameters())
-        red = FlatGradReducer(used, bucket_bytes=4 * 100, comm_dtype=torch.float32)  # tiny buckets -> several
-        assert len(red.buckets) > 1
-        red.zero()
-        net(x).square().mean().backward()       # accumulates into the flat buffers
-        local = [p.grad.clone() for p in used]
-        red.all_reduce()
-        gathered = [torch.zeros_like(torch.cat([g.reshape(-1) for g in local])) for _ in range(world)]
-        dist.all_gather(gathered, torch.cat([g.reshape(-1) for g in local]))
-        want = sum(gathered) / world
-        got = torch.cat([p.grad.reshape(-1) for p in used])
-        w0 = [torch.zeros_like(net[0].weight) for _ in range(world)]
-        dist.all_gather(w0, net[0].weight.detach())
-        out.put((rank, float((got - want).abs().max()), float((w0[0] - w0[1]).abs().max()),
-                 all(p.grad is None for p in dead.parameters())))
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.timeout(300)
-def test_flat_grad_reducer_world2_gloo():
-    ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker_flat, args=(r, 2, port, out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [out.get(timeout=200) for _ in procs]
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
-    for rank, err, drift, dead_none in res:
-        assert err < 1e-6 and drift == 0.0 and dead_none
-
-
 def _worker_packed(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
@@ -137,10 +85,18 @@ def _worker_packed(rank, world, port, out):
         x = torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + rank))
         # two groups exchanged separately, as the phases of pipeline.PhasedTrainStep do
         groups = [list(net[0].parameters()), list(net[2].parameters())]
-        reds = [PackedGradReducer(g, comm_dtype=torch.float32) for g in groups]
+        from bridgeqa_amd.ddp import check_coverage
+        reds = [PackedGradReducer(g) for g in groups]          # fp32 on the wire by default (the reference's DDP dtype)
+        assert reds[0].comm.dtype == torch.float32
         net.zero_grad(set_to_none=True)
         net(x).square().mean().backward()       # .grad tensors are whatever autograd allocated
         ptrs = [p.grad.data_ptr() for p in net.parameters()]
+        check_coverage(net, reds)
+        try:
+            check_coverage(net, reds[:1])                      # the second group's gradients are outside: must raise
+            raise AssertionError("check_coverage did not raise")
+        except RuntimeError:
+            pass
         local = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
         for r in reversed(reds):                # backward order: last layer's group first
             r.all_reduce()

@@ -221,3 +221,46 @@ def test_fused_adamw_checkpoint_resume_and_scheduler_under_replay(dev):
     frozen = [p.detach().clone() for p in e]
     gr.replay(); torch.cuda.synchronize()
     assert all(torch.equal(x, y) for x, y in zip(frozen, e))
+
+
+def test_data_parallel_step_on_rccl_world_1_equals_the_plain_step(dev):
+    """Multi-GPU readiness on a one-GPU box: the phased step with its per-phase PackedGradReducers on a communication
+    stream, over the REAL RCCL backend at world size 1 (forced collectives), produces the same loss and the same
+    gradients as the step without any exchange; the three groups cover every parameter that receives a gradient
+    (reference: DistributedDataParallel of scripts/train.py:346-347)."""
+    import os
+    import torch.distributed as dist
+    import bench
+    from bridgeqa_amd.ddp import PackedGradReducer, check_coverage
+    from bridgeqa_amd.pipeline import PhasedTrainStep
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group(backend="nccl", init_method="env://", rank=0, world_size=1)
+    try:
+        model = _small_model(dev)
+        batch = _batch(dev)
+        plain = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, optimizer=None, use_graphs=False)
+        plain.capture(warmup=0)
+        want_loss = plain.eager_step().item()
+        torch.cuda.synchronize()
+        want = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        dp = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, optimizer=None, use_graphs=False)
+
+        def make(ps):
+            r = PackedGradReducer(ps)       # fp32 on the wire
+            r.force = True                  # run the collective although the world has one rank
+            return r
+        reds = dp.attach_reducers(make)
+        assert set(reds) == {"fusion", "image", "det"}
+        dp.capture(warmup=0)
+        got_loss = dp.eager_step().item()
+        dp.wait()
+        torch.cuda.synchronize()
+        check_coverage(model, reds.values())
+        got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+        assert set(got) == set(want)
+        assert abs(got_loss - want_loss) <= 1e-4 * abs(want_loss)
+        worst = max(((got[n] - want[n]).norm() / (want[n].norm() + 1e-12)).item() for n in want)
+        assert worst < 2e-3, worst          # fp32 atomics of the detector backward; the all-reduce itself is exact at world 1
+        assert sum(r.nbytes_on_wire() for r in reds.values()) == 4 * sum(p.numel() for p in model.parameters() if p.grad is not None)
+    finally:
+        dist.destroy_process_group()

@@ -579,7 +579,7 @@ def drop_add_ln_bwd(x, residual, gamma, dy, mean, rstd, eps, p_drop, seed, seed_
 
 # ---- MFMA bf16 GEMM family (csrc/gemm.hip) ------------------------------------------------------------
 GEMM_P_XC, GEMM_Q_XC, GEMM_OUT_F32 = 1, 2, 4
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU = 0, 1, 2, 3
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_BIAS_CE = 0, 1, 2, 3, 4
 
 
 class _GemmDesc(ctypes.Structure):
@@ -625,6 +625,7 @@ def gemm_grouped(problems, flags, epilogue=EPI_NONE, tile=None):
             raise RuntimeError("gemm: out must be %s" % ("float32" if f32 else "bfloat16"))
         Ni, Kc = (P.shape[1], P.shape[0]) if pxc else (P.shape[0], P.shape[1])
         Nj, Kq = (Q.shape[1], Q.shape[0]) if qxc else (Q.shape[0], Q.shape[1])
+        Ni = int(pr.get("Ni", Ni))  # output wider than P's rows (padded vocabulary): P's true extent goes in p_bytes
         if (Kq != Kc and "Kc" not in pr) or tuple(out.shape) != (Nj, Ni):
             raise RuntimeError("gemm: shape mismatch P%s Q%s out%s" % (tuple(P.shape), tuple(Q.shape), tuple(out.shape)))
         d = arr[k]
@@ -634,10 +635,12 @@ def gemm_grouped(problems, flags, epilogue=EPI_NONE, tile=None):
                                  or not bias.is_contiguous()):
             raise RuntimeError("gemm: bias must be a contiguous fp32 or bf16 (Ni,) tensor")
         d.bias_bf16 = int(bias is not None and bias.dtype == torch.bfloat16)
-        if colsum is not None and (colsum.dtype != torch.float32 or colsum.numel() != Ni or not colsum.is_contiguous()):
+        if epilogue != EPI_BIAS_CE and colsum is not None and (colsum.dtype != torch.float32 or colsum.numel() != Ni
+                                                               or not colsum.is_contiguous()):
             raise RuntimeError("gemm: colsum must be a contiguous fp32 (Ni,) tensor")
         for t, nm in ((out2, "out2"), (aux, "aux")):
-            if t is not None and (t.dtype != torch.bfloat16 or tuple(t.shape) != (Nj, Ni) or t.stride() != out.stride()):
+            if epilogue != EPI_BIAS_CE and t is not None and (t.dtype != torch.bfloat16 or tuple(t.shape) != (Nj, Ni)
+                                                              or t.stride() != out.stride()):
                 raise RuntimeError("gemm: %s must be bf16 and laid out like out" % nm)
         d.bias, d.out2, d.aux, d.colsum = _p(bias), _p(out2), _p(aux), _p(colsum)
         d.ldp, d.ldq, d.ldo = P.stride(0), Q.stride(0), out.stride(0)
@@ -743,3 +746,40 @@ def pwconv_bn_relu_fwd(x, K, w_pad, gamma, beta, running_mean, running_var, num_
         _check(_lib.bq_bn_apply(_p(y_raw), _p(stats[0]), _p(stats[1]), _p(out), R, N, int(S), int(bool(relu)),
                                 int(bool(pool)), _stream()), "bn_apply")
     return out, y_raw, stats
+
+
+# ---- LM head + label-smoothed cross entropy (csrc/lmhead.hip + the cross-entropy epilogue of csrc/gemm.hip) -----------
+_lib.bq_lmhead_ce_combine.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]
+_lib.bq_lmhead_ce_combine.restype = ctypes.c_int
+_lib.bq_lmhead_ce_dlogits.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]
+_lib.bq_lmhead_ce_dlogits.restype = ctypes.c_int
+
+
+def lmhead_ce_fwd(h, w, bias_pad, target, V, label_smoothing):
+    """h bf16 (R, D), w bf16 (V, D) (contiguous), bias_pad f32 (Vp,) with Vp = V rounded up to 64 and zeros beyond V,
+    target int32 (R,) (< 0: ignored).  Returns logits bf16 (R, Vp) (columns >= V are padding), loss f32 (R,), lse f32 (R,)."""
+    R, D = h.shape
+    Vp = bias_pad.numel()
+    tiles_i = (Vp + 255) // 256
+    with torch.cuda.device(h.device):
+        logits = torch.empty(R, Vp, dtype=torch.bfloat16, device=h.device)
+        part = torch.empty(tiles_i * 2, R, 3, dtype=torch.float32, device=h.device)
+        zt = torch.zeros(R, dtype=torch.float32, device=h.device)
+        loss = torch.empty(R, dtype=torch.float32, device=h.device)
+        lse = torch.empty(R, dtype=torch.float32, device=h.device)
+        # P = the vocabulary matrix with its TRUE extent in p_bytes (rows V .. Vp-1 of the last tile are out of bounds
+        # for the bounds-checked LDS-DMA: zeros), Ni = the padded width of the logits
+        gemm_grouped([dict(P=w, Q=h, out=logits, bias=bias_pad, out2=part, aux=target, colsum=zt, ksplit=V, Ni=Vp,
+                           p_bytes=w.shape[0] * w.stride(0) * 2)], 0, EPI_BIAS_CE, 256)
+        _check(_lib.bq_lmhead_ce_combine(_p(part), _p(zt), _p(target), _p(loss), _p(lse), R, tiles_i * 2, int(V),
+                                         float(label_smoothing), _stream()), "lmhead_ce_combine")
+    return logits, loss, lse
+
+
+def lmhead_ce_dlogits(logits, lse, target, grad_loss, V, label_smoothing):
+    """logits (R, Vp) bf16 from lmhead_ce_fwd -> dlogits IN PLACE (returned)"""
+    R, Vp = logits.shape
+    with torch.cuda.device(logits.device):
+        _check(_lib.bq_lmhead_ce_dlogits(_p(logits), _p(lse), _p(target), _p(grad_loss), R, int(V), logits.stride(0),
+                                         float(label_smoothing), _stream()), "lmhead_ce_dlogits")
+    return logits

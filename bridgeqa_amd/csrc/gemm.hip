@@ -35,7 +35,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_DGELU = 3 };
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_DGELU = 3, EPI_BIAS_CE = 4 };
 enum { GF_P_XC = 1, GF_Q_XC = 2, GF_OUT_F32 = 4, GF_ACCUM = 8 };
 
 struct GemmProblem {
@@ -323,6 +323,63 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
     }
     return;
   }
+  if (EPI == EPI_BIAS_CE) {
+    // Cross-entropy partials of the LM head (csrc/lmhead.hip combines them): for every row j of this wave and the 128
+    // vocabulary entries i of its half tile -- the fp32 logits acc + bias, before any rounding -- the running maximum,
+    // sum exp(z - max) and sum z over the VALID entries (i < n_valid = pr.ksplit), and the target's logit where this lane
+    // holds it.  Field reuse for this epilogue: out2 = partial f32 [tiles_i * 2][Nj][3], aux = int32 targets [Nj]
+    // (-100 = ignore), colsum = f32 [Nj] target logits, ksplit = number of valid vocabulary entries.
+    const int n_valid = pr.ksplit;
+    float *part = reinterpret_cast<float *>(pr.out2) + (long)(bi * 2 + wr) * Nj * 3;
+    const int *tgt = reinterpret_cast<const int *>(pr.aux);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int j = jw + b * 16 + row16;
+      const int t = j < Nj ? tgt[j] : -100;
+      float m = -INFINITY, sz = 0.f;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const int i = iw + a * 16 + q4 * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (pr.bias != nullptr && i < Ni) load_bias4(pr, i, bv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float z = acc[a][b][r] + bv[r];
+          if (i + r < n_valid) {
+            m = fmaxf(m, z);
+            sz += z;
+            if (i + r == t) pr.colsum[j] = z;   // exactly one lane of the grid holds the target of row j
+          }
+        }
+      }
+      float se = 0.f;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const int i = iw + a * 16 + q4 * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (pr.bias != nullptr && i < Ni) load_bias4(pr, i, bv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (i + r < n_valid) se += __builtin_amdgcn_exp2f((acc[a][b][r] + bv[r] - m) * 1.4426950408889634f);
+      }
+      // the four lanes row16 + 16 q hold the other vocabulary entries of the same row
+#pragma unroll
+      for (int sh = 16; sh <= 32; sh <<= 1) {
+        const float mo = __shfl_xor(m, sh), so = __shfl_xor(se, sh), zo = __shfl_xor(sz, sh);
+        const float mn = fmaxf(m, mo);
+        const float fa = m == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m - mn) * 1.4426950408889634f);
+        const float fb = mo == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((mo - mn) * 1.4426950408889634f);
+        se = se * fa + so * fb;
+        m = mn;
+        sz += zo;
+      }
+      if (q4 == 0 && j < Nj) {
+        part[(long)j * 3 + 0] = m;
+        part[(long)j * 3 + 1] = se;
+        part[(long)j * 3 + 2] = sz;
+      }
+    }
+  }
   // bf16 outputs go through LDS so that global stores are whole 256-B row pieces: wave-private [64 j][128 i] image
   // (16 KB, 16-B chunk c of row j at j*256 + ((c ^ (j & 15)) << 4): conflict-free both ways), written as 8-B pieces,
   // read back as 16-B pieces.
@@ -336,7 +393,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
     for (int a = 0; a < 8; ++a) {
       const int i = iw + a * 16 + q4 * 4;
       float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && pr.bias != nullptr && i < Ni) load_bias4(pr, i, bv);
+      if ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_CE) && pr.bias != nullptr && i < Ni) load_bias4(pr, i, bv);
       float cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
@@ -880,6 +937,12 @@ static int launch_gemm(const GemmArgs &ga, int flags, int epi, int tile, hipStre
     if (epi == EPI_NONE) return launch_variant<false, false, EPI_NONE, false>(ga, tile, st);
     if (epi == EPI_BIAS) return launch_variant<false, false, EPI_BIAS, false>(ga, tile, st);
     if (epi == EPI_BIAS_GELU) return launch_variant<false, false, EPI_BIAS_GELU, false>(ga, tile, st);
+    if (epi == EPI_BIAS_CE && tile == 256) {
+      hipLaunchKernelGGL((gemm256_kernel<false, false, EPI_BIAS_CE, false>), dim3(ga.total_tiles), dim3(512), 0, st, ga);
+      return 0;
+    }
+  } else if (pxc && !qxc && f32) {
+    if (epi == EPI_NONE && tile != 256) return launch_variant<true, false, EPI_NONE, true>(ga, tile, st);
   } else if (pxc && !qxc && !f32) {
     if (epi == EPI_NONE) return launch_variant<true, false, EPI_NONE, false>(ga, tile, st);
     if (epi == EPI_DGELU) return launch_variant<true, false, EPI_DGELU, false>(ga, tile, st);
@@ -931,11 +994,18 @@ extern "C" int bq_gemm_bf16(const bq_gemm_desc *d, int n, int flags, int epilogu
       g.bias_bf16 = s.bias_bf16;
       g.p_bytes = (unsigned)(s.p_bytes > 0 ? s.p_bytes : pb);
       g.q_bytes = (unsigned)(s.q_bytes > 0 ? s.q_bytes : qb);
-      g.ksplit = (f32 && tile != 256 && s.ksplit > 1) ? s.ksplit : 1;
-      BQ_REQUIRE(s.ksplit <= 1 || (f32 && tile != 256), BQ_EINVAL, "bq_gemm_bf16: ksplit needs fp32 out and tile 64");
+      if (epilogue == EPI_BIAS_CE) {
+        BQ_REQUIRE(s.out2 && s.aux && s.colsum && s.ksplit > 0 && s.ksplit <= s.Ni && tile == 256, BQ_EINVAL,
+                   "bq_gemm_bf16: the cross-entropy epilogue needs out2 (partials), aux (targets), colsum (target logits), "
+                   "ksplit = valid vocabulary entries, tile 256");
+        g.ksplit = s.ksplit;
+      } else {
+        g.ksplit = (f32 && tile != 256 && s.ksplit > 1) ? s.ksplit : 1;
+        BQ_REQUIRE(s.ksplit <= 1 || (f32 && tile != 256), BQ_EINVAL, "bq_gemm_bf16: ksplit needs fp32 out and tile 64");
+      }
       g.tiles_i = (s.Ni + ti - 1) / ti;
       g.tile0 = ga.total_tiles;
-      ga.total_tiles += g.tiles_i * ((s.Nj + tj - 1) / tj) * g.ksplit;
+      ga.total_tiles += g.tiles_i * ((s.Nj + tj - 1) / tj) * (epilogue == EPI_BIAS_CE ? 1 : g.ksplit);
       ++ga.n;
       ++done;
     }

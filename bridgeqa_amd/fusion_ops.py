@@ -1015,12 +1015,70 @@ def attention_q_kv(q, kv, scale, dropout_p=0.0, mask=None):
     return ctx
 
 
+class _LMHeadCE(torch.autograd.Function):
+    """Tied LM head + shifted label-smoothed cross entropy on the kernels (csrc/gemm.hip cross-entropy epilogue +
+    csrc/lmhead.hip): logits computed tile by tile on the MFMA pipeline and stored once as bf16; the loss statistics
+    come from the fp32 accumulators; no fp32 logits, no softmax / log-softmax / nll kernels.  hidden (B, L, D) bf16,
+    weight (V, D) fp32 parameter (the word-embedding matrix), bias fp32 parameter (V,), labels (B, L) with -100 =
+    ignore.  Returns (logits (B, L, V) bf16 view of the padded buffer, per-row loss (B, L) f32 with position t holding
+    the loss of predicting labels[:, t+1]; last position 0)."""
+
+    @staticmethod
+    def forward(ctx, hidden, weight, bias, labels, label_smoothing):
+        from . import _ext
+        B, L, D = hidden.shape
+        V = weight.shape[0]
+        Vp = (V + 63) // 64 * 64
+        wb = _shadow(weight)
+        h2 = _rows(hidden)
+        tgt = torch.full((B, L), -100, dtype=torch.int32, device=hidden.device)
+        tgt[:, :-1] = labels[:, 1:].to(torch.int32)
+        bias_pad = torch.zeros(Vp, dtype=torch.float32, device=hidden.device)
+        if bias is not None:
+            bias_pad[:V] = bias.detach()
+        logits, loss, lse = _ext.lmhead_ce_fwd(h2, wb, bias_pad, tgt.view(-1), V, label_smoothing)
+        ctx.save_for_backward(h2, wb, logits, lse, tgt)
+        ctx.cfg = (B, L, D, V, Vp, float(label_smoothing), hidden.dtype, bias is not None)
+        ctx.params = (weight, bias)
+        out_logits = logits.view(B, L, Vp)[:, :, :V]   # NB consumed by the backward (turned into dlogits in place)
+        ctx.mark_non_differentiable(out_logits)
+        return out_logits, loss.view(B, L)
+
+    @staticmethod
+    def backward(ctx, _dlogits, dloss):
+        from . import _ext
+        h2, wb, logits, lse, tgt = ctx.saved_tensors
+        B, L, D, V, Vp, eps, h_dtype, has_bias = ctx.cfg
+        g = dloss.reshape(-1).to(torch.float32).contiguous()
+        dl = _ext.lmhead_ce_dlogits(logits, lse, tgt.view(-1), g, V, eps)   # in place: the logits are consumed
+        R = B * L
+        # dH (R, D) = dlogits (R, Vp) W (V, D): a 30 528-long contraction for a small output -> cut into pieces that
+        # accumulate with fp32 atomics (the rows of W beyond V are out of bounds for the DMA: zeros)
+        dh = torch.zeros(R, D, dtype=torch.float32, device=h2.device)
+        tiles = ((D + 63) // 64) * ((R + 31) // 32)
+        ksplit = max(1, min(Vp // 64, (768 + tiles - 1) // tiles))
+        _ext.gemm_grouped([dict(P=wb, Q=dl, out=dh, Kc=Vp, p_bytes=wb.shape[0] * wb.stride(0) * 2, ksplit=ksplit)],
+                          _ext.GEMM_P_XC | _ext.GEMM_OUT_F32, _ext.EPI_NONE, 32)
+        dhidden = dh.view(B, L, D).to(h_dtype)
+        # dW (Vp, D) = dlogits^T h (fp32; its first V rows are the gradient of the tied embedding matrix)
+        dw = torch.empty(Vp, D, dtype=torch.float32, device=h2.device)
+        _ext.gemm_grouped([dict(P=h2, Q=dl, out=dw)], _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32, _ext.EPI_NONE, 256)
+        db = _ext.colsum_grouped([dl])[0][:V] if has_bias else None
+        return dhidden, dw[:V], db, None, None
+
+
 def lm_loss(hidden, decoder_weight, decoder_bias, labels, label_smoothing=0.1):
     """Tied LM head + shifted label-smoothed cross entropy, summed per sequence (med.py:1417-1432).
 
     hidden (B,L,D) = output of the prediction-head transform; labels (B,L) with -100 = ignore.
-    Returns (logits (B,L,V) or None, loss (B,)).
+    Returns (logits (B,L,V), loss (B,)).
     """
+    D = hidden.shape[-1]
+    if (_NATIVE_GEMM[0] and hidden.is_cuda and _COMPUTE_DTYPE == torch.bfloat16 and D % 64 == 0
+            and isinstance(decoder_weight, torch.nn.Parameter) and decoder_weight.dtype == torch.float32
+            and decoder_weight.is_contiguous() and hidden.dim() == 3):
+        logits, row_loss = _LMHeadCE.apply(hidden, decoder_weight, decoder_bias, labels, float(label_smoothing))
+        return logits, row_loss.sum(1)
     logits = linear(hidden, decoder_weight, decoder_bias).float()
     B, L, V = logits.shape
     shifted = logits[:, :-1, :].reshape(-1, V)

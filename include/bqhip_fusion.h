@@ -164,6 +164,11 @@ BQ_API int bq_adamw_multi(const void *table, const void *chunks, int n_chunks, c
 #define BQ_GEMM_EPI_BIAS 1
 #define BQ_GEMM_EPI_BIAS_GELU 2
 #define BQ_GEMM_EPI_DGELU 3
+#define BQ_GEMM_EPI_BIAS_CE 4 /* LM head: out = bf16(acc + bias) AND cross-entropy partials from the fp32 values; tile 256
+                                 only; field reuse: out2 = f32 partials [2 * ceil(Ni/256)][Nj][3] (max, sum exp(z - max),
+                                 sum z over the valid entries of each 128-wide half tile), aux = int32 targets [Nj] (< 0:
+                                 ignored row), colsum = f32 [Nj] receives the target's logit, ksplit = number of valid
+                                 entries along i (the vocabulary size; Ni may be padded beyond it) */
 typedef struct bq_gemm_desc {
   const void *P, *Q;
   void *out;
@@ -208,6 +213,18 @@ BQ_API int bq_pwconv_bn_fwd(const void *x, long R, int K, int ldx, const void *w
                             float *partial, const float *gamma, const float *beta, float *running_mean,
                             float *running_var, long long *num_batches_tracked, float eps, float momentum,
                             float *scale, float *shift, float *mean, float *rstd, void *stream);
+
+/* ---- LM head + label-smoothed cross entropy (csrc/lmhead.hip, with BQ_GEMM_EPI_BIAS_CE of bq_gemm_bf16) -------------
+ * Replaces prediction_scores = cls(sequence_output) -> .float() -> CrossEntropyLoss(reduction='none',
+ * label_smoothing=0.1) of models/med.py:1417-1432 (no fp32 logits tensor; the bf16 logits are stored once).
+ * bq_lmhead_ce_combine: partial f32 [nrec][R][3] from the GEMM epilogue, target_logit f32 [R], target int32 [R] (< 0 =
+ *   ignore_index) -> loss f32 [R] = (1-eps)(lse - z_t) + eps (lse - mean_v z_v) (0 for ignored rows), lse f32 [R].
+ * bq_lmhead_ce_dlogits: logits bf16 (R rows of ld >= V elements) -> IN PLACE grad_loss[r] * (softmax - (1-eps) onehot -
+ *   eps/V), zero in ignored rows and in the padding columns v >= V: the operand of the dW / dH / db launches. */
+BQ_API int bq_lmhead_ce_combine(const float *partial, const float *target_logit, const int *target, float *loss,
+                                float *lse, int R, int nrec, int V, float label_smoothing, void *stream);
+BQ_API int bq_lmhead_ce_dlogits(void *logits, const float *lse, const int *target, const float *grad_loss, int R, int V,
+                                int ld, float label_smoothing, void *stream);
 
 #ifdef __cplusplus
 }

@@ -180,3 +180,42 @@ def test_rejects_bad_arguments(dev):
         _ext.gemm_fwd(x, w)                       # K-contiguous operands need K % 64 == 0 (and ld % 8 == 0)
     with pytest.raises(RuntimeError):
         _ext.gemm_fwd(x.cpu(), w.cpu())           # no CPU path
+
+
+def test_lm_head_cross_entropy_vs_torch(dev):
+    """fusion_ops.lm_loss on the kernels (cross-entropy epilogue of the GEMM + csrc/lmhead.hip) at the real head size
+    (vocabulary 30524 -- not a multiple of anything convenient --, hidden 768, 32 x 5 rows) and at a tiny one, against
+    torch's fp32 composition of the reference (med.py:1417-1432): per-sequence loss 2e-3 relative (operands bf16, loss
+    statistics fp32), gradients of the hidden states / the tied weight / the bias rel-L2 2e-2."""
+    from bridgeqa_amd import fusion_ops as ops
+    prev = ops.set_compute_dtype(torch.bfloat16)
+    try:
+        for (B, L, D, V) in ((32, 5, 768, 30524), (3, 6, 256, 200)):
+            g = torch.Generator().manual_seed(V)
+            w = torch.nn.Parameter((torch.randn(V, D, generator=g) * 0.05).to(dev))
+            b = torch.nn.Parameter((torch.randn(V, generator=g) * 0.1).to(dev))
+            h0 = torch.randn(B, L, D, generator=g).to(dev).to(torch.bfloat16)
+            labels = torch.randint(0, V, (B, L), generator=g).to(dev)
+            labels[0, 2:] = -100
+            labels[:, 0] = -100
+            wseq = torch.rand(B, generator=g).to(dev) + 0.5
+            h = h0.clone().requires_grad_(True)
+            logits, loss = ops.lm_loss(h, w, b, labels, label_smoothing=0.1)
+            assert logits.shape == (B, L, V) and logits.dtype == torch.bfloat16
+            logits_copy = logits.float().clone()
+            (loss * wseq).sum().backward()
+            hr = h0.float().clone().requires_grad_(True)
+            wr = w.detach().to(torch.bfloat16).float().requires_grad_(True)
+            br = b.detach().clone().requires_grad_(True)
+            lr = hr @ wr.t() + br
+            ce = torch.nn.functional.cross_entropy(lr[:, :-1].reshape(-1, V), labels[:, 1:].reshape(-1), reduction="none",
+                                                   label_smoothing=0.1).view(B, -1).sum(1)
+            (ce * wseq).sum().backward()
+            rel = lambda x, y: ((x.float() - y.float()).norm() / (y.float().norm() + 1e-20)).item()
+            assert rel(logits_copy, lr) < 3e-3
+            assert (loss - ce).abs().max().item() <= 2e-3 * ce.abs().max().item(), (loss, ce)
+            assert rel(h.grad, hr.grad) < 2e-2, rel(h.grad, hr.grad)
+            assert rel(w.grad, wr.grad) < 2e-2, rel(w.grad, wr.grad)
+            assert rel(b.grad, br.grad) < 2e-2, rel(b.grad, br.grad)
+    finally:
+        ops.set_compute_dtype(prev)

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
   unsigned char *ep = smem + wave * 16384;
   __bf16 *outb = reinterpret_cast<__bf16 *>(pr.out);
   const int npass = (EPI == EPI_BIAS_GELU) ? 2 : 1;
-  const bool want_colsum = pr.colsum != nullptr;
+  const bool want_colsum = EPI != EPI_BIAS_CE && pr.colsum != nullptr;  // (the CE epilogue reuses the field)
 #pragma unroll 1
   for (int pass = 0; pass < npass; ++pass) {
 #pragma unroll

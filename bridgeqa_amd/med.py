@@ -314,6 +314,7 @@ class BertLayer(nn.Module):
 
 
 _TWO_SEGMENT = os.environ.get("BQ_TWO_SEGMENT_KV", "0") == "1"
+_TWO_SEGMENT_FORK = os.environ.get("BQ_TWO_SEGMENT_FORK", "0") == "1"  # also when the twin branches run on two streams
 
 
 def _wants(output_attentions, i, last):
@@ -390,7 +391,8 @@ class BertEncoderTwin(BertEncoder):
         # "last" as BLIP_VQA3D asks) keep the concatenated wiring.
         hoisted_layers = []
         if (_TWO_SEGMENT and mode == "multimodal" and ops.compute_dtype() == torch.bfloat16
-                and hidden_states.shape[1] <= 32 and not ops.overlap_enabled(hidden_states)):
+                and hidden_states.shape[1] <= 32
+                and (_TWO_SEGMENT_FORK or not ops.overlap_enabled(hidden_states))):
             hoisted_layers = [i for i in layers if i < self.num_hidden_layers_twin
                               and not _wants(output_attentions, i, layers[-1])
                               and not self.layer[i].crossattention.self.save_attention
@@ -414,7 +416,8 @@ class BertEncoderTwin(BertEncoder):
             if twin is not None and ops.overlap_enabled(hidden_states):
                 # the two streams of a layer only depend on each other's PREVIOUS state: run them side by side
                 with ops.fork("twin", hidden_states) as f:
-                    f.uses(hidden_states_twin, mix3d, attention_mask, encoder_attention_mask_twin)
+                    f.uses(hidden_states_twin, attention_mask, encoder_attention_mask_twin,
+                           *([mix3d] if torch.is_tensor(mix3d) else [mix3d.tail, mix3d.hoisted.outs[mix3d.slot]]))
                     out3d = twin(hidden_states_twin, attention_mask, None, mix3d, encoder_attention_mask_twin, None,
                                  want, mode=mode, layernorm_idx=layernorm_idx)
                 out2d = self.layer[i](hidden_states, attention_mask, None, mix2d, encoder_attention_mask, None, want,

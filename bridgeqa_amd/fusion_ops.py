@@ -155,7 +155,9 @@ def padded_conv_shadow(weight):
     Kc = (K + 63) // 64 * 64
     with torch.no_grad():
         buf = torch.zeros(N, Kc, dtype=torch.bfloat16, device=weight.device)
-        view = buf[:, :K].view(N, K, 1, 1) if Kc == K else buf[:, :K].unsqueeze(-1).unsqueeze(-1)
+        view = buf[:, :K]
+        for _ in range(weight.dim() - 2):  # (N, K, 1, 1) for Conv2d, (N, K, 1) for Conv1d: a view of the padded rows
+            view = view.unsqueeze(-1)
         view.copy_(weight.detach())
     _SHADOW[id(weight)] = (weakref.ref(weight), weight._version, view)
     _PADDED[id(weight)] = (weakref.ref(weight), buf)

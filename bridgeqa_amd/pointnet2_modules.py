@@ -102,4 +102,12 @@ class PointnetFPModule(nn.Module):
             new_features = torch.cat([interpolated_feats, unknow_feats], dim=1)
         else:
             new_features = interpolated_feats
+        if (pt_utils.native_rows_ok(new_features) and self.training
+                and all(pt_utils._native_layer_ok(layer) for layer in self.mlp) and new_features.shape[1] % 8 == 0):
+            # point-major bf16 rows through the native SharedMLP layers (GEMM + BatchNorm statistics in its epilogue);
+            # the (B, C, n) result is a transposed view of the rows, fp32 at the module boundary
+            B, C, n = new_features.shape
+            rows = pt_utils.to_rows(new_features)
+            out = self.mlp(rows.view(B, n, 1, C).permute(0, 3, 1, 2))
+            return out.squeeze(-1).float()
         return self.mlp(new_features.unsqueeze(-1)).squeeze(-1)

@@ -60,13 +60,27 @@ class ProposalModule(nn.Module):
         self.register_buffer("_mean_size", torch.from_numpy(np.asarray(mean_size_arr).astype(np.float32)),
                              persistent=False)  # not in the state dict: key set must equal the reference's
 
+    def _proposal_head(self, features):
+        """self.proposal (conv-bn-relu x2 + conv, proposal_module.py:44-50); on the bf16 GPU path the two conv + BatchNorm
+        + ReLU stages run as native point-major layers and the last convolution as a linear on the rows"""
+        from . import pytorch_utils as pt_utils
+        p = self.proposal
+        if pt_utils.native_rows_ok(features) and self.training:
+            B, C, K = features.shape
+            h = pt_utils.rows_conv_bn_relu(pt_utils.to_rows(features), p[0], p[1])
+            h = pt_utils.rows_conv_bn_relu(h, p[3], p[4]) if h is not None else None
+            if h is not None:
+                net = torch.nn.functional.linear(h.float(), p[6].weight.squeeze(-1), p[6].bias)
+                return net.view(B, K, -1).transpose(1, 2)
+        return p(features)
+
     def forward(self, xyz, features, data_dict):
         """xyz (B,K,3) votes, features (B,C,K) -> data_dict with the proposal outputs."""
         xyz, features, fps_inds = self.vote_aggregation(xyz, features)
         data_dict["aggregated_vote_xyz"] = xyz
         data_dict["aggregated_vote_features"] = features.permute(0, 2, 1).contiguous()
         data_dict["aggregated_vote_inds"] = fps_inds
-        net = self.proposal(features)
+        net = self._proposal_head(features)
         return self.decode_scores(net, data_dict, self.num_class, self.num_heading_bin, self.num_size_cluster,
                                   self.mean_size_arr)
 

@@ -98,15 +98,19 @@ class _ConvBNReLUPointMajor(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, conv_weight, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, relu,
-                pool, S):
+                pool, S, conv_bias=None):
         from . import _ext, fusion_ops
         K = conv_weight.shape[1]
         w_pad = fusion_ops.padded_conv_shadow(conv_weight)
         out, y_raw, stats = _ext.pwconv_bn_relu_fwd(x, K, w_pad, gamma, beta, running_mean, running_var,
                                                     num_batches_tracked, eps, momentum, S, relu, pool)
+        if conv_bias is not None and running_mean is not None:
+            # a convolution bias in front of a training-mode BatchNorm cancels in the normalised output (it shifts the
+            # batch mean by itself) and its gradient is identically zero; the only trace it leaves is in running_mean
+            running_mean.add_(conv_bias.detach(), alpha=float(momentum))
         ctx.save_for_backward(x, w_pad, y_raw, stats)
         ctx.cfg = (K, S, relu, pool)
-        ctx.conv_weight = conv_weight
+        ctx.conv_weight, ctx.conv_bias = conv_weight, conv_bias
         return out
 
     @staticmethod
@@ -135,7 +139,8 @@ class _ConvBNReLUPointMajor(torch.autograd.Function):
             _ext.gemm_grouped([dict(P=xs, Q=dy, out=dwf, ksplit=ksplit)],
                               _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32, _ext.EPI_NONE, 64)
             dw = dwf[:, :K].reshape(ctx.conv_weight.shape)
-        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None
+        dcb = torch.zeros_like(ctx.conv_bias) if ctx.conv_bias is not None else None
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None, dcb
 
 
 def _rows_view(x):
@@ -148,6 +153,34 @@ def _rows_view(x):
     if ld < C or ld % 8 or x.stride(2) != S * ld or x.stride(0) != M * S * ld or x.data_ptr() % 16:
         return None
     return torch.as_strided(x, (B * M * S, C), (ld, 1))
+
+
+def rows_conv_bn_relu(rows, conv, bn, relu=True):
+    """1x1 Conv1d / Conv2d (+ bias) -> training-mode BatchNorm -> ReLU on point-major bf16 rows (R, K) through the native
+    layer; None when its preconditions do not hold (the caller then runs the reference composition).  Used by the
+    feature-propagation SharedMLPs, the voting module and the proposal head (reference lib/pointnet2/
+    pointnet2_modules.py:330-340, models/voting_module.py:33-40, models/proposal_module.py:44-50)."""
+    C = bn.num_features
+    if not (rows.is_cuda and rows.dtype == torch.bfloat16 and rows.dim() == 2 and rows.stride(1) == 1
+            and rows.stride(0) % 8 == 0 and bn.training and bn.momentum is not None and bn.track_running_stats and bn.affine
+            and C % 64 == 0 and (C & (C - 1)) == 0 and conv.weight.dtype == torch.float32
+            and all(k == 1 for k in conv.kernel_size)):
+        return None
+    return _ConvBNReLUPointMajor.apply(rows, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                       bn.num_batches_tracked, bn.eps, bn.momentum, relu, False, 1, conv.bias)
+
+
+def to_rows(x):
+    """(B, C, n) channel-major features -> (B*n, C) bf16 point-major rows (one transposing cast)"""
+    B, C, n = x.shape
+    return x.transpose(1, 2).to(torch.bfloat16).contiguous().view(B * n, C)
+
+
+def native_rows_ok(x):
+    """the row-form native layers apply: bf16 compute dtype on a GPU with the HIP backend"""
+    from . import fusion_ops, pointnet2_utils
+    return (x.is_cuda and fusion_ops.compute_dtype() == torch.bfloat16 and fusion_ops.POINT_MAJOR[0]
+            and pointnet2_utils.backend_is_hip())
 
 
 def _native_layer_ok(layer):

@@ -7,6 +7,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import pytorch_utils as pt_utils
+
 
 class VotingModule(nn.Module):
     def __init__(self, vote_factor, seed_feature_dim):
@@ -24,9 +26,20 @@ class VotingModule(nn.Module):
         """seed_xyz (B,S,3), seed_features (B,C,S) -> vote_xyz (B,S*vf,3), vote_features (B,C,S*vf)"""
         B, S = seed_xyz.shape[0], seed_xyz.shape[1]
         vf, C = self.vote_factor, self.out_dim
-        net = F.relu(self.bn1(self.conv1(seed_features)))
-        net = F.relu(self.bn2(self.conv2(net)))
-        net = self.conv3(net)  # (B, (3+C)*vf, S); channel = v*(3+C) + [offset(3) | residual(C)]
+        net = None
+        if pt_utils.native_rows_ok(seed_features) and self.training:
+            # point-major rows: conv + BatchNorm + ReLU twice on the native layer (csrc/gemm.hip pwconv + csrc/bn.hip),
+            # the last convolution (259 output channels, no BatchNorm) as a plain linear on the rows
+            rows = pt_utils.to_rows(seed_features)
+            h = pt_utils.rows_conv_bn_relu(rows, self.conv1, self.bn1)
+            h = pt_utils.rows_conv_bn_relu(h, self.conv2, self.bn2) if h is not None else None
+            if h is not None:
+                net = F.linear(h.float(), self.conv3.weight.squeeze(-1), self.conv3.bias)
+                net = net.view(B, S, -1).transpose(1, 2)
+        if net is None:
+            net = F.relu(self.bn1(self.conv1(seed_features)))
+            net = F.relu(self.bn2(self.conv2(net)))
+            net = self.conv3(net)  # (B, (3+C)*vf, S); channel = v*(3+C) + [offset(3) | residual(C)]
         net = net.view(B, vf, 3 + C, S)
         offset = net[:, :, 0:3, :].permute(0, 3, 1, 2)  # (B,S,vf,3)
         vote_xyz = (seed_xyz.unsqueeze(2) + offset).reshape(B, S * vf, 3)

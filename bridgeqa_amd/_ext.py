@@ -57,6 +57,10 @@ _lib.bq_drop_add_ln_fwd.argtypes = [_vp] * 9 + [_i, _i, _f, _f, _f, _i, _u, _vp,
 _lib.bq_drop_add_ln_fwd.restype = ctypes.c_int
 _lib.bq_drop_add_ln_bwd.argtypes = [_vp] * 10 + [_i, _i, _f, _f, _f, _i, _u, _vp, _vp]
 _lib.bq_drop_add_ln_bwd.restype = ctypes.c_int
+_lib.bq_twin_drop_add_ln_fwd.argtypes = [_vp] * 10 + [_i, _i, _f, _f, _u, _vp, _vp]
+_lib.bq_twin_drop_add_ln_fwd.restype = ctypes.c_int
+_lib.bq_twin_drop_add_ln_bwd.argtypes = [_vp] * 10 + [_i, _i, _f, _f, _u, _vp, _vp]
+_lib.bq_twin_drop_add_ln_bwd.restype = ctypes.c_int
 _lib.bq_fps_workspace_bytes.argtypes = [_i, _i]
 _lib.bq_fps_workspace_bytes.restype = ctypes.c_size_t
 
@@ -323,7 +327,7 @@ def key_mask_log2(mask, B, Lk):
     return m
 
 
-def attn_fwd(q, k, v, scale, mask_log2=None, p_drop=0.0, seed=0, seed_tensor=None, causal=False):
+def attn_fwd(q, k, v, scale, mask_log2=None, p_drop=0.0, seed=0, seed_tensor=None, causal=False, out=None):
     """softmax(q k^T * scale + mask) v without materialising the scores.  q: bf16 (B, Lq, H, 64) view, k / v:
     (B, Lk, H, 64) views with equal strides; mask_log2 from key_mask_log2.  Returns out (B, Lq, H, 64) bf16 contiguous
     and lse (B, H, Lq) f32 (log2 domain).  No transposed copies: the kernels transpose out of LDS."""
@@ -336,7 +340,10 @@ def attn_fwd(q, k, v, scale, mask_log2=None, p_drop=0.0, seed=0, seed_tensor=Non
     Lk = k.shape[1]
     Lkp = _pad64(Lk)
     with torch.cuda.device(q.device):
-        out = torch.empty(B, Lq, H, D, dtype=torch.bfloat16, device=q.device)
+        if out is None:
+            out = torch.empty(B, Lq, H, D, dtype=torch.bfloat16, device=q.device)
+        elif tuple(out.shape) != (B, Lq, H, D) or out.dtype != torch.bfloat16 or not out.is_contiguous():
+            raise RuntimeError("attn_fwd: out must be a contiguous bf16 (B, Lq, H, 64) tensor")
         lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
         qs, ks, os_ = _bhd_strides(q), _bhd_strides(k), _bhd_strides(out)
         _check(_lib.bq_attn_fwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(mask_log2), B, H, Lq, Lk, Lkp, *qs, *ks,
@@ -575,6 +582,37 @@ def drop_add_ln_bwd(x, residual, gamma, dy, mean, rstd, eps, p_drop, seed, seed_
                                        int(rows_per_sample), int(seed) & 0xFFFFFFFF, _p(seed_tensor), _stream()),
                "drop_add_ln_bwd")
     return dx, dres, dgb[0], dgb[1]
+
+
+def twin_drop_add_ln_fwd(x, residual, gamma, beta, gamma2, beta2, eps, p_drop, seed, seed_tensor, want_dgb=False):
+    """drop_add_ln_fwd over two row groups (first / second half of the rows of x) with their own LayerNorm parameters;
+    returns y, mean, rstd, dgb (zeroed f32 (2, 2, H), or None)"""
+    H = x.shape[-1]
+    M = x.numel() // H
+    with torch.cuda.device(x.device):
+        y = torch.empty_like(x)
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+        dgb = torch.empty(2, 2, H, dtype=torch.float32, device=x.device) if want_dgb else None
+        _check(_lib.bq_twin_drop_add_ln_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(gamma2), _p(beta2), _p(y),
+                                            _p(mean), _p(rstd), _p(dgb), M, H, float(eps), float(p_drop),
+                                            int(seed) & 0xFFFFFFFF, _p(seed_tensor), _stream()), "twin_drop_add_ln_fwd")
+    return y, mean, rstd, dgb
+
+
+def twin_drop_add_ln_bwd(x, residual, gamma, gamma2, dy, mean, rstd, eps, p_drop, seed, seed_tensor, dgb=None):
+    """-> dx, dresidual, dgb (2, 2, H): [group][dgamma | dbeta]"""
+    H = x.shape[-1]
+    M = x.numel() // H
+    with torch.cuda.device(x.device):
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if residual is not None else None
+        if dgb is None:
+            dgb = torch.zeros(2, 2, H, dtype=torch.float32, device=x.device)
+        _check(_lib.bq_twin_drop_add_ln_bwd(_p(x), _p(residual), _p(gamma), _p(gamma2), _p(dy), _p(mean), _p(rstd),
+                                            _p(dx), _p(dres), _p(dgb), M, H, float(eps), float(p_drop),
+                                            int(seed) & 0xFFFFFFFF, _p(seed_tensor), _stream()), "twin_drop_add_ln_bwd")
+    return dx, dres, dgb
 
 
 # ---- MFMA bf16 GEMM family (csrc/gemm.hip) ------------------------------------------------------------

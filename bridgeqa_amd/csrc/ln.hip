@@ -32,6 +32,11 @@ struct LnArgs {
   unsigned path_thresh;
   float path_inv_keep;
   int rows_per_sample;
+  // row groups (the two text streams of the twin encoder stacked in one tensor, reference med.py:549-614): group g =
+  // rows [g*M/groups, (g+1)*M/groups) with its OWN LayerNorm parameters (gamma2 / beta2 for g = 1) and its own dgamma /
+  // dbeta accumulator (dgb + g*2H); blockIdx.y = group
+  int groups;
+  const float *gamma2, *beta2;
 };
 
 __device__ __forceinline__ float ln_path_scale(const LnArgs &a, unsigned seed, int row) {
@@ -73,10 +78,12 @@ __global__ __launch_bounds__(256) void drop_add_ln_fwd_kernel(const __bf16 *__re
                                                               float *__restrict__ rstd_out,
                                                               float *__restrict__ zero_out, LnArgs a) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int grp = blockIdx.y, Mg = a.M / a.groups;
+  if (grp) { gamma = a.gamma2; beta = a.beta2; }
   if (zero_out && blockIdx.x == 0)  // the backward's dgamma / dbeta accumulators, cleared here for free
-    for (int c = threadIdx.x; c < 2 * a.H; c += 256) zero_out[c] = 0.0f;
+    for (int c = threadIdx.x; c < 2 * a.H; c += 256) zero_out[grp * 2 * a.H + c] = 0.0f;
   const unsigned seed = ln_seed(a);
-  for (int row = blockIdx.x * 4 + wid; row < a.M; row += gridDim.x * 4) {
+  for (int row = grp * Mg + blockIdx.x * 4 + wid; row < (grp + 1) * Mg; row += gridDim.x * 4) {
   const long rowoff = (long)row * a.H;
   float z[4 * NCH];
   load_z<NCH>(x, res, rowoff, row, lane, a, seed, z);
@@ -124,6 +131,8 @@ __global__ __launch_bounds__(256) void drop_add_ln_bwd_kernel(const __bf16 *__re
                                                               float *__restrict__ dgb, LnArgs a) {
   __shared__ float s_g[4][256 * NCH], s_b[4][256 * NCH];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int grp = blockIdx.y, Mg = a.M / a.groups;
+  if (grp) { gamma = a.gamma2; dgb += 2 * a.H; }
   const unsigned seed = ln_seed(a);
   float ag[4 * NCH], ab[4 * NCH], gm[4 * NCH];
 #pragma unroll
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(256) void drop_add_ln_bwd_kernel(const __bf16 *__re
 #pragma unroll
   for (int i = 0; i < 4 * NCH; ++i) { ag[i] = 0.0f; ab[i] = 0.0f; }
   const float invH = 1.0f / (float)a.H;
-  for (int row = blockIdx.x * 4 + wid; row < a.M; row += gridDim.x * 4) {
+  for (int row = grp * Mg + blockIdx.x * 4 + wid; row < (grp + 1) * Mg; row += gridDim.x * 4) {
     const long rowoff = (long)row * a.H;
     float z[4 * NCH], g[4 * NCH];
     load_z<NCH>(x, res, rowoff, row, lane, a, seed, z);
@@ -403,21 +412,23 @@ extern "C" __attribute__((visibility("default"))) int bq_colsum_bf16(const void 
 // sum_out (bf16 (M, H)) may be NULL, else it receives dropout(x) + residual -- the carried residual stream of a
 // pre-LN block (reference models/vit.py:106-109).  zero_out (f32 (2, H), may be NULL) is set to 0: pass the buffer
 // that bq_drop_add_ln_bwd of this site will accumulate dgamma / dbeta into.
-extern "C" __attribute__((visibility("default"))) int bq_drop_add_ln_fwd(
-    const void *x, const void *residual, const float *gamma, const float *beta, void *y, void *sum_out, float *mean,
-    float *rstd, float *zero_out, int M, int H, float eps, float p_drop, float p_path, int rows_per_sample,
-    unsigned seed, const unsigned *seed_ptr, void *stream) {
+static int ln_fwd_launch(const void *x, const void *residual, const float *gamma, const float *beta, const float *gamma2,
+                         const float *beta2, int groups, void *y, void *sum_out, float *mean, float *rstd,
+                         float *zero_out, int M, int H, float eps, float p_drop, float p_path, int rows_per_sample,
+                         unsigned seed, const unsigned *seed_ptr, void *stream) {
   BQ_REQUIRE(M >= 0 && H > 0 && H % 256 == 0 && H <= 1024, BQ_ELIMIT, "drop_add_ln: H=%d unsupported", H);
+  BQ_REQUIRE(groups == 1 || (groups == 2 && gamma2 && beta2 && M % 2 == 0), BQ_EINVAL, "drop_add_ln: bad row groups");
   if (M == 0) {
-    if (zero_out) (void)hipMemsetAsync(zero_out, 0, sizeof(float) * 2 * H, (hipStream_t)stream);
+    if (zero_out) (void)hipMemsetAsync(zero_out, 0, sizeof(float) * 2 * H * groups, (hipStream_t)stream);
     return check_launch("drop_add_ln_fwd");
   }
   BQ_REQUIRE(x && gamma && beta && y && mean && rstd, BQ_EINVAL, "drop_add_ln: null pointer");
   BQ_REQUIRE(p_path == 0.0f || rows_per_sample > 0, BQ_EINVAL, "drop_add_ln: rows_per_sample");
   LnArgs a{M, H, eps, 1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr,
-           (unsigned)((double)p_path * 4294967296.0), 1.0f / (1.0f - p_path), rows_per_sample};
+           (unsigned)((double)p_path * 4294967296.0), 1.0f / (1.0f - p_path), rows_per_sample, groups, gamma2, beta2};
   static const int fwd_cap = getenv("BQ_LN_FWD_BLOCKS") ? atoi(getenv("BQ_LN_FWD_BLOCKS")) : 1024;  // rows are strided over the grid (tools/ln_sweep.sh)
-  const dim3 grid(((M + 3) / 4) < fwd_cap ? (M + 3) / 4 : fwd_cap);
+  const int Mg = M / groups;
+  const dim3 grid(((Mg + 3) / 4) < fwd_cap ? (Mg + 3) / 4 : fwd_cap, groups);
   hipStream_t st = (hipStream_t)stream;
 #define BQ_LN_FWD(N)                                                                                           \
   hipLaunchKernelGGL(drop_add_ln_fwd_kernel<N>, grid, dim3(256), 0, st, (const __bf16 *)x, (const __bf16 *)residual, \
@@ -426,31 +437,63 @@ extern "C" __attribute__((visibility("default"))) int bq_drop_add_ln_fwd(
 #undef BQ_LN_FWD
   return check_launch("drop_add_ln_fwd");
 }
+extern "C" __attribute__((visibility("default"))) int bq_drop_add_ln_fwd(
+    const void *x, const void *residual, const float *gamma, const float *beta, void *y, void *sum_out, float *mean,
+    float *rstd, float *zero_out, int M, int H, float eps, float p_drop, float p_path, int rows_per_sample,
+    unsigned seed, const unsigned *seed_ptr, void *stream) {
+  return ln_fwd_launch(x, residual, gamma, beta, nullptr, nullptr, 1, y, sum_out, mean, rstd, zero_out, M, H, eps, p_drop,
+                       p_path, rows_per_sample, seed, seed_ptr, stream);
+}
+// The same over TWO row groups with their own LayerNorm parameters: rows [0, M/2) use gamma / beta, rows [M/2, M) gamma2 /
+// beta2 (the 2D and the 3D text stream of the twin encoder stacked in one tensor); zero_out: f32 (2, 2, H).
+extern "C" __attribute__((visibility("default"))) int bq_twin_drop_add_ln_fwd(
+    const void *x, const void *residual, const float *gamma, const float *beta, const float *gamma2, const float *beta2,
+    void *y, float *mean, float *rstd, float *zero_out, int M, int H, float eps, float p_drop, unsigned seed,
+    const unsigned *seed_ptr, void *stream) {
+  return ln_fwd_launch(x, residual, gamma, beta, gamma2, beta2, 2, y, nullptr, mean, rstd, zero_out, M, H, eps, p_drop,
+                       0.0f, 0, seed, seed_ptr, stream);
+}
 
 // dgb: f32 (2, H) = dgamma then dbeta, ACCUMULATED into (float atomics): it must hold zeros on entry -- the
 // forward's zero_out does that.  dx, dresidual bf16 (M, H).  residual / dresidual NULL together for the plain
 // form; dsum (bf16 (M, H), may be NULL) is the gradient that reached sum_out and is added to both.
-extern "C" __attribute__((visibility("default"))) int bq_drop_add_ln_bwd(
-    const void *x, const void *residual, const float *gamma, const void *dy, const void *dsum, const float *mean,
-    const float *rstd, void *dx, void *dresidual, float *dgb, int M, int H, float eps, float p_drop, float p_path,
-    int rows_per_sample, unsigned seed, const unsigned *seed_ptr, void *stream) {
+static int ln_bwd_launch(const void *x, const void *residual, const float *gamma, const float *gamma2, int groups,
+                         const void *dy, const void *dsum, const float *mean, const float *rstd, void *dx,
+                         void *dresidual, float *dgb, int M, int H, float eps, float p_drop, float p_path,
+                         int rows_per_sample, unsigned seed, const unsigned *seed_ptr, void *stream) {
   BQ_REQUIRE(M >= 0 && H > 0 && H % 256 == 0 && H <= 1024, BQ_ELIMIT, "drop_add_ln: H=%d unsupported", H);
+  BQ_REQUIRE(groups == 1 || (groups == 2 && gamma2 && M % 2 == 0), BQ_EINVAL, "drop_add_ln_bwd: bad row groups");
   if (M == 0) return BQ_OK;
   BQ_REQUIRE(x && gamma && dy && mean && rstd && dx && dgb && (!residual == !dresidual), BQ_EINVAL,
              "drop_add_ln_bwd: null pointer");
   BQ_REQUIRE(p_path == 0.0f || rows_per_sample > 0, BQ_EINVAL, "drop_add_ln_bwd: rows_per_sample");
   LnArgs a{M, H, eps, 1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr,
-           (unsigned)((double)p_path * 4294967296.0), 1.0f / (1.0f - p_path), rows_per_sample};
+           (unsigned)((double)p_path * 4294967296.0), 1.0f / (1.0f - p_path), rows_per_sample, groups, gamma2, nullptr};
   static const int bwd_cap = getenv("BQ_LN_BWD_BLOCKS") ? atoi(getenv("BQ_LN_BWD_BLOCKS")) : 512;
-  int blocks = (M + 3) / 4;
+  int blocks = (M / groups + 3) / 4;
   if (blocks > bwd_cap) blocks = bwd_cap;
   hipStream_t st = (hipStream_t)stream;
 #define BQ_LN_BWD(N)                                                                                            \
-  hipLaunchKernelGGL(drop_add_ln_bwd_kernel<N>, dim3(blocks), dim3(256), 0, st, (const __bf16 *)x,               \
+  hipLaunchKernelGGL(drop_add_ln_bwd_kernel<N>, dim3(blocks, groups), dim3(256), 0, st, (const __bf16 *)x,       \
                      (const __bf16 *)residual, gamma, (const __bf16 *)dy, (const __bf16 *)dsum, mean, rstd,      \
                      (__bf16 *)dx, (__bf16 *)dresidual, dgb, a)
   switch (H / 256) { case 1: BQ_LN_BWD(1); break; case 2: BQ_LN_BWD(2); break; case 3: BQ_LN_BWD(3); break; default: BQ_LN_BWD(4); }
 #undef BQ_LN_BWD
   return check_launch("drop_add_ln_bwd");
+}
+extern "C" __attribute__((visibility("default"))) int bq_drop_add_ln_bwd(
+    const void *x, const void *residual, const float *gamma, const void *dy, const void *dsum, const float *mean,
+    const float *rstd, void *dx, void *dresidual, float *dgb, int M, int H, float eps, float p_drop, float p_path,
+    int rows_per_sample, unsigned seed, const unsigned *seed_ptr, void *stream) {
+  return ln_bwd_launch(x, residual, gamma, nullptr, 1, dy, dsum, mean, rstd, dx, dresidual, dgb, M, H, eps, p_drop, p_path,
+                       rows_per_sample, seed, seed_ptr, stream);
+}
+// backward of bq_twin_drop_add_ln_fwd: dgb f32 (2, 2, H) = per row group dgamma then dbeta, accumulated
+extern "C" __attribute__((visibility("default"))) int bq_twin_drop_add_ln_bwd(
+    const void *x, const void *residual, const float *gamma, const float *gamma2, const void *dy, const float *mean,
+    const float *rstd, void *dx, void *dresidual, float *dgb, int M, int H, float eps, float p_drop, unsigned seed,
+    const unsigned *seed_ptr, void *stream) {
+  return ln_bwd_launch(x, residual, gamma, gamma2, 2, dy, nullptr, mean, rstd, dx, dresidual, dgb, M, H, eps, p_drop, 0.0f,
+                       0, seed, seed_ptr, stream);
 }
 

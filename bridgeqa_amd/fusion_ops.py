@@ -787,6 +787,312 @@ class _QKVAttention(torch.autograd.Function):
         return dq, dkv, None, None, None
 
 
+# ---- the two text streams of the twin encoder as ONE batch ---------------------------------------------------------
+# The twin encoder (reference med.py:549-614) runs two BertLayers per level -- `layer[i]` on the 2D stream, `layer_twin[i]`
+# on the 3D stream -- that only exchange their PREVIOUS states.  Same shapes, different weights: every projection of a
+# level is one grouped GEMM launch with one problem per stream (csrc/gemm.hip takes a problem list), every add +
+# LayerNorm one launch over two row groups with their own gamma / beta (csrc/ln.hip), the self-attention one launch over
+# the stacked batch.  The states travel stacked, (2B, L, D): rows [0, B) = 2D stream, [B, 2B) = 3D stream.
+
+def _param_ok(*ps):
+    return all(isinstance(p, torch.nn.Parameter) and p.dtype == torch.float32 for p in ps)
+
+
+def _group_operands(ws, bs, G, k):
+    """per group: the bf16 weight operand ((k N, K): the k linears' shadows are row blocks of one buffer) and its bias"""
+    wops, bops = [], []
+    for g in range(G):
+        wg, bg = ws[g * k:(g + 1) * k], bs[g * k:(g + 1) * k]
+        if k > 1:
+            wc, bc = _cat_shadow(wg, bg)
+        else:
+            wc, bc = _shadow(wg[0]), _f32_bias(bg[0])
+        wops.append(wc)
+        bops.append(bc)
+    return wops, bops
+
+
+def _grouped_wgrad(g2s, x2s, ws, bs, k):
+    """weight / bias gradients of G groups of k fused linears: parked inside a deferred scope (-> Nones), else now"""
+    G = len(g2s)
+    if all(_defer_ok(g2, x2) for g2, x2 in zip(g2s, x2s)):
+        for g in range(G):
+            _park(g2s[g], x2s[g], list(ws[g * k:(g + 1) * k]), list(bs[g * k:(g + 1) * k]))
+        return (None,) * (2 * G * k)
+    dws, dbs = [], []
+    for g in range(G):
+        dw, db = _dw_db(g2s[g], x2s[g], True, True)
+        n = dw.shape[0] // k
+        dws += [dw[j * n:(j + 1) * n] for j in range(k)]
+        dbs += [db[j * n:(j + 1) * n] for j in range(k)]
+    return tuple(dws) + tuple(dbs)
+
+
+class _GroupedLinearFn(torch.autograd.Function):
+    """G groups x k linears in ONE GEMM launch: group g applies its k linears (fused: one (k N, K) operand) to its own
+    rows.  stacked: ONE input whose rows are G equal blocks and one output laid out the same way ((rows, k N)); else G
+    inputs (any row counts: the image-side and the object-side K/V projections) and G outputs.  Backward: one grouped
+    dX launch; dW / db parked per group for the phase's grouped launches."""
+
+    @staticmethod
+    def forward(ctx, G, k, stacked, *t):
+        from . import _ext
+        nx = 1 if stacked else G
+        xs, ws, bs = t[:nx], t[nx:nx + G * k], t[nx + G * k:]
+        wops, bops = _group_operands(ws, bs, G, k)
+        N = wops[0].shape[0]
+        dev = xs[0].device
+        if stacked:
+            x2 = _rows(xs[0])
+            M = x2.shape[0] // G
+            xg = [x2[g * M:(g + 1) * M] for g in range(G)]
+            y = torch.empty(x2.shape[0], N, dtype=torch.bfloat16, device=dev)
+            yg = [y[g * M:(g + 1) * M] for g in range(G)]
+            outs = (y.view(*xs[0].shape[:-1], N),)
+        else:
+            xg = [_rows(x) for x in xs]
+            yg = [torch.empty(x2.shape[0], N, dtype=torch.bfloat16, device=dev) for x2 in xg]
+            outs = tuple(y.view(*x.shape[:-1], N) for y, x in zip(yg, xs))
+        _ext.gemm_grouped([dict(P=w, Q=x2, out=o, bias=b) for w, x2, o, b in zip(wops, xg, yg, bops)], 0, _ext.EPI_BIAS)
+        ctx.save_for_backward(*xg, *wops)
+        ctx.cfg = (G, k, stacked, [x.shape for x in xs], [x.dtype for x in xs])
+        ctx.params = (ws, bs)
+        return outs[0] if stacked else outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        from . import _ext
+        G, k, stacked, shapes, dtypes = ctx.cfg
+        xg, wops = ctx.saved_tensors[:G], ctx.saved_tensors[G:]
+        ws, bs = ctx.params
+        N, K = wops[0].shape
+        if stacked:
+            g2 = _rows(grads[0].reshape(-1, N))
+            M = g2.shape[0] // G
+            gg = [g2[g * M:(g + 1) * M] for g in range(G)]
+            dx = torch.empty(g2.shape[0], K, dtype=torch.bfloat16, device=g2.device)
+            dxg = [dx[g * M:(g + 1) * M] for g in range(G)]
+        else:
+            gg = [_rows(g.reshape(-1, N)) for g in grads]
+            dxg = [torch.empty(g2.shape[0], K, dtype=torch.bfloat16, device=g2.device) for g2 in gg]
+        need = [i for i in range(1 if stacked else G) if ctx.needs_input_grad[3 + i]]
+        if need:
+            sel = range(G) if stacked else need
+            _ext.gemm_grouped([dict(P=wops[g], Q=gg[g], out=dxg[g]) for g in sel], _ext.GEMM_P_XC, _ext.EPI_NONE)
+        if stacked:
+            dxs = (dx.view(shapes[0]).to(dtypes[0]) if need else None,)
+        else:
+            dxs = tuple(dxg[g].view(shapes[g]).to(dtypes[g]) if g in need else None for g in range(G))
+        return (None, None, None) + dxs + _grouped_wgrad(gg, xg, ws, bs, k)
+
+
+class _GroupedMlpFn(torch.autograd.Function):
+    """fc2(gelu(fc1(x))) of G streams stacked along the rows, each with its own (fc1, fc2): the fused node of _MlpFn with
+    every launch grouped -- forward 2 launches (GELU epilogue, bias epilogue), backward 2 (dGELU epilogue, plain) + parks."""
+
+    @staticmethod
+    def forward(ctx, G, x, *p):
+        from . import _ext
+        w1, b1, w2, b2 = p[0::4], p[1::4], p[2::4], p[3::4]
+        w1o, w2o = [_shadow(w) for w in w1], [_shadow(w) for w in w2]
+        x2 = _rows(x)
+        M = x2.shape[0] // G
+        I, D = w1o[0].shape[0], w2o[0].shape[0]
+        y1 = torch.empty(x2.shape[0], I, dtype=torch.bfloat16, device=x.device)
+        h = torch.empty_like(y1)
+        y2 = torch.empty(x2.shape[0], D, dtype=torch.bfloat16, device=x.device)
+        rows = lambda t, g: t[g * M:(g + 1) * M]
+        _ext.gemm_grouped([dict(P=w1o[g], Q=rows(x2, g), out=rows(y1, g), out2=rows(h, g), bias=_f32_bias(b1[g]))
+                           for g in range(G)], 0, _ext.EPI_BIAS_GELU)
+        _ext.gemm_grouped([dict(P=w2o[g], Q=rows(h, g), out=rows(y2, g), bias=_f32_bias(b2[g])) for g in range(G)], 0,
+                          _ext.EPI_BIAS)
+        ctx.save_for_backward(x2, y1, h, *w1o, *w2o)
+        ctx.params, ctx.G = (w1, b1, w2, b2), G
+        ctx.x_dtype, ctx.x_shape = x.dtype, x.shape
+        return y2.view(*x.shape[:-1], D)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _ext
+        G = ctx.G
+        x2, y1, h = ctx.saved_tensors[:3]
+        w1o, w2o = ctx.saved_tensors[3:3 + G], ctx.saved_tensors[3 + G:]
+        w1, b1, w2, b2 = ctx.params
+        g2 = _rows(g.reshape(-1, g.shape[-1]))
+        M = g2.shape[0] // G
+        rows = lambda t, i: t[i * M:(i + 1) * M]
+        dy1 = torch.empty_like(y1)
+        _ext.gemm_grouped([dict(P=w2o[i], Q=rows(g2, i), out=rows(dy1, i), aux=rows(y1, i)) for i in range(G)],
+                          _ext.GEMM_P_XC, _ext.EPI_DGELU)
+        dx = None
+        if ctx.needs_input_grad[1]:
+            dx = torch.empty_like(x2)
+            _ext.gemm_grouped([dict(P=w1o[i], Q=rows(dy1, i), out=rows(dx, i)) for i in range(G)], _ext.GEMM_P_XC,
+                              _ext.EPI_NONE)
+            dx = dx.view(ctx.x_shape).to(ctx.x_dtype)
+        gw2 = _grouped_wgrad([rows(g2, i) for i in range(G)], [rows(h, i) for i in range(G)], w2, b2, 1)
+        gw1 = _grouped_wgrad([rows(dy1, i) for i in range(G)], [rows(x2, i) for i in range(G)], w1, b1, 1)
+        out = []
+        for i in range(G):
+            out += [gw1[i], gw1[G + i], gw2[i], gw2[G + i]]
+        return (None, dx) + tuple(out)
+
+
+class _TwinDropAddLN(torch.autograd.Function):
+    """LayerNorm_g(dropout(x) + residual) for the two row groups g of a stacked (2B, L, H) tensor, each with its own
+    gamma / beta -- one launch each way (csrc/ln.hip, blockIdx.y = group)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, wa, ba, wb, bb, eps, p_drop):
+        from . import _ext
+        _CALL_SEED[0] += 1
+        seed, st = _CALL_SEED[0] * 104729, (step_seed(x.device) if p_drop > 0 else None)
+        y, mean, rstd, dgb = _ext.twin_drop_add_ln_fwd(x, residual, wa, ba, wb, bb, eps, p_drop, seed, st,
+                                                       any(ctx.needs_input_grad[:6]))
+        ctx.save_for_backward(x, residual, wa, wb, mean, rstd, st if st is not None else x.new_empty(0))
+        ctx.cfg = (eps, p_drop, seed, st is not None)
+        ctx.dgb = dgb
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _ext
+        x, residual, wa, wb, mean, rstd, st = ctx.saved_tensors
+        eps, p_drop, seed, has_st = ctx.cfg
+        dgb, ctx.dgb = ctx.dgb, None
+        dx, dres, dgb = _ext.twin_drop_add_ln_bwd(x, residual, wa, wb, dy.contiguous(), mean, rstd, eps, p_drop, seed,
+                                                  st if has_st else None, dgb)
+        return dx, dres, dgb[0, 0], dgb[0, 1], dgb[1, 0], dgb[1, 1], None, None
+
+
+class _TwinMixFn(torch.autograd.Function):
+    """keys / values source of the two cross-attentions of one twin level from the stacked states hs (2B, L, D):
+    mix2d = cat(image tokens, 3D-stream states), mix3d = cat(object tokens, 2D-stream states) (reference med.py:549-562);
+    the backward hands the states' gradient back STACKED (one cat) instead of two zero-filled slice gradients."""
+
+    @staticmethod
+    def forward(ctx, enc2d, enc3d, hs):
+        B = hs.shape[0] // 2
+        ctx.cfg = (enc2d.shape[1], enc3d.shape[1])
+        return torch.cat((enc2d, hs[B:]), dim=1), torch.cat((enc3d, hs[:B]), dim=1)
+
+    @staticmethod
+    def backward(ctx, g2d, g3d):
+        P2, P3 = ctx.cfg
+        return g2d[:, :P2], g3d[:, :P3], torch.cat((g3d[:, P3:], g2d[:, P2:]), dim=0)
+
+
+class _TwinSplitFn(torch.autograd.Function):
+    """stacked (2B, ...) -> the two streams' states; backward = one cat"""
+
+    @staticmethod
+    def forward(ctx, hs):
+        B = hs.shape[0] // 2
+        return hs[:B].clone(), hs[B:].clone()
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        return torch.cat((ga, gb), dim=0)
+
+
+class _TwinCrossAttention(torch.autograd.Function):
+    """the two cross-attentions of one twin level: queries stacked (2B, L, H, 64), keys / values per stream as fused
+    K/V tensors (B, Lk_g, 2, H, 64) of different lengths; context and dq come back stacked (no slice gradients)"""
+
+    @staticmethod
+    def forward(ctx, q, kva, kvb, scale, ma, mb, p_drop):
+        from . import _ext
+        B = q.shape[0] // 2
+        out = torch.empty_like(q)
+        seeds, lses = [], []
+        for g, (kv, m) in enumerate(((kva, ma), (kvb, mb))):
+            seed, st = _seed_args(p_drop, q.device)
+            _, lse = _ext.attn_fwd(q[g * B:(g + 1) * B], kv[:, :, 0], kv[:, :, 1], scale, m, p_drop, seed, st,
+                                   out=out[g * B:(g + 1) * B])
+            seeds.append(seed)
+            lses.append(lse)
+        e = q.new_empty(0)
+        ctx.save_for_backward(q, kva, kvb, out, lses[0], lses[1], ma if ma is not None else e, mb if mb is not None else e,
+                              st if st is not None else e)
+        ctx.cfg = (scale, p_drop, seeds, ma is not None, mb is not None, st is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import _ext
+        q, kva, kvb, out, lsa, lsb, ma, mb, st = ctx.saved_tensors
+        scale, p_drop, seeds, has_a, has_b, has_st = ctx.cfg
+        B = q.shape[0] // 2
+        grad_out = grad_out.contiguous()
+        dq = torch.empty_like(q)
+        dkvs = []
+        for g, (kv, lse, m, has) in enumerate(((kva, lsa, ma, has_a), (kvb, lsb, mb, has_b))):
+            dkv = torch.empty_like(kv)
+            r = slice(g * B, (g + 1) * B)
+            _ext.attn_bwd(q[r], kv[:, :, 0], kv[:, :, 1], out[r], lse, grad_out[r], scale, dq[r], dkv[:, :, 0],
+                          dkv[:, :, 1], m if has else None, p_drop, seeds[g], st if has_st else None)
+            dkvs.append(dkv)
+        return dq, dkvs[0], dkvs[1], None, None, None, None
+
+
+def twin_cross_attention(q, kva, kvb, scale, p_drop, mask_a, mask_b):
+    """q (2B, L, H, 64) stacked; kva (B, Lka, 2, H, 64), kvb (B, Lkb, 2, H, 64); masks (B,1,1,Lk) or None"""
+    B = q.shape[0] // 2
+    return _TwinCrossAttention.apply(q.contiguous(), kva, kvb, scale, _mask_log2(mask_a, B, kva.shape[1]),
+                                     _mask_log2(mask_b, B, kvb.shape[1]), float(p_drop))
+
+
+def twin_kernel_ok(hs, linears):
+    """the stacked twin path needs the kernel formats: bf16 compute, CUDA, width % 256 (LayerNorm kernel) and fp32
+    master parameters with biases"""
+    D = hs.shape[-1]
+    return (_COMPUTE_DTYPE == torch.bfloat16 and _NATIVE_GEMM[0] and hs.is_cuda and hs.dtype == torch.bfloat16
+            and D % 256 == 0 and D <= 1024 and hs.shape[0] % 2 == 0
+            and all(l.bias is not None and _param_ok(l.weight, l.bias) and l.weight.shape[0] % 64 == 0
+                    and l.weight.shape[1] % 64 == 0 for l in linears))
+
+
+def twin_linear(hs, lin_a, lin_b):
+    """stacked states -> [lin_a(2D rows); lin_b(3D rows)], one launch"""
+    return _GroupedLinearFn.apply(2, 1, True, hs, lin_a.weight, lin_b.weight, lin_a.bias, lin_b.bias)
+
+
+def twin_multi_linear(hs, lins_a, lins_b):
+    """stacked states -> (..., k, N): the k fused projections (Q/K/V) of each stream, one launch"""
+    k = len(lins_a)
+    ws = [l.weight for l in lins_a] + [l.weight for l in lins_b]
+    bs = [l.bias for l in lins_a] + [l.bias for l in lins_b]
+    y = _GroupedLinearFn.apply(2, k, True, hs, *ws, *bs)
+    return y.view(*y.shape[:-1], k, y.shape[-1] // k)
+
+
+def twin_multi_linear_var(xa, xb, lins_a, lins_b):
+    """the k fused projections of stream a over xa and of stream b over xb (different row counts), one launch"""
+    k = len(lins_a)
+    ws = [l.weight for l in lins_a] + [l.weight for l in lins_b]
+    bs = [l.bias for l in lins_a] + [l.bias for l in lins_b]
+    ya, yb = _GroupedLinearFn.apply(2, k, False, xa, xb, *ws, *bs)
+    return ya.view(*ya.shape[:-1], k, ya.shape[-1] // k), yb.view(*yb.shape[:-1], k, yb.shape[-1] // k)
+
+
+def twin_mlp(hs, fc1_a, fc2_a, fc1_b, fc2_b):
+    return _GroupedMlpFn.apply(2, hs, fc1_a.weight, fc1_a.bias, fc2_a.weight, fc2_a.bias,
+                               fc1_b.weight, fc1_b.bias, fc2_b.weight, fc2_b.bias)
+
+
+def twin_dropout_add_layer_norm(x, residual, ln_a, ln_b, p_drop, training):
+    return _TwinDropAddLN.apply(x.contiguous(), residual.contiguous(), ln_a.weight, ln_a.bias, ln_b.weight, ln_b.bias,
+                                ln_a.eps, float(p_drop) if training else 0.0)
+
+
+def twin_mix(enc2d, enc3d, hs):
+    return _TwinMixFn.apply(enc2d, enc3d, hs)
+
+
+def twin_split(hs):
+    return _TwinSplitFn.apply(hs)
+
+
 # ---- two-segment cross-attention over a hoisted K/V projection ----------------------------------------------
 # The twin encoder's layer i cross-attends to cat(image tokens, other stream's states of layer i-1) (reference
 # med.py:549-562).  The image tokens are the same in all layers, so their K/V projections for ALL layers are one GEMM

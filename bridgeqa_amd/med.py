@@ -313,6 +313,7 @@ class BertLayer(nn.Module):
                            intermediate=self.intermediate)
 
 
+_TWIN_BATCH = [os.environ.get("BQ_TWIN_BATCH", "1") != "0"]  # both text streams of a twin level as one stacked batch
 _TWO_SEGMENT = os.environ.get("BQ_TWO_SEGMENT_KV", "0") == "1"
 _TWO_SEGMENT_FORK = os.environ.get("BQ_TWO_SEGMENT_FORK", "0") == "1"  # also when the twin branches run on two streams
 
@@ -373,6 +374,54 @@ class BertEncoderTwin(BertEncoder):
         for i in range(self.num_hidden_layers_twin):
             self.layer_twin[i].load_state_dict(self.layer[i].state_dict())
 
+    def _pairable(self, i, hs):
+        """level i can run both streams as one stacked batch: twin layer present, kernel formats, no attention maps asked"""
+        if not _TWIN_BATCH[0] or i >= self.num_hidden_layers_twin:
+            return False
+        a, b = self.layer[i], self.layer_twin[i]
+        if a.crossattention.self.save_attention or b.crossattention.self.save_attention:
+            return False
+        if a.attention.self.attention_head_size != 64:
+            return False
+        lins = []
+        for l in (a, b):
+            for att in (l.attention, l.crossattention):
+                lins += [att.self.query, att.self.key, att.self.value, att.output.dense]
+            lins += [l.intermediate.dense, l.output.dense]
+        return ops.twin_kernel_ok(hs, lins)
+
+    def _twin_level(self, i, hs, mask2, enc2d, enc3d, mask2d, mask3d, layernorm_idx):
+        """one level of BOTH streams on the stacked states hs (2B, L, D) (rows [0,B) = 2D stream through layer[i], rows
+        [B,2B) = 3D stream through layer_twin[i]); the arithmetic per stream is BertLayer.forward's (self-attention ->
+        cross-attention over cat(fixed tokens, other stream's previous states) -> FFN, post-LN; reference
+        med.py:549-614), with one launch per projection / LayerNorm for the pair."""
+        a, b = self.layer[i], self.layer_twin[i]
+        sa, sb = a.attention.self, b.attention.self
+        B2, L, D = hs.shape
+        B, H, hd = B2 // 2, sa.num_attention_heads, sa.attention_head_size
+        scale = 1.0 / math.sqrt(hd)
+        p_att = sa.dropout.p if self.training else 0.0
+        # keys / values of the cross-attentions come from the PREVIOUS states of the other stream
+        mix2d, mix3d = ops.twin_mix(enc2d, enc3d, hs)
+        qkv = ops.twin_multi_linear(hs, (sa.query, sa.key, sa.value), (sb.query, sb.key, sb.value))
+        ctx = ops.attention_packed(qkv.view(B2, L, 3, H, hd), scale, p_att, mask2)
+        h = ops.twin_linear(ctx.reshape(B2, L, D), a.attention.output.dense, b.attention.output.dense)
+        att = ops.twin_dropout_add_layer_norm(h, hs, a.attention.output.LayerNorm, b.attention.output.LayerNorm,
+                                              a.attention.output.dropout.p, self.training)
+        ca, cb = a.crossattention.self, b.crossattention.self
+        q = ops.twin_linear(att, ca.query, cb.query).view(B2, L, H, hd)
+        kv2d, kv3d = ops.twin_multi_linear_var(mix2d, mix3d, (ca.key, ca.value), (cb.key, cb.value))
+        p_c = ca.dropout.p if self.training else 0.0
+        c = ops.twin_cross_attention(q, kv2d.view(B, mix2d.shape[1], 2, H, hd), kv3d.view(B, mix3d.shape[1], 2, H, hd),
+                                     scale, p_c, mask2d, mask3d)
+        h = ops.twin_linear(c.reshape(B2, L, D), a.crossattention.output.dense, b.crossattention.output.dense)
+        att = ops.twin_dropout_add_layer_norm(h, att, a.crossattention.output.LayerNorm, b.crossattention.output.LayerNorm,
+                                              a.crossattention.output.dropout.p, self.training)
+        h = ops.twin_mlp(att, a.intermediate.dense, a.output.dense, b.intermediate.dense, b.output.dense)
+        lna = a.output.LayerNorm if layernorm_idx == 0 else a.output.LayerNorms[layernorm_idx - 1]
+        lnb = b.output.LayerNorm if layernorm_idx == 0 else b.output.LayerNorms[layernorm_idx - 1]
+        return ops.twin_dropout_add_layer_norm(h, att, lna, lnb, a.output.dropout.p, self.training)
+
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, encoder_hidden_states_twin=None, encoder_attention_mask_twin=None,
                 past_key_values=None, use_cache=None, output_attentions=False, output_hidden_states=False,
@@ -402,11 +451,31 @@ class BertEncoderTwin(BertEncoder):
             heads = self.config.num_attention_heads
             h2d = ops.HoistedKV(enc2d, [self.layer[i].crossattention.self for i in hoisted_layers], heads)
             h3d = ops.HoistedKV(enc3d, [self.layer_twin[i].crossattention.self for i in hoisted_layers], heads)
+        stacked = mask2 = None   # the two streams as one (2B, L, D) tensor while consecutive levels run paired
         for i in layers:
             if output_hidden_states:
+                if stacked is not None:
+                    hidden_states, hidden_states_twin = ops.twin_split(stacked)
+                    stacked = None
                 all_hidden_states = all_hidden_states + (hidden_states,)
             want = _wants(output_attentions, i, layers[-1])
             twin = self.layer_twin[i] if i < self.num_hidden_layers_twin else None
+            key_only = lambda m: m is None or (m.dim() == 4 and m.shape[1] == 1 and m.shape[2] == 1)
+            if (not want and not hoisted_layers and mode == "multimodal" and attention_mask is not None
+                    and key_only(attention_mask) and key_only(encoder_attention_mask)
+                    and key_only(encoder_attention_mask_twin)
+                    and self._pairable(i, ops._c(hidden_states) if stacked is None else stacked)):
+                if stacked is None:
+                    stacked = torch.cat((ops._c(hidden_states), ops._c(hidden_states_twin)), dim=0)
+                if mask2 is None:
+                    mask2 = torch.cat((attention_mask, attention_mask), dim=0)
+                    ops.prime_masks(mask2)
+                stacked = self._twin_level(i, stacked, mask2, enc2d, enc3d, encoder_attention_mask,
+                                           encoder_attention_mask_twin, layernorm_idx)
+                continue
+            if stacked is not None:
+                hidden_states, hidden_states_twin = ops.twin_split(stacked)
+                stacked = None
             if i in slot_of:
                 mix2d = TwoSegmentStates(h2d, slot_of[i], ops._c(hidden_states_twin))
                 mix3d = TwoSegmentStates(h3d, slot_of[i], ops._c(hidden_states))
@@ -439,6 +508,8 @@ class BertEncoderTwin(BertEncoder):
                 all_self_attentions = all_self_attentions + (self_att,)
                 if all_cross_attentions is not None:
                     all_cross_attentions = all_cross_attentions + (cross_att,)
+        if stacked is not None:
+            hidden_states, hidden_states_twin = ops.twin_split(stacked)
         if output_hidden_states:
             all_hidden_states = all_hidden_states + (hidden_states, hidden_states_twin)
         return ModelOutput(last_hidden_state=(hidden_states, hidden_states_twin),

@@ -125,6 +125,18 @@ BQ_API int bq_bn_backward(const void *dy, const void *x, const float *scale, con
 /* exact (erf) GELU, bf16 (vit.py:23-41 Mlp act_layer=nn.GELU); n % 8 == 0, 16-B aligned */
 BQ_API int bq_gelu_fwd_bf16(const void *x, void *y, long n, void *stream);
 
+/* The same over TWO row groups with their own LayerNorm parameters -- the 2D and the 3D text stream of the twin encoder
+ * (models/med.py:549-614) stacked in one (M, H) tensor: rows [0, M/2) use gamma / beta, rows [M/2, M) gamma2 / beta2; one
+ * launch for both streams' BertSelfOutput / BertOutput tails.  zero_out / dgb: f32 (2, 2, H) = per group dgamma, dbeta. */
+BQ_API int bq_twin_drop_add_ln_fwd(const void *x, const void *residual, const float *gamma, const float *beta,
+                                   const float *gamma2, const float *beta2, void *y, float *mean, float *rstd,
+                                   float *zero_out, int M, int H, float eps, float p_drop, unsigned seed,
+                                   const unsigned *seed_ptr, void *stream);
+BQ_API int bq_twin_drop_add_ln_bwd(const void *x, const void *residual, const float *gamma, const float *gamma2,
+                                   const void *dy, const float *mean, const float *rstd, void *dx, void *dresidual,
+                                   float *dgb, int M, int H, float eps, float p_drop, unsigned seed,
+                                   const unsigned *seed_ptr, void *stream);
+
 /* ---- multi-tensor AdamW that also writes the bf16 operand copies (csrc/adamw.hip) ----------------------------
  * Replaces torch.optim.AdamW(...).step() of the reference's training step (scripts/train.py:410-417) and the
  * per-weight fp32 -> bf16 casts of the next forward.  table: n records {p, g, m, v, shadow|NULL (device pointers),

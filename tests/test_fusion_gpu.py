@@ -138,3 +138,74 @@ def test_blip_vqa3d_bf16_hip_path_vs_reference_golden(golden, dev, bf16):
                                scene_object_mask=tm("tw_om"), data_dict={})
     assert rel_l2(fused_e, g["bl_fused_eval"]) <= 2e-2
     assert rel_l2(scores[1], g["bl_rank_scene"]) <= 2e-2 and rel_l2(scores[2], g["bl_rank_2d"]) <= 2e-2
+
+
+def test_twin_levels_stacked_equal_per_stream_path(dev, bf16):
+    """the stacked twin level (one grouped launch per projection / LayerNorm for both text streams) against the
+    per-stream BertLayer path on the same weights and inputs: states, and every gradient (tolerance = bf16 rounding of
+    differently ordered fp32 sums; no dropout)"""
+    from bridgeqa_amd import med
+    torch.manual_seed(3)
+    cfg = med.BertConfig(hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=3,
+                         vocab_size=200, max_position_embeddings=64, encoder_width=256)
+    twin = med.BertModelTwin(config=cfg, add_pooling_layer=False).to(dev).eval()
+    for p in twin.parameters():  # distinct weights in the two streams, non-trivial biases / LayerNorm parameters
+        p.data.add_(0.05 * torch.randn_like(p))
+    B, L, P2, P3 = 4, 20, 70, 33
+    ids = torch.randint(1, 200, (B, L), device=dev)
+    am = torch.ones(B, L, dtype=torch.long, device=dev)
+    am[1, 15:] = 0
+    om = torch.ones(B, P3, dtype=torch.long, device=dev)
+    om[2, 20:] = 0
+    w2, w3 = torch.randn(B, L, 256, device=dev), torch.randn(B, L, 256, device=dev)
+    res = {}
+    for mode in (False, True):
+        med._TWIN_BATCH[0] = mode
+        try:
+            img = torch.randn(B, P2, 256, device=dev, generator=torch.Generator(dev).manual_seed(5)).requires_grad_(True)
+            obj = torch.randn(B, P3, 256, device=dev, generator=torch.Generator(dev).manual_seed(6)).requires_grad_(True)
+            for p in twin.parameters():
+                p.grad = None
+            r = twin(ids, attention_mask=am, encoder_hidden_states=img,
+                     encoder_attention_mask=torch.ones(B, P2, dtype=torch.long, device=dev),
+                     encoder_hidden_states_twin=obj, encoder_attention_mask_twin=om, return_dict=True,
+                     output_attentions="last")
+            h2d, h3d = r.last_hidden_state
+            ((h2d.float() * w2).sum() + (h3d.float() * w3).sum()).backward()
+            res[mode] = dict(h2d=h2d.float(), h3d=h3d.float(), img=img.grad.float(), obj=obj.grad.float(),
+                             grads={n: p.grad.float().clone() for n, p in twin.named_parameters() if p.grad is not None})
+        finally:
+            med._TWIN_BATCH[0] = True
+    a, b = res[False], res[True]
+    rel = lambda x, y: ((x - y).norm() / (y.norm() + 1e-20)).item()
+    assert rel(b["h2d"], a["h2d"]) <= 5e-3 and rel(b["h3d"], a["h3d"]) <= 5e-3
+    assert rel(b["img"], a["img"]) <= 2e-2 and rel(b["obj"], a["obj"]) <= 2e-2
+    assert a["grads"].keys() == b["grads"].keys() and len(a["grads"]) > 80
+    worst = max((rel(b["grads"][n], a["grads"][n]), n) for n in a["grads"])
+    assert worst[0] <= 2e-2, worst
+
+
+def test_twin_layer_norm_kernel_equals_two_single_launches(dev):
+    from bridgeqa_amd import _ext
+    torch.manual_seed(0)
+    M, H = 2 * 333, 768
+    x = torch.randn(M, H, device=dev).bfloat16()
+    r = torch.randn(M, H, device=dev).bfloat16()
+    dy = torch.randn(M, H, device=dev).bfloat16()
+    ga, ba, gb, bb = [torch.randn(H, device=dev) for _ in range(4)]
+    st = torch.full((1,), 11, dtype=torch.int32, device=dev)
+    for p in (0.0, 0.1):
+        y, mean, rstd, dgb = _ext.twin_drop_add_ln_fwd(x, r, ga, ba, gb, bb, 1e-12, p, 77, st, True)
+        assert float(dgb.abs().max()) == 0.0
+        dx, dres, dgb = _ext.twin_drop_add_ln_bwd(x, r, ga, gb, dy, mean, rstd, 1e-12, p, 77, st, dgb)
+        for g, (gam, bet) in enumerate(((ga, ba), (gb, bb))):
+            s = slice(g * M // 2, (g + 1) * M // 2)
+            if p == 0.0:  # (the dropout hash is keyed by the absolute row: only p = 0 is comparable launch by launch)
+                y1, _, m1, r1, d1 = _ext.drop_add_ln_fwd(x[s].contiguous(), r[s].contiguous(), gam, bet, 1e-12, 0.0, 77, st, False, 0.0, 0, True)
+                dx1, dres1, dg1, db1 = _ext.drop_add_ln_bwd(x[s].contiguous(), r[s].contiguous(), gam, dy[s].contiguous(), m1, r1, 1e-12, 0.0, 77, st, None, 0.0, 0, d1)
+                assert torch.equal(y[s], y1) and torch.equal(dx[s], dx1) and torch.equal(dres[s], dres1)
+                assert torch.allclose(dgb[g, 0], dg1, rtol=1e-4, atol=1e-3) and torch.allclose(dgb[g, 1], db1, rtol=1e-4, atol=1e-3)
+            else:
+                assert torch.isfinite(y[s].float()).all() and torch.isfinite(dx[s].float()).all()
+                kept = (dx[s].float() != 0).float().mean().item()
+                assert 0.85 < kept < 0.95, kept

@@ -412,6 +412,7 @@ def main():
             step()
         if os.environ.get("BQ_PIPE_TRACE") == "1":
             pipe.host_times = {}
+            pipe.phase_events = {}
         use_graph = False  # (the single-graph capture below is the other schedule)
     else:
         step = eager_step
@@ -487,6 +488,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     assert torch.isfinite(loss).item()
+    if rank == 0 and pipe is not None and pipe.phase_events:
+        print("GPU ms since the step's first launch, per phase [start -> end on its stream]: " +
+              "  ".join("%s %.1f->%.1f" % (k, a, b) for k, (a, b) in pipe.phase_gpu_ms().items()), file=sys.stderr)
     if rank == 0 and pipe is not None and pipe.host_times:
         print("host ms per graph launch: " + "  ".join("%s %.1f" % (k, sum(v) / len(v)) for k, v in pipe.host_times.items()),
               file=sys.stderr)

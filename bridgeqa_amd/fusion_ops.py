@@ -290,9 +290,20 @@ def _accumulate_grad(p, g):
         p.grad.add_(g)
 
 
+def take_deferred_wgrad():
+    """end the scope WITHOUT computing: returns the parked (dY, X, weights, biases) records for
+    flush_deferred_items() -- pipeline.PhasedTrainStep produces the fusion phase's weight gradients on another stream,
+    off the critical path between the fusion backward and the image / detector backward"""
+    items, _DEFER[0] = _DEFER[0], None
+    return items or []
+
+
 def flush_deferred_wgrad():
     """compute the parked weight / bias gradients (current stream) and store them in the parameters' .grad"""
-    items, _DEFER[0] = _DEFER[0], None
+    flush_deferred_items(take_deferred_wgrad())
+
+
+def flush_deferred_items(items):
     if not items:
         return
     from . import _ext

@@ -20,16 +20,16 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError("FusedAdamW: betas and eps must be the same for every parameter group (lr / weight_decay "
                              "may differ)")
         self._step_t = None
-        self._sig = None
-        self._table = self._chunks = None
-        self._pinned = None
-        self._order = []   # (parameter, group) in table order: sync_hyperparams() rewrites their lr / weight_decay
+        # one device table per SUBSET of the parameters (step(subset=...)): None = all parameters in one launch
+        self._subs = {}
 
-    def _records(self):
+    def _records(self, sub):
         recs = []
         for g in self.param_groups:
             for p in g["params"]:
                 if p.grad is None:
+                    continue
+                if sub["members"] is not None and id(p) not in sub["members"]:
                     continue
                 if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or not p.grad.is_contiguous():
                     raise RuntimeError("FusedAdamW: parameters and gradients must be contiguous fp32 CUDA tensors")
@@ -61,67 +61,82 @@ class FusedAdamW(torch.optim.Optimizer):
             self._step(dev).fill_(max(steps))
             for st in self.state.values():
                 st["step"] = self._step_t
-        self._sig = None  # moments were re-allocated: rebuild the device table
+        for sub in self._subs.values():
+            sub["sig"] = None  # moments were re-allocated: rebuild the device tables
 
     def sync_hyperparams(self):
         """Rewrite lr / weight_decay of every table record from param_groups into the pinned staging copy.  step() does
         it itself; call this before REPLAYING a captured step (the graph holds the H2D copy node of the table and the
         kernel launch, but no Python runs): LR schedulers then take effect under graph replay."""
-        if self._pinned is None:
-            return
-        tab = self._pinned.numpy()[:len(self._order) * 56].view(self._dtype)
-        for i, (_, g) in enumerate(self._order):
-            tab["lr"][i] = g["lr"]
-            tab["wd"][i] = g["weight_decay"]
+        for sub in self._subs.values():
+            if sub["pinned"] is None:
+                continue
+            tab = sub["pinned"].numpy()[:len(sub["order"]) * 56].view(self._dtype)
+            for i, (_, g) in enumerate(sub["order"]):
+                tab["lr"][i] = g["lr"]
+                tab["wd"][i] = g["weight_decay"]
 
-    def _build(self, recs, device):
+    def _build(self, sub, recs, device):
         from . import _ext
         assert _ext.ADAMW_TENSOR_BYTES == 56
         dt = self._dtype = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("s", "<u8"), ("n", "<i8"),
                                      ("lr", "<f4"), ("wd", "<f4")])
         tab = np.zeros(len(recs), dtype=dt)
         chunks = []
-        self._order = [(r[0], r[7]) for r in recs]
+        sub["order"] = [(r[0], r[7]) for r in recs]   # (parameter, group): sync_hyperparams() rewrites lr / weight_decay
         for i, (p, g, m, v, sh, lr, wd, _) in enumerate(recs):
             tab[i] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr() if sh is not None else 0,
                       p.numel(), lr, wd)
             nchunk = (p.numel() + _ext.ADAMW_CHUNK - 1) // _ext.ADAMW_CHUNK
             chunks.append(np.stack([np.full(nchunk, i, dtype=np.int32), np.arange(nchunk, dtype=np.int32)], axis=1))
         host = np.concatenate([tab.view(np.uint8).reshape(-1), np.concatenate(chunks).reshape(-1).view(np.uint8)])
-        if self._pinned is None or self._pinned.numel() != host.size:
+        if sub["pinned"] is None or sub["pinned"].numel() != host.size:
             # first build (eager warm-up): the staging buffers are allocated once; a rebuild under graph capture (the
             # gradients move into the graph's pool) only rewrites them and records one H2D copy node
-            self._pinned = torch.empty(host.size, dtype=torch.uint8).pin_memory()
-            self._devbuf = torch.empty(host.size, dtype=torch.uint8, device=device)
-        self._pinned.numpy()[:] = host
+            sub["pinned"] = torch.empty(host.size, dtype=torch.uint8).pin_memory()
+            sub["devbuf"] = torch.empty(host.size, dtype=torch.uint8, device=device)
+        sub["pinned"].numpy()[:] = host
         nt = len(recs) * 56
-        self._table = self._devbuf[:nt]
-        self._chunks = self._devbuf[nt:].view(torch.int32).view(-1, 2)
+        sub["table"] = sub["devbuf"][:nt]
+        sub["chunks"] = sub["devbuf"][nt:].view(torch.int32).view(-1, 2)
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, subset=None, params=None, advance=True):
+        """subset=None: every parameter that has a gradient, one launch (torch.optim semantics).
+        subset="name", params=<iterable>: only those parameters (the membership is fixed by the first call for that
+        name; later calls may omit params) -- pipeline.PhasedTrainStep steps the fusion parameters as soon as their
+        gradients are complete, under the image / detector backward, and the rest at the end of the step.  The caller
+        keeps the subsets disjoint and passes advance=True to exactly ONE of a training step's subset calls -- the first
+        to run: it increments the shared update counter."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        recs = self._records()
+        sub = self._subs.get(subset)
+        if sub is None:
+            if subset is not None and params is None:
+                raise ValueError("FusedAdamW.step: the first call for subset %r must pass params" % (subset,))
+            sub = self._subs[subset] = dict(name=subset, sig=None, table=None, chunks=None, pinned=None, devbuf=None,
+                                            order=[], members=None if subset is None else {id(p) for p in params})
+        recs = self._records(sub)
         if not recs:
             return loss
         from . import _ext
         device = recs[0][0].device
         sig = tuple((r[0].data_ptr(), r[1].data_ptr(), r[2].data_ptr(), r[3].data_ptr(),
                      r[4].data_ptr() if r[4] is not None else 0) for r in recs)
-        if sig != self._sig:
-            self._build(recs, device)
-            self._sig = sig
+        if sig != sub["sig"]:
+            self._build(sub, recs, device)
+            sub["sig"] = sig
         else:
             self.sync_hyperparams()
         # the table travels to the device on EVERY step (tens of KB): a captured step therefore always contains the
         # copy node, and lr / weight_decay written into the pinned copy reach the kernel of the next launch / replay
-        self._devbuf.copy_(self._pinned, non_blocking=True)
-        self._step(device).add_(1.0)
+        sub["devbuf"].copy_(sub["pinned"], non_blocking=True)
+        if advance:
+            self._step(device).add_(1.0)
         beta1, beta2 = self.param_groups[0]["betas"]
-        _ext.adamw_multi(self._table, self._chunks, self._step_t, beta1, beta2, self.param_groups[0]["eps"],
+        _ext.adamw_multi(sub["table"], sub["chunks"], self._step(device), beta1, beta2, self.param_groups[0]["eps"],
                          self.grad_clip_value)
         fusion_ops.shadows_written([r[0] for r in recs if r[4] is not None])
         return loss

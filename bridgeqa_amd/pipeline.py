@@ -10,6 +10,14 @@ explicit stream with explicit events:
     main stream:  image fwd ............. fusion fwd+bwd ..........-> image bwd ........ optimizer
     det  stream:  detector fwd -> (event) geometry of the NEXT batch -> detector bwd -> (event)
 
+Measured and NOT adopted (round 2, c3, per-phase HIP events, BQ_PIPE_TRACE=1): moving the fusion phase's tail -- its
+grouped weight-gradient GEMMs (2.3 ms) and the AdamW update of its 399 M parameters (2.0 ms) -- to a third stream under
+the image / detector backward (split_fusion_tail / split_fusion_opt below).  The fusion phase hands over 1.0 ms earlier,
+but the image backward stretches from 18.2 to 21.8 ms and the detector backward from 13.3 to 15.3 ms: a HBM-bound
+update next to GEMMs that stream their operands from HBM only moves the time (one dX GEMM that normally takes 73 us ran
+2.0 ms beside the AdamW kernel).  Step: 47.1 ms inline, 46.9 ms with the weight gradients on the side stream, 49.8 ms
+with the optimizer there too.  Both stay off.
+
 The fusion phase is ~2000 short kernels that leave most of the 256 CUs idle, and FPS / ball query / three-NN depend
 on coordinates only (no parameters): the sampling and grouping indices of the next batch are computed under it
 (4 ms per step hidden, measured) and handed to the next detector forward through a copy, so the backward of the
@@ -53,7 +61,7 @@ def _cu_masked_stream(device, lo, hi, total=256):
 class PhasedTrainStep(object):
     def __init__(self, model, batch, det_loss, fusion_loss, optimizer=None, use_graphs=True, det_priority=0,
                  grad_hook=None, next_batch=None, prefetch_geometry=None, eager_phases=(), reducers=None,
-                 reserve_cus=0):
+                 reserve_cus=0, split_fusion_tail=False, split_fusion_opt=False):
         """model: ScanQAHotPath (use_blip=True, train mode); batch: static device tensors (replayed in place);
         det_loss(data_dict) -> scalar over detector outputs; fusion_loss(data_dict) -> scalar over blip_loss /
         fused_feat; optimizer: stepped at the end of the step (None: the caller steps);
@@ -73,7 +81,10 @@ class PhasedTrainStep(object):
         reserve_cus: N > 0 runs the two image-encoder phases on a stream masked to CUs [N, 256): its GPU-filling
         kernels then leave N CUs to the detector stream, which otherwise only gets to dispatch at their kernel
         boundaries (see the module docstring).  MEASURED on c3: 0 -> 50.1 ms/step, 16 -> 52.7, 32 -> 52.7, 48 -> 57.0:
-        the encoder loses more than the detector gains, so the default stays 0 (knob kept for other shapes)."""
+        the encoder loses more than the detector gains, so the default stays 0 (knob kept for other shapes);
+        split_fusion_tail / split_fusion_opt: produce the fusion phase's weight gradients / additionally step its
+        parameters (optim.FusedAdamW subsets) on a third stream under the image and detector backward -- measured
+        neutral / slower (module docstring), off by default."""
         self.model, self.batch, self.det_loss, self.fusion_loss = model, batch, det_loss, fusion_loss
         self.opt, self.grad_hook = optimizer, grad_hook
         if prefetch_geometry and next_batch is None:
@@ -91,6 +102,7 @@ class PhasedTrainStep(object):
         self._comm_events = []
         self._geo_next, self._geo_cur = None, None
         self.host_times = None  # set to {} to record the host time of every graph launch (ms, per phase)
+        self.phase_events = None  # set to {} to bracket every phase with events on its stream (phase_gpu_ms())
         dev = batch["point_clouds"].device
         self.dev = dev
         self.s_main = torch.cuda.Stream(device=dev)
@@ -98,6 +110,15 @@ class PhasedTrainStep(object):
         self.e_img_fwd = torch.cuda.Event()
         self.s_det = torch.cuda.Stream(device=dev, priority=det_priority)
         self.e_det_fwd, self.e_fused, self.e_det_bwd, self.e_done = (torch.cuda.Event() for _ in range(4))
+        # the fusion phase's tail on its own stream: weight gradients (whenever they are deferred), and the optimizer
+        # step of the fusion parameters when the optimizer can step subsets (optim.FusedAdamW) and no grad_hook needs
+        # every gradient before any update
+        self.s_aux = torch.cuda.Stream(device=dev)
+        self._params = None
+        self.e_fusion_wgrad, self.e_fusion_opt = torch.cuda.Event(), torch.cuda.Event()
+        # (both measured slower or neutral on c3 -- see the module docstring -- and therefore opt-in)
+        self.split_wgrad = bool(split_fusion_tail)
+        self._split_opt_ok = self.split_wgrad and bool(split_fusion_opt) and grad_hook is None
         self.use_graphs = use_graphs
         self.graphs = None
         self.loss = None
@@ -153,9 +174,35 @@ class PhasedTrainStep(object):
         try:
             loss.backward()
         finally:
-            ops.flush_deferred_wgrad()
+            if self.defer_wgrad and self.split_wgrad:
+                # (the records stay referenced from here until the next step / capture replaces them: under graph
+                # replay the aux stream reads these tensors while later main-stream graphs of the same memory pool
+                # run, so they must never go back to that pool)
+                st["fusion_parked"] = ops.take_deferred_wgrad()
+            else:
+                ops.flush_deferred_wgrad()
         st["img_grad"], st["obj_grad"] = img_leaf.grad, obj_leaf.grad
         st["fusion_loss"] = loss.detach()
+
+    def _split_opt(self):
+        return self._split_opt_ok and self.opt is not None and hasattr(self.opt, "_subs")
+
+    def _fusion_wgrad(self):
+        ops.flush_deferred_items(self._state.get("fusion_parked"))
+
+    def _param_split(self):
+        """(fusion parameters, the rest): the fusion phase produces the gradients of the BLIP text side (twin encoder,
+        answer decoder, heads); the image encoder's come from image_bwd, the detector's from det_bwd"""
+        if self._params is None:
+            fus, rest = [], []
+            for name, p in self.model.named_parameters():
+                is_fusion = name.startswith("blip_model.") and not name.startswith("blip_model.visual_encoder.")
+                (fus if is_fusion else rest).append(p)
+            self._params = (fus, rest)
+        return self._params
+
+    def _fusion_opt(self):
+        self.opt.step(subset="fusion", params=self._param_split()[0], advance=True)
 
     def _image_bwd(self):
         if self.defer_wgrad:
@@ -176,20 +223,52 @@ class PhasedTrainStep(object):
         if self.grad_hook is not None:
             self.grad_hook()
         if self.opt is not None:
-            self.opt.step()  # (fusion_ops' optimizer post-step hook refreshes the bf16 weight shadows here)
+            # (fusion_ops' optimizer post-step hook refreshes the bf16 weight shadows here)
+            if self._split_opt():
+                # (the fusion parameters were stepped on the aux stream)
+                self.opt.step(subset="rest", params=self._param_split()[1], advance=False)
+            else:
+                self.opt.step()
         st = self._state
         self.loss = st["det_loss"].detach() + st["fusion_loss"]
 
     # (phase, stream, memory pool): the image phases may sit on their own (CU-masked) stream but still alternate
     # strictly with the main stream's phases, so they share its pool
     _ORDER = (("det_fwd", "det", "det"), ("geometry", "det", "det"), ("image_fwd", "img", "main"),
-              ("fusion", "main", "main"), ("det_bwd", "det", "det"), ("image_bwd", "img", "main"),
-              ("finish", "main", "main"))
+              ("fusion", "main", "main"), ("fusion_wgrad", "aux", "aux"), ("fusion_opt", "aux", "aux"),
+              ("det_bwd", "det", "det"), ("image_bwd", "img", "main"), ("finish", "main", "main"))
 
     def _stream(self, which):
-        return {"main": self.s_main, "det": self.s_det, "img": self.s_img}[which]
+        return {"main": self.s_main, "det": self.s_det, "img": self.s_img, "aux": self.s_aux}[which]
+
+    def _skipped(self, name):
+        return ((name == "geometry" and not self.prefetch) or
+                (name == "fusion_wgrad" and not (self.defer_wgrad and self.split_wgrad)) or
+                (name == "fusion_opt" and not self._split_opt()))
+
+    def phase_gpu_ms(self):
+        """after a synchronize: {phase: (mean start, mean end)} in ms relative to the start of the step's first phase,
+        from the events recorded while phase_events was a dict"""
+        out = {}
+        steps = min(len(v) for v in self.phase_events.values())
+        for name, evs in self.phase_events.items():
+            a = [self.phase_events["det_fwd"][i][0].elapsed_time(evs[i][0]) for i in range(steps)]
+            b = [self.phase_events["det_fwd"][i][0].elapsed_time(evs[i][1]) for i in range(steps)]
+            out[name] = (sum(a) / steps, sum(b) / steps)
+        return out
 
     def _run(self, name, eager):
+        if self.phase_events is not None:
+            s_ = torch.cuda.current_stream(self.dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s_)
+            self._run_inner(name, eager)
+            e1.record(s_)
+            self.phase_events.setdefault(name, []).append((e0, e1))
+        else:
+            self._run_inner(name, eager)
+
+    def _run_inner(self, name, eager):
         if eager or name in self.eager_phases:
             getattr(self, "_" + name)()
         elif self.host_times is not None:
@@ -204,20 +283,21 @@ class PhasedTrainStep(object):
         """exchange one gradient group on the communication stream once `after_event` (its backward) has passed"""
         r = self.reducers.get(group)
         if r is None:
-            return
+            return None
         self.s_comm.wait_event(after_event)
         with torch.cuda.stream(self.s_comm):
             r.all_reduce()
             ev = torch.cuda.Event()
             ev.record(self.s_comm)
         self._comm_events.append(ev)
+        return ev
 
     def _schedule(self, eager):
         """Launch the phases with their cross-stream dependencies (the host returns without waiting for the GPU).
         Host ORDER matters: a graph launch blocks the host while its stream's hardware queue is full, so at every
         point the detector stream's launches (short, its queue is usually empty) are issued before the main
         stream's -- otherwise the detector only gets its packets once the main stream has drained (measured)."""
-        sm, sd, si = self.s_main, self.s_det, self.s_img
+        sm, sd, si, sa = self.s_main, self.s_det, self.s_img, self.s_aux
         sd.wait_event(self.e_done)  # parameters of the previous step's optimizer
         with torch.cuda.stream(sd):
             self._run("det_fwd", eager)
@@ -234,11 +314,25 @@ class PhasedTrainStep(object):
             sm.wait_event(self.e_det_fwd)
             self._run("fusion", eager)
             self.e_fused.record(sm)
-        self._reduce("fusion", self.e_fused)
         sd.wait_event(self.e_fused)
         with torch.cuda.stream(sd):
             self._run("det_bwd", eager)
             self.e_det_bwd.record(sd)
+        # the fusion phase's tail, off the critical path (the detector / image backward only need e_fused)
+        fusion_grads = self.e_fused
+        if not self._skipped("fusion_wgrad"):
+            sa.wait_event(self.e_fused)
+            with torch.cuda.stream(sa):
+                self._run("fusion_wgrad", eager)
+                self.e_fusion_wgrad.record(sa)
+            fusion_grads = self.e_fusion_wgrad
+        ev = self._reduce("fusion", fusion_grads)
+        if not self._skipped("fusion_opt"):
+            if ev is not None:
+                sa.wait_event(ev)
+            with torch.cuda.stream(sa):
+                self._run("fusion_opt", eager)
+                self.e_fusion_opt.record(sa)
         self._reduce("det", self.e_det_bwd)
         si.wait_event(self.e_fused)
         with torch.cuda.stream(si):
@@ -248,6 +342,10 @@ class PhasedTrainStep(object):
         with torch.cuda.stream(sm):
             sm.wait_event(self.e_img_bwd)
             sm.wait_event(self.e_det_bwd)
+            if not self._skipped("fusion_wgrad"):
+                sm.wait_event(self.e_fusion_wgrad)
+            if not self._skipped("fusion_opt"):
+                sm.wait_event(self.e_fusion_opt)
             for ev in self._comm_events:
                 sm.wait_event(ev)
             del self._comm_events[:]
@@ -260,7 +358,7 @@ class PhasedTrainStep(object):
         (Parameters that get no gradient on this path -- unused BLIP heads -- are left out, as DDP's
         find_unused_parameters would discover every step.)"""
         cur = torch.cuda.current_stream(self.dev)
-        for s_ in (self.s_main, self.s_det, self.s_img):
+        for s_ in (self.s_main, self.s_det, self.s_img, self.s_aux):
             s_.wait_stream(cur)
         self.e_done.record(self.s_main)
         if self.prefetch and self._geo_next is None:
@@ -302,7 +400,7 @@ class PhasedTrainStep(object):
         running statistics), moments and the step count are put back afterwards, so training starts from the state
         the caller handed over."""
         cur = torch.cuda.current_stream(self.dev)
-        for s_ in (self.s_main, self.s_det, self.s_img):
+        for s_ in (self.s_main, self.s_det, self.s_img, self.s_aux):
             s_.wait_stream(cur)
         self.e_done.record(self.s_main)
         if self.prefetch:
@@ -331,14 +429,18 @@ class PhasedTrainStep(object):
             return self
         self.zero_grad()
         self._state = {}
-        pools = {"main": torch.cuda.graph_pool_handle(), "det": torch.cuda.graph_pool_handle()}
+        pools = {"main": torch.cuda.graph_pool_handle(), "det": torch.cuda.graph_pool_handle(),
+                 "aux": torch.cuda.graph_pool_handle()}
         self.graphs = {}
         for name, which, pool in self._ORDER:
-            if (name == "geometry" and not self.prefetch) or name in self.eager_phases:
+            if self._skipped(name) or name in self.eager_phases:
                 continue
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pools[pool], stream=self._stream(which)):
-                getattr(self, "_" + name)()
+            try:
+                with torch.cuda.graph(g, pool=pools[pool], stream=self._stream(which)):
+                    getattr(self, "_" + name)()
+            except Exception as e:
+                raise RuntimeError("PhasedTrainStep.capture: phase '%s' could not be captured: %s" % (name, e)) from e
             self.graphs[name] = g
             torch.cuda.synchronize(self.dev)
         self.e_done.record(self.s_main)

@@ -606,3 +606,29 @@ def test_gelu_kernel_matches_torch_exact_gelu(dev):
     want = torch.nn.functional.gelu(x)
     assert got.dtype == torch.bfloat16 and (got.float() - want.float()).abs().max().item() <= 2 ** -7 * max(1.0, want.float().abs().max().item()) * 0.01 + 1e-2
     assert ((got.float() - want.float()).norm() / want.float().norm()).item() < 2e-3
+
+
+def test_fused_adamw_subset_steps_equal_one_step(dev):
+    """FusedAdamW.step(subset=...): a training step's update issued as two launches over disjoint parameter subsets
+    (pipeline.PhasedTrainStep steps the fusion parameters early, the rest at the end) == torch.optim.AdamW's one step;
+    the membership is fixed by the first call of a subset; the update counter advances once."""
+    from bridgeqa_amd.optim import FusedAdamW
+    torch.manual_seed(7)
+    shapes = [(300, 7), (1001,), (64, 64), (5,)]
+    mine = [torch.nn.Parameter(torch.randn(*s, device=dev)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    o1, o2 = FusedAdamW(mine, lr=1e-2, weight_decay=1e-2), torch.optim.AdamW(ref, lr=1e-2, weight_decay=1e-2)
+    for step in range(4):
+        grads = [torch.randn_like(p) for p in mine]
+        for b, g in zip(ref, grads):
+            b.grad = g.clone()
+        for p in mine:
+            p.grad = None
+        for p, g in zip(mine, grads):   # every gradient is there at both calls: the membership decides
+            p.grad = g.clone()
+        o1.step(subset="early", params=mine[:2] if step == 0 else None, advance=True)
+        o1.step(subset="late", params=mine[2:] if step == 0 else None, advance=False)
+        o2.step()
+        for a, b in zip(mine, ref):
+            assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), (step, a.shape, (a - b).abs().max().item())
+    assert float(o1.state[mine[0]]["step"]) == 4.0

@@ -49,7 +49,42 @@ def xc_frag_addrs(sub16, kk, second):
     return out
 
 
+# ---- images of csrc/attn.hip ---------------------------------------------------------------------------------------
+def attn_key_r1(row):
+    return row & 7
+
+
+def attn_key(row):
+    """swz_key of csrc/attn.hip: row bits (1, 2, 1^3)"""
+    return ((row >> 1) & 3) | ((((row >> 1) ^ (row >> 3)) & 1) << 2)
+
+
+def attn_report(key):
+    swz = lambda row, ch: row * 128 + ((ch ^ key(row)) << 4)
+    worst = 1
+    for base in (0, 32):          # ds_read_b128 rows of K / V / Q / dO: lane (r, h) -> row base + r, chunk 2 s + h
+        for s in range(4):
+            worst = max(worst, ways("b128", [swz(base + (l & 31), 2 * s + (l >> 5)) for l in range(64)]))
+    rows = worst
+    worst = 1
+    for row0 in (0, 16, 32, 48):  # ds_read_b64_tr_b16 (tfrag_tr): 4 rows x 4 chunks x 2 halves per 32 lanes
+        for dbase in (0, 32):
+            for second in (0, 8):
+                a = []
+                for l in range(64):
+                    r, h = l & 31, l >> 5
+                    q, p = (r & 15) >> 2, r & 3
+                    a.append(swz(row0 + 4 * h + q + second, ((dbase + 16 * (r >> 4)) >> 3) + (p >> 1)) + 8 * (p & 1))
+                worst = max(worst, ways("tr", a))
+    return rows, worst
+
+
 if __name__ == "__main__":
+    import sys
+    if "--attn" in sys.argv:
+        for name, key in (("round-1 key row & 7", attn_key_r1), ("swz_key (row bits 1, 2, 1^3)", attn_key)):
+            print("%-32s ds_read_b128 rows: %d-way   ds_read_b64_tr_b16: %d-way" % ((name,) + attn_report(key)))
+        sys.exit(0)
     for sub in range(4):
         for kk in range(2):
             print("KC frag sub16=%d kk=%d: %d-way" % (sub, kk, ways("b128", kc_frag_addrs(sub, kk))))

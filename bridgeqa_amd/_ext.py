@@ -642,7 +642,7 @@ def _mat(t, name):
 def pick_tile(Ni, Nj, q_xc):
     if Nj >= GEMM_TILE_ROWS and Ni >= 256:
         return 256
-    if q_xc or Nj > 512:
+    if q_xc or Nj > 512:  # (64-row tiles from 100 / 200 rows up: measured 0.3-0.4 ms SLOWER per c3 step)
         return 64
     return 32
 

@@ -17,14 +17,19 @@ namespace bq {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // one thread per row: merge nrec (max, sumexp, sumz) records
-__global__ __launch_bounds__(64) void lmhead_ce_combine_kernel(const float *__restrict__ part, const float *__restrict__ zt,
-                                                               const int *__restrict__ tgt, float *__restrict__ loss,
-                                                               float *__restrict__ lse, int R, int nrec, int V,
-                                                               float smoothing) {
-  const int r = blockIdx.x * 64 + threadIdx.x;
-  if (r >= R) return;
+// one WAVE per row: lane g folds records g, g+64, ... (independent loads in flight instead of one serial chain of nrec
+// dependent HBM round trips per thread: 81 us -> a few us at nrec = 240), then the 64 (max, sum) pairs are merged by
+// xor-shuffles -- the merge of two online-softmax states is associative and commutative up to rounding, and the shuffle
+// tree is fixed, so the result is deterministic
+__global__ __launch_bounds__(256) void lmhead_ce_combine_kernel(const float *__restrict__ part, const float *__restrict__ zt,
+                                                                const int *__restrict__ tgt, float *__restrict__ loss,
+                                                                float *__restrict__ lse, int R, int nrec, int V,
+                                                                float smoothing) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;  // wave-uniform
   float m = -INFINITY, s = 0.f, sz = 0.f;
-  for (int g = 0; g < nrec; ++g) {
+  for (int g = lane; g < nrec; g += 64) {
     const float *p = part + ((long)g * R + r) * 3;
     const float mg = p[0], sg = p[1];
     sz += p[2];
@@ -33,6 +38,15 @@ __global__ __launch_bounds__(64) void lmhead_ce_combine_kernel(const float *__re
     s = s * (m == -INFINITY ? 0.f : __expf(m - mn)) + sg * __expf(mg - mn);
     m = mn;
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float mo = __shfl_xor(m, off), so = __shfl_xor(s, off);
+    sz += __shfl_xor(sz, off);
+    const float mn = fmaxf(m, mo);
+    s = (m == -INFINITY ? 0.f : s * __expf(m - mn)) + (mo == -INFINITY ? 0.f : so * __expf(mo - mn));
+    m = mn;
+  }
+  if (lane != 0) return;
   const float l = m + __logf(s);
   lse[r] = l;
   const int t = tgt[r];
@@ -74,7 +88,7 @@ extern "C" int bq_lmhead_ce_combine(const float *partial, const float *target_lo
   using namespace bq;
   BQ_REQUIRE(partial && target_logit && target && loss && lse && R > 0 && nrec > 0 && V > 0, BQ_EINVAL,
              "lmhead_ce_combine: bad arguments");
-  hipLaunchKernelGGL(lmhead_ce_combine_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial,
+  hipLaunchKernelGGL(lmhead_ce_combine_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial,
                      target_logit, target, loss, lse, R, nrec, V, label_smoothing);
   return check_launch("lmhead_ce_combine");
 }

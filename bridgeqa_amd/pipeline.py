@@ -18,7 +18,7 @@ update next to GEMMs that stream their operands from HBM only moves the time (on
 2.0 ms beside the AdamW kernel).  Step: 47.1 ms inline, 46.9 ms with the weight gradients on the side stream, 49.8 ms
 with the optimizer there too.  Both stay off.
 
-The fusion phase is ~2000 short kernels that leave most of the 256 CUs idle, and FPS / ball query / three-NN depend
+The fusion phase is ~1200 short kernels that leave most of the 256 CUs idle, and FPS / ball query / three-NN depend
 on coordinates only (no parameters): the sampling and grouping indices of the next batch are computed under it
 (4 ms per step hidden, measured) and handed to the next detector forward through a copy, so the backward of the
 current step still reads the indices it was built with.

@@ -61,7 +61,7 @@ def _cu_masked_stream(device, lo, hi, total=256):
 class PhasedTrainStep(object):
     def __init__(self, model, batch, det_loss, fusion_loss, optimizer=None, use_graphs=True, det_priority=0,
                  grad_hook=None, next_batch=None, prefetch_geometry=None, eager_phases=(), reducers=None,
-                 reserve_cus=0, split_fusion_tail=False, split_fusion_opt=False):
+                 reserve_cus=0, split_fusion_tail=False, split_fusion_opt=False, main_priority=-1):
         """model: ScanQAHotPath (use_blip=True, train mode); batch: static device tensors (replayed in place);
         det_loss(data_dict) -> scalar over detector outputs; fusion_loss(data_dict) -> scalar over blip_loss /
         fused_feat; optimizer: stepped at the end of the step (None: the caller steps);
@@ -105,10 +105,13 @@ class PhasedTrainStep(object):
         self.phase_events = None  # set to {} to bracket every phase with events on its stream (phase_gpu_ms())
         dev = batch["point_clouds"].device
         self.dev = dev
-        self.s_main = torch.cuda.Stream(device=dev)
+        # the critical path (image forward -> fusion -> image backward -> optimizer) on a HIGH-priority stream: its
+        # kernels win the dispatch whenever both streams have work (measured, c3: 46.5 -> 45.5 ms; the detector stream at
+        # high priority instead: 47.3 ms; this stack offers two levels, 0 and -1)
+        self.s_main = torch.cuda.Stream(device=dev, priority=int(main_priority))
         self.s_img = _cu_masked_stream(dev, int(reserve_cus), 256) if reserve_cus else self.s_main
         self.e_img_fwd = torch.cuda.Event()
-        self.s_det = torch.cuda.Stream(device=dev, priority=det_priority)
+        self.s_det = torch.cuda.Stream(device=dev, priority=int(det_priority))
         self.e_det_fwd, self.e_fused, self.e_det_bwd, self.e_done = (torch.cuda.Event() for _ in range(4))
         # the fusion phase's tail on its own stream: weight gradients (whenever they are deferred), and the optimizer
         # step of the fusion parameters when the optimizer can step subsets (optim.FusedAdamW) and no grad_hook needs

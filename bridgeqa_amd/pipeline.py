@@ -118,6 +118,7 @@ class PhasedTrainStep(object):
         # every gradient before any update
         self.s_aux = torch.cuda.Stream(device=dev)
         self._params = None
+        self._bn_modules, self._bn_sig = None, None
         self.e_fusion_wgrad, self.e_fusion_opt = torch.cuda.Event(), torch.cuda.Event()
         # (both measured slower or neutral on c3 -- see the module docstring -- and therefore opt-in)
         self.split_wgrad = bool(split_fusion_tail)
@@ -394,7 +395,15 @@ class PhasedTrainStep(object):
         self._schedule(eager=True)
         return self.loss
 
-    def capture(self, warmup=3, keep_warmup_updates=False):
+    def _bn_momenta(self):
+        """BatchNorm momentum is a HOST scalar baked into the captured launches (F.batch_norm and the bq BN kernels take
+        it by value): the reference's BNMomentumScheduler (lib/pointnet2/pytorch_utils.py BNMomentumScheduler, stepped
+        once per epoch) would have no effect under replay, so step() compares this signature and re-captures"""
+        if self._bn_modules is None:
+            self._bn_modules = [m for m in self.model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+        return tuple(m.momentum for m in self._bn_modules)
+
+    def capture(self, warmup=3, keep_warmup_updates=False, _again=False):
         """`warmup` eager steps on the phase streams (autograd's AccumulateGrad nodes remember the stream they were
         created on -- they must be born on the stream that is later captured), then one graph per phase.  Graphs of
         one stream share a memory pool (they always replay in capture order); the two streams' pools are separate
@@ -406,7 +415,7 @@ class PhasedTrainStep(object):
         for s_ in (self.s_main, self.s_det, self.s_img, self.s_aux):
             s_.wait_stream(cur)
         self.e_done.record(self.s_main)
-        if self.prefetch:
+        if self.prefetch and not _again:  # (a re-capture keeps the geometry the previous step prefetched)
             with torch.cuda.stream(self.s_det):
                 self._geometry()  # the first step's own geometry
         snapshot = None
@@ -435,6 +444,7 @@ class PhasedTrainStep(object):
         pools = {"main": torch.cuda.graph_pool_handle(), "det": torch.cuda.graph_pool_handle(),
                  "aux": torch.cuda.graph_pool_handle()}
         self.graphs = {}
+        self._bn_sig = self._bn_momenta()
         for name, which, pool in self._ORDER:
             if self._skipped(name) or name in self.eager_phases:
                 continue
@@ -455,6 +465,11 @@ class PhasedTrainStep(object):
             return self.eager_step()
         if self.opt is not None and hasattr(self.opt, "sync_hyperparams"):
             self.opt.sync_hyperparams()  # LR schedulers act on param_groups; the captured step reads the pinned table
+        if self._bn_momenta() != self._bn_sig:
+            # a BN-momentum scheduler stepped (once per epoch in the reference): the value is baked into the graphs
+            torch.cuda.synchronize(self.dev)
+            self.graphs = None
+            self.capture(warmup=0, _again=True)
         self._schedule(eager=False)
         return self.loss
 

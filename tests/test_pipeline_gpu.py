@@ -269,3 +269,37 @@ def test_data_parallel_step_on_rccl_world_1_equals_the_plain_step(dev):
         assert sum(r.nbytes_on_wire() for r in reds.values()) == 4 * sum(p.numel() for p in model.parameters() if p.grad is not None)
     finally:
         dist.destroy_process_group()
+
+
+def test_bn_momentum_change_recaptures_the_graphs(dev):
+    """BatchNorm momentum is baked into the captured launches; after a BN-momentum scheduler step the phased
+    step must re-capture -- with momentum 0 the running statistics must stop moving, the loss keeps going down"""
+    import bench
+    from bridgeqa_amd import fusion_ops as ops
+    from bridgeqa_amd.optim import FusedAdamW
+    from bridgeqa_amd.pipeline import PhasedTrainStep
+    from bridgeqa_amd.pytorch_utils import BNMomentumScheduler
+    prev = ops.set_compute_dtype(torch.bfloat16)
+    try:
+        model = _small_model(dev)
+        batch = _batch(dev)
+        opt = FusedAdamW(model.parameters(), lr=1e-3)
+        pipe = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, opt, use_graphs=True).capture(warmup=3)
+        bn = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)][0]
+        sched = BNMomentumScheduler(model, lambda it: 0.5 if it < 1 else 0.0, last_epoch=-1)  # epoch 0: 0.5, then 0.0
+        graphs0 = pipe.graphs
+        means, losses = [], []
+        for it in range(7):
+            if it == 3:
+                sched.step(1)   # momentum -> 0.0
+            l = pipe.step()
+            pipe.wait()
+            torch.cuda.synchronize()
+            losses.append(l.item())
+            means.append(bn.running_mean.detach().clone())
+        assert pipe.graphs is not graphs0                      # re-captured
+        assert not torch.equal(means[0], means[1]) and not torch.equal(means[1], means[2])   # momentum 0.5: moving
+        assert torch.equal(means[3], means[2]) and torch.equal(means[5], means[2])           # momentum 0.0: frozen
+        assert all(x == x for x in losses) and losses[-1] < losses[0]
+    finally:
+        ops.set_compute_dtype(prev)

@@ -345,7 +345,9 @@ def main():
         # next_batch=batch: the benchmark replays ONE static synthetic batch, so "the next step's point clouds" are the
         # same buffers (a training loop passes the buffers its loader fills one step ahead)
         pipe = PhasedTrainStep(model, batch, det_loss, fusion_loss, opt, use_graphs=use_graph, next_batch=batch,
-                               eager_phases=("geometry",), reserve_cus=int(os.environ.get("BQ_RESERVE_CUS", "0")))
+                               eager_phases=("geometry",), reserve_cus=int(os.environ.get("BQ_RESERVE_CUS", "0")),
+                               split_fusion_tail=os.environ.get("BQ_SPLIT_TAIL") == "1",
+                               split_fusion_opt=os.environ.get("BQ_SPLIT_OPT") == "1")
         eager_step = pipe.eager_step
         reducers = {}
         if dp:

@@ -20,6 +20,7 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError("FusedAdamW: betas and eps must be the same for every parameter group (lr / weight_decay "
                              "may differ)")
         self._step_t = None
+        self.shadow_ids = set()  # parameters whose bf16 operand copy the update kernel writes (fusion_ops' refresh hook skips them)
         # one device table per SUBSET of the parameters (step(subset=...)): None = all parameters in one launch
         self._subs = {}
 
@@ -84,6 +85,7 @@ class FusedAdamW(torch.optim.Optimizer):
         tab = np.zeros(len(recs), dtype=dt)
         chunks = []
         sub["order"] = [(r[0], r[7]) for r in recs]   # (parameter, group): sync_hyperparams() rewrites lr / weight_decay
+        self.shadow_ids.update(id(r[0]) for r in recs if r[4] is not None)
         for i, (p, g, m, v, sh, lr, wd, _) in enumerate(recs):
             tab[i] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr() if sh is not None else 0,
                       p.numel(), lr, wd)

@@ -12,11 +12,11 @@ explicit stream with explicit events:
 
 Measured and NOT adopted (round 2, c3, per-phase HIP events, BQ_PIPE_TRACE=1): moving the fusion phase's tail -- its
 grouped weight-gradient GEMMs (2.3 ms) and the AdamW update of its 399 M parameters (2.0 ms) -- to a third stream under
-the image / detector backward (split_fusion_tail / split_fusion_opt below).  The fusion phase hands over 1.0 ms earlier,
-but the image backward stretches from 18.2 to 21.8 ms and the detector backward from 13.3 to 15.3 ms: a HBM-bound
-update next to GEMMs that stream their operands from HBM only moves the time (one dX GEMM that normally takes 73 us ran
-2.0 ms beside the AdamW kernel).  Step: 47.1 ms inline, 46.9 ms with the weight gradients on the side stream, 49.8 ms
-with the optimizer there too.  Both stay off.
+the image / detector backward (split_fusion_tail / split_fusion_opt below).  The fusion phase hands over 1.6 ms earlier
+and the final optimizer phase shrinks from 2.7 to 0.5 ms, but the image backward stretches from 17.9 to 21.8 ms and the
+detector backward from 13.4 to 15.9 ms: a HBM-bound update next to GEMMs that stream their operands from HBM only moves
+the time (one dX GEMM that normally takes 73 us ran 2.0 ms beside the AdamW kernel).  Step, same box: 46.5 ms inline,
+46.7 ms with the weight gradients on the side stream, 46.8 ms with the optimizer there too.  Both stay off.
 
 The fusion phase is ~1200 short kernels that leave most of the 256 CUs idle, and FPS / ball query / three-NN depend
 on coordinates only (no parameters): the sampling and grouping indices of the next batch are computed under it

@@ -1,22 +1,65 @@
 """The slice of `ScanQA.forward` that IS the hot path (reference models/qa_module.py:438-479 for the
 detector branch and :611-668 for the BLIP branch), with the reference's attribute names so its
 state-dict keys are a subset of ScanQA's: detection_backbone.*, voting_net.*, proposal_net.*,
-object_feat_linear.*, blip_model.*.  The rest of ScanQA (language/MCAN heads, losses, reference
-head) is the caller on either side of the path -- SURVEY.md §8f rank 1, not built here.
+object_feat_linear.*, blip_model.*.
+
+Round 2 widened it to the rest of the VQA branch: the language-classification head and the
+reference-object head that follow the fusion (qa_module.py:735-754 over the modules of :234-249: lang_cls, object_cls,
+linear_blip_to_object, dec_list_qo; enc_list_o exists for state-dict parity only -- the reference never calls it),
+switched on by the reference's own flags use_lang_cls / use_reference (default off, as in ScanQA.__init__).  The
+non-BLIP branch (LSTM language module, MCAN fusion backbone, AttFlat heads: qa_module.py:496-590) stays out.
 """
 import numpy as np
 import torch
 import torch.nn as nn
 
 from .backbone_module import Pointnet2Backbone
+from .mcan_module import SA, SGA
 from .proposal_module import ProposalModule
 from .voting_module import VotingModule
+
+
+def build_qa_heads(module, hidden_size, blip_enc_size, num_object_class, mcan_num_layers=2, mcan_num_heads=8,
+                   mcan_pdrop=0.1):
+    """registers, on `module`, the heads ScanQA.__init__ creates under use_blip (qa_module.py:223-249), same names and
+    registration order: enc_list_o, lang_cls, object_cls, linear_blip_to_object, dec_list_qo"""
+    module.enc_list_o = nn.ModuleList([SA(hidden_size, mcan_num_heads, mcan_pdrop) for _ in range(mcan_num_layers)])
+    module.lang_cls = nn.Sequential(nn.Linear(blip_enc_size, hidden_size), nn.GELU(), nn.Dropout(0.1),
+                                    nn.Linear(hidden_size, num_object_class))
+    module.object_cls = nn.Sequential(nn.Linear(hidden_size, hidden_size), nn.GELU(), nn.Dropout(0.1),
+                                      nn.Linear(hidden_size, 1))
+    module.linear_blip_to_object = nn.Linear(blip_enc_size, hidden_size)
+    module.dec_list_qo = nn.ModuleList([SGA(hidden_size, mcan_num_heads, mcan_pdrop) for _ in range(mcan_num_layers)])
+    return module
+
+
+def qa_heads_forward(module, data_dict, object_feat, object_mask, fused_feat, fused_mask, use_lang_cls, use_reference):
+    """qa_module.py:735-754.  object_feat (B,K,hidden); object_mask (B,1,1,K) bool, True = NOT an object; fused_feat
+    (B,L,blip width) and fused_mask (B,L), 1 = real token, from BLIP_VQA3D.  Writes lang_scores (B, classes) and
+    cluster_ref (B,K).  Kept as the reference has it: the decoder's self-attention receives ~object_mask, i.e. it hides
+    the VALID proposals from each other (qa_module.py:750) -- parity first; flagged here, not "fixed"."""
+    fused_feat = fused_feat.float()
+    if use_lang_cls:
+        data_dict["lang_scores"] = module.lang_cls(fused_feat[:, 0, :])
+    if use_reference:
+        y = module.linear_blip_to_object(fused_feat)
+        y_mask = fused_mask.unsqueeze(1).unsqueeze(2).bool()
+        x = object_feat.float()
+        for dec in module.dec_list_qo:
+            x = dec(x, y, ~object_mask, ~y_mask, att_pdrop=None, att_drop_topk=None)
+        conf = x * data_dict["objectness_scores"].max(2)[1].float().unsqueeze(2)
+        data_dict["cluster_ref"] = module.object_cls(conf).squeeze(-1)
+    return data_dict
 
 
 class ScanQAHotPath(nn.Module):
     def __init__(self, input_feature_dim=132, num_proposal=256, vote_factor=1, seed_feat_dim=256, proposal_size=128,
                  vote_radius=0.3, vote_nsample=16, hidden_size=256, num_class=18, num_heading_bin=1,
-                 num_size_cluster=18, mean_size_arr=None, use_blip=True, blip_kwargs=None):
+                 num_size_cluster=18, mean_size_arr=None, use_blip=True, blip_kwargs=None, use_lang_cls=False,
+                 use_reference=False, qa_heads=None, mcan_num_layers=2, mcan_num_heads=8, mcan_pdrop=0.1):
+        """use_lang_cls / use_reference: ScanQA's flags for the two heads after the fusion; qa_heads: create their
+        modules (default: iff one of the flags is set; ScanQA itself always creates them under use_blip -- pass True to
+        load a reference checkpoint with strict=True)"""
         super().__init__()
         if mean_size_arr is None:
             mean_size_arr = np.ones((num_size_cluster, 3))
@@ -33,6 +76,10 @@ class ScanQAHotPath(nn.Module):
                       scene_feature_position="paralleltwin")
             kw.update(blip_kwargs or {})
             self.blip_model = BLIP_VQA3D(**kw)
+            self.use_lang_cls, self.use_reference = use_lang_cls, use_reference
+            if qa_heads if qa_heads is not None else (use_lang_cls or use_reference):
+                build_qa_heads(self, hidden_size, self.blip_model.text_encoder.config.hidden_size, num_class,
+                               mcan_num_layers, mcan_num_heads, mcan_pdrop)
 
     def detect(self, data_dict):
         data_dict = self.detection_backbone(data_dict)
@@ -65,8 +112,12 @@ class ScanQAHotPath(nn.Module):
                               answer=data_dict["answer"], train=train, k_test=256, data_dict=data_dict)
         if train:
             data_dict["blip_loss"], data_dict["fused_feat"], data_dict["fused_mask"] = out
+            data_dict["decoder_loss"] = data_dict["blip_loss"]  # the name lib/loss_helper.py reads (qa_module.py:696)
         else:
             data_dict["fused_feat"], data_dict["answer_scores"], data_dict["fused_mask"] = out
+        if self.use_lang_cls or self.use_reference:
+            qa_heads_forward(self, data_dict, object_feat, object_mask.unsqueeze(1).unsqueeze(2), data_dict["fused_feat"],
+                             data_dict["fused_mask"], self.use_lang_cls, self.use_reference)
         return data_dict
 
     def forward(self, data_dict):

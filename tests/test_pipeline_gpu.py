@@ -303,3 +303,50 @@ def test_bn_momentum_change_recaptures_the_graphs(dev):
         assert all(x == x for x in losses) and losses[-1] < losses[0]
     finally:
         ops.set_compute_dtype(prev)
+
+
+def test_hot_path_with_qa_heads_and_full_get_loss(dev):
+    """SURVEY §8f rank 1 wired end to end: ScanQAHotPath(use_lang_cls, use_reference) writes lang_scores / cluster_ref /
+    decoder_loss, loss_helper.get_loss (reference / language / answer + detection terms, the reference's weights of
+    scripts/train.py) consumes them, one backward reaches the new heads, the detector and the fusion; bf16 kernel path"""
+    import bench
+    from bridgeqa_amd import fusion_ops as ops
+    from bridgeqa_amd.hotpath import ScanQAHotPath
+    from bridgeqa_amd.loss_helper import get_loss
+    prev = ops.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(0)
+        m = ScanQAHotPath(input_feature_dim=4, use_blip=True, blip_kwargs=dict(image_size=64), use_lang_cls=True,
+                          use_reference=True).to(dev)
+        m.train()
+        keys = set(m.state_dict())
+        for k in ("lang_cls.0.weight", "object_cls.3.bias", "linear_blip_to_object.weight",
+                  "dec_list_qo.1.mhatt2.linear_merge.weight", "dec_list_qo.0.norm3.a_2", "enc_list_o.1.ffn.mlp.fc.linear.bias"):
+            assert k in keys, k   # ScanQA's own names (qa_module.py:223-249)
+        batch = _batch(dev)
+        B = batch["point_clouds"].shape[0]
+        dd = m(dict(batch))
+        assert dd["lang_scores"].shape == (B, 18) and dd["cluster_ref"].shape == (B, 256) and "decoder_loss" in dd
+        g = torch.Generator().manual_seed(1)
+        dd["ref_center_label"] = dd["center_label"][:, 0]
+        dd["ref_heading_class_label"] = dd["heading_class_label"][:, 0]
+        dd["ref_heading_residual_label"] = dd["heading_residual_label"][:, 0]
+        dd["ref_size_class_label"] = dd["size_class_label"][:, 0]
+        dd["ref_size_residual_label"] = dd["size_residual_label"][:, 0]
+        dd["ref_obj_mask"] = torch.ones(B, device=dev)
+        dd["object_cat"] = torch.randint(0, 18, (B,), generator=g).to(dev)
+        weights = dict(bench.DET_LOSS_WEIGHTS, ref_loss=0.1, lang_loss=0.1, answer_loss=1.0)
+        loss, dd = get_loss(dd, bench.det_config(), detection=True, use_reference=True, use_lang_classifier=True,
+                            use_answer=True, loss_weights=weights)
+        assert torch.isfinite(loss) and dd["cluster_labels"].sum().item() == B      # one referred proposal per scene
+        assert abs(dd["answer_loss"].item() - dd["blip_loss"].item()) < 1e-6
+        loss.backward()
+        for name in ("lang_cls.0.weight", "object_cls.0.weight", "dec_list_qo.0.mhatt2.linear_q.weight",
+                     "linear_blip_to_object.weight", "object_feat_linear.0.weight",
+                     "detection_backbone.sa1.mlp_module.layer0.conv.weight",
+                     "blip_model.text_encoder.encoder.layer.0.attention.self.query.weight"):
+            p = dict(m.named_parameters())[name]
+            assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0, name
+        assert dict(m.named_parameters())["enc_list_o.0.mhatt.linear_q.weight"].grad is None   # never called upstream either
+    finally:
+        ops.set_compute_dtype(prev)

@@ -18,7 +18,8 @@ def timeit(f, n=50):
     a.record(); g.replay(); b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
 
-for M, N, K in ((640, 768, 768), (640, 2304, 768), (640, 3072, 768), (640, 768, 3072), (160, 768, 768), (160, 768, 3072)):
+for M, N, K in ((640, 768, 768), (640, 2304, 768), (640, 3072, 768), (640, 768, 3072), (160, 768, 768), (160, 768, 3072),
+                (16400, 768, 768), (16400, 2304, 768), (16400, 3072, 768), (16400, 768, 3072)):
     x = torch.randn(M, K, device="cuda").bfloat16()
     w = torch.randn(N, K, device="cuda").bfloat16()
     wt = w.t().contiguous()

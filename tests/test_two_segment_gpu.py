@@ -122,13 +122,6 @@ def test_twin_encoder_hoisted_two_segment_wiring_on_gpu(dev):
     assert worst[0] < 6e-2, worst
 
 
-import os
-
-
-@pytest.mark.skipif(os.environ.get("BQ_TEST_TWO_SEGMENT_PIPELINE") != "1",
-                    reason="graph-replay training with the opt-in two-segment path: written when the round's GPU "
-                           "minutes were spent, not yet run -- BQ_TEST_TWO_SEGMENT_PIPELINE=1 runs it (first step of the "
-                           "next round, before BQ_TWO_SEGMENT_KV becomes the default)")
 def test_phased_pipeline_trains_with_two_segment_path(dev):
     """tests/test_pipeline_gpu.py::test_phased_step_graph_replay_trains with med._TWO_SEGMENT on: the captured fusion
     phase (hoisted projection, gradient sink allocated inside the capture, FusedAdamW writing the re-registered
@@ -141,11 +134,16 @@ def test_phased_pipeline_trains_with_two_segment_path(dev):
     prev = ops.set_compute_dtype(torch.bfloat16)
     flag = med._TWO_SEGMENT
     med._TWO_SEGMENT = True
+    prev_overlap = ops.set_overlap(False)   # the hoisted path is taken on the single-stream fusion graph only
+    built = []
+    init = ops.HoistedKV.__init__
+    ops.HoistedKV.__init__ = lambda self, *a, **k: (built.append(1), init(self, *a, **k))[1]
     try:
         model = _small_model(dev)
         batch = _batch(dev)
         opt = FusedAdamW(model.parameters(), lr=1e-3)
         pipe = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, opt, use_graphs=True).capture(warmup=3)
+        assert len(built) >= 2   # one hoisted projection per stream and forward: the two-segment path really ran
         w = model.blip_model.text_encoder.encoder.layer[0].crossattention.self.value.weight
         w0 = w.detach().clone()
         losses = []
@@ -158,5 +156,7 @@ def test_phased_pipeline_trains_with_two_segment_path(dev):
         assert not torch.equal(w0, w.detach())
         assert min(losses[-3:]) < 0.9 * losses[0], losses
     finally:
+        ops.HoistedKV.__init__ = init
+        ops.set_overlap(prev_overlap)
         med._TWO_SEGMENT = flag
         ops.set_compute_dtype(prev)

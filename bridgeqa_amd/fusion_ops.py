@@ -280,7 +280,8 @@ def _dw_db(g2, x2, need_dw, need_db):
 # 256 x 256 with the full 16400-row contraction each -- instead of 48 launches of 27-36 tiles) and ALL bias gradients
 # with one grouped column-sum launch.  MI355X has the HBM for it: the parked dY of config c3 are 2.7 GB.
 _DEFER = [None]
-_BIG_ROWS = 1024  # contractions at least this long run on the 256 x 256 kernel
+_BIG_ROWS = 1024  # contractions at least this long run on the 256 x 256 kernel (measured: sending the text side's 160-640-row
+                  # contractions there too costs +1.5 ms per c3 step -- its pipeline fill and 256 KB fp32 tile epilogue dominate)
 
 
 def begin_deferred_wgrad():

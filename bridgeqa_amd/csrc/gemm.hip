@@ -458,12 +458,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
 // ======================================================================================================================
 namespace bq {
 
-template <int BJ, bool P_XC, bool Q_XC, int EPI, bool OUT_F32>
+// KT = K tiles per pipeline step (1 or 2): with KT = 2 a step stages, waits for and consumes TWO 64-wide K tiles between
+// barriers -- half the barriers / counted waits of a long contraction (text side: K = 2304 / 3072 at M <= 640 rows, a
+// latency chain of 36-48 steps otherwise).
+template <int BJ, bool P_XC, bool Q_XC, int EPI, bool OUT_F32, int KT = 1>
 __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
   static_assert(BJ == 64 || (BJ == 32 && !Q_XC), "32-wide j tiles only for K-contiguous Q");
+  static_assert(KT == 1 || KT == 2, "one or two K tiles per step");
   constexpr int QF = BJ / 32;               // 16-wide j fragments per wave
-  constexpr int Q_UNIT = BJ * 128;          // bytes of the Q image per stage
-  constexpr int STAGE = 8192 + Q_UNIT;
+  constexpr int Q_UNIT = BJ * 128;          // bytes of the Q image per K tile
+  constexpr int TILE_BYTES = 8192 + Q_UNIT;
+  constexpr int STAGE = KT * TILE_BYTES;
   // NS LDS stages, NS - 1 K tiles in flight.  MEASURED (profiles/r02_gemm_bench_v2.json): 5 stages instead of 3 change
   // nothing for the forward / dX forms (a K tile costs ~0.24 us either way: the loop is bound by the ISSUE of its 3-4
   // LDS-DMA instructions per wave, ~100 cycles each, not by memory latency) and halve the weight-gradient form
@@ -512,23 +517,26 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
     vp[d] += (unsigned)kt0 * p_step;
     vq[d] += (unsigned)kt0 * q_step;
   }
-  constexpr int NDMA = 2 + (BJ == 64 ? 2 : 1);  // LDS-DMAs per wave per stage
+  constexpr int NDMA = KT * (2 + (BJ == 64 ? 2 : 1));  // LDS-DMAs per wave per step
 
-  auto stage = [&](int kt) {
-    const bool live = kt < nkt;
-    const unsigned base = (unsigned)((kt % NS) * STAGE);
+  auto stage = [&](int step) {
 #pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_void_t *)(smem + base + (wave * 2 + d) * 1024), 16,
-                                               live ? vp[d] : 0x80000000u, 0, 0, 0);
-      vp[d] += p_step;
-    }
+    for (int h = 0; h < KT; ++h) {
+      const bool live = step * KT + h < nkt;
+      const unsigned base = (unsigned)((step % NS) * STAGE + h * TILE_BYTES);
 #pragma unroll
-    for (int d = 0; d < (BJ == 64 ? 2 : 1); ++d) {
-      const int blk = (BJ == 64) ? wave * 2 + d : wave;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_void_t *)(smem + base + 8192 + blk * 1024), 16,
-                                               live ? vq[d] : 0x80000000u, 0, 0, 0);
-      vq[d] += q_step;
+      for (int d = 0; d < 2; ++d) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_void_t *)(smem + base + (wave * 2 + d) * 1024), 16,
+                                                 live ? vp[d] : 0x80000000u, 0, 0, 0);
+        vp[d] += p_step;
+      }
+#pragma unroll
+      for (int d = 0; d < (BJ == 64 ? 2 : 1); ++d) {
+        const int blk = (BJ == 64) ? wave * 2 + d : wave;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_void_t *)(smem + base + 8192 + blk * 1024), 16,
+                                                 live ? vq[d] : 0x80000000u, 0, 0, 0);
+        vq[d] += q_step;
+      }
     }
   };
 
@@ -549,31 +557,37 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
 
 #pragma unroll
   for (int p = 0; p < NS - 1; ++p) stage(p);
-  for (int kt = 0; kt < nkt; ++kt) {
-    // stage kt has landed for this wave (stages kt+1 .. kt+NS-2 may still be in flight); after the barrier: for every
-    // wave, and every wave has finished reading the buffer that stage kt+NS-1 is about to overwrite
+  const int nsteps = (nkt + KT - 1) / KT;
+  for (int step = 0; step < nsteps; ++step) {
+    // step `step` has landed for this wave (steps step+1 .. step+NS-2 may still be in flight); after the barrier: for
+    // every wave, and every wave has finished reading the buffer that step step+NS-1 is about to overwrite
     static_assert(NS == 3, "the counted waits below are (NS - 2) * NDMA");
-    if (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     BQ_BARRIER();
-    stage(kt + NS - 1);
-    const unsigned char *buf = smem + (kt % NS) * STAGE;
-    bf16x8 fa[2][2], fb[QF][2];
+    stage(step + NS - 1);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag<P_XC>(buf, wr * 2 + a, kk, kc_base, xc_base);
-#pragma unroll
-    for (int b = 0; b < QF; ++b)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) fb[b][kk] = read_frag<Q_XC>(buf + 8192, wc * QF + b, kk, kc_base, xc_base);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    for (int h = 0; h < KT; ++h) {  // (a K tile past the end was staged as zeros: it adds nothing)
+      const unsigned char *buf = smem + (step % NS) * STAGE + h * TILE_BYTES;
+      bf16x8 fa[2][2], fb[QF][2];
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < QF; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][kk], fb[b][kk], acc[a][b], 0, 0, 0);
+        for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag<P_XC>(buf, wr * 2 + a, kk, kc_base, xc_base);
+#pragma unroll
+      for (int b = 0; b < QF; ++b)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fb[b][kk] = read_frag<Q_XC>(buf + 8192, wc * QF + b, kk, kc_base, xc_base);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < QF; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][kk], fb[b][kk], acc[a][b], 0, 0, 0);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -915,14 +929,29 @@ __global__ __launch_bounds__(256) void colsum_grouped_kernel(const ColsumArgs ar
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
+// long_k: every problem of the launch has >= 12 K tiles and the launch is small (host decision in launch_gemm):
+// the bf16-output small-tile forms then run two K tiles per pipeline step
 template <bool P_XC, bool Q_XC, int EPI, bool OUT_F32>
-static int launch_variant(const GemmArgs &ga, int tile, hipStream_t st) {
+static int launch_variant(const GemmArgs &ga, int tile, hipStream_t st, bool long_k = false) {
+  constexpr bool KT2_OK = !OUT_F32 && !Q_XC && EPI != EPI_BIAS_CE;
   if (tile == 256) {
     hipLaunchKernelGGL((gemm256_kernel<P_XC, Q_XC, EPI, OUT_F32>), dim3(ga.total_tiles), dim3(512), 0, st, ga);
   } else if (tile == 64) {
+    if constexpr (KT2_OK) {
+      if (long_k) {
+        hipLaunchKernelGGL((gemm64_kernel<64, P_XC, Q_XC, EPI, OUT_F32, 2>), dim3(ga.total_tiles), dim3(256), 0, st, ga);
+        return 0;
+      }
+    }
     hipLaunchKernelGGL((gemm64_kernel<64, P_XC, Q_XC, EPI, OUT_F32>), dim3(ga.total_tiles), dim3(256), 0, st, ga);
   } else {
     if constexpr (!Q_XC) {
+      if constexpr (KT2_OK) {
+        if (long_k) {
+          hipLaunchKernelGGL((gemm64_kernel<32, P_XC, Q_XC, EPI, OUT_F32, 2>), dim3(ga.total_tiles), dim3(256), 0, st, ga);
+          return 0;
+        }
+      }
       hipLaunchKernelGGL((gemm64_kernel<32, P_XC, Q_XC, EPI, OUT_F32>), dim3(ga.total_tiles), dim3(256), 0, st, ga);
     } else {
       return -1;
@@ -933,10 +962,14 @@ static int launch_variant(const GemmArgs &ga, int tile, hipStream_t st) {
 
 static int launch_gemm(const GemmArgs &ga, int flags, int epi, int tile, hipStream_t st) {
   const bool pxc = flags & BQ_GEMM_P_XC, qxc = flags & BQ_GEMM_Q_XC, f32 = flags & BQ_GEMM_OUT_F32;
+  // measured on the c3 step (A/B in one call): never 46.2 ms, from 24 K tiles 45.5-45.9, from 12 K tiles 45.3-45.6
+  static const int long_k_tiles = getenv("BQ_GEMM_LONGK") ? atoi(getenv("BQ_GEMM_LONGK")) : 12;  // 0 = never
+  bool long_k = long_k_tiles > 0 && tile != 256 && ga.total_tiles <= 2048;
+  for (int k = 0; k < ga.n; ++k) long_k = long_k && ga.p[k].Kc >= 64 * long_k_tiles;
   if (!pxc && !qxc && !f32) {
-    if (epi == EPI_NONE) return launch_variant<false, false, EPI_NONE, false>(ga, tile, st);
-    if (epi == EPI_BIAS) return launch_variant<false, false, EPI_BIAS, false>(ga, tile, st);
-    if (epi == EPI_BIAS_GELU) return launch_variant<false, false, EPI_BIAS_GELU, false>(ga, tile, st);
+    if (epi == EPI_NONE) return launch_variant<false, false, EPI_NONE, false>(ga, tile, st, long_k);
+    if (epi == EPI_BIAS) return launch_variant<false, false, EPI_BIAS, false>(ga, tile, st, long_k);
+    if (epi == EPI_BIAS_GELU) return launch_variant<false, false, EPI_BIAS_GELU, false>(ga, tile, st, long_k);
     if (epi == EPI_BIAS_CE && tile == 256) {
       hipLaunchKernelGGL((gemm256_kernel<false, false, EPI_BIAS_CE, false>), dim3(ga.total_tiles), dim3(512), 0, st, ga);
       return 0;
@@ -944,8 +977,8 @@ static int launch_gemm(const GemmArgs &ga, int flags, int epi, int tile, hipStre
   } else if (pxc && !qxc && f32) {
     if (epi == EPI_NONE && tile != 256) return launch_variant<true, false, EPI_NONE, true>(ga, tile, st);
   } else if (pxc && !qxc && !f32) {
-    if (epi == EPI_NONE) return launch_variant<true, false, EPI_NONE, false>(ga, tile, st);
-    if (epi == EPI_DGELU) return launch_variant<true, false, EPI_DGELU, false>(ga, tile, st);
+    if (epi == EPI_NONE) return launch_variant<true, false, EPI_NONE, false>(ga, tile, st, long_k);
+    if (epi == EPI_DGELU) return launch_variant<true, false, EPI_DGELU, false>(ga, tile, st, long_k);
   } else if (pxc && qxc && f32) {
     if (epi == EPI_NONE) return launch_variant<true, true, EPI_NONE, true>(ga, tile, st);
   }

@@ -219,3 +219,19 @@ def test_lm_head_cross_entropy_vs_torch(dev):
             assert rel(b.grad, br.grad) < 2e-2, rel(b.grad, br.grad)
     finally:
         ops.set_compute_dtype(prev)
+
+
+@pytest.mark.parametrize("M,N,K", [(640, 768, 3072), (160, 768, 3072), (200, 264, 1600), (320, 768, 2304), (77, 128, 1536 + 64)])
+@pytest.mark.parametrize("tile", [64, 32])
+def test_long_contraction_two_k_tiles_per_step(dev, M, N, K, tile):
+    """the small-tile kernels' KT = 2 instantiation (two K tiles per pipeline step, chosen by the launcher when every
+    contraction of a small launch has >= 24 K tiles): forward with bias, forward without, and the input-gradient form;
+    odd K-tile counts (1600 = 25 tiles, 1600 = 1536 + 64) exercise the zero-staged half step at the end"""
+    from bridgeqa_amd import _ext
+    x, w = _rand((M, K), dev, 21), _rand((N, K), dev, 22, 0.05)
+    b = torch.randn(N, device=dev)
+    _check(_ext.gemm_fwd(x, w, b, tile=tile), x.float() @ w.float().t() + b)
+    _check(_ext.gemm_fwd(x, w, None, tile=tile), x.float() @ w.float().t())
+    # dX = dY W with the contraction over N: a long one needs a wide layer
+    dy, w2 = _rand((M, K), dev, 23), _rand((K, N), dev, 24, 0.05)      # dY (M, K_out = K), W (K_out, N_in = N)
+    _check(_ext.gemm_dx(dy, w2, tile=tile), dy.float() @ w2.float())

@@ -464,7 +464,7 @@ namespace bq {
 template <int BJ, bool P_XC, bool Q_XC, int EPI, bool OUT_F32, int KT = 1>
 __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
   static_assert(BJ == 64 || (BJ == 32 && !Q_XC), "32-wide j tiles only for K-contiguous Q");
-  static_assert(KT == 1 || KT == 2, "one or two K tiles per step");
+  static_assert(KT == 1 || KT == 2 || (KT == 4 && BJ == 32), "one, two or (32-row tiles) four K tiles per step");
   constexpr int QF = BJ / 32;               // 16-wide j fragments per wave
   constexpr int Q_UNIT = BJ * 128;          // bytes of the Q image per K tile
   constexpr int TILE_BYTES = 8192 + Q_UNIT;
@@ -562,7 +562,8 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
     // step `step` has landed for this wave (steps step+1 .. step+NS-2 may still be in flight); after the barrier: for
     // every wave, and every wave has finished reading the buffer that step step+NS-1 is about to overwrite
     static_assert(NS == 3, "the counted waits below are (NS - 2) * NDMA");
-    if (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (NDMA == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -947,6 +948,14 @@ static int launch_variant(const GemmArgs &ga, int tile, hipStream_t st, bool lon
   } else {
     if constexpr (!Q_XC) {
       if constexpr (KT2_OK) {
+        // four K tiles per step (144 KB of LDS: one workgroup per CU) for launches of <= 512 tiles: c3 45.05 -> 44.57 ms
+        static const int k4_tiles = getenv("BQ_GEMM_K4") ? atoi(getenv("BQ_GEMM_K4")) : 12;
+        bool k4 = long_k && k4_tiles > 0 && ga.total_tiles <= 512;
+        for (int k = 0; k < ga.n; ++k) k4 = k4 && ga.p[k].Kc >= 64 * k4_tiles;
+        if (k4) {
+          hipLaunchKernelGGL((gemm64_kernel<32, P_XC, Q_XC, EPI, OUT_F32, 4>), dim3(ga.total_tiles), dim3(256), 0, st, ga);
+          return 0;
+        }
         if (long_k) {
           hipLaunchKernelGGL((gemm64_kernel<32, P_XC, Q_XC, EPI, OUT_F32, 2>), dim3(ga.total_tiles), dim3(256), 0, st, ga);
           return 0;

@@ -53,6 +53,8 @@ _lib.bq_attn_fwd.argtypes = [_vp] * 6 + [_i] * 5 + [_l] * 9 + [_f, _f, _u, _vp, 
 _lib.bq_attn_fwd.restype = ctypes.c_int
 _lib.bq_attn_bwd.argtypes = [_vp] * 11 + [_i] * 5 + [_l] * 9 + [_f, _f, _u, _vp, _i, _vp]
 _lib.bq_attn_bwd.restype = ctypes.c_int
+_lib.bq_attn_probs.argtypes = [_vp] * 5 + [_i] * 5 + [_l] * 6 + [_f, _f, _u, _vp, _i, _vp]
+_lib.bq_attn_probs.restype = ctypes.c_int
 _lib.bq_drop_add_ln_fwd.argtypes = [_vp] * 9 + [_i, _i, _f, _f, _f, _i, _u, _vp, _vp]
 _lib.bq_drop_add_ln_fwd.restype = ctypes.c_int
 _lib.bq_drop_add_ln_bwd.argtypes = [_vp] * 10 + [_i, _i, _f, _f, _f, _i, _u, _vp, _vp]
@@ -350,6 +352,21 @@ def attn_fwd(q, k, v, scale, mask_log2=None, p_drop=0.0, seed=0, seed_tensor=Non
                                 *os_, float(scale), float(p_drop), int(seed) & 0xFFFFFFFF, _p(seed_tensor),
                                 int(bool(causal)), _stream()), "attn_fwd")
     return out, lse
+
+
+def attn_probs(q, k, lse, scale, mask_log2=None, p_drop=0.0, seed=0, seed_tensor=None, causal=False):
+    """the softmax probabilities of the attn_fwd call that produced `lse`: f32 (B, H, Lq, Lk).  p_drop = 0 (default): the
+    map BEFORE dropout, which is what the reference returns (med.py:202,223); with the forward's p_drop / seed: the dropped
+    map the context was computed from"""
+    B, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    with torch.cuda.device(q.device):
+        P = torch.empty(B, H, Lq, Lk, dtype=torch.float32, device=q.device)
+        qs, ks = _bhd_strides(q), _bhd_strides(k)
+        _check(_lib.bq_attn_probs(_p(q), _p(k), _p(lse), _p(mask_log2), _p(P), B, H, Lq, Lk, _pad64(Lk), *qs, *ks,
+                                  float(scale), float(p_drop), int(seed) & 0xFFFFFFFF, _p(seed_tensor), int(bool(causal)),
+                                  _stream()), "attn_probs")
+    return P
 
 
 def attn_bwd(q, k, v, out, lse, grad_out, scale, dq, dk, dv, mask_log2=None, p_drop=0.0, seed=0, seed_tensor=None,

@@ -1224,3 +1224,66 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_bwd2(
                      (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)dO, LSE, DELTA, (__bf16 *)dK, (__bf16 *)dV, dm);
   return check_launch("attn_bwd2_dkv");
 }
+
+// ---- attention probabilities on request ---------------------------------------------------------------------------------
+// The reference returns the softmax matrix of a layer (before dropout) when asked (output_attentions, models/med.py:202,223;
+// BLIP_VQA3D stores the last level's cross-attention maps in data_dict, blip_vqa_3d.py:262-281).  The fused kernels
+// never form it; this kernel rebuilds it from Q, K and the forward's LSE: P[b][h][q][k] = exp2(c * q.k + mask[k] - LSE[q]),
+// fp32 (B, H, Lq, Lk); with a drop threshold also the dropped map (x 1/(1-p) where the forward's hash kept the entry, 0
+// elsewhere).  Thread = one key; the queries of a (batch, head) go through LDS 32 rows at a time.  A few MB for the
+// text shapes it exists for.
+__global__ __launch_bounds__(256) void attn_probs_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+                                                         const float *__restrict__ LSE, float *__restrict__ P, AttnDims dm) {
+  __shared__ float s_q[32][64];
+  __shared__ float s_l[32];
+  const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
+  const int key = blockIdx.x * 256 + threadIdx.x;
+  const bool live = key < dm.Lk;
+  const float c = dm.scale * 1.4426950408889634f;
+  const unsigned seed = eff_seed(dm);
+  float kr[64];
+  {
+    const __bf16 *kp = K + b * dm.k_bs + hd * dm.k_hs + (long)min(key, dm.Lk - 1) * dm.k_rs;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8 *>(kp + 8 * ch);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kr[8 * ch + j] = (float)v[j];
+    }
+  }
+  const float mk = (dm.mask && live) ? dm.mask[(long)b * dm.Lkp + key] : 0.0f;
+  for (int q0 = 0; q0 < dm.Lq; q0 += 32) {
+    const int nq = min(32, dm.Lq - q0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < nq * 64; e += 256)
+      s_q[e >> 6][e & 63] = (float)Q[b * dm.q_bs + hd * dm.q_hs + (long)(q0 + (e >> 6)) * dm.q_rs + (e & 63)];
+    if (threadIdx.x < nq) s_l[threadIdx.x] = LSE[(long)bh * dm.Lq + q0 + threadIdx.x];
+    __syncthreads();
+    if (!live) continue;
+    for (int r = 0; r < nq; ++r) {
+      float dot = 0.0f;
+#pragma unroll
+      for (int d = 0; d < 64; ++d) dot = __builtin_fmaf(s_q[r][d], kr[d], dot);
+      const int q = q0 + r;
+      float p = __builtin_amdgcn_exp2f(__builtin_fmaf(dot, c, mk) - s_l[r]);
+      if (dm.causal && key > q) p = 0.0f;
+      if (dm.drop_thresh) p = drop_keep(seed, bh, q, key, dm.drop_thresh) ? p * dm.inv_keep : 0.0f;
+      P[((long)bh * dm.Lq + q) * dm.Lk + key] = p;
+    }
+  }
+}
+
+extern "C" __attribute__((visibility("default"))) int bq_attn_probs(
+    const void *Q, const void *K, const float *LSE, const float *mask, float *P, int B, int H, int Lq, int Lk, int Lkp,
+    long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, float scale, float p_drop, unsigned seed,
+    const unsigned *seed_ptr, int causal, void *stream) {
+  BQ_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && Q && K && LSE && P, BQ_EINVAL, "attn_probs: bad arguments");
+  BQ_REQUIRE(!mask || (Lkp >= Lk), BQ_EINVAL, "attn_probs: mask row shorter than Lk");
+  BQ_REQUIRE((k_rs % 8) == 0 && (k_hs % 8) == 0, BQ_EINVAL, "attn_probs: K rows must be 16-byte aligned");
+  BQ_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, BQ_EINVAL, "attn_probs: bad dropout probability");
+  AttnDims dm{B, H, Lq, Lk, 0, Lkp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, 0, 0, 0, mask, scale,
+              1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr, causal ? 1 : 0};
+  hipLaunchKernelGGL(attn_probs_kernel, dim3((Lk + 255) / 256, B * H), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16 *)Q, (const __bf16 *)K, LSE, P, dm);
+  return check_launch("attn_probs");
+}

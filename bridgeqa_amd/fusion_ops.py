@@ -759,50 +759,58 @@ class _PackedAttention(torch.autograd.Function):
     way, so the QKV projection's backward needs no concat."""
 
     @staticmethod
-    def forward(ctx, qkv, scale, mask_log2, p_drop, causal=False):
+    def forward(ctx, qkv, scale, mask_log2, p_drop, causal=False, want_probs=False):
         from . import _ext
         seed, st = _seed_args(p_drop, qkv.device)
         out, lse = _ext.attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], scale, mask_log2, p_drop, seed, st, causal)
         ctx.save_for_backward(qkv, out, lse, mask_log2 if mask_log2 is not None else qkv.new_empty(0),
                               st if st is not None else qkv.new_empty(0))
         ctx.cfg = (scale, p_drop, seed, mask_log2 is not None, st is not None, causal)
+        if want_probs:  # the softmax map BEFORE dropout (what med.py:202,223 returns), rebuilt from the LSE; DETACHED
+            probs = _ext.attn_probs(qkv[:, :, 0], qkv[:, :, 1], lse, scale, mask_log2, causal=causal)
+            ctx.mark_non_differentiable(probs)
+            return out, probs
         return out
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, _gp=None):
         from . import _ext
         qkv, out, lse, mask_log2, st = ctx.saved_tensors
         scale, p_drop, seed, has_mask, has_st, causal = ctx.cfg
         dqkv = torch.empty_like(qkv)
-        _ext.attn_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out, lse, grad_out, scale,
+        _ext.attn_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out, lse, grad_out.contiguous(), scale,
                       dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], mask_log2 if has_mask else None, p_drop, seed,
                       st if has_st else None, causal)
-        return dqkv, None, None, None, None
+        return dqkv, None, None, None, None, None
 
 
 class _QKVAttention(torch.autograd.Function):
     """Cross-attention with q (B, Lq, H, 64) and a fused K/V tensor kv (B, Lk, 2, H, 64); dkv comes back packed."""
 
     @staticmethod
-    def forward(ctx, q, kv, scale, mask_log2, p_drop):
+    def forward(ctx, q, kv, scale, mask_log2, p_drop, want_probs=False):
         from . import _ext
         seed, st = _seed_args(p_drop, q.device)
         out, lse = _ext.attn_fwd(q, kv[:, :, 0], kv[:, :, 1], scale, mask_log2, p_drop, seed, st)
         ctx.save_for_backward(q, kv, out, lse, mask_log2 if mask_log2 is not None else q.new_empty(0),
                               st if st is not None else q.new_empty(0))
         ctx.cfg = (scale, p_drop, seed, mask_log2 is not None, st is not None)
+        if want_probs:
+            probs = _ext.attn_probs(q, kv[:, :, 0], lse, scale, mask_log2)
+            ctx.mark_non_differentiable(probs)
+            return out, probs
         return out
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, _gp=None):
         from . import _ext
         q, kv, out, lse, mask_log2, st = ctx.saved_tensors
         scale, p_drop, seed, has_mask, has_st = ctx.cfg
         qc = q if q.is_contiguous() else q.contiguous()
         dq, dkv = torch.empty_like(qc), torch.empty_like(kv)
-        _ext.attn_bwd(qc, kv[:, :, 0], kv[:, :, 1], out, lse, grad_out, scale, dq, dkv[:, :, 0], dkv[:, :, 1],
+        _ext.attn_bwd(qc, kv[:, :, 0], kv[:, :, 1], out, lse, grad_out.contiguous(), scale, dq, dkv[:, :, 0], dkv[:, :, 1],
                       mask_log2 if has_mask else None, p_drop, seed, st if has_st else None)
-        return dq, dkv, None, None, None
+        return dq, dkv, None, None, None, None
 
 
 # ---- the two text streams of the twin encoder as ONE batch ---------------------------------------------------------
@@ -1018,25 +1026,30 @@ class _TwinCrossAttention(torch.autograd.Function):
     K/V tensors (B, Lk_g, 2, H, 64) of different lengths; context and dq come back stacked (no slice gradients)"""
 
     @staticmethod
-    def forward(ctx, q, kva, kvb, scale, ma, mb, p_drop):
+    def forward(ctx, q, kva, kvb, scale, ma, mb, p_drop, want_probs=False):
         from . import _ext
         B = q.shape[0] // 2
         out = torch.empty_like(q)
-        seeds, lses = [], []
+        seeds, lses, probs = [], [], []
         for g, (kv, m) in enumerate(((kva, ma), (kvb, mb))):
             seed, st = _seed_args(p_drop, q.device)
             _, lse = _ext.attn_fwd(q[g * B:(g + 1) * B], kv[:, :, 0], kv[:, :, 1], scale, m, p_drop, seed, st,
                                    out=out[g * B:(g + 1) * B])
             seeds.append(seed)
             lses.append(lse)
+            if want_probs:
+                probs.append(_ext.attn_probs(q[g * B:(g + 1) * B], kv[:, :, 0], lse, scale, m))
         e = q.new_empty(0)
         ctx.save_for_backward(q, kva, kvb, out, lses[0], lses[1], ma if ma is not None else e, mb if mb is not None else e,
                               st if st is not None else e)
         ctx.cfg = (scale, p_drop, seeds, ma is not None, mb is not None, st is not None)
+        if want_probs:
+            ctx.mark_non_differentiable(*probs)
+            return out, probs[0], probs[1]
         return out
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, _ga=None, _gb=None):
         from . import _ext
         q, kva, kvb, out, lsa, lsb, ma, mb, st = ctx.saved_tensors
         scale, p_drop, seeds, has_a, has_b, has_st = ctx.cfg
@@ -1050,14 +1063,15 @@ class _TwinCrossAttention(torch.autograd.Function):
             _ext.attn_bwd(q[r], kv[:, :, 0], kv[:, :, 1], out[r], lse, grad_out[r], scale, dq[r], dkv[:, :, 0],
                           dkv[:, :, 1], m if has else None, p_drop, seeds[g], st if has_st else None)
             dkvs.append(dkv)
-        return dq, dkvs[0], dkvs[1], None, None, None, None
+        return dq, dkvs[0], dkvs[1], None, None, None, None, None
 
 
-def twin_cross_attention(q, kva, kvb, scale, p_drop, mask_a, mask_b):
-    """q (2B, L, H, 64) stacked; kva (B, Lka, 2, H, 64), kvb (B, Lkb, 2, H, 64); masks (B,1,1,Lk) or None"""
+def twin_cross_attention(q, kva, kvb, scale, p_drop, mask_a, mask_b, return_probs=False):
+    """q (2B, L, H, 64) stacked; kva (B, Lka, 2, H, 64), kvb (B, Lkb, 2, H, 64); masks (B,1,1,Lk) or None.
+    return_probs: -> (context, probs_a, probs_b), the maps detached (attention_probs)"""
     B = q.shape[0] // 2
     return _TwinCrossAttention.apply(q.contiguous(), kva, kvb, scale, _mask_log2(mask_a, B, kva.shape[1]),
-                                     _mask_log2(mask_b, B, kvb.shape[1]), float(p_drop))
+                                     _mask_log2(mask_b, B, kvb.shape[1]), float(p_drop), bool(return_probs))
 
 
 def twin_kernel_ok(hs, linears):
@@ -1320,25 +1334,32 @@ def packed_kernel_ok(qkv, key_mask):
     return _packed_ok(qkv, key_mask)
 
 
-def attention_packed(qkv, scale, dropout_p=0.0, mask=None, causal=False):
+def attention_packed(qkv, scale, dropout_p=0.0, mask=None, causal=False, return_probs=False):
     """Self-attention on the output of a fused QKV projection, qkv (B, L, 3, H, D) -> (B, L, H, D).
     bf16 / D=64 / CUDA goes to the fused kernels; anything else to the reference composition.  causal=True (kernel
     path only, see packed_kernel_ok): `mask` is the (B,1,1,L) key mask and keys after the query are hidden too."""
     if _packed_ok(qkv, mask):
+        # return_probs: (context, probs f32 (B,H,L,L)).  On the kernel path the map is rebuilt from the forward's LSE
+        # (csrc/attn.hip attn_probs_kernel) and is DETACHED: the reference's is part of the autograd graph, but nothing
+        # on this path differentiates through it (a caller that does -- save_attention + attn_gradients hooks -- gets the
+        # reference composition, med.BertSelfAttention)
         return _PackedAttention.apply(qkv, scale, _mask_log2(mask, qkv.shape[0], qkv.shape[1]), float(dropout_p),
-                                      bool(causal))
+                                      bool(causal), bool(return_probs))
     if causal:
         raise RuntimeError("attention_packed(causal=True) needs the kernel path; pass the full (B,1,L,L) mask instead")
-    ctx, _ = attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], mask, scale, dropout_p=dropout_p)
-    return ctx
+    ctx, probs = attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], mask, scale, return_probs=return_probs,
+                           dropout_p=dropout_p)
+    return (ctx, probs) if return_probs else ctx
 
 
-def attention_q_kv(q, kv, scale, dropout_p=0.0, mask=None):
-    """Cross-attention: q (B, Lq, H, D), kv (B, Lk, 2, H, D) from a fused K/V projection -> (B, Lq, H, D)."""
+def attention_q_kv(q, kv, scale, dropout_p=0.0, mask=None, return_probs=False):
+    """Cross-attention: q (B, Lq, H, D), kv (B, Lk, 2, H, D) from a fused K/V projection -> (B, Lq, H, D)
+    (return_probs: see attention_packed)."""
     if _packed_ok(kv, mask) and q.is_cuda and q.dtype == torch.bfloat16 and q.stride(-1) == 1:
-        return _QKVAttention.apply(q, kv, scale, _mask_log2(mask, kv.shape[0], kv.shape[1]), float(dropout_p))
-    ctx, _ = attention(q, kv[:, :, 0], kv[:, :, 1], mask, scale, dropout_p=dropout_p)
-    return ctx
+        return _QKVAttention.apply(q, kv, scale, _mask_log2(mask, kv.shape[0], kv.shape[1]), float(dropout_p),
+                                   bool(return_probs))
+    ctx, probs = attention(q, kv[:, :, 0], kv[:, :, 1], mask, scale, return_probs=return_probs, dropout_p=dropout_p)
+    return (ctx, probs) if return_probs else ctx
 
 
 class _LMHeadCE(torch.autograd.Function):

@@ -149,10 +149,16 @@ class BertSelfAttention(nn.Module):
         H, D = self.num_attention_heads, self.attention_head_size
         p_drop = self.dropout.p if self.training else 0.0
         two_seg = isinstance(encoder_hidden_states, TwoSegmentStates)
-        if not want and past_key_value is None and ops.compute_dtype() == torch.bfloat16 and (hidden_states.is_cuda or two_seg):
+        # the fused kernels also serve output_attentions (the map is rebuilt from the LSE, detached); a caller that
+        # differentiates through the map -- save_attention + the attn_gradients hook -- gets the reference composition
+        hooked = is_cross and self.save_attention
+        if (not hooked and (not output_attentions or not two_seg) and past_key_value is None
+                and ops.compute_dtype() == torch.bfloat16 and (hidden_states.is_cuda or two_seg)):
             # fused projections: Q/K/V (self) or K/V (cross) as ONE GEMM over the shared input, and the attention
             # kernels read / write the packed tensors in place
             B, L = hidden_states.shape[:2]
+            rp = bool(output_attentions)
+            probs = None
             if is_cross and isinstance(encoder_hidden_states, TwoSegmentStates):
                 # keys / values = cat(hoisted projection of the fixed tokens, this layer's projection of the other
                 # stream's states) -- handed to the kernels as two segments, never concatenated
@@ -167,20 +173,24 @@ class BertSelfAttention(nn.Module):
                 Lk = encoder_hidden_states.shape[1]
                 q = self._heads(ops.linear(hidden_states, self.query.weight, self.query.bias))
                 kv = ops.multi_linear(encoder_hidden_states, (self.key, self.value)).view(B, Lk, 2, H, D)
-                ctx = ops.attention_q_kv(q, kv, 1.0 / math.sqrt(D), p_drop, encoder_attention_mask)
+                ctx = ops.attention_q_kv(q, kv, 1.0 / math.sqrt(D), p_drop, encoder_attention_mask, return_probs=rp)
                 present = (kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3))
             else:
                 qkv = ops.multi_linear(hidden_states, (self.query, self.key, self.value)).view(B, L, 3, H, D)
                 key_mask = getattr(attention_mask, "_bq_causal_key_mask", None)
                 if key_mask is not None and ops.packed_kernel_ok(qkv, key_mask):
                     # decoder: the (B,1,L,L) mask is causal AND key padding -- the kernels take it factored
-                    ctx = ops.attention_packed(qkv, 1.0 / math.sqrt(D), p_drop, key_mask, causal=True)
+                    ctx = ops.attention_packed(qkv, 1.0 / math.sqrt(D), p_drop, key_mask, causal=True, return_probs=rp)
                 elif attention_mask is not None and not (attention_mask.shape[1] == 1 and attention_mask.shape[2] == 1):
-                    ctx, _ = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], attention_mask,
-                                           1.0 / math.sqrt(D), dropout_p=p_drop)  # causal decoder mask
+                    ctx = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], attention_mask,
+                                        1.0 / math.sqrt(D), return_probs=rp, dropout_p=p_drop)  # causal decoder mask
+                    ctx = ctx if rp else ctx[0]
                 else:
-                    ctx = ops.attention_packed(qkv, 1.0 / math.sqrt(D), p_drop, attention_mask)
+                    ctx = ops.attention_packed(qkv, 1.0 / math.sqrt(D), p_drop, attention_mask, return_probs=rp)
                 present = (qkv[:, :, 1].permute(0, 2, 1, 3), qkv[:, :, 2].permute(0, 2, 1, 3))
+            if rp:
+                ctx, probs = ctx
+                return (ctx.reshape(B, L, self.all_head_size), probs, present)
             return (ctx.reshape(B, L, self.all_head_size), present)
         q = self._heads(ops.linear(hidden_states, self.query.weight, self.query.bias))
         src = encoder_hidden_states if is_cross else hidden_states
@@ -390,7 +400,7 @@ class BertEncoderTwin(BertEncoder):
             lins += [l.intermediate.dense, l.output.dense]
         return ops.twin_kernel_ok(hs, lins)
 
-    def _twin_level(self, i, hs, mask2, enc2d, enc3d, mask2d, mask3d, layernorm_idx):
+    def _twin_level(self, i, hs, mask2, enc2d, enc3d, mask2d, mask3d, layernorm_idx, want=False):
         """one level of BOTH streams on the stacked states hs (2B, L, D) (rows [0,B) = 2D stream through layer[i], rows
         [B,2B) = 3D stream through layer_twin[i]); the arithmetic per stream is BertLayer.forward's (self-attention ->
         cross-attention over cat(fixed tokens, other stream's previous states) -> FFN, post-LN; reference
@@ -404,7 +414,9 @@ class BertEncoderTwin(BertEncoder):
         # keys / values of the cross-attentions come from the PREVIOUS states of the other stream
         mix2d, mix3d = ops.twin_mix(enc2d, enc3d, hs)
         qkv = ops.twin_multi_linear(hs, (sa.query, sa.key, sa.value), (sb.query, sb.key, sb.value))
-        ctx = ops.attention_packed(qkv.view(B2, L, 3, H, hd), scale, p_att, mask2)
+        ctx = ops.attention_packed(qkv.view(B2, L, 3, H, hd), scale, p_att, mask2, return_probs=want)
+        if want:
+            ctx, p_self = ctx
         h = ops.twin_linear(ctx.reshape(B2, L, D), a.attention.output.dense, b.attention.output.dense)
         att = ops.twin_dropout_add_layer_norm(h, hs, a.attention.output.LayerNorm, b.attention.output.LayerNorm,
                                               a.attention.output.dropout.p, self.training)
@@ -413,14 +425,19 @@ class BertEncoderTwin(BertEncoder):
         kv2d, kv3d = ops.twin_multi_linear_var(mix2d, mix3d, (ca.key, ca.value), (cb.key, cb.value))
         p_c = ca.dropout.p if self.training else 0.0
         c = ops.twin_cross_attention(q, kv2d.view(B, mix2d.shape[1], 2, H, hd), kv3d.view(B, mix3d.shape[1], 2, H, hd),
-                                     scale, p_c, mask2d, mask3d)
+                                     scale, p_c, mask2d, mask3d, return_probs=want)
+        if want:
+            c, p_c2d, p_c3d = c
         h = ops.twin_linear(c.reshape(B2, L, D), a.crossattention.output.dense, b.crossattention.output.dense)
         att = ops.twin_dropout_add_layer_norm(h, att, a.crossattention.output.LayerNorm, b.crossattention.output.LayerNorm,
                                               a.crossattention.output.dropout.p, self.training)
         h = ops.twin_mlp(att, a.intermediate.dense, a.output.dense, b.intermediate.dense, b.output.dense)
         lna = a.output.LayerNorm if layernorm_idx == 0 else a.output.LayerNorms[layernorm_idx - 1]
         lnb = b.output.LayerNorm if layernorm_idx == 0 else b.output.LayerNorms[layernorm_idx - 1]
-        return ops.twin_dropout_add_layer_norm(h, att, lna, lnb, a.output.dropout.p, self.training)
+        out = ops.twin_dropout_add_layer_norm(h, att, lna, lnb, a.output.dropout.p, self.training)
+        if want:
+            return out, (p_self[:B], p_self[B:]), (p_c2d, p_c3d)
+        return out
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, encoder_hidden_states_twin=None, encoder_attention_mask_twin=None,
@@ -461,7 +478,7 @@ class BertEncoderTwin(BertEncoder):
             want = _wants(output_attentions, i, layers[-1])
             twin = self.layer_twin[i] if i < self.num_hidden_layers_twin else None
             key_only = lambda m: m is None or (m.dim() == 4 and m.shape[1] == 1 and m.shape[2] == 1)
-            if (not want and not hoisted_layers and mode == "multimodal" and attention_mask is not None
+            if (not hoisted_layers and mode == "multimodal" and attention_mask is not None
                     and key_only(attention_mask) and key_only(encoder_attention_mask)
                     and key_only(encoder_attention_mask_twin)
                     and self._pairable(i, ops._c(hidden_states) if stacked is None else stacked)):
@@ -471,7 +488,12 @@ class BertEncoderTwin(BertEncoder):
                     mask2 = torch.cat((attention_mask, attention_mask), dim=0)
                     ops.prime_masks(mask2)
                 stacked = self._twin_level(i, stacked, mask2, enc2d, enc3d, encoder_attention_mask,
-                                           encoder_attention_mask_twin, layernorm_idx)
+                                           encoder_attention_mask_twin, layernorm_idx, want)
+                if want:
+                    stacked, self_att, cross_att = stacked
+                    all_self_attentions = all_self_attentions + (self_att,)
+                    if all_cross_attentions is not None:
+                        all_cross_attentions = all_cross_attentions + (cross_att,)
                 continue
             if stacked is not None:
                 hidden_states, hidden_states_twin = ops.twin_split(stacked)

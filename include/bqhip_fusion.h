@@ -37,6 +37,14 @@ BQ_API int bq_attn_bwd(const void *Q, const void *K, const void *V, const void *
                        long g_hs, float scale, float p_drop, unsigned seed, const unsigned *seed_ptr, int causal,
                        void *stream);
 
+/* The attention probabilities of a bq_attn_fwd call, rebuilt from Q, K and its LSE -- what the reference returns under
+ * output_attentions (models/med.py:202,223: the softmax BEFORE dropout; BLIP_VQA3D keeps the last level's cross-attention
+ * maps, blip_vqa_3d.py:262-281): P f32 (B, H, Lq, Lk) = exp2(scale*log2e * q.k + mask - LSE), causal flag as in the
+ * forward.  p_drop = 0 gives that map; the forward's p_drop / seed / seed_ptr give the dropped map it multiplied V with. */
+BQ_API int bq_attn_probs(const void *Q, const void *K, const float *LSE, const float *mask, float *P, int B, int H, int Lq,
+                         int Lk, int Lkp, long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, float scale,
+                         float p_drop, unsigned seed, const unsigned *seed_ptr, int causal, void *stream);
+
 /* Attention of Lq <= 32 queries over cat(segment 1, segment 2) along the key axis without the concatenated tensor:
  * replaces  encoder_hidden_states = torch.cat([image_embeds | object_embeds, other stream's states], dim=1)  followed
  * by the cross-attention of models/med.py:549-562, 179-217 (BertEncoderTwin / BertSelfAttention).  K / V = segment 1

@@ -632,3 +632,35 @@ def test_fused_adamw_subset_steps_equal_one_step(dev):
         for a, b in zip(mine, ref):
             assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), (step, a.shape, (a - b).abs().max().item())
     assert float(o1.state[mine[0]]["step"]) == 4.0
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,masked,causal", [(2, 4, 20, 1045, True, False), (1, 2, 20, 276, False, False),
+                                                      (2, 3, 6, 6, True, True), (1, 2, 77, 77, False, False),
+                                                      (2, 2, 1, 300, True, False)])
+def test_attention_probabilities_rebuilt_from_the_lse(dev, B, H, Lq, Lk, masked, causal):
+    """bq_attn_probs: the softmax map of a fused forward, rebuilt from Q, K and its LSE (what output_attentions returns
+    on the kernel path, reference med.py:202,223) == softmax(q k^T * scale + mask) of the composition; rows sum to 1"""
+    from bridgeqa_amd import _ext
+    g = torch.Generator().manual_seed(Lk)
+    q = torch.randn(B, Lq, H, 64, generator=g).to(dev).to(torch.bfloat16)
+    kv = torch.randn(B, Lk, 2, H, 64, generator=g).to(dev).to(torch.bfloat16)
+    mask = None
+    if masked:
+        keep = torch.ones(B, Lk)
+        keep[0, Lk - min(Lk - 1, 3):] = 0
+        mask = ((1.0 - keep) * -10000.0).view(B, 1, 1, Lk).to(dev)
+    ml = _ext.key_mask_log2(mask, B, Lk) if mask is not None else None
+    out, lse = _ext.attn_fwd(q, kv[:, :, 0], kv[:, :, 1], 0.125, ml, 0.0, 0, None, causal)
+    P = _ext.attn_probs(q, kv[:, :, 0], lse, 0.125, ml, causal=causal)
+    s = torch.einsum("bqhd,bkhd->bhqk", q.float(), kv[:, :, 0].float()) * 0.125
+    if mask is not None:
+        s = s + mask
+    if causal:
+        s = s + torch.triu(torch.full((Lq, Lk), -1e9, device=dev), 1)
+    want = torch.softmax(s, -1)
+    assert P.shape == want.shape and torch.isfinite(P).all()
+    assert (P - want).abs().max().item() < 2e-5 + 2e-3 * want.max().item()
+    assert (P.sum(-1) - 1).abs().max().item() < 1e-3
+    # and it is the map the fused forward used: P V == the kernel's context (bf16 tolerance)
+    ctx = torch.einsum("bhqk,bkhd->bqhd", P, kv[:, :, 1].float())
+    assert ((ctx - out.float()).norm() / out.float().norm()).item() < 1e-2

@@ -634,7 +634,7 @@ def twin_drop_add_ln_bwd(x, residual, gamma, gamma2, dy, mean, rstd, eps, p_drop
 
 # ---- MFMA bf16 GEMM family (csrc/gemm.hip) ------------------------------------------------------------
 GEMM_P_XC, GEMM_Q_XC, GEMM_OUT_F32 = 1, 2, 4
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_BIAS_CE = 0, 1, 2, 3, 4
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_BIAS_CE, EPI_ADD = 0, 1, 2, 3, 4, 5
 
 
 class _GemmDesc(ctypes.Structure):
@@ -721,14 +721,17 @@ def gemm_fwd(x, w, bias=None, gelu=False, tile=None):
     return (y, act) if gelu else y
 
 
-def gemm_dx(dy, w, pre_act=None, colsum=None, tile=None):
-    """dx = dy @ w (dy (M,N), w (N,K) bf16) [* gelu'(pre_act) (M,K)]; colsum (K,) fp32 += column sums of dx"""
+def gemm_dx(dy, w, pre_act=None, colsum=None, tile=None, add=None):
+    """dx = dy @ w (dy (M,N), w (N,K) bf16) [* gelu'(pre_act) (M,K)] [+ add (M,K) bf16]; colsum (K,) fp32 += column
+    sums of dx"""
     _mat(dy, "dy"), _mat(w, "w")
     M, K = dy.shape[0], w.shape[1]
+    if pre_act is not None and add is not None:
+        raise RuntimeError("gemm_dx: pre_act and add are exclusive")
     with torch.cuda.device(dy.device):
         dx = torch.empty(M, K, dtype=torch.bfloat16, device=dy.device)
-    gemm_grouped([dict(P=w, Q=dy, out=dx, aux=pre_act, colsum=colsum)], GEMM_P_XC,
-                 EPI_DGELU if pre_act is not None else EPI_NONE, tile)
+    gemm_grouped([dict(P=w, Q=dy, out=dx, aux=pre_act if add is None else add, colsum=colsum)], GEMM_P_XC,
+                 EPI_DGELU if pre_act is not None else (EPI_ADD if add is not None else EPI_NONE), tile)
     return dx
 
 

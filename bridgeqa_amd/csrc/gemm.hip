@@ -35,7 +35,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_DGELU = 3, EPI_BIAS_CE = 4 };
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_DGELU = 3, EPI_BIAS_CE = 4, EPI_ADD = 5 };
 enum { GF_P_XC = 1, GF_Q_XC = 2, GF_OUT_F32 = 4, GF_ACCUM = 8 };
 
 struct GemmProblem {
@@ -43,7 +43,7 @@ struct GemmProblem {
   void *out;           // out[j * ldo + i]: bf16, or fp32 with GF_OUT_F32
   const void *bias;    // over i (EPI_BIAS / EPI_BIAS_GELU) or null: fp32, or bf16 when bias_bf16
   void *out2;          // EPI_BIAS_GELU: gelu(out) as bf16, same layout as out
-  const __bf16 *aux;   // EPI_DGELU: the pre-activation y[j][i] (ld = ldo): out = acc * gelu'(y)
+  const __bf16 *aux;   // EPI_DGELU: the pre-activation y[j][i] (ld = ldo): out = acc * gelu'(y); EPI_ADD: out = acc + aux[j][i]
   float *colsum;       // optional fp32 [Ni]: += sum_j out[j][i] (bias gradient of the producing layer)
   int ldp, ldq, ldo;   // leading dimensions in elements
   int Ni, Nj, Kc;
@@ -408,6 +408,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] *= dgelu_f((float)y[r]);
         }
+        if (EPI == EPI_ADD) {  // out = acc + aux: a second gradient of the same tensor rides on the dX GEMM
+          bf16x4 y = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+          if (ok) y = *reinterpret_cast<const bf16x4 *>(pr.aux + (long)j * ldo + i);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)y[r];
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (float)(__bf16)v[r];  // what is stored (and what a backward differentiates at)
         if (want_colsum && pass == 0) {
@@ -621,6 +627,11 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
         const bf16x4 y = *reinterpret_cast<const bf16x4 *>(pr.aux + (long)j * ldo + i);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= dgelu_f((float)y[r]);
+      }
+      if (EPI == EPI_ADD && ok) {
+        const bf16x4 y = *reinterpret_cast<const bf16x4 *>(pr.aux + (long)j * ldo + i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)y[r];
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = (float)(__bf16)v[r];
@@ -988,6 +999,7 @@ static int launch_gemm(const GemmArgs &ga, int flags, int epi, int tile, hipStre
   } else if (pxc && !qxc && !f32) {
     if (epi == EPI_NONE) return launch_variant<true, false, EPI_NONE, false>(ga, tile, st, long_k);
     if (epi == EPI_DGELU) return launch_variant<true, false, EPI_DGELU, false>(ga, tile, st, long_k);
+    if (epi == EPI_ADD) return launch_variant<true, false, EPI_ADD, false>(ga, tile, st, long_k);
   } else if (pxc && qxc && f32) {
     if (epi == EPI_NONE) return launch_variant<true, true, EPI_NONE, true>(ga, tile, st);
   }
@@ -1023,6 +1035,7 @@ extern "C" int bq_gemm_bf16(const bq_gemm_desc *d, int n, int flags, int epilogu
                  "bq_gemm_bf16: operands must be 16-byte aligned");
       BQ_REQUIRE(epilogue != EPI_BIAS_GELU || s.out2, BQ_EINVAL, "bq_gemm_bf16: BIAS_GELU needs out2");
       BQ_REQUIRE(epilogue != EPI_DGELU || s.aux, BQ_EINVAL, "bq_gemm_bf16: DGELU needs aux");
+      BQ_REQUIRE(epilogue != EPI_ADD || s.aux, BQ_EINVAL, "bq_gemm_bf16: ADD needs aux");
       const long pb = pxc ? ((long)(s.Kc - 1) * s.ldp + s.Ni) * 2 : ((long)(s.Ni - 1) * s.ldp + s.Kc) * 2;
       const long qb = qxc ? ((long)(s.Kc - 1) * s.ldq + s.Nj) * 2 : ((long)(s.Nj - 1) * s.ldq + s.Kc) * 2;
       const int tj = tile == 256 ? 256 : tile, ti = tile == 256 ? 256 : 64;

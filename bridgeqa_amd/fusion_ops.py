@@ -345,18 +345,72 @@ def _park(g2, x2, ws, bs):
     _DEFER[0].append((_rows(g2), _rows(x2), ws, bs))
 
 
+# ---- gradient taps ------------------------------------------------------------------------------------------------
+# A post-LN transformer sub-block reads its input twice: y = LN(x + f(x)).  Autograd therefore sums two gradients for x
+# -- the residual one, which the LayerNorm backward produces first, and the input gradient of f's first linear -- with
+# an accumulation kernel per site (~100 launches of 4-5 us in the text side of a c3 step).  A GradTap carries the first
+# gradient to the node that produces the second, whose dX GEMM adds it in its epilogue (BQ_GEMM_EPI_ADD): the residual
+# branch goes through tap(x, holder) (identity; its backward parks the incoming gradient in the holder and returns
+# nothing), the linear receives tap=holder.  Autograd runs nodes in reverse creation order, so the tap -- created after the
+# linear, just before the LayerNorm -- always fires before the linear's backward of the same pass.
+# Should the consumer run first after all (its holder is then marked consumed), the tap simply returns its gradient to
+# autograd, which accumulates it the ordinary way: the order is a performance assumption, never a correctness one.
+class GradTap(object):
+    __slots__ = ("grad", "consumed")
+
+    def __init__(self):
+        self.grad, self.consumed = None, False
+
+
+class _TapFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, holder):
+        ctx.holder = holder
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        h = ctx.holder
+        if h.consumed:
+            return g, None
+        h.grad = g if h.grad is None else h.grad + g
+        return None, None
+
+
+def tap(x, holder):
+    """x for the residual branch; its gradient will reach x through the consumer that was given tap=holder"""
+    if holder is None or not torch.is_tensor(x) or not x.requires_grad or not torch.is_grad_enabled():
+        return x
+    return _TapFn.apply(x, holder)
+
+
+def _take_tap(holder, like_rows):
+    """the parked gradient as (rows, K) bf16 rows laid out like the dX about to be produced, or None"""
+    if holder is None:
+        return None
+    holder.consumed = True
+    if holder.grad is None:
+        return None
+    g, holder.grad = holder.grad, None
+    g2 = g.reshape(-1, g.shape[-1])
+    if g2.dtype != torch.bfloat16:
+        g2 = g2.to(torch.bfloat16)
+    return g2 if g2.is_contiguous() else g2.contiguous()
+
+
 class _LinearFn(torch.autograd.Function):
     """bf16-operand linear with fp32 master weights: the forward reads the bf16 shadow of W and the fp32 bias itself
     (bias / GELU in the GEMM epilogue), the backward produces dX with the same kernel family and dW / db in fp32
     (parked inside a deferred-wgrad scope)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gelu):
+    def forward(ctx, x, weight, bias, gelu, tap_holder=None):
         wb = _shadow(weight)
         if wb.dim() > 2:  # a convolution whose stride equals its kernel (ViT patch embedding): (N, C, kh, kw) = (N, K)
             wb = wb.view(wb.shape[0], -1)
         N, K = wb.shape
         ctx.gelu, ctx.has_bias, ctx.x_dtype, ctx.x_shape = gelu, bias is not None, x.dtype, x.shape
+        ctx.tap = tap_holder
         ctx.params = (weight, bias)
         if _native_ok(x, N, K):
             from . import _ext
@@ -396,13 +450,16 @@ class _LinearFn(torch.autograd.Function):
             dw, db = _dw_db(g2, x2, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         dx = None
         if ctx.needs_input_grad[0]:
+            extra = _take_tap(ctx.tap, g2)
             if native:
                 from . import _ext
-                dx = _ext.gemm_dx(g2, wb)
+                dx = _ext.gemm_dx(g2, wb, add=extra)
             else:
                 dx = torch.mm(g2, wb)
+                if extra is not None:
+                    dx = dx + extra
             dx = dx.view(ctx.x_shape).to(ctx.x_dtype)
-        return dx, (dw.view(w.shape) if dw is not None else None), db, None
+        return dx, (dw.view(w.shape) if dw is not None else None), db, None, None
 
 
 class _MlpFn(torch.autograd.Function):
@@ -415,8 +472,9 @@ class _MlpFn(torch.autograd.Function):
                 the same 12 KB -- than one more matrix in the grouped column-sum launch.)"""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, tap_holder=None):
         from . import _ext
+        ctx.tap = tap_holder
         w1b, w2b = _shadow(w1), _shadow(w2)
         x2 = _rows(x)
         y1, h = _ext.gemm_fwd(x2, w1b, _f32_bias(b1), gelu=True)
@@ -433,7 +491,8 @@ class _MlpFn(torch.autograd.Function):
         w1, b1, w2, b2 = ctx.params
         g2 = _rows(g)
         dy1 = _ext.gemm_dx(g2, w2b, pre_act=y1)
-        dx = _ext.gemm_dx(dy1, w1b).view(ctx.x_shape).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
+        dx = _ext.gemm_dx(dy1, w1b, add=_take_tap(ctx.tap, dy1)).view(ctx.x_shape).to(ctx.x_dtype) \
+            if ctx.needs_input_grad[0] else None
         if _DEFER[0] is not None:
             _park(g2, h, [w2], [b2] if b2 is not None else None)
             _park(dy1, x2, [w1], [b1] if b1 is not None else None)
@@ -441,18 +500,19 @@ class _MlpFn(torch.autograd.Function):
         else:
             dw2, db2 = _dw_db(g2, h, True, b2 is not None)
             dw1, db1 = _dw_db(dy1, x2, True, b1 is not None)
-        return dx, dw1, db1, dw2, db2
+        return dx, dw1, db1, dw2, db2, None
 
 
-def mlp(x, fc1, fc2):
-    """fc2(gelu(fc1(x))) for two nn.Linear modules; one fused autograd node on the bf16 CUDA path"""
+def mlp(x, fc1, fc2, tap=None):
+    """fc2(gelu(fc1(x))) for two nn.Linear modules; one fused autograd node on the bf16 CUDA path.  tap: a GradTap whose
+    parked gradient (of x, from the residual branch) is added to the input gradient by the last dX GEMM"""
     w1, w2 = fc1.weight, fc2.weight
     if (_native_ok(x, w1.shape[0], w1.shape[1]) and _native_ok(x, w2.shape[0], w2.shape[1])
             and _native_dx_ok(x, w1.shape[0], w1.shape[1]) and _native_dx_ok(x, w2.shape[0], w2.shape[1])
             and all(isinstance(t, torch.nn.Parameter) and t.dtype == torch.float32
                     for t in (w1, w2, fc1.bias, fc2.bias) if t is not None)):
-        return _MlpFn.apply(x, w1, fc1.bias, w2, fc2.bias)
-    return linear(linear(x, w1, fc1.bias, act="gelu"), w2, fc2.bias)
+        return _MlpFn.apply(x, w1, fc1.bias, w2, fc2.bias, tap)
+    return linear(linear(x, w1, fc1.bias, act="gelu", tap=tap), w2, fc2.bias)
 
 
 _CAT_CACHE = {}
@@ -496,11 +556,12 @@ class _MultiLinearFn(torch.autograd.Function):
     per-layer gradients are row blocks (views) of the fused results."""
 
     @staticmethod
-    def forward(ctx, x, *wb):
+    def forward(ctx, x, tap_holder, *wb):
         k = len(wb) // 2
         weights, biases = wb[:k], wb[k:]
         wc, bc = _cat_shadow(weights, biases)
         ctx.k, ctx.x_dtype, ctx.x_shape = k, x.dtype, x.shape
+        ctx.tap = tap_holder
         ctx.params = (weights, biases)
         if _native_ok(x, wc.shape[0], wc.shape[1]):
             from . import _ext
@@ -525,37 +586,61 @@ class _MultiLinearFn(torch.autograd.Function):
             g2 = g2.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
+            extra = _take_tap(ctx.tap, g2)
             if native:
                 from . import _ext
-                dx = _ext.gemm_dx(g2, wc)
+                dx = _ext.gemm_dx(g2, wc, add=extra)
             else:
                 dx = torch.mm(g2, wc)
+                if extra is not None:
+                    dx = dx + extra
             dx = dx.view(ctx.x_shape).to(ctx.x_dtype)
         if _defer_ok(g2, x2):
             ws, bs = ctx.params
             _park(g2, x2, list(ws), list(bs))
-            return (dx,) + (None,) * (2 * k)
+            return (dx, None) + (None,) * (2 * k)
         dw, db = _dw_db(g2, x2, True, True)
         n = dw.shape[0] // k
-        return (dx,) + tuple(dw[i * n:(i + 1) * n] for i in range(k)) + tuple(db[i * n:(i + 1) * n] for i in range(k))
+        return (dx, None) + tuple(dw[i * n:(i + 1) * n] for i in range(k)) + tuple(db[i * n:(i + 1) * n] for i in range(k))
 
 
-def multi_linear(x, linears):
-    """[lin_i(x)] stacked on a new second-to-last axis: (..., k, N).  Fused on the bf16 CUDA path."""
+def multi_linear(x, linears, tap=None):
+    """[lin_i(x)] stacked on a new second-to-last axis: (..., k, N).  Fused on the bf16 CUDA path.  tap: see mlp()."""
     ws, bs = [l.weight for l in linears], [l.bias for l in linears]
     if (_COMPUTE_DTYPE != torch.float32 and x.is_cuda and all(w.dtype == torch.float32 for w in ws)
             and all(b is not None for b in bs) and len({w.shape for w in ws}) == 1):
-        return _MultiLinearFn.apply(x, *ws, *bs)
-    return torch.stack([linear(x, w, b) for w, b in zip(ws, bs)], dim=-2)
+        return _MultiLinearFn.apply(x, tap, *ws, *bs)
+    return torch.stack([linear(x, w, b, tap=(tap if i == 0 else None)) for i, (w, b) in enumerate(zip(ws, bs))], dim=-2)
 
 
-def linear(x, weight, bias=None, act=None):
-    """y = act(x @ weight^T + bias); weight (out,in) as nn.Linear stores it.  Output in the compute dtype."""
+class _AddTapFn(torch.autograd.Function):
+    """fallback consumer of a GradTap for paths without a dX GEMM of their own: identity whose backward adds the parked
+    gradient"""
+
+    @staticmethod
+    def forward(ctx, x, holder):
+        ctx.holder = holder
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        h = ctx.holder
+        h.consumed = True
+        if h.grad is not None:
+            g, h.grad = g + h.grad.to(g.dtype), None
+        return g, None
+
+
+def linear(x, weight, bias=None, act=None, tap=None):
+    """y = act(x @ weight^T + bias); weight (out,in) as nn.Linear stores it.  Output in the compute dtype.
+    tap: see mlp()."""
     if act not in (None, "gelu"):
         raise ValueError(act)
     if (_COMPUTE_DTYPE != torch.float32 and x.is_cuda and isinstance(weight, torch.nn.Parameter)
             and weight.dtype == torch.float32 and (bias is None or isinstance(bias, torch.nn.Parameter))):
-        return _LinearFn.apply(x, weight, bias, act == "gelu")
+        return _LinearFn.apply(x, weight, bias, act == "gelu", tap)
+    if tap is not None and torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled():
+        x = _AddTapFn.apply(x, tap)
     if weight.dim() > 2:
         weight = weight.reshape(weight.shape[0], -1)
     y = F.linear(_c(x), _c(weight), _c(bias) if bias is not None else None)
@@ -861,8 +946,9 @@ class _GroupedLinearFn(torch.autograd.Function):
     dX launch; dW / db parked per group for the phase's grouped launches."""
 
     @staticmethod
-    def forward(ctx, G, k, stacked, *t):
+    def forward(ctx, G, k, stacked, tap_holder, *t):
         from . import _ext
+        ctx.tap = tap_holder  # (stacked form only) the residual-branch gradient of the input, added by the dX launch
         nx = 1 if stacked else G
         xs, ws, bs = t[:nx], t[nx:nx + G * k], t[nx + G * k:]
         wops, bops = _group_operands(ws, bs, G, k)
@@ -901,15 +987,20 @@ class _GroupedLinearFn(torch.autograd.Function):
         else:
             gg = [_rows(g.reshape(-1, N)) for g in grads]
             dxg = [torch.empty(g2.shape[0], K, dtype=torch.bfloat16, device=g2.device) for g2 in gg]
-        need = [i for i in range(1 if stacked else G) if ctx.needs_input_grad[3 + i]]
+        need = [i for i in range(1 if stacked else G) if ctx.needs_input_grad[4 + i]]
         if need:
             sel = range(G) if stacked else need
-            _ext.gemm_grouped([dict(P=wops[g], Q=gg[g], out=dxg[g]) for g in sel], _ext.GEMM_P_XC, _ext.EPI_NONE)
+            extra = _take_tap(ctx.tap, g2) if stacked else None
+            if extra is not None:
+                _ext.gemm_grouped([dict(P=wops[g], Q=gg[g], out=dxg[g], aux=extra[g * M:(g + 1) * M]) for g in sel],
+                                  _ext.GEMM_P_XC, _ext.EPI_ADD)
+            else:
+                _ext.gemm_grouped([dict(P=wops[g], Q=gg[g], out=dxg[g]) for g in sel], _ext.GEMM_P_XC, _ext.EPI_NONE)
         if stacked:
             dxs = (dx.view(shapes[0]).to(dtypes[0]) if need else None,)
         else:
             dxs = tuple(dxg[g].view(shapes[g]).to(dtypes[g]) if g in need else None for g in range(G))
-        return (None, None, None) + dxs + _grouped_wgrad(gg, xg, ws, bs, k)
+        return (None, None, None, None) + dxs + _grouped_wgrad(gg, xg, ws, bs, k)
 
 
 class _GroupedMlpFn(torch.autograd.Function):
@@ -917,8 +1008,9 @@ class _GroupedMlpFn(torch.autograd.Function):
     every launch grouped -- forward 2 launches (GELU epilogue, bias epilogue), backward 2 (dGELU epilogue, plain) + parks."""
 
     @staticmethod
-    def forward(ctx, G, x, *p):
+    def forward(ctx, G, tap_holder, x, *p):
         from . import _ext
+        ctx.tap = tap_holder
         w1, b1, w2, b2 = p[0::4], p[1::4], p[2::4], p[3::4]
         w1o, w2o = [_shadow(w) for w in w1], [_shadow(w) for w in w2]
         x2 = _rows(x)
@@ -951,17 +1043,22 @@ class _GroupedMlpFn(torch.autograd.Function):
         _ext.gemm_grouped([dict(P=w2o[i], Q=rows(g2, i), out=rows(dy1, i), aux=rows(y1, i)) for i in range(G)],
                           _ext.GEMM_P_XC, _ext.EPI_DGELU)
         dx = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[2]:
             dx = torch.empty_like(x2)
-            _ext.gemm_grouped([dict(P=w1o[i], Q=rows(dy1, i), out=rows(dx, i)) for i in range(G)], _ext.GEMM_P_XC,
-                              _ext.EPI_NONE)
+            extra = _take_tap(ctx.tap, dy1)
+            if extra is not None:
+                _ext.gemm_grouped([dict(P=w1o[i], Q=rows(dy1, i), out=rows(dx, i), aux=rows(extra, i)) for i in range(G)],
+                                  _ext.GEMM_P_XC, _ext.EPI_ADD)
+            else:
+                _ext.gemm_grouped([dict(P=w1o[i], Q=rows(dy1, i), out=rows(dx, i)) for i in range(G)], _ext.GEMM_P_XC,
+                                  _ext.EPI_NONE)
             dx = dx.view(ctx.x_shape).to(ctx.x_dtype)
         gw2 = _grouped_wgrad([rows(g2, i) for i in range(G)], [rows(h, i) for i in range(G)], w2, b2, 1)
         gw1 = _grouped_wgrad([rows(dy1, i) for i in range(G)], [rows(x2, i) for i in range(G)], w1, b1, 1)
         out = []
         for i in range(G):
             out += [gw1[i], gw1[G + i], gw2[i], gw2[G + i]]
-        return (None, dx) + tuple(out)
+        return (None, None, dx) + tuple(out)
 
 
 class _TwinDropAddLN(torch.autograd.Function):
@@ -1084,17 +1181,17 @@ def twin_kernel_ok(hs, linears):
                     and l.weight.shape[1] % 64 == 0 for l in linears))
 
 
-def twin_linear(hs, lin_a, lin_b):
-    """stacked states -> [lin_a(2D rows); lin_b(3D rows)], one launch"""
-    return _GroupedLinearFn.apply(2, 1, True, hs, lin_a.weight, lin_b.weight, lin_a.bias, lin_b.bias)
+def twin_linear(hs, lin_a, lin_b, tap=None):
+    """stacked states -> [lin_a(2D rows); lin_b(3D rows)], one launch (tap: a GradTap, see mlp())"""
+    return _GroupedLinearFn.apply(2, 1, True, tap, hs, lin_a.weight, lin_b.weight, lin_a.bias, lin_b.bias)
 
 
-def twin_multi_linear(hs, lins_a, lins_b):
+def twin_multi_linear(hs, lins_a, lins_b, tap=None):
     """stacked states -> (..., k, N): the k fused projections (Q/K/V) of each stream, one launch"""
     k = len(lins_a)
     ws = [l.weight for l in lins_a] + [l.weight for l in lins_b]
     bs = [l.bias for l in lins_a] + [l.bias for l in lins_b]
-    y = _GroupedLinearFn.apply(2, k, True, hs, *ws, *bs)
+    y = _GroupedLinearFn.apply(2, k, True, tap, hs, *ws, *bs)
     return y.view(*y.shape[:-1], k, y.shape[-1] // k)
 
 
@@ -1103,12 +1200,12 @@ def twin_multi_linear_var(xa, xb, lins_a, lins_b):
     k = len(lins_a)
     ws = [l.weight for l in lins_a] + [l.weight for l in lins_b]
     bs = [l.bias for l in lins_a] + [l.bias for l in lins_b]
-    ya, yb = _GroupedLinearFn.apply(2, k, False, xa, xb, *ws, *bs)
+    ya, yb = _GroupedLinearFn.apply(2, k, False, None, xa, xb, *ws, *bs)
     return ya.view(*ya.shape[:-1], k, ya.shape[-1] // k), yb.view(*yb.shape[:-1], k, yb.shape[-1] // k)
 
 
-def twin_mlp(hs, fc1_a, fc2_a, fc1_b, fc2_b):
-    return _GroupedMlpFn.apply(2, hs, fc1_a.weight, fc1_a.bias, fc2_a.weight, fc2_a.bias,
+def twin_mlp(hs, fc1_a, fc2_a, fc1_b, fc2_b, tap=None):
+    return _GroupedMlpFn.apply(2, tap, hs, fc1_a.weight, fc1_a.bias, fc2_a.weight, fc2_a.bias,
                                fc1_b.weight, fc1_b.bias, fc2_b.weight, fc2_b.bias)
 
 

@@ -141,7 +141,9 @@ class BertSelfAttention(nn.Module):
         return x.view(x.shape[0], x.shape[1], self.num_attention_heads, self.attention_head_size)
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
-                encoder_attention_mask=None, past_key_value=None, output_attentions=False):
+                encoder_attention_mask=None, past_key_value=None, output_attentions=False, tap=None):
+        """tap: an ops.GradTap -- the projection that reads hidden_states adds the gradient parked there (the residual
+        branch of the following BertSelfOutput) to its input gradient"""
         if head_mask is not None:
             raise NotImplementedError("head_mask is always None on the BridgeQA path")
         is_cross = encoder_hidden_states is not None
@@ -163,7 +165,7 @@ class BertSelfAttention(nn.Module):
                 # keys / values = cat(hoisted projection of the fixed tokens, this layer's projection of the other
                 # stream's states) -- handed to the kernels as two segments, never concatenated
                 es = encoder_hidden_states
-                q = self._heads(ops.linear(hidden_states, self.query.weight, self.query.bias))
+                q = self._heads(ops.linear(hidden_states, self.query.weight, self.query.bias, tap=tap))
                 kv1 = es.hoisted.kv(es.slot)
                 kv2 = es.hoisted.tail_kv(es.slot, es.tail)
                 ctx = ops.attention_q_kv2(q, kv1, kv2, 1.0 / math.sqrt(D), p_drop, encoder_attention_mask,
@@ -171,12 +173,12 @@ class BertSelfAttention(nn.Module):
                 present = None
             elif is_cross:
                 Lk = encoder_hidden_states.shape[1]
-                q = self._heads(ops.linear(hidden_states, self.query.weight, self.query.bias))
+                q = self._heads(ops.linear(hidden_states, self.query.weight, self.query.bias, tap=tap))
                 kv = ops.multi_linear(encoder_hidden_states, (self.key, self.value)).view(B, Lk, 2, H, D)
                 ctx = ops.attention_q_kv(q, kv, 1.0 / math.sqrt(D), p_drop, encoder_attention_mask, return_probs=rp)
                 present = (kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3))
             else:
-                qkv = ops.multi_linear(hidden_states, (self.query, self.key, self.value)).view(B, L, 3, H, D)
+                qkv = ops.multi_linear(hidden_states, (self.query, self.key, self.value), tap=tap).view(B, L, 3, H, D)
                 key_mask = getattr(attention_mask, "_bq_causal_key_mask", None)
                 if key_mask is not None and ops.packed_kernel_ok(qkv, key_mask):
                     # decoder: the (B,1,L,L) mask is causal AND key padding -- the kernels take it factored
@@ -192,7 +194,7 @@ class BertSelfAttention(nn.Module):
                 ctx, probs = ctx
                 return (ctx.reshape(B, L, self.all_head_size), probs, present)
             return (ctx.reshape(B, L, self.all_head_size), present)
-        q = self._heads(ops.linear(hidden_states, self.query.weight, self.query.bias))
+        q = self._heads(ops.linear(hidden_states, self.query.weight, self.query.bias, tap=tap))
         src = encoder_hidden_states if is_cross else hidden_states
         k = self._heads(ops.linear(src, self.key.weight, self.key.bias))
         v = self._heads(ops.linear(src, self.value.weight, self.value.bias))
@@ -234,9 +236,10 @@ class BertAttention(nn.Module):
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, past_key_value=None, output_attentions=False):
+        t = ops.GradTap()  # the residual gradient of hidden_states rides on the query / QKV projection's dX GEMM
         self_outputs = self.self(hidden_states, attention_mask, head_mask, encoder_hidden_states,
-                                 encoder_attention_mask, past_key_value, output_attentions)
-        attention_output = self.output(self_outputs[0], hidden_states)
+                                 encoder_attention_mask, past_key_value, output_attentions, tap=t)
+        attention_output = self.output(self_outputs[0], ops.tap(hidden_states, t))
         return (attention_output,) + self_outputs[1:]
 
 
@@ -277,7 +280,12 @@ class BertOutputParallel(BertOutput):
         """intermediate: the BertIntermediate whose dense + GELU feeds this layer; given, `hidden_states` is ITS input
         and both linears run as one fused autograd node (ops.mlp)"""
         if intermediate is not None:
-            h = ops.mlp(hidden_states, intermediate.dense, self.dense)
+            if input_tensor is hidden_states:  # the block's input is also its residual: tap its gradient into the MLP's dX
+                t = ops.GradTap()
+                h = ops.mlp(hidden_states, intermediate.dense, self.dense, tap=t)
+                input_tensor = ops.tap(input_tensor, t)
+            else:
+                h = ops.mlp(hidden_states, intermediate.dense, self.dense)
         else:
             h = ops.linear(hidden_states, self.dense.weight, self.dense.bias)
         ln = self.LayerNorm if layernorm_idx == 0 else self.LayerNorms[layernorm_idx - 1]
@@ -413,15 +421,17 @@ class BertEncoderTwin(BertEncoder):
         p_att = sa.dropout.p if self.training else 0.0
         # keys / values of the cross-attentions come from the PREVIOUS states of the other stream
         mix2d, mix3d = ops.twin_mix(enc2d, enc3d, hs)
-        qkv = ops.twin_multi_linear(hs, (sa.query, sa.key, sa.value), (sb.query, sb.key, sb.value))
+        # (t1-t3: the residual-branch gradient of each sub-block's input rides on the dX GEMM of its first linear)
+        t1, t2, t3 = ops.GradTap(), ops.GradTap(), ops.GradTap()
+        qkv = ops.twin_multi_linear(hs, (sa.query, sa.key, sa.value), (sb.query, sb.key, sb.value), tap=t1)
         ctx = ops.attention_packed(qkv.view(B2, L, 3, H, hd), scale, p_att, mask2, return_probs=want)
         if want:
             ctx, p_self = ctx
         h = ops.twin_linear(ctx.reshape(B2, L, D), a.attention.output.dense, b.attention.output.dense)
-        att = ops.twin_dropout_add_layer_norm(h, hs, a.attention.output.LayerNorm, b.attention.output.LayerNorm,
-                                              a.attention.output.dropout.p, self.training)
+        att = ops.twin_dropout_add_layer_norm(h, ops.tap(hs, t1), a.attention.output.LayerNorm,
+                                              b.attention.output.LayerNorm, a.attention.output.dropout.p, self.training)
         ca, cb = a.crossattention.self, b.crossattention.self
-        q = ops.twin_linear(att, ca.query, cb.query).view(B2, L, H, hd)
+        q = ops.twin_linear(att, ca.query, cb.query, tap=t2).view(B2, L, H, hd)
         kv2d, kv3d = ops.twin_multi_linear_var(mix2d, mix3d, (ca.key, ca.value), (cb.key, cb.value))
         p_c = ca.dropout.p if self.training else 0.0
         c = ops.twin_cross_attention(q, kv2d.view(B, mix2d.shape[1], 2, H, hd), kv3d.view(B, mix3d.shape[1], 2, H, hd),
@@ -429,12 +439,13 @@ class BertEncoderTwin(BertEncoder):
         if want:
             c, p_c2d, p_c3d = c
         h = ops.twin_linear(c.reshape(B2, L, D), a.crossattention.output.dense, b.crossattention.output.dense)
-        att = ops.twin_dropout_add_layer_norm(h, att, a.crossattention.output.LayerNorm, b.crossattention.output.LayerNorm,
-                                              a.crossattention.output.dropout.p, self.training)
-        h = ops.twin_mlp(att, a.intermediate.dense, a.output.dense, b.intermediate.dense, b.output.dense)
+        att = ops.twin_dropout_add_layer_norm(h, ops.tap(att, t2), a.crossattention.output.LayerNorm,
+                                              b.crossattention.output.LayerNorm, a.crossattention.output.dropout.p,
+                                              self.training)
+        h = ops.twin_mlp(att, a.intermediate.dense, a.output.dense, b.intermediate.dense, b.output.dense, tap=t3)
         lna = a.output.LayerNorm if layernorm_idx == 0 else a.output.LayerNorms[layernorm_idx - 1]
         lnb = b.output.LayerNorm if layernorm_idx == 0 else b.output.LayerNorms[layernorm_idx - 1]
-        out = ops.twin_dropout_add_layer_norm(h, att, lna, lnb, a.output.dropout.p, self.training)
+        out = ops.twin_dropout_add_layer_norm(h, ops.tap(att, t3), lna, lnb, a.output.dropout.p, self.training)
         if want:
             return out, (p_self[:B], p_self[B:]), (p_c2d, p_c3d)
         return out

@@ -184,6 +184,9 @@ BQ_API int bq_adamw_multi(const void *table, const void *chunks, int n_chunks, c
 #define BQ_GEMM_EPI_BIAS 1
 #define BQ_GEMM_EPI_BIAS_GELU 2
 #define BQ_GEMM_EPI_DGELU 3
+#define BQ_GEMM_EPI_ADD 5 /* out = acc + aux (aux bf16, laid out like out): in the input-gradient form the gradient that reached the
+                            same tensor through another branch (the residual input of the following LayerNorm) is added here
+                            instead of by a separate accumulation kernel */
 #define BQ_GEMM_EPI_BIAS_CE 4 /* LM head: out = bf16(acc + bias) AND cross-entropy partials from the fp32 values; tile 256
                                  only; field reuse: out2 = f32 partials [2 * ceil(Ni/256)][Nj][3] (max, sum exp(z - max),
                                  sum z over the valid entries of each 128-wide half tile), aux = int32 targets [Nj] (< 0:

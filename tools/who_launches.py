@@ -23,8 +23,16 @@ def step():
     for p in params:
         p.grad = None
     fusion_ops.new_step(dev)
-    loss = bench.total_loss(model(dict(batch)))
-    loss.backward()
+    prev = fusion_ops.set_overlap(False)   # single-stream fusion, as the phased step runs it
+    try:
+        loss = bench.total_loss(model(dict(batch)))
+        fusion_ops.begin_deferred_wgrad()  # weight gradients parked and flushed once, as in pipeline.PhasedTrainStep
+        try:
+            loss.backward()
+        finally:
+            fusion_ops.flush_deferred_wgrad()
+    finally:
+        fusion_ops.set_overlap(prev)
     return loss
 
 
@@ -62,5 +70,5 @@ for e in evs:
         key = (short, e.name, str(e.input_shapes)[:60], site if not node else node[:60])
         agg[key][0] += 1
         agg[key][1] += k.duration
-for k, v in sorted(agg.items(), key=lambda x: -x[1][0])[:70]:
+for k, v in sorted(agg.items(), key=lambda x: -x[1][1])[:70]:
     print("%4d %8.1fus  %-60s %-28s %-60s %s" % (v[0], v[1], k[0], k[1][:28], k[2], k[3]))

@@ -350,3 +350,46 @@ def test_hot_path_with_qa_heads_and_full_get_loss(dev):
         assert dict(m.named_parameters())["enc_list_o.0.mhatt.linear_q.weight"].grad is None   # never called upstream either
     finally:
         ops.set_compute_dtype(prev)
+
+
+def test_batch_stager_feeds_replayed_graphs_with_changing_batches(dev):
+    """solver.BatchStager + PhasedTrainStep under graph replay: host batches that change every step go
+    through pinned staging into next_batch while the previous step runs, advance() hands them to the graphs' static
+    buffers, the geometry prefetch reads next_batch -- the replayed losses equal plain eager forwards on the same data"""
+    import bench
+    from bridgeqa_amd.pipeline import PhasedTrainStep
+    from bridgeqa_amd.solver import BatchStager, PackedRunningLog
+    model = _small_model(dev)
+    base = _batch(dev, B=2, N=4096)
+    host = []
+    for k in range(4):
+        g = torch.Generator().manual_seed(200 + k)
+        hb = {n: ({m: t.cpu() for m, t in v.items()} if isinstance(v, dict) else (v.cpu() if torch.is_tensor(v) else v))
+              for n, v in base.items()}
+        pc = hb["point_clouds"].clone()
+        pc[..., :3] = torch.rand(pc.shape[0], pc.shape[1], 3, generator=g) * torch.tensor([8.0, 8.0, 3.0])
+        hb["point_clouds"] = pc
+        host.append(hb)
+    want = []
+    with torch.no_grad():
+        for hb in host:
+            dd = {n: ({m: t.to(dev) for m, t in v.items()} if isinstance(v, dict) else (v.to(dev) if torch.is_tensor(v) else v))
+                  for n, v in hb.items()}
+            want.append(bench.total_loss(model(dd)).item())
+    assert abs(want[0] - want[1]) > 1e-3 * abs(want[0])
+    st = BatchStager(host[0], dev)
+    st.advance()
+    pipe = PhasedTrainStep(model, st.batch, bench.det_loss, bench.fusion_loss, None, use_graphs=True,
+                           next_batch=st.next_batch)
+    pipe.capture(warmup=1)      # (no optimizer: the parameters stay what `want` was computed with)
+    log = PackedRunningLog(dev)
+    for k in range(4):
+        if k > 0:
+            st.advance()                              # batch <- data k (uploaded during step k - 1)
+        st.stage(host[(k + 1) % 4])                   # data k + 1 -> next_batch, under this step
+        st.wait(pipe.s_det)                           # the geometry prefetch of this step reads next_batch
+        loss = pipe.step()
+        pipe.wait()
+        got = log.reduce({"loss": loss, "pos_ratio": 0.25})
+        assert abs(got["loss"] - want[k]) <= 5e-4 * abs(want[k]), (k, got["loss"], want[k])
+        assert got["pos_ratio"] == 0.25 and got["mae_loss"] == 0.0

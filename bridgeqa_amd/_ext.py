@@ -632,6 +632,45 @@ def twin_drop_add_ln_bwd(x, residual, gamma, gamma2, dy, mean, rstd, eps, p_drop
     return dx, dres, dgb
 
 
+# ---- proposal post-processing (csrc/nms.hip) ------------------------------------------------------------
+_lib.bq_box_point_count.argtypes = [_vp] * 5 + [_i] * 5 + [_vp]
+_lib.bq_box_point_count.restype = ctypes.c_int
+_lib.bq_nms.argtypes = [_vp] * 5 + [_i, _i, _f, _i, _i, _vp]
+_lib.bq_nms.restype = ctypes.c_int
+
+
+def box_point_count(points, center, size, heading, cap=0):
+    """points f32 (B, N, >=3) (xyz first), center / size f32 (B, K, 3), heading f32 (B, K) -> i32 (B, K) points inside each
+    oriented box (closed)"""
+    for t, n in ((points, "points"), (center, "center"), (size, "size"), (heading, "heading")):
+        if not t.is_cuda:
+            raise RuntimeError("%s: CPU not supported" % n)
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("%s must be a contiguous float32 tensor" % n)
+    B, N, ld = points.shape
+    K = center.shape[1]
+    with torch.cuda.device(points.device):
+        out = torch.empty(B, K, dtype=torch.int32, device=points.device)
+        _check(_lib.bq_box_point_count(_p(points), _p(center), _p(size), _p(heading), _p(out), B, N, ld, K, int(cap),
+                                       _stream()), "box_point_count")
+    return out
+
+
+def nms(box, score, thresh, cls=None, valid=None, old_type=False, same_cls=False):
+    """box f32 (B, K, 6) axis-aligned extents, score f32 (B, K), cls i32 (B, K), valid u8 / bool (B, K) -> bool (B, K)"""
+    if not box.is_cuda:
+        raise RuntimeError("box: CPU not supported")
+    B, K = score.shape
+    box, score = box.contiguous().float(), score.contiguous().float()
+    cls = cls.contiguous().to(torch.int32) if cls is not None else None
+    valid = valid.contiguous().to(torch.uint8) if valid is not None else None
+    with torch.cuda.device(box.device):
+        keep = torch.empty(B, K, dtype=torch.uint8, device=box.device)
+        _check(_lib.bq_nms(_p(box), _p(score), _p(cls), _p(valid), _p(keep), B, K, float(thresh), int(bool(old_type)),
+                           int(bool(same_cls)), _stream()), "nms")
+    return keep.bool()
+
+
 # ---- MFMA bf16 GEMM family (csrc/gemm.hip) ------------------------------------------------------------
 GEMM_P_XC, GEMM_Q_XC, GEMM_OUT_F32 = 1, 2, 4
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_BIAS_CE, EPI_ADD = 0, 1, 2, 3, 4, 5

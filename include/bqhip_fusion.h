@@ -159,6 +159,21 @@ BQ_API int bq_adamw_tensor_bytes(void);
 BQ_API int bq_adamw_multi(const void *table, const void *chunks, int n_chunks, const float *step, float beta1,
                           float beta2, float eps, float grad_clip_value, void *stream);
 
+/* ---- post-processing of the proposals (csrc/nms.hip) -------------------------------------------------------------
+ * Replaces the host loops of lib/ap_helper.py:40-178 parse_predictions (the evaluation path).
+ * bq_box_point_count: count[b][k] = number of points of scene b inside box k (remove_empty_box, ap_helper.py:88-100,
+ *   whose in-hull test over the 8 corners of utils/box_util.py:282-300 get_3d_box is the closed oriented box):
+ *   points f32 (B, N, ld) with xyz first, center / size f32 (B, K, 3) (size = l, w, h), heading f32 (B, K) radians
+ *   (rotation `roty`); cap > 0 clamps the count (the caller only compares with 5).
+ * bq_nms: greedy NMS of every scene (utils/nms.py:40-152 nms_2d_faster / nms_3d_faster / nms_3d_faster_samecls): box
+ *   f32 (B, K, 6) = (x1, y1, z1, x2, y2, z2) (2-D: z1 = 0, z2 = 1), score f32 (B, K), cls i32 (B, K) or NULL, valid u8
+ *   (B, K) or NULL (boxes left out), keep u8 (B, K) out; old_type: overlap = intersection / the other box's volume
+ *   instead of IoU; same_cls: only boxes of the picked box's class are suppressed.  K <= 1024.  Double arithmetic. */
+BQ_API int bq_box_point_count(const float *points, const float *center, const float *size, const float *heading, int *count,
+                              int B, int N, int ld, int K, int cap, void *stream);
+BQ_API int bq_nms(const float *box, const float *score, const int *cls, const unsigned char *valid, unsigned char *keep,
+                  int B, int K, float thresh, int old_type, int same_cls, void *stream);
+
 /* ---- MFMA bf16 GEMM family (csrc/gemm.hip) -----------------------------------------------------------------
  * Replaces every nn.Linear of the fusion half and its autograd: models/vit.py:30-32 (Mlp fc1 / fc2), :51-53 (qkv /
  * proj), timm PatchEmbed as a GEMM over 16x16x3 patches (vit.py:144-145), models/med.py:112-118 (query / key / value),

@@ -125,3 +125,32 @@ def test_twin_init_copies_2d_stream_and_backward_reaches_both():
     assert twin.encoder.layer[0].crossattention.self.key.weight.grad.abs().sum() > 0
     assert twin.encoder.layer_twin[1].crossattention.self.key.weight.grad.abs().sum() > 0
     assert twin.encoder.layer[0].output.LayerNorms[0].weight.grad is None  # unused extra LN (state-dict parity only)
+
+
+def test_grad_tap_is_correct_in_either_backward_order():
+    """fusion_ops.GradTap: the residual-branch gradient parked by tap() must reach x exactly once, whether the tap fires
+    before the consuming linear's backward (the designed order: it then rides on the dX GEMM) or after it (the tap then
+    hands its gradient back to autograd)"""
+    from bridgeqa_amd import fusion_ops as ops
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(8, 8)
+    x0 = torch.randn(5, 8)
+
+    def run(order):
+        x = x0.clone().requires_grad_(True)
+        h = x * 1.0                                       # a non-leaf, as a hidden state is
+        t = ops.GradTap()
+        if order == "designed":                           # consumer first, tap created later -> tap fires first
+            y = ops.linear(h, lin.weight, lin.bias, tap=t)
+            r = ops.tap(h, t)
+        elif order == "reversed":                         # tap created first -> the consumer's backward runs first
+            r = ops.tap(h, t)
+            y = ops.linear(h, lin.weight, lin.bias, tap=t)
+        else:
+            y, r = torch.nn.functional.linear(h, lin.weight, lin.bias), h
+        ((y * y).sum() + (r * 3.0).sum()).backward()
+        return x.grad.clone()
+
+    want = run("plain")
+    assert torch.allclose(run("designed"), want, atol=1e-6)
+    assert torch.allclose(run("reversed"), want, atol=1e-6)

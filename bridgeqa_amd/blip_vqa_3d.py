@@ -21,6 +21,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import fusion_ops as ops
 from .med import BertConfig, BertLMHeadModel, BertModelTwin
 from .vit import create_vit, interpolate_pos_embed
 
@@ -89,6 +90,16 @@ def _mlp_head(d_in, d_hidden, d_out, pdrop):
 
 def _adapter(d_in, d):
     return nn.Sequential(nn.Linear(d_in, d), nn.GELU(), nn.Dropout(0.1), nn.Linear(d, d), nn.GELU(), nn.LayerNorm(d))
+
+
+def _run_adapter(seq, x):
+    """the nn.Sequential of _adapter (blip_vqa_3d.py:113-120 linear_scene_object), evaluated through fusion_ops so that on
+    the bf16 path its two linears run on the MFMA GEMM kernels with the GELU in the epilogue (as nn.Sequential they were
+    fp32 library GEMMs on the critical path); same modules, same state-dict keys"""
+    h = ops.linear(x, seq[0].weight, seq[0].bias, act="gelu")
+    h = seq[2](h)
+    h = ops.linear(h, seq[3].weight, seq[3].bias, act="gelu")
+    return ops.layer_norm(h, seq[5])
 
 
 class BLIP_VQA3D(nn.Module):
@@ -175,7 +186,7 @@ class BLIP_VQA3D(nn.Module):
         if self.use_scene_weight:
             scene_object_mask = scene_object_mask * torch.clamp(self.scene_weight, min=0, max=1)
         if scene_object_embeds is not None:
-            scene_object_embeds = self.linear_scene_object(scene_object_embeds)
+            scene_object_embeds = _run_adapter(self.linear_scene_object, scene_object_embeds)
         out = self.text_encoder(question.input_ids, attention_mask=question.attention_mask,
                                 encoder_hidden_states=image_embeds, encoder_attention_mask=image_atts,
                                 encoder_hidden_states_twin=scene_object_embeds,
@@ -295,6 +306,12 @@ class BLIP_VQA3D(nn.Module):
         # nn.Bilinear as two dense contractions: out[.,o] = sum_ij a_i W[o,i,j] b_j + bias_o.  (torch's bilinear
         # runs one small GEMM pair PER OUTPUT FEATURE on the GPU -- 768 x 3 launches per call.)
         W = self.bilinear_fusion.weight  # (out, r, r)
+        if ops.compute_dtype() == torch.bfloat16 and a.is_cuda:
+            # one contraction over the r * r outer-product features: out = (a (x) b) . W^T with W viewed (out, r*r) -- a
+            # single MFMA GEMM (M = B L rows, K = r^2 = 9216) instead of a 94 MB fp32 intermediate and library GEMMs
+            x = (a.unsqueeze(-1) * b.unsqueeze(-2)).flatten(-2)                  # (B, L, r * r), row-major (i, j) as W
+            out = ops.linear(x, W, self.bilinear_fusion.bias).float()
+            return out + (h2d + h3d) / 2.0
         t = torch.matmul(a, W.permute(1, 0, 2).reshape(W.shape[1], -1))          # (B, L, out * r)
         out = (t.view(*a.shape[:-1], W.shape[0], W.shape[2]) * b.unsqueeze(-2)).sum(-1)
         if self.bilinear_fusion.bias is not None:

@@ -188,6 +188,9 @@ __device__ __forceinline__ void fwd_tile(const unsigned char *s_k, const unsigne
     }
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2) {
+      // the second 32-key block of a segment's last tile may lie wholly past its end (L = 1025: one key in the 17th
+      // tile): wave-uniform skip of its 8 MFMAs and softmax
+      if (last && kb2 == 1 && kt * AT_KB + 32 >= kend) continue;
       const f32x16 acc = EARLY ? early[kb2] : score_block(s_k, qf, kb2, r, h);
       // sc is kept in log2 units when there is a mask (one fma per element) and in raw dot-product units otherwise
       // (the scale is folded into the max once and into the exp2 argument by an fma): fewer VALU ops per pair
@@ -652,6 +655,7 @@ __device__ __forceinline__ void dq_tile(const unsigned char *s_k, const unsigned
     const bool drop = !PLAIN && dm.drop_thresh != 0;
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2) {
+      if (last && kb2 == 1 && kt * AT_KB + 32 >= kend) continue;  // (as in fwd_tile: a block wholly past the end)
       f32x16 sacc = {0}, pacc = {0};
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -892,6 +896,7 @@ __device__ __forceinline__ void dkv_tile(const unsigned char *s_q, const unsigne
     const bool drop = !PLAIN && dm.drop_thresh != 0;
 #pragma unroll
     for (int qb2 = 0; qb2 < 2; ++qb2) {
+      if (last && qb2 == 1 && qt * 64 + 32 >= dm.Lq) continue;  // the last query tile's second block wholly past the end
       f32x16 sacc = {0}, pacc = {0};
 #pragma unroll
       for (int s = 0; s < 4; ++s) {

@@ -22,8 +22,10 @@ class PackedGradReducer(object):
     "first gradient is an assignment" form -- no zero-fill, no accumulate kernel per parameter), and the exchange is
 
         pack  (multi-tensor copy of the fp32 gradients into one flat wire buffer: fp32, or bf16 when asked for)
-        all-reduce of the flat buffer (RCCL, one large message per group)
-        unpack (multi-tensor copy back) and scale by 1 / world
+        all-reduce of the flat buffer (RCCL, one large message per group) -- ReduceOp.AVG where the backend has it
+                 (RCCL does: the division by the world size happens inside the collective), else SUM followed by ONE
+                 scaling kernel over the flat buffer (gloo), never a multi-tensor pass over the fp32 gradients
+        unpack (multi-tensor copy back)
 
     issued on whatever stream is current (PhasedTrainStep uses a communication stream, so the exchange of the
     fusion gradients runs under the image / detector backward)."""
@@ -32,6 +34,7 @@ class PackedGradReducer(object):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.force = False  # run the collective even for a single rank (exercises the RCCL path on a 1-GPU box)
+        self._avg = None    # ReduceOp.AVG available (decided at the first exchange from the group's backend)
         self.params = [p for p in params]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
@@ -46,10 +49,15 @@ class PackedGradReducer(object):
             return
         grads = [p.grad for p in self.params]
         torch._foreach_copy_(self.views, grads)
-        dist.all_reduce(self.comm, op=dist.ReduceOp.SUM, group=self.group)
+        if self._avg is None:
+            self._avg = dist.get_backend(self.group) == "nccl"
+        if self._avg:
+            dist.all_reduce(self.comm, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(self.comm, op=dist.ReduceOp.SUM, group=self.group)
+            if self.world > 1:
+                self.comm.mul_(1.0 / self.world)
         torch._foreach_copy_(grads, self.views)
-        if self.world > 1:
-            torch._foreach_mul_(grads, 1.0 / self.world)
 
     def nbytes_on_wire(self):
         return self.comm.numel() * self.comm.element_size()

@@ -143,20 +143,48 @@ __global__ __launch_bounds__(256) void drop_add_ln_bwd_kernel(const __bf16 *__re
 #pragma unroll
   for (int i = 0; i < 4 * NCH; ++i) { ag[i] = 0.0f; ab[i] = 0.0f; }
   const float invH = 1.0f / (float)a.H;
-  for (int row = grp * Mg + blockIdx.x * 4 + wid; row < (grp + 1) * Mg; row += gridDim.x * 4) {
+  // the loads of row r + stride are issued BEFORE row r is reduced (a wave otherwise has one row = 6 KB in flight and
+  // waits a full memory round trip per row: 2.5 TB/s at the ViT shape)
+  struct Raw {
+    bf16x4 x[NCH], r[NCH], d[NCH], s[NCH];
+    float mean, rstd;
+  };
+  const bf16x4 zero4 = {(__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f};
+  auto fetch = [&](int row, Raw &w) {
+    const long rowoff = (long)row * a.H;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c0 = ch * 256 + lane * 4;
+      w.x[ch] = *reinterpret_cast<const bf16x4 *>(x + rowoff + c0);
+      w.r[ch] = res ? *reinterpret_cast<const bf16x4 *>(res + rowoff + c0) : zero4;
+      w.d[ch] = *reinterpret_cast<const bf16x4 *>(dy + rowoff + c0);
+      w.s[ch] = dsum ? *reinterpret_cast<const bf16x4 *>(dsum + rowoff + c0) : zero4;
+    }
+    w.mean = mean_in[row];
+    w.rstd = rstd_in[row];
+  };
+  const int row_end = (grp + 1) * Mg, stride = gridDim.x * 4;
+  int row = grp * Mg + blockIdx.x * 4 + wid;
+  Raw cur, nxt;
+  if (row < row_end) fetch(row, cur);
+  for (; row < row_end; row += stride) {
+    const bool more = row + stride < row_end;  // wave-uniform
+    if (more) fetch(row + stride, nxt);
     const long rowoff = (long)row * a.H;
     float z[4 * NCH], g[4 * NCH];
-    load_z<NCH>(x, res, rowoff, row, lane, a, seed, z);
-    const float mean = mean_in[row], rstd = rstd_in[row];
     const float ps = ln_path_scale(a, seed, row);
+    const float mean = cur.mean, rstd = cur.rstd;
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      const bf16x4 d = *reinterpret_cast<const bf16x4 *>(dy + rowoff + ch * 256 + lane * 4);
+      const int c0 = ch * 256 + lane * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int i = ch * 4 + j;
-        const float dyv = (float)d[j];
+        float v = (float)cur.x[ch][j];
+        if (a.thresh) v = ln_keep(seed, row, c0 + j, a.thresh) ? v * a.inv_keep : 0.0f;
+        z[i] = v * ps + (float)cur.r[ch][j];       // dropout(x) * path + residual, as load_z
+        const float dyv = (float)cur.d[ch][j];
         z[i] = (z[i] - mean) * rstd;  // z_hat
         g[i] = dyv * gm[i];
         s1 += g[i];
@@ -171,12 +199,10 @@ __global__ __launch_bounds__(256) void drop_add_ln_bwd_kernel(const __bf16 *__re
     for (int ch = 0; ch < NCH; ++ch) {
       const int c0 = ch * 256 + lane * 4;
       bf16x4 ox, orr;
-      bf16x4 ds = {(__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f};
-      if (dsum) ds = *reinterpret_cast<const bf16x4 *>(dsum + rowoff + c0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int i = ch * 4 + j;
-        const float dz = rstd * (g[i] - s1 - z[i] * s2) + (float)ds[j];
+        const float dz = rstd * (g[i] - s1 - z[i] * s2) + (float)cur.s[ch][j];
         orr[j] = (__bf16)dz;
         float dxv = dz * ps;
         if (a.thresh) dxv = ln_keep(seed, row, c0 + j, a.thresh) ? dxv * a.inv_keep : 0.0f;
@@ -185,6 +211,7 @@ __global__ __launch_bounds__(256) void drop_add_ln_bwd_kernel(const __bf16 *__re
       *reinterpret_cast<bf16x4 *>(dx + rowoff + c0) = ox;
       if (dres) *reinterpret_cast<bf16x4 *>(dres + rowoff + c0) = orr;
     }
+    if (more) cur = nxt;
   }
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch)
@@ -469,7 +496,9 @@ static int ln_bwd_launch(const void *x, const void *residual, const float *gamma
   BQ_REQUIRE(p_path == 0.0f || rows_per_sample > 0, BQ_EINVAL, "drop_add_ln_bwd: rows_per_sample");
   LnArgs a{M, H, eps, 1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr,
            (unsigned)((double)p_path * 4294967296.0), 1.0f / (1.0f - p_path), rows_per_sample, groups, gamma2, nullptr};
-  static const int bwd_cap = getenv("BQ_LN_BWD_BLOCKS") ? atoi(getenv("BQ_LN_BWD_BLOCKS")) : 512;
+  // (with the cross-row prefetch: 256 / 384 / 512 / 640 / 1024 / 2048 workgroups -> 33.1 / 32.2 / 35.2 / 40.6 / 41.6 / 60.6 us
+  // at the ViT shape, tools/bench_ln.py: every workgroup ends with 2 H float atomics on the same 2 H addresses)
+  static const int bwd_cap = getenv("BQ_LN_BWD_BLOCKS") ? atoi(getenv("BQ_LN_BWD_BLOCKS")) : 384;
   int blocks = (M / groups + 3) / 4;
   if (blocks > bwd_cap) blocks = bwd_cap;
   hipStream_t st = (hipStream_t)stream;

@@ -83,10 +83,39 @@ __global__ __launch_bounds__(256) void drop_add_ln_fwd_kernel(const __bf16 *__re
   if (zero_out && blockIdx.x == 0)  // the backward's dgamma / dbeta accumulators, cleared here for free
     for (int c = threadIdx.x; c < 2 * a.H; c += 256) zero_out[grp * 2 * a.H + c] = 0.0f;
   const unsigned seed = ln_seed(a);
-  for (int row = grp * Mg + blockIdx.x * 4 + wid; row < (grp + 1) * Mg; row += gridDim.x * 4) {
+  // (as in the backward: the next row's loads are in flight while this row is normalised)
+  const bf16x4 zero4 = {(__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f};
+  bf16x4 cx[NCH], cr[NCH], nx[NCH], nr[NCH];
+  auto fetch = [&](int row, bf16x4 (&fx)[NCH], bf16x4 (&fr)[NCH]) {
+    const long rowoff = (long)row * a.H;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c0 = ch * 256 + lane * 4;
+      fx[ch] = *reinterpret_cast<const bf16x4 *>(x + rowoff + c0);
+      fr[ch] = res ? *reinterpret_cast<const bf16x4 *>(res + rowoff + c0) : zero4;
+    }
+  };
+  const int row_end = (grp + 1) * Mg, stride = gridDim.x * 4;
+  int row0 = grp * Mg + blockIdx.x * 4 + wid;
+  if (row0 < row_end) fetch(row0, cx, cr);
+  for (int row = row0; row < row_end; row += stride) {
+  const bool more = row + stride < row_end;
+  if (more) fetch(row + stride, nx, nr);
   const long rowoff = (long)row * a.H;
   float z[4 * NCH];
-  load_z<NCH>(x, res, rowoff, row, lane, a, seed, z);
+  {
+    const float ps = ln_path_scale(a, seed, row);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c0 = ch * 256 + lane * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = (float)cx[ch][j];
+        if (a.thresh) v = ln_keep(seed, row, c0 + j, a.thresh) ? v * a.inv_keep : 0.0f;
+        z[ch * 4 + j] = v * ps + (float)cr[ch][j];
+      }
+    }
+  }
   float s = 0.0f;
 #pragma unroll
   for (int i = 0; i < 4 * NCH; ++i) s += z[i];
@@ -112,6 +141,10 @@ __global__ __launch_bounds__(256) void drop_add_ln_fwd_kernel(const __bf16 *__re
     }
   }
   if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+  if (more) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) { cx[ch] = nx[ch]; cr[ch] = nr[ch]; }
+  }
   }
 }
 

@@ -24,6 +24,8 @@
 //   and stages (2 DMAs per wave) p0: B1(t+1)        p1: A1(t+1)     p2: A0(t+2)     p3: B0(t+2)
 //   followed by ONE s_waitcnt vmcnt(8): everything older than the last four stages has landed (a stage is consumed
 //   >= 4 phases ~ 2000 cycles after it was issued: HBM misses are covered), then barrier | MFMA | barrier.
+#include <type_traits>
+
 #include "bq_common.h"
 #include "bqhip_fusion.h"
 
@@ -102,6 +104,29 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return fabsf(x) <= 8.0f ? s + x * s * (1.0f - s) * dz : s;
 }
 
+// Both functions above are applied to bf16 VALUES (the stored pre-activation), i.e. they have 65536 possible arguments:
+// the 256-tile kernel tabulates them in LDS once per workgroup (filled with the very functions above while the prologue's
+// DMAs are in flight) and its epilogue gathers instead of evaluating ~25 VALU operations per element with the matrix pipe
+// idle.  Index = [sign][magnitude bits clamped to 2^-16 .. 8]: below 2^-16 Phi and gelu' are 0.5 to 2e-5, at and beyond
+// 8 the functions above are clamped themselves.  4866 entries (19 KB beside the 128 KB of staging / output images).
+constexpr unsigned GELU_TAB_LO = (127 - 16) << 7, GELU_TAB_HI = (127 + 3) << 7;
+constexpr int GELU_TAB_HALF = (int)(GELU_TAB_HI - GELU_TAB_LO) + 1, GELU_TAB_N = 2 * GELU_TAB_HALF;
+template <bool DERIV>
+__device__ __forceinline__ void gelu_tab_fill(float *tab, int tid, int nthreads) {
+  for (int e = tid; e < GELU_TAB_N; e += nthreads) {
+    const unsigned sgn = e >= GELU_TAB_HALF ? 1u : 0u;
+    const unsigned bits = (sgn << 15) | ((unsigned)e - sgn * GELU_TAB_HALF + GELU_TAB_LO);
+    const float x = __uint_as_float(bits << 16);
+    float x2;
+    tab[e] = DERIV ? dgelu_f(x) : gauss_cdf(x, x2);
+  }
+}
+// bits16: the bf16 pattern in the low half of a dword (upper half ignored)
+__device__ __forceinline__ float gelu_tab_at(const float *tab, unsigned bits16) {
+  const unsigned mag = min(max(bits16 & 0x7fffu, GELU_TAB_LO), GELU_TAB_HI) - GELU_TAB_LO;
+  return tab[mag + ((bits16 >> 15) & 1u) * GELU_TAB_HALF];
+}
+
 // value of the lane `n` to the left in the same 16-lane row, 0 where there is none (bound_ctrl): row-prefix sums
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32_add(float v) {
@@ -138,6 +163,8 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char *unit, int sub16
 template <bool P_XC, bool Q_XC, int EPI, bool OUT_F32>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[131072];
+  constexpr bool GTAB = !OUT_F32 && (EPI == EPI_BIAS_GELU || EPI == EPI_DGELU);
+  __shared__ float s_gtab[GTAB ? GELU_TAB_N : 1];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -233,6 +260,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
 
   // ---- prologue: stages 0..5 = A0(0) B0(0) B1(0) A1(0) A0(1) B0(1) ------------------------------------------------
   stage_pair(0, 0); stage_pair(4, 0); stage_pair(6, 0); stage_pair(2, 0); stage_pair(0, 1); stage_pair(4, 1);
+  if (GTAB) gelu_tab_fill<EPI == EPI_DGELU>(s_gtab, tid, 512);  // under the prologue's DMA latency; read after the K loop
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   BQ_BARRIER();
   if (wr == 1) BQ_BARRIER();  // group 1 runs half a phase behind group 0
@@ -389,58 +417,149 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
   const bool want_colsum = EPI != EPI_BIAS_CE && pr.colsum != nullptr;  // (the CE epilogue reuses the field)
 #pragma unroll 1
   for (int pass = 0; pass < npass; ++pass) {
+    if (EPI == EPI_DGELU || EPI == EPI_ADD) {
+      // a second operand `aux` in the accumulator's own map (8 B per lane).  j block outermost: the eight pieces of one j
+      // block are the 16 rows' whole 256-B spans, requested back to back (with i outermost the four 32-B pieces of a line
+      // are requested an epilogue apart and every line came from memory twice: 269 MB read for 130 MB of operands)
+      float cs[8][4];
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      const int i = iw + a * 16 + q4 * 4;
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_CE) && pr.bias != nullptr && i < Ni) load_bias4(pr, i, bv);
-      float cs[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cs[a][r] = 0.f;
+      // bounds-checked buffer loads (rows past Nj read zeros; columns past Ni read the next row -- never stored), the
+      // next j block's eight pieces in flight while this one is processed
+      const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void *)pr.aux, 0, (int)((long)Nj * ldo * 2), 0x00020000);
+      uint2 yy[2][8];  // (the column-sum variant, tests only, fetches one block at a time: 32 more live registers)
+      auto fetch = [&](int b, uint2(&dst)[8]) {
+        const unsigned off = (unsigned)(((jw + b * 16 + row16) * ldo + iw + q4 * 4) * 2);
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+          dst[a] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsX, off + a * 32, 0, 0));
+      };
+      auto sweep = [&](auto wc_tag) {  // (two copies: the column-sum variant keeps its values apart)
+        constexpr bool WC = decltype(wc_tag)::value;
+        if (!WC) fetch(0, yy[0]);
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int j = jw + b * 16 + row16;
-        const bool ok = j < Nj && i < Ni;
-        float v[4];
+        if (WC) fetch(b, yy[0]);
+        else if (b + 1 < 4) fetch(b + 1, yy[(b + 1) & 1]);
+        float gd[8][4];  // gelu'(y): all 32 table gathers of the block in flight before the first use
+        if (EPI == EPI_DGELU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] + bv[r];
-        if (EPI == EPI_DGELU) {  // out = acc * gelu'(y): y read with the accumulator's own map (8 B per lane)
-          bf16x4 y = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-          if (ok) y = *reinterpret_cast<const bf16x4 *>(pr.aux + (long)j * ldo + i);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= dgelu_f((float)y[r]);
-        }
-        if (EPI == EPI_ADD) {  // out = acc + aux: a second gradient of the same tensor rides on the dX GEMM
-          bf16x4 y = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-          if (ok) y = *reinterpret_cast<const bf16x4 *>(pr.aux + (long)j * ldo + i);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)y[r];
+          for (int a = 0; a < 8; ++a) {
+            const uint2 yb = yy[WC ? 0 : (b & 1)][a];
+            gd[a][0] = gelu_tab_at(s_gtab, yb.x);
+            gd[a][1] = gelu_tab_at(s_gtab, yb.x >> 16);
+            gd[a][2] = gelu_tab_at(s_gtab, yb.y);
+            gd[a][3] = gelu_tab_at(s_gtab, yb.y >> 16);
+          }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (float)(__bf16)v[r];  // what is stored (and what a backward differentiates at)
-        if (want_colsum && pass == 0) {
+        for (int a = 0; a < 8; ++a) {
+          const uint2 yb = yy[WC ? 0 : (b & 1)][a];
+          float v[4];
+          if (EPI == EPI_DGELU) {  // out = acc * gelu'(y)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) cs[r] += ok ? v[r] : 0.f;
-        }
-        if (EPI == EPI_BIAS_GELU && pass == 1) {
+            for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * gd[a][r];
+          } else {                 // out = acc + aux: a second gradient of the same tensor rides on the dX GEMM
+            v[0] = acc[a][b][0] + __uint_as_float(yb.x << 16);
+            v[1] = acc[a][b][1] + __uint_as_float(yb.x & 0xffff0000u);
+            v[2] = acc[a][b][2] + __uint_as_float(yb.y << 16);
+            v[3] = acc[a][b][3] + __uint_as_float(yb.y & 0xffff0000u);
+          }
+          if (WC) {
+            const bool ok = j < Nj && iw + a * 16 + q4 * 4 < Ni;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-        }
-        uint2 pk;
-        pk.x = pack_bf16x2(v[0], v[1]);
-        pk.y = pack_bf16x2(v[2], v[3]);
-        *reinterpret_cast<uint2 *>(ep + (b * 16 + row16) * 256 + (((a * 2 + (q4 >> 1)) ^ row16) << 4) + (q4 & 1) * 8) = pk;
-      }
-      if (want_colsum && pass == 0) {
-        // sum over this wave's 64 j: the 16 lanes of a q4 group hold different j of the same four i
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float sacc = cs[r];
-          sacc += dpp_f32_add<0x111>(sacc);
-          sacc += dpp_f32_add<0x112>(sacc);
-          sacc += dpp_f32_add<0x114>(sacc);
-          sacc += dpp_f32_add<0x118>(sacc);
-          if (row16 == 15 && i + r < Ni) atomicAdd(pr.colsum + i + r, sacc);
+            for (int r = 0; r < 4; ++r) cs[a][r] += ok ? (float)(__bf16)v[r] : 0.f;
+          }
+          uint2 pk;
+          pk.x = pack_bf16x2(v[0], v[1]);
+          pk.y = pack_bf16x2(v[2], v[3]);
+          *reinterpret_cast<uint2 *>(ep + (b * 16 + row16) * 256 + (((a * 2 + (q4 >> 1)) ^ row16) << 4) + (q4 & 1) * 8) = pk;
         }
       }
+      };
+      if (want_colsum) sweep(std::true_type{}); else sweep(std::false_type{});
+      if (want_colsum) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float sacc = cs[a][r];
+            sacc += dpp_f32_add<0x111>(sacc);
+            sacc += dpp_f32_add<0x112>(sacc);
+            sacc += dpp_f32_add<0x114>(sacc);
+            sacc += dpp_f32_add<0x118>(sacc);
+            const int i = iw + a * 16 + q4 * 4 + r;
+            if (row16 == 15 && i < Ni) atomicAdd(pr.colsum + i, sacc);
+          }
+      }
+    } else {
+      // straight-line copies per (pass, column sums wanted): the runtime tests used to cut the sweep into ~10 basic blocks
+      // per i block and the table gathers could not be batched
+      auto sweep = [&](auto pass_tag, auto wc_tag) {
+        constexpr int PASS = decltype(pass_tag)::value;
+        constexpr bool WC = decltype(wc_tag)::value;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+          const int i = iw + a * 16 + q4 * 4;
+          float bv[4] = {0.f, 0.f, 0.f, 0.f};
+          if ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_CE) && pr.bias != nullptr && i < Ni) load_bias4(pr, i, bv);
+          float cs[4] = {0.f, 0.f, 0.f, 0.f};
+          float vv[4][4];
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const int j = jw + b * 16 + row16;
+            const bool ok = j < Nj && i < Ni;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vv[b][r] = (float)(__bf16)(acc[a][b][r] + bv[r]);  // what is stored (and what a backward differentiates at)
+            if (WC) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) cs[r] += ok ? vv[b][r] : 0.f;
+            }
+          }
+          if (EPI == EPI_BIAS_GELU && PASS == 1) {  // x * Phi(x), Phi of the bf16 value from the LDS table
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {  // eight gathers in flight, then their uses (the scheduler serialises them otherwise)
+              float ph[2][4];
+#pragma unroll
+              for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ph[b][r] = gelu_tab_at(s_gtab, __float_as_uint(vv[2 * h + b][r]) >> 16);
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vv[2 * h + b][r] *= ph[b][r];
+            }
+          }
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            uint2 pk;
+            pk.x = pack_bf16x2(vv[b][0], vv[b][1]);
+            pk.y = pack_bf16x2(vv[b][2], vv[b][3]);
+            *reinterpret_cast<uint2 *>(ep + (b * 16 + row16) * 256 + (((a * 2 + (q4 >> 1)) ^ row16) << 4) + (q4 & 1) * 8) = pk;
+          }
+          if (WC) {
+            // sum over this wave's 64 j: the 16 lanes of a q4 group hold different j of the same four i
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float sacc = cs[r];
+              sacc += dpp_f32_add<0x111>(sacc);
+              sacc += dpp_f32_add<0x112>(sacc);
+              sacc += dpp_f32_add<0x114>(sacc);
+              sacc += dpp_f32_add<0x118>(sacc);
+              if (row16 == 15 && i + r < Ni) atomicAdd(pr.colsum + i + r, sacc);
+            }
+          }
+        }
+      };
+      typedef std::integral_constant<int, 0> P0;
+      typedef std::integral_constant<int, 1> P1;
+      if (pass == 1) sweep(P1{}, std::false_type{});
+      else if (want_colsum) sweep(P0{}, std::true_type{});
+      else sweep(P0{}, std::false_type{});
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __bf16 *dst = (pass == 1) ? reinterpret_cast<__bf16 *>(pr.out2) : outb;
@@ -1036,6 +1155,8 @@ extern "C" int bq_gemm_bf16(const bq_gemm_desc *d, int n, int flags, int epilogu
       BQ_REQUIRE(epilogue != EPI_BIAS_GELU || s.out2, BQ_EINVAL, "bq_gemm_bf16: BIAS_GELU needs out2");
       BQ_REQUIRE(epilogue != EPI_DGELU || s.aux, BQ_EINVAL, "bq_gemm_bf16: DGELU needs aux");
       BQ_REQUIRE(epilogue != EPI_ADD || s.aux, BQ_EINVAL, "bq_gemm_bf16: ADD needs aux");
+      BQ_REQUIRE((epilogue != EPI_ADD && epilogue != EPI_DGELU) || ((long)s.Nj + 256) * s.ldo * 2 < 0x7FFFFFFFL, BQ_EINVAL,
+                 "bq_gemm_bf16: aux larger than 2 GB (problem %d)", done);
       const long pb = pxc ? ((long)(s.Kc - 1) * s.ldp + s.Ni) * 2 : ((long)(s.Ni - 1) * s.ldp + s.Kc) * 2;
       const long qb = qxc ? ((long)(s.Kc - 1) * s.ldq + s.Nj) * 2 : ((long)(s.Nj - 1) * s.ldq + s.Kc) * 2;
       const int tj = tile == 256 ? 256 : tile, ti = tile == 256 ? 256 : 64;

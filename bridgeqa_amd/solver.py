@@ -1,5 +1,5 @@
 """Per-iteration hygiene of the training loop around the hot path -- SURVEY.md §8f rank 2 (reference lib/solver.py:463-595
-`Solver._feed`): the two places where the reference's loop stalls the GPU every iteration although no kernel needs it.
+`Solver._feed`): the places where the reference's loop stalls the GPU every iteration although no kernel needs it.
 
 1. The running log.  `_feed` keeps 27 scalars per iteration (`_running_log`, solver.py:487-517), and for each of them does
    `.item()` (a device->host sync), `torch.tensor(value).cuda()` (a host->device copy) and, under DDP, its own
@@ -11,6 +11,10 @@
    before the forward.  `BatchStager` owns the static device buffers `pipeline.PhasedTrainStep` replays its graphs on
    (and the `next_batch` set its geometry prefetch reads), stages the host batch through pinned memory and copies on a
    side stream, so the upload of step n+1 runs under step n.
+
+3. The per-iteration evaluation.  `_eval` (solver.py:437-461) runs eval_helper.get_eval -- 160 host round trips at batch 16
+   -- and `.item()`s every accuracy.  bridgeqa_amd.eval_helper.get_eval(host_outputs=False) keeps everything on the device;
+   `collect_running_log` gathers the 27 entries as device values for the ONE copy of item 1.
 
 What the reference also has and this path drops on purpose: `torch.autograd.set_detect_anomaly(True)` around every
 forward / backward (solver.py:524) and `CUDA_LAUNCH_BLOCKING=1` (scripts/train.py) -- debugging aids that serialise the
@@ -63,6 +67,32 @@ class PackedRunningLog(object):
         self._host.copy_(self._buf, non_blocking=False)  # the one synchronisation of the iteration's logging
         out = (self._host / float(world)).tolist()
         return dict(zip(self.keys, out))
+
+
+def collect_running_log(data_dict):
+    """The running-log entries `_compute_loss` (solver.py:424-435) and `_eval` (:437-461) take from the data_dict of one
+    iteration, WITHOUT their `.item()` / `np.mean` round trips: values stay device tensors (or python numbers where the
+    dict holds them), ready for PackedRunningLog.reduce.  Works on the output of eval_helper.get_eval with
+    host_outputs=False (device `ref_acc` / IoU rates) as well as with the reference's host lists."""
+    def mean(v):
+        if torch.is_tensor(v):
+            return v.float().mean()
+        return float(sum(v) / max(len(v), 1)) if isinstance(v, (list, tuple)) else float(v)
+
+    log = {}
+    for k in ("ref_loss", "answer_loss", "lang_loss", "objectness_loss", "vote_loss", "box_loss", "sem_cls_loss",
+              "align_loss", "mae_loss", "loss", "lang_acc", "obj_acc", "pos_ratio", "neg_ratio"):
+        if k in data_dict:
+            log[k] = data_dict[k]
+    if "ref_acc" in data_dict:
+        log["ref_acc"] = mean(data_dict["ref_acc"])
+    for k, v in data_dict.items():
+        if "answer_acc" in k:
+            log[k] = v
+    for src, dst in (("ref_iou_rate_0.25", "iou_rate_0.25"), ("ref_iou_rate_0.5", "iou_rate_0.5")):
+        if src in data_dict:
+            log[dst] = mean(data_dict[src])
+    return log
 
 
 def _walk(d, prefix=()):

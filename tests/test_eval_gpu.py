@@ -1,0 +1,45 @@
+"""eval_helper.get_eval on the device: the post-processing variant of the golden (parse_predictions -> HIP point-count / NMS
+kernels), the device-resident form, and the claim that it synchronises with the host exactly once (or never)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_eval_cpu import GOLD, check_variant, load_variant  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("v", [0, 1, 2, 3])
+@pytest.mark.parametrize("host", [True, False])
+def test_get_eval_device_matches_reference(v, host):
+    from bridgeqa_amd.eval_helper import get_eval
+    z = np.load(GOLD)
+    d, cfg, kw = load_variant(z, v, "cuda:0")
+    out = get_eval(d, cfg, host_outputs=host, **kw)
+    check_variant(z, v, out, host)
+
+
+def test_get_eval_device_form_never_synchronises():
+    from bridgeqa_amd.eval_helper import get_eval
+    from bridgeqa_amd.solver import PackedRunningLog, collect_running_log
+    z = np.load(GOLD)
+    d, cfg, kw = load_variant(z, 0, "cuda:0")
+    get_eval(dict(d), cfg, host_outputs=False, **kw)            # warm-up: constants cached on the device
+    d, cfg, kw = load_variant(z, 0, "cuda:0")
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        out = get_eval(d, cfg, host_outputs=False, **kw)
+        log = collect_running_log(out)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert all(torch.is_tensor(v) and v.is_cuda for k, v in log.items())
+    vals = PackedRunningLog("cuda:0").reduce(log)               # the one copy of the iteration
+    np.testing.assert_allclose(vals["ref_acc"], float(np.mean(z["v0_out_ref_acc"])), atol=1e-6)
+    np.testing.assert_allclose(vals["iou_rate_0.25"], float(z["v0_out_ref_iou_rates"][0]), atol=1e-6)
+    np.testing.assert_allclose(vals["answer_acc_at10_2d3d"], float(z["v0_out_answer_acc_at10_2d3d"]), atol=1e-6)
+    np.testing.assert_allclose(vals["obj_acc"], float(z["v0_out_obj_acc"]), atol=1e-6)

@@ -94,3 +94,24 @@ def test_batch_stager_protocol_cpu():
     bad["point_clouds"] = torch.randn(2, 51, 7)
     with pytest.raises(ValueError):
         st.stage(bad)
+
+
+def test_collect_running_log_matches_the_reference_mapping():
+    """solver.py:424-461: which data_dict entries land under which running-log key"""
+    from bridgeqa_amd.solver import RUNNING_LOG_KEYS, PackedRunningLog, collect_running_log
+    d = {"loss": torch.tensor(3.0), "ref_loss": torch.tensor(0.5), "answer_loss": torch.tensor(1.5), "lang_loss": torch.tensor(0.25),
+         "objectness_loss": torch.tensor(0.1), "vote_loss": torch.tensor(0.2), "box_loss": torch.tensor(0.3),
+         "sem_cls_loss": torch.tensor(0.4), "align_loss": torch.tensor(0.0), "mae_loss": torch.tensor(0.0),
+         "ref_acc": [1.0, 0.0, 0.0, 1.0], "lang_acc": torch.tensor(0.75), "answer_acc_at1": torch.tensor(0.5),
+         "answer_acc_at10": torch.tensor(1.0), "obj_acc": torch.tensor(0.9), "pos_ratio": torch.tensor(0.3),
+         "neg_ratio": torch.tensor(0.6), "ref_iou_rate_0.25": 0.5, "ref_iou_rate_0.5": 0.25, "ref_iou": [0.1, 0.6],
+         "pred_bboxes": None}
+    log = collect_running_log(d)
+    assert set(log) <= set(RUNNING_LOG_KEYS)
+    assert log["ref_acc"] == 0.5 and log["iou_rate_0.25"] == 0.5 and log["iou_rate_0.5"] == 0.25
+    vals = PackedRunningLog("cpu").reduce(log)
+    assert vals["loss"] == 3.0 and vals["answer_acc_at10"] == 1.0 and vals["answer_acc_at1_2d"] == 0.0
+    # device form of get_eval: ref_acc / rates are tensors
+    d["ref_acc"], d["ref_iou_rate_0.25"] = torch.tensor([1.0, 0.0, 0.0, 0.0]), torch.tensor(0.75, dtype=torch.float64)
+    vals = PackedRunningLog("cpu").reduce(collect_running_log(d))
+    assert vals["ref_acc"] == 0.25 and vals["iou_rate_0.25"] == 0.75

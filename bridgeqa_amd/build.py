@@ -51,6 +51,13 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        # a kernel whose body does not compile in the HOST pass loses its launch stub without a diagnostic (deferred
+        # device-code errors) and the library then fails at dlopen on the GPU box: catch it here
+        syms = subprocess.run(["nm", "-D", "--undefined-only", LIB], capture_output=True, text=True).stdout
+        lost = [l.split()[-1] for l in syms.splitlines() if "__device_stub__" in l]
+        if lost:
+            os.remove(LIB)
+            raise RuntimeError("kernels without a host launch stub (host-pass compile error in their body): %s" % ", ".join(lost))
     return LIB
 
 

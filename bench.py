@@ -346,6 +346,8 @@ def main():
         # same buffers (a training loop passes the buffers its loader fills one step ahead)
         pipe = PhasedTrainStep(model, batch, det_loss, fusion_loss, opt, use_graphs=use_graph, next_batch=batch,
                                eager_phases=("geometry",), reserve_cus=int(os.environ.get("BQ_RESERVE_CUS", "0")),
+                               det_cus=int(os.environ.get("BQ_DET_CUS", "0")),
+                               det_cus_spread=os.environ.get("BQ_DET_SPREAD") == "1",
                                split_fusion_tail=os.environ.get("BQ_SPLIT_TAIL") == "1",
                                split_fusion_opt=os.environ.get("BQ_SPLIT_OPT") == "1")
         eager_step = pipe.eager_step

@@ -43,13 +43,19 @@ import torch
 from . import fusion_ops as ops
 
 
-def _cu_masked_stream(device, lo, hi, total=256):
-    """a HIP stream whose kernels may only run on CUs [lo, hi) (hipExtStreamCreateWithCUMask), as a torch stream"""
+def _cu_masked_stream(device, lo, hi, total=256, spread=False, priority=None):
+    """a HIP stream whose kernels may only run on CUs [lo, hi) (hipExtStreamCreateWithCUMask), as a torch stream;
+    spread: the hi - lo CUs are taken evenly from the eight 32-bit words of the mask instead of contiguously"""
     import ctypes
     hip = ctypes.CDLL("libamdhip64.so")
     words = (ctypes.c_uint32 * (total // 32))()
-    for i in range(lo, hi):
-        words[i // 32] |= (1 << (i % 32))
+    if spread:
+        per = max(1, (hi - lo) // (total // 32))
+        for w in range(total // 32):
+            words[w] = (1 << per) - 1
+    else:
+        for i in range(lo, hi):
+            words[i // 32] |= (1 << (i % 32))
     h = ctypes.c_void_p()
     with torch.cuda.device(device):
         rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), total // 32, words)
@@ -61,7 +67,8 @@ def _cu_masked_stream(device, lo, hi, total=256):
 class PhasedTrainStep(object):
     def __init__(self, model, batch, det_loss, fusion_loss, optimizer=None, use_graphs=True, det_priority=0,
                  grad_hook=None, next_batch=None, prefetch_geometry=None, eager_phases=(), reducers=None,
-                 reserve_cus=0, split_fusion_tail=False, split_fusion_opt=False, main_priority=-1):
+                 reserve_cus=0, split_fusion_tail=False, split_fusion_opt=False, main_priority=-1, det_cus=0,
+                 det_cus_spread=False):
         """model: ScanQAHotPath (use_blip=True, train mode); batch: static device tensors (replayed in place);
         det_loss(data_dict) -> scalar over detector outputs; fusion_loss(data_dict) -> scalar over blip_loss /
         fused_feat; optimizer: stepped at the end of the step (None: the caller steps);
@@ -111,7 +118,10 @@ class PhasedTrainStep(object):
         self.s_main = torch.cuda.Stream(device=dev, priority=int(main_priority))
         self.s_img = _cu_masked_stream(dev, int(reserve_cus), 256) if reserve_cus else self.s_main
         self.e_img_fwd = torch.cuda.Event()
-        self.s_det = torch.cuda.Stream(device=dev, priority=int(det_priority))
+        # det_cus: N > 0 confines the detector stream to N CUs (its HBM-streaming backward kernels then cannot take the
+        # memory system away from the image backward's GEMMs on the other 256 - N)
+        self.s_det = (_cu_masked_stream(dev, 0, int(det_cus), spread=bool(det_cus_spread)) if det_cus
+                      else torch.cuda.Stream(device=dev, priority=int(det_priority)))
         self.e_det_fwd, self.e_fused, self.e_det_bwd, self.e_done = (torch.cuda.Event() for _ in range(4))
         # the fusion phase's tail on its own stream: weight gradients (whenever they are deferred), and the optimizer
         # step of the fusion parameters when the optimizer can step subsets (optim.FusedAdamW) and no grad_hook needs

@@ -66,6 +66,32 @@ def test_attn_bwd_vs_torch_autograd_fp32(dev, B, H, L):
         assert err < 3e-2, (name, err)
 
 
+@pytest.mark.parametrize("B,H,L", [(2, 3, 129), (1, 2, 257), (1, 2, 1025), (2, 2, 160), (1, 2, 161)])
+def test_attn_ragged_last_block_rows_and_keys(dev, B, H, L):
+    """L = 128 n + r (a ViT's class token: r = 1): the rows / keys of the ragged last block are 1 in ~1000 of the tensors
+    the whole-tensor tests above norm over, so they are checked on their own here."""
+    from bridgeqa_amd import fusion_ops, _ext
+    g = torch.Generator().manual_seed(7 * L)
+    qkv = (torch.randn(B, L, 3, H, 64, generator=g)).to(dev).to(torch.bfloat16).requires_grad_(True)
+    go = torch.randn(B, L, H, 64, generator=g).to(dev).to(torch.bfloat16)
+    out = fusion_ops.attention_packed(qkv, 0.125)
+    out.backward(go)
+    _, lse = _ext.attn_fwd(qkv.detach()[:, :, 0], qkv.detach()[:, :, 1], qkv.detach()[:, :, 2], 0.125)
+    ref_in = qkv.detach().float().requires_grad_(True)
+    want, want_lse = ref_attention(ref_in[:, :, 0], ref_in[:, :, 1], ref_in[:, :, 2], 0.125)
+    want.backward(go.float())
+    r = L % 128 if L % 128 else 128
+    rows = slice(L - r, L)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    assert rel(out.detach().float()[:, rows], want.detach()[:, rows]) < 2e-2
+    assert (lse[:, :, rows] - want_lse.detach()[:, :, rows]).abs().max() < 2e-3
+    got = qkv.grad.float()
+    for i, name in enumerate(("dq", "dk", "dv")):
+        e_tail = rel(got[:, rows, i], ref_in.grad[:, rows, i])
+        e_rest = rel(got[:, :L - r, i], ref_in.grad[:, :L - r, i])
+        assert e_tail < 3e-2 and e_rest < 3e-2, (name, e_tail, e_rest)
+
+
 def test_vit_block_bf16_fused_vs_fp32_composition(dev):
     """A ViT block through the fused path (bf16) against the same block in fp32 reference composition."""
     from bridgeqa_amd import fusion_ops, vit

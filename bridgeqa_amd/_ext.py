@@ -671,6 +671,49 @@ def nms(box, score, thresh, cls=None, valid=None, old_type=False, same_cls=False
     return keep.bool()
 
 
+# ---- multiview projection (csrc/projection.hip) ---------------------------------------------------------
+_lib.bq_project_points.argtypes = [_vp] * 4 + [_i] * 4 + [_f] * 7 + [_vp]
+_lib.bq_project_points.restype = ctypes.c_int
+_lib.bq_fuse_point_features.argtypes = [_vp] * 3 + [_i] * 5 + [_vp]
+_lib.bq_fuse_point_features.restype = ctypes.c_int
+
+
+def project_points(points, depth, frames, image_dims, fx, fy, cx, cy, depth_min, depth_max, accuracy):
+    """points f32 (N, 3), depth f32 (F, H, W), frames f32 (F, 40) -> i32 (F, N): pixel index y * W + x or -1"""
+    for t, n in ((points, "points"), (depth, "depth"), (frames, "frames")):
+        if not t.is_cuda:
+            raise RuntimeError("%s: CPU not supported" % n)
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("%s must be a contiguous float32 tensor" % n)
+    W, H = int(image_dims[0]), int(image_dims[1])
+    F, N = depth.shape[0], points.shape[0]
+    if depth.numel() != F * W * H or frames.shape != (F, 40) or points.shape[1] != 3:
+        raise RuntimeError("project_points: shapes %s %s %s" % (tuple(points.shape), tuple(depth.shape), tuple(frames.shape)))
+    with torch.cuda.device(points.device):
+        pix = torch.empty(F, N, dtype=torch.int32, device=points.device)
+        _check(_lib.bq_project_points(_p(points), _p(depth), _p(frames), _p(pix), F, N, W, H, float(fx), float(fy), float(cx),
+                                      float(cy), float(depth_min), float(depth_max), float(accuracy), _stream()),
+               "project_points")
+    return pix
+
+
+def fuse_point_features(pix, feat, maxpool):
+    """pix i32 (F, N), feat f32 (F, H*W, C) pixel-major -> f32 (N, C)"""
+    if not (pix.is_cuda and feat.is_cuda):
+        raise RuntimeError("fuse_point_features: CPU not supported")
+    if pix.dtype != torch.int32 or feat.dtype != torch.float32 or not pix.is_contiguous() or not feat.is_contiguous():
+        raise RuntimeError("fuse_point_features: pix must be contiguous int32, feat contiguous float32")
+    F, N = pix.shape
+    if feat.dim() != 3 or feat.shape[0] != F:
+        raise RuntimeError("fuse_point_features: feat must be (F, H*W, C)")
+    HW, C = feat.shape[1], feat.shape[2]
+    with torch.cuda.device(pix.device):
+        out = torch.empty(N, C, dtype=torch.float32, device=pix.device)
+        _check(_lib.bq_fuse_point_features(_p(pix), _p(feat), _p(out), F, N, HW, C, int(bool(maxpool)), _stream()),
+               "fuse_point_features")
+    return out
+
+
 # ---- MFMA bf16 GEMM family (csrc/gemm.hip) ------------------------------------------------------------
 GEMM_P_XC, GEMM_Q_XC, GEMM_OUT_F32 = 1, 2, 4
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_BIAS_CE, EPI_ADD = 0, 1, 2, 3, 4, 5

@@ -174,6 +174,23 @@ BQ_API int bq_box_point_count(const float *points, const float *center, const fl
 BQ_API int bq_nms(const float *box, const float *score, const int *cls, const unsigned char *valid, unsigned char *keep,
                   int B, int K, float thresh, int old_type, int same_cls, void *stream);
 
+/* ---- multiview projection (csrc/projection.hip) ---------------------------------------------------------------------
+ * Replaces the per-frame host loop of lib/projection.py:194-252 ProjectionHelper.compute_projection / :254-276 project
+ * as driven by scripts/project_multiview_features.py:103-202 (offline preprocessing).
+ * bq_project_points: pix[f][n] (i32, F x N) = y * W + x of the pixel of frame f that sees point n, or -1.  points f32
+ *   (N, 3); depth f32 (F, H * W) metres; frames f32 (F, 40) = per frame: world-to-camera 4x4 row-major (16), the six
+ *   inward frustum-plane normals (18), frustum corner 2 and corner 4 (6) -- computed by the host as the reference does.
+ *   Tests in the reference's order: inside the six planes (round(100 d) / 100 < 0), pinhole projection rounded half to
+ *   even, inside the W x H image, depth_min <= depth <= depth_max, |depth - z| <= accuracy.  fp32.
+ * bq_fuse_point_features: out f32 (N, C) from pix and the frames' features feat f32 (F, H * W, C) (pixel-major), frames
+ *   in order: maxpool = 0 -- an all-zero point takes the vector of the frame that sees it; maxpool = 1 -- a vector that is
+ *   not all zero fills an all-zero point and is max-ed into a filled one.  C = 64, 128 or 256. */
+BQ_API int bq_project_points(const float *points, const float *depth, const float *frames, int *pix, int F, int N, int W,
+                             int H, float fx, float fy, float cx, float cy, float depth_min, float depth_max,
+                             float accuracy, void *stream);
+BQ_API int bq_fuse_point_features(const int *pix, const float *feat, float *out, int F, int N, int HW, int C, int maxpool,
+                                  void *stream);
+
 /* ---- MFMA bf16 GEMM family (csrc/gemm.hip) -----------------------------------------------------------------
  * Replaces every nn.Linear of the fusion half and its autograd: models/vit.py:30-32 (Mlp fc1 / fc2), :51-53 (qkv /
  * proj), timm PatchEmbed as a GEMM over 16x16x3 patches (vit.py:144-145), models/med.py:112-118 (query / key / value),

@@ -419,8 +419,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
   for (int pass = 0; pass < npass; ++pass) {
     if (EPI == EPI_DGELU || EPI == EPI_ADD) {
       // a second operand `aux` in the accumulator's own map (8 B per lane).  j block outermost: the eight pieces of one j
-      // block are the 16 rows' whole 256-B spans, requested back to back (with i outermost the four 32-B pieces of a line
-      // are requested an epilogue apart and every line came from memory twice: 269 MB read for 130 MB of operands)
+      // block are the 16 rows' whole 256-B spans, requested back to back and one block ahead of their use (with i
+      // outermost the four 32-B pieces of a line were requested an epilogue apart, each load waited for on the spot)
       float cs[8][4];
 #pragma unroll
       for (int a = 0; a < 8; ++a)

@@ -408,7 +408,7 @@ class BertEncoderTwin(BertEncoder):
             lins += [l.intermediate.dense, l.output.dense]
         return ops.twin_kernel_ok(hs, lins)
 
-    def _twin_level(self, i, hs, mask2, enc2d, enc3d, mask2d, mask3d, layernorm_idx, want=False):
+    def _twin_level(self, i, hs, mask2, enc2d, enc3d, mask2d, mask3d, layernorm_idx, want=False, hoist=None):
         """one level of BOTH streams on the stacked states hs (2B, L, D) (rows [0,B) = 2D stream through layer[i], rows
         [B,2B) = 3D stream through layer_twin[i]); the arithmetic per stream is BertLayer.forward's (self-attention ->
         cross-attention over cat(fixed tokens, other stream's previous states) -> FFN, post-LN; reference
@@ -420,7 +420,8 @@ class BertEncoderTwin(BertEncoder):
         scale = 1.0 / math.sqrt(hd)
         p_att = sa.dropout.p if self.training else 0.0
         # keys / values of the cross-attentions come from the PREVIOUS states of the other stream
-        mix2d, mix3d = ops.twin_mix(enc2d, enc3d, hs)
+        if hoist is None:
+            mix2d, mix3d = ops.twin_mix(enc2d, enc3d, hs)
         # (t1-t3: the residual-branch gradient of each sub-block's input rides on the dX GEMM of its first linear)
         t1, t2, t3 = ops.GradTap(), ops.GradTap(), ops.GradTap()
         qkv = ops.twin_multi_linear(hs, (sa.query, sa.key, sa.value), (sb.query, sb.key, sb.value), tap=t1)
@@ -432,12 +433,22 @@ class BertEncoderTwin(BertEncoder):
                                               b.attention.output.LayerNorm, a.attention.output.dropout.p, self.training)
         ca, cb = a.crossattention.self, b.crossattention.self
         q = ops.twin_linear(att, ca.query, cb.query, tap=t2).view(B2, L, H, hd)
-        kv2d, kv3d = ops.twin_multi_linear_var(mix2d, mix3d, (ca.key, ca.value), (cb.key, cb.value))
         p_c = ca.dropout.p if self.training else 0.0
-        c = ops.twin_cross_attention(q, kv2d.view(B, mix2d.shape[1], 2, H, hd), kv3d.view(B, mix3d.shape[1], 2, H, hd),
-                                     scale, p_c, mask2d, mask3d, return_probs=want)
-        if want:
-            c, p_c2d, p_c3d = c
+        if hoist is not None:
+            # BQ_TWO_SEGMENT_KV=1: the fixed tokens' K/V of this level are a column block of ONE hoisted projection (no
+            # cat, no per-level K/V GEMM over the image tokens, its gradient written in place), the other stream's
+            # states go through the same weights as a 20-row second key segment
+            h2d, h3d, slot = hoist
+            c = torch.cat((ops.attention_q_kv2(q[:B], h2d.kv(slot), h2d.tail_kv(slot, hs[B:]), scale, p_c, mask2d,
+                                               sink=(h2d, slot)),
+                           ops.attention_q_kv2(q[B:], h3d.kv(slot), h3d.tail_kv(slot, hs[:B]), scale, p_c, mask3d,
+                                               sink=(h3d, slot))), dim=0)
+        else:
+            kv2d, kv3d = ops.twin_multi_linear_var(mix2d, mix3d, (ca.key, ca.value), (cb.key, cb.value))
+            c = ops.twin_cross_attention(q, kv2d.view(B, mix2d.shape[1], 2, H, hd), kv3d.view(B, mix3d.shape[1], 2, H, hd),
+                                         scale, p_c, mask2d, mask3d, return_probs=want)
+            if want:
+                c, p_c2d, p_c3d = c
         h = ops.twin_linear(c.reshape(B2, L, D), a.crossattention.output.dense, b.crossattention.output.dense)
         att = ops.twin_dropout_add_layer_norm(h, ops.tap(att, t2), a.crossattention.output.LayerNorm,
                                               b.crossattention.output.LayerNorm, a.crossattention.output.dropout.p,
@@ -489,7 +500,7 @@ class BertEncoderTwin(BertEncoder):
             want = _wants(output_attentions, i, layers[-1])
             twin = self.layer_twin[i] if i < self.num_hidden_layers_twin else None
             key_only = lambda m: m is None or (m.dim() == 4 and m.shape[1] == 1 and m.shape[2] == 1)
-            if (not hoisted_layers and mode == "multimodal" and attention_mask is not None
+            if ((not hoisted_layers or (i in slot_of and not want)) and mode == "multimodal" and attention_mask is not None
                     and key_only(attention_mask) and key_only(encoder_attention_mask)
                     and key_only(encoder_attention_mask_twin)
                     and self._pairable(i, ops._c(hidden_states) if stacked is None else stacked)):
@@ -499,7 +510,8 @@ class BertEncoderTwin(BertEncoder):
                     mask2 = torch.cat((attention_mask, attention_mask), dim=0)
                     ops.prime_masks(mask2)
                 stacked = self._twin_level(i, stacked, mask2, enc2d, enc3d, encoder_attention_mask,
-                                           encoder_attention_mask_twin, layernorm_idx, want)
+                                           encoder_attention_mask_twin, layernorm_idx, want,
+                                           hoist=(h2d, h3d, slot_of[i]) if i in slot_of else None)
                 if want:
                     stacked, self_att, cross_att = stacked
                     all_self_attentions = all_self_attentions + (self_att,)

@@ -348,6 +348,27 @@ def test_hot_path_with_qa_heads_and_full_get_loss(dev):
             p = dict(m.named_parameters())[name]
             assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0, name
         assert dict(m.named_parameters())["enc_list_o.0.mhatt.linear_q.weight"].grad is None   # never called upstream either
+        # ... and the iteration's evaluation + log (lib/solver.py:437-461, :547-556) without a host round trip until the
+        # ONE copy of the packed log: get_eval on the device, 27 entries through PackedRunningLog
+        from bridgeqa_amd.eval_helper import get_eval
+        from bridgeqa_amd.solver import RUNNING_LOG_KEYS, PackedRunningLog, collect_running_log
+        dd = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in dd.items()}
+        dd["ref_box_label"] = torch.nn.functional.one_hot(torch.zeros(B, dtype=torch.long, device=dev), dd["center_label"].shape[1])
+        dd["answer_scores"] = torch.randn(B, 40, generator=g).to(dev)
+        dd["answer_cats"] = torch.nn.functional.one_hot(torch.randint(0, 40, (B,), generator=g), 40).float().to(dev)
+        get_eval(dict(dd), bench.det_config(), use_lang_classifier=True, host_outputs=False)     # warm-up (cached constants)
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            ev = get_eval(dd, bench.det_config(), use_reference=True, use_lang_classifier=True, host_outputs=False)
+            log = collect_running_log(ev)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        vals = PackedRunningLog(dev).reduce(log)
+        assert set(vals) == set(RUNNING_LOG_KEYS)
+        assert abs(vals["loss"] - loss.item()) < 1e-4 * max(1.0, abs(loss.item())) and 0.0 <= vals["ref_acc"] <= 1.0
+        assert 0.0 <= vals["iou_rate_0.25"] <= 1.0 and vals["iou_rate_0.5"] <= vals["iou_rate_0.25"]
+        assert 0.0 <= vals["obj_acc"] <= 1.0 and 0.0 <= vals["answer_acc_at10"] <= 1.0
     finally:
         ops.set_compute_dtype(prev)
 

@@ -256,7 +256,25 @@ class BLIP_VQA3D(nn.Module):
             return loss, self.fuse_2d3d(q2d, q3d), q_mask
 
         if inference == "generate":
-            raise NotImplementedError("beam-search generate is inference-only (SURVEY.md §8f rank 3)")
+            # blip_vqa_3d.py:394-417: ten beams per sample, slots 0-4 attend to the 2D question states, slots 5-9 to the 3D
+            # ones (beam search itself: generation.py -- the reference's comes from an unpinned `transformers`, parity
+            # unpinned); answers decoded with the tokenizer, or the token ids up to [SEP] when no vocabulary is loaded
+            num_beams = 5
+            question_states = concat_repeat(q2d.last_hidden_state, q3d.last_hidden_state, num_beams)
+            question_atts = torch.repeat_interleave(q_mask, 2 * num_beams, dim=0)
+            bos_ids = torch.full((B, 1), self.tokenizer.bos_token_id, dtype=torch.long, device=dev)
+            outputs = self.text_decoder.generate(input_ids=bos_ids, max_length=20, min_length=1, num_beams=num_beams * 2,
+                                                 eos_token_id=self.tokenizer.sep_token_id,
+                                                 pad_token_id=self.tokenizer.pad_token_id,
+                                                 encoder_hidden_states=question_states,
+                                                 encoder_attention_mask=question_atts)
+            if hasattr(self.tokenizer, "decode"):
+                answers = [self.tokenizer.decode(o, skip_special_tokens=True) for o in outputs]
+            else:
+                special = {self.tokenizer.pad_token_id, self.tokenizer.sep_token_id, self.tokenizer.bos_token_id,
+                           self.tokenizer.enc_token_id}
+                answers = [[t for t in o.tolist() if t not in special] for o in outputs]
+            return answers, self.fuse_2d3d(q2d, q3d), q_mask
 
         # ---- rank answers: one-step shortlist + full re-score (blip_vqa_3d.py:418-500) ----------
         assert answer is not None, "answer must be specified if use text decoder (free-form answer mode)"

@@ -826,3 +826,39 @@ class BertLMHeadModel(BertPreTrainedModel):
         return ModelOutput(loss=lm_loss, logits=logits, past_key_values=outputs.past_key_values,
                            hidden_states=outputs.hidden_states, attentions=outputs.attentions,
                            cross_attentions=outputs.cross_attentions)
+
+    # ---- generation (reference med.py:1447-1470 + HF GenerationMixin.generate, see generation.py) ----------------------
+    def prepare_inputs_for_generation(self, input_ids, past=None, attention_mask=None, **model_kwargs):
+        if attention_mask is None:
+            attention_mask = input_ids.new_ones(input_ids.shape)
+        if past is not None:
+            input_ids = input_ids[:, -1:]
+        return {"input_ids": input_ids, "attention_mask": attention_mask, "past_key_values": past,
+                "encoder_hidden_states": model_kwargs.get("encoder_hidden_states", None),
+                "encoder_attention_mask": model_kwargs.get("encoder_attention_mask", None), "is_decoder": True}
+
+    def _reorder_cache(self, past, beam_idx):
+        return tuple(tuple(t.index_select(0, beam_idx) for t in layer_past) for layer_past in past)
+
+    @torch.no_grad()
+    def generate(self, input_ids, max_length=20, min_length=0, num_beams=1, eos_token_id=None, pad_token_id=None,
+                 length_penalty=1.0, early_stopping=False, return_scores=False, **model_kwargs):
+        """beam search as `transformers` v4.15 `generate` runs it for a decoder-only model (generation.py; parity
+        unpinned): input_ids (B, L0) is repeated num_beams times per sample; encoder_hidden_states / encoder_attention_mask
+        must already have B * num_beams rows (the caller chooses what every beam slot attends to)."""
+        from .generation import beam_search
+        if eos_token_id is None or pad_token_id is None:
+            raise ValueError("generate needs eos_token_id and pad_token_id")
+        ids = input_ids.repeat_interleave(num_beams, dim=0)
+        enc = model_kwargs.get("encoder_hidden_states")
+        if enc is not None and enc.shape[0] != ids.shape[0]:
+            raise ValueError("encoder_hidden_states must have batch * num_beams = %d rows, got %d" % (ids.shape[0], enc.shape[0]))
+
+        def step(cur, past):
+            inp = self.prepare_inputs_for_generation(cur, past=past, **model_kwargs)
+            out = self(**inp, use_cache=True, return_dict=True)
+            return out.logits[:, -1, :], out.past_key_values
+
+        seq, scores = beam_search(step, self._reorder_cache, ids, num_beams, max_length, eos_token_id, pad_token_id,
+                                  min_length=min_length, length_penalty=length_penalty, early_stopping=early_stopping)
+        return (seq, scores) if return_scores else seq

@@ -1,0 +1,167 @@
+"""generation.beam_search / BertLMHeadModel.generate (the restated HF v4.15 beam search; parity unpinned -- see
+bridgeqa_amd/generation.py) checked against things that need no reference: greedy decoding, an exhaustive search, and a
+teacher-forced re-scoring of what it returns.  fp32 torch composition on the CPU; tests/test_generate_gpu.py runs the
+device path."""
+import itertools
+import math
+
+import pytest
+import torch
+
+PAD, EOS, BOS = 0, 2, 1
+
+
+def make_decoder(vocab, dev, seed=0):
+    from bridgeqa_amd import med
+    cfg = med.BertConfig(hidden_size=64, num_attention_heads=4, intermediate_size=128, num_hidden_layers=2, vocab_size=vocab,
+                         max_position_embeddings=32, encoder_width=64, pad_token_id=PAD)
+    cfg.add_cross_attention = True
+    torch.manual_seed(seed)
+    dec = med.BertLMHeadModel(config=cfg).to(dev).eval()
+    with torch.no_grad():   # random init gives nearly flat logits; sharpen them so that the search has something to find
+        dec.cls.predictions.bias.copy_(torch.randn(vocab, device=dev) * 1.5)
+        dec.cls.predictions.decoder.weight.mul_(8.0)
+    return dec
+
+
+def logprobs_of(dec, seq, enc, enc_mask):
+    """teacher-forced log p(seq[t] | seq[:t]) without any cache"""
+    out = dec(seq[None, :], attention_mask=torch.ones(1, len(seq), dtype=torch.long, device=seq.device),
+              encoder_hidden_states=enc[None], encoder_attention_mask=enc_mask[None], return_dict=True)
+    lp = torch.log_softmax(out.logits[0].float(), -1)
+    return [float(lp[t - 1, seq[t]]) for t in range(1, len(seq))]
+
+
+def run_greedy_equivalence(dev):
+    V, B, Lenc = 50, 3, 6
+    dec = make_decoder(V, dev)
+    g = torch.Generator().manual_seed(3)
+    enc = torch.randn(B, Lenc, 64, generator=g).to(dev)
+    em = torch.ones(B, Lenc, dtype=torch.long, device=dev)
+    em[1, 4:] = 0
+    bos = torch.full((B, 1), BOS, dtype=torch.long, device=dev)
+    seq, scores = dec.generate(bos, max_length=9, min_length=1, num_beams=1, eos_token_id=EOS, pad_token_id=PAD,
+                               encoder_hidden_states=enc, encoder_attention_mask=em, return_scores=True)
+    for b in range(B):
+        cur = [BOS]
+        total = 0.0
+        while len(cur) < 9:
+            out = dec(torch.tensor([cur], device=dev), attention_mask=torch.ones(1, len(cur), dtype=torch.long, device=dev),
+                      encoder_hidden_states=enc[b:b + 1], encoder_attention_mask=em[b:b + 1], return_dict=True)
+            lp = torch.log_softmax(out.logits[0, -1].float(), -1)
+            nxt = int(lp.argmax())
+            total += float(lp[nxt])
+            if nxt == EOS:
+                break
+            cur.append(nxt)
+        got = [t for t in seq[b].tolist() if t != PAD]
+        want = cur + ([EOS] if len(cur) < 9 else [])
+        assert got == want, (b, got, want)
+        assert abs(float(scores[b]) - total / len(cur)) < 1e-3 * max(1.0, abs(total))
+
+
+def run_exhaustive(dev, length_penalty):
+    """V = 6 tokens, at most 3 generated: with more beams than there are candidates the search is exhaustive, so the winner
+    must be the best hypothesis under the scorer's own rule sum_logprobs / len(prefix) ** length_penalty"""
+    V, MAXLEN = 6, 4
+    dec = make_decoder(V, dev, seed=5)
+    g = torch.Generator().manual_seed(4)
+    enc = torch.randn(5, 64, generator=g).to(dev)
+    em = torch.ones(5, dtype=torch.long, device=dev)
+    K = V ** (MAXLEN - 1) + 1
+    bos = torch.full((1, 1), BOS, dtype=torch.long, device=dev)
+    seq, score = dec.generate(bos, max_length=MAXLEN, min_length=1, num_beams=K, eos_token_id=EOS, pad_token_id=PAD,
+                              length_penalty=length_penalty, encoder_hidden_states=enc[None].expand(K, -1, -1).contiguous(),
+                              encoder_attention_mask=em[None].expand(K, -1).contiguous(), return_scores=True)
+    best, best_seq = -math.inf, None
+    toks = [t for t in range(V) if t != EOS]
+    for n in range(0, MAXLEN):                       # n non-eos tokens after [BOS]
+        for body in itertools.product(toks, repeat=n):
+            prefix = [BOS] + list(body)
+            if len(prefix) < MAXLEN:                 # ... then eos: a finished hypothesis, normalised by the prefix length
+                full = prefix + [EOS]
+                lps = logprobs_of(dec, torch.tensor(full, device=dev), enc, em)
+                s = sum(lps) / len(prefix) ** length_penalty
+            else:                                    # ... or it runs into max_length: an open beam at the end
+                lps = logprobs_of(dec, torch.tensor(prefix, device=dev), enc, em)
+                s = sum(lps) / len(prefix) ** length_penalty
+                full = prefix
+            if s > best:
+                best, best_seq = s, full
+    got = [t for t in seq[0].tolist() if t != PAD]
+    assert got == best_seq, (got, best_seq)
+    assert abs(float(score[0]) - best) < 1e-4 * max(1.0, abs(best))
+
+
+def test_one_beam_is_greedy_decoding():
+    run_greedy_equivalence(torch.device("cpu"))
+
+
+@pytest.mark.parametrize("length_penalty", [1.0, 0.0])
+def test_wide_beam_search_is_exhaustive(length_penalty):
+    run_exhaustive(torch.device("cpu"), length_penalty)
+
+
+def test_returned_score_is_the_sequences_own_and_slots_keep_their_encoder_states():
+    """ten beams, the first five slots of every sample on one set of encoder states and the last five on another
+    (blip_vqa_3d.py:396-401): the reported score must be reproducible by a step-by-step replay that follows the winning
+    hypothesis through its slots -- i.e. the cache reorder and the fixed slot -> encoder-state map are what they claim"""
+    dev = torch.device("cpu")
+    V, B, Lenc, K = 40, 2, 5, 10
+    dec = make_decoder(V, dev, seed=2)
+    g = torch.Generator().manual_seed(9)
+    a, b = torch.randn(B, Lenc, 64, generator=g), torch.randn(B, Lenc, 64, generator=g)
+    from bridgeqa_amd.blip_vqa_3d import concat_repeat
+    enc = concat_repeat(a, b, K // 2)
+    em = torch.ones(B * K, Lenc, dtype=torch.long)
+    bos = torch.full((B, 1), BOS, dtype=torch.long)
+    seq, score = dec.generate(bos, max_length=8, min_length=1, num_beams=K, eos_token_id=EOS, pad_token_id=PAD,
+                              encoder_hidden_states=enc, encoder_attention_mask=em, return_scores=True)
+    assert seq.shape[0] == B and seq.shape[1] <= 8 and bool((seq[:, 0] == BOS).all())
+    assert bool(torch.isfinite(score).all()) and bool((score < 0).all())
+    # identical encoder states in both halves: the score is then checkable by plain teacher forcing
+    enc_same = concat_repeat(a, a, K // 2)
+    seq2, score2 = dec.generate(bos, max_length=8, min_length=1, num_beams=K, eos_token_id=EOS, pad_token_id=PAD,
+                                encoder_hidden_states=enc_same, encoder_attention_mask=em, return_scores=True)
+    for i in range(B):
+        s = [t for t in seq2[i].tolist() if t != PAD]
+        lps = logprobs_of(dec, torch.tensor(s), a[i], torch.ones(Lenc, dtype=torch.long))
+        n_prefix = len(s) - 1 if s[-1] == EOS else len(s)
+        assert abs(sum(lps) / n_prefix - float(score2[i])) < 1e-3 * max(1.0, abs(float(score2[i]))), (i, s)
+
+
+def run_blip_generate(dev):
+    """BLIP_VQA3D.forward(inference='generate') (blip_vqa_3d.py:394-417): B answers (token ids without a vocabulary), the
+    fused question states of the rank path, the question mask; deterministic"""
+    import numpy as np
+    import conftest
+    from bridgeqa_amd.blip_vqa_3d import BLIP_VQA3D, SyntheticTokenizer
+    from bridgeqa_amd.med import BertConfig
+    from golden_util import fill_params
+    cfg = BertConfig(num_hidden_layers=2, vocab_size=200, max_position_embeddings=64)
+    m = BLIP_VQA3D(med_config=cfg, image_size=64, num_answers=10, use_text_decoder=True, share_decoder=True, scene_size=32,
+                   tokenizer=SyntheticTokenizer(0, 102, 198, 199))
+    fill_params(m, "blip_model.")
+    m = m.to(dev).eval()
+    gm = dict(np.load(__import__("os").path.join(conftest.GOLDEN, "fusion_med.npz")))
+    gb = dict(np.load(__import__("os").path.join(conftest.GOLDEN, "fusion_blip.npz")))
+    t = lambda g_, k: torch.from_numpy(g_[k]).to(dev)
+    q = {"input_ids": t(gm, "tw_ids"), "attention_mask": t(gm, "tw_am")}
+    outs = []
+    with torch.no_grad():
+        for _ in range(2):
+            outs.append(m(t(gb, "bl_img"), q, None, train=False, inference="generate", scene_object_embeds=t(gb, "bl_obj"),
+                          scene_object_mask=t(gm, "tw_om"), data_dict={}))
+    answers, fused, qmask = outs[0]
+    B = q["input_ids"].shape[0]
+    assert len(answers) == B and all(isinstance(a, list) and len(a) <= 19 for a in answers)
+    assert all(0 <= tok < 200 and tok not in (0, 102, 198, 199) for a in answers for tok in a)
+    assert answers == outs[1][0] and torch.equal(fused, outs[1][1])
+    assert fused.shape[0] == B and torch.equal(qmask.cpu(), torch.from_numpy(gb["bl_qmask"]))
+    return fused, gb
+
+
+def test_blip_vqa3d_generate_mode():
+    fused, gb = run_blip_generate(torch.device("cpu"))
+    from test_fusion_cpu import close
+    close(fused, gb["bl_fused_eval"], 1e-4, 1e-4)     # the same fused states as the rank path of the reference golden

@@ -409,7 +409,7 @@ def key_mask_log2_two(mask, B, Lk1, Lk2):
     return m
 
 
-def attn_fwd2(q, k1, v1, k2, v2, scale, mask_log2=None, p_drop=0.0, seed=0, seed_tensor=None):
+def attn_fwd2(q, k1, v1, k2, v2, scale, mask_log2=None, p_drop=0.0, seed=0, seed_tensor=None, out=None):
     """attn_fwd over the keys cat(k1, k2) / values cat(v1, v2) without forming them (Lq <= 32).  k1 / v1 (B, Lk1, H, 64)
     views with equal strides, k2 / v2 (B, Lk2, H, 64) likewise; mask_log2 from key_mask_log2_two."""
     for t, n in ((q, "q"), (k1, "k1"), (v1, "v1"), (k2, "k2"), (v2, "v2")):
@@ -421,7 +421,10 @@ def attn_fwd2(q, k1, v1, k2, v2, scale, mask_log2=None, p_drop=0.0, seed=0, seed
     Lk1, Lk2 = k1.shape[1], k2.shape[1]
     Lkp = _pad64(Lk1) + _pad64(Lk2)
     with torch.cuda.device(q.device):
-        out = torch.empty(B, Lq, H, D, dtype=torch.bfloat16, device=q.device)
+        if out is None:
+            out = torch.empty(B, Lq, H, D, dtype=torch.bfloat16, device=q.device)
+        elif out.shape != (B, Lq, H, D) or out.dtype != torch.bfloat16 or not out.is_contiguous():
+            raise RuntimeError("attn_fwd2: out must be a contiguous bf16 (B, Lq, H, 64) tensor")
         lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
         _check(_lib.bq_attn_fwd2(_p(q), _p(k1), _p(v1), _p(k2), _p(v2), _p(out), _p(lse), _p(mask_log2), B, H, Lq, Lk1,
                                  Lk2, Lkp, *_bhd_strides(q), *_bhd_strides(k1), *_bhd_strides(k2), *_bhd_strides(out),

@@ -1314,6 +1314,13 @@ class _HoistedKVFn(torch.autograd.Function):
         G2 = G.view(-1, G.shape[-1])
         x2 = xb.reshape(-1, xb.shape[-1])
         dx = _dx2(G2, hold.wc).view(xb.shape).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
+        if _defer_ok(G2, x2) and not hold.tails:
+            # inside a deferred-wgrad scope the [key_i; value_i] blocks are ONE parked record (the flush splits its rows
+            # evenly over the 2 n weights); the per-level tail projections parked theirs from _TailKVFn.backward
+            k = ctx.k
+            _park(G2, x2, [sa_w for sa in hold.selfattns for sa_w in (sa.key.weight, sa.value.weight)],
+                  [sa_b for sa in hold.selfattns for sa_b in (sa.key.bias, sa.value.bias)])
+            return (dx, None) + (None,) * (2 * k)
         dw, db = _dw_db(G2, x2, True, True)
         n = dw.shape[0] // hold.n
         for slot, g2, t2 in hold.tails:  # the per-layer second segments went through the same weights
@@ -1346,7 +1353,12 @@ class _TailKVFn(torch.autograd.Function):
         g2 = g.reshape(-1, g.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
-        ctx.hold.tails.append((ctx.i, g2, tb.reshape(-1, tb.shape[-1])))
+        t2 = tb.reshape(-1, tb.shape[-1])
+        if _defer_ok(g2, t2):
+            sa = ctx.hold.selfattns[ctx.i]
+            _park(g2, t2, [sa.key.weight, sa.value.weight], [sa.key.bias, sa.value.bias])
+        else:
+            ctx.hold.tails.append((ctx.i, g2, t2))
         return _dx2(g2, w).view(tb.shape).to(ctx.t_dtype), None, None
 
 
@@ -1401,6 +1413,58 @@ class _QKV2Attention(torch.autograd.Function):
                        dkv1[:, :, 0], dkv1[:, :, 1], dkv2[:, :, 0], dkv2[:, :, 1], mask_log2 if has_mask else None,
                        p_drop, seed, st if has_st else None)
         return dq, dkv1, dkv2, None, None, None, None
+
+
+class _TwinQKV2Attention(torch.autograd.Function):
+    """the two cross-attentions of one twin level over hoisted projections: queries stacked (2B, L, H, 64); stream g reads
+    the keys / values cat(kv1_g (hoisted, strided), kv2_g (B, L2, 2, H, 64)); context and dq come back stacked (no cat, no
+    slice gradients), d(kv1_g) goes straight into its hoisted gradient buffer"""
+
+    @staticmethod
+    def forward(ctx, q, kva1, kva2, kvb1, kvb2, scale, ma, mb, p_drop, sink_a, sink_b):
+        from . import _ext
+        B = q.shape[0] // 2
+        out = torch.empty_like(q)
+        seeds, lses = [], []
+        for g, (k1, k2, m) in enumerate(((kva1, kva2, ma), (kvb1, kvb2, mb))):
+            seed, st = _seed_args(p_drop, q.device)
+            _, lse = _ext.attn_fwd2(q[g * B:(g + 1) * B], k1[:, :, 0], k1[:, :, 1], k2[:, :, 0], k2[:, :, 1], scale, m, p_drop,
+                                    seed, st, out=out[g * B:(g + 1) * B])
+            seeds.append(seed)
+            lses.append(lse)
+        e = q.new_empty(0)
+        ctx.save_for_backward(q, kva1, kva2, kvb1, kvb2, out, lses[0], lses[1], ma if ma is not None else e,
+                              mb if mb is not None else e, st if st is not None else e)
+        ctx.cfg = (scale, p_drop, seeds, ma is not None, mb is not None, st is not None, sink_a, sink_b)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import _ext
+        q, kva1, kva2, kvb1, kvb2, out, lsa, lsb, ma, mb, st = ctx.saved_tensors
+        scale, p_drop, seeds, has_ma, has_mb, has_st, sink_a, sink_b = ctx.cfg
+        B = q.shape[0] // 2
+        go = grad_out if grad_out.is_contiguous() else grad_out.contiguous()
+        dq = torch.empty_like(q)
+        d2a, d2b = torch.empty_like(kva2), torch.empty_like(kvb2)
+        d1a, d1b = sink_a[0].grad_view(sink_a[1], kva1), sink_b[0].grad_view(sink_b[1], kvb1)
+        for g, (k1, k2, d1, d2, lse, m, has_m) in enumerate(((kva1, kva2, d1a, d2a, lsa, ma, has_ma),
+                                                             (kvb1, kvb2, d1b, d2b, lsb, mb, has_mb))):
+            sl = slice(g * B, (g + 1) * B)
+            _ext.attn_bwd2(q[sl], k1[:, :, 0], k1[:, :, 1], k2[:, :, 0], k2[:, :, 1], out[sl], lse, go[sl], scale, dq[sl],
+                           d1[:, :, 0], d1[:, :, 1], d2[:, :, 0], d2[:, :, 1], m if has_m else None, p_drop, seeds[g],
+                           st if has_st else None)
+        return dq, d1a, d2a, d1b, d2b, None, None, None, None, None, None
+
+
+def twin_cross_attention2(q, h2d, h3d, slot, tail2d, tail3d, scale, dropout_p, mask2d, mask3d):
+    """stacked twin cross-attention over (hoisted projection slot, per-level tail) key segments; q (2B, L, H, 64) contiguous
+    bf16; tail2d / tail3d (B, L2, 2, H, 64) from HoistedKV.tail_kv"""
+    B = q.shape[0] // 2
+    kva1, kvb1 = h2d.kv(slot), h3d.kv(slot)
+    ma = _mask_log2_two(mask2d, B, kva1.shape[1], tail2d.shape[1])
+    mb = _mask_log2_two(mask3d, B, kvb1.shape[1], tail3d.shape[1])
+    return _TwinQKV2Attention.apply(q, kva1, tail2d, kvb1, tail3d, scale, ma, mb, float(dropout_p), (h2d, slot), (h3d, slot))
 
 
 def two_segment_ok(q, kv1, kv2, mask):

@@ -439,10 +439,9 @@ class BertEncoderTwin(BertEncoder):
             # cat, no per-level K/V GEMM over the image tokens, its gradient written in place), the other stream's
             # states go through the same weights as a 20-row second key segment
             h2d, h3d, slot = hoist
-            c = torch.cat((ops.attention_q_kv2(q[:B], h2d.kv(slot), h2d.tail_kv(slot, hs[B:]), scale, p_c, mask2d,
-                                               sink=(h2d, slot)),
-                           ops.attention_q_kv2(q[B:], h3d.kv(slot), h3d.tail_kv(slot, hs[:B]), scale, p_c, mask3d,
-                                               sink=(h3d, slot))), dim=0)
+            hs3, hs2 = ops.twin_split(hs)[::-1]   # (3D-stream states, 2D-stream states): backward = one cat
+            c = ops.twin_cross_attention2(q, h2d, h3d, slot, h2d.tail_kv(slot, hs3), h3d.tail_kv(slot, hs2), scale, p_c,
+                                          mask2d, mask3d)
         else:
             kv2d, kv3d = ops.twin_multi_linear_var(mix2d, mix3d, (ca.key, ca.value), (cb.key, cb.value))
             c = ops.twin_cross_attention(q, kv2d.view(B, mix2d.shape[1], 2, H, hd), kv3d.view(B, mix3d.shape[1], 2, H, hd),

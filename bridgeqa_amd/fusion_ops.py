@@ -12,6 +12,8 @@ parity tests use.
 """
 import math
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -310,22 +312,84 @@ def flush_deferred_wgrad():
     flush_deferred_items(take_deferred_wgrad())
 
 
+_PLAN_CACHE = {}
+_PLAN_WGRAD = [os.environ.get("BQ_WGRAD_PLAN", "1") != "0"]
+
+
+def plan_big_launches(tiles, cus, max_problems=36, moved_cost=0.011):
+    """How to issue the 256 x 256-tile weight-gradient problems of one flush.  Every tile of such a launch runs the full
+    contraction (all rows of the batch), so a launch costs ceil(tiles / cus) rounds of equal length -- 1296 tiles on 256 CUs
+    are 5.06 rounds, i.e. SIX, for sixteen tiles.  Returns (groups, moved): `groups` = lists of problem indices, one grouped
+    launch each (<= max_problems problems, the kernel-argument limit), `moved` = indices of small problems sent to the
+    64 x 64-tile kernel instead, chosen so that rounds + moved_cost * (tiles moved) is smallest.  The problems come in a
+    handful of distinct sizes, so the search walks the counts per size of the second launch (a few thousand cases, cached)."""
+    key = (tuple(tiles), cus, max_problems)
+    hit = _PLAN_CACHE.get(key)
+    if hit is not None:
+        return hit
+    n = len(tiles)
+    rounds = lambda t: -(-t // cus) if t > 0 else 0
+    order = sorted(range(n), key=lambda k: tiles[k])
+    default = [list(range(n))[i:i + max_problems] for i in range(0, n, max_problems)]
+    best = (sum(rounds(sum(tiles[k] for k in g)) for g in default), default, [])
+    if n <= 2 * max_problems:
+        for m in range(0, min(6, n)):
+            moved = order[:m]
+            rest = order[m:]
+            cost_moved = moved_cost * sum(tiles[k] for k in moved)
+            by_size = {}
+            for k in rest:
+                by_size.setdefault(tiles[k], []).append(k)
+            sizes = sorted(by_size)
+            if len(sizes) > 5:
+                break
+            total, cnt = sum(tiles[k] for k in rest), len(rest)
+            combos = [[]]
+            for sz in sizes:
+                combos = [c + [x] for c in combos for x in range(len(by_size[sz]) + 1)]
+                if len(combos) > 50000:
+                    combos = None
+                    break
+            if combos is None:
+                break
+            for c in combos:
+                nb = sum(c)
+                if nb > max_problems or cnt - nb > max_problems:
+                    continue
+                tb = sum(x * sz for x, sz in zip(c, sizes))
+                cost = rounds(tb) + rounds(total - tb) + cost_moved
+                if cost < best[0] - 1e-9:
+                    gb = [k for x, sz in zip(c, sizes) for k in by_size[sz][:x]]
+                    ga = [k for x, sz in zip(c, sizes) for k in by_size[sz][x:]]
+                    best = (cost, [g for g in (ga, gb) if g], list(moved))
+    plan = (best[1], best[2])
+    _PLAN_CACHE[key] = plan
+    return plan
+
+
 def flush_deferred_items(items):
     if not items:
         return
     from . import _ext
     flags = _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32
     dws = [None] * len(items)
-    for tile, pick in ((256, lambda m: m >= _BIG_ROWS), (64, lambda m: m < _BIG_ROWS)):
-        idx = [k for k, it in enumerate(items) if pick(it[0].shape[0])]
-        if not idx:
-            continue
-        probs = []
-        for k in idx:
-            g2, x2 = items[k][0], items[k][1]
-            dws[k] = torch.empty(g2.shape[1], x2.shape[1], dtype=torch.float32, device=g2.device)
-            probs.append(dict(P=x2, Q=g2, out=dws[k]))
-        _ext.gemm_grouped(probs, flags, _ext.EPI_NONE, tile)
+    big = [k for k, it in enumerate(items) if it[0].shape[0] >= _BIG_ROWS]
+    small = [k for k, it in enumerate(items) if it[0].shape[0] < _BIG_ROWS]
+    groups = [big] if big else []
+    if big and _PLAN_WGRAD[0]:
+        tiles = [-(-items[k][0].shape[1] // 256) * -(-items[k][1].shape[1] // 256) for k in big]
+        cus = torch.cuda.get_device_properties(items[big[0]][0].device).multi_processor_count
+        plan_groups, moved = plan_big_launches(tiles, cus)
+        groups = [[big[j] for j in g] for g in plan_groups]
+        small = small + [big[j] for j in moved]
+    for tile, idx_groups in ((256, groups), (64, [small] if small else [])):
+        for idx in idx_groups:
+            probs = []
+            for k in idx:
+                g2, x2 = items[k][0], items[k][1]
+                dws[k] = torch.empty(g2.shape[1], x2.shape[1], dtype=torch.float32, device=g2.device)
+                probs.append(dict(P=x2, Q=g2, out=dws[k]))
+            _ext.gemm_grouped(probs, flags, _ext.EPI_NONE, tile)
     with_b = [k for k, it in enumerate(items) if it[3] is not None]
     dbs = dict(zip(with_b, _ext.colsum_grouped([items[k][0] for k in with_b]))) if with_b else {}
     for k, (g2, x2, ws, bs) in enumerate(items):

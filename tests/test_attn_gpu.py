@@ -472,6 +472,36 @@ def test_deferred_grouped_weight_gradients_are_value_neutral(dev):
         ops.set_compute_dtype(prev_dt)
 
 
+def test_deferred_weight_gradients_with_a_launch_plan_that_moves_problems(dev):
+    """22 problems of 12 tiles = 264 tiles: 2 rounds on 256 CUs; the plan sends one to the 64 x 64-tile kernel (252 tiles,
+    one round).  Whatever the plan, every dW / db must equal the inline computation."""
+    from bridgeqa_amd import fusion_ops as ops
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    n = max(2, cus // 12 + 1)
+    g = torch.Generator().manual_seed(5)
+    lins = [torch.nn.Linear(768, 1024).to(dev) for _ in range(n)]
+    xs = [torch.randn(1024, 768, generator=g).to(dev).to(torch.bfloat16) for _ in range(n)]
+    prev = ops.set_compute_dtype(torch.bfloat16)
+    try:
+        def run(deferred):
+            for l in lins:
+                l.zero_grad(set_to_none=True)
+            if deferred:
+                ops.begin_deferred_wgrad()
+            for l, x in zip(lins, xs):
+                ops.linear(x, l.weight, l.bias).float().square().sum().backward()
+            if deferred:
+                ops.flush_deferred_wgrad()
+            return [(l.weight.grad.clone(), l.bias.grad.clone()) for l in lins]
+        inline, parked = run(False), run(True)
+        groups, moved = ops.plan_big_launches([12] * n, cus)
+        assert len(moved) >= 1 or cus != 256          # (on a 256-CU part the plan does move a problem)
+        for (dw0, db0), (dw1, db1) in zip(inline, parked):
+            assert (dw1 - dw0).norm() <= 1e-5 * dw0.norm() and (db1 - db0).norm() <= 1e-5 * db0.norm()
+    finally:
+        ops.set_compute_dtype(prev)
+
+
 def test_deferred_batched_weight_gradients_match_inline(dev):
     """fusion_ops.begin/flush_deferred_wgrad: parked dW / db of same-shape linears computed as one batched GEMM + one
     reduction == computed per layer inside the backward (fp32 accumulation either way; kernels differ -> 1e-3)."""

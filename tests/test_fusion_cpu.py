@@ -154,3 +154,22 @@ def test_grad_tap_is_correct_in_either_backward_order():
     want = run("plain")
     assert torch.allclose(run("designed"), want, atol=1e-6)
     assert torch.allclose(run("reversed"), want, atol=1e-6)
+
+
+def test_weight_gradient_launch_plan_saves_the_partial_round():
+    """fusion_ops.plan_big_launches: 1296 tiles of equal length on 256 CUs are six rounds as (972 | 324), five when three
+    9-tile problems go to the small-tile kernel and the rest is cut (765 | 504)"""
+    from bridgeqa_amd.fusion_ops import plan_big_launches
+    tiles = [36, 36, 9, 27] * 12                      # fc2, fc1, proj, qkv of 12 ViT blocks (256 x 256 tiles)
+    groups, moved = plan_big_launches(tiles, 256)
+    seen = sorted([k for g in groups for k in g] + moved)
+    assert seen == list(range(len(tiles))) and all(len(g) <= 36 for g in groups)
+    rounds = sum(-(-sum(tiles[k] for k in g) // 256) for g in groups)
+    assert rounds == 5 and sorted(tiles[k] for k in moved) == [9, 9, 9]
+    # nothing to gain: one launch that is already whole rounds / a single short launch
+    assert plan_big_launches([32] * 8, 256) == ([list(range(8))], [])
+    assert plan_big_launches([18] * 12, 256) == ([list(range(12))], [])
+    # more problems than two launches can hold: the plain cut
+    many = [4] * 80
+    groups, moved = plan_big_launches(many, 256)
+    assert moved == [] and [len(g) for g in groups] == [36, 36, 8]

@@ -103,3 +103,22 @@ def test_get_eval_cat_rand_picks_a_candidate():
     assert pick.shape == cand.shape and bool(((pick == 0) | (pick == 1)).all())
     assert bool((pick.sum(1) == cand.any(1).float()).all())            # one pick where there is a candidate, none otherwise
     assert bool((pick * (~cand).float() == 0).all())                   # ... and it is a candidate
+
+
+def test_get_eval_single_sample_and_no_objects_predicted():
+    """B = 1, and a batch where no proposal is predicted as an object (pred_mask all zero): the reference then divides
+    0 / 0 in sem_acc (eval_helper.py:317) -- NaN there, NaN here -- and the arg-max over an all-zero vector picks proposal 0"""
+    from bridgeqa_amd.eval_helper import get_eval
+    z = np.load(GOLD)
+    d, cfg, kw = load_variant(z, 0, "cpu")
+    one = {k: (v[:1].clone() if torch.is_tensor(v) else v) for k, v in d.items()}
+    out = get_eval(one, cfg, **kw)
+    assert len(out["ref_acc"]) == 1 and len(out["ref_iou"]) == 1 and out["pred_bboxes"][0].shape == (8, 3)
+    np.testing.assert_allclose(out["ref_iou"][0], z["v0_out_ref_iou"][0], atol=1e-9)
+    d, cfg, kw = load_variant(z, 0, "cpu")
+    d["objectness_scores"] = torch.stack([torch.ones_like(d["objectness_scores"][..., 0]),
+                                          -torch.ones_like(d["objectness_scores"][..., 1])], -1)
+    out = get_eval(d, cfg, **kw)
+    assert float(out["pred_mask"].sum()) == 0.0 and bool(torch.isnan(out["sem_acc"]))
+    assert out["ref_acc"] == [0.0] * len(out["ref_acc"]) or all(a in (0.0, 1.0) for a in out["ref_acc"])
+    assert torch.equal(out["cluster_ref"], torch.zeros_like(out["cluster_ref"]))

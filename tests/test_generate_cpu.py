@@ -165,3 +165,24 @@ def test_blip_vqa3d_generate_mode():
     fused, gb = run_blip_generate(torch.device("cpu"))
     from test_fusion_cpu import close
     close(fused, gb["bl_fused_eval"], 1e-4, 1e-4)     # the same fused states as the rank path of the reference golden
+
+
+def test_generate_runs_into_max_length_and_respects_min_length():
+    """a decoder that never prefers [SEP] fills max_length tokens and the sequence is returned without an eos slot beyond
+    it; with min_length above the prompt length, eos cannot be the first generated token (MinLengthLogitsProcessor)"""
+    dev = torch.device("cpu")
+    V, B, K = 30, 2, 4
+    dec = make_decoder(V, dev, seed=7)
+    with torch.no_grad():
+        dec.cls.predictions.bias[EOS] = -50.0
+    enc = torch.randn(B * K, 4, 64)
+    em = torch.ones(B * K, 4, dtype=torch.long)
+    bos = torch.full((B, 1), BOS, dtype=torch.long)
+    seq = dec.generate(bos, max_length=6, min_length=1, num_beams=K, eos_token_id=EOS, pad_token_id=PAD,
+                       encoder_hidden_states=enc, encoder_attention_mask=em)
+    assert seq.shape == (B, 6) and bool((seq != EOS).all()) and bool((seq != PAD).all())
+    with torch.no_grad():
+        dec.cls.predictions.bias[EOS] = 50.0              # now eos wins everywhere it is allowed
+    seq = dec.generate(bos, max_length=6, min_length=3, num_beams=K, eos_token_id=EOS, pad_token_id=PAD,
+                       encoder_hidden_states=enc, encoder_attention_mask=em)
+    assert bool((seq[:, 1] != EOS).all()) and bool((seq[:, 2] != EOS).all()) and bool((seq[:, 3] == EOS).all())

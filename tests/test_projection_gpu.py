@@ -86,3 +86,25 @@ def test_pixel_map_properties_at_scene_size(dev):
     assert int(seen.sum()) > 0 and int(pix.max()) < 32 * 41 and int(pix.min()) >= -1
     d = depths.to(dev).reshape(F, -1).gather(1, pix.clamp(min=0).long())[seen]
     assert bool(((d >= helper.depth_min) & (d <= helper.depth_max)).all())
+
+
+def test_edge_cases_no_frame_sees_anything_and_single_point(dev):
+    """a scene no camera looks at -> an all -1 map, all-zero features, `compute_projection` returns None (the reference's
+    early `return None`s, projection.py:222,236,243); one point, one frame, 64 channels"""
+    z, helper = setup(dev)
+    far = torch.from_numpy(z["points"]) + 100.0
+    F = z["poses"].shape[0]
+    pix = helper.project_frames(far, z["depths"], z["poses"])
+    assert pix.shape == (F, far.shape[0]) and int(pix.max()) == -1
+    out = helper.project_scene(far, z["depths"], z["poses"], features(z, F), maxpool=True)
+    assert float(out.abs().max()) == 0.0
+    assert helper.compute_projection(far.to(dev), torch.from_numpy(z["depths"][0]).to(dev),
+                                     torch.from_numpy(z["poses"][0]).to(dev)) is None
+    # a single point that frame 0 does see, 64-channel features
+    seen = torch.from_numpy(z["f0_indices_3d"])
+    p = torch.from_numpy(z["points"])[int(seen[1])].reshape(1, 3)
+    g = torch.Generator().manual_seed(2)
+    feat = torch.randn(1, 64, 32, 41, generator=g)
+    one = helper.project_scene(p, z["depths"][:1], z["poses"][:1], feat, maxpool=False)
+    pixel = int(z["f0_indices_2d"][1])
+    assert torch.equal(one.cpu()[0], feat[0].reshape(64, -1)[:, pixel])

@@ -390,6 +390,79 @@ def attn_bwd(q, k, v, out, lse, grad_out, scale, dq, dk, dv, mask_log2=None, p_d
                                 int(seed) & 0xFFFFFFFF, _p(seed_tensor), int(bool(causal)), _stream()), "attn_bwd")
 
 
+class _AttnSide(ctypes.Structure):
+    _fields_ = [("Q", _vp), ("K", _vp), ("V", _vp), ("dO", _vp), ("O", _vp), ("out", _vp), ("dK", _vp), ("dV", _vp),
+                ("LSE", _vp), ("DELTA", _vp), ("mask", _vp), ("Lq", _i), ("Lk", _i), ("Lkp", _i),
+                ("q_bs", _l), ("q_rs", _l), ("q_hs", _l), ("k_bs", _l), ("k_rs", _l), ("k_hs", _l),
+                ("o_bs", _l), ("o_rs", _l), ("o_hs", _l), ("seed", _u)]
+
+
+_lib.bq_attn_fwd_pair.argtypes = [ctypes.POINTER(_AttnSide), _i, _i, _f, _f, _vp, _vp]
+_lib.bq_attn_fwd_pair.restype = ctypes.c_int
+_lib.bq_attn_bwd_pair.argtypes = [ctypes.POINTER(_AttnSide), _i, _i, _f, _f, _vp, _vp]
+_lib.bq_attn_bwd_pair.restype = ctypes.c_int
+
+
+def attn_pair_ok(qa, ka, qb, kb):
+    """both attentions qualify for the narrow kernels (bq_attn_fwd_pair): 1..32 queries, more than 128 keys"""
+    return qa.shape[1] <= 32 and qb.shape[1] <= 32 and ka.shape[1] > 128 and kb.shape[1] > 128 and qa.shape[0] == qb.shape[0]
+
+
+def _side(d, q, k, v, lse, mask_log2, seed):
+    if k.stride() != v.stride():
+        raise RuntimeError("attn pair: k and v must have equal strides")
+    d.Q, d.K, d.V, d.LSE, d.mask = _p(q), _p(k), _p(v), _p(lse), _p(mask_log2)
+    d.Lq, d.Lk, d.Lkp = q.shape[1], k.shape[1], _pad64(k.shape[1])
+    (d.q_bs, d.q_rs, d.q_hs), (d.k_bs, d.k_rs, d.k_hs) = _bhd_strides(q), _bhd_strides(k)
+    d.seed = int(seed) & 0xFFFFFFFF
+
+
+def attn_fwd_pair(sides, scale, p_drop=0.0, seed_tensor=None):
+    """two narrow attentions in one launch.  sides: two dicts with q (B, Lq <= 32, H, 64), k / v (B, Lk > 128, H, 64), out
+    (B, Lq, H, 64) contiguous bf16 (written), mask_log2 (from key_mask_log2) or None, seed.  Returns the two lse (B, H, Lq)."""
+    arr = (_AttnSide * 2)()
+    q0 = sides[0]["q"]
+    B, H = q0.shape[0], q0.shape[2]
+    lses = []
+    with torch.cuda.device(q0.device):
+        for d, s in zip(arr, sides):
+            q, out = s["q"], s["out"]
+            if not q.is_cuda or out.shape != q.shape or out.dtype != torch.bfloat16 or not out.is_contiguous():
+                raise RuntimeError("attn_fwd_pair: out must be a contiguous bf16 tensor shaped like q (CUDA)")
+            lse = torch.empty(B, H, q.shape[1], dtype=torch.float32, device=q.device)
+            _side(d, q, s["k"], s["v"], lse, s.get("mask_log2"), s.get("seed", 0))
+            d.out = _p(out)
+            d.o_bs, d.o_rs, d.o_hs = _bhd_strides(out)
+            lses.append(lse)
+        _check(_lib.bq_attn_fwd_pair(arr, B, H, float(scale), float(p_drop), _p(seed_tensor), _stream()), "attn_fwd_pair")
+    return lses
+
+
+def attn_bwd_pair(sides, scale, p_drop=0.0, seed_tensor=None):
+    """backward of attn_fwd_pair.  sides: q, k, v, out (the forward's, contiguous), lse, grad_out, dq, dk, dv
+    (preallocated bf16 views strided like q / k), mask_log2, seed."""
+    arr = (_AttnSide * 2)()
+    q0 = sides[0]["q"]
+    B, H = q0.shape[0], q0.shape[2]
+    keep = []
+    with torch.cuda.device(q0.device):
+        for d, s in zip(arr, sides):
+            q, k, go = s["q"], s["k"], s["grad_out"]
+            if s["dq"].stride() != q.stride() or s["dk"].stride() != k.stride() or s["dv"].stride() != k.stride():
+                raise RuntimeError("attn_bwd_pair: stride contract violated")
+            if go.stride(3) != 1 or go.stride(1) % 8 or go.stride(2) % 8:
+                go = go.contiguous()
+            if not s["out"].is_contiguous():
+                raise RuntimeError("attn_bwd_pair: the forward output must be contiguous")
+            delta = torch.empty(B, H, q.shape[1], dtype=torch.float32, device=q.device)
+            keep += [go, delta]
+            _side(d, q, k, s["v"], s["lse"], s.get("mask_log2"), s.get("seed", 0))
+            d.dO, d.O, d.DELTA = _p(go), _p(s["out"]), _p(delta)
+            d.out, d.dK, d.dV = _p(s["dq"]), _p(s["dk"]), _p(s["dv"])
+            d.o_bs, d.o_rs, d.o_hs = _bhd_strides(go)
+        _check(_lib.bq_attn_bwd_pair(arr, B, H, float(scale), float(p_drop), _p(seed_tensor), _stream()), "attn_bwd_pair")
+
+
 _lib.bq_attn_fwd2.argtypes = [_vp] * 8 + [_i] * 6 + [_l] * 12 + [_f, _f, _u, _vp, _vp]
 _lib.bq_attn_fwd2.restype = ctypes.c_int
 _lib.bq_attn_bwd2.argtypes = [_vp] * 15 + [_i] * 6 + [_l] * 12 + [_f, _f, _u, _vp, _vp]

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "bq_common.h"
+#include "bqhip_fusion.h"
 
 namespace bq {
 
@@ -523,16 +524,16 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_plain_kernel(const __bf16 
 // workgroup per (batch, head) would keep ONE wave busy for ceil(Lk / 64) serial tiles.  Here the four waves share the
 // 32 queries and take every fourth key tile each (own LDS images, own running max / sum / O^T), and the four partial
 // softmax states are merged through LDS at the end:  O = sum_w 2^(m_w - m*) O_w / sum_w 2^(m_w - m*) l_w.
-__global__ __launch_bounds__(256) void attn_fwd_narrow_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
-                                                              const __bf16 *__restrict__ V, __bf16 *__restrict__ O,
-                                                              float *__restrict__ LSE, AttnDims dm) {
+__device__ __forceinline__ void attn_fwd_narrow_body(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+                                                     const __bf16 *__restrict__ V, __bf16 *__restrict__ O,
+                                                     float *__restrict__ LSE, const AttnDims &dm, const int bh) {
   __shared__ __align__(16) unsigned char s_k[AT_NW][AT_KB * 128];
   __shared__ __align__(16) unsigned char s_v[AT_NW][AT_KB * 128];
   __shared__ float s_m[AT_NW][32], s_l[AT_NW][32];
   __shared__ float s_o[AT_NW][AT_D][33];
   const float scale_log2e = dm.scale * 1.4426950408889634f;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
+  const int b = bh / dm.H, hd = bh % dm.H;
   const unsigned seed = eff_seed(dm);
   const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
   const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
@@ -603,6 +604,28 @@ __global__ __launch_bounds__(256) void attn_fwd_narrow_kernel(const __bf16 *__re
   }
 }
 
+
+__global__ __launch_bounds__(256) void attn_fwd_narrow_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+                                                              const __bf16 *__restrict__ V, __bf16 *__restrict__ O,
+                                                              float *__restrict__ LSE, AttnDims dm) {
+  attn_fwd_narrow_body(Q, K, V, O, LSE, dm, blockIdx.y);
+}
+
+// Two independent narrow attentions in ONE launch (blockIdx.z = which): the two cross-attentions of a twin level (text
+// queries over cat(image tokens, 3D states) and over cat(object tokens, 2D states): 1045 and 276 keys) are latency-bound
+// launches of B.H workgroups each; side by side the short one runs under the long one.
+struct AttnPair {
+  const __bf16 *Q[2], *K[2], *V[2], *dO[2], *O[2];
+  const float *LSE[2];
+  float *LSEw[2], *DELTA[2];
+  __bf16 *out[2], *dK[2], *dV[2];   // out: O (forward) or dQ (backward)
+  AttnDims dm[2];
+};
+
+__global__ __launch_bounds__(256) void attn_fwd_narrow_pair_kernel(const AttnPair a) {
+  const int g = blockIdx.z;
+  attn_fwd_narrow_body(a.Q[g], a.K[g], a.V[g], a.out[g], a.LSEw[g], a.dm[g], blockIdx.y);
+}
 
 // =====================================================================================================
 // Backward.  With P = softmax(S), S = scale * Q K^T, delta[q] = rowsum(dO o O):
@@ -802,17 +825,17 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const __bf16 *__
 
 // Lq <= 32: the four waves share the queries and split the key tiles (see attn_fwd_narrow_kernel); dQ^T partials are
 // summed through LDS in wave order.
-__global__ __launch_bounds__(256) void attn_bwd_dq_narrow_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
-                                                                 const __bf16 *__restrict__ V,
-                                                                 const __bf16 *__restrict__ dO, const float *__restrict__ LSE,
-                                                                 const __bf16 *__restrict__ O, float *__restrict__ DELTA,
-                                                                 __bf16 *__restrict__ dQ, BwdDims dm) {
+__device__ __forceinline__ void attn_bwd_dq_narrow_body(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+                                                        const __bf16 *__restrict__ V, const __bf16 *__restrict__ dO,
+                                                        const float *__restrict__ LSE, const __bf16 *__restrict__ O,
+                                                        float *__restrict__ DELTA, __bf16 *__restrict__ dQ,
+                                                        const BwdDims &dm, const int bh) {
   __shared__ __align__(16) unsigned char s_k[AT_NW][AT_KB * 128];
   __shared__ __align__(16) unsigned char s_v[AT_NW][AT_KB * 128];
   __shared__ float s_o[AT_NW][AT_D][33];
   const float scale = dm.scale;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
+  const int b = bh / dm.H, hd = bh % dm.H;
   const unsigned seed = eff_seed(dm);
   const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
   const __bf16 *Gb = dO + b * dm.o_bs + hd * dm.o_hs;
@@ -880,6 +903,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_narrow_kernel(const __bf16 *_
       out[j] = (__bf16)(((s_o[0][d0 + j][q] + s_o[1][d0 + j][q]) + (s_o[2][d0 + j][q] + s_o[3][d0 + j][q])) * scale);
     *reinterpret_cast<bf16x8 *>(dQ + b * dm.q_bs + hd * dm.q_hs + (long)q * dm.q_rs + d0) = out;
   }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_narrow_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+                                                                 const __bf16 *__restrict__ V,
+                                                                 const __bf16 *__restrict__ dO, const float *__restrict__ LSE,
+                                                                 const __bf16 *__restrict__ O, float *__restrict__ DELTA,
+                                                                 __bf16 *__restrict__ dQ, BwdDims dm) {
+  attn_bwd_dq_narrow_body(Q, K, V, dO, LSE, O, DELTA, dQ, dm, blockIdx.y);
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_narrow_pair_kernel(const AttnPair a) {
+  const int g = blockIdx.z;
+  attn_bwd_dq_narrow_body(a.Q[g], a.K[g], a.V[g], a.dO[g], a.LSE[g], a.O[g], a.DELTA[g], a.out[g], a.dm[g], blockIdx.y);
 }
 
 // One 64-query tile of the dK/dV pass for the 32 keys of a wave (lane = key): S = Q.K^T and dP = dO.V^T (A = Q / dO
@@ -953,23 +989,23 @@ __device__ __forceinline__ void dkv_tile(const unsigned char *s_q, const unsigne
     }
 }
 
-template <int MINW, bool PLAIN = false>
-__global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
-                                                           const __bf16 *__restrict__ V,
-                                                           const __bf16 *__restrict__ dO,
-                                                           const float *__restrict__ LSE, const float *__restrict__ DELTA,
-                                                           __bf16 *__restrict__ dK, __bf16 *__restrict__ dV, BwdDims dm) {
+template <bool PLAIN = false>
+__device__ __forceinline__ void attn_bwd_dkv_body(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+                                                  const __bf16 *__restrict__ V, const __bf16 *__restrict__ dO,
+                                                  const float *__restrict__ LSE, const float *__restrict__ DELTA,
+                                                  __bf16 *__restrict__ dK, __bf16 *__restrict__ dV, const BwdDims &dm,
+                                                  const int bx, const int bh) {
   __shared__ __align__(16) unsigned char s_q[2][AT_KB * 128];  // double-buffered: see attn_fwd_kernel
   __shared__ __align__(16) unsigned char s_g[2][AT_KB * 128];
   __shared__ __align__(16) float s_lse[2][AT_KB];
   __shared__ __align__(16) float s_del[2][AT_KB];
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
+  const int b = bh / dm.H, hd = bh % dm.H;
   const unsigned seed = eff_seed(dm);
   // key blocks of segment 1 first, then those of the optional second segment (AttnDims): a block never straddles
   const int nb1 = (dm.Lk + AT_QB - 1) / AT_QB;
-  const bool seg2 = !PLAIN && (int)blockIdx.x >= nb1;   // wave-uniform (PLAIN is never used with two segments)
-  const int k0 = (seg2 ? (int)blockIdx.x - nb1 : (int)blockIdx.x) * AT_QB + wid * AT_QW;  // first key of this wave, in its segment
+  const bool seg2 = !PLAIN && bx >= nb1;   // wave-uniform (PLAIN is never used with two segments)
+  const int k0 = (seg2 ? bx - nb1 : bx) * AT_QB + wid * AT_QW;  // first key of this wave, in its segment
   const int Lks = seg2 ? dm.Lk2 : dm.Lk;               // keys in this block's segment
   const int kpad0 = seg2 ? dm.nkt1 * 64 : 0;           // padded key index (mask row, dropout hash) of the segment's key 0
   const long ks_rs = seg2 ? dm.k2_rs : dm.k_rs;
@@ -1049,6 +1085,24 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *_
     store_T((seg2 ? dm.dK2 : dK) + off, dk0, dk1, h, scale);
     store_T((seg2 ? dm.dV2 : dV) + off, dv0, dv1, h, 1.0f);
   }
+}
+
+template <int MINW, bool PLAIN = false>
+__global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+                                                           const __bf16 *__restrict__ V,
+                                                           const __bf16 *__restrict__ dO,
+                                                           const float *__restrict__ LSE, const float *__restrict__ DELTA,
+                                                           __bf16 *__restrict__ dK, __bf16 *__restrict__ dV, BwdDims dm) {
+  attn_bwd_dkv_body<PLAIN>(Q, K, V, dO, LSE, DELTA, dK, dV, dm, blockIdx.x, blockIdx.y);
+}
+
+// the dK / dV passes of an AttnPair: the grid's x extent is the larger of the two key-block counts
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_pair_kernel(const AttnPair a) {
+  const int g = blockIdx.z;
+  const BwdDims &dm = a.dm[g];
+  const int nb = (dm.Lk + AT_QB - 1) / AT_QB + (dm.Lk2 > 0 ? (dm.Lk2 + AT_QB - 1) / AT_QB : 0);
+  if ((int)blockIdx.x >= nb) return;
+  attn_bwd_dkv_body<false>(a.Q[g], a.K[g], a.V[g], a.dO[g], a.LSE[g], a.DELTA[g], a.dK[g], a.dV[g], dm, blockIdx.x, blockIdx.y);
 }
 
 }  // namespace bq
@@ -1228,6 +1282,58 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_bwd2(
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, false>), dim3(nb, B * H), dim3(256), 0, st, (const __bf16 *)Q,
                      (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)dO, LSE, DELTA, (__bf16 *)dK, (__bf16 *)dV, dm);
   return check_launch("attn_bwd2_dkv");
+}
+
+// ---- two narrow attentions per launch (AttnPair) ----------------------------------------------------------------------
+static int fill_pair(const bq_attn_side *sd, int B, int H, float scale, float p_drop, const unsigned *seed_ptr, bool backward,
+                     AttnPair &a) {
+  for (int g = 0; g < 2; ++g) {
+    const bq_attn_side &s = sd[g];
+    BQ_REQUIRE(s.Lq > 0 && s.Lq <= AT_QW && s.Lk > 2 * AT_KB && s.Lkp >= s.Lk && s.Lkp % 64 == 0, BQ_EINVAL,
+               "attn pair: side %d needs 1 <= Lq <= 32 queries and more than 128 keys (Lq %d, Lk %d)", g, s.Lq, s.Lk);
+    BQ_REQUIRE(s.Q && s.K && s.V && s.out && s.LSE, BQ_EINVAL, "attn pair: null pointer (side %d)", g);
+    BQ_REQUIRE(!backward || (s.dO && s.O && s.DELTA && s.dK && s.dV), BQ_EINVAL, "attn pair: null pointer (side %d)", g);
+    BQ_REQUIRE((s.q_rs % 8) == 0 && (s.k_rs % 8) == 0 && (s.o_rs % 8) == 0 && (s.q_hs % 8) == 0 && (s.k_hs % 8) == 0 &&
+                   (s.o_hs % 8) == 0, BQ_EINVAL, "attn pair: rows must be 16-byte aligned");
+    BQ_REQUIRE(s.q_rs > 0 && s.k_rs > 0 && s.q_rs < (1 << 23) && s.k_rs < (1 << 23), BQ_EINVAL,
+               "attn pair: row stride out of range");
+    a.Q[g] = (const __bf16 *)s.Q; a.K[g] = (const __bf16 *)s.K; a.V[g] = (const __bf16 *)s.V;
+    a.dO[g] = (const __bf16 *)s.dO; a.O[g] = (const __bf16 *)s.O;
+    a.LSE[g] = s.LSE; a.LSEw[g] = s.LSE; a.DELTA[g] = s.DELTA;
+    a.out[g] = (__bf16 *)s.out; a.dK[g] = (__bf16 *)s.dK; a.dV[g] = (__bf16 *)s.dV;
+    AttnDims dm{B, H, s.Lq, s.Lk, 0, s.Lkp, s.q_bs, s.q_rs, s.q_hs, s.k_bs, s.k_rs, s.k_hs, s.o_bs, s.o_rs, s.o_hs, s.mask,
+                scale, 1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), s.seed, seed_ptr, 0};
+    dm.nkt1 = (s.Lk + AT_KB - 1) / AT_KB;
+    a.dm[g] = dm;
+  }
+  return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int bq_attn_fwd_pair(const bq_attn_side *sides, int B, int H, float scale,
+                                                                     float p_drop, const unsigned *seed_ptr, void *stream) {
+  BQ_REQUIRE(sides && B > 0 && H > 0, BQ_EINVAL, "attn_fwd_pair: bad arguments");
+  BQ_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, BQ_EINVAL, "attn_fwd_pair: bad dropout probability");
+  AttnPair a;
+  int rc = fill_pair(sides, B, H, scale, p_drop, seed_ptr, false, a);
+  if (rc) return rc;
+  hipLaunchKernelGGL(attn_fwd_narrow_pair_kernel, dim3(1, B * H, 2), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("attn_fwd_pair");
+}
+
+extern "C" __attribute__((visibility("default"))) int bq_attn_bwd_pair(const bq_attn_side *sides, int B, int H, float scale,
+                                                                     float p_drop, const unsigned *seed_ptr, void *stream) {
+  BQ_REQUIRE(sides && B > 0 && H > 0, BQ_EINVAL, "attn_bwd_pair: bad arguments");
+  BQ_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, BQ_EINVAL, "attn_bwd_pair: bad dropout probability");
+  AttnPair a;
+  int rc = fill_pair(sides, B, H, scale, p_drop, seed_ptr, true, a);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_bwd_dq_narrow_pair_kernel, dim3(1, B * H, 2), dim3(256), 0, st, a);
+  rc = check_launch("attn_bwd_pair_dq");
+  if (rc) return rc;
+  const int nb0 = (sides[0].Lk + AT_QB - 1) / AT_QB, nb1 = (sides[1].Lk + AT_QB - 1) / AT_QB;
+  hipLaunchKernelGGL(attn_bwd_dkv_pair_kernel, dim3(nb0 > nb1 ? nb0 : nb1, B * H, 2), dim3(256), 0, st, a);
+  return check_launch("attn_bwd_pair_dkv");
 }
 
 // ---- attention probabilities on request ---------------------------------------------------------------------------------

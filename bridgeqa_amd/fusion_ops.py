@@ -1182,6 +1182,9 @@ class _TwinSplitFn(torch.autograd.Function):
         return torch.cat((ga, gb), dim=0)
 
 
+_ATTN_PAIR = [os.environ.get("BQ_ATTN_PAIR", "1") != "0"]
+
+
 class _TwinCrossAttention(torch.autograd.Function):
     """the two cross-attentions of one twin level: queries stacked (2B, L, H, 64), keys / values per stream as fused
     K/V tensors (B, Lk_g, 2, H, 64) of different lengths; context and dq come back stacked (no slice gradients)"""
@@ -1192,18 +1195,28 @@ class _TwinCrossAttention(torch.autograd.Function):
         B = q.shape[0] // 2
         out = torch.empty_like(q)
         seeds, lses, probs = [], [], []
+        pair = _ATTN_PAIR[0] and _ext.attn_pair_ok(q[:B], kva, q[B:], kvb)
+        if pair:  # both cross-attentions in one launch: the 276-key one runs under the 1045-key one
+            sides = []
+            for g, (kv, m) in enumerate(((kva, ma), (kvb, mb))):
+                seed, st = _seed_args(p_drop, q.device)
+                seeds.append(seed)
+                sides.append(dict(q=q[g * B:(g + 1) * B], k=kv[:, :, 0], v=kv[:, :, 1], out=out[g * B:(g + 1) * B],
+                                  mask_log2=m, seed=seed))
+            lses = _ext.attn_fwd_pair(sides, scale, p_drop, st)
         for g, (kv, m) in enumerate(((kva, ma), (kvb, mb))):
-            seed, st = _seed_args(p_drop, q.device)
-            _, lse = _ext.attn_fwd(q[g * B:(g + 1) * B], kv[:, :, 0], kv[:, :, 1], scale, m, p_drop, seed, st,
-                                   out=out[g * B:(g + 1) * B])
-            seeds.append(seed)
-            lses.append(lse)
+            if not pair:
+                seed, st = _seed_args(p_drop, q.device)
+                _, lse = _ext.attn_fwd(q[g * B:(g + 1) * B], kv[:, :, 0], kv[:, :, 1], scale, m, p_drop, seed, st,
+                                       out=out[g * B:(g + 1) * B])
+                seeds.append(seed)
+                lses.append(lse)
             if want_probs:
-                probs.append(_ext.attn_probs(q[g * B:(g + 1) * B], kv[:, :, 0], lse, scale, m))
+                probs.append(_ext.attn_probs(q[g * B:(g + 1) * B], kv[:, :, 0], lses[g], scale, m))
         e = q.new_empty(0)
         ctx.save_for_backward(q, kva, kvb, out, lses[0], lses[1], ma if ma is not None else e, mb if mb is not None else e,
                               st if st is not None else e)
-        ctx.cfg = (scale, p_drop, seeds, ma is not None, mb is not None, st is not None)
+        ctx.cfg = (scale, p_drop, seeds, ma is not None, mb is not None, st is not None, pair)
         if want_probs:
             ctx.mark_non_differentiable(*probs)
             return out, probs[0], probs[1]
@@ -1213,17 +1226,23 @@ class _TwinCrossAttention(torch.autograd.Function):
     def backward(ctx, grad_out, _ga=None, _gb=None):
         from . import _ext
         q, kva, kvb, out, lsa, lsb, ma, mb, st = ctx.saved_tensors
-        scale, p_drop, seeds, has_a, has_b, has_st = ctx.cfg
+        scale, p_drop, seeds, has_a, has_b, has_st, pair = ctx.cfg
         B = q.shape[0] // 2
         grad_out = grad_out.contiguous()
         dq = torch.empty_like(q)
-        dkvs = []
+        dkvs, sides = [], []
         for g, (kv, lse, m, has) in enumerate(((kva, lsa, ma, has_a), (kvb, lsb, mb, has_b))):
             dkv = torch.empty_like(kv)
             r = slice(g * B, (g + 1) * B)
-            _ext.attn_bwd(q[r], kv[:, :, 0], kv[:, :, 1], out[r], lse, grad_out[r], scale, dq[r], dkv[:, :, 0],
-                          dkv[:, :, 1], m if has else None, p_drop, seeds[g], st if has_st else None)
+            if pair:
+                sides.append(dict(q=q[r], k=kv[:, :, 0], v=kv[:, :, 1], out=out[r], lse=lse, grad_out=grad_out[r], dq=dq[r],
+                                  dk=dkv[:, :, 0], dv=dkv[:, :, 1], mask_log2=m if has else None, seed=seeds[g]))
+            else:
+                _ext.attn_bwd(q[r], kv[:, :, 0], kv[:, :, 1], out[r], lse, grad_out[r], scale, dq[r], dkv[:, :, 0],
+                              dkv[:, :, 1], m if has else None, p_drop, seeds[g], st if has_st else None)
             dkvs.append(dkv)
+        if pair:
+            _ext.attn_bwd_pair(sides, scale, p_drop, st if has_st else None)
         return dq, dkvs[0], dkvs[1], None, None, None, None, None
 
 

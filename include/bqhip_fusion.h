@@ -37,6 +37,25 @@ BQ_API int bq_attn_bwd(const void *Q, const void *K, const void *V, const void *
                        long g_hs, float scale, float p_drop, unsigned seed, const unsigned *seed_ptr, int causal,
                        void *stream);
 
+/* Two narrow attentions (1 <= Lq <= 32 queries, more than 128 keys, one key segment, no causal order) in ONE launch per
+ * kernel: the two cross-attentions of a twin level (reference med.py:549-614: text queries over cat(image tokens, 3D
+ * states) and over cat(object tokens, 2D states)) are latency-bound launches of B * H workgroups each; side by side the
+ * short one runs under the long one.  Per side: the arguments of bq_attn_fwd / bq_attn_bwd (out = O in the forward, dQ in
+ * the backward; o_* strides describe O in the forward, dO in the backward; O contiguous (B, Lq, H, 64)). */
+typedef struct bq_attn_side {
+  const void *Q, *K, *V, *dO, *O;
+  void *out, *dK, *dV;
+  float *LSE, *DELTA;
+  const float *mask;
+  int Lq, Lk, Lkp;
+  long q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, o_bs, o_rs, o_hs;
+  unsigned seed;
+} bq_attn_side;
+BQ_API int bq_attn_fwd_pair(const bq_attn_side *sides, int B, int H, float scale, float p_drop, const unsigned *seed_ptr,
+                            void *stream);
+BQ_API int bq_attn_bwd_pair(const bq_attn_side *sides, int B, int H, float scale, float p_drop, const unsigned *seed_ptr,
+                            void *stream);
+
 /* The attention probabilities of a bq_attn_fwd call, rebuilt from Q, K and its LSE -- what the reference returns under
  * output_attentions (models/med.py:202,223: the softmax BEFORE dropout; BLIP_VQA3D keeps the last level's cross-attention
  * maps, blip_vqa_3d.py:262-281): P f32 (B, H, Lq, Lk) = exp2(scale*log2e * q.k + mask - LSE), causal flag as in the

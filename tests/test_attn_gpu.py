@@ -220,6 +220,48 @@ def test_masked_cross_attention_with_dropout_fwd_bwd(dev, B, H, Lq, Lk, p):
         assert abs(frac - (1 - p)) < 0.02
 
 
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_paired_narrow_attention_equals_two_launches(dev, p):
+    """bq_attn_fwd_pair / bq_attn_bwd_pair (the two cross-attentions of a twin level in one launch per kernel) against the
+    single launches, bit for bit: key masks, dropout with per-side seeds, different key counts (1045 / 276)"""
+    from bridgeqa_amd import _ext
+    B, H, L = 3, 4, 20
+    g = torch.Generator().manual_seed(11)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev).to(torch.bfloat16)
+    q = mk(2 * B, L, H, 64)
+    kvs = [mk(B, 1045, 2, H, 64), mk(B, 276, 2, H, 64)]
+    masks = []
+    for Lk in (1045, 276):
+        m = torch.zeros(B, 1, 1, Lk, device=dev)
+        m[1, 0, 0, Lk - 7:] = -10000.0
+        masks.append(_ext.key_mask_log2(m, B, Lk))
+    go = mk(2 * B, L, H, 64)
+    seeds = [123, 456]
+    out1, lse1, d1 = torch.empty_like(q), [], []
+    for s_ in range(2):
+        r = slice(s_ * B, (s_ + 1) * B)
+        _, lse = _ext.attn_fwd(q[r], kvs[s_][:, :, 0], kvs[s_][:, :, 1], 0.125, masks[s_], p, seeds[s_], None, out=out1[r])
+        lse1.append(lse)
+    dq1 = torch.empty_like(q)
+    for s_ in range(2):
+        r = slice(s_ * B, (s_ + 1) * B)
+        dkv = torch.empty_like(kvs[s_])
+        _ext.attn_bwd(q[r], kvs[s_][:, :, 0], kvs[s_][:, :, 1], out1[r], lse1[s_], go[r], 0.125, dq1[r], dkv[:, :, 0],
+                      dkv[:, :, 1], masks[s_], p, seeds[s_], None)
+        d1.append(dkv)
+    out2 = torch.empty_like(q)
+    sides = [dict(q=q[s_ * B:(s_ + 1) * B], k=kvs[s_][:, :, 0], v=kvs[s_][:, :, 1], out=out2[s_ * B:(s_ + 1) * B],
+                  mask_log2=masks[s_], seed=seeds[s_]) for s_ in range(2)]
+    assert _ext.attn_pair_ok(sides[0]["q"], sides[0]["k"], sides[1]["q"], sides[1]["k"])
+    lse2 = _ext.attn_fwd_pair(sides, 0.125, p, None)
+    assert torch.equal(out2, out1) and torch.equal(lse2[0], lse1[0]) and torch.equal(lse2[1], lse1[1])
+    dq2, d2 = torch.empty_like(q), [torch.empty_like(kv) for kv in kvs]
+    bsides = [dict(sides[s_], lse=lse2[s_], grad_out=go[s_ * B:(s_ + 1) * B], dq=dq2[s_ * B:(s_ + 1) * B],
+                   dk=d2[s_][:, :, 0], dv=d2[s_][:, :, 1]) for s_ in range(2)]
+    _ext.attn_bwd_pair(bsides, 0.125, p, None)
+    assert torch.equal(dq2, dq1) and torch.equal(d2[0], d1[0]) and torch.equal(d2[1], d1[1])
+
+
 def test_text_attention_routes_to_kernel_and_matches_composition(dev):
     """fusion_ops.attention in bf16 mode with a key mask == the fp32 composition (eval: no dropout)."""
     from bridgeqa_amd import fusion_ops

@@ -848,9 +848,11 @@ def gemm_grouped(problems, flags, epilogue=EPI_NONE, tile=None):
                                  or not bias.is_contiguous()):
             raise RuntimeError("gemm: bias must be a contiguous fp32 or bf16 (Ni,) tensor")
         d.bias_bf16 = int(bias is not None and bias.dtype == torch.bfloat16)
-        if epilogue != EPI_BIAS_CE and colsum is not None and (colsum.dtype != torch.float32 or colsum.numel() != Ni
+        # (weight-gradient form, 256-tile kernel: colsum (Nj,) receives the column sums of Q over the contraction)
+        n_cs = Nj if (pxc and qxc and f32) else Ni
+        if epilogue != EPI_BIAS_CE and colsum is not None and (colsum.dtype != torch.float32 or colsum.numel() != n_cs
                                                                or not colsum.is_contiguous()):
-            raise RuntimeError("gemm: colsum must be a contiguous fp32 (Ni,) tensor")
+            raise RuntimeError("gemm: colsum must be a contiguous fp32 (%d,) tensor" % n_cs)
         for t, nm in ((out2, "out2"), (aux, "aux")):
             if epilogue != EPI_BIAS_CE and t is not None and (t.dtype != torch.bfloat16 or tuple(t.shape) != (Nj, Ni)
                                                               or t.stride() != out.stride()):

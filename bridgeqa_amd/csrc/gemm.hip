@@ -258,6 +258,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // weight-gradient form (P and Q contraction-major, fp32 out) with pr.colsum set: the column sums of Q over the
+  // contraction -- the layer's BIAS gradient, sum over rows of dY -- from four more MFMAs per K tile with an all-ones A
+  // operand on the B fragments already in registers, in the waves wr == 0 of the i = 0 tiles only (every j is then summed
+  // by exactly one wave: plain stores, no atomics).  The grouped column-sum launch re-read every dY (2.7 GB at c3) for it.
+  constexpr bool QSUM = P_XC && Q_XC && OUT_F32;
+  const bool do_qsum = QSUM && pr.colsum != nullptr && bi == 0 && wr == 0;   // wave-uniform
+  f32x4 qs[4];
+  bf16x8 ones;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) qs[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#define BQ_MFMA_QSUM(FB, BO)                                                                          \
+  if (QSUM && do_qsum) {                                                                              \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int b = 0; b < 2; ++b)    \
+        qs[BO + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, FB[b][kk], qs[BO + b], 0, 0, 0);   \
+  }
+
   // ---- prologue: stages 0..5 = A0(0) B0(0) B1(0) A1(0) A0(1) B0(1) ------------------------------------------------
   stage_pair(0, 0); stage_pair(4, 0); stage_pair(6, 0); stage_pair(2, 0); stage_pair(0, 1); stage_pair(4, 1);
   if (GTAB) gelu_tab_fill<EPI == EPI_DGELU>(s_gtab, tid, 512);  // under the prologue's DMA latency; read after the K loop
@@ -298,6 +316,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
     stage_pair(6, kt + 1);
     BQ_PHASE_SYNC_A();
     if (vA0 && vB0) { BQ_MFMA_Q(0, fb0, 0) }
+    if (vB0) { BQ_MFMA_QSUM(fb0, 0) }
     BQ_PHASE_SYNC_B();
     // ---- p1: B1 -> Q01 ; stage A1(t+1)
     if (vB1) {
@@ -309,6 +328,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
     stage_pair(2, kt + 1);
     BQ_PHASE_SYNC_A();
     if (vA0 && vB1) { BQ_MFMA_Q(0, fb1, 2) }
+    if (vB1) { BQ_MFMA_QSUM(fb1, 2) }
     BQ_PHASE_SYNC_B();
     // ---- p2: A1 -> Q11 ; stage A0(t+2)
     if (vA1) {
@@ -336,6 +356,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
   const int ldo = pr.ldo;
   if (OUT_F32) {
     float *out = reinterpret_cast<float *>(pr.out);
+    if (QSUM && do_qsum && q4 == 0) {  // every row of the all-ones product holds the sums: lane row16 has j's in element 0
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int j = jw + b * 16 + row16;
+        if (j < Nj) pr.colsum[j] = qs[b][0];
+      }
+    }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int j = jw + b * 16 + row16;

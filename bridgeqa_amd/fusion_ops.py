@@ -314,6 +314,7 @@ def flush_deferred_wgrad():
 
 _PLAN_CACHE = {}
 _PLAN_WGRAD = [os.environ.get("BQ_WGRAD_PLAN", "1") != "0"]
+_QSUM = [os.environ.get("BQ_WGRAD_QSUM", "1") != "0"]
 
 
 def plan_big_launches(tiles, cus, max_problems=36, moved_cost=0.011):
@@ -387,16 +388,24 @@ def flush_deferred_items(items):
         plan_groups, moved = plan_big_launches(tiles, cus)
         groups = [[big[j] for j in g] for g in plan_groups]
         small = small + [big[j] for j in moved]
+    dbs = {}
     for tile, idx_groups in ((256, groups), (64, [small] if small else [])):
         for idx in idx_groups:
             probs = []
             for k in idx:
                 g2, x2 = items[k][0], items[k][1]
                 dws[k] = torch.empty(g2.shape[1], x2.shape[1], dtype=torch.float32, device=g2.device)
-                probs.append(dict(P=x2, Q=g2, out=dws[k]))
+                pr = dict(P=x2, Q=g2, out=dws[k])
+                if tile == 256 and items[k][3] is not None and _QSUM[0]:
+                    # the bias gradient (column sums of dY) from the same launch: four more MFMAs per K tile in a third
+                    # of the workgroups instead of a second pass over dY (csrc/gemm.hip, QSUM)
+                    dbs[k] = torch.empty(g2.shape[1], dtype=torch.float32, device=g2.device)
+                    pr["colsum"] = dbs[k]
+                probs.append(pr)
             _ext.gemm_grouped(probs, flags, _ext.EPI_NONE, tile)
-    with_b = [k for k, it in enumerate(items) if it[3] is not None]
-    dbs = dict(zip(with_b, _ext.colsum_grouped([items[k][0] for k in with_b]))) if with_b else {}
+    with_b = [k for k, it in enumerate(items) if it[3] is not None and k not in dbs]
+    if with_b:
+        dbs.update(zip(with_b, _ext.colsum_grouped([items[k][0] for k in with_b])))
     for k, (g2, x2, ws, bs) in enumerate(items):
         n = g2.shape[1] // len(ws)
         for j, w in enumerate(ws):

@@ -112,6 +112,27 @@ def test_dw(dev, M, N, K, tile):
     _check(dw, dy.float().t() @ x.float(), f32=True)
 
 
+def test_dw_with_bias_gradient_from_the_same_launch(dev):
+    """the weight-gradient form of the 256-tile kernel with colsum set: colsum[j] = sum over the contraction of Q (= the bias
+    gradient, column sums of dY), from all-ones MFMAs in the i = 0 tiles; grouped problems of ragged sizes (rows not a
+    multiple of 64, out features not a multiple of 256, several i tiles) -- and dW itself unchanged by it"""
+    from bridgeqa_amd import _ext
+    flags = _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32
+    probs, dys = [], []
+    for k, (M, N, K) in enumerate([(1000, 768, 768), (16400, 2304, 768), (1025, 776, 3072), (4416, 1536, 768), (70, 8, 64)]):
+        dy, x = _rand((M, N), dev, 60 + k), _rand((M, K), dev, 80 + k)
+        probs.append(dict(P=x, Q=dy, out=torch.empty(N, K, device=dev), colsum=torch.full((N,), float("nan"), device=dev)))
+        dys.append(dy)
+    _ext.gemm_grouped(probs, flags, _ext.EPI_NONE, 256)
+    plain = [dict(P=p["P"], Q=p["Q"], out=torch.empty_like(p["out"])) for p in probs]
+    _ext.gemm_grouped(plain, flags, _ext.EPI_NONE, 256)
+    for p, q, dy in zip(probs, plain, dys):
+        assert torch.equal(p["out"], q["out"])
+        ref = dy.float().sum(0)
+        assert torch.isfinite(p["colsum"]).all()
+        assert ((p["colsum"] - ref).abs().max() / (ref.abs().max() + 1e-20)).item() < 1e-5
+
+
 def test_grouped_launch(dev):
     """several problems of different sizes in ONE launch (the deferred weight gradients of a layer stack)"""
     from bridgeqa_amd import _ext

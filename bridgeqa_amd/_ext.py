@@ -848,7 +848,8 @@ def gemm_grouped(problems, flags, epilogue=EPI_NONE, tile=None):
                                  or not bias.is_contiguous()):
             raise RuntimeError("gemm: bias must be a contiguous fp32 or bf16 (Ni,) tensor")
         d.bias_bf16 = int(bias is not None and bias.dtype == torch.bfloat16)
-        # (weight-gradient form, 256-tile kernel: colsum (Nj,) receives the column sums of Q over the contraction)
+        # (weight-gradient form: colsum (Nj,) receives the column sums of Q over the contraction; with ksplit > 1 it is
+        # accumulated with atomics and must arrive zeroed)
         n_cs = Nj if (pxc and qxc and f32) else Ni
         if epilogue != EPI_BIAS_CE and colsum is not None and (colsum.dtype != torch.float32 or colsum.numel() != n_cs
                                                                or not colsum.is_contiguous()):

@@ -706,6 +706,16 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < QF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // weight-gradient form with pr.colsum set: the column sums of Q over this workgroup's share of the contraction (the
+  // bias gradient) from all-ones MFMAs on the B fragments, waves wr == 0 of the i = 0 tiles (see gemm256_kernel)
+  constexpr bool QSUM = P_XC && Q_XC && OUT_F32;
+  const bool do_qsum = QSUM && pr.colsum != nullptr && bi == 0 && wr == 0;   // wave-uniform
+  f32x4 qs[QF];
+  bf16x8 ones;
+#pragma unroll
+  for (int b = 0; b < QF; ++b) qs[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
 #pragma unroll
   for (int p = 0; p < NS - 1; ++p) stage(p);
@@ -740,6 +750,12 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
 #pragma unroll
           for (int b = 0; b < QF; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][kk], fb[b][kk], acc[a][b], 0, 0, 0);
+      if (QSUM && do_qsum) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int b = 0; b < QF; ++b) qs[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fb[b][kk], qs[b], 0, 0, 0);
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -747,6 +763,16 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
   // ---- epilogue: straight from the accumulators (8-B bf16 / 16-B fp32 pieces of an output row) ---------------------
   const int ldo = pr.ldo;
   const int iw = i0 + wr * 32, jw = j0 + wc * (BJ / 2);
+  if (QSUM && do_qsum && q4 == 0) {
+#pragma unroll
+    for (int b = 0; b < QF; ++b) {
+      const int j = jw + b * 16 + row16;
+      if (j < Nj) {
+        if (ksplit == 1) pr.colsum[j] = qs[b][0];
+        else atomicAdd(pr.colsum + j, qs[b][0]);   // (zero-initialised by the caller, as `out` is)
+      }
+    }
+  }
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     const int i = iw + a * 16 + q4 * 4;

@@ -315,6 +315,7 @@ def flush_deferred_wgrad():
 _PLAN_CACHE = {}
 _PLAN_WGRAD = [os.environ.get("BQ_WGRAD_PLAN", "1") != "0"]
 _QSUM = [os.environ.get("BQ_WGRAD_QSUM", "1") != "0"]
+_QSUM64 = [os.environ.get("BQ_WGRAD_QSUM64", "1") != "0"]
 
 
 def plan_big_launches(tiles, cus, max_problems=36, moved_cost=0.011):
@@ -396,7 +397,7 @@ def flush_deferred_items(items):
                 g2, x2 = items[k][0], items[k][1]
                 dws[k] = torch.empty(g2.shape[1], x2.shape[1], dtype=torch.float32, device=g2.device)
                 pr = dict(P=x2, Q=g2, out=dws[k])
-                if tile == 256 and items[k][3] is not None and _QSUM[0]:
+                if items[k][3] is not None and _QSUM[0] and (tile == 256 or _QSUM64[0]):
                     # the bias gradient (column sums of dY) from the same launch: four more MFMAs per K tile in a third
                     # of the workgroups instead of a second pass over dY (csrc/gemm.hip, QSUM)
                     dbs[k] = torch.empty(g2.shape[1], dtype=torch.float32, device=g2.device)

@@ -223,8 +223,8 @@ BQ_API int bq_fuse_point_features(const int *pix, const float *feat, float *out,
  *   epilogue: BQ_GEMM_EPI_NONE; _BIAS: + bias[i] (fp32); _BIAS_GELU: out = bf16(acc + bias), out2 = gelu(out) (exact
  *     erf GELU, vit.py act_layer=nn.GELU / med hidden_act "gelu"); _DGELU: out = acc * gelu'(aux[j][i]) (the backward
  *     of the GELU fused into the dX GEMM of the layer after it).  colsum != NULL: colsum[i] += sum_j out[j][i] (fp32
- *     atomics; the bias gradient of the layer that produced the operand).  In the weight-gradient form on 256-tiles
- *     (P_XC | Q_XC | OUT_F32, tile 256) colsum has Nj entries instead and RECEIVES colsum[j] = sum_kc Q(j, kc): the column
+ *     atomics; the bias gradient of the layer that produced the operand).  In the weight-gradient form
+ *     (P_XC | Q_XC | OUT_F32; with ksplit > 1 through atomics onto a zeroed vector) colsum has Nj entries instead and RECEIVES colsum[j] = sum_kc Q(j, kc): the column
  *     sums of dY over the rows = the bias gradient of the same layer, from the same launch (plain stores).
  *   tile: 256 = 256x256 tiles, 8 waves, LDS-DMA pipeline (large M); 64 / 32 = 64 x {64,32} tiles (small M; 32 needs a
  *     K-contiguous Q).  All problems of one call run in ONE launch (grouped GEMM) and must share flags / epilogue.

@@ -123,14 +123,24 @@ def test_dw_with_bias_gradient_from_the_same_launch(dev):
         dy, x = _rand((M, N), dev, 60 + k), _rand((M, K), dev, 80 + k)
         probs.append(dict(P=x, Q=dy, out=torch.empty(N, K, device=dev), colsum=torch.full((N,), float("nan"), device=dev)))
         dys.append(dy)
-    _ext.gemm_grouped(probs, flags, _ext.EPI_NONE, 256)
-    plain = [dict(P=p["P"], Q=p["Q"], out=torch.empty_like(p["out"])) for p in probs]
-    _ext.gemm_grouped(plain, flags, _ext.EPI_NONE, 256)
-    for p, q, dy in zip(probs, plain, dys):
-        assert torch.equal(p["out"], q["out"])
-        ref = dy.float().sum(0)
-        assert torch.isfinite(p["colsum"]).all()
-        assert ((p["colsum"] - ref).abs().max() / (ref.abs().max() + 1e-20)).item() < 1e-5
+    for tile in (256, 64):
+        for p in probs:
+            p["colsum"].fill_(float("nan"))
+        _ext.gemm_grouped(probs, flags, _ext.EPI_NONE, tile)
+        plain = [dict(P=p["P"], Q=p["Q"], out=torch.empty_like(p["out"])) for p in probs]
+        _ext.gemm_grouped(plain, flags, _ext.EPI_NONE, tile)
+        for p, q, dy in zip(probs, plain, dys):
+            assert torch.equal(p["out"], q["out"])
+            ref = dy.float().sum(0)
+            assert torch.isfinite(p["colsum"]).all()
+            assert ((p["colsum"] - ref).abs().max() / (ref.abs().max() + 1e-20)).item() < 1e-5
+    # split contraction (64-tile kernel, ksplit pieces): out and colsum accumulate with atomics onto zeros
+    dy, x = dys[1], probs[1]["P"]
+    out, cs = torch.zeros(dy.shape[1], x.shape[1], device=dev), torch.zeros(dy.shape[1], device=dev)
+    _ext.gemm_grouped([dict(P=x, Q=dy, out=out, colsum=cs, ksplit=7)], flags, _ext.EPI_NONE, 64)
+    ref = dy.float().sum(0)
+    assert ((cs - ref).abs().max() / ref.abs().max()).item() < 1e-5
+    _check(out, dy.float().t() @ x.float(), f32=True)
 
 
 def test_grouped_launch(dev):

@@ -566,6 +566,27 @@ def colsum(g2d):
     return out
 
 
+_lib.bq_twin_mix_bf16.argtypes = [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]
+_lib.bq_twin_mix_bf16.restype = ctypes.c_int
+
+
+def twin_mix(fixed_a, tail_a, fixed_b, tail_b):
+    """(cat(fixed_a, tail_a), cat(fixed_b, tail_b)) along dim 1 for contiguous bf16 (B, *, D) tensors, one launch"""
+    B, Pa, D = fixed_a.shape
+    Pb, L = fixed_b.shape[1], tail_a.shape[1]
+    for t in (fixed_a, tail_a, fixed_b, tail_b):
+        if not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and t.shape[0] == B and t.shape[2] == D):
+            raise RuntimeError("twin_mix: contiguous bf16 CUDA tensors (B, *, D) expected")
+    if tail_b.shape[1] != L or D % 8:
+        raise RuntimeError("twin_mix: tails must have the same length and D % 8 == 0")
+    with torch.cuda.device(fixed_a.device):
+        oa = torch.empty(B, Pa + L, D, dtype=torch.bfloat16, device=fixed_a.device)
+        ob = torch.empty(B, Pb + L, D, dtype=torch.bfloat16, device=fixed_a.device)
+        _check(_lib.bq_twin_mix_bf16(_p(fixed_a), _p(tail_a), _p(oa), Pa, _p(fixed_b), _p(tail_b), _p(ob), Pb, B, L, D,
+                                     _stream()), "twin_mix")
+    return oa, ob
+
+
 _lib.bq_gelu_fwd_bf16.argtypes = [_vp, _vp, _l, _vp]
 _lib.bq_gelu_fwd_bf16.restype = ctypes.c_int
 

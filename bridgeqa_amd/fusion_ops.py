@@ -1167,6 +1167,9 @@ class _TwinDropAddLN(torch.autograd.Function):
         return dx, dres, dgb[0, 0], dgb[0, 1], dgb[1, 0], dgb[1, 1], None, None
 
 
+_TWIN_MIX_KERNEL = [os.environ.get("BQ_TWIN_MIX_KERNEL", "1") != "0"]
+
+
 class _TwinMixFn(torch.autograd.Function):
     """keys / values source of the two cross-attentions of one twin level from the stacked states hs (2B, L, D):
     mix2d = cat(image tokens, 3D-stream states), mix3d = cat(object tokens, 2D-stream states) (reference med.py:549-562);
@@ -1176,6 +1179,10 @@ class _TwinMixFn(torch.autograd.Function):
     def forward(ctx, enc2d, enc3d, hs):
         B = hs.shape[0] // 2
         ctx.cfg = (enc2d.shape[1], enc3d.shape[1])
+        if (_TWIN_MIX_KERNEL[0] and hs.is_cuda and hs.dtype == torch.bfloat16 and enc2d.dtype == torch.bfloat16 and enc3d.dtype == torch.bfloat16
+                and hs.is_contiguous() and enc2d.is_contiguous() and enc3d.is_contiguous() and hs.shape[-1] % 8 == 0):
+            from . import _ext
+            return _ext.twin_mix(enc2d, hs[B:], enc3d, hs[:B])   # both concatenations in one streaming launch
         return torch.cat((enc2d, hs[B:]), dim=1), torch.cat((enc3d, hs[:B]), dim=1)
 
     @staticmethod

@@ -151,6 +151,11 @@ BQ_API int bq_bn_backward(const void *dy, const void *x, const float *scale, con
 
 /* exact (erf) GELU, bf16 (vit.py:23-41 Mlp act_layer=nn.GELU); n % 8 == 0, 16-B aligned */
 BQ_API int bq_gelu_fwd_bf16(const void *x, void *y, long n, void *stream);
+/* The key / value sources of the two cross-attentions of a twin level (med.py:549-562), both concatenations in one
+ * launch: out_g (B, P_g + L, D) = cat(fixed_g (B, P_g, D), tail_g (B, L, D)) along the token axis, bf16, D % 8 == 0,
+ * contiguous tensors. */
+BQ_API int bq_twin_mix_bf16(const void *fixed_a, const void *tail_a, void *out_a, int Pa, const void *fixed_b,
+                            const void *tail_b, void *out_b, int Pb, int B, int L, int D, void *stream);
 
 /* The same over TWO row groups with their own LayerNorm parameters -- the 2D and the 3D text stream of the twin encoder
  * (models/med.py:549-614) stacked in one (M, H) tensor: rows [0, M/2) use gamma / beta, rows [M/2, M) gamma2 / beta2; one

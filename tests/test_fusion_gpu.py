@@ -209,3 +209,13 @@ def test_twin_layer_norm_kernel_equals_two_single_launches(dev):
                 assert torch.isfinite(y[s].float()).all() and torch.isfinite(dx[s].float()).all()
                 kept = (dx[s].float() != 0).float().mean().item()
                 assert 0.85 < kept < 0.95, kept
+
+
+def test_twin_mix_kernel_equals_torch_cat(dev):
+    from bridgeqa_amd import _ext
+    g = torch.Generator().manual_seed(3)
+    for B, Pa, Pb, L, D in ((16, 1025, 256, 20, 768), (2, 7, 300, 5, 256), (1, 1, 1, 1, 8)):
+        mk = lambda *s: torch.randn(*s, generator=g).to(dev).to(torch.bfloat16)
+        fa, fb, hs = mk(B, Pa, D), mk(B, Pb, D), mk(2 * B, L, D)
+        oa, ob = _ext.twin_mix(fa, hs[B:], fb, hs[:B])
+        assert torch.equal(oa, torch.cat((fa, hs[B:]), 1)) and torch.equal(ob, torch.cat((fb, hs[:B]), 1))

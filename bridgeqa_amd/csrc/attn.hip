@@ -732,19 +732,19 @@ __device__ __forceinline__ void dq_tile(const unsigned char *s_k, const unsigned
     }
 }
 
-template <int MINW, bool PLAIN = false>
-__global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
-                                                          const __bf16 *__restrict__ V,
-                                                          const __bf16 *__restrict__ dO, const float *__restrict__ LSE,
-                                                          const __bf16 *__restrict__ O, float *__restrict__ DELTA,
-                                                          __bf16 *__restrict__ dQ, BwdDims dm) {
+template <bool PLAIN = false>
+__device__ __forceinline__ void attn_bwd_dq_body(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+                                                 const __bf16 *__restrict__ V, const __bf16 *__restrict__ dO,
+                                                 const float *__restrict__ LSE, const __bf16 *__restrict__ O,
+                                                 float *__restrict__ DELTA, __bf16 *__restrict__ dQ, const BwdDims &dm,
+                                                 const int bx, const int bh) {
   __shared__ __align__(16) unsigned char s_k[2][AT_KB * 128];  // double-buffered: see attn_fwd_kernel
   __shared__ __align__(16) unsigned char s_v[2][AT_KB * 128];
   const float scale = dm.scale;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
+  const int b = bh / dm.H, hd = bh % dm.H;
   const unsigned seed = eff_seed(dm);
-  const int q0 = blockIdx.x * AT_QB + wid * AT_QW;
+  const int q0 = bx * AT_QB + wid * AT_QW;
   const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
   const __bf16 *Gb = dO + b * dm.o_bs + hd * dm.o_hs;
   const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
@@ -821,6 +821,15 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const __bf16 *__
       dq_tile<true, true>(s_k[(nkt - 1) & 1], s_v[(nkt - 1) & 1], qf, gf, dm, nullptr, c, scale, lse, delta, seed, bh, q0 + r, nkt - 1, true, r, h, a0, a1);
   }
   if (q0 + r < dm.Lq) store_T(dQ + b * dm.q_bs + hd * dm.q_hs + (long)(q0 + r) * dm.q_rs, a0, a1, h, scale);
+}
+
+template <int MINW, bool PLAIN = false>
+__global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+                                                          const __bf16 *__restrict__ V,
+                                                          const __bf16 *__restrict__ dO, const float *__restrict__ LSE,
+                                                          const __bf16 *__restrict__ O, float *__restrict__ DELTA,
+                                                          __bf16 *__restrict__ dQ, BwdDims dm) {
+  attn_bwd_dq_body<PLAIN>(Q, K, V, dO, LSE, O, DELTA, dQ, dm, blockIdx.x, blockIdx.y);
 }
 
 // Lq <= 32: the four waves share the queries and split the key tiles (see attn_fwd_narrow_kernel); dQ^T partials are
@@ -989,12 +998,15 @@ __device__ __forceinline__ void dkv_tile(const unsigned char *s_q, const unsigne
     }
 }
 
-template <bool PLAIN = false>
+// IDELTA: delta[q] = rowsum(dO o O) is computed here from O (contiguous (B, Lq, H, 64)) instead of read from DELTA -- for
+// the launch that runs the dQ and the dK/dV pass of a SMALL attention side by side (attn_bwd_small_kernel), where the
+// dQ pass's DELTA is not ordered before this pass
+template <bool PLAIN = false, bool IDELTA = false>
 __device__ __forceinline__ void attn_bwd_dkv_body(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
                                                   const __bf16 *__restrict__ V, const __bf16 *__restrict__ dO,
                                                   const float *__restrict__ LSE, const float *__restrict__ DELTA,
                                                   __bf16 *__restrict__ dK, __bf16 *__restrict__ dV, const BwdDims &dm,
-                                                  const int bx, const int bh) {
+                                                  const int bx, const int bh, const __bf16 *__restrict__ O = nullptr) {
   __shared__ __align__(16) unsigned char s_q[2][AT_KB * 128];  // double-buffered: see attn_fwd_kernel
   __shared__ __align__(16) unsigned char s_g[2][AT_KB * 128];
   __shared__ __align__(16) float s_lse[2][AT_KB];
@@ -1042,7 +1054,23 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const __bf16 *__restrict__ Q, 
     }
     qa = stage_ld(qbase, qoa); qb = stage_ld(qbase, qob);
     ga = stage_ld(gbase, goa); gb = stage_ld(gbase, gob);
-    if (t < AT_KB) { rl = lseb[min(qt * AT_KB + t, dm.Lq - 1)]; rd = delb[min(qt * AT_KB + t, dm.Lq - 1)]; }
+    if (t < AT_KB) {
+      const int qq = min(qt * AT_KB + t, dm.Lq - 1);
+      rl = lseb[qq];
+      if (IDELTA) {
+        const __bf16 *grow = Gb + (long)qq * dm.o_rs, *orow = O + (((long)b * dm.Lq + qq) * dm.H + hd) * AT_D;
+        float acc = 0.0f;
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+          const bf16x8 gv = *reinterpret_cast<const bf16x8 *>(grow + 8 * s8), ov = *reinterpret_cast<const bf16x8 *>(orow + 8 * s8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc += (float)ov[j] * (float)gv[j];
+        }
+        rd = acc;
+      } else {
+        rd = delb[qq];
+      }
+    }
   };
   auto commit = [&](int buf) {
     stage_store(s_q[buf], t, qa); stage_store(s_q[buf], t + 256, qb);
@@ -1103,6 +1131,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_pair_kernel(const AttnPai
   const int nb = (dm.Lk + AT_QB - 1) / AT_QB + (dm.Lk2 > 0 ? (dm.Lk2 + AT_QB - 1) / AT_QB : 0);
   if ((int)blockIdx.x >= nb) return;
   attn_bwd_dkv_body<false>(a.Q[g], a.K[g], a.V[g], a.dO[g], a.LSE[g], a.DELTA[g], a.dK[g], a.dV[g], dm, blockIdx.x, blockIdx.y);
+}
+
+// A SMALL attention's backward (at most one 128-row block of queries and of keys: the 20-token self-attentions of the twin
+// levels, the 5-token decoder's self- and cross-attentions) in ONE launch: blockIdx.z = 0 runs the dQ pass, 1 the dK/dV pass
+// with its own delta -- both are ~6 us launches at the floor of what a launch costs, 36 of each per c3 step.
+__global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+                                                                const __bf16 *__restrict__ V,
+                                                                const __bf16 *__restrict__ dO,
+                                                                const float *__restrict__ LSE,
+                                                                const __bf16 *__restrict__ O, float *__restrict__ DELTA,
+                                                                __bf16 *__restrict__ dQ, __bf16 *__restrict__ dK,
+                                                                __bf16 *__restrict__ dV, BwdDims dm) {
+  if (blockIdx.z == 0) attn_bwd_dq_body<false>(Q, K, V, dO, LSE, O, DELTA, dQ, dm, 0, blockIdx.y);
+  else attn_bwd_dkv_body<false, true>(Q, K, V, dO, LSE, DELTA, dK, dV, dm, 0, blockIdx.y, O);
 }
 
 }  // namespace bq
@@ -1189,6 +1231,13 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_bwd(
                                        st, (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)dO, \
                                        LSE, (const __bf16 *)O, DELTA, (__bf16 *)dQ, dm)
   static const bool narrow_ok = !getenv("BQ_ATTN_NO_NARROW");
+  static const bool small_ok = !getenv("BQ_ATTN_NO_SMALL");
+  if (small_ok && !plain && Lq <= AT_QB && Lk <= AT_QB) {
+    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(1, B * H, 2), dim3(256), 0, st, (const __bf16 *)Q, (const __bf16 *)K,
+                       (const __bf16 *)V, (const __bf16 *)dO, LSE, (const __bf16 *)O, DELTA, (__bf16 *)dQ, (__bf16 *)dK,
+                       (__bf16 *)dV, dm);
+    return check_launch("attn_bwd_small");
+  }
   if (narrow_ok && Lq <= AT_QW && Lk > 2 * AT_KB)
     hipLaunchKernelGGL(attn_bwd_dq_narrow_kernel, dim3(1, B * H), dim3(256), 0, st, (const __bf16 *)Q, (const __bf16 *)K,
                        (const __bf16 *)V, (const __bf16 *)dO, LSE, (const __bf16 *)O, DELTA, (__bf16 *)dQ, dm);

@@ -952,13 +952,13 @@ class _QKVAttention(torch.autograd.Function):
     """Cross-attention with q (B, Lq, H, 64) and a fused K/V tensor kv (B, Lk, 2, H, 64); dkv comes back packed."""
 
     @staticmethod
-    def forward(ctx, q, kv, scale, mask_log2, p_drop, want_probs=False):
+    def forward(ctx, q, kv, scale, mask_log2, p_drop, want_probs=False, sink=None):
         from . import _ext
         seed, st = _seed_args(p_drop, q.device)
         out, lse = _ext.attn_fwd(q, kv[:, :, 0], kv[:, :, 1], scale, mask_log2, p_drop, seed, st)
         ctx.save_for_backward(q, kv, out, lse, mask_log2 if mask_log2 is not None else q.new_empty(0),
                               st if st is not None else q.new_empty(0))
-        ctx.cfg = (scale, p_drop, seed, mask_log2 is not None, st is not None)
+        ctx.cfg = (scale, p_drop, seed, mask_log2 is not None, st is not None, sink)
         if want_probs:
             probs = _ext.attn_probs(q, kv[:, :, 0], lse, scale, mask_log2)
             ctx.mark_non_differentiable(probs)
@@ -969,12 +969,14 @@ class _QKVAttention(torch.autograd.Function):
     def backward(ctx, grad_out, _gp=None):
         from . import _ext
         q, kv, out, lse, mask_log2, st = ctx.saved_tensors
-        scale, p_drop, seed, has_mask, has_st = ctx.cfg
+        scale, p_drop, seed, has_mask, has_st, sink = ctx.cfg
         qc = q if q.is_contiguous() else q.contiguous()
-        dq, dkv = torch.empty_like(qc), torch.empty_like(kv)
+        dq = torch.empty_like(qc)
+        # sink = (HoistedKV, slot): kv is this layer's column block of a hoisted projection and so is its gradient
+        dkv = sink[0].grad_view(sink[1], kv) if sink is not None else torch.empty_like(kv)
         _ext.attn_bwd(qc, kv[:, :, 0], kv[:, :, 1], out, lse, grad_out.contiguous(), scale, dq, dkv[:, :, 0], dkv[:, :, 1],
                       mask_log2 if has_mask else None, p_drop, seed, st if has_st else None)
-        return dq, dkv, None, None, None, None
+        return dq, dkv, None, None, None, None, None
 
 
 # ---- the two text streams of the twin encoder as ONE batch ---------------------------------------------------------
@@ -1589,8 +1591,9 @@ def attention_q_kv2(q, kv1, kv2, scale, dropout_p=0.0, mask=None, sink=None):
     return ctx
 
 
-def _packed_ok(t, mask):
-    return (t.is_cuda and t.dtype == torch.bfloat16 and t.shape[-1] == 64 and t.is_contiguous()
+def _packed_ok(t, mask, strided=False):
+    return (t.is_cuda and t.dtype == torch.bfloat16 and t.shape[-1] == 64
+            and (t.is_contiguous() or (strided and t.stride(-1) == 1 and all(st % 8 == 0 for st in t.stride()[:-1])))
             and (mask is None or (mask.dim() == 4 and mask.shape[1] == 1 and mask.shape[2] == 1)))
 
 
@@ -1618,9 +1621,15 @@ def attention_packed(qkv, scale, dropout_p=0.0, mask=None, causal=False, return_
     return (ctx, probs) if return_probs else ctx
 
 
-def attention_q_kv(q, kv, scale, dropout_p=0.0, mask=None, return_probs=False):
+def attention_q_kv(q, kv, scale, dropout_p=0.0, mask=None, return_probs=False, sink=None):
     """Cross-attention: q (B, Lq, H, D), kv (B, Lk, 2, H, D) from a fused K/V projection -> (B, Lq, H, D)
-    (return_probs: see attention_packed)."""
+    (return_probs: see attention_packed).  sink = (HoistedKV, slot): kv is that projection's strided block for this
+    layer (kernel path only) and its gradient is written in place into the projection's gradient buffer."""
+    if sink is not None:
+        if not (_packed_ok(kv, mask, strided=True) and q.is_cuda and q.dtype == torch.bfloat16 and q.stride(-1) == 1):
+            raise RuntimeError("attention_q_kv: a hoisted K/V block needs the kernel path (bf16, D = 64, key-only mask)")
+        return _QKVAttention.apply(q, kv, scale, _mask_log2(mask, kv.shape[0], kv.shape[1]), float(dropout_p),
+                                   bool(return_probs), sink)
     if _packed_ok(kv, mask) and q.is_cuda and q.dtype == torch.bfloat16 and q.stride(-1) == 1:
         return _QKVAttention.apply(q, kv, scale, _mask_log2(mask, kv.shape[0], kv.shape[1]), float(dropout_p),
                                    bool(return_probs))

@@ -106,6 +106,14 @@ class TwoSegmentStates(object):
         self.hoisted, self.slot, self.tail = hoisted, slot, tail
 
 
+class HoistedStates(object):
+    """encoder_hidden_states whose K/V projection for this layer is slot `slot` of `hoisted` (ops.HoistedKV): the
+    decoder's 12 cross-attentions read the same question states, so their key / value linears run as one GEMM."""
+
+    def __init__(self, hoisted, slot):
+        self.hoisted, self.slot = hoisted, slot
+
+
 class BertSelfAttention(nn.Module):
     def __init__(self, config, is_cross_attention):
         super().__init__()
@@ -150,7 +158,7 @@ class BertSelfAttention(nn.Module):
         want = output_attentions or (is_cross and self.save_attention)
         H, D = self.num_attention_heads, self.attention_head_size
         p_drop = self.dropout.p if self.training else 0.0
-        two_seg = isinstance(encoder_hidden_states, TwoSegmentStates)
+        two_seg = isinstance(encoder_hidden_states, (TwoSegmentStates, HoistedStates))
         # the fused kernels also serve output_attentions (the map is rebuilt from the LSE, detached); a caller that
         # differentiates through the map -- save_attention + the attn_gradients hook -- gets the reference composition
         hooked = is_cross and self.save_attention
@@ -171,6 +179,13 @@ class BertSelfAttention(nn.Module):
                 ctx = ops.attention_q_kv2(q, kv1, kv2, 1.0 / math.sqrt(D), p_drop, encoder_attention_mask,
                                           sink=(es.hoisted, es.slot))
                 present = None
+            elif is_cross and isinstance(encoder_hidden_states, HoistedStates):
+                es = encoder_hidden_states
+                q = self._heads(ops.linear(hidden_states, self.query.weight, self.query.bias, tap=tap))
+                kv = es.hoisted.kv(es.slot)
+                ctx = ops.attention_q_kv(q, kv, 1.0 / math.sqrt(D), p_drop, encoder_attention_mask, return_probs=rp,
+                                         sink=(es.hoisted, es.slot))
+                present = (kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3))
             elif is_cross:
                 Lk = encoder_hidden_states.shape[1]
                 q = self._heads(ops.linear(hidden_states, self.query.weight, self.query.bias, tap=tap))
@@ -332,6 +347,7 @@ class BertLayer(nn.Module):
 
 
 _TWIN_BATCH = [os.environ.get("BQ_TWIN_BATCH", "1") != "0"]  # both text streams of a twin level as one stacked batch
+_HOIST_CROSS_KV = os.environ.get("BQ_HOIST_CROSS_KV", "1") != "0"  # plain encoder / decoder: all layers' cross K/V in one GEMM
 _TWO_SEGMENT = os.environ.get("BQ_TWO_SEGMENT_KV", "0") == "1"
 _TWO_SEGMENT_FORK = os.environ.get("BQ_TWO_SEGMENT_FORK", "0") == "1"  # also when the twin branches run on two streams
 
@@ -356,12 +372,26 @@ class BertEncoder(nn.Module):
         all_cross_attentions = () if output_attentions and self.config.add_cross_attention else None
         next_decoder_cache = () if use_cache else None
         layers = [i for i in range(self.config.num_hidden_layers) if forward_layers is None or i in forward_layers]
-        for i in layers:
+        hoisted = None
+        key_only = lambda m: m is None or (m.dim() == 4 and m.shape[1] == 1 and m.shape[2] == 1)
+        if (_HOIST_CROSS_KV and mode == "multimodal" and len(layers) > 1 and past_key_values is None
+                and torch.is_tensor(encoder_hidden_states) and encoder_hidden_states.is_cuda
+                and ops.compute_dtype() == torch.bfloat16 and key_only(encoder_attention_mask)
+                and self.layer[0].crossattention.self.attention_head_size == 64
+                and not any(self.layer[i].crossattention.self.save_attention for i in layers)
+                and all(lin.bias is not None and ops._param_ok(lin.weight, lin.bias) for i in layers
+                        for lin in (self.layer[i].crossattention.self.key, self.layer[i].crossattention.self.value))):
+            # every layer's cross-attention reads the SAME states: their key / value projections as one GEMM (and one dX,
+            # one weight-gradient record) instead of one small launch per layer
+            hoisted = ops.HoistedKV(ops._c(encoder_hidden_states), [self.layer[i].crossattention.self for i in layers],
+                                    self.config.num_attention_heads)
+        for n, i in enumerate(layers):
             if output_hidden_states:
                 all_hidden_states = all_hidden_states + (hidden_states,)
             past_key_value = past_key_values[i] if past_key_values is not None else None
             want = _wants(output_attentions, i, layers[-1])
-            layer_outputs = self.layer[i](hidden_states, attention_mask, None, encoder_hidden_states,
+            layer_outputs = self.layer[i](hidden_states, attention_mask, None,
+                                          HoistedStates(hoisted, n) if hoisted is not None else encoder_hidden_states,
                                           encoder_attention_mask, past_key_value, want, mode=mode,
                                           layernorm_idx=layernorm_idx)
             hidden_states = layer_outputs[0]

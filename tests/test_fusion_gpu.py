@@ -219,3 +219,44 @@ def test_twin_mix_kernel_equals_torch_cat(dev):
         fa, fb, hs = mk(B, Pa, D), mk(B, Pb, D), mk(2 * B, L, D)
         oa, ob = _ext.twin_mix(fa, hs[B:], fb, hs[:B])
         assert torch.equal(oa, torch.cat((fa, hs[B:]), 1)) and torch.equal(ob, torch.cat((fb, hs[:B]), 1))
+
+
+def test_decoder_hoisted_cross_kv_equals_per_layer_projections(dev, bf16):
+    """plain encoder / decoder: the key / value projections of all layers' cross-attentions as ONE GEMM over the shared
+    encoder states (ops.HoistedKV, gradients written in place into one buffer) against the per-layer projections"""
+    from bridgeqa_amd import med
+    torch.manual_seed(11)
+    cfg = med.BertConfig(hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=3,
+                         vocab_size=200, max_position_embeddings=64, encoder_width=256)
+    dec = med.BertLMHeadModel(config=cfg).to(dev).eval()
+    for p in dec.parameters():
+        p.data.add_(0.05 * torch.randn_like(p))
+    B, L, Lk = 4, 7, 20
+    aid = torch.randint(1, 200, (B, L), device=dev)
+    am = torch.ones(B, L, dtype=torch.long, device=dev)
+    am[1, 5:] = 0
+    em = torch.ones(B, Lk, dtype=torch.long, device=dev)
+    em[2, 13:] = 0
+    res = {}
+    for hoist in (False, True):
+        med._HOIST_CROSS_KV = hoist
+        try:
+            enc = torch.randn(B, Lk, 256, device=dev, generator=torch.Generator(dev).manual_seed(5)).requires_grad_(True)
+            for p in dec.parameters():
+                p.grad = None
+            r = dec(aid, attention_mask=am, encoder_hidden_states=enc, encoder_attention_mask=em,
+                    labels=aid.masked_fill(am == 0, -100), return_dict=True, reduction="none")
+            r.loss.sum().backward()
+            res[hoist] = dict(loss=r.loss.detach().float().clone(), logits=r.logits.detach().float().clone(),
+                              enc=enc.grad.float().clone(),
+                              grads={n: p.grad.float().clone() for n, p in dec.named_parameters() if p.grad is not None})
+        finally:
+            med._HOIST_CROSS_KV = True
+    a, b = res[False], res[True]
+    rel = lambda x, y: ((x - y).norm() / (y.norm() + 1e-20)).item()
+    assert rel(b["logits"], a["logits"]) <= 5e-3 and rel(b["loss"], a["loss"]) <= 5e-3
+    assert rel(b["enc"], a["enc"]) <= 2e-2
+    assert a["grads"].keys() == b["grads"].keys()
+    assert any("crossattention.self.key.weight" in n for n in a["grads"])
+    worst = max((rel(b["grads"][n], a["grads"][n]), n) for n in a["grads"])
+    assert worst[0] <= 2e-2, worst

@@ -956,6 +956,33 @@ def colsum_grouped(mats):
     return outs
 
 
+_lib.bq_wgrad_rows_supported.argtypes = [_i, _i]
+_lib.bq_wgrad_rows_supported.restype = ctypes.c_int
+_lib.bq_wgrad_rows_workgroups.argtypes = [_l, _i, _i, _i]
+_lib.bq_wgrad_rows_workgroups.restype = ctypes.c_int
+_lib.bq_wgrad_rows_bf16.argtypes = [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _vp]
+_lib.bq_wgrad_rows_bf16.restype = ctypes.c_int
+
+
+def wgrad_rows_ok(Ni, Nj):
+    return bool(_lib.bq_wgrad_rows_supported(int(Ni), int(Nj)))
+
+
+def wgrad_rows(x, dy, out, workgroups=0):
+    """out (Nj, ldo) fp32 = dy^T x over whole rows: x (R, Ni) bf16 rows of stride ldp, dy (R, Nj) bf16; every operand row
+    read once, per-workgroup partial products summed by a second kernel (bq_wgrad_rows_bf16; the detector's SharedMLP
+    weight gradients).  out must be a whole (Nj, ldo) buffer: its columns [Ni, ldo) are zeroed."""
+    _mat(x, "x"), _mat(dy, "dy")
+    if out.dtype != torch.float32 or out.stride(1) != 1 or x.shape[0] != dy.shape[0] or out.shape[0] != dy.shape[1]:
+        raise RuntimeError("wgrad_rows: out must be fp32 (Nj, ldo) rows, x and dy the same number of rows")
+    with torch.cuda.device(x.device):
+        w = _lib.bq_wgrad_rows_workgroups(x.shape[0], x.shape[1], dy.shape[1], int(workgroups))
+        part = torch.empty(w * dy.shape[1] * out.stride(0), dtype=torch.float32, device=x.device)
+        _check(_lib.bq_wgrad_rows_bf16(_p(x), _p(dy), _p(out), _p(part), x.shape[0], x.shape[1], dy.shape[1], x.stride(0),
+                                       dy.stride(0), out.stride(0), int(workgroups), _stream()), "wgrad_rows")
+    return out
+
+
 # ---- SharedMLP layer on point-major rows: 1x1 convolution + BatchNorm statistics in its epilogue (csrc/gemm.hip) ----
 _lib.bq_pwconv_records.argtypes = [_l, _i]
 _lib.bq_pwconv_records.restype = ctypes.c_int

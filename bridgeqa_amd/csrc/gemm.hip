@@ -613,7 +613,14 @@ namespace bq {
 // KT = K tiles per pipeline step (1 or 2): with KT = 2 a step stages, waits for and consumes TWO 64-wide K tiles between
 // barriers -- half the barriers / counted waits of a long contraction (text side: K = 2304 / 3072 at M <= 640 rows, a
 // latency chain of 36-48 steps otherwise).
-template <int BJ, bool P_XC, bool Q_XC, int EPI, bool OUT_F32, int KT = 1>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// NS = LDS stages (NS - 1 K tiles in flight): 3 everywhere except the detector's weight gradients (a contraction over
+// millions of rows cut into a few hundred workgroups, which must keep HBM busy with few workgroups: 5)
+template <int BJ, bool P_XC, bool Q_XC, int EPI, bool OUT_F32, int KT = 1, int NS = 3>
 __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
   static_assert(BJ == 64 || (BJ == 32 && !Q_XC), "32-wide j tiles only for K-contiguous Q");
   static_assert(KT == 1 || KT == 2 || (KT == 4 && BJ == 32), "one, two or (32-row tiles) four K tiles per step");
@@ -625,7 +632,7 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
   // nothing for the forward / dX forms (a K tile costs ~0.24 us either way: the loop is bound by the ISSUE of its 3-4
   // LDS-DMA instructions per wave, ~100 cycles each, not by memory latency) and halve the weight-gradient form
   // (80 KB of LDS = 2 workgroups per CU for a kernel that lives on its output stores) => 3.
-  constexpr int NS = 3;
+  static_assert(NS >= 3 && NS * STAGE <= 160 * 1024, "LDS stages");
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -638,10 +645,25 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
     if (t >= args.p[k].tile0) pi = k;
   const GemmProblem &pr = args.p[pi];
   const int ksplit = OUT_F32 ? pr.ksplit : 1;
-  const int tl = (t - pr.tile0) / ksplit, ks = (t - pr.tile0) % ksplit;
+  const int Ni = pr.Ni, Nj = pr.Nj, Kc = pr.Kc;
+  int tl = t - pr.tile0, ks = 0;
+  if (ksplit > 1) {
+    // a cut contraction (detector weight gradients: millions of rows, 1 - 8 output tiles): the output tiles of ONE piece
+    // read the same rows of both operands, so they get neighbouring slots of the same XCD (workgroups go to the XCDs
+    // round-robin by blockIdx) and meet in its L2 -- tile-major order read every operand row once per tile from HBM
+    const int lt = t - pr.tile0;
+    const int ntl = pr.tiles_i * ((Nj + BJ - 1) / BJ);
+    if ((ksplit & 7) == 0 && (pr.tile0 & 7) == 0) {
+      const int slot = lt >> 3;
+      tl = slot % ntl;
+      ks = (slot / ntl) * 8 + (lt & 7);
+    } else {
+      tl = lt % ntl;
+      ks = lt / ntl;
+    }
+  }
   const int bj = tl / pr.tiles_i, bi = tl % pr.tiles_i;
   const int i0 = bi * 64, j0 = bj * BJ;
-  const int Ni = pr.Ni, Nj = pr.Nj, Kc = pr.Kc;
   const int ldp = pr.ldp, ldq = pr.ldq;
   const int nkt_all = (Kc + 63) >> 6;
   const int kt_per = (nkt_all + ksplit - 1) / ksplit;
@@ -723,12 +745,8 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
   for (int step = 0; step < nsteps; ++step) {
     // step `step` has landed for this wave (steps step+1 .. step+NS-2 may still be in flight); after the barrier: for
     // every wave, and every wave has finished reading the buffer that step step+NS-1 is about to overwrite
-    static_assert(NS == 3, "the counted waits below are (NS - 2) * NDMA");
-    if (NDMA == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    static_assert((NS - 2) * NDMA <= 63, "vmcnt is a 6-bit counter");
+    wait_vmcnt<(NS - 2) * NDMA>();
     BQ_BARRIER();
     stage(step + NS - 1);
 #pragma unroll
@@ -1127,6 +1145,17 @@ static int launch_variant(const GemmArgs &ga, int tile, hipStream_t st, bool lon
         return 0;
       }
     }
+    if constexpr (P_XC && Q_XC && OUT_F32 && EPI == EPI_NONE) {
+      // every problem a cut contraction with >= 16 K tiles per piece (the detector's weight gradients): deep staging
+      static const int deep_on = getenv("BQ_GEMM_DEEP") ? atoi(getenv("BQ_GEMM_DEEP")) : 1;
+      bool deep = deep_on != 0;
+      for (int k = 0; k < ga.n; ++k)
+        deep = deep && ga.p[k].ksplit > 1 && ((ga.p[k].Kc + 63) / 64) >= 16 * ga.p[k].ksplit;
+      if (deep) {
+        hipLaunchKernelGGL((gemm64_kernel<64, P_XC, Q_XC, EPI, OUT_F32, 1, 5>), dim3(ga.total_tiles), dim3(256), 0, st, ga);
+        return 0;
+      }
+    }
     hipLaunchKernelGGL((gemm64_kernel<64, P_XC, Q_XC, EPI, OUT_F32>), dim3(ga.total_tiles), dim3(256), 0, st, ga);
   } else {
     if constexpr (!Q_XC) {
@@ -1273,6 +1302,224 @@ extern "C" int bq_colsum_grouped_bf16(const bq_colsum_desc *d, int n, void *stre
     if (rc) return rc;
   }
   return 0;
+}
+
+// ======================================================================================================================
+// wgrad_rows_kernel: dW (Nj x Ni, fp32) += Q^T P over a piece of the R rows, for the detector's SharedMLP layers -- R in
+// the millions, Ni / Nj <= 256 channels.  The 64-tile kernel above cuts this into (tile, piece) workgroups and so reads
+// every operand row once per TILE (measured: its 3 - 8 tiles do not meet in the L2; SA1's first layer moved 1.37 GB for
+// 0.84 GB of operands); here a workgroup stages WHOLE rows -- TI 64-column units of P and TJ of Q per K tile, the gemm64
+// LDS images and transposing fragment reads -- and keeps all TI x TJ output tiles in its accumulators, so HBM sees every
+// row once.  One workgroup per CU (3 stages x (TI + TJ) x 8 KB), a contiguous run of K tiles each; every workgroup
+// stores its product into its own slice and wgrad_rows_reduce_kernel sums the slices.  HBM roofline: R (Ni + Nj) 2
+// bytes per launch.
+// ======================================================================================================================
+namespace bq {
+
+struct WgradRowsArgs {
+  const __bf16 *P, *Q;
+  float *part;   // (workgroups, Nj, ldo) partial products, one slice per workgroup
+  float *out;    // (Nj, ldo): written by wgrad_rows_reduce_kernel
+  int R, Ni, Nj, ldp, ldq, ldo, pieces;
+  unsigned p_bytes, q_bytes;
+};
+
+template <int TI, int TJ>
+__global__ __launch_bounds__(256) void wgrad_rows_kernel(const WgradRowsArgs ar) {
+  constexpr int UNITS = TI + TJ, STAGE = UNITS * 8192, NS = 3, NDMA = 2 * UNITS;
+  static_assert(NS * STAGE <= 160 * 1024 && (NS - 2) * NDMA <= 63, "LDS stages / counted waits");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int nkt_all = (ar.R + 63) >> 6;
+  const int kt_per = (nkt_all + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int kt0 = (int)blockIdx.x * kt_per;
+  const int nkt = max(0, min(kt_per, nkt_all - kt0));   // (0: this workgroup's slice is all zeros)
+
+  const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void *)ar.P, 0, ar.p_bytes, 0x00020000);
+  const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void *)ar.Q, 0, ar.q_bytes, 0x00020000);
+  const int cp = lane & 7;
+  unsigned vp[2], vq[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const int ur = (wave * 2 + d) * 8 + (lane >> 3);
+    vp[d] = (unsigned)((ur * ar.ldp + (cp ^ (xg(ur) << 1)) * 8) * 2) + (unsigned)kt0 * (unsigned)(64 * ar.ldp * 2);
+    vq[d] = (unsigned)((ur * ar.ldq + (cp ^ (xg(ur) << 1)) * 8) * 2) + (unsigned)kt0 * (unsigned)(64 * ar.ldq * 2);
+  }
+  const unsigned p_step = (unsigned)(64 * ar.ldp * 2), q_step = (unsigned)(64 * ar.ldq * 2);
+
+  auto stage = [&](int step) {
+    const bool live = step < nkt;
+    const unsigned base = (unsigned)((step % NS) * STAGE);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+#pragma unroll
+      for (int u = 0; u < TI; ++u)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_void_t *)(smem + base + u * 8192 + (wave * 2 + d) * 1024), 16,
+                                                 live ? vp[d] + u * 128 : 0x80000000u, 0, 0, 0);
+#pragma unroll
+      for (int v = 0; v < TJ; ++v)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_void_t *)(smem + base + (TI + v) * 8192 + (wave * 2 + d) * 1024),
+                                                 16, live ? vq[d] + v * 128 : 0x80000000u, 0, 0, 0);
+      vp[d] += p_step;
+      vq[d] += q_step;
+    }
+  };
+
+  const int row16 = lane & 15, q4 = lane >> 4;
+  const int kc_base = 0;  // (K-contiguous form unused here)
+  int xc_base[4];
+  {
+    const int q = (lane & 15) >> 2, p = lane & 3, g = (q >> 1) | ((q4 & 1) << 1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xc_base[s] = (8 * q4 + q) * 128 + ((s ^ g) << 5) + 8 * p;
+  }
+
+  f32x4 acc[TI][TJ][2][2];
+#pragma unroll
+  for (int u = 0; u < TI; ++u)
+#pragma unroll
+    for (int v = 0; v < TJ; ++v)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[u][v][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int p = 0; p < NS - 1; ++p) stage(p);
+  for (int step = 0; step < nkt; ++step) {
+    wait_vmcnt<(NS - 2) * NDMA>();
+    BQ_BARRIER();
+    stage(step + NS - 1);
+    const unsigned char *buf = smem + (step % NS) * STAGE;
+#pragma unroll
+    for (int v = 0; v < TJ; ++v) {
+      bf16x8 fb[2][2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fb[b][kk] = read_frag<true>(buf + (TI + v) * 8192, wc * 2 + b, kk, kc_base, xc_base);
+#pragma unroll
+      for (int u = 0; u < TI; ++u) {
+        bf16x8 fa[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag<true>(buf + u * 8192, wr * 2 + a, kk, kc_base, xc_base);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              acc[u][v][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][kk], fb[b][kk], acc[u][v][a][b], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  float *slice = ar.part + (long)blockIdx.x * ar.Nj * ar.ldo;
+#pragma unroll
+  for (int u = 0; u < TI; ++u)
+#pragma unroll
+    for (int v = 0; v < TJ; ++v)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int i = u * 64 + wr * 32 + a * 16 + q4 * 4;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int j = v * 64 + wc * 32 + b * 16 + row16;
+          if (i < ar.Ni && j < ar.Nj)
+            *reinterpret_cast<float4 *>(slice + (long)j * ar.ldo + i) =
+                make_float4(acc[u][v][a][b][0], acc[u][v][a][b][1], acc[u][v][a][b][2], acc[u][v][a][b][3]);
+        }
+      }
+}
+
+// out = sum over the workgroups' slices (plain stores: no atomics -- 4096 scattered fp32 atomics per output tile and
+// workgroup were the whole cost of the cut contraction, ~50 G atomics/s -- and a fixed summation order)
+__global__ __launch_bounds__(256) void wgrad_rows_reduce_kernel(const WgradRowsArgs ar) {
+  const int n4 = ar.Nj * ar.ldo / 4;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n4) return;
+  const float4 *src = reinterpret_cast<const float4 *>(ar.part) + e;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  int p = 0;
+  for (; p + 4 <= ar.pieces; p += 4) {
+    const float4 a = src[(long)p * n4], b = src[(long)(p + 1) * n4], c = src[(long)(p + 2) * n4], d = src[(long)(p + 3) * n4];
+    s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+    s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+    s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w;
+    s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
+  }
+  for (; p < ar.pieces; ++p) {
+    const float4 a = src[(long)p * n4];
+    s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+  }
+  const int col = (e * 4) % ar.ldo;
+  float4 r = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                         (s0.w + s1.w) + (s2.w + s3.w));
+  if (col >= ar.Ni) r = make_float4(0.f, 0.f, 0.f, 0.f);   // padding columns of a slice are never written
+  reinterpret_cast<float4 *>(ar.out)[e] = r;
+}
+
+template <int TI>
+static int launch_wgrad_rows_j(int tj, int wgs, hipStream_t st, const WgradRowsArgs &a) {
+  if constexpr (TI + 1 <= 6)
+    if (tj == 1) { hipLaunchKernelGGL((wgrad_rows_kernel<TI, 1>), dim3(wgs), dim3(256), 0, st, a); return 0; }
+  if constexpr (TI + 2 <= 6)
+    if (tj == 2) { hipLaunchKernelGGL((wgrad_rows_kernel<TI, 2>), dim3(wgs), dim3(256), 0, st, a); return 0; }
+  if constexpr (TI + 4 <= 6)
+    if (tj == 4) { hipLaunchKernelGGL((wgrad_rows_kernel<TI, 4>), dim3(wgs), dim3(256), 0, st, a); return 0; }
+  return -1;
+}
+
+}  // namespace bq
+
+extern "C" int bq_wgrad_rows_supported(int Ni, int Nj) {
+  const int ti = (Ni + 63) / 64, tj = (Nj + 63) / 64;
+  return ti >= 1 && ti <= 4 && (tj == 1 || tj == 2 || tj == 4) && ti + tj <= 6;
+}
+
+extern "C" int bq_wgrad_rows_workgroups(long R, int Ni, int Nj, int workgroups) {
+  const long nkt = (R + 63) / 64;
+  // default: one workgroup per CU; two where two fit the LDS (<= 3 units: 72 KB each), measured tools/bench_det_wgrad.py
+  long wgs = workgroups > 0 ? workgroups : (((Ni + 63) / 64 + (Nj + 63) / 64 <= 3) ? 512 : 256);
+  if (wgs > nkt) wgs = nkt;
+  return (int)(wgs < 1 ? 1 : wgs);
+}
+
+extern "C" int bq_wgrad_rows_bf16(const void *P, const void *Q, float *out, float *part, long R, int Ni, int Nj, int ldp,
+                                  int ldq, int ldo, int workgroups, void *stream) {
+  using namespace bq;
+  BQ_REQUIRE(P && Q && out && part && R > 0, BQ_EINVAL, "bq_wgrad_rows_bf16: null pointer / no rows");
+  BQ_REQUIRE(ldo % 4 == 0 && ((uintptr_t)part % 16 == 0), BQ_EINVAL, "bq_wgrad_rows_bf16: ldo %% 4, part 16-byte aligned");
+  BQ_REQUIRE(bq_wgrad_rows_supported(Ni, Nj), BQ_EINVAL, "bq_wgrad_rows_bf16: %d x %d channels not supported", Ni, Nj);
+  BQ_REQUIRE(Ni % 4 == 0 && ldp % 8 == 0 && ldq % 8 == 0 && ldp >= Ni && ldq >= Nj && ldo >= Ni, BQ_EINVAL,
+             "bq_wgrad_rows_bf16: Ni %% 4, ld %% 8, ld >= channels (Ni=%d Nj=%d ldp=%d ldq=%d ldo=%d)", Ni, Nj, ldp, ldq, ldo);
+  BQ_REQUIRE(((uintptr_t)P % 16 == 0) && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)out % 16 == 0), BQ_EINVAL,
+             "bq_wgrad_rows_bf16: operands must be 16-byte aligned");
+  BQ_REQUIRE(R * (long)ldp * 2 < 0x7FFFFFFFL - 64L * ldp * 2 - 1024 && R * (long)ldq * 2 < 0x7FFFFFFFL - 64L * ldq * 2 - 1024,
+             BQ_ELIMIT, "bq_wgrad_rows_bf16: an operand larger than 2 GB");
+  WgradRowsArgs a;
+  a.P = (const __bf16 *)P; a.Q = (const __bf16 *)Q; a.out = out; a.part = part;
+  a.R = (int)R; a.Ni = Ni; a.Nj = Nj; a.ldp = ldp; a.ldq = ldq; a.ldo = ldo;
+  a.p_bytes = (unsigned)(R * (long)ldp * 2);
+  a.q_bytes = (unsigned)(R * (long)ldq * 2);
+  const int wgs = bq_wgrad_rows_workgroups(R, Ni, Nj, workgroups);
+  a.pieces = wgs;
+  const int ti = (Ni + 63) / 64, tj = (Nj + 63) / 64;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = -1;
+  if (ti == 1) rc = launch_wgrad_rows_j<1>(tj, wgs, st, a);
+  else if (ti == 2) rc = launch_wgrad_rows_j<2>(tj, wgs, st, a);
+  else if (ti == 3) rc = launch_wgrad_rows_j<3>(tj, wgs, st, a);
+  else if (ti == 4) rc = launch_wgrad_rows_j<4>(tj, wgs, st, a);
+  BQ_REQUIRE(rc == 0, BQ_EINVAL, "bq_wgrad_rows_bf16: no kernel for %d x %d units", ti, tj);
+  hipLaunchKernelGGL(wgrad_rows_reduce_kernel, dim3((Nj * ldo / 4 + 255) / 256), dim3(256), 0, st, a);
+  return check_launch("wgrad_rows");
 }
 
 extern "C" int bq_pwconv_records(long R, int N) {

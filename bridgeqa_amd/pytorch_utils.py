@@ -6,6 +6,8 @@ State-dict layout is part of the drop-in contract (SURVEY.md §5 "Checkpoint / r
 num_batches_tracked}`.  Conv bias is dropped when bn=True (pytorch_utils.py:124), conv weights are
 kaiming-normal, BN weight 1 / bias 0 (:78-83,133-135).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -133,14 +135,31 @@ class _ConvBNReLUPointMajor(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             xs = torch.as_strided(x, (R, ldx), (ldx, 1))  # whole padded rows (the padding is zero / zero-weighted)
-            dwf = torch.zeros(N, ldx, dtype=torch.float32, device=x.device)
             tiles = ((ldx + 63) // 64) * (N // 64)
-            ksplit = max(1, min((R + 63) // 64, (1024 + tiles - 1) // tiles))
-            _ext.gemm_grouped([dict(P=xs, Q=dy, out=dwf, ksplit=ksplit)],
-                              _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32, _ext.EPI_NONE, 64)
+            if _WGRAD_ROWS and R >= _WGRAD_ROWS_MIN and _ext.wgrad_rows_ok(ldx, N):
+                # whole rows: every operand row from HBM once, no atomics
+                dwf = _ext.wgrad_rows(xs, dy, torch.empty(N, ldx, dtype=torch.float32, device=x.device), _WGRAD_ROWS_WGS)
+            else:
+                dwf = torch.zeros(N, ldx, dtype=torch.float32, device=x.device)
+                ksplit = _wgrad_pieces(R, tiles)
+                _ext.gemm_grouped([dict(P=xs, Q=dy, out=dwf, ksplit=ksplit)],
+                                  _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32, _ext.EPI_NONE, 64)
             dw = dwf[:, :K].reshape(ctx.conv_weight.shape)
         dcb = torch.zeros_like(ctx.conv_bias) if ctx.conv_bias is not None else None
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None, dcb
+
+
+_WGRAD_ROWS = os.environ.get("BQ_WGRAD_ROWS", "1") != "0"          # the whole-row weight-gradient kernel for long contractions
+_WGRAD_ROWS_MIN = int(os.environ.get("BQ_WGRAD_ROWS_MIN", "65536"))
+_WGRAD_ROWS_WGS = int(os.environ.get("BQ_WGRAD_ROWS_WGS", "0"))     # 0: the library's default per shape
+_WGRAD_WGS = int(os.environ.get("BQ_DET_WGRAD_WGS", "384"))
+
+
+def _wgrad_pieces(R, tiles):
+    """pieces the row contraction of a layer's weight gradient is cut into: ~_WGRAD_WGS workgroups in all (the 64-tile
+    kernel keeps 3 per CU resident: 768 a round), a multiple of 8 so that the kernel's XCD-aware order applies"""
+    ks = max(1, min((R + 63) // 64, _WGRAD_WGS // tiles))
+    return ks - ks % 8 if ks >= 8 else ks
 
 
 def _rows_view(x):

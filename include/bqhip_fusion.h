@@ -280,6 +280,20 @@ typedef struct bq_colsum_desc {
 } bq_colsum_desc;
 BQ_API int bq_colsum_grouped_bf16(const bq_colsum_desc *problems, int n, void *stream);
 
+/* ---- weight gradient of a SharedMLP layer over whole rows (csrc/gemm.hip wgrad_rows_kernel + reduce) ----
+ * Replaces the conv weight gradient of autograd for the 1x1 convolutions of lib/pointnet2/pytorch_utils.py:104-157 on
+ * point-major rows:  out[j][i] = sum_r Q[r][j] P[r][i]  (P = the layer's input rows (R, ldp) bf16, Q = the gradient
+ * w.r.t. the convolution output (R, ldq) bf16, out (Nj, ldo) fp32, columns [Ni, ldo) set to 0).  Every operand row is
+ * read from HBM once (bq_gemm_bf16's weight-gradient form reads it once per 64 x 64 output tile); no atomics: each of
+ * the W = bq_wgrad_rows_workgroups(R, Ni, Nj, workgroups) workgroups stores its share into part (W x Nj x ldo floats of
+ * scratch) and a second kernel sums the slices in a fixed order.  Supported: ceil(Ni / 64) in 1..4, ceil(Nj / 64) in
+ * {1, 2, 4}, their sum <= 6 (bq_wgrad_rows_supported); Ni % 4 == 0, ldp % 8 == 0, ldq % 8 == 0, ldo % 4 == 0,
+ * operands below 2 GB.  workgroups <= 0: 256, or 512 when two workgroups fit a CU's LDS (at most 3 units). */
+BQ_API int bq_wgrad_rows_supported(int Ni, int Nj);
+BQ_API int bq_wgrad_rows_workgroups(long R, int Ni, int Nj, int workgroups);
+BQ_API int bq_wgrad_rows_bf16(const void *P, const void *Q, float *out, float *part, long R, int Ni, int Nj, int ldp,
+                              int ldq, int ldo, int workgroups, void *stream);
+
 /* ---- SharedMLP layer: 1x1 convolution on point-major rows + BatchNorm statistics in its epilogue (csrc/gemm.hip) ----
  * Replaces conv (1x1, bias=False) -> the statistics pass of BatchNorm2d(train) of one SharedMLP layer
  * (lib/pointnet2/pytorch_utils.py:104-157, :11-36):  y[r][n] = sum_k x[r][k] w[n][k]  for bf16 x (R rows of ldx >= K

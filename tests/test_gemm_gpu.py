@@ -143,6 +143,65 @@ def test_dw_with_bias_gradient_from_the_same_launch(dev):
     _check(out, dy.float().t() @ x.float(), f32=True)
 
 
+@pytest.mark.parametrize("R,N,K", [(70000, 64, 136), (33000, 128, 64), (9000, 256, 128), (5000, 128, 264)])
+@pytest.mark.parametrize("ksplit", [8, 48, 5, 1])
+def test_dw_cut_contraction_detector_shapes(dev, R, N, K, ksplit):
+    """the detector's weight gradients: a contraction over very many rows cut into ksplit pieces that accumulate with
+    atomics onto zeros; ksplit % 8 == 0 takes the XCD-aware slot order (tiles of one piece on one XCD), other values the
+    piece-major order -- every (tile, piece) pair must be computed exactly once.  Two problems in one launch: the second
+    starts at a tile offset that is not a multiple of 8."""
+    from bridgeqa_amd import _ext
+    flags = _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32
+    dy, x = _rand((R, N), dev, 30), _rand((R, K), dev, 31)
+    dy2, x2 = _rand((777, 64), dev, 32), _rand((777, 72), dev, 33)
+    out, out2 = torch.zeros(N, K, device=dev), torch.zeros(64, 72, device=dev)
+    _ext.gemm_grouped([dict(P=x2, Q=dy2, out=out2, ksplit=3), dict(P=x, Q=dy, out=out, ksplit=ksplit)], flags,
+                      _ext.EPI_NONE, 64)
+    _check(out, dy.float().t() @ x.float(), f32=True)
+    _check(out2, dy2.float().t() @ x2.float(), f32=True)
+    out.zero_()
+    _ext.gemm_grouped([dict(P=x, Q=dy, out=out, ksplit=ksplit)], flags, _ext.EPI_NONE, 64)
+    _check(out, dy.float().t() @ x.float(), f32=True)
+
+
+@pytest.mark.parametrize("R,N,K", [(70001, 64, 136), (33000, 128, 64), (9000, 256, 120), (5000, 64, 64), (4100, 128, 136),
+                                   (3000, 128, 128), (2500, 256, 64), (2000, 64, 248), (1500, 128, 200), (64, 64, 72),
+                                   (130, 128, 192)])
+@pytest.mark.parametrize("wgs", [0, 7])
+def test_wgrad_rows(dev, R, N, K, wgs):
+    """bq_wgrad_rows_bf16 (whole rows staged, all output tiles of a row piece in one workgroup, slices summed by a second
+    kernel) = dy^T x; every supported (input, output) unit combination, row counts that are not multiples of 64, an input
+    row stride larger than its channel count (zero padding columns), more workgroups than K tiles"""
+    from bridgeqa_amd import _ext
+    assert _ext.wgrad_rows_ok(K, N)
+    dy = _rand((R, N), dev, 40)
+    ld = K + 8
+    xbuf = torch.zeros(R, ld, device=dev, dtype=torch.bfloat16)
+    xbuf[:, :K] = _rand((R, K), dev, 41)
+    x = xbuf[:, :K]
+    out = torch.full((N, ld), float("nan"), device=dev)
+    _ext.wgrad_rows(torch.as_strided(xbuf, (R, ld), (ld, 1)), dy, out, wgs)       # whole padded rows as channels
+    ref = dy.float().t() @ xbuf.float()
+    _check(out, ref, f32=True)
+    out2 = torch.full((N, K), float("nan"), device=dev)
+    _ext.wgrad_rows(x, dy, out2, wgs)                               # a column view: stride ld, K channels
+    _check(out2, ref[:, :K], f32=True)
+    out3 = torch.full((N, ld), float("nan"), device=dev)
+    _ext.wgrad_rows(x, dy, out3, wgs)                               # K channels into a wider buffer: padding zeroed
+    assert torch.equal(out3[:, :K], out2) and (out3[:, K:] == 0).all()
+    again = torch.empty_like(out2)
+    _ext.wgrad_rows(x, dy, again, wgs)
+    assert torch.equal(again, out2)                                 # fixed summation order: bitwise reproducible
+
+
+def test_wgrad_rows_rejects_unsupported_shapes(dev):
+    from bridgeqa_amd import _ext
+    assert not _ext.wgrad_rows_ok(264, 128) and not _ext.wgrad_rows_ok(64, 192) and not _ext.wgrad_rows_ok(192, 256)
+    x, dy = _rand((100, 264), dev, 1), _rand((100, 128), dev, 2)
+    with pytest.raises(RuntimeError):
+        _ext.wgrad_rows(x, dy, torch.zeros(128, 264, device=dev))
+
+
 def test_grouped_launch(dev):
     """several problems of different sizes in ONE launch (the deferred weight gradients of a layer stack)"""
     from bridgeqa_amd import _ext

@@ -618,8 +618,8 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// NS = LDS stages (NS - 1 K tiles in flight): 3 everywhere except the detector's weight gradients (a contraction over
-// millions of rows cut into a few hundred workgroups, which must keep HBM busy with few workgroups: 5)
+// NS = LDS stages (NS - 1 K tiles in flight).  MEASURED: 5 instead of 3 changes nothing for the detector's cut
+// contractions either (tools/bench_det_wgrad.py, to 0.1 us) -- they were bound by their atomics, not by bytes in flight
 template <int BJ, bool P_XC, bool Q_XC, int EPI, bool OUT_F32, int KT = 1, int NS = 3>
 __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
   static_assert(BJ == 64 || (BJ == 32 && !Q_XC), "32-wide j tiles only for K-contiguous Q");
@@ -1145,17 +1145,6 @@ static int launch_variant(const GemmArgs &ga, int tile, hipStream_t st, bool lon
         return 0;
       }
     }
-    if constexpr (P_XC && Q_XC && OUT_F32 && EPI == EPI_NONE) {
-      // every problem a cut contraction with >= 16 K tiles per piece (the detector's weight gradients): deep staging
-      static const int deep_on = getenv("BQ_GEMM_DEEP") ? atoi(getenv("BQ_GEMM_DEEP")) : 1;
-      bool deep = deep_on != 0;
-      for (int k = 0; k < ga.n; ++k)
-        deep = deep && ga.p[k].ksplit > 1 && ((ga.p[k].Kc + 63) / 64) >= 16 * ga.p[k].ksplit;
-      if (deep) {
-        hipLaunchKernelGGL((gemm64_kernel<64, P_XC, Q_XC, EPI, OUT_F32, 1, 5>), dim3(ga.total_tiles), dim3(256), 0, st, ga);
-        return 0;
-      }
-    }
     hipLaunchKernelGGL((gemm64_kernel<64, P_XC, Q_XC, EPI, OUT_F32>), dim3(ga.total_tiles), dim3(256), 0, st, ga);
   } else {
     if constexpr (!Q_XC) {
@@ -1439,30 +1428,45 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const WgradRowsArgs ar)
 }
 
 // out = sum over the workgroups' slices (plain stores: no atomics -- 4096 scattered fp32 atomics per output tile and
-// workgroup were the whole cost of the cut contraction, ~50 G atomics/s -- and a fixed summation order)
+// workgroup were the whole cost of the cut contraction, ~50 G atomics/s -- and a fixed summation order).  A block owns 16
+// consecutive float4 columns; its 16 lane groups take the slices p = g, g + 16, ... (8 loads in flight each: the kernel
+// is a latency chain otherwise, 31 us for 9 MB with one thread per column) and meet in LDS.
 __global__ __launch_bounds__(256) void wgrad_rows_reduce_kernel(const WgradRowsArgs ar) {
+  __shared__ float4 red[16][16];
   const int n4 = ar.Nj * ar.ldo / 4;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= n4) return;
-  const float4 *src = reinterpret_cast<const float4 *>(ar.part) + e;
-  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
-  int p = 0;
-  for (; p + 4 <= ar.pieces; p += 4) {
-    const float4 a = src[(long)p * n4], b = src[(long)(p + 1) * n4], c = src[(long)(p + 2) * n4], d = src[(long)(p + 3) * n4];
-    s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-    s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
-    s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w;
-    s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + c;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  if (e < n4) {
+    const float4 *src = reinterpret_cast<const float4 *>(ar.part) + e;
+    int p = g;
+    for (; p + 112 < ar.pieces; p += 128) {
+      float4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = src[(long)(p + 16 * k) * n4];
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        s0.x += v[k].x; s0.y += v[k].y; s0.z += v[k].z; s0.w += v[k].w;
+        s1.x += v[k + 1].x; s1.y += v[k + 1].y; s1.z += v[k + 1].z; s1.w += v[k + 1].w;
+      }
+    }
+    for (; p < ar.pieces; p += 16) {
+      const float4 a = src[(long)p * n4];
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+    }
   }
-  for (; p < ar.pieces; ++p) {
-    const float4 a = src[(long)p * n4];
-    s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+  red[g][c] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+  __syncthreads();
+  if (g == 0 && e < n4) {
+    float4 r = red[0][c];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      const float4 a = red[k][c];
+      r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
+    }
+    if ((e * 4) % ar.ldo >= ar.Ni) r = make_float4(0.f, 0.f, 0.f, 0.f);   // padding columns of a slice are never written
+    reinterpret_cast<float4 *>(ar.out)[e] = r;
   }
-  const int col = (e * 4) % ar.ldo;
-  float4 r = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
-                         (s0.w + s1.w) + (s2.w + s3.w));
-  if (col >= ar.Ni) r = make_float4(0.f, 0.f, 0.f, 0.f);   // padding columns of a slice are never written
-  reinterpret_cast<float4 *>(ar.out)[e] = r;
 }
 
 template <int TI>
@@ -1518,7 +1522,7 @@ extern "C" int bq_wgrad_rows_bf16(const void *P, const void *Q, float *out, floa
   else if (ti == 3) rc = launch_wgrad_rows_j<3>(tj, wgs, st, a);
   else if (ti == 4) rc = launch_wgrad_rows_j<4>(tj, wgs, st, a);
   BQ_REQUIRE(rc == 0, BQ_EINVAL, "bq_wgrad_rows_bf16: no kernel for %d x %d units", ti, tj);
-  hipLaunchKernelGGL(wgrad_rows_reduce_kernel, dim3((Nj * ldo / 4 + 255) / 256), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(wgrad_rows_reduce_kernel, dim3((Nj * ldo / 4 + 15) / 16), dim3(256), 0, st, a);
   return check_launch("wgrad_rows");
 }
 

@@ -72,10 +72,14 @@ class FusedAdamW(torch.optim.Optimizer):
         for sub in self._subs.values():
             if sub["pinned"] is None:
                 continue
-            tab = sub["pinned"].numpy()[:len(sub["order"]) * 56].view(self._dtype)
-            for i, (_, g) in enumerate(sub["order"]):
-                tab["lr"][i] = g["lr"]
-                tab["wd"][i] = g["weight_decay"]
+            bufs = [sub["pinned"]] + [b for b in sub["stage"] if b is not None and b is not sub["pinned"]
+                                      and b.numel() == sub["pinned"].numel()]
+            lrs = np.fromiter((g["lr"] for _, g in sub["order"]), dtype=np.float32, count=len(sub["order"]))
+            wds = np.fromiter((g["weight_decay"] for _, g in sub["order"]), dtype=np.float32, count=len(sub["order"]))
+            for buf in bufs:   # (a captured step reads whichever staging buffer was current at capture time)
+                tab = buf.numpy()[:len(sub["order"]) * 56].view(self._dtype)
+                tab["lr"][:] = lrs
+                tab["wd"][:] = wds
 
     def _build(self, sub, recs, device):
         from . import _ext
@@ -119,6 +123,7 @@ class FusedAdamW(torch.optim.Optimizer):
             if subset is not None and params is None:
                 raise ValueError("FusedAdamW.step: the first call for subset %r must pass params" % (subset,))
             sub = self._subs[subset] = dict(name=subset, sig=None, table=None, chunks=None, pinned=None, devbuf=None,
+                                            stage=[None, None], copied=[None, None], cur=0,
                                             order=[], members=None if subset is None else {id(p) for p in params})
         recs = self._records(sub)
         if not recs:
@@ -127,14 +132,32 @@ class FusedAdamW(torch.optim.Optimizer):
         device = recs[0][0].device
         sig = tuple((r[0].data_ptr(), r[1].data_ptr(), r[2].data_ptr(), r[3].data_ptr(),
                      r[4].data_ptr() if r[4] is not None else 0) for r in recs)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing and sub["pinned"] is not None:
+            # The pinned staging copy is about to be rewritten while an earlier step's asynchronous upload may not have
+            # read it yet (eager training re-allocates the gradients every step, so every step rebuilds the table; a host
+            # running ahead of the GPU would hand step k the gradient pointers of step k + 1).  Two staging buffers
+            # alternate: the host only waits for the upload of two steps ago.
+            nxt = 1 - sub["cur"]
+            if sub["copied"][nxt] is not None:
+                sub["copied"][nxt].synchronize()
+            if sub["stage"][nxt] is None or sub["stage"][nxt].numel() != sub["pinned"].numel():
+                sub["stage"][nxt] = torch.empty(sub["pinned"].numel(), dtype=torch.uint8).pin_memory()
+            sub["stage"][nxt].numpy()[:] = sub["pinned"].numpy()
+            sub["pinned"], sub["cur"] = sub["stage"][nxt], nxt
         if sig != sub["sig"]:
             self._build(sub, recs, device)
             sub["sig"] = sig
         else:
             self.sync_hyperparams()
+        sub["stage"][sub["cur"]] = sub["pinned"]
         # the table travels to the device on EVERY step (tens of KB): a captured step therefore always contains the
         # copy node, and lr / weight_decay written into the pinned copy reach the kernel of the next launch / replay
         sub["devbuf"].copy_(sub["pinned"], non_blocking=True)
+        sub["copied"][sub["cur"]] = None
+        if not capturing:
+            sub["copied"][sub["cur"]] = torch.cuda.Event()
+            sub["copied"][sub["cur"]].record()
         if advance:
             self._step(device).add_(1.0)
         beta1, beta2 = self.param_groups[0]["betas"]

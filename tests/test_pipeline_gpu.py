@@ -171,6 +171,34 @@ def test_geometry_prefetch_follows_changing_batches(dev):
         assert abs(got.item() - want[k]) <= 2e-4 * abs(want[k]), (k, got.item(), want[k])
 
 
+def test_fused_adamw_eager_steps_with_a_lagging_gpu(dev):
+    """eager training hands step() freshly allocated gradients every time, so every step rebuilds the pointer table in the
+    pinned staging buffer and uploads it asynchronously; with the GPU far behind the host, step k's upload must still
+    carry step k's pointers (the host waits for the previous upload before it rewrites the buffer)"""
+    from bridgeqa_amd.optim import FusedAdamW
+    torch.manual_seed(1)
+    ps = [torch.randn(300, 70, device=dev), torch.randn(1000, device=dev)]
+    grads = [[torch.randn_like(p) for p in ps] for _ in range(6)]
+    big = torch.randn(4096, 4096, device=dev)
+
+    def run(lag):
+        params = [torch.nn.Parameter(p.clone()) for p in ps]
+        opt = FusedAdamW(params, lr=1e-2, weight_decay=1e-2)
+        for k in range(6):
+            if lag:
+                for _ in range(20):
+                    big @ big                      # queue ~40 ms of work: the host is now well ahead of the GPU
+            for p, g in zip(params, grads[k]):
+                p.grad = g.clone()
+            opt.step()
+            if not lag:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return params
+    for x, y in zip(run(False), run(True)):
+        assert torch.equal(x, y)
+
+
 def test_fused_adamw_checkpoint_resume_and_scheduler_under_replay(dev):
     """(1) state_dict() carries the step count in torch.optim.AdamW's layout: a resumed FusedAdamW continues exactly
     like an uninterrupted one, and a torch AdamW checkpoint loads (reference: lib/solver.py:687, scripts/train.py:449).

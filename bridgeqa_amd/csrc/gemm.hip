@@ -650,7 +650,8 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
   if (ksplit > 1) {
     // a cut contraction (detector weight gradients: millions of rows, 1 - 8 output tiles): the output tiles of ONE piece
     // read the same rows of both operands, so they get neighbouring slots of the same XCD (workgroups go to the XCDs
-    // round-robin by blockIdx) and meet in its L2 -- tile-major order read every operand row once per tile from HBM
+    // round-robin by blockIdx) and meet in its L2 (PMC: operands fetched once) -- 170 -> 125 us on SA2's first layer
+    // against the piece-major order that spreads them over the XCDs
     const int lt = t - pr.tile0;
     const int ntl = pr.tiles_i * ((Nj + BJ - 1) / BJ);
     if ((ksplit & 7) == 0 && (pr.tile0 & 7) == 0) {
@@ -1294,14 +1295,15 @@ extern "C" int bq_colsum_grouped_bf16(const bq_colsum_desc *d, int n, void *stre
 }
 
 // ======================================================================================================================
-// wgrad_rows_kernel: dW (Nj x Ni, fp32) += Q^T P over a piece of the R rows, for the detector's SharedMLP layers -- R in
-// the millions, Ni / Nj <= 256 channels.  The 64-tile kernel above cuts this into (tile, piece) workgroups and so reads
-// every operand row once per TILE (measured: its 3 - 8 tiles do not meet in the L2; SA1's first layer moved 1.37 GB for
-// 0.84 GB of operands); here a workgroup stages WHOLE rows -- TI 64-column units of P and TJ of Q per K tile, the gemm64
-// LDS images and transposing fragment reads -- and keeps all TI x TJ output tiles in its accumulators, so HBM sees every
-// row once.  One workgroup per CU (3 stages x (TI + TJ) x 8 KB), a contiguous run of K tiles each; every workgroup
-// stores its product into its own slice and wgrad_rows_reduce_kernel sums the slices.  HBM roofline: R (Ni + Nj) 2
-// bytes per launch.
+// wgrad_rows_kernel: dW (Nj x Ni, fp32) = Q^T P over the R rows, for the detector's SharedMLP layers -- R in the millions,
+// Ni / Nj <= 256 channels.  The 64-tile kernel above cuts this into (tile, piece) workgroups that each end in 4096
+// scattered fp32 atomics (~50 G atomics/s: THE cost of that form -- its HBM traffic is fine, with the XCD-aware piece
+// order the tiles of a piece meet in the L2 and PMC shows every operand row fetched once, profiles/r02_det_wgrad_pmc.txt).
+// Here a workgroup stages WHOLE rows -- TI 64-column units of P and TJ of Q per K tile, the gemm64 LDS images and
+// transposing fragment reads -- keeps all TI x TJ output tiles in its accumulators and walks a contiguous run of K tiles;
+// every workgroup stores its product into its own slice and wgrad_rows_reduce_kernel sums the slices (no atomics, fixed
+// order).  One workgroup per CU (3 stages x (TI + TJ) x 8 KB).  HBM roofline: R (Ni + Nj) 2 bytes per launch (PMC:
+// 839.0 MB for 838.9 MB of operands at SA1's first layer, 4.7 TB/s).
 // ======================================================================================================================
 namespace bq {
 

@@ -137,7 +137,7 @@ class _ConvBNReLUPointMajor(torch.autograd.Function):
             xs = torch.as_strided(x, (R, ldx), (ldx, 1))  # whole padded rows (the padding is zero / zero-weighted)
             tiles = ((ldx + 63) // 64) * (N // 64)
             if _WGRAD_ROWS and R >= _WGRAD_ROWS_MIN and _ext.wgrad_rows_ok(ldx, N):
-                # whole rows: every operand row from HBM once, no atomics
+                # whole rows staged once for all output tiles, slices summed in a fixed order: no atomics
                 dwf = _ext.wgrad_rows(xs, dy, torch.empty(N, ldx, dtype=torch.float32, device=x.device), _WGRAD_ROWS_WGS)
             else:
                 dwf = torch.zeros(N, ldx, dtype=torch.float32, device=x.device)

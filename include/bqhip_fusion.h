@@ -284,7 +284,8 @@ BQ_API int bq_colsum_grouped_bf16(const bq_colsum_desc *problems, int n, void *s
  * Replaces the conv weight gradient of autograd for the 1x1 convolutions of lib/pointnet2/pytorch_utils.py:104-157 on
  * point-major rows:  out[j][i] = sum_r Q[r][j] P[r][i]  (P = the layer's input rows (R, ldp) bf16, Q = the gradient
  * w.r.t. the convolution output (R, ldq) bf16, out (Nj, ldo) fp32, columns [Ni, ldo) set to 0).  Every operand row is
- * read from HBM once (bq_gemm_bf16's weight-gradient form reads it once per 64 x 64 output tile); no atomics: each of
+ * staged once for all its output tiles and there are no atomics (bq_gemm_bf16's cut weight-gradient form ends every
+ * workgroup in 4096 scattered fp32 atomics per 64 x 64 tile, which is what it spends its time on): each of
  * the W = bq_wgrad_rows_workgroups(R, Ni, Nj, workgroups) workgroups stores its share into part (W x Nj x ldo floats of
  * scratch) and a second kernel sums the slices in a fixed order.  Supported: ceil(Ni / 64) in 1..4, ceil(Nj / 64) in
  * {1, 2, 4}, their sum <= 6 (bq_wgrad_rows_supported); Ni % 4 == 0, ldp % 8 == 0, ldq % 8 == 0, ldo % 4 == 0,

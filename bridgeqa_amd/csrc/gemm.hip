@@ -1317,8 +1317,9 @@ struct WgradRowsArgs {
 
 template <int TI, int TJ>
 __global__ __launch_bounds__(256) void wgrad_rows_kernel(const WgradRowsArgs ar) {
-  constexpr int UNITS = TI + TJ, STAGE = UNITS * 8192, NS = 3, NDMA = 2 * UNITS;
-  static_assert(NS * STAGE <= 160 * 1024 && (NS - 2) * NDMA <= 63, "LDS stages / counted waits");
+  // three LDS stages while they fit (<= 6 units), two for 7 units (264 -> 128 channels: SA3 / SA4's first layers)
+  constexpr int UNITS = TI + TJ, STAGE = UNITS * 8192, NS = UNITS <= 6 ? 3 : 2, NDMA = 2 * UNITS;
+  static_assert(NS >= 2 && NS * STAGE <= 160 * 1024 && (NS - 2) * NDMA <= 63, "LDS stages / counted waits");
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1475,9 +1476,9 @@ template <int TI>
 static int launch_wgrad_rows_j(int tj, int wgs, hipStream_t st, const WgradRowsArgs &a) {
   if constexpr (TI + 1 <= 6)
     if (tj == 1) { hipLaunchKernelGGL((wgrad_rows_kernel<TI, 1>), dim3(wgs), dim3(256), 0, st, a); return 0; }
-  if constexpr (TI + 2 <= 6)
+  if constexpr (TI + 2 <= 7)
     if (tj == 2) { hipLaunchKernelGGL((wgrad_rows_kernel<TI, 2>), dim3(wgs), dim3(256), 0, st, a); return 0; }
-  if constexpr (TI + 4 <= 6)
+  if constexpr (TI + 4 <= 7)
     if (tj == 4) { hipLaunchKernelGGL((wgrad_rows_kernel<TI, 4>), dim3(wgs), dim3(256), 0, st, a); return 0; }
   return -1;
 }
@@ -1486,7 +1487,7 @@ static int launch_wgrad_rows_j(int tj, int wgs, hipStream_t st, const WgradRowsA
 
 extern "C" int bq_wgrad_rows_supported(int Ni, int Nj) {
   const int ti = (Ni + 63) / 64, tj = (Nj + 63) / 64;
-  return ti >= 1 && ti <= 4 && (tj == 1 || tj == 2 || tj == 4) && ti + tj <= 6;
+  return ti >= 1 && ti <= 5 && (tj == 1 || tj == 2 || tj == 4) && ti + tj <= 7 && !(ti == 5 && tj == 1);
 }
 
 extern "C" int bq_wgrad_rows_workgroups(long R, int Ni, int Nj, int workgroups) {
@@ -1523,6 +1524,7 @@ extern "C" int bq_wgrad_rows_bf16(const void *P, const void *Q, float *out, floa
   else if (ti == 2) rc = launch_wgrad_rows_j<2>(tj, wgs, st, a);
   else if (ti == 3) rc = launch_wgrad_rows_j<3>(tj, wgs, st, a);
   else if (ti == 4) rc = launch_wgrad_rows_j<4>(tj, wgs, st, a);
+  else if (ti == 5 && tj == 2) { hipLaunchKernelGGL((wgrad_rows_kernel<5, 2>), dim3(wgs), dim3(256), 0, st, a); rc = 0; }
   BQ_REQUIRE(rc == 0, BQ_EINVAL, "bq_wgrad_rows_bf16: no kernel for %d x %d units", ti, tj);
   hipLaunchKernelGGL(wgrad_rows_reduce_kernel, dim3((Nj * ldo / 4 + 15) / 16), dim3(256), 0, st, a);
   return check_launch("wgrad_rows");

@@ -287,8 +287,8 @@ BQ_API int bq_colsum_grouped_bf16(const bq_colsum_desc *problems, int n, void *s
  * staged once for all its output tiles and there are no atomics (bq_gemm_bf16's cut weight-gradient form ends every
  * workgroup in 4096 scattered fp32 atomics per 64 x 64 tile, which is what it spends its time on): each of
  * the W = bq_wgrad_rows_workgroups(R, Ni, Nj, workgroups) workgroups stores its share into part (W x Nj x ldo floats of
- * scratch) and a second kernel sums the slices in a fixed order.  Supported: ceil(Ni / 64) in 1..4, ceil(Nj / 64) in
- * {1, 2, 4}, their sum <= 6 (bq_wgrad_rows_supported); Ni % 4 == 0, ldp % 8 == 0, ldq % 8 == 0, ldo % 4 == 0,
+ * scratch) and a second kernel sums the slices in a fixed order.  Supported: ceil(Ni / 64) in 1..5, ceil(Nj / 64) in
+ * {1, 2, 4}, their sum <= 7, not 5 + 1 (bq_wgrad_rows_supported); Ni % 4 == 0, ldp % 8 == 0, ldq % 8 == 0, ldo % 4 == 0,
  * operands below 2 GB.  workgroups <= 0: 256, or 512 when two workgroups fit a CU's LDS (at most 3 units). */
 BQ_API int bq_wgrad_rows_supported(int Ni, int Nj);
 BQ_API int bq_wgrad_rows_workgroups(long R, int Ni, int Nj, int workgroups);

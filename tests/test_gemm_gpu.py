@@ -166,7 +166,7 @@ def test_dw_cut_contraction_detector_shapes(dev, R, N, K, ksplit):
 
 @pytest.mark.parametrize("R,N,K", [(70001, 64, 136), (33000, 128, 64), (9000, 256, 120), (5000, 64, 64), (4100, 128, 136),
                                    (3000, 128, 128), (2500, 256, 64), (2000, 64, 248), (1500, 128, 200), (64, 64, 72),
-                                   (130, 128, 192)])
+                                   (130, 128, 192), (5000, 128, 264), (3000, 256, 136)])
 @pytest.mark.parametrize("wgs", [0, 7])
 def test_wgrad_rows(dev, R, N, K, wgs):
     """bq_wgrad_rows_bf16 (whole rows staged, all output tiles of a row piece in one workgroup, slices summed by a second
@@ -196,10 +196,11 @@ def test_wgrad_rows(dev, R, N, K, wgs):
 
 def test_wgrad_rows_rejects_unsupported_shapes(dev):
     from bridgeqa_amd import _ext
-    assert not _ext.wgrad_rows_ok(264, 128) and not _ext.wgrad_rows_ok(64, 192) and not _ext.wgrad_rows_ok(192, 256)
-    x, dy = _rand((100, 264), dev, 1), _rand((100, 128), dev, 2)
+    assert not _ext.wgrad_rows_ok(328, 128) and not _ext.wgrad_rows_ok(64, 192) and not _ext.wgrad_rows_ok(256, 256)
+    assert not _ext.wgrad_rows_ok(320, 64)
+    x, dy = _rand((100, 328), dev, 1), _rand((100, 128), dev, 2)
     with pytest.raises(RuntimeError):
-        _ext.wgrad_rows(x, dy, torch.zeros(128, 264, device=dev))
+        _ext.wgrad_rows(x, dy, torch.zeros(128, 328, device=dev))
 
 
 def test_grouped_launch(dev):

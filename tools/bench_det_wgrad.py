@@ -10,7 +10,7 @@ from bridgeqa_amd.pytorch_utils import _wgrad_pieces
 
 SHAPES = [("SA1.l1", 2097152, 64, 136), ("SA1.l2", 2097152, 64, 64), ("SA1.l3", 2097152, 128, 64),
           ("SA2.l1", 524288, 128, 136), ("SA2.l2", 524288, 128, 128), ("SA2.l3", 524288, 256, 128),
-          ("SA3.l1", 131072, 128, 264), ("SA3.l3", 131072, 256, 128)]
+          ("SA3.l1", 131072, 128, 264), ("SA3.l3", 131072, 256, 128), ("SA4.l1", 65536, 128, 264)]
 dev = torch.device("cuda:0")
 flags = _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32
 odd = "odd" in sys.argv   # pieces = 8 k - 1: the kernel falls back to the piece-major order (tiles of a piece on different XCDs)

@@ -158,12 +158,13 @@ class BertSelfAttention(nn.Module):
         want = output_attentions or (is_cross and self.save_attention)
         H, D = self.num_attention_heads, self.attention_head_size
         p_drop = self.dropout.p if self.training else 0.0
-        two_seg = isinstance(encoder_hidden_states, (TwoSegmentStates, HoistedStates))
+        two_seg = isinstance(encoder_hidden_states, TwoSegmentStates)     # (its kernels have no attention-map output)
+        hoisted_kv = isinstance(encoder_hidden_states, HoistedStates)
         # the fused kernels also serve output_attentions (the map is rebuilt from the LSE, detached); a caller that
         # differentiates through the map -- save_attention + the attn_gradients hook -- gets the reference composition
         hooked = is_cross and self.save_attention
         if (not hooked and (not output_attentions or not two_seg) and past_key_value is None
-                and ops.compute_dtype() == torch.bfloat16 and (hidden_states.is_cuda or two_seg)):
+                and ops.compute_dtype() == torch.bfloat16 and (hidden_states.is_cuda or two_seg or hoisted_kv)):
             # fused projections: Q/K/V (self) or K/V (cross) as ONE GEMM over the shared input, and the attention
             # kernels read / write the packed tensors in place
             B, L = hidden_states.shape[:2]
@@ -209,6 +210,9 @@ class BertSelfAttention(nn.Module):
                 ctx, probs = ctx
                 return (ctx.reshape(B, L, self.all_head_size), probs, present)
             return (ctx.reshape(B, L, self.all_head_size), present)
+        if two_seg or hoisted_kv:
+            raise RuntimeError("factored encoder states (hoisted K/V projections) reached the reference composition: "
+                               "they need the kernel path (bf16 compute, no past_key_value, no save_attention hook)")
         q = self._heads(ops.linear(hidden_states, self.query.weight, self.query.bias, tap=tap))
         src = encoder_hidden_states if is_cross else hidden_states
         k = self._heads(ops.linear(src, self.key.weight, self.key.bias))

@@ -245,9 +245,10 @@ def test_decoder_hoisted_cross_kv_equals_per_layer_projections(dev, bf16):
             for p in dec.parameters():
                 p.grad = None
             r = dec(aid, attention_mask=am, encoder_hidden_states=enc, encoder_attention_mask=em,
-                    labels=aid.masked_fill(am == 0, -100), return_dict=True, reduction="none")
+                    labels=aid.masked_fill(am == 0, -100), return_dict=True, reduction="none", output_attentions=True)
             r.loss.sum().backward()
             res[hoist] = dict(loss=r.loss.detach().float().clone(), logits=r.logits.detach().float().clone(),
+                              cross=torch.stack([c.float() for c in r.cross_attentions]),
                               enc=enc.grad.float().clone(),
                               grads={n: p.grad.float().clone() for n, p in dec.named_parameters() if p.grad is not None})
         finally:
@@ -256,6 +257,7 @@ def test_decoder_hoisted_cross_kv_equals_per_layer_projections(dev, bf16):
     rel = lambda x, y: ((x - y).norm() / (y.norm() + 1e-20)).item()
     assert rel(b["logits"], a["logits"]) <= 5e-3 and rel(b["loss"], a["loss"]) <= 5e-3
     assert rel(b["enc"], a["enc"]) <= 2e-2
+    assert a["cross"].shape == (3, B, 4, L, Lk) and rel(b["cross"], a["cross"]) <= 5e-3   # maps asked of the hoisted path
     assert a["grads"].keys() == b["grads"].keys()
     assert any("crossattention.self.key.weight" in n for n in a["grads"])
     worst = max((rel(b["grads"][n], a["grads"][n]), n) for n in a["grads"])

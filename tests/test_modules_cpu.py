@@ -154,3 +154,16 @@ def test_unused_reference_options_fail_loudly():
         QueryAndGroup(0.2, 16, sample_uniformly=True)
     with pytest.raises(NotImplementedError):
         PointnetSAModuleVotes(mlp=[3, 8], npoint=4, radius=0.2, nsample=4, pooling="avg")
+
+
+def test_detector_weight_gradient_piece_count_host_logic():
+    """pytorch_utils._wgrad_pieces: ~384 workgroups per launch, a multiple of 8 pieces (the kernel's XCD-aware order),
+    never more pieces than 64-row K tiles"""
+    from bridgeqa_amd.pytorch_utils import _wgrad_pieces, _WGRAD_WGS
+    assert _WGRAD_WGS == 384
+    for R, tiles in ((2097152, 3), (2097152, 1), (524288, 8), (131072, 10), (8192, 16), (300, 4), (64, 1)):
+        ks = _wgrad_pieces(R, tiles)
+        assert 1 <= ks <= (R + 63) // 64
+        assert ks * tiles <= max(_WGRAD_WGS, tiles)
+        assert ks < 8 or ks % 8 == 0
+    assert _wgrad_pieces(2097152, 3) == 128 and _wgrad_pieces(300, 4) == 5 and _wgrad_pieces(64, 1) == 1

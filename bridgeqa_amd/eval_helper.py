@@ -19,7 +19,11 @@ Reference quirks kept on purpose:
   * `cluster_labels *= label_masks` acts IN PLACE on data_dict["cluster_labels"] when that is fp32 (`.float()` of an fp32
     tensor is the tensor itself), so the masked labels are what `use_best` and later readers see (:88-89);
   * `ref_acc` divides by (1 + 1e-8) (:93-94); `sem_acc` divides by pred_mask.sum() without an epsilon (:317);
-  * `use_reference` is accepted and not read (the reference never tests it inside get_eval).
+  * `use_reference` is accepted and not read (the reference never tests it inside get_eval);
+  * `if use_best: ...` is followed by a SEPARATE `if use_cat_rand: ... else: ...` (:97-124): under use_best alone the else
+    branch still runs on the replaced cluster_ref -- pred_ref = argmax(cluster_labels * pred_masks) and cluster_ref =
+    cluster_labels * pred_masks, which differ from the unmasked labels whenever the best proposal is not predicted to be
+    an object.
 `use_cat_rand` (:103-121) draws ONE uniformly random proposal among those assigned to a GT box of the question's category
 -- here the arg-max of uniform noise over the candidate mask (the same distribution, not the same random stream, and no
 host synchronisation); with no candidate both forms pick proposal 0.
@@ -77,7 +81,9 @@ def get_eval(data_dict, config, answer_vocab=None, use_reference=False, use_lang
     if use_best:
         pred_ref = torch.argmax(data_dict["cluster_labels"], 1)
         data_dict["cluster_ref"] = data_dict["cluster_labels"]
-    elif use_cat_rand:
+    # (a separate `if`, as in the reference: with use_best and without use_cat_rand the `else` below still runs, on the
+    # cluster_ref just replaced -- pred_ref = argmax(cluster_labels * pred_masks), cluster_ref = cluster_labels * pred_masks)
+    if use_cat_rand:
         sem = data_dict["sem_cls_label"].clone()
         k2 = torch.arange(sem.shape[1], device=dev).unsqueeze(0)
         sem = sem - (k2 >= data_dict["num_bbox"].view(-1, 1)).to(sem.dtype)            # sem_cls_label[num_bbox:] -= 1

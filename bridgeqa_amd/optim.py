@@ -51,6 +51,20 @@ class FusedAdamW(torch.optim.Optimizer):
             self._step_t = torch.zeros((), dtype=torch.float32, device=device)
         return self._step_t
 
+    def state_dict(self):
+        """torch.optim.AdamW's layout with an INDEPENDENT "step" tensor per parameter: the shared device counter is an
+        internal detail of the kernel -- saved as one storage, a plain torch.optim.AdamW that loads the checkpoint would
+        bump it once per parameter on every step (its _foreach_add_ runs over all the "step" entries)."""
+        sd = super().state_dict()
+        state = {}
+        for k, st in sd["state"].items():   # (the per-parameter dicts are the optimizer's own objects: copy, never mutate)
+            st = dict(st)
+            if torch.is_tensor(st.get("step")):
+                st["step"] = st["step"].detach().clone()
+            state[k] = st
+        sd["state"] = state
+        return sd
+
     def load_state_dict(self, state_dict):
         """accepts torch.optim.AdamW checkpoints: the per-parameter "step" entries collapse into the one device counter
         (their maximum: parameters that never had a gradient sit at 0 there)"""

@@ -312,6 +312,12 @@ class PhasedTrainStep(object):
         point the detector stream's launches (short, its queue is usually empty) are issued before the main
         stream's -- otherwise the detector only gets its packets once the main stream has drained (measured)."""
         sm, sd, si, sa = self.s_main, self.s_det, self.s_img, self.s_aux
+        # whatever the caller enqueued on ITS stream before this step -- solver.BatchStager.advance() copies the next
+        # batch into the static buffers there -- happens before any phase reads the batch
+        cur = torch.cuda.current_stream(self.dev)
+        for s_ in {sm, sd, si}:
+            if s_ is not cur:
+                s_.wait_stream(cur)
         sd.wait_event(self.e_done)  # parameters of the previous step's optimizer
         with torch.cuda.stream(sd):
             self._run("det_fwd", eager)
@@ -428,10 +434,18 @@ class PhasedTrainStep(object):
         if self.prefetch and not _again:  # (a re-capture keeps the geometry the previous step prefetched)
             with torch.cuda.stream(self.s_det):
                 self._geometry()  # the first step's own geometry
-        snapshot = None
+        snapshot, opt_snapshot = None, None
         if warmup and not keep_warmup_updates:
             torch.cuda.synchronize(self.dev)
             snapshot = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+            if self.opt is not None:
+                # a resumed optimizer (load_state_dict) hands over moments and a step count: they come back as they were;
+                # (storage pointer -> copy: FusedAdamW's shared step counter is saved once)
+                opt_snapshot = {}
+                for st in self.opt.state.values():
+                    for t in st.values():
+                        if torch.is_tensor(t) and t.data_ptr() not in opt_snapshot:
+                            opt_snapshot[t.data_ptr()] = t.detach().clone()
         for _ in range(warmup):
             self.eager_step()
         torch.cuda.synchronize(self.dev)
@@ -440,12 +454,19 @@ class PhasedTrainStep(object):
                 for k, v in self.model.state_dict().items():
                     v.copy_(snapshot[k])
                 if self.opt is not None:
+                    done = set()
                     for st in self.opt.state.values():
                         for name, t in st.items():
-                            if torch.is_tensor(t):
-                                t.zero_()
+                            if not torch.is_tensor(t) or t.data_ptr() in done:
+                                continue
+                            done.add(t.data_ptr())
+                            old = opt_snapshot.get(t.data_ptr())
+                            if old is not None and old.shape == t.shape:
+                                t.copy_(old)
+                            else:
+                                t.zero_()   # state the warm-up created: a fresh optimizer starts from zero
             ops.refresh_shadows(only_with_grad=False)
-            del snapshot
+            del snapshot, opt_snapshot
             torch.cuda.synchronize(self.dev)
         if not self.use_graphs:
             return self

@@ -65,13 +65,14 @@ class ProposalModule(nn.Module):
         + ReLU stages run as native point-major layers and the last convolution as a linear on the rows"""
         from . import pytorch_utils as pt_utils
         p = self.proposal
-        if pt_utils.native_rows_ok(features) and self.training:
+        if (pt_utils.native_rows_ok(features) and self.training and features.shape[1] % 8 == 0
+                and pt_utils.rows_layer_ok(p[0], p[1]) and pt_utils.rows_layer_ok(p[3], p[4])):
+            # (both layers' preconditions are checked before either runs: no fallback after a BatchNorm update)
             B, C, K = features.shape
             h = pt_utils.rows_conv_bn_relu(pt_utils.to_rows(features), p[0], p[1])
-            h = pt_utils.rows_conv_bn_relu(h, p[3], p[4]) if h is not None else None
-            if h is not None:
-                net = torch.nn.functional.linear(h.float(), p[6].weight.squeeze(-1), p[6].bias)
-                return net.view(B, K, -1).transpose(1, 2)
+            h = pt_utils.rows_conv_bn_relu(h, p[3], p[4])
+            net = torch.nn.functional.linear(h.float(), p[6].weight.squeeze(-1), p[6].bias)
+            return net.view(B, K, -1).transpose(1, 2)
         return p(features)
 
     def forward(self, xyz, features, data_dict):

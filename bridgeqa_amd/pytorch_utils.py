@@ -179,14 +179,20 @@ def rows_conv_bn_relu(rows, conv, bn, relu=True):
     layer; None when its preconditions do not hold (the caller then runs the reference composition).  Used by the
     feature-propagation SharedMLPs, the voting module and the proposal head (reference lib/pointnet2/
     pointnet2_modules.py:330-340, models/voting_module.py:33-40, models/proposal_module.py:44-50)."""
-    C = bn.num_features
     if not (rows.is_cuda and rows.dtype == torch.bfloat16 and rows.dim() == 2 and rows.stride(1) == 1
-            and rows.stride(0) % 8 == 0 and bn.training and bn.momentum is not None and bn.track_running_stats and bn.affine
-            and C % 64 == 0 and (C & (C - 1)) == 0 and conv.weight.dtype == torch.float32
-            and all(k == 1 for k in conv.kernel_size)):
+            and rows.stride(0) % 8 == 0 and rows_layer_ok(conv, bn)):
         return None
     return _ConvBNReLUPointMajor.apply(rows, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                        bn.num_batches_tracked, bn.eps, bn.momentum, relu, False, 1, conv.bias)
+
+
+def rows_layer_ok(conv, bn):
+    """the layer-side preconditions of rows_conv_bn_relu: a caller that chains several layers checks ALL of them before
+    running the first (a fallback after a native layer has run would update that layer's running statistics twice)"""
+    C = bn.num_features
+    return (bn.training and bn.momentum is not None and bn.track_running_stats and bn.affine
+            and C % 64 == 0 and (C & (C - 1)) == 0 and conv.weight.dtype == torch.float32
+            and all(k == 1 for k in conv.kernel_size))
 
 
 def to_rows(x):

@@ -46,7 +46,11 @@ class PackedRunningLog(object):
         if self.device.type == "cuda":
             self._host = self._host.pin_memory()
 
-    def reduce(self, running_log):
+    def reduce(self, running_log, after=None):
+        """after: the pipeline.PhasedTrainStep (anything with wait()) that produced the device values on its own streams
+        -- the current stream waits for its completion event before reading them"""
+        if after is not None:
+            after.wait()
         vals, idx_t, idx_f, floats = [], [], [], []
         for i, k in enumerate(self.keys):
             v = running_log.get(k, 0)
@@ -112,11 +116,17 @@ class BatchStager(object):
         stager = BatchStager(host_batch_0, device)                       # allocates both sets, uploads batch 0 into `next`
         step = PhasedTrainStep(model, stager.batch, ..., next_batch=stager.next_batch)
         for host_next in loader:                                         # host_next = data of step n + 1
-            stager.advance()                                             # batch <- next_batch (device copy, ~0.1 ms)
+            stager.advance(step)                                         # batch <- next_batch (device copy, ~0.1 ms) on
+                                                                         #   the current stream, AFTER step n - 1 has finished
+                                                                         #   reading `batch` (step.wait())
             stager.stage(host_next)                                      # pinned staging + H2D on a side stream: runs
             stager.wait(step.s_det)                                      #   under step n; its geometry phase waits for it
-            step.step()
+            step.step()                                                  # every phase stream first waits for the current
+                                                                         #   stream, i.e. for the copy of advance()
 
+    Stream ordering: advance() writes `batch` on the CURRENT stream; PhasedTrainStep.step() makes its phase streams wait
+    for the current stream before the first phase, and advance(step) makes the current stream wait for the previous
+    step's last phase (its backward graphs still read `batch`) before overwriting it.
     Shapes must not change between batches (graphs are shape-static; the reference's collate pads to fixed lengths)."""
 
     def __init__(self, host_batch, device):
@@ -172,8 +182,12 @@ class BatchStager(object):
         if self.cuda:
             (stream or torch.cuda.current_stream(self.device)).wait_event(self.e_uploaded)
 
-    def advance(self):
-        """batch <- next_batch on the current stream (after the upload); non-tensor entries by reference"""
+    def advance(self, step=None):
+        """batch <- next_batch on the current stream (after the upload); non-tensor entries by reference.
+        step: the pipeline.PhasedTrainStep (anything with wait()) whose in-flight phases still read `batch`: the current
+        stream waits for its completion event before the copy overwrites the buffers."""
+        if step is not None:
+            step.wait()
         self.wait()
         src, dst = [], []
         for path in self._pinned:

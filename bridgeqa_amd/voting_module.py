@@ -27,15 +27,16 @@ class VotingModule(nn.Module):
         B, S = seed_xyz.shape[0], seed_xyz.shape[1]
         vf, C = self.vote_factor, self.out_dim
         net = None
-        if pt_utils.native_rows_ok(seed_features) and self.training:
+        if (pt_utils.native_rows_ok(seed_features) and self.training and seed_features.shape[1] % 8 == 0
+                and pt_utils.rows_layer_ok(self.conv1, self.bn1) and pt_utils.rows_layer_ok(self.conv2, self.bn2)):
             # point-major rows: conv + BatchNorm + ReLU twice on the native layer (csrc/gemm.hip pwconv + csrc/bn.hip),
-            # the last convolution (259 output channels, no BatchNorm) as a plain linear on the rows
+            # the last convolution (259 output channels, no BatchNorm) as a plain linear on the rows.  (Both layers'
+            # preconditions are checked before either runs: no fallback after a BatchNorm update.)
             rows = pt_utils.to_rows(seed_features)
             h = pt_utils.rows_conv_bn_relu(rows, self.conv1, self.bn1)
-            h = pt_utils.rows_conv_bn_relu(h, self.conv2, self.bn2) if h is not None else None
-            if h is not None:
-                net = F.linear(h.float(), self.conv3.weight.squeeze(-1), self.conv3.bias)
-                net = net.view(B, S, -1).transpose(1, 2)
+            h = pt_utils.rows_conv_bn_relu(h, self.conv2, self.bn2)
+            net = F.linear(h.float(), self.conv3.weight.squeeze(-1), self.conv3.bias)
+            net = net.view(B, S, -1).transpose(1, 2)
         if net is None:
             net = F.relu(self.bn1(self.conv1(seed_features)))
             net = F.relu(self.bn2(self.conv2(net)))

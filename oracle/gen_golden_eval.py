@@ -6,7 +6,8 @@ TEST INFRASTRUCTURE.  Usage:  python oracle/gen_golden_eval.py   -> tests/golden
 
 Variants: 0 = plain (lang classifier on, all four answer-score branches present); 1 = use_oracle, no lang classifier, only
 `answer_scores`; 2 = use_best; 3 = post_processing (parse_predictions: remove_empty_box + per-class 3-D NMS) ahead of the
-masks.  use_cat_rand draws from torch.randperm and has no golden.
+masks; 4 = use_best where the best proposal is often NOT predicted to be an object (the masked-else quirk).  use_cat_rand
+draws from torch.randperm and has no golden.
 
 Shims (as oracle/gen_golden_qa.py / gen_golden_nms.py): icecream / trimesh / plyfile -> empty modules;
 data.scannet.model_util_scannet is ABSENT from the reference checkout -- the ScannetDatasetConfig members get_loss,
@@ -56,6 +57,9 @@ VARIANTS = (
     dict(seed=8, NH=4, kw=dict(use_reference=True, use_lang_classifier=True), extra=("2d3d",),
          post=dict(remove_empty_box=True, use_3d_nms=True, nms_iou=0.25, use_old_type_nms=False, cls_nms=True,
                    per_class_proposal=True, conf_thresh=0.05)),
+    # use_best with most proposals predicted "not an object": the reference's `if use_best` / separate `if use_cat_rand ...
+    # else` then masks the replaced cluster_ref (eval_helper.py:97-124), which differs from the unmasked labels
+    dict(seed=9, NH=1, kw=dict(use_reference=True, use_lang_classifier=True, use_best=True), extra=(), obj_bias=-0.9),
 )
 POST_KEYS = ("remove_empty_box", "use_3d_nms", "nms_iou", "use_old_type_nms", "cls_nms", "per_class_proposal", "conf_thresh")
 EVAL_INPUTS = ("objectness_scores", "objectness_label", "objectness_mask", "object_assignment", "cluster_ref", "cluster_labels",
@@ -100,7 +104,7 @@ def main():
         d["cluster_ref"] = torch.randn(B, K, generator=g) + 4.0 * torch.exp(-dist * dist / 0.05)
         d["point_clouds"] = torch.cat([torch.rand(B, 2500, 3, generator=g) * 4.2 - 0.1, torch.randn(B, 2500, 1, generator=g)], -1)
         # objectness logits that favour "object" near GT centres, so that the masks are not trivially empty / full
-        d["objectness_scores"] = d["objectness_scores"] + torch.tensor([0.0, 0.6])
+        d["objectness_scores"] = d["objectness_scores"] + torch.tensor([0.0, var.get("obj_bias", 0.6)])
         cfg = EvalConfigShim(dims["NH"], dims["NS"], dims["NC"], mean_size_arr)
         _, d = lh.get_loss(d, cfg, detection=True, use_reference=True, use_lang_classifier=True, use_answer=True,
                            loss_weights=weights)
@@ -127,6 +131,10 @@ def main():
         save["v%d_out_gt_bboxes" % v] = np.asarray(out["gt_bboxes"], dtype=np.float64)
         if "pred_langs" in out:
             save["v%d_out_pred_langs" % v] = out["pred_langs"]
+        if var["kw"].get("use_best"):
+            lab = torch.as_tensor(save["v%d_out_cluster_labels" % v])
+            print("  use_best: samples whose cluster_ref differs from the unmasked labels:",
+                  int((torch.as_tensor(save["v%d_out_cluster_ref" % v]) != lab).any(1).sum()), "of", lab.shape[0])
         print("variant", v, "ref_acc", out["ref_acc"], "iou", np.round(out["ref_iou"], 3).tolist(),
               "rates", out["ref_iou_rate_0.25"], out["ref_iou_rate_0.5"], "pred_mask sum", float(out["pred_mask"].sum()),
               "acc@1", float(out["answer_acc_at1"]), "acc@10", float(out["answer_acc_at10"]), "obj_acc", float(out["obj_acc"]),

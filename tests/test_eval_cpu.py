@@ -65,7 +65,7 @@ def check_variant(z, v, out, host=True):
         assert isinstance(out["ref_iou_rate_0.25"], float) and isinstance(out["pred_bboxes"], list)
 
 
-@pytest.mark.parametrize("v", [0, 1, 2])
+@pytest.mark.parametrize("v", [0, 1, 2, 4])
 @pytest.mark.parametrize("host", [True, False])
 def test_get_eval_matches_reference(v, host):
     from bridgeqa_amd.eval_helper import get_eval

@@ -13,7 +13,7 @@ from test_eval_cpu import GOLD, check_variant, load_variant  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("v", [0, 1, 2, 3])
+@pytest.mark.parametrize("v", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("host", [True, False])
 def test_get_eval_device_matches_reference(v, host):
     from bridgeqa_amd.eval_helper import get_eval

@@ -232,6 +232,15 @@ def test_fused_adamw_checkpoint_resume_and_scheduler_under_replay(dev):
     run(ot, range(3, 6)); run(od, range(3, 6))
     for x, y in zip(t, d):
         assert torch.allclose(x, y, rtol=2e-5, atol=2e-6)
+    # the other direction: a FusedAdamW checkpoint resumes a plain torch.optim.AdamW -- state_dict() emits one INDEPENDENT
+    # step tensor per parameter (a shared storage would be bumped once per parameter by torch's _foreach_add_)
+    assert len({st["step"].data_ptr() for st in sd["state"].values()}) == len(sd["state"])
+    assert ob.state[b[0]]["step"] is ob.state[b[1]]["step"]   # (the optimizer's own state still shares the device counter)
+    f = [torch.nn.Parameter(p.detach().clone()) for p in b]; of = torch.optim.AdamW(f, lr=1e-2, weight_decay=1e-2)
+    of.load_state_dict(__import__("copy").deepcopy(sd))
+    run(of, range(3, 6))
+    for x, y in zip(a, f):
+        assert torch.allclose(x, y, rtol=2e-5, atol=2e-6)
     # (2) graph replay reads the lr of param_groups at replay time
     e = fresh(); oe = FusedAdamW(e, lr=1e-2, weight_decay=0.0)
     for p, g in zip(e, grads[0]):
@@ -254,6 +263,41 @@ def test_fused_adamw_checkpoint_resume_and_scheduler_under_replay(dev):
     frozen = [p.detach().clone() for p in e]
     gr.replay(); torch.cuda.synchronize()
     assert all(torch.equal(x, y) for x, y in zip(frozen, e))
+
+
+def test_capture_hands_a_resumed_optimizer_back_unchanged(dev):
+    """PhasedTrainStep.capture(warmup > 0) runs real optimizer steps and then restores the model AND the optimizer state
+    the caller handed over: a resumed optimizer (load_state_dict) keeps its moments and step count; state the warm-up
+    created for a fresh optimizer starts from zero"""
+    import bench
+    from bridgeqa_amd import fusion_ops as ops
+    from bridgeqa_amd.optim import FusedAdamW
+    from bridgeqa_amd.pipeline import PhasedTrainStep
+    prev = ops.set_compute_dtype(torch.bfloat16)
+    try:
+        model = _small_model(dev)
+        batch = _batch(dev)
+        opt = FusedAdamW(model.parameters(), lr=1e-3)
+        pipe = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, opt, use_graphs=False)
+        pipe.capture(warmup=2)                         # fresh optimizer: the state exists now, zeroed
+        torch.cuda.synchronize()
+        w = model.blip_model.visual_encoder.blocks[0].attn.qkv.weight
+        assert float(opt.state[w]["step"]) == 0.0 and not opt.state[w]["exp_avg"].any()
+        for _ in range(3):
+            pipe.eager_step()
+        torch.cuda.synchronize()
+        want_m = opt.state[w]["exp_avg"].clone()
+        want_v = opt.state[w]["exp_avg_sq"].clone()
+        want_w = w.detach().clone()
+        assert float(opt.state[w]["step"]) == 3.0 and want_m.any()
+        pipe2 = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, opt, use_graphs=False)
+        pipe2.capture(warmup=2)                        # "resumed": moments, step count and weights come back
+        torch.cuda.synchronize()
+        assert float(opt.state[w]["step"]) == 3.0
+        assert torch.equal(opt.state[w]["exp_avg"], want_m) and torch.equal(opt.state[w]["exp_avg_sq"], want_v)
+        assert torch.equal(w.detach(), want_w)
+    finally:
+        ops.set_compute_dtype(prev)
 
 
 def test_data_parallel_step_on_rccl_world_1_equals_the_plain_step(dev):
@@ -434,11 +478,10 @@ def test_batch_stager_feeds_replayed_graphs_with_changing_batches(dev):
     log = PackedRunningLog(dev)
     for k in range(4):
         if k > 0:
-            st.advance()                              # batch <- data k (uploaded during step k - 1)
+            st.advance(pipe)                          # batch <- data k (uploaded during step k - 1), after step k - 1
         st.stage(host[(k + 1) % 4])                   # data k + 1 -> next_batch, under this step
         st.wait(pipe.s_det)                           # the geometry prefetch of this step reads next_batch
-        loss = pipe.step()
-        pipe.wait()
-        got = log.reduce({"loss": loss, "pos_ratio": 0.25})
+        loss = pipe.step()                            # (its phase streams wait for the copy of advance() themselves)
+        got = log.reduce({"loss": loss, "pos_ratio": 0.25}, after=pipe)
         assert abs(got["loss"] - want[k]) <= 5e-4 * abs(want[k]), (k, got["loss"], want[k])
         assert got["pos_ratio"] == 0.25 and got["mae_loss"] == 0.0

@@ -301,9 +301,36 @@ def gemm_roofline(args, dev):
     return out, tot_f, tot_t
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (one process per GPU, RCCL) through
+    torch.distributed.run as a CHILD process, before this process has made any GPU call, and exit with its code.  Never
+    silently runs fewer GPUs than asked for: too few devices is an error."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()   # (counts devices without initialising the GPU on this image)
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d requested, %d visible device(s): refusing to run fewer ranks\n"
+                         % (args.gpus, have))
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python -m torch.distributed.run "
+                         "--nproc-per-node %d ... bench.py --gpus %d)\n" % (args.gpus, world, args.gpus, args.gpus))
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU product path)"

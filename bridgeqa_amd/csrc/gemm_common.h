@@ -1,0 +1,149 @@
+// Shared definitions of the MFMA bf16 GEMM family (csrc/gemm.hip: 256 x 256 and 64 x {64, 32} tiles, the SharedMLP
+// kernels; csrc/gemm_mid.hip: the 256 x 128 tile with two co-resident workgroups per CU): the problem descriptor, the LDS
+// images of K-contiguous / contraction-major operands and their fragment reads, the GELU fit and its LDS table.
+#pragma once
+#include <type_traits>
+
+#include "bq_common.h"
+#include "bqhip_fusion.h"
+
+namespace bq {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_DGELU = 3, EPI_BIAS_CE = 4, EPI_ADD = 5 };
+enum { GF_P_XC = 1, GF_Q_XC = 2, GF_OUT_F32 = 4, GF_ACCUM = 8 };
+
+struct GemmProblem {
+  const __bf16 *P, *Q;
+  void *out;           // out[j * ldo + i]: bf16, or fp32 with GF_OUT_F32
+  const void *bias;    // over i (EPI_BIAS / EPI_BIAS_GELU) or null: fp32, or bf16 when bias_bf16
+  void *out2;          // EPI_BIAS_GELU: gelu(out) as bf16, same layout as out
+  const __bf16 *aux;   // EPI_DGELU: the pre-activation y[j][i] (ld = ldo): out = acc * gelu'(y); EPI_ADD: out = acc + aux[j][i]
+  float *colsum;       // optional fp32 [Ni]: += sum_j out[j][i] (bias gradient of the producing layer)
+  int ldp, ldq, ldo;   // leading dimensions in elements
+  int Ni, Nj, Kc;
+  int tile0, tiles_i;  // first workgroup of this problem in the launch; tiles along i
+  int bias_bf16;
+  unsigned p_bytes, q_bytes;  // bounds of the operand buffers (a K-contiguous operand whose rows are shorter than Kc:
+                              // its partner is zero-padded, its own tail reads run into the next row)
+  int ksplit;          // > 1 (fp32 out, small-tile kernel): the contraction is cut into ksplit pieces, one workgroup
+                       // each, accumulated with fp32 atomics into a zero-initialised `out`
+};
+
+__device__ __forceinline__ void load_bias4(const GemmProblem &pr, int i, float (&bv)[4]) {
+  if (pr.bias_bf16) {
+    const bf16x4 b = *reinterpret_cast<const bf16x4 *>(reinterpret_cast<const __bf16 *>(pr.bias) + i);
+    bv[0] = (float)b[0]; bv[1] = (float)b[1]; bv[2] = (float)b[2]; bv[3] = (float)b[3];
+  } else {
+    const float4 b = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(pr.bias) + i);
+    bv[0] = b.x; bv[1] = b.y; bv[2] = b.z; bv[3] = b.w;
+  }
+}
+
+constexpr int GEMM_MAX_PROBLEMS = 36;
+struct GemmArgs {
+  int n;
+  int total_tiles;
+  GemmProblem p[GEMM_MAX_PROBLEMS];
+};
+
+// ---- LDS images -----------------------------------------------------------------------------------------------------
+// KC unit: [64 rows][64 k] bf16, 128-B rows, 16-B chunk ch of row r at r*128 + ((ch ^ (r & 7)) << 4)
+// XC unit: [64 kc][64 outs] bf16, 128-B rows, 16-B chunk ch of row kc at kc*128 + ((ch ^ (xg(kc) << 1)) << 4)
+// both conflict-free for the fragment reads below (tools/lds_bank_sim.py)
+__device__ __forceinline__ int xg(int kc) { return ((kc >> 1) & 1) | (((kc >> 3) & 1) << 1); }
+
+// GELU x * Phi(x) (reference: nn.GELU / HF "gelu", the erf form) and its derivative, fp32, for epilogues whose result
+// is rounded to bf16.  Phi(x) = sigmoid(x * (a1 + a3 x^2 + a5 x^4)) on |x| <= 8 (clamped beyond: Phi is 0 / 1 to fp32
+// there): a minimax fit of the Gaussian CDF, max |Phi - Phi_erf| = 3.1e-5, max |gelu - gelu_erf| = 3.1e-5, and the
+// derivative of the fitted function differs from gelu_erf' by <= 1.2e-4 (fit and error scan: DESIGN.md §4.4) -- two
+// orders of magnitude below the bf16 rounding (2^-9 relative) applied to the result.  9 VALU operations per element
+// (one v_exp_f32, one v_rcp_f32) instead of ~20 for an erf polynomial: the epilogue runs with the matrix pipe idle.
+constexpr float GELU_A1 = 1.59525515f, GELU_A3 = 7.38511083e-2f, GELU_A5 = -6.82350683e-4f;
+__device__ __forceinline__ float gauss_cdf(float x, float &x2) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
+  x2 = xc * xc;
+  const float z = xc * (GELU_A1 + x2 * (GELU_A3 + x2 * GELU_A5));
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float x2;
+  return x * gauss_cdf(x, x2);
+}
+__device__ __forceinline__ float dgelu_f(float x) {
+  float x2;
+  const float s = gauss_cdf(x, x2);
+  const float dz = GELU_A1 + x2 * (3.0f * GELU_A3 + x2 * (5.0f * GELU_A5));
+  return fabsf(x) <= 8.0f ? s + x * s * (1.0f - s) * dz : s;
+}
+
+// Both functions above are applied to bf16 VALUES (the stored pre-activation), i.e. they have 65536 possible arguments:
+// the 256-tile kernel tabulates them in LDS once per workgroup (filled with the very functions above while the prologue's
+// DMAs are in flight) and its epilogue gathers instead of evaluating ~25 VALU operations per element with the matrix pipe
+// idle.  Index = [sign][magnitude bits clamped to 2^-16 .. 8]: below 2^-16 Phi and gelu' are 0.5 to 2e-5, at and beyond
+// 8 the functions above are clamped themselves.  4866 entries (19 KB beside the 128 KB of staging / output images).
+constexpr unsigned GELU_TAB_LO = (127 - 16) << 7, GELU_TAB_HI = (127 + 3) << 7;
+constexpr int GELU_TAB_HALF = (int)(GELU_TAB_HI - GELU_TAB_LO) + 1, GELU_TAB_N = 2 * GELU_TAB_HALF;
+template <bool DERIV>
+__device__ __forceinline__ void gelu_tab_fill(float *tab, int tid, int nthreads) {
+  for (int e = tid; e < GELU_TAB_N; e += nthreads) {
+    const unsigned sgn = e >= GELU_TAB_HALF ? 1u : 0u;
+    const unsigned bits = (sgn << 15) | ((unsigned)e - sgn * GELU_TAB_HALF + GELU_TAB_LO);
+    const float x = __uint_as_float(bits << 16);
+    float x2;
+    tab[e] = DERIV ? dgelu_f(x) : gauss_cdf(x, x2);
+  }
+}
+// bits16: the bf16 pattern in the low half of a dword (upper half ignored)
+__device__ __forceinline__ float gelu_tab_at(const float *tab, unsigned bits16) {
+  const unsigned mag = min(max(bits16 & 0x7fffu, GELU_TAB_LO), GELU_TAB_HI) - GELU_TAB_LO;
+  return tab[mag + ((bits16 >> 15) & 1u) * GELU_TAB_HALF];
+}
+
+// value of the lane `n` to the left in the same 16-lane row, 0 where there is none (bound_ctrl): row-prefix sums
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32_add(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  bf16x2_t v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+template <bool XC>
+__device__ __forceinline__ bf16x8 read_frag(const unsigned char *unit, int sub16, int kk, int kc_base, const int (&xc_base)[4]) {
+  // KC: kc_base = lane term row16*128 + ((q4 ^ (row16 & 7)) << 4) for kk = 0; kk = 1 toggles bit 6
+  if (!XC) {
+    return *reinterpret_cast<const bf16x8 *>(unit + sub16 * 2048 + (kc_base ^ (kk << 6)));
+  } else {
+    // XC: xc_base[s] = (8*gq + q)*128 + ((s ^ g) << 5) + 8*p ; rows +kk*32, second read +4 rows
+    const unsigned char *a0 = unit + xc_base[sub16] + kk * 4096;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)a0);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(a0 + 512));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+
+#define BQ_BARRIER()                                        \
+  do {                                                      \
+    __builtin_amdgcn_sched_barrier(0);                      \
+    asm volatile("s_barrier" ::: "memory");                 \
+    __builtin_amdgcn_sched_barrier(0);                      \
+  } while (0)
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// csrc/gemm_mid.hip: the 256 (i) x 128 (j) tile kernel (bf16 out, K-contiguous Q); -1 when it has no such form
+int launch_gemm_mid(const GemmArgs &ga, bool p_xc, int epi, hipStream_t st);
+
+}  // namespace bq

@@ -231,8 +231,11 @@ BQ_API int bq_fuse_point_features(const int *pix, const float *feat, float *out,
  *     atomics; the bias gradient of the layer that produced the operand).  In the weight-gradient form
  *     (P_XC | Q_XC | OUT_F32; with ksplit > 1 through atomics onto a zeroed vector) colsum has Nj entries instead and RECEIVES colsum[j] = sum_kc Q(j, kc): the column
  *     sums of dY over the rows = the bias gradient of the same layer, from the same launch (plain stores).
- *   tile: 256 = 256x256 tiles, 8 waves, LDS-DMA pipeline (large M); 64 / 32 = 64 x {64,32} tiles (small M; 32 needs a
- *     K-contiguous Q).  All problems of one call run in ONE launch (grouped GEMM) and must share flags / epilogue.
+ *   tile: 256 = 256x256 tiles, 8 waves, LDS-DMA pipeline (large M, long contractions: the weight gradients); 128 = 256 (i) x
+ *     128 (j) tiles, 4 waves, two workgroups co-resident per CU (large M with SHORT contractions: the forward and
+ *     input-gradient forms of the image encoder -- one workgroup's prologue / epilogue runs under the other's MFMAs; bf16
+ *     out, K-contiguous Q, no colsum); 64 / 32 = 64 x {64,32} tiles (small M; 32 needs a K-contiguous Q).  All problems
+ *     of one call run in ONE launch (grouped GEMM) and must share flags / epilogue.
  * Requirements: 16-byte aligned operands, ldp / ldq / Ni / ldo multiples of 8 (ldo of 4 for fp32), Kc a multiple of
  * 64 for K-contiguous operands (any Kc for contraction-major ones), operands below 2 GB. */
 #define BQ_GEMM_P_XC 1

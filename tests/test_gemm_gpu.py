@@ -32,10 +32,10 @@ FWD_SHAPES = [(1000, 512, 192), (256, 256, 64), (2100, 1024, 256), (16400, 768, 
 
 
 @pytest.mark.parametrize("M,N,K", FWD_SHAPES)
-@pytest.mark.parametrize("tile", [256, 64, 32])
+@pytest.mark.parametrize("tile", [256, 128, 64, 32])
 def test_forward_bias(dev, M, N, K, tile):
     from bridgeqa_amd import _ext
-    if tile != 256 and M * N > 4e6:
+    if tile < 128 and M * N > 4e6:
         pytest.skip("small-tile kernels are for small problems")
     x, w = _rand((M, K), dev, 1), _rand((N, K), dev, 2, 0.1)
     b = torch.randn(N, device=dev)
@@ -46,7 +46,7 @@ def test_forward_bias(dev, M, N, K, tile):
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 512, 192), (2100, 1024, 256), (320, 3072, 768)])
-@pytest.mark.parametrize("tile", [256, 64, 32])
+@pytest.mark.parametrize("tile", [256, 128, 64, 32])
 def test_forward_bias_gelu(dev, M, N, K, tile):
     from bridgeqa_amd import _ext
     x, w = _rand((M, K), dev, 3), _rand((N, K), dev, 4, 0.1)
@@ -64,7 +64,7 @@ def test_identity_asymmetric(dev):
     N = 256
     w = torch.eye(N, device=dev, dtype=torch.bfloat16)
     x = (torch.arange(512 * N, device=dev).reshape(512, N) % 251).to(torch.bfloat16)
-    for tile in (256, 64, 32):
+    for tile in (256, 128, 64, 32):
         y = _ext.gemm_fwd(x, w, None, tile=tile)
         assert torch.equal(y, x), tile
         dx = _ext.gemm_dx(x, w, tile=tile)
@@ -74,11 +74,11 @@ def test_identity_asymmetric(dev):
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 384, 512), (1500, 768, 256), (16400, 768, 768), (320, 768, 3072), (80, 1536, 768)])
-@pytest.mark.parametrize("tile", [256, 64, 32])
+@pytest.mark.parametrize("tile", [256, 128, 64, 32])
 def test_dx(dev, M, N, K, tile):
     """dx = dy @ W (contraction over N): P = W contraction-major (transposed LDS reads)"""
     from bridgeqa_amd import _ext
-    if tile != 256 and M * K > 4e6:
+    if tile < 128 and M * K > 4e6:
         pytest.skip("small-tile kernels are for small problems")
     dy, w = _rand((M, N), dev, 5), _rand((N, K), dev, 6, 0.1)
     dx = _ext.gemm_dx(dy, w, tile=tile)
@@ -110,6 +110,62 @@ def test_dw(dev, M, N, K, tile):
     dy, x = _rand((M, N), dev, 10), _rand((M, K), dev, 11)
     dw = _ext.gemm_dw(dy, x, tile=tile)
     _check(dw, dy.float().t() @ x.float(), f32=True)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 384, 512), (2000, 768, 3072), (16400, 768, 3072), (130, 768, 256)])
+def test_dx_dgelu_and_add_on_the_256x128_tile(dev, M, N, K):
+    """csrc/gemm_mid.hip (tile=128: 256 x 128 tiles, two workgroups per CU): the input-gradient form with the GELU
+    derivative evaluated in the epilogue (no LDS table there) and with a second gradient added; ragged last row tiles
+    (1000 = 7 x 128 + 104, 16400 = 128 x 128 + 16, 130 = 128 + 2)"""
+    from bridgeqa_amd import _ext
+    dy, w = _rand((M, N), dev, 7), _rand((N, K), dev, 8, 0.1)
+    pre = _rand((M, K), dev, 9, 1.5)
+    dx = _ext.gemm_dx(dy, w, pre_act=pre, tile=128)
+    p32 = pre.float().requires_grad_(True)
+    _gelu(p32).backward(dy.float() @ w.float())
+    _check(dx, p32.grad)
+    assert torch.equal(dx, _ext.gemm_dx(dy, w, pre_act=pre, tile=256)) or \
+        ((dx.float() - _ext.gemm_dx(dy, w, pre_act=pre, tile=256).float()).abs().max() <= 2e-2 * dx.float().abs().max())
+    other = _rand((M, K), dev, 12)
+    _check(_ext.gemm_dx(dy, w, add=other, tile=128), dy.float() @ w.float() + other.float())
+    with pytest.raises(RuntimeError):   # no column sums on this tile: rejected, never silently dropped
+        _ext.gemm_dx(dy, w, pre_act=pre, colsum=torch.zeros(K, device=dev), tile=128)
+
+
+def test_256x128_tile_grouped_ragged_and_repeatable_under_load(dev):
+    """tile=128: a grouped launch of problems with ragged i and j extents (Ni not a multiple of 256, Nj not of 128), and
+    -- single-buffered P units restaged one phase after their last read, counted waits across barriers -- bitwise
+    repeatability of the c3 shapes while another stream keeps the memory system busy (a mis-placed wait shows up as rare
+    wrong tiles)"""
+    from bridgeqa_amd import _ext
+    probs, refs = [], []
+    for k, (M, N, K) in enumerate([(1000, 264, 192), (129, 768, 768), (4416, 1536, 768), (70, 8, 64), (16720, 1536, 768)]):
+        x, w = _rand((M, K), dev, 20 + k), _rand((N, K), dev, 40 + k, 0.1)
+        b = torch.randn(N, device=dev)
+        probs.append(dict(P=w, Q=x, out=torch.empty(M, N, device=dev, dtype=torch.bfloat16), bias=b))
+        refs.append(x.float() @ w.float().t() + b)
+    _ext.gemm_grouped(probs, 0, _ext.EPI_BIAS, 128)
+    for p, r in zip(probs, refs):
+        _check(p["out"], r)
+    M = 16400
+    x, w, dy = _rand((M, 768), dev, 50), _rand((2304, 768), dev, 51, 0.05), _rand((M, 2304), dev, 52)
+    w2, h = _rand((768, 3072), dev, 53, 0.05), _rand((M, 3072), dev, 54)
+    dy2 = _rand((M, 768), dev, 55)
+    y0 = _ext.gemm_fwd(x, w, None, tile=128)
+    dx0 = _ext.gemm_dx(dy, w, tile=128)
+    g0 = _ext.gemm_dx(dy2, w2, pre_act=h, tile=128)
+    _check(y0, x.float() @ w.float().t())
+    _check(dx0, dy.float() @ w.float())
+    side = torch.cuda.Stream()
+    big = torch.empty(256 << 20, device=dev, dtype=torch.uint8)
+    for it in range(12):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                big.add_(1)     # HBM-bound traffic beside the GEMMs
+        assert torch.equal(_ext.gemm_fwd(x, w, None, tile=128), y0), it
+        assert torch.equal(_ext.gemm_dx(dy, w, tile=128), dx0), it
+        assert torch.equal(_ext.gemm_dx(dy2, w2, pre_act=h, tile=128), g0), it
+    torch.cuda.synchronize()
 
 
 def test_dw_with_bias_gradient_from_the_same_launch(dev):

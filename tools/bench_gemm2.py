@@ -48,6 +48,7 @@ def graph_time(fn, reps=20, rounds=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--small", action="store_true", help="text-side shapes only")
+    ap.add_argument("--big", action="store_true", help="image-encoder shapes only (256 x 256 against 256 x 128 tiles)")
     ap.add_argument("--json", default=None)
     args = ap.parse_args()
     M = 16400
@@ -65,7 +66,7 @@ def main():
                   ("dx proj M=%d" % m, "dx", m, 768, 768), ("dx fc2+dgelu M=%d" % m, "dxg", m, 768, 3072),
                   ("dw proj M=%d" % m, "dw", m, 768, 768), ("dw fc1 M=%d" % m, "dw", m, 3072, 768)]
     rows = []
-    for name, kind, m, n, k in (small if args.small else big + small):
+    for name, kind, m, n, k in (small if args.small else big if args.big else big + small):
         # (m, n, k): rows, out features, in features of the LINEAR LAYER; fwd: x(m,k) w(n,k); dx: dy(m,n) w(n,k);
         # dw: dy(m,n) x(m,k)
         x, w, dy = rnd(m, k), rnd(n, k, scale=0.05), rnd(m, n)
@@ -73,7 +74,7 @@ def main():
         bb = b.to(torch.bfloat16)
         pre = rnd(m, k)
         flops = 2.0 * m * n * k
-        tiles = [256] if m >= 1024 else [64, 32]
+        tiles = [256, 128] if m >= 1024 else [64, 32]
         if kind == "dw":
             tiles = [256, 64] if m >= 1024 else [64]
         res = {}

@@ -1099,8 +1099,8 @@ extern "C" int bq_gemm_bf16(const bq_gemm_desc *d, int n, int flags, int epilogu
       BQ_REQUIRE(epilogue != EPI_BIAS_GELU || s.out2, BQ_EINVAL, "bq_gemm_bf16: BIAS_GELU needs out2");
       BQ_REQUIRE(epilogue != EPI_DGELU || s.aux, BQ_EINVAL, "bq_gemm_bf16: DGELU needs aux");
       BQ_REQUIRE(epilogue != EPI_ADD || s.aux, BQ_EINVAL, "bq_gemm_bf16: ADD needs aux");
-      BQ_REQUIRE((epilogue != EPI_ADD && epilogue != EPI_DGELU) || ((long)s.Nj + 256) * s.ldo * 2 < 0x7FFFFFFFL, BQ_EINVAL,
-                 "bq_gemm_bf16: aux larger than 2 GB (problem %d)", done);
+      BQ_REQUIRE((epilogue != EPI_ADD && epilogue != EPI_DGELU && tile != 128) || ((long)s.Nj + 256) * s.ldo * 2 < 0x7FFFFFFFL,
+                 BQ_EINVAL, "bq_gemm_bf16: out / aux larger than 2 GB (problem %d)", done);
       const long pb = pxc ? ((long)(s.Kc - 1) * s.ldp + s.Ni) * 2 : ((long)(s.Ni - 1) * s.ldp + s.Kc) * 2;
       const long qb = qxc ? ((long)(s.Kc - 1) * s.ldq + s.Nj) * 2 : ((long)(s.Nj - 1) * s.ldq + s.Kc) * 2;
       const int tj = tile == 256 ? 256 : tile, ti = (tile == 256 || tile == 128) ? 256 : 64;

@@ -79,7 +79,10 @@ __device__ __forceinline__ float dgelu_f(float x) {
   float x2;
   const float s = gauss_cdf(x, x2);
   const float dz = GELU_A1 + x2 * (3.0f * GELU_A3 + x2 * (5.0f * GELU_A5));
-  return fabsf(x) <= 8.0f ? s + x * s * (1.0f - s) * dz : s;
+  // (a select of constants, not of the two results: hipcc turns the latter into a branch per element, and in a fully
+  // unrolled epilogue spills around every one of them)
+  const float inside = fabsf(x) <= 8.0f ? 1.0f : 0.0f;
+  return s + inside * (x * s * (1.0f - s) * dz);
 }
 
 // Both functions above are applied to bf16 VALUES (the stored pre-activation), i.e. they have 65536 possible arguments:

@@ -1,114 +1,66 @@
 // gemm128_kernel: the forward / input-gradient GEMMs of the image encoder and of the K/V projections over the image
-// tokens (reference models/vit.py:30-32,51-53, models/med.py:112-118: nn.Linear + bias / GELU, and their autograd dX) on a
-// 256 (i) x 128 (j) output tile with TWO workgroups co-resident per CU.
+// tokens (reference models/vit.py:30-32,51-53, models/med.py:112-118: nn.Linear + bias / GELU, and their autograd dX) on
+// 256 (i) x 128 (j) output tiles, PERSISTENT workgroups, TWO of them co-resident per CU.
 //
-// Why a second tile shape (profiles/r02_gemm_pmc.txt): the 256 x 256 kernel of csrc/gemm.hip keeps the
-// matrix pipe 58 % busy inside its K loop, but these contractions are SHORT (K = 768: 12 K tiles, 18 us) against a
-// prologue (first operands from HBM) and an epilogue (128 KB of output per workgroup, written by all 256 workgroups of a
-// round at once) of ~9 us per round, and 16400 rows are 64.06 row tiles: whole launches end at 19-33 % MFMA busy.  One
-// workgroup per CU cannot hide its own epilogue (the persistent form was built and measured slower, §4.4).  Here a
-// workgroup is 4 waves (one per SIMD, <= 256 VGPRs) with 64 KB of LDS, so a CU holds two INDEPENDENT workgroups: one's
-// prologue, epilogue stores and barrier / LDS-read gaps run under the other's MFMA clusters, the tiles are half as long
-// (129 x 3k tiles over 512 slots: the tail is one small tile, and a CU left with one workgroup runs it at full rate), and
-// the workgroups of a CU drift apart by themselves (the older one wins the issue arbitration), so the output stores of
-// the chip are spread over the launch instead of arriving in lock-step bursts.
+// Why a second tile shape: the 256 x 256 kernel of csrc/gemm.hip keeps the matrix pipe 58 % busy inside
+// its K loop, but these contractions are SHORT (K = 768: 12 K tiles) against a prologue (first operands from HBM) and an
+// epilogue (128 KB of output per workgroup, written by all 256 workgroups of a round at once), and 16400 rows are 64.06 row
+// tiles: whole launches ended at 19-33 % MFMA busy.  One workgroup per CU cannot hide its own epilogue.  Here a workgroup
+// is 4 waves (one per SIMD, <= 256 VGPRs) with 64 KB of LDS, so a CU holds two INDEPENDENT workgroups: one's epilogue and
+// its barrier / LDS-read / DMA-issue gaps run under the other's MFMA clusters, and the two drift apart by themselves, so
+// the output stores of the chip are spread over the launch instead of arriving in lock-step bursts.  Ablations of the
+// non-persistent first version (tools/bench_gemm_ablate.py) put ~11 us of every ~28 us tile of the K = 768 shapes OUTSIDE
+// the K loop (workgroup launch, address set-up, first operands' latency, epilogue through LDS), hence the second step:
+//   * persistent workgroups (grid = min(tiles, 2 x CUs)) walking tiles v, v + grid, ... of an XCD-aware order;
+//   * ONE continuous LDS-DMA stream across tiles: the slots that would stage K tiles past a tile's end stage the first K
+//     tiles of the workgroup's NEXT tile (per-group cursors that roll over to the next tile's addresses), so a tile's
+//     first operands are already in LDS when its K loop starts -- no prologue after the first tile;
+//   * an epilogue that leaves the staging buffers alone (they belong to the next tile by then): a wave-private 2 KB image
+//     turns the accumulator layout into whole 128-B lines; every load of the epilogue (bias, second operand) is issued
+//     before its first store and the last K tile's two youngest restages behind those loads (vmcnt retires in issue
+//     order: a load behind a store waits for the store's acknowledgement, a load behind a fresh DMA for its landing);
+//     bounds-checked buffer stores that ALWAYS issue (rows / columns past the edge are dropped by the descriptor / an
+//     out-of-range offset), so the counted waits of the next tile's first K tile know how many stores sit in front.
 //
 // Same formulation, LDS images and fragment maps as gemm256_kernel (gemm_common.h):  out[j][i] = sum_kc P(i,kc) Q(j,kc),
 // P K-contiguous (forward: W) or contraction-major (dX: W read transposed with ds_read_b64_tr_b16), Q K-contiguous.
 // Wave tile 128 (i) x 64 (j) = gemm256's; waves 2 (i) x 2 (j).  Staging units of 64 rows x 64 k (8 KB):
 //   PA0(g) PA1(g)  the two 64-row halves of wave row g's P rows          -- SINGLE-buffered (weights: L2-resident)
-//   QB0[b] QB1[b]  the first / second 32 rows of both wave columns       -- DOUBLE-buffered (b = K tile & 1: the
+//   QB0[b] QB1[b]  the first / second 32 rows of both wave columns       -- DOUBLE-buffered (b = running K tile & 1: the
 //                                                                            activation stream comes from HBM / MALL)
-// = 64 KB.  Per K tile four phases, ONE barrier each:
+// = 64 KB (+ 8 KB of epilogue images).  Per K tile four phases, ONE barrier each ("t+1" rolls over into the next tile):
 //   phase   waits for (counted)         reads (LDS -> registers)   MFMA quadrant        restages (LDS-DMA, per wave)
 //   p0(t)   vmcnt(6): PA0(t), QB0(t)    PA0, QB0                   A0 x B0              QB1(t+1)  x2   [read next in p1(t+1)]
 //   p1(t)   --                          QB1                        A0 x B1              PA0(t+1)  x4   [p0(t+1): 3 phases]
 //   p2(t)   vmcnt(6): PA1(t)            PA1                        A1 x B1              QB0(t+2)  x2   [p0(t+2): 6 phases]
 //   p3(t)   --                          (B0 kept in registers)     A1 x B0              PA1(t+1)  x4   [p2(t+1): 3 phases]
 // A unit is restaged in the phase AFTER its last read (that phase's barrier orders every wave's reads before the DMA);
-// vmcnt counts a wave's DMAs in issue order, so vmcnt(6) at p0(t) = "everything up to PA0(t) has landed" (issued after
-// it: QB0(t+1) x2, PA1(t) x4) and at p2(t) = "up to PA1(t)" (after it: QB1(t+1) x2, PA0(t+1) x4); the barrier that follows
-// makes every wave's DMAs visible to all.  DMAs past the last K tile use the out-of-range sentinel (zeros, no traffic)
-// so that the counts keep their meaning.
+// vmcnt counts a wave's vector-memory operations in issue order, so vmcnt(6) at p0(t) = "everything up to PA0(t) has
+// landed" (issued after it: QB0(t+1) x2, PA1(t) x4) and at p2(t) = "up to PA1(t)" (after it: QB1(t+1) x2, PA0(t+1) x4); the
+// barrier that follows makes every wave's DMAs visible to all.  In the FIRST K tile of a continuing tile the previous
+// tile's S epilogue stores sit between those DMAs and the wait: vmcnt(6 + S) there.  Past the workgroup's last tile the
+// cursors park on the out-of-range sentinel (zeros, no traffic) so that the counts keep their meaning.
 #include "gemm_common.h"
 
 namespace bq {
 
-template <bool P_XC, int EPI>
+// ST_AUX: cache policy of the output stores (buffer-store aux bits: 0 default, 2 nt, 16 sc1 = write-through, the line is
+// dropped from the XCD's L2 -- MI355X_MICROARCH.md, stores of each flavour)
+typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+template <bool P_XC, int EPI, int ST_AUX>
 __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[65536];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[65536 + 4 * 2048];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
+  const int nwg = args.total_tiles, G = (int)gridDim.x;
 
-  // ---- workgroup -> (problem, tile), XCD-aware as in gemm256_kernel ---------------------------------------------------
-  const int nwg = args.total_tiles;
-  int t;
-  {
-    const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
-    t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-  }
-  int pi = 0;
-  for (int k = 1; k < args.n; ++k)
-    if (t >= args.p[k].tile0) pi = k;
-  const GemmProblem &pr = args.p[pi];
-  const int tl = t - pr.tile0;
-  const int tiles_j = (pr.Nj + 127) >> 7;
-  const int bj = tiles_j - 1 - tl / pr.tiles_i, bi = tl % pr.tiles_i;   // ragged last j block first
-  const int i0 = bi * 256, j0 = bj * 128;
-  const int Ni = pr.Ni, Nj = pr.Nj, Kc = pr.Kc;
-  const int ldp = pr.ldp, ldq = pr.ldq;
-  const int nkt = (Kc + 63) >> 6;
-
-  // ---- staging: a unit = 8 DMAs of 1 KB (8 rows x 128 B), two per wave: unit rows (w + 4 d) * 8 + lane / 8 ------------
-  const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void *)pr.P, 0, pr.p_bytes, 0x00020000);
-  const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void *)pr.Q, 0, pr.q_bytes, 0x00020000);
-  const int cp = lane & 7;
-  unsigned vP[4][2], vQ[2][2];   // P units PA0(0) PA0(1) PA1(0) PA1(1); Q units QB0 QB1
-#pragma unroll
-  for (int d = 0; d < 2; ++d) {
-    const int ur = (wave + 4 * d) * 8 + (lane >> 3);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int g = u & 1, half = u >> 1;
-      if (!P_XC) vP[u][d] = (unsigned)(((i0 + g * 128 + half * 64 + ur) * ldp + (cp ^ (ur & 7)) * 8) * 2);
-      else vP[u][d] = (unsigned)((ur * ldp + i0 + g * 128 + half * 64 + (cp ^ (xg(ur) << 1)) * 8) * 2);
-    }
-#pragma unroll
-    for (int half = 0; half < 2; ++half)  // unit row r -> j0 + (r >> 5) * 64 + half * 32 + (r & 31)
-      vQ[half][d] = (unsigned)(((j0 + (ur >> 5) * 64 + half * 32 + (ur & 31)) * ldq + (cp ^ (ur & 7)) * 8) * 2);
-  }
-  const unsigned p_step = P_XC ? (unsigned)(64 * ldp * 2) : 128u;
-  constexpr unsigned q_step = 128u;
-  constexpr int PA0 = 0, PA1 = 16384, QB = 32768;   // QB + buf * 16384 + half * 8192
-
-  // stage P unit pair `half` (PA0 / PA1: both wave rows, 4 DMAs per wave) of K tile kt
-  auto stage_p = [&](int half, int kt) {
-    const bool live = kt < nkt;
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        const int u = half * 2 + g;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_void_t *)(smem + (half ? PA1 : PA0) + g * 8192 + (wave + 4 * d) * 1024),
-                                                 16, live ? vP[u][d] : 0x80000000u, 0, 0, 0);
-        vP[u][d] += p_step;
-      }
-  };
-  // stage Q unit `half` (QB0 / QB1, 2 DMAs per wave) of K tile kt into buffer kt & 1
-  auto stage_q = [&](int half, int kt) {
-    const bool live = kt < nkt;
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_void_t *)(smem + QB + (kt & 1) * 16384 + half * 8192 + (wave + 4 * d) * 1024),
-                                               16, live ? vQ[half][d] : 0x80000000u, 0, 0, 0);
-      vQ[half][d] += q_step;
-    }
-  };
-
-  // ---- fragment read addresses (lane-dependent parts), as in gemm256_kernel -----------------------------------------
-  const int row16 = lane & 15, q4 = lane >> 4;
+  // ---- lane-dependent constants ---------------------------------------------------------------------------------------
+  const int row16 = lane & 15, q4 = lane >> 4, cp = lane & 7, lr = lane >> 3;
   const int kc_base = row16 * 128 + ((q4 ^ (row16 & 7)) << 4);
   int xc_base[4];
   {
@@ -116,21 +68,99 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) xc_base[s] = (8 * q4 + q) * 128 + ((s ^ g) << 5) + 8 * p;
   }
+  constexpr int PA0 = 0, PA1 = 16384, QB = 32768;   // QB + buf * 16384 + half * 8192
   const int uA0 = PA0 + wr * 8192, uA1 = PA1 + wr * 8192;
   const int bsub = wc * 2;
 
-  const int iw = i0 + wr * 128, jw = j0 + wc * 64;
-  const bool vA0 = iw < Ni, vA1 = iw + 64 < Ni, vB0 = jw < Nj, vB1 = jw + 32 < Nj;
+  // ---- virtual block id -> (problem, tile): XCD-aware as in gemm256_kernel (blocks b, b + 8, ... share an XCD's L2; G is
+  // a multiple of 8 or the whole grid, so v = b + n G stays on b's XCD) -------------------------------------------------
+  struct Tile { int pi, i0, j0, nkt; };
+  auto decode = [&](int v) {
+    const int q = nwg >> 3, r = nwg & 7, x = v & 7;
+    const int t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (v >> 3);
+    int pi = 0;
+    for (int k = 1; k < args.n; ++k)
+      if (t >= args.p[k].tile0) pi = k;
+    const GemmProblem &pr = args.p[pi];
+    const int tl = t - pr.tile0;
+    const int tiles_j = (pr.Nj + 127) >> 7;
+    Tile tt;
+    tt.pi = pi;
+    tt.j0 = (tiles_j - 1 - tl / pr.tiles_i) * 128;   // ragged last j block first
+    tt.i0 = (tl % pr.tiles_i) * 256;
+    tt.nkt = (pr.Kc + 63) >> 6;
+    return tt;
+  };
+
+  // ---- the DMA stream: one cursor per staging group, (tile, K tile) advancing independently of the compute side ------
+  // a unit = 8 DMAs of 1 KB (8 rows x 128 B), two per wave: unit rows (w + 4 d) * 8 + lane / 8
+  unsigned vP[2], vQ[2];                // [half]: the next byte offset to stage of DMA (g = 0, d = 0); the other DMAs of
+                                        // the group add wave-uniform deltas (in the bounds-checked vector offset)
+  unsigned stepP[2], dgP[2], ddP[2], ddQ[2];   // per group: bytes per K tile / per wave row g / per DMA d of the cursor's problem
+  int remP[2], remQ[2];                 // K tiles left before the cursor rolls over to the next tile
+  int rsrcP_pi[2], rsrcQ_pi[2];         // problem of each cursor (its buffer descriptor)
+  const unsigned DEAD = 0x80000000u;    // (+ a few deltas and steps stays out of range)
+  const int ur0 = wave * 8 + lr;        // unit row of DMA d = 0; d = 1: + 32 (same row & 7, same xg: same chunk swizzle)
+
+  auto set_p = [&](int half, const Tile &tt, bool live) {
+    const GemmProblem &pr = args.p[tt.pi];
+    const int ldp = pr.ldp;
+    unsigned v;
+    if (!P_XC) v = (unsigned)(((tt.i0 + half * 64 + ur0) * ldp + (cp ^ (ur0 & 7)) * 8) * 2);
+    else v = (unsigned)((ur0 * ldp + tt.i0 + half * 64 + (cp ^ (xg(ur0) << 1)) * 8) * 2);
+    vP[half] = live ? v : DEAD;
+    stepP[half] = P_XC ? (unsigned)(64 * ldp * 2) : 128u;
+    dgP[half] = P_XC ? 256u : (unsigned)(128 * ldp * 2);
+    ddP[half] = (unsigned)(32 * ldp * 2);
+    remP[half] = live ? tt.nkt : 0x40000000;
+    rsrcP_pi[half] = tt.pi;
+  };
+  auto set_q = [&](int half, const Tile &tt, bool live) {
+    const GemmProblem &pr = args.p[tt.pi];
+    // unit row r -> j0 + (r >> 5) * 64 + half * 32 + (r & 31); d = 1 is r + 32: 64 rows further
+    const unsigned v = (unsigned)(((tt.j0 + half * 32 + ur0) * pr.ldq + (cp ^ (ur0 & 7)) * 8) * 2);
+    vQ[half] = live ? v : DEAD;
+    ddQ[half] = (unsigned)(64 * pr.ldq * 2);
+    remQ[half] = live ? tt.nkt : 0x40000000;
+    rsrcQ_pi[half] = tt.pi;
+  };
+
+  int v = blockIdx.x;
+  Tile cur = decode(v);
+  bool has_next = v + G < nwg;
+  Tile nxt = has_next ? decode(v + G) : cur;
+
+  // stage P unit pair `half` (PA0 / PA1: both wave rows, 4 DMAs per wave) at its cursor, advance the cursor
+  auto dma_p = [&](int half) {
+    const GemmProblem &pr = args.p[rsrcP_pi[half]];
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)pr.P, 0, pr.p_bytes, 0x00020000);
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(smem + (half ? PA1 : PA0) + g * 8192 + (wave + 4 * d) * 1024),
+                                                 16, vP[half] + (g * dgP[half] + d * ddP[half]), 0, 0, 0);
+    vP[half] += stepP[half];
+    if (--remP[half] == 0) set_p(half, nxt, has_next);
+  };
+  // stage Q unit `half` (QB0 / QB1, 2 DMAs per wave) at its cursor into buffer `par` & 1, advance the cursor
+  auto dma_q = [&](int half, unsigned par) {
+    const GemmProblem &pr = args.p[rsrcQ_pi[half]];
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)pr.Q, 0, pr.q_bytes, 0x00020000);
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(smem + QB + (par & 1) * 16384 + half * 8192 + (wave + 4 * d) * 1024),
+                                               16, vQ[half] + d * ddQ[half], 0, 0, 0);
+    vQ[half] += 128u;
+    if (--remQ[half] == 0) set_q(half, nxt, has_next);
+  };
+
+  // ---- prologue of the workgroup's first tile: the issue order the steady state would have produced before p0(0) -------
+  set_q(0, cur, true); set_q(1, cur, true); set_p(0, cur, true); set_p(1, cur, true);
+  unsigned gk = 0;   // running K tile count of this workgroup (Q buffer parity)
+  dma_q(0, 0); dma_q(1, 0); dma_p(0); dma_q(0, 1); dma_p(1);
 
   f32x4 acc[8][4];
-#pragma unroll
-  for (int a = 0; a < 8; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // ---- prologue: the issue order the steady state would have produced before p0(0) ---------------------------------
-  stage_q(0, 0); stage_q(1, 0); stage_p(0, 0); stage_q(0, 1); stage_p(1, 0);
-
   bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
 #define BQ_MID_MFMA(AO, FB, BO)                                                                       \
   _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int a = 0; a < 4; ++a)      \
@@ -143,151 +173,241 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
 #define BQ_MID_COMPUTE_END()                                \
   __builtin_amdgcn_s_setprio(0);                            \
   __builtin_amdgcn_sched_barrier(0);
+  constexpr int NPASS = (EPI == EPI_BIAS_GELU) ? 2 : 1;
+  constexpr int NSTORE = 16 * NPASS;   // epilogue stores per wave (4 j blocks x 2 i halves x 2): always issued
 
-  for (int kt = 0; kt < nkt; ++kt) {
-    const unsigned char *qb = smem + QB + (kt & 1) * 16384;
-    // ---- p0: PA0, QB0 -> A0 x B0 ; restage QB1(t+1)
-    wait_vmcnt<6>();
-    BQ_BARRIER();
-    if (vA0) {
+  for (bool first = true;; first = false) {
+    const GemmProblem &pr = args.p[cur.pi];
+    const int Ni = pr.Ni, Nj = pr.Nj;
+    const int iw = cur.i0 + wr * 128, jw = cur.j0 + wc * 64;
+    const bool vA0 = iw < Ni, vA1 = iw + 64 < Ni, vB0 = jw < Nj, vB1 = jw + 32 < Nj;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < cur.nkt; ++kt, ++gk) {
+      const unsigned char *qb = smem + QB + (gk & 1) * 16384;
+      const bool after_stores = kt == 0 && !first;   // the previous tile's epilogue stores are in front of the wait
+      const bool last = kt == cur.nkt - 1;           // its p2 / p3 restages are issued from the epilogue (see there)
+      // ---- p0: PA0, QB0 -> A0 x B0 ; restage QB1(t+1)
+      if (after_stores) wait_vmcnt<6 + NSTORE>(); else wait_vmcnt<6>();
+      BQ_BARRIER();
+      // (fragment reads are unconditional -- a skipped read would keep the fragment registers live across the epilogue;
+      // only the MFMAs of quadrants that lie wholly past a ragged edge are skipped)
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag<P_XC>(smem + uA0, a, kk, kc_base, xc_base);
-    }
-    if (vB0) {
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) fb0[b][kk] = read_frag<false>(qb, bsub + b, kk, kc_base, xc_base);
-    }
-    stage_q(1, kt + 1);
-    BQ_MID_COMPUTE_BEGIN();
-    if (vA0 && vB0) { BQ_MID_MFMA(0, fb0, 0) }
-    BQ_MID_COMPUTE_END();
-    // ---- p1: QB1 -> A0 x B1 ; restage PA0(t+1)
-    BQ_BARRIER();
-    if (vB1) {
+      dma_q(1, gk + 1);
+      BQ_MID_COMPUTE_BEGIN();
+      if (vA0 && vB0) { BQ_MID_MFMA(0, fb0, 0) }
+      BQ_MID_COMPUTE_END();
+      // ---- p1: QB1 -> A0 x B1 ; restage PA0(t+1)
+      BQ_BARRIER();
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) fb1[b][kk] = read_frag<false>(qb + 8192, bsub + b, kk, kc_base, xc_base);
-    }
-    stage_p(0, kt + 1);
-    BQ_MID_COMPUTE_BEGIN();
-    if (vA0 && vB1) { BQ_MID_MFMA(0, fb1, 2) }
-    BQ_MID_COMPUTE_END();
-    // ---- p2: PA1 -> A1 x B1 ; restage QB0(t+2)
-    wait_vmcnt<6>();
-    BQ_BARRIER();
-    if (vA1) {
+      dma_p(0);
+      BQ_MID_COMPUTE_BEGIN();
+      if (vA0 && vB1) { BQ_MID_MFMA(0, fb1, 2) }
+      BQ_MID_COMPUTE_END();
+      // ---- p2: PA1 -> A1 x B1 ; restage QB0(t+2)
+      if (after_stores) wait_vmcnt<6 + NSTORE>(); else wait_vmcnt<6>();
+      BQ_BARRIER();
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag<P_XC>(smem + uA1, a, kk, kc_base, xc_base);
+      if (!last) dma_q(0, gk + 2);
+      BQ_MID_COMPUTE_BEGIN();
+      if (vA1 && vB1) { BQ_MID_MFMA(4, fb1, 2) }
+      BQ_MID_COMPUTE_END();
+      // ---- p3: (B0 kept in registers) -> A1 x B0 ; restage PA1(t+1)
+      BQ_BARRIER();
+      if (!last) dma_p(1);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      if (vA1 && vB0) { BQ_MID_MFMA(4, fb0, 0) }
+      BQ_MID_COMPUTE_END();
     }
-    stage_q(0, kt + 2);
-    BQ_MID_COMPUTE_BEGIN();
-    if (vA1 && vB1) { BQ_MID_MFMA(4, fb1, 2) }
-    BQ_MID_COMPUTE_END();
-    // ---- p3: (B0 kept in registers) -> A1 x B0 ; restage PA1(t+1)
-    BQ_BARRIER();
-    stage_p(1, kt + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    if (vA1 && vB0) { BQ_MID_MFMA(4, fb0, 0) }
-    BQ_MID_COMPUTE_END();
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing out-of-range DMAs have written their zeros
-  BQ_BARRIER();
 
-  // ---- epilogue (gemm256_kernel's, without the LDS table: GELU / GELU' are evaluated -- the co-resident workgroup's
-  // MFMAs run meanwhile).  accumulator (a, b)[r]: i = iw + a*16 + q4*4 + r, j = jw + b*16 + row16.  bf16 outputs go through
-  // a wave-private [64 j][128 i] LDS image (16 KB, chunk c of row j at j*256 + ((c ^ (j & 15)) << 4)) so that global stores
-  // are whole 256-B row pieces.
-  const int ldo = pr.ldo;
-  unsigned char *ep = smem + wave * 16384;
-  constexpr int NPASS = (EPI == EPI_BIAS_GELU) ? 2 : 1;
+    // ---- epilogue.  accumulator (a, b)[r]: i = iw + a*16 + q4*4 + r, j = jw + b*16 + row16.  The staging buffers belong
+    // to the next tile by now, so the bf16 results go through a wave-private 2 KB image of their own -- [16 j][64 i], 16-B
+    // chunk c of row j at j*128 + ((c ^ (j & 7)) << 4), one (j block, i half) at a time -- and leave as whole 128-B lines
+    // (8 rows per store instruction; stores of 64-B row pieces straight from the accumulators measured 15 % slower on the
+    // whole launch).  Bounds-checked buffer stores that ALWAYS issue: the next tile's counted waits know their number.
+    {
+      const int ldo = pr.ldo;
+      const unsigned obytes = (unsigned)((long)Nj * ldo * 2);
+      const auto rsO = __builtin_amdgcn_make_buffer_rsrc(pr.out, 0, obytes, 0x00020000);
+      const auto rsO2 = __builtin_amdgcn_make_buffer_rsrc(EPI == EPI_BIAS_GELU ? pr.out2 : pr.out, 0, obytes, 0x00020000);
+      const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void *)((EPI == EPI_DGELU || EPI == EPI_ADD) ? (const void *)pr.aux : pr.out), 0, obytes, 0x00020000);
+      const int wj = row16 * 128 + (q4 & 1) * 8, wx = row16 & 7, wc2 = q4 >> 1;
+      // every load of the epilogue is issued BEFORE its first store: vmcnt retires in issue order, so a load behind a store
+      // could only be consumed once that store has been acknowledged (the fragment registers are free by now: the bias of
+      // the wave's 128 columns / the second operand of its whole 128 x 64 tile fit)
+      // FOLD phase: bias / the second operand go into the accumulators in place, BEFORE the tile's first store -- vmcnt
+      // retires in issue order, so a load issued behind a store could only be consumed once that store has been
+      // acknowledged.  The last K tile's p2 / p3 restages (QB0 two K tiles ahead, PA1 one ahead: both belong to the next
+      // tile) are issued behind the LAST of these loads: the loads then only queue behind DMAs that are >= 2 phases old.
+      auto deferred_dmas = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        dma_q(0, gk + 1);   // (gk already counts this tile's last K tile: "K tile + 2" of the stream)
+        dma_p(1);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+        float bias_r[8][4];
+        const bool bb = pr.bias_bf16 != 0;
+        const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void *)pr.bias, 0, pr.bias == nullptr ? 0 : Ni * (bb ? 2 : 4), 0x00020000);
+        const unsigned bo = (unsigned)(iw + q4 * 4);
+        if (bb) {
+          uint2 raw[8];
 #pragma unroll
-  for (int pass = 0; pass < NPASS; ++pass) {
-    if (EPI == EPI_DGELU || EPI == EPI_ADD) {
-      // second operand `aux` in the accumulator's own map (8 B per lane), j block outermost, the next block's eight
-      // pieces in flight while one is processed; bounds-checked (rows past Nj read zeros)
-      const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void *)pr.aux, 0, (int)((long)Nj * ldo * 2), 0x00020000);
-      uint2 yy[2][8];
-      auto fetch = [&](int b, uint2(&dst)[8]) {
-        const unsigned off = (unsigned)(((jw + b * 16 + row16) * ldo + iw + q4 * 4) * 2);
+          for (int a = 0; a < 8; ++a) raw[a] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsB, (bo + a * 16) * 2, 0, 0));
+#pragma unroll
+          for (int a = 0; a < 8; ++a) {
+            bias_r[a][0] = __uint_as_float(raw[a].x << 16); bias_r[a][1] = __uint_as_float(raw[a].x & 0xffff0000u);
+            bias_r[a][2] = __uint_as_float(raw[a].y << 16); bias_r[a][3] = __uint_as_float(raw[a].y & 0xffff0000u);
+          }
+        } else {
+#pragma unroll
+          for (int a = 0; a < 8; ++a) {
+            const float4 t4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (bo + a * 16) * 4, 0, 0));
+            bias_r[a][0] = t4.x; bias_r[a][1] = t4.y; bias_r[a][2] = t4.z; bias_r[a][3] = t4.w;
+          }
+        }
+        deferred_dmas();
 #pragma unroll
         for (int a = 0; a < 8; ++a)
-          dst[a] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsX, off + a * 32, 0, 0));
-      };
-      fetch(0, yy[0]);
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] += bias_r[a][r];
+      } else if (EPI == EPI_DGELU || EPI == EPI_ADD) {
+        uint2 yA[8], yB[8];   // the second operand in the accumulator's own map (8 B per lane), one j block each
+        auto fetch = [&](int b, uint2(&dst)[8]) {
+          const unsigned off = (unsigned)(((jw + b * 16 + row16) * ldo + iw + q4 * 4) * 2);
+#pragma unroll
+          for (int a = 0; a < 8; ++a)
+            dst[a] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsX, off + a * 32, 0, 0));
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        auto fold = [&](auto b_tag, const uint2(&src)[8]) {
+          constexpr int b = decltype(b_tag)::value;
+#pragma unroll
+          for (int a = 0; a < 8; ++a) {
+            const uint2 yb = src[a];
+            const float y0 = __uint_as_float(yb.x << 16), y1 = __uint_as_float(yb.x & 0xffff0000u);
+            const float y2 = __uint_as_float(yb.y << 16), y3 = __uint_as_float(yb.y & 0xffff0000u);
+            if (EPI == EPI_DGELU) {  // out = acc * gelu'(y)
+              acc[a][b][0] *= dgelu_f(y0); acc[a][b][1] *= dgelu_f(y1); acc[a][b][2] *= dgelu_f(y2); acc[a][b][3] *= dgelu_f(y3);
+              __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise interleaves all the evaluations and spills)
+            } else {                 // out = acc + aux
+              acc[a][b][0] += y0; acc[a][b][1] += y1; acc[a][b][2] += y2; acc[a][b][3] += y3;
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        typedef std::integral_constant<int, 0> B0; typedef std::integral_constant<int, 1> B1;
+        typedef std::integral_constant<int, 2> B2; typedef std::integral_constant<int, 3> B3;
+        fetch(0, yA); fetch(1, yB);
+        fold(B0{}, yA);
+        fetch(2, yA);
+        fold(B1{}, yB);
+        fetch(3, yB);
+        deferred_dmas();
+        fold(B2{}, yA);
+        fold(B3{}, yB);
+      } else {
+        deferred_dmas();
+      }
+      const unsigned ep_lds = (unsigned)(size_t)((lds_u8_t *)smem) + 65536u + (unsigned)(wave * 2048);
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        if (b + 1 < 4) fetch(b + 1, yy[(b + 1) & 1]);
 #pragma unroll
-        for (int a = 0; a < 8; ++a) {
-          const uint2 yb = yy[b & 1][a];
-          const float y0 = __uint_as_float(yb.x << 16), y1 = __uint_as_float(yb.x & 0xffff0000u);
-          const float y2 = __uint_as_float(yb.y << 16), y3 = __uint_as_float(yb.y & 0xffff0000u);
-          float v[4];
-          if (EPI == EPI_DGELU) {  // out = acc * gelu'(y)
-            v[0] = acc[a][b][0] * dgelu_f(y0); v[1] = acc[a][b][1] * dgelu_f(y1);
-            v[2] = acc[a][b][2] * dgelu_f(y2); v[3] = acc[a][b][3] * dgelu_f(y3);
-          } else {                 // out = acc + aux
-            v[0] = acc[a][b][0] + y0; v[1] = acc[a][b][1] + y1; v[2] = acc[a][b][2] + y2; v[3] = acc[a][b][3] + y3;
+        for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {
+              const int a = half * 4 + a4;
+              float vv[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) vv[r] = (float)(__bf16)acc[a][b][r];  // what is stored (and what a backward differentiates at)
+              if (EPI == EPI_BIAS_GELU && pass == 1) {  // x * Phi(x), Phi of the bf16 value
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vv[r] = gelu_f(vv[r]);
+              }
+              // (inline asm: a compiler-visible LDS access here would be fenced with vmcnt(0) against the LDS-DMAs in flight)
+              const u32x2_t pk = {pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3])};
+              asm volatile("ds_write_b64 %0, %1" ::"v"(ep_lds + (unsigned)(wj + (((a4 * 2 + wc2) ^ wx) << 4))), "v"(pk) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4_t d[2];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+              const int jr = t2 * 8 + lr;                  // image row; 16-B chunk cp
+              asm volatile("ds_read_b128 %0, %1" : "=v"(d[t2]) : "v"(ep_lds + (unsigned)(jr * 128 + ((cp ^ (jr & 7)) << 4))) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1])::"memory");   // (the image is rewritten next)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+              const int jr = t2 * 8 + lr;
+              const int j = jw + b * 16 + jr, i_st = iw + half * 64 + cp * 8;
+              const unsigned off = i_st < Ni ? (unsigned)((j * ldo + i_st) * 2) : DEAD;   // Ni % 8 == 0 (host check)
+              __builtin_amdgcn_raw_buffer_store_b128(d[t2], pass == 1 ? rsO2 : rsO, off, 0, ST_AUX);
+            }
           }
-          uint2 pk;
-          pk.x = pack_bf16x2(v[0], v[1]);
-          pk.y = pack_bf16x2(v[2], v[3]);
-          *reinterpret_cast<uint2 *>(ep + (b * 16 + row16) * 256 + (((a * 2 + (q4 >> 1)) ^ row16) << 4) + (q4 & 1) * 8) = pk;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int a = 0; a < 8; ++a) {
-        const int i = iw + a * 16 + q4 * 4;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && pr.bias != nullptr && i < Ni) load_bias4(pr, i, bv);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = (float)(__bf16)(acc[a][b][r] + bv[r]);  // what is stored (and what a backward differentiates at)
-          if (EPI == EPI_BIAS_GELU && pass == 1) {  // x * Phi(x), Phi of the bf16 value
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-          }
-          uint2 pk;
-          pk.x = pack_bf16x2(v[0], v[1]);
-          pk.y = pack_bf16x2(v[2], v[3]);
-          *reinterpret_cast<uint2 *>(ep + (b * 16 + row16) * 256 + (((a * 2 + (q4 >> 1)) ^ row16) << 4) + (q4 & 1) * 8) = pk;
         }
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __bf16 *dst = (pass == 1) ? reinterpret_cast<__bf16 *>(pr.out2) : reinterpret_cast<__bf16 *>(pr.out);
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int jr = it * 4 + q4;          // row of the wave image
-      const int j = jw + jr, i = iw + row16 * 8;
-      const uint4 v = *reinterpret_cast<const uint4 *>(ep + jr * 256 + ((row16 ^ (jr & 15)) << 4));
-      if (j < Nj && i < Ni) *reinterpret_cast<uint4 *>(dst + (long)j * ldo + i) = v;  // Ni % 8 == 0 (host check)
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    v += G;
+    if (v >= nwg) break;
+    cur = nxt;
+    has_next = v + G < nwg;
+    if (has_next) nxt = decode(v + G);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the parked cursors' out-of-range DMAs have written their zeros
 }
 
-int launch_gemm_mid(const GemmArgs &ga, bool p_xc, int epi, hipStream_t st) {
-  const dim3 grid(ga.total_tiles), block(256);
+int launch_gemm_mid(const GemmArgs &ga, bool p_xc, int epi, hipStream_t stream) {
+  static int slots = 0;
+  if (slots == 0) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    slots = 2 * cus;   // two co-resident workgroups per CU (64 KB of LDS, <= 256 VGPRs each)
+    if (getenv("BQ_GEMM_MID_SLOTS")) slots = atoi(getenv("BQ_GEMM_MID_SLOTS"));   // (tools/bench_gemm_slots.py)
+  }
+  for (int k = 0; k < ga.n; ++k)
+    if (ga.p[k].Kc < 128) return -1;   // (the QB0 cursor runs two K tiles ahead: a tile has at least two)
+  const dim3 grid(ga.total_tiles < slots ? ga.total_tiles : slots), block(256);
+  // output stores write-through (sc1): the lines are dropped from the XCD's L2, which then keeps the weight / activation
+  // panels the co-scheduled tiles share.  MEASURED against the default policy, every c3 shape: 3-9 % faster (qkv 60.5 ->
+  // 59.7 us, proj 26.6 -> 24.2, fc1 + GELU 104.5 -> 99.9, dX qkv 60.4 -> 57.3)
+#define BQ_MID_LAUNCH(PX, E)                                                                                        \
+  do {                                                                                                              \
+    hipLaunchKernelGGL((gemm128_kernel<PX, E, 16>), grid, block, 0, st_, ga);                                       \
+    return 0;                                                                                                       \
+  } while (0)
+  hipStream_t st_ = stream;
   if (!p_xc) {
-    if (epi == EPI_NONE) { hipLaunchKernelGGL((gemm128_kernel<false, EPI_NONE>), grid, block, 0, st, ga); return 0; }
-    if (epi == EPI_BIAS) { hipLaunchKernelGGL((gemm128_kernel<false, EPI_BIAS>), grid, block, 0, st, ga); return 0; }
-    if (epi == EPI_BIAS_GELU) { hipLaunchKernelGGL((gemm128_kernel<false, EPI_BIAS_GELU>), grid, block, 0, st, ga); return 0; }
+    if (epi == EPI_NONE) BQ_MID_LAUNCH(false, EPI_NONE);
+    if (epi == EPI_BIAS) BQ_MID_LAUNCH(false, EPI_BIAS);
+    if (epi == EPI_BIAS_GELU) BQ_MID_LAUNCH(false, EPI_BIAS_GELU);
   } else {
-    if (epi == EPI_NONE) { hipLaunchKernelGGL((gemm128_kernel<true, EPI_NONE>), grid, block, 0, st, ga); return 0; }
-    if (epi == EPI_DGELU) { hipLaunchKernelGGL((gemm128_kernel<true, EPI_DGELU>), grid, block, 0, st, ga); return 0; }
-    if (epi == EPI_ADD) { hipLaunchKernelGGL((gemm128_kernel<true, EPI_ADD>), grid, block, 0, st, ga); return 0; }
+    if (epi == EPI_NONE) BQ_MID_LAUNCH(true, EPI_NONE);
+    if (epi == EPI_DGELU) BQ_MID_LAUNCH(true, EPI_DGELU);
+    if (epi == EPI_ADD) BQ_MID_LAUNCH(true, EPI_ADD);
   }
   return -1;
 }

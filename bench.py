@@ -31,6 +31,8 @@ WORKLOADS = {
           "answer decoder on both streams), fwd+bwd+AdamW, LM answer loss + the reference's detection loss "
           "(vote/objectness/box/sem-cls) on synthetic boxes",
 }
+WORKLOADS["c5"] = ("c5 (one rank's share): " + WORKLOADS["c3"][4:] + " -- at B=32 x 80000 points + one 1024x1024 view "
+                   "(4097 image tokens) per scene")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -39,11 +41,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=os.environ.get("BQ_WORKLOAD", "auto"), choices=["auto", "c2", "c3"])
+    ap.add_argument("--workload", default=os.environ.get("BQ_WORKLOAD", "auto"), choices=["auto", "c2", "c3", "c5"],
+                    help="auto = c3 (the configuration BASELINE.json's metric is quoted on); c5 = one rank's share of the "
+                         "large-context configuration (B=32 x 80000 points + 1024^2 views, 4097 image tokens)")
     ap.add_argument("--cin", type=int, default=132, help="per-point feature channels (README recipe: 128+3+1)")
-    ap.add_argument("--batch", type=int, default=16)
-    ap.add_argument("--points", type=int, default=40000)
-    ap.add_argument("--image", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=None, help="scenes per rank (default 16; c5: 32)")
+    ap.add_argument("--points", type=int, default=None, help="points per scene (default 40000; c5: 80000)")
+    ap.add_argument("--image", type=int, default=None, help="view side in pixels (default 512; c5: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dp-path", action="store_true", help="use the data-parallel step structure even on one GPU")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
@@ -53,7 +57,12 @@ def parse():
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
                     help="arithmetic of the dense layers: bf16 = the HIP kernel path (MFMA GEMMs, point-major detector); "
                          "f32 = the reference composition on torch ops (c2 only)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    big = args.workload == "c5"
+    args.batch = args.batch or (32 if big else 16)
+    args.points = args.points or (80000 if big else 40000)
+    args.image = args.image or (1024 if big else 512)
+    return args
 
 
 def synth_batch(B, N, cin, seed, device):
@@ -270,35 +279,128 @@ def cpu_info():
 
 
 VIT_GEMMS = (("qkv", 2304, 768), ("proj", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072))
+PROFILE_PMC = os.path.join(ROOT, "profiles", "r03_gemm_pmc.jsonl")       # tools/run_gemm_pmc.sh -> tools/pmc_summary.py --json
+PROFILE_STATS = os.path.join(ROOT, "profiles", "r03_c3_kernel_stats.csv")  # rocprofv3 --kernel-trace --stats of this bench
+# kernel instantiation each launch form runs as (for the in-step averages of the committed profile)
+GEMM_KERNELS = {"fwd": "gemm128_kernel<false, 1, 16>", "fwd_gelu": "gemm128_kernel<false, 2, 16>",
+                "dx": "gemm128_kernel<true, 0, 16>", "dx_dgelu": "gemm128_kernel<true, 3, 16>",
+                "dw": "gemm256_kernel<true, true, 0, true>"}
+
+
+def _event_median_ms(fn, reps=10, warm=3):
+    """median over `reps` single launches, HIP events on the stream the launch goes to (the current one)"""
+    for _ in range(warm):
+        fn()
+    evs = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    return sorted(a.elapsed_time(b_) for a, b_ in evs)[len(evs) // 2]
+
+
+def _profile_records():
+    """(per-launch PMC records by label, in-step kernel averages by name) from the committed profiles, {} when absent"""
+    pmc, stats = {}, {}
+    try:
+        for line in open(PROFILE_PMC):
+            r = json.loads(line)
+            pmc.setdefault(r["label"], []).append(r)
+    except OSError:
+        pass
+    try:
+        import csv
+        for r in csv.DictReader(open(PROFILE_STATS)):
+            stats[r["Name"]] = (float(r["AverageNs"]) / 1e3, int(r["Calls"]))
+    except OSError:
+        pass
+    return pmc, stats
 
 
 def gemm_roofline(args, dev):
-    """The dominant dense kernel of the step, bq::gemm256_kernel (csrc/gemm.hip): the four forward GEMMs of one ViT
-    block at this run's token count, HIP events around each launch on the stream it is launched on (the step itself
-    replays them from HIP graphs, where no event can be placed: these are the SAME kernels on the SAME shapes, launched
-    right after the timed region).  flops = 2 M N K per launch (algorithmic)."""
+    """The dominant dense kernels of the step: the launches ONE ViT block runs forward (qkv / proj / fc1 + GELU / fc2, with
+    the epilogues and the tile the step uses) and backward (their input gradients, fc2's with the GELU derivative), at this
+    run's token count -- HIP events around each launch on the stream it is launched on (the step itself replays them from
+    HIP graphs, where no event can be placed: these are the SAME kernels on the SAME shapes, launched right after the timed
+    region) -- and the grouped weight-gradient launch of all 12 blocks.  flops = 2 M N K per launch."""
     from bridgeqa_amd import _ext
     M = args.batch * ((args.image // 16) ** 2 + 1)
     g = torch.Generator().manual_seed(5)
-    out, tot_f, tot_t = [], 0.0, 0.0
+    rnd = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(dev).to(torch.bfloat16)
+    pmc, stats = _profile_records()
+    out, tot_f, tot_t, tot_alg, tot_fetch, tot_write = [], 0.0, 0.0, 0.0, 0.0, 0.0
+
+    def add(label, form, fn, fl, alg_bytes, N, K):
+        nonlocal tot_f, tot_t, tot_alg, tot_fetch, tot_write
+        ms = _event_median_ms(fn)
+        rec = {"launch": label, "M": M, "N": N, "K": K, "us": round(ms * 1e3, 1), "TFLOPs": round(fl / ms / 1e9, 1),
+               "frac": round(fl / ms / 1e9 / 2500.0, 4), "algorithmic_bytes": alg_bytes}
+        kn = "void bq::%s(bq::GemmArgs)" % GEMM_KERNELS[form]
+        if kn in stats:
+            rec["in_step_avg_us_all_shapes_of_this_kernel"] = round(stats[kn][0], 1)
+        p = [r for r in pmc.get(label, []) if r.get("fetch_bytes") is not None]
+        if p:
+            rec["pmc"] = {"us": sum(r["avg_us"] for r in p), "mfma_util": p[0].get("mfma_util"),
+                          "hbm_read_bytes": sum(r["fetch_bytes"] for r in p), "hbm_write_bytes": sum(r["write_bytes"] for r in p)}
+            tot_fetch += rec["pmc"]["hbm_read_bytes"]
+            tot_write += rec["pmc"]["hbm_write_bytes"]
+        out.append(rec)
+        tot_f += fl; tot_t += ms; tot_alg += alg_bytes
+
     for name, N, K in VIT_GEMMS:
-        x = torch.randn(M, K, generator=g).to(dev).to(torch.bfloat16)
-        w = (torch.randn(N, K, generator=g) * 0.05).to(dev).to(torch.bfloat16)
+        x, w, dy, pre = rnd(M, K), rnd(N, K, sc=0.05), rnd(M, N), rnd(M, K)
         b = torch.randn(N, generator=g).to(dev)
-        for _ in range(3):
-            _ext.gemm_fwd(x, w, b, tile=256)
-        evs = []
-        for _ in range(10):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); _ext.gemm_fwd(x, w, b, tile=256); e1.record()
-            evs.append((e0, e1))
-        torch.cuda.synchronize()
-        ms = sorted(a.elapsed_time(b_) for a, b_ in evs)[len(evs) // 2]
         fl = 2.0 * M * N * K
-        out.append({"gemm": name, "M": M, "N": N, "K": K, "us": round(ms * 1e3, 1), "TFLOPs": round(fl / ms / 1e9, 1)})
-        tot_f += fl
-        tot_t += ms
-    return out, tot_f, tot_t
+        if name == "fc1":
+            add("fwd_fc1_gelu", "fwd_gelu", lambda: _ext.gemm_fwd(x, w, b, gelu=True), fl, 2.0 * (M * K + N * K + 2 * M * N), N, K)
+        else:
+            add("fwd_" + name, "fwd", lambda: _ext.gemm_fwd(x, w, b), fl, 2.0 * (M * K + N * K + M * N), N, K)
+        if name == "fc2":
+            add("dx_fc2_dgelu", "dx_dgelu", lambda: _ext.gemm_dx(dy, w, pre_act=pre), fl, 2.0 * (M * N + N * K + 2 * M * K), N, K)
+        else:
+            add("dx_" + name, "dx", lambda: _ext.gemm_dx(dy, w), fl, 2.0 * (M * N + N * K + M * K), N, K)
+        del x, w, dy, pre
+    probs, fl, by = [], 0.0, 0.0
+    for blk in range(12):
+        for name, N, K in VIT_GEMMS:
+            probs.append(dict(P=rnd(M, K), Q=rnd(M, N), out=torch.empty(N, K, device=dev)))
+            fl += 2.0 * M * N * K
+            by += 2.0 * M * (N + K) + 4.0 * N * K
+    flags = _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32
+    add("dw_grouped48", "dw", lambda: _ext.gemm_grouped(probs, flags, _ext.EPI_NONE, 256), fl, by, 0, 0)
+    out[-1]["note"] = "all 48 weight gradients of the 12 blocks, one grouped call (36 + 12 problems: two launches)"
+    traffic = ({"hbm_read_bytes": tot_fetch, "hbm_write_bytes": tot_write, "algorithmic_bytes": tot_alg,
+                "ratio": round((tot_fetch + tot_write) / tot_alg, 3), "file": "profiles/r03_gemm_pmc.jsonl",
+                "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, one launch form per process; read = 2 x "
+                          "FETCH_SIZE x 1024 (gfx950 tallies a 128-B request as 64 B), write = WRITE_SIZE x 1024 "
+                          "(MI355X_MICROARCH.md, HBM); fabric-side counters: Infinity-Cache hits are included"}
+               if tot_fetch else None)
+    return out, tot_f, tot_t, traffic
+
+
+def attn_roofline(args, dev):
+    """The fused attention kernels (csrc/attn.hip) at the ViT shape of this run: forward and backward of one block,
+    flops = 4 B H L^2 64 forward, 2.5 x that backward (the minimal count; the kernels recompute S: 3.5 x executed)"""
+    from bridgeqa_amd import _ext
+    B, H, L = args.batch, 12, (args.image // 16) ** 2 + 1
+    g = torch.Generator().manual_seed(6)
+    qkv = torch.randn(B, L, 3, H, 64, generator=g).to(dev).to(torch.bfloat16)
+    go = torch.randn(B, L, H, 64, generator=g).to(dev).to(torch.bfloat16)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    tf = _event_median_ms(lambda: _ext.attn_fwd(q, k, v, 0.125))
+    o, lse = _ext.attn_fwd(q, k, v, 0.125)
+    dqkv = torch.empty_like(qkv)
+    tb = _event_median_ms(lambda: _ext.attn_bwd(q, k, v, o, lse, go, 0.125, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]))
+    fl = 4.0 * B * H * L * L * 64
+    return {"kernel": "bq::attn_fwd_kernel / attn_bwd_dq_kernel / attn_bwd_dkv_kernel (csrc/attn.hip), ViT block, B=%d H=12 "
+                      "L=%d D=64" % (B, L), "bound": "mfma", "peak": 2500.0, "unit": "TFLOP/s",
+            "fwd": {"us": round(tf * 1e3, 1), "achieved": round(fl / tf / 1e9, 1), "frac": round(fl / tf / 1e9 / 2500.0, 4)},
+            "bwd": {"us": round(tb * 1e3, 1), "achieved": round(2.5 * fl / tb / 1e9, 1),
+                    "frac": round(2.5 * fl / tb / 1e9 / 2500.0, 4), "executed_flops_factor": 3.5},
+            "achieved": round(3.5 * fl / (tf + tb) / 1e9, 1), "frac": round(3.5 * fl / (tf + tb) / 1e9 / 2500.0, 4),
+            "pmc_file": "profiles/r02_attn_pmc.txt (MFMA busy: fwd 25.5 %, dQ 34.4 %, dK/dV 32.4 % at this shape)",
+            "timed_on": "dedicated launches after the timed region, HIP events on the launch stream, median of 10"}
 
 
 def launch_ranks(args):
@@ -340,7 +442,7 @@ def main():
     if world > 1 or (args.dp_path and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", init_method="env://")
-    workload = "c3" if args.workload == "auto" else args.workload
+    workload = "c3" if args.workload in ("auto", "c5") else args.workload   # (c5 = the c3 path at the large sizes)
 
     from bridgeqa_amd import _ext, fusion_ops
     if workload == "c3" and args.dtype != "bf16":
@@ -541,15 +643,16 @@ def main():
         alg = 20.0 * args.points * (2048 - 1) * args.batch
         achieved = alg / (fps_ms * 1e-3) / 1e9
         out = {
-            "metric": ("train samples/s (40k-pt scene + 512^2 view, bs16)" if workload == "c3"
-                       else "train samples/s (40k-pt scene, DET stage only, bs16)"),
+            "metric": ("train samples/s (%dk-pt scene + %d^2 view, bs%d)" % (args.points // 1000, args.image, args.batch)
+                       if workload == "c3" else "train samples/s (40k-pt scene, DET stage only, bs16)"),
             "value": round(args.batch * world * args.steps / dt, 3),
             "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": WORKLOADS[workload], "global_batch": args.batch * world, "points": args.points,
+            "config": {"workload": WORKLOADS["c5" if args.workload == "c5" else workload], "global_batch": args.batch * world,
+                       "points": args.points,
                        "c_in": args.cin, "image": args.image if workload == "c3" else None,
                        "parallelism": "dp%d" % world, "hip_graph": graphed,
                        "schedule": "phased: 6 graphs on 2 streams" if phased else "single graph",
@@ -582,20 +685,23 @@ def main():
                                                **det})(*path_roofline(args, workload)),
         }
         if workload == "c3":
-            per, tot_f, tot_ms = gemm_roofline(args, dev)
-            out["roofline"] = {"kernel": "bq::gemm256_kernel (csrc/gemm.hip), forward form with bias epilogue: the four "
-                                         "GEMMs of one ViT block", "bound": "mfma",
+            per, tot_f, tot_ms, traffic = gemm_roofline(args, dev)
+            out["roofline"] = {"kernel": "bq::gemm128_kernel (csrc/gemm_mid.hip: forward / input-gradient forms, 256x128 tiles, "
+                                         "persistent, 2 workgroups per CU) + bq::gemm256_kernel (csrc/gemm.hip: weight gradients): "
+                                         "the 8 launches of one ViT block (forward + dX, with the epilogues the step uses) + "
+                                         "the grouped dW launch of all 12 blocks", "bound": "mfma",
                                "achieved": round(tot_f / tot_ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
                                "frac": round(tot_f / tot_ms / 1e9 / 2500.0, 4),
-                               "traffic": None,
-                               "traffic_from_profile": "profiles/r02_gemm_pmc.txt (FETCH_SIZE x2 + WRITE_SIZE per launch)",
-                               "algorithmic_flops_per_block": tot_f, "ms_per_block": round(tot_ms, 4), "per_gemm": per,
+                               "traffic": traffic,
+                               "algorithmic_flops": tot_f, "ms_total": round(tot_ms, 4), "per_gemm": per,
                                "timed_on": "dedicated launches after the timed region, HIP events on the launch stream, "
-                                           "median of 10 (inside the step the same kernels replay from HIP graphs; their "
-                                           "in-step averages are in profiles/r02_c3_kernel_stats.csv)"}
+                                           "median of 10 (inside the step the same kernels replay from HIP graphs; the "
+                                           "in-step averages come from profiles/r03_c3_kernel_stats.csv, the counters from "
+                                           "profiles/r03_gemm_pmc.jsonl)"}
+            out["roofline_attn"] = attn_roofline(args, dev)
         else:
             out["roofline"] = out["roofline_fps"]
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload != "c5":   # (c3 is the headline: its baseline is the one reported)
             out["cpu_baseline"] = cpu_baseline(args, workload)
         print(json.dumps(out))
     if dist.is_initialized():

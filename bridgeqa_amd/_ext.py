@@ -824,7 +824,10 @@ class _GemmDesc(ctypes.Structure):
 _lib.bq_gemm_bf16.argtypes = [ctypes.POINTER(_GemmDesc), _i, _i, _i, _i, _vp]
 _lib.bq_gemm_bf16.restype = ctypes.c_int
 _lib.bq_gemm_max_problems.restype = ctypes.c_int
-GEMM_TILE_ROWS = 1024  # problems with at least this many j rows (and i columns >= 256) run on the 256 x 256 kernel
+GEMM_TILE_ROWS = 1024  # problems with at least this many j rows (and i columns >= 256) run on the large-tile kernels
+# Large problems whose output is bf16 with a K-contiguous Q (forward, input gradient) take the 256 x 128 persistent kernel
+# (csrc/gemm_mid.hip: two workgroups per CU); BQ_GEMM_MID=0 sends them back to the 256 x 256 one (A/B measurements).
+GEMM_MID = os.environ.get("BQ_GEMM_MID", "1") != "0"
 
 
 def _mat(t, name):
@@ -835,9 +838,9 @@ def _mat(t, name):
     return t
 
 
-def pick_tile(Ni, Nj, q_xc):
+def pick_tile(Ni, Nj, q_xc, mid_ok=False):
     if Nj >= GEMM_TILE_ROWS and Ni >= 256:
-        return 256
+        return 128 if mid_ok else 256
     if q_xc or Nj > 512:  # (64-row tiles from 100 / 200 rows up: measured 0.3-0.4 ms SLOWER per c3 step)
         return 64
     return 32
@@ -885,7 +888,12 @@ def gemm_grouped(problems, flags, epilogue=EPI_NONE, tile=None):
         d.p_bytes, d.q_bytes, d.ksplit = int(pr.get("p_bytes", 0)), int(pr.get("q_bytes", 0)), int(pr.get("ksplit", 1))
         if "Kc" in pr:  # contraction longer than the K-contiguous operand's rows (its partner is zero-padded)
             d.Kc = int(pr["Kc"])
-        t_auto = max(t_auto, pick_tile(Ni, Nj, qxc))
+        mid_ok = (not qxc and not f32 and d.Kc >= 128 and colsum is None
+                  and epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_ADD))
+        all_mid_ok = mid_ok if k == 0 else (all_mid_ok and mid_ok)
+        t_auto = max(t_auto, pick_tile(Ni, Nj, qxc, True))
+    if t_auto == 128 and not (all_mid_ok and GEMM_MID):
+        t_auto = 256   # (one tile class per launch: every problem of the group must be able to take the 256 x 128 kernel)
     dev = problems[0]["out"].device
     with torch.cuda.device(dev):
         _check(_lib.bq_gemm_bf16(arr, n, int(flags), int(epilogue), int(tile or t_auto), _stream()), "gemm_bf16")

@@ -78,43 +78,46 @@ def test_c3_full_size_forward_backward_properties(dev):
     assert all(x == x and abs(x) < 1e6 for x in (a["loss"], b["loss"]))
 
 
-def test_c5_per_rank_one_step_and_peak_hbm(dev):
+def test_c5_per_rank_phased_step_and_peak_hbm(dev):
     """BASELINE config c5, one rank's share (B=32 x 80000 points + 1024x1024 views -> 4097 image tokens, text decoder):
-    one eager training step (forward + backward + fused AdamW) completes, losses and gradients are finite, and the peak
-    HBM of the step is recorded (gpurun_out/c5_peak_hbm.json; DESIGN.md quotes it).  No activation recompute is needed
-    on 288 GB: the reference's lever for this config (vit.py:103-105 checkpoint_wrapper) stays off."""
+    the PHASED training step (pipeline.PhasedTrainStep: one HIP graph per phase, forward + backward + fused AdamW) is
+    captured and replayed, losses and gradients are finite, and the peak HBM of the step is recorded
+    (gpurun_out/c5_peak_hbm.json; DESIGN.md quotes it).  No activation recompute is needed on 288 GB: the reference's lever
+    for this config (vit.py:103-105 checkpoint_wrapper) stays off.  `bench.py --workload c5` times the same step."""
     import bench
     from bridgeqa_amd import fusion_ops as ops
     from bridgeqa_amd.optim import FusedAdamW
+    from bridgeqa_amd.pipeline import PhasedTrainStep
     args = _Args(80000, 1024)
     prev = ops.set_compute_dtype(torch.bfloat16)
     try:
         torch.manual_seed(0)
         model = bench.build_model("c3", args.cin, args.image).to(dev)
         model.train()
-        opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=1e-5)
+        opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, grad_clip_value=1.0)
         batch = bench.make_batch(args, "c3", 32, 43, dev)
         torch.cuda.synchronize()
         torch.cuda.reset_peak_memory_stats(dev)
+        pipe = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, opt, use_graphs=True, next_batch=batch)
+        pipe.capture(warmup=1, keep_warmup_updates=True)
         t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
         losses = []
-        for step in range(2):
-            t0.record()
-            opt.zero_grad(set_to_none=True)
-            dd = model(dict(batch))
-            loss = bench.total_loss(dd)
-            loss.backward()
-            opt.step()
+        for step in range(3):
+            t0.record(pipe.s_main)
+            loss = pipe.step()
+            pipe.wait()
             t1.record()
             torch.cuda.synchronize()
             losses.append(loss.item())
+        dd = pipe._state["dd"]
         assert all(x == x and abs(x) < 1e6 for x in losses), losses
-        assert dd["fused_feat"].shape[0] == 32 and dd["sa1_inds"].shape == (32, 2048)
+        assert dd["sa1_inds"].shape == (32, 2048) and tuple(pipe._state["img"].shape[:2]) == (32, 4097)
         assert _finite_grads(model) > 400
         peak = torch.cuda.max_memory_allocated(dev)
-        rec = {"config": "c5 per rank: B=32 x 80000 pts x C_in=132 + 1024^2 view, bf16, eager fwd+bwd+FusedAdamW",
+        rec = {"config": "c5 per rank: B=32 x 80000 pts x C_in=132 + 1024^2 view, bf16, phased fwd+bwd+FusedAdamW replayed "
+                         "from HIP graphs (1 eager warm-up step + capture + 3 replays)",
                "peak_allocated_GB": round(peak / 2 ** 30, 2), "reserved_GB": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2),
-               "eager_step_ms": round(t0.elapsed_time(t1), 1), "losses": losses}
+               "replayed_step_ms": round(t0.elapsed_time(t1), 1), "losses": losses}
         os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
         with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "c5_peak_hbm.json"), "w") as f:
             json.dump(rec, f)

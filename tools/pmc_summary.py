@@ -1,6 +1,9 @@
 """Summarise rocprofv3 output directories (one per pass) into per-kernel averages.
 
-    python tools/pmc_summary.py <dir> [<dir> ...] [--match gemm]
+    python tools/pmc_summary.py <dir> [<dir> ...] [--match gemm] [--json FILE --label NAME]
+
+--json appends one record per (kernel, grid) group to FILE (a JSON-lines file): label, kernel, grid, launches, avg_us,
+mfma_util, valu_busy, fetch_bytes (2 x FETCH_SIZE), write_bytes -- what bench.py reads back for `roofline.traffic`.
 
 Reads every *_kernel_trace.csv (durations) and *_counter_collection.csv (PMC values) below the directories, groups
 dispatches by (kernel name [first 70 chars], grid size) and prints the mean duration and mean counter values.  Derived
@@ -22,10 +25,14 @@ def short(name):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    match = None
+    match = jfile = label = None
     if "--match" in sys.argv:
         match = sys.argv[sys.argv.index("--match") + 1]
         args = [a for a in args if a != match]
+    if "--json" in sys.argv:
+        jfile = sys.argv[sys.argv.index("--json") + 1]
+        label = sys.argv[sys.argv.index("--label") + 1] if "--label" in sys.argv else ""
+        args = [a for a in args if a not in (jfile, label)]
     dur = collections.defaultdict(list)
     ctr = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in args:
@@ -62,6 +69,20 @@ def main():
                 der.append("LDS conflict cycles %.1f %%" % (100 * c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]))
             if der:
                 print("   => " + "   ".join(der))
+        if jfile:
+            import json
+            rec = dict(label=label, kernel=key[0].strip(), grid=key[1], launches=len(dur[key]),
+                       avg_us=round(sum(dur[key]) / len(dur[key]), 2) if dur[key] else None)
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+                rec["mfma_util"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024), 4)
+            if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+                rec["valu_busy"] = round(4 * c["SQ_ACTIVE_INST_VALU"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024), 4)
+            if "FETCH_SIZE" in c:
+                rec["fetch_bytes"] = round(2 * c["FETCH_SIZE"] * 1024)
+            if "WRITE_SIZE" in c:
+                rec["write_bytes"] = round(c["WRITE_SIZE"] * 1024)
+            with open(jfile, "a") as f:
+                f.write(json.dumps(rec) + "\n")
 
 
 if __name__ == "__main__":

@@ -123,7 +123,7 @@ extern "C" __attribute__((visibility("default"))) int bq_adamw_multi(const void 
   if (n_chunks == 0) return BQ_OK;
   BQ_REQUIRE(table && chunks && step, BQ_EINVAL, "adamw: null pointer");
   const float clip = grad_clip_value > 0.f ? grad_clip_value : INFINITY;
-  static const bool nt = !getenv("BQ_ADAMW_NT") || atoi(getenv("BQ_ADAMW_NT")) != 0;  // default on: 1.95 -> 1.83 ms at 354 M parameters (tools/bench_adamw.py)
+  constexpr bool nt = true;  // default on: 1.95 -> 1.83 ms at 354 M parameters (tools/bench_adamw.py)
   if (nt)
     hipLaunchKernelGGL(adamw_kernel<true>, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream,
                        (const AdamWTensor *)table, (const int2 *)chunks, step, beta1, beta2, eps, clip);

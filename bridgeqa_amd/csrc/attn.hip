@@ -357,169 +357,9 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__res
   }
 }
 
-// ---- PLAIN forward, second generation (the ViT's attention: no mask, not causal, no dropout) -------------------------
-// Same tiling and MFMA mapping as attn_fwd_kernel; the softmax costs fewer vector instructions per score (the kernel is
-// bound by vector ISSUE, not by the matrix pipe: MI355X_MICROARCH.md 'vector-instruction ISSUE cost'):
-//   * Q is pre-multiplied by scale * log2(e) once per kernel (fp32 multiply, ONE bf16 rounding), so S is in log2 units;
-//   * the subtraction of the softmax reference rides on the matrix pipe: a FIFTH k-step of the S^T = K.Q^T chain with
-//     A = e_0 (1 in k-slot 0 of every key row) and B = -m_ref of the lane's query in k-slot 0 adds -m_ref to every score
-//     of the column, so the chain delivers S - m_ref and p = exp2(acc) needs no v_sub / v_fma (16 per block traded for
-//     one MFMA: 8 issue cycles instead of 64);
-//   * m_ref is a LAGGING reference, not the running max: it moves (and O^T and l are rescaled) only when a block's max
-//     exceeds it by more than AT_TAU = 8 in log2 units (p <= 2^8: harmless in the fp32 sums and in bf16, whose exponent
-//     range is fp32's).  It is always (the bf16 rounding of) the max of some earlier block, so running max - 8.5 <= m_ref
-//     <= running max + 0.5 at |scores| < 128: the result is the exact softmax for any inputs, only the reference point
-//     differs; being a bf16 value, -m_ref is exact in the B operand.
-// Per 32-key block and lane: 8 v_max3 + 16 v_exp + 16 v_add + 8 v_cvt_pk (+ the rare rescale) instead of
-// 9 + 17 + 16 + 8 + 16 v_fma.
-constexpr float AT_TAU = 8.0f;
-
-template <bool LASTP>
-__device__ __forceinline__ void fwd_tile_seeded(const unsigned char *s_k, const unsigned char *s_v, const bf16x8 (&qf)[4],
-                                                int kend, int kt, int r, int h, f32x16 &o0, f32x16 &o1,
-                                                const bf16x8 &a_one, bf16x8 &b_ref, float &mref, float &lsum) {
-#pragma unroll
-  for (int kb2 = 0; kb2 < 2; ++kb2) {
-    f32x16 acc = {0};
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_one, b_ref, acc, 0, 0, 0);  // -m_ref down every query column
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8 *>(s_k + swz(kb2 * 32 + r, 2 * s + h));
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], acc, 0, 0, 0);
-    }
-    if (LASTP) {  // compile time: only the peeled last tile has keys past the end
-      const int kbase = kt * AT_KB + kb2 * 32;
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        if (kbase + crow(i, h) >= kend) acc[i] = -INFINITY;
-    }
-    float mloc = acc[0];
-#pragma unroll
-    for (int i = 1; i < 16; ++i) mloc = fmaxf(mloc, acc[i]);
-    mloc = xhalf_max(mloc);
-    const bool fresh = kt == 0 && kb2 == 0;  // wave-uniform: the first block sets the reference
-    if (fresh || __ballot(mloc > AT_TAU)) {
-      const bool mine = fresh || mloc > AT_TAU;
-      const float mnew = mine ? (float)(__bf16)(mref + mloc) : mref;  // a bf16 value: exact as a B-operand element
-      const float delta = mnew - mref;
-      const float alpha = fresh ? 0.0f : __builtin_amdgcn_exp2f(-delta);
-      mref = mnew;
-      lsum *= alpha;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        o0[i] *= alpha;
-        o1[i] *= alpha;
-        acc[i] -= delta;
-      }
-      if (h == 0) b_ref[0] = (__bf16)(-mref);
-    }
-    float pv[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) pv[i] = __builtin_amdgcn_exp2f(acc[i]);
-    float psum = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) psum += pv[i];
-    lsum += psum;
-    bf16x8 pb0, pb1;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      pb0[i] = (__bf16)pv[i];
-      pb1[i] = (__bf16)pv[8 + i];
-    }
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const int key0 = 32 * kb2 + 16 * s2 + 4 * h;
-      const bf16x8 v0 = tfrag_tr(s_v, key0, 0, r), v1 = tfrag_tr(s_v, key0, 32, r);
-      const bf16x8 pb = s2 == 0 ? pb0 : pb1;
-      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb, o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, o1, 0, 0, 0);
-    }
-  }
-}
-
-template <int MINW>
-__global__ __launch_bounds__(256, MINW) void attn_fwd_plain_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
-                                                             const __bf16 *__restrict__ V, __bf16 *__restrict__ O,
-                                                             float *__restrict__ LSE, AttnDims dm) {
-  __shared__ __align__(16) unsigned char s_k[2][AT_KB * 128];
-  __shared__ __align__(16) unsigned char s_v[2][AT_KB * 128];
-  const float scale_log2e = dm.scale * 1.4426950408889634f;
-  const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
-  const int q0 = blockIdx.x * AT_QB + wid * AT_QW;
-  const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
-  const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
-  const __bf16 *Vb = V + b * dm.k_bs + hd * dm.k_hs;
-  bf16x8 qf[4];
-  {
-    const int qr = min(q0 + r, dm.Lq - 1);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bf16x8 x = *reinterpret_cast<const bf16x8 *>(Qb + (long)qr * dm.q_rs + 16 * s + 8 * h);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) qf[s][j] = (__bf16)((float)x[j] * scale_log2e);
-    }
-  }
-  f32x16 o0 = {0}, o1 = {0};
-  float mref = 0.0f, lsum = 0.0f;
-  bf16x8 a_one = {0}, b_ref = {0};  // e_0 rows / -m_ref in k-slot 0 (lane half 0 holds k-slots 0..7)
-  if (h == 0) a_one[0] = (__bf16)1.0f;
-  const int nkt = (dm.Lk + AT_KB - 1) / AT_KB;
-  uint4 ka, kb, va, vb;
-  const unsigned off_a = stage_off(dm.k_rs, t >> 3, t), off_b = stage_off(dm.k_rs, 32 + (t >> 3), t);
-  auto fetch = [&](int kt) {
-    const __bf16 *kbase = Kb + (long)kt * AT_KB * dm.k_rs, *vbase = Vb + (long)kt * AT_KB * dm.k_rs;
-    unsigned oa = off_a, ob = off_b;
-    if (kt == nkt - 1) {
-      const int lim = dm.Lk - 1 - kt * AT_KB;
-      oa = stage_off(dm.k_rs, min(t >> 3, lim), t);
-      ob = stage_off(dm.k_rs, min(32 + (t >> 3), lim), t);
-    }
-    ka = stage_ld(kbase, oa); kb = stage_ld(kbase, ob);
-    va = stage_ld(vbase, oa); vb = stage_ld(vbase, ob);
-  };
-  auto commit = [&](int buf) {
-    stage_store(s_k[buf], t, ka); stage_store(s_k[buf], t + 256, kb);
-    stage_store(s_v[buf], t, va); stage_store(s_v[buf], t + 256, vb);
-  };
-  auto advance = [&](int kt) {
-    if (kt + 1 < nkt) {
-      commit((kt + 1) & 1);
-      if (kt + 2 < nkt) fetch(kt + 2);
-    }
-    __syncthreads();
-  };
-  fetch(0);
-  commit(0);
-  if (nkt > 1) fetch(1);
-  __syncthreads();
-  const bool active = q0 < dm.Lq;
-  for (int kt = 0; kt < nkt - 1; ++kt) {
-    if (active) fwd_tile_seeded<false>(s_k[kt & 1], s_v[kt & 1], qf, dm.Lk, kt, r, h, o0, o1, a_one, b_ref, mref, lsum);
-    advance(kt);
-  }
-  if (active)
-    fwd_tile_seeded<true>(s_k[(nkt - 1) & 1], s_v[(nkt - 1) & 1], qf, dm.Lk, nkt - 1, r, h, o0, o1, a_one, b_ref, mref, lsum);
-  const float l = xhalf_sum(lsum);
-  const float inv = 1.0f / l;
-  const int q = q0 + r;
-  if (q < dm.Lq) {
-    __bf16 *Orow = O + b * dm.o_bs + hd * dm.o_hs + (long)q * dm.o_rs;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bf16x4 w0, w1;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        w0[j] = (__bf16)(o0[4 * g + j] * inv);
-        w1[j] = (__bf16)(o1[4 * g + j] * inv);
-      }
-      *reinterpret_cast<bf16x4 *>(Orow + 8 * g + 4 * h) = w0;
-      *reinterpret_cast<bf16x4 *>(Orow + 32 + 8 * g + 4 * h) = w1;
-    }
-    if (h == 0) LSE[(long)bh * dm.Lq + q] = mref + __builtin_amdgcn_logf(l);
-  }
-}
-
+// (Round 2's second-generation PLAIN forward -- Q pre-multiplied by scale * log2(e) in bf16, the softmax reference subtracted
+// on the matrix pipe by a fifth k-step, a lagging reference -- ran 10 % faster and doubled the output error / quadrupled
+// the gradient error through the LSE; it was opt-in, never the default, and was removed in round 3.)
 // Lq <= 32 (the text queries of the twin cross-attention: 20 tokens against 1045 image / 276 object keys): one
 // workgroup per (batch, head) would keep ONE wave busy for ceil(Lk / 64) serial tiles.  Here the four waves share the
 // 32 queries and take every fourth key tile each (own LDS images, own running max / sum / O^T), and the four partial
@@ -1173,33 +1013,21 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_fwd(
   AttnDims dm{B, H, Lq, Lk, 0, Lkp, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, o_bs, o_rs, o_hs, mask, scale,
               1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr, causal ? 1 : 0};
   dm.nkt1 = (Lk + AT_KB - 1) / AT_KB;  // single key/value segment
-  static const bool narrow_ok = !getenv("BQ_ATTN_NO_NARROW");
-  if (narrow_ok && Lq <= AT_QW && Lk > 2 * AT_KB && (o_rs % 8) == 0 && (o_hs % 8) == 0) {
+  if (Lq <= AT_QW && Lk > 2 * AT_KB && (o_rs % 8) == 0 && (o_hs % 8) == 0) {
     hipLaunchKernelGGL(attn_fwd_narrow_kernel, dim3(1, B * H), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Q,
                        (const __bf16 *)K, (const __bf16 *)V, (__bf16 *)O, LSE, dm);
     return check_launch("attn_fwd_narrow");
   }
   const dim3 grid((Lq + AT_QB - 1) / AT_QB, B * H);
-  static const int minw = getenv("BQ_ATTN_MINW") ? atoi(getenv("BQ_ATTN_MINW")) : 3;  // waves/SIMD (tools/attn_sweep.sh)
-  static const int plain_mode = getenv("BQ_ATTN_FWD_MODE") ? atoi(getenv("BQ_ATTN_FWD_MODE")) : 1;
-  const int mode = (!mask && !causal && dm.drop_thresh == 0) ? plain_mode : 0;
-#define BQ_FWD(W, M) hipLaunchKernelGGL((attn_fwd_kernel<W, M>), grid, dim3(256), 0, (hipStream_t)stream,           \
-                                        (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (__bf16 *)O, LSE, dm)
-#define BQ_FWDP(W) hipLaunchKernelGGL((attn_fwd_plain_kernel<W>), grid, dim3(256), 0, (hipStream_t)stream,            \
-                                      (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (__bf16 *)O, LSE, dm)
-  switch (mode * 10 + minw) {
-    case 32: BQ_FWDP(2); break;
-    case 33: BQ_FWDP(3); break;
-    case 34: BQ_FWDP(4); break;
-    case 2: BQ_FWD(2, 0); break;
-    case 12: BQ_FWD(2, 1); break;
-    case 13: BQ_FWD(3, 1); break;
-    case 22: BQ_FWD(2, 2); break;
-    case 23: BQ_FWD(3, 2); break;
-    default: BQ_FWD(3, 0);
-  }
-#undef BQ_FWD
-#undef BQ_FWDP
+  // 3 waves / SIMD, and for the ViT's case (no mask, not causal, no dropout) the PLAIN instantiation with the last tile
+  // peeled: tools/bench_attn.py sweeps of round 1 / 2 (2 waves: slower; EARLY score issue: no gain)
+  const bool plain = !mask && !causal && dm.drop_thresh == 0;
+  if (plain)
+    hipLaunchKernelGGL((attn_fwd_kernel<3, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Q, (const __bf16 *)K,
+                       (const __bf16 *)V, (__bf16 *)O, LSE, dm);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<3, 0>), grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Q, (const __bf16 *)K,
+                       (const __bf16 *)V, (__bf16 *)O, LSE, dm);
   return check_launch("attn_fwd");
 }
 
@@ -1223,43 +1051,31 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_bwd(
              1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr, causal ? 1 : 0};
   dm.nkt1 = (Lk + AT_KB - 1) / AT_KB;  // single key/value segment
   hipStream_t st = (hipStream_t)stream;
-  static const int dq_w = getenv("BQ_ATTN_DQ_MINW") ? atoi(getenv("BQ_ATTN_DQ_MINW")) : 2;
-  static const int dkv_w = getenv("BQ_ATTN_DKV_MINW") ? atoi(getenv("BQ_ATTN_DKV_MINW")) : 2;  // 2 waves/SIMD (tools/attn_sweep.sh)
-  static const bool plain_ok = !getenv("BQ_ATTN_NO_PLAIN");
-  const bool plain = plain_ok && !mask && !causal && dm.drop_thresh == 0;
+  constexpr int dq_w = 2, dkv_w = 2;   // waves / SIMD: measured (dK/dV at 2: 0.34 -> 0.25 ms, round 1)
+  const bool plain = !mask && !causal && dm.drop_thresh == 0;
 #define BQ_DQ(W, P) hipLaunchKernelGGL((attn_bwd_dq_kernel<W, P>), dim3((Lq + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, \
                                        st, (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)dO, \
                                        LSE, (const __bf16 *)O, DELTA, (__bf16 *)dQ, dm)
-  static const bool narrow_ok = !getenv("BQ_ATTN_NO_NARROW");
-  static const bool small_ok = !getenv("BQ_ATTN_NO_SMALL");
-  if (small_ok && !plain && Lq <= AT_QB && Lk <= AT_QB) {
+  if (!plain && Lq <= AT_QB && Lk <= AT_QB) {
     hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(1, B * H, 2), dim3(256), 0, st, (const __bf16 *)Q, (const __bf16 *)K,
                        (const __bf16 *)V, (const __bf16 *)dO, LSE, (const __bf16 *)O, DELTA, (__bf16 *)dQ, (__bf16 *)dK,
                        (__bf16 *)dV, dm);
     return check_launch("attn_bwd_small");
   }
-  if (narrow_ok && Lq <= AT_QW && Lk > 2 * AT_KB)
+  if (Lq <= AT_QW && Lk > 2 * AT_KB)
     hipLaunchKernelGGL(attn_bwd_dq_narrow_kernel, dim3(1, B * H), dim3(256), 0, st, (const __bf16 *)Q, (const __bf16 *)K,
                        (const __bf16 *)V, (const __bf16 *)dO, LSE, (const __bf16 *)O, DELTA, (__bf16 *)dQ, dm);
   else
-    switch (dq_w * 2 + (plain ? 1 : 0)) {
-      case 6: BQ_DQ(3, false); break;
-      case 7: BQ_DQ(3, true); break;
-      case 5: BQ_DQ(2, true); break;
-      default: BQ_DQ(2, false);
-    }
+  {
+    if (plain) BQ_DQ(dq_w, true); else BQ_DQ(dq_w, false);
+  }
 #undef BQ_DQ
   int rc = check_launch("attn_bwd_dq");
   if (rc) return rc;
 #define BQ_DKV(W, P) hipLaunchKernelGGL((attn_bwd_dkv_kernel<W, P>), dim3((Lk + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, \
                                         st, (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)dO,  \
                                         LSE, DELTA, (__bf16 *)dK, (__bf16 *)dV, dm)
-  switch (dkv_w * 2 + (plain ? 1 : 0)) {
-    case 2: BQ_DKV(1, false); break;
-    case 3: BQ_DKV(1, true); break;
-    case 5: BQ_DKV(2, true); break;
-    default: BQ_DKV(2, false);
-  }
+  if (plain) BQ_DKV(dkv_w, true); else BQ_DKV(dkv_w, false);
 #undef BQ_DKV
   return check_launch("attn_bwd_dkv");
 }

@@ -1016,7 +1016,7 @@ static int launch_variant(const GemmArgs &ga, int tile, hipStream_t st, bool lon
     if constexpr (!Q_XC) {
       if constexpr (KT2_OK) {
         // four K tiles per step (144 KB of LDS: one workgroup per CU) for launches of <= 512 tiles: c3 45.05 -> 44.57 ms
-        static const int k4_tiles = getenv("BQ_GEMM_K4") ? atoi(getenv("BQ_GEMM_K4")) : 12;
+        constexpr int k4_tiles = 12;
         bool k4 = long_k && k4_tiles > 0 && ga.total_tiles <= 512;
         for (int k = 0; k < ga.n; ++k) k4 = k4 && ga.p[k].Kc >= 64 * k4_tiles;
         if (k4) {
@@ -1039,7 +1039,7 @@ static int launch_variant(const GemmArgs &ga, int tile, hipStream_t st, bool lon
 static int launch_gemm(const GemmArgs &ga, int flags, int epi, int tile, hipStream_t st) {
   const bool pxc = flags & BQ_GEMM_P_XC, qxc = flags & BQ_GEMM_Q_XC, f32 = flags & BQ_GEMM_OUT_F32;
   // measured on the c3 step (A/B in one call): never 46.2 ms, from 24 K tiles 45.5-45.9, from 12 K tiles 45.3-45.6
-  static const int long_k_tiles = getenv("BQ_GEMM_LONGK") ? atoi(getenv("BQ_GEMM_LONGK")) : 12;  // 0 = never
+  constexpr int long_k_tiles = 12;
   bool long_k = long_k_tiles > 0 && tile != 256 && ga.total_tiles <= 2048;
   for (int k = 0; k < ga.n; ++k) long_k = long_k && ga.p[k].Kc >= 64 * long_k_tiles;
   if (tile == 128) {  // csrc/gemm_mid.hip: bf16 out, K-contiguous Q, no column sums

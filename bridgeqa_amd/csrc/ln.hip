@@ -523,7 +523,7 @@ static int ln_fwd_launch(const void *x, const void *residual, const float *gamma
   BQ_REQUIRE(p_path == 0.0f || rows_per_sample > 0, BQ_EINVAL, "drop_add_ln: rows_per_sample");
   LnArgs a{M, H, eps, 1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr,
            (unsigned)((double)p_path * 4294967296.0), 1.0f / (1.0f - p_path), rows_per_sample, groups, gamma2, beta2};
-  static const int fwd_cap = getenv("BQ_LN_FWD_BLOCKS") ? atoi(getenv("BQ_LN_FWD_BLOCKS")) : 1024;  // rows are strided over the grid (tools/ln_sweep.sh)
+  constexpr int fwd_cap = 1024;  // rows are strided over the grid (tools/ln_sweep.sh)
   const int Mg = M / groups;
   const dim3 grid(((Mg + 3) / 4) < fwd_cap ? (Mg + 3) / 4 : fwd_cap, groups);
   hipStream_t st = (hipStream_t)stream;
@@ -568,7 +568,7 @@ static int ln_bwd_launch(const void *x, const void *residual, const float *gamma
            (unsigned)((double)p_path * 4294967296.0), 1.0f / (1.0f - p_path), rows_per_sample, groups, gamma2, nullptr};
   // (with the cross-row prefetch: 256 / 384 / 512 / 640 / 1024 / 2048 workgroups -> 33.1 / 32.2 / 35.2 / 40.6 / 41.6 / 60.6 us
   // at the ViT shape, tools/bench_ln.py: every workgroup ends with 2 H float atomics on the same 2 H addresses)
-  static const int bwd_cap = getenv("BQ_LN_BWD_BLOCKS") ? atoi(getenv("BQ_LN_BWD_BLOCKS")) : 384;
+  constexpr int bwd_cap = 384;
   int blocks = (M / groups + 3) / 4;
   if (blocks > bwd_cap) blocks = bwd_cap;
   hipStream_t st = (hipStream_t)stream;

@@ -17,412 +17,10 @@ import os
 import torch
 import torch.nn.functional as F
 
-_COMPUTE_DTYPE = torch.float32
-
-# ---- stream-level concurrency --------------------------------------------------------------------
-# Large parts of the step are chains of short, latency-bound kernels that use a fraction of the 256 CUs
-# (furthest point sampling runs on B workgroups; the text streams work on 320 tokens).  Independent chains are
-# therefore issued on separate HIP streams -- detector branch || image encoder, 2D text stream || 3D text stream --
-# and joined with events; under HIP-graph capture the forks become parallel branches of the graph.
-_OVERLAP = [True]
-SHAREDMLP_BF16 = [False]
-# Detector fast path (bf16 compute dtype only): features are kept POINT-MAJOR (B,N,C) so neighbourhood grouping is
-# a copy of contiguous rows, the grouped tensor is written once as bf16 NHWC and the SharedMLP convolutions run on
-# it without layout transposes.  Values at the module boundary keep the reference layout (B,C,N) as strided views.
-POINT_MAJOR = [True]
-_SIDE_STREAMS = {}
-
-
-def set_overlap(flag):
-    prev, _OVERLAP[0] = _OVERLAP[0], bool(flag)
-    return prev
-
-
-def overlap_enabled(t):
-    return _OVERLAP[0] and t.is_cuda
-
-
-def side_stream(name, device):
-    key = (name, device.index if device.index is not None else torch.cuda.current_device())
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _SIDE_STREAMS[key]
-
-
-class fork(object):
-    """with fork("name", tensor) as s: ... runs the body on a side stream that first waits for the current one.
-    Call .join(*tensors) afterwards: the current stream waits for the side stream and the tensors produced on it
-    are marked as used by the current stream (allocator safety)."""
-
-    def __init__(self, name, like):
-        self.main = torch.cuda.current_stream(like.device)
-        self.side = side_stream(name, like.device)
-        self.ctx = torch.cuda.stream(self.side)
-
-    def __enter__(self):
-        self.side.wait_stream(self.main)
-        self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *a):
-        return self.ctx.__exit__(*a)
-
-    def uses(self, *tensors):
-        """tensors made on the main stream that the side stream reads"""
-        for t in tensors:
-            if t is not None:
-                t.record_stream(self.side)
-
-    def join(self, *tensors):
-        self.main.wait_stream(self.side)
-        for t in tensors:
-            if t is not None:
-                t.record_stream(self.main)
-
-
-_OPT_HOOK = [None]
-
-
-def set_compute_dtype(dtype):
-    """bf16: GEMM operands are bf16 copies ("shadows") of the fp32 master parameters.  A global optimizer post-step
-    hook keeps them current (refresh_shadows), whatever optimizer the caller uses."""
-    global _COMPUTE_DTYPE
-    prev, _COMPUTE_DTYPE = _COMPUTE_DTYPE, dtype
-    if dtype != torch.float32 and _OPT_HOOK[0] is None:
-        from torch.optim.optimizer import register_optimizer_step_post_hook
-        # (optim.FusedAdamW writes most shadows in its own kernel and lists them in `shadow_ids`: they are never re-cast
-        # here -- without this a SUBSET step re-cast the other subsets' 399 M weights, 2.3 ms)
-        _OPT_HOOK[0] = register_optimizer_step_post_hook(
-            lambda opt, args, kwargs: refresh_shadows(skip=getattr(opt, "shadow_ids", None)))
-    return prev
-
-
-def compute_dtype():
-    return _COMPUTE_DTYPE
-
-
-def _c(t):
-    """Cast to the compute dtype (inside autograd: gradients reach an fp32 parameter through the cast).  No caching:
-    version counters cannot be trusted to see an optimizer update (the fused multi-tensor optimizers do not bump
-    them -- measured on torch 2.10), and the parameters on hot paths go through _shadow() / refresh_shadows()."""
-    if t.dtype == _COMPUTE_DTYPE:
-        return t
-    return t.to(_COMPUTE_DTYPE)
-
-
-_SHADOW = {}
-
-
-def _shadow(t):
-    """bf16 copy of an fp32 parameter made OUTSIDE autograd, once per optimizer step (keyed by the in-place
-    version counter).  _LinearFn routes the gradient to the fp32 parameter itself, in fp32."""
-    if t.dtype == _COMPUTE_DTYPE:
-        return t.detach()
-    hit = _SHADOW.get(id(t))
-    if hit is not None and hit[0]() is t and hit[1] == t._version and hit[2].dtype == _COMPUTE_DTYPE:
-        return hit[2]
-    import weakref
-    with torch.no_grad():
-        c = t.detach().to(_COMPUTE_DTYPE)
-    _SHADOW[id(t)] = (weakref.ref(t), t._version, c)
-    return c
-
-
-def shadow_of(param):
-    """the registered bf16 shadow tensor of a parameter that an optimizer kernel may write element for element (None if
-    it has none, is not of the current compute dtype, or is a strided view -- those are refreshed by refresh_shadows)"""
-    ent = _SHADOW.get(id(param))
-    if (ent is None or ent[0]() is not param or ent[2].dtype != _COMPUTE_DTYPE or ent[2].device != param.device
-            or not ent[2].is_contiguous()):
-        return None
-    return ent[2]
-
-
-_PADDED = {}
-
-
-def padded_conv_shadow(weight):
-    """bf16 GEMM operand of a 1x1 convolution weight (N, K, 1, 1): (N, Kc) with Kc = K rounded up to 64, ZERO beyond K
-    (csrc/gemm.hip pwconv64_kernel contracts whole 64-wide K tiles; the padding multiplies whatever follows the K
-    channels of a point row).  The registered shadow of the parameter is the (N, K, 1, 1) view of that buffer, so the
-    optimizer's shadow refresh keeps it current."""
-    import weakref
-    N, K = weight.shape[0], weight.shape[1]
-    hit = _PADDED.get(id(weight))
-    if hit is not None and hit[0]() is weight and hit[1].device == weight.device:
-        ent = _SHADOW.get(id(weight))
-        if ent is not None and ent[2].untyped_storage().data_ptr() == hit[1].untyped_storage().data_ptr():
-            if ent[1] != weight._version:  # an in-place update nobody refreshed (load_state_dict, plain optimizers)
-                with torch.no_grad():
-                    ent[2].copy_(weight.detach())
-                _SHADOW[id(weight)] = (ent[0], weight._version, ent[2])
-            return hit[1]
-    Kc = (K + 63) // 64 * 64
-    with torch.no_grad():
-        buf = torch.zeros(N, Kc, dtype=torch.bfloat16, device=weight.device)
-        view = buf[:, :K]
-        for _ in range(weight.dim() - 2):  # (N, K, 1, 1) for Conv2d, (N, K, 1) for Conv1d: a view of the padded rows
-            view = view.unsqueeze(-1)
-        view.copy_(weight.detach())
-    _SHADOW[id(weight)] = (weakref.ref(weight), weight._version, view)
-    _PADDED[id(weight)] = (weakref.ref(weight), buf)
-    return buf
-
-
-_FRESH = set()
-
-
-def shadows_written(params):
-    """An optimizer that writes the shadows itself (optim.FusedAdamW) reports them here; the post-step hook's
-    refresh_shadows() then skips them."""
-    for p in params:
-        ent = _SHADOW.get(id(p))
-        if ent is not None:
-            _SHADOW[id(p)] = (ent[0], p._version, ent[2])
-            _FRESH.add(id(p))
-
-
-def refresh_shadows(only_with_grad=True, skip=None):
-    """Bring every registered bf16 shadow (and, through them, the concatenated QKV / KV operands, whose row blocks ARE
-    the per-weight shadows) up to date with ONE multi-tensor cast.  Runs as a global optimizer post-step hook
-    (set_compute_dtype); call it yourself after any other in-place parameter update.  It does NOT consult version
-    counters: torch's fused multi-tensor optimizers update parameters without bumping them (the lazy check in
-    _shadow() only catches ordinary in-place ops and load_state_dict).  only_with_grad: skip parameters that have no
-    gradient, i.e. that the optimizer did not touch.  skip: ids of parameters whose shadows the stepping optimizer writes
-    itself."""
-    dst, src = [], []
-    for key, (ref, ver, c) in list(_SHADOW.items()):
-        t = ref()
-        if t is None:
-            del _SHADOW[key]
-            continue
-        if skip is not None and key in skip and ver == t._version:
-            continue
-        if c.dtype != _COMPUTE_DTYPE or c.device != t.device:
-            continue
-        if key in _FRESH and ver == t._version:
-            continue  # written by the optimizer kernel itself
-        if only_with_grad and t.grad is None and ver == t._version:
-            continue
-        dst.append(c)
-        src.append(t.detach())
-        _SHADOW[key] = (ref, t._version, c)
-    _FRESH.clear()
-    if dst:
-        with torch.no_grad():
-            torch._foreach_copy_(dst, src)
-    return len(dst)
-
-
-# ---- native GEMMs (csrc/gemm.hip through _ext.gemm_*) ------------------------------------------------------------
-# Every nn.Linear of the fusion half on the bf16 CUDA path: forward (+bias, +GELU), input gradient (+GELU derivative,
-# +bias gradient of the layer before), weight gradient (fp32).  BQ_TORCH_GEMM=1 is a MEASUREMENT knob only: it routes
-# the same call sites to torch (hipBLASLt) so that bench.py can A/B the kernels inside the whole step.
-_NATIVE_GEMM = [__import__("os").environ.get("BQ_TORCH_GEMM", "0") != "1"]
-
-
-def _rows(t):
-    """(M, K) bf16 view/copy the GEMM kernels accept: contiguous last dim, 16-B aligned rows"""
-    t2 = t.reshape(-1, t.shape[-1])
-    if t2.dtype != torch.bfloat16:
-        t2 = t2.to(torch.bfloat16)
-    if t2.stride(1) != 1 or t2.stride(0) % 8 or t2.data_ptr() % 16:
-        t2 = t2.contiguous()
-    return t2
-
-
-def _native_ok(t, N, K):
-    """forward y (M, N) = x (M, K) w^T: the contraction K is K-contiguous in both operands => K % 64"""
-    return _NATIVE_GEMM[0] and t.is_cuda and _COMPUTE_DTYPE == torch.bfloat16 and K % 64 == 0 and N % 8 == 0
-
-
-def _native_dx_ok(t, N, K):
-    """input gradient dx (M, K) = dy (M, N) w: the contraction is N (K-contiguous in dy) => N % 64"""
-    return _NATIVE_GEMM[0] and t.is_cuda and _COMPUTE_DTYPE == torch.bfloat16 and N % 64 == 0 and K % 8 == 0
-
-
-def _f32_bias(bias):
-    """the fp32 master bias itself when possible (no operand copy needed: the kernel adds fp32), else its shadow"""
-    if bias is None:
-        return None
-    if bias.dtype == torch.float32 and bias.is_contiguous():
-        return bias.detach()
-    return _shadow(bias)
-
-
-def _mm_f32(a, b):
-    """a @ b for bf16 operands with an fp32 result (torch fallback of the weight gradient)"""
-    return torch.mm(a.float(), b.float()) if not a.is_cuda else torch.mm(a, b, out_dtype=torch.float32)
-
-
-def _dw_db(g2, x2, need_dw, need_db):
-    """weight / bias gradient of one linear, now: dW = g2^T x2 (fp32), db = column sums of g2 (fp32)"""
-    dw = db = None
-    native = g2.is_cuda and g2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and g2.shape[1] % 8 == 0 \
-        and x2.shape[1] % 8 == 0 and _NATIVE_GEMM[0]
-    if need_dw:
-        if native:
-            from . import _ext
-            dw = _ext.gemm_dw(_rows(g2), _rows(x2), tile=256 if g2.shape[0] >= _BIG_ROWS else 64)
-        else:
-            dw = _mm_f32(g2.t(), x2)
-    if need_db:
-        if native:
-            from . import _ext
-            db = _ext.colsum_grouped([_rows(g2)])[0]
-        else:
-            db = g2.sum(0, dtype=torch.float32)
-    return dw, db
-
-
-# ---- deferred, grouped weight gradients ---------------------------------------------------------------------------
-# dW / db are not on the critical path of a backward pass.  Inside a begin/flush scope the backward of every bf16
-# linear computes ONLY dX and parks (dY, X, parameters); flush_deferred_wgrad() then produces ALL weight gradients
-# of the scope with ONE grouped GEMM launch per tile class (12 ViT blocks x 4 linears = 48 problems, 1296 tiles of
-# 256 x 256 with the full 16400-row contraction each -- instead of 48 launches of 27-36 tiles) and ALL bias gradients
-# with one grouped column-sum launch.  MI355X has the HBM for it: the parked dY of config c3 are 2.7 GB.
-_DEFER = [None]
-_BIG_ROWS = 1024  # contractions at least this long run on the 256 x 256 kernel (measured: sending the text side's 160-640-row
-                  # contractions there too costs +1.5 ms per c3 step -- its pipeline fill and 256 KB fp32 tile epilogue dominate)
-
-
-def begin_deferred_wgrad():
-    _DEFER[0] = []
-
-
-def _accumulate_grad(p, g):
-    if p is None or not p.requires_grad:
-        return
-    if p.grad is None:
-        p.grad = g
-    else:
-        p.grad.add_(g)
-
-
-def take_deferred_wgrad():
-    """end the scope WITHOUT computing: returns the parked (dY, X, weights, biases) records for
-    flush_deferred_items() -- pipeline.PhasedTrainStep produces the fusion phase's weight gradients on another stream,
-    off the critical path between the fusion backward and the image / detector backward"""
-    items, _DEFER[0] = _DEFER[0], None
-    return items or []
-
-
-def flush_deferred_wgrad():
-    """compute the parked weight / bias gradients (current stream) and store them in the parameters' .grad"""
-    flush_deferred_items(take_deferred_wgrad())
-
-
-_PLAN_CACHE = {}
-_PLAN_WGRAD = [os.environ.get("BQ_WGRAD_PLAN", "1") != "0"]
-_QSUM = [os.environ.get("BQ_WGRAD_QSUM", "1") != "0"]
-_QSUM64 = [os.environ.get("BQ_WGRAD_QSUM64", "1") != "0"]
-
-
-def plan_big_launches(tiles, cus, max_problems=36, moved_cost=0.011):
-    """How to issue the 256 x 256-tile weight-gradient problems of one flush.  Every tile of such a launch runs the full
-    contraction (all rows of the batch), so a launch costs ceil(tiles / cus) rounds of equal length -- 1296 tiles on 256 CUs
-    are 5.06 rounds, i.e. SIX, for sixteen tiles.  Returns (groups, moved): `groups` = lists of problem indices, one grouped
-    launch each (<= max_problems problems, the kernel-argument limit), `moved` = indices of small problems sent to the
-    64 x 64-tile kernel instead, chosen so that rounds + moved_cost * (tiles moved) is smallest.  The problems come in a
-    handful of distinct sizes, so the search walks the counts per size of the second launch (a few thousand cases, cached)."""
-    key = (tuple(tiles), cus, max_problems)
-    hit = _PLAN_CACHE.get(key)
-    if hit is not None:
-        return hit
-    n = len(tiles)
-    rounds = lambda t: -(-t // cus) if t > 0 else 0
-    order = sorted(range(n), key=lambda k: tiles[k])
-    default = [list(range(n))[i:i + max_problems] for i in range(0, n, max_problems)]
-    best = (sum(rounds(sum(tiles[k] for k in g)) for g in default), default, [])
-    if n <= 2 * max_problems:
-        for m in range(0, min(6, n)):
-            moved = order[:m]
-            rest = order[m:]
-            cost_moved = moved_cost * sum(tiles[k] for k in moved)
-            by_size = {}
-            for k in rest:
-                by_size.setdefault(tiles[k], []).append(k)
-            sizes = sorted(by_size)
-            if len(sizes) > 5:
-                break
-            total, cnt = sum(tiles[k] for k in rest), len(rest)
-            combos = [[]]
-            for sz in sizes:
-                combos = [c + [x] for c in combos for x in range(len(by_size[sz]) + 1)]
-                if len(combos) > 50000:
-                    combos = None
-                    break
-            if combos is None:
-                break
-            for c in combos:
-                nb = sum(c)
-                if nb > max_problems or cnt - nb > max_problems:
-                    continue
-                tb = sum(x * sz for x, sz in zip(c, sizes))
-                cost = rounds(tb) + rounds(total - tb) + cost_moved
-                if cost < best[0] - 1e-9:
-                    gb = [k for x, sz in zip(c, sizes) for k in by_size[sz][:x]]
-                    ga = [k for x, sz in zip(c, sizes) for k in by_size[sz][x:]]
-                    best = (cost, [g for g in (ga, gb) if g], list(moved))
-    plan = (best[1], best[2])
-    _PLAN_CACHE[key] = plan
-    return plan
-
-
-def flush_deferred_items(items):
-    if not items:
-        return
-    from . import _ext
-    flags = _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32
-    dws = [None] * len(items)
-    big = [k for k, it in enumerate(items) if it[0].shape[0] >= _BIG_ROWS]
-    small = [k for k, it in enumerate(items) if it[0].shape[0] < _BIG_ROWS]
-    if _PLAN_WGRAD[0]:
-        # longest contractions first: a launch's workgroups start in tile order, so the long tiles (16 720-row image
-        # tokens) run from the beginning and the short ones (4 416-row object tokens) fill in behind them (A/B x4: 40.88 vs
-        # 40.91 ms -- inside the noise; kept because it cannot hurt)
-        big.sort(key=lambda k: -items[k][0].shape[0])
-    groups = [big] if big else []
-    if big and _PLAN_WGRAD[0]:
-        tiles = [-(-items[k][0].shape[1] // 256) * -(-items[k][1].shape[1] // 256) for k in big]
-        cus = torch.cuda.get_device_properties(items[big[0]][0].device).multi_processor_count
-        plan_groups, moved = plan_big_launches(tiles, cus)
-        groups = [[big[j] for j in g] for g in plan_groups]
-        small = small + [big[j] for j in moved]
-    dbs = {}
-    for tile, idx_groups in ((256, groups), (64, [small] if small else [])):
-        for idx in idx_groups:
-            probs = []
-            for k in idx:
-                g2, x2 = items[k][0], items[k][1]
-                dws[k] = torch.empty(g2.shape[1], x2.shape[1], dtype=torch.float32, device=g2.device)
-                pr = dict(P=x2, Q=g2, out=dws[k])
-                if items[k][3] is not None and _QSUM[0] and (tile == 256 or _QSUM64[0]):
-                    # the bias gradient (column sums of dY) from the same launch: four more MFMAs per K tile in a third
-                    # of the workgroups instead of a second pass over dY (csrc/gemm.hip, QSUM)
-                    dbs[k] = torch.empty(g2.shape[1], dtype=torch.float32, device=g2.device)
-                    pr["colsum"] = dbs[k]
-                probs.append(pr)
-            _ext.gemm_grouped(probs, flags, _ext.EPI_NONE, tile)
-    with_b = [k for k, it in enumerate(items) if it[3] is not None and k not in dbs]
-    if with_b:
-        dbs.update(zip(with_b, _ext.colsum_grouped([items[k][0] for k in with_b])))
-    for k, (g2, x2, ws, bs) in enumerate(items):
-        n = g2.shape[1] // len(ws)
-        for j, w in enumerate(ws):
-            _accumulate_grad(w, dws[k][j * n:(j + 1) * n] if len(ws) > 1 else dws[k].view(w.shape))
-            if bs is not None:
-                _accumulate_grad(bs[j], dbs[k][j * n:(j + 1) * n] if len(ws) > 1 else dbs[k])
-
-
-def _defer_ok(g2, x2):
-    return (_DEFER[0] is not None and _NATIVE_GEMM[0] and g2.is_cuda and g2.dtype == torch.bfloat16
-            and x2.dtype == torch.bfloat16 and g2.shape[1] % 8 == 0 and x2.shape[1] % 8 == 0)
-
-
-def _park(g2, x2, ws, bs):
-    _DEFER[0].append((_rows(g2), _rows(x2), ws, bs))
-
+# the module is split in three (round 3): state + operand shadows, deferred weight gradients, and -- here -- the autograd
+# nodes and the functional surface; the first two are re-exported so that `fusion_ops.X` keeps meaning what it meant
+from .fusion_state import *  # noqa: F401,F403
+from .fusion_wgrad import *  # noqa: F401,F403
 
 # ---- gradient taps ------------------------------------------------------------------------------------------------
 # A post-LN transformer sub-block reads its input twice: y = LN(x + f(x)).  Autograd therefore sums two gradients for x
@@ -1169,7 +767,7 @@ class _TwinDropAddLN(torch.autograd.Function):
         return dx, dres, dgb[0, 0], dgb[0, 1], dgb[1, 0], dgb[1, 1], None, None
 
 
-_TWIN_MIX_KERNEL = [os.environ.get("BQ_TWIN_MIX_KERNEL", "1") != "0"]
+_TWIN_MIX_KERNEL = [True]
 
 
 class _TwinMixFn(torch.autograd.Function):
@@ -1206,7 +804,7 @@ class _TwinSplitFn(torch.autograd.Function):
         return torch.cat((ga, gb), dim=0)
 
 
-_ATTN_PAIR = [os.environ.get("BQ_ATTN_PAIR", "1") != "0"]
+_ATTN_PAIR = [True]
 
 
 class _TwinCrossAttention(torch.autograd.Function):

@@ -1,0 +1,210 @@
+"""State shared by the dense operators of the fusion path (bridgeqa_amd/fusion_ops.py is the public surface and re-exports
+everything here): the compute dtype, the side streams / fork helper of the stream-level concurrency, and the bf16
+operand copies ("shadows") of the fp32 parameters with their refresh protocol (optimizer hook, FusedAdamW writes them
+in its own pass).  No autograd node lives here."""
+import math
+
+import os
+
+import torch
+import torch.nn.functional as F
+
+_COMPUTE_DTYPE = torch.float32
+
+# ---- stream-level concurrency --------------------------------------------------------------------
+# Large parts of the step are chains of short, latency-bound kernels that use a fraction of the 256 CUs
+# (furthest point sampling runs on B workgroups; the text streams work on 320 tokens).  Independent chains are
+# therefore issued on separate HIP streams -- detector branch || image encoder, 2D text stream || 3D text stream --
+# and joined with events; under HIP-graph capture the forks become parallel branches of the graph.
+_OVERLAP = [True]
+SHAREDMLP_BF16 = [False]
+# Detector fast path (bf16 compute dtype only): features are kept POINT-MAJOR (B,N,C) so neighbourhood grouping is
+# a copy of contiguous rows, the grouped tensor is written once as bf16 NHWC and the SharedMLP convolutions run on
+# it without layout transposes.  Values at the module boundary keep the reference layout (B,C,N) as strided views.
+POINT_MAJOR = [True]
+_SIDE_STREAMS = {}
+
+
+def set_overlap(flag):
+    prev, _OVERLAP[0] = _OVERLAP[0], bool(flag)
+    return prev
+
+
+def overlap_enabled(t):
+    return _OVERLAP[0] and t.is_cuda
+
+
+def side_stream(name, device):
+    key = (name, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+class fork(object):
+    """with fork("name", tensor) as s: ... runs the body on a side stream that first waits for the current one.
+    Call .join(*tensors) afterwards: the current stream waits for the side stream and the tensors produced on it
+    are marked as used by the current stream (allocator safety)."""
+
+    def __init__(self, name, like):
+        self.main = torch.cuda.current_stream(like.device)
+        self.side = side_stream(name, like.device)
+        self.ctx = torch.cuda.stream(self.side)
+
+    def __enter__(self):
+        self.side.wait_stream(self.main)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        return self.ctx.__exit__(*a)
+
+    def uses(self, *tensors):
+        """tensors made on the main stream that the side stream reads"""
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.side)
+
+    def join(self, *tensors):
+        self.main.wait_stream(self.side)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.main)
+
+
+_OPT_HOOK = [None]
+
+
+def set_compute_dtype(dtype):
+    """bf16: GEMM operands are bf16 copies ("shadows") of the fp32 master parameters.  A global optimizer post-step
+    hook keeps them current (refresh_shadows), whatever optimizer the caller uses."""
+    global _COMPUTE_DTYPE
+    prev, _COMPUTE_DTYPE = _COMPUTE_DTYPE, dtype
+    if dtype != torch.float32 and _OPT_HOOK[0] is None:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+        # (optim.FusedAdamW writes most shadows in its own kernel and lists them in `shadow_ids`: they are never re-cast
+        # here -- without this a SUBSET step re-cast the other subsets' 399 M weights, 2.3 ms)
+        _OPT_HOOK[0] = register_optimizer_step_post_hook(
+            lambda opt, args, kwargs: refresh_shadows(skip=getattr(opt, "shadow_ids", None)))
+    return prev
+
+
+def compute_dtype():
+    return _COMPUTE_DTYPE
+
+
+def _c(t):
+    """Cast to the compute dtype (inside autograd: gradients reach an fp32 parameter through the cast).  No caching:
+    version counters cannot be trusted to see an optimizer update (the fused multi-tensor optimizers do not bump
+    them -- measured on torch 2.10), and the parameters on hot paths go through _shadow() / refresh_shadows()."""
+    if t.dtype == _COMPUTE_DTYPE:
+        return t
+    return t.to(_COMPUTE_DTYPE)
+
+
+_SHADOW = {}
+
+
+def _shadow(t):
+    """bf16 copy of an fp32 parameter made OUTSIDE autograd, once per optimizer step (keyed by the in-place
+    version counter).  _LinearFn routes the gradient to the fp32 parameter itself, in fp32."""
+    if t.dtype == _COMPUTE_DTYPE:
+        return t.detach()
+    hit = _SHADOW.get(id(t))
+    if hit is not None and hit[0]() is t and hit[1] == t._version and hit[2].dtype == _COMPUTE_DTYPE:
+        return hit[2]
+    import weakref
+    with torch.no_grad():
+        c = t.detach().to(_COMPUTE_DTYPE)
+    _SHADOW[id(t)] = (weakref.ref(t), t._version, c)
+    return c
+
+
+def shadow_of(param):
+    """the registered bf16 shadow tensor of a parameter that an optimizer kernel may write element for element (None if
+    it has none, is not of the current compute dtype, or is a strided view -- those are refreshed by refresh_shadows)"""
+    ent = _SHADOW.get(id(param))
+    if (ent is None or ent[0]() is not param or ent[2].dtype != _COMPUTE_DTYPE or ent[2].device != param.device
+            or not ent[2].is_contiguous()):
+        return None
+    return ent[2]
+
+
+_PADDED = {}
+
+
+def padded_conv_shadow(weight):
+    """bf16 GEMM operand of a 1x1 convolution weight (N, K, 1, 1): (N, Kc) with Kc = K rounded up to 64, ZERO beyond K
+    (csrc/gemm.hip pwconv64_kernel contracts whole 64-wide K tiles; the padding multiplies whatever follows the K
+    channels of a point row).  The registered shadow of the parameter is the (N, K, 1, 1) view of that buffer, so the
+    optimizer's shadow refresh keeps it current."""
+    import weakref
+    N, K = weight.shape[0], weight.shape[1]
+    hit = _PADDED.get(id(weight))
+    if hit is not None and hit[0]() is weight and hit[1].device == weight.device:
+        ent = _SHADOW.get(id(weight))
+        if ent is not None and ent[2].untyped_storage().data_ptr() == hit[1].untyped_storage().data_ptr():
+            if ent[1] != weight._version:  # an in-place update nobody refreshed (load_state_dict, plain optimizers)
+                with torch.no_grad():
+                    ent[2].copy_(weight.detach())
+                _SHADOW[id(weight)] = (ent[0], weight._version, ent[2])
+            return hit[1]
+    Kc = (K + 63) // 64 * 64
+    with torch.no_grad():
+        buf = torch.zeros(N, Kc, dtype=torch.bfloat16, device=weight.device)
+        view = buf[:, :K]
+        for _ in range(weight.dim() - 2):  # (N, K, 1, 1) for Conv2d, (N, K, 1) for Conv1d: a view of the padded rows
+            view = view.unsqueeze(-1)
+        view.copy_(weight.detach())
+    _SHADOW[id(weight)] = (weakref.ref(weight), weight._version, view)
+    _PADDED[id(weight)] = (weakref.ref(weight), buf)
+    return buf
+
+
+_FRESH = set()
+
+
+def shadows_written(params):
+    """An optimizer that writes the shadows itself (optim.FusedAdamW) reports them here; the post-step hook's
+    refresh_shadows() then skips them."""
+    for p in params:
+        ent = _SHADOW.get(id(p))
+        if ent is not None:
+            _SHADOW[id(p)] = (ent[0], p._version, ent[2])
+            _FRESH.add(id(p))
+
+
+def refresh_shadows(only_with_grad=True, skip=None):
+    """Bring every registered bf16 shadow (and, through them, the concatenated QKV / KV operands, whose row blocks ARE
+    the per-weight shadows) up to date with ONE multi-tensor cast.  Runs as a global optimizer post-step hook
+    (set_compute_dtype); call it yourself after any other in-place parameter update.  It does NOT consult version
+    counters: torch's fused multi-tensor optimizers update parameters without bumping them (the lazy check in
+    _shadow() only catches ordinary in-place ops and load_state_dict).  only_with_grad: skip parameters that have no
+    gradient, i.e. that the optimizer did not touch.  skip: ids of parameters whose shadows the stepping optimizer writes
+    itself."""
+    dst, src = [], []
+    for key, (ref, ver, c) in list(_SHADOW.items()):
+        t = ref()
+        if t is None:
+            del _SHADOW[key]
+            continue
+        if skip is not None and key in skip and ver == t._version:
+            continue
+        if c.dtype != _COMPUTE_DTYPE or c.device != t.device:
+            continue
+        if key in _FRESH and ver == t._version:
+            continue  # written by the optimizer kernel itself
+        if only_with_grad and t.grad is None and ver == t._version:
+            continue
+        dst.append(c)
+        src.append(t.detach())
+        _SHADOW[key] = (ref, t._version, c)
+    _FRESH.clear()
+    if dst:
+        with torch.no_grad():
+            torch._foreach_copy_(dst, src)
+    return len(dst)
+
+
+
+__all__ = [n for n in list(globals()) if not n.startswith("__")]

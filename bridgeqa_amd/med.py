@@ -350,10 +350,10 @@ class BertLayer(nn.Module):
                            intermediate=self.intermediate)
 
 
-_TWIN_BATCH = [os.environ.get("BQ_TWIN_BATCH", "1") != "0"]  # both text streams of a twin level as one stacked batch
-_HOIST_CROSS_KV = os.environ.get("BQ_HOIST_CROSS_KV", "1") != "0"  # plain encoder / decoder: all layers' cross K/V in one GEMM
-_TWO_SEGMENT = os.environ.get("BQ_TWO_SEGMENT_KV", "0") == "1"
-_TWO_SEGMENT_FORK = os.environ.get("BQ_TWO_SEGMENT_FORK", "0") == "1"  # also when the twin branches run on two streams
+_TWIN_BATCH = [True]  # both text streams of a twin level as one stacked batch
+_HOIST_CROSS_KV = True  # plain encoder / decoder: all layers' cross K/V in one GEMM
+_TWO_SEGMENT = False   # (measured neutral, DESIGN.md §5 c: kept as a tested alternative wiring, off)
+_TWO_SEGMENT_FORK = False  # also when the twin branches run on two streams
 
 
 def _wants(output_attentions, i, last):

@@ -16,7 +16,11 @@ the image / detector backward (split_fusion_tail / split_fusion_opt below).  The
 and the final optimizer phase shrinks from 2.7 to 0.5 ms, but the image backward stretches from 17.9 to 21.8 ms and the
 detector backward from 13.4 to 15.9 ms: a HBM-bound update next to GEMMs that stream their operands from HBM only moves
 the time (one dX GEMM that normally takes 73 us ran 2.0 ms beside the AdamW kernel).  Step, same box: 46.5 ms inline,
-46.7 ms with the weight gradients on the side stream, 46.8 ms with the optimizer there too.  Both stay off.
+46.7 ms with the weight gradients on the side stream, 46.8 ms with the optimizer there too.  Round 3 repeated the
+optimizer part with the side stream confined to 16 / 32 / 64 CUs (hipExtStreamCreateWithCUMask): 40.1 - 42.3 ms against
+38.6 -- the backward window is bound by the SUM of its work, memory traffic included.  The schedules and their knobs
+(split_fusion_tail / split_fusion_opt, CU-masked encoder and detector streams) were removed in round 3; DESIGN.md §5
+keeps the numbers.
 
 The fusion phase is ~1200 short kernels that leave most of the 256 CUs idle, and FPS / ball query / three-NN depend
 on coordinates only (no parameters): the sampling and grouping indices of the next batch are computed under it
@@ -43,32 +47,10 @@ import torch
 from . import fusion_ops as ops
 
 
-def _cu_masked_stream(device, lo, hi, total=256, spread=False, priority=None):
-    """a HIP stream whose kernels may only run on CUs [lo, hi) (hipExtStreamCreateWithCUMask), as a torch stream;
-    spread: the hi - lo CUs are taken evenly from the eight 32-bit words of the mask instead of contiguously"""
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    words = (ctypes.c_uint32 * (total // 32))()
-    if spread:
-        per = max(1, (hi - lo) // (total // 32))
-        for w in range(total // 32):
-            words[w] = (1 << per) - 1
-    else:
-        for i in range(lo, hi):
-            words[i // 32] |= (1 << (i % 32))
-    h = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), total // 32, words)
-    if rc != 0:
-        raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
-    return torch.cuda.ExternalStream(h.value, device=device)
-
-
 class PhasedTrainStep(object):
     def __init__(self, model, batch, det_loss, fusion_loss, optimizer=None, use_graphs=True, det_priority=0,
                  grad_hook=None, next_batch=None, prefetch_geometry=None, eager_phases=(), reducers=None,
-                 reserve_cus=0, split_fusion_tail=False, split_fusion_opt=False, main_priority=-1, det_cus=0,
-                 det_cus_spread=False):
+                 main_priority=-1):
         """model: ScanQAHotPath (use_blip=True, train mode); batch: static device tensors (replayed in place);
         det_loss(data_dict) -> scalar over detector outputs; fusion_loss(data_dict) -> scalar over blip_loss /
         fused_feat; optimizer: stepped at the end of the step (None: the caller steps);
@@ -85,13 +67,7 @@ class PhasedTrainStep(object):
         gradients that phase produces}: each group is exchanged on a communication stream as soon as its backward
         phase has finished (the fusion group, 3/4 of the bytes, travels under the image and detector backward) and
         the optimizer waits for all of them;
-        reserve_cus: N > 0 runs the two image-encoder phases on a stream masked to CUs [N, 256): its GPU-filling
-        kernels then leave N CUs to the detector stream, which otherwise only gets to dispatch at their kernel
-        boundaries (see the module docstring).  MEASURED on c3: 0 -> 50.1 ms/step, 16 -> 52.7, 32 -> 52.7, 48 -> 57.0:
-        the encoder loses more than the detector gains, so the default stays 0 (knob kept for other shapes);
-        split_fusion_tail / split_fusion_opt: produce the fusion phase's weight gradients / additionally step its
-        parameters (optim.FusedAdamW subsets) on a third stream under the image and detector backward -- measured
-        neutral / slower (module docstring), off by default."""
+        main_priority: stream priority of the critical path (image forward -> fusion -> image backward -> optimizer)."""
         self.model, self.batch, self.det_loss, self.fusion_loss = model, batch, det_loss, fusion_loss
         self.opt, self.grad_hook = optimizer, grad_hook
         if prefetch_geometry and next_batch is None:
@@ -116,23 +92,11 @@ class PhasedTrainStep(object):
         # kernels win the dispatch whenever both streams have work (measured, c3: 46.5 -> 45.5 ms; the detector stream at
         # high priority instead: 47.3 ms; this stack offers two levels, 0 and -1)
         self.s_main = torch.cuda.Stream(device=dev, priority=int(main_priority))
-        self.s_img = _cu_masked_stream(dev, int(reserve_cus), 256) if reserve_cus else self.s_main
+        self.s_img = self.s_main
         self.e_img_fwd = torch.cuda.Event()
-        # det_cus: N > 0 confines the detector stream to N CUs (its HBM-streaming backward kernels then cannot take the
-        # memory system away from the image backward's GEMMs on the other 256 - N)
-        self.s_det = (_cu_masked_stream(dev, 0, int(det_cus), spread=bool(det_cus_spread)) if det_cus
-                      else torch.cuda.Stream(device=dev, priority=int(det_priority)))
+        self.s_det = torch.cuda.Stream(device=dev, priority=int(det_priority))
         self.e_det_fwd, self.e_fused, self.e_det_bwd, self.e_done = (torch.cuda.Event() for _ in range(4))
-        # the fusion phase's tail on its own stream: weight gradients (whenever they are deferred), and the optimizer
-        # step of the fusion parameters when the optimizer can step subsets (optim.FusedAdamW) and no grad_hook needs
-        # every gradient before any update
-        self.s_aux = torch.cuda.Stream(device=dev)
-        self._params = None
         self._bn_modules, self._bn_sig = None, None
-        self.e_fusion_wgrad, self.e_fusion_opt = torch.cuda.Event(), torch.cuda.Event()
-        # (both measured slower or neutral on c3 -- see the module docstring -- and therefore opt-in)
-        self.split_wgrad = bool(split_fusion_tail)
-        self._split_opt_ok = self.split_wgrad and bool(split_fusion_opt) and grad_hook is None
         self.use_graphs = use_graphs
         self.graphs = None
         self.loss = None
@@ -167,16 +131,6 @@ class PhasedTrainStep(object):
         self._state["det_loss"] = self.det_loss(dd)
 
     def _fusion(self):
-        import os
-        if os.environ.get("BQ_FUSION_NO_FORK") == "1":
-            prev = ops.set_overlap(False)
-            try:
-                return self._fusion_body()
-            finally:
-                ops.set_overlap(prev)
-        return self._fusion_body()
-
-    def _fusion_body(self):
         st = self._state
         img_leaf = st["img"].detach().requires_grad_(True)
         obj_leaf = st["dd"]["object_feat"].detach().requires_grad_(True)
@@ -188,35 +142,9 @@ class PhasedTrainStep(object):
         try:
             loss.backward()
         finally:
-            if self.defer_wgrad and self.split_wgrad:
-                # (the records stay referenced from here until the next step / capture replaces them: under graph
-                # replay the aux stream reads these tensors while later main-stream graphs of the same memory pool
-                # run, so they must never go back to that pool)
-                st["fusion_parked"] = ops.take_deferred_wgrad()
-            else:
-                ops.flush_deferred_wgrad()
+            ops.flush_deferred_wgrad()
         st["img_grad"], st["obj_grad"] = img_leaf.grad, obj_leaf.grad
         st["fusion_loss"] = loss.detach()
-
-    def _split_opt(self):
-        return self._split_opt_ok and self.opt is not None and hasattr(self.opt, "_subs")
-
-    def _fusion_wgrad(self):
-        ops.flush_deferred_items(self._state.get("fusion_parked"))
-
-    def _param_split(self):
-        """(fusion parameters, the rest): the fusion phase produces the gradients of the BLIP text side (twin encoder,
-        answer decoder, heads); the image encoder's come from image_bwd, the detector's from det_bwd"""
-        if self._params is None:
-            fus, rest = [], []
-            for name, p in self.model.named_parameters():
-                is_fusion = name.startswith("blip_model.") and not name.startswith("blip_model.visual_encoder.")
-                (fus if is_fusion else rest).append(p)
-            self._params = (fus, rest)
-        return self._params
-
-    def _fusion_opt(self):
-        self.opt.step(subset="fusion", params=self._param_split()[0], advance=True)
 
     def _image_bwd(self):
         if self.defer_wgrad:
@@ -238,27 +166,21 @@ class PhasedTrainStep(object):
             self.grad_hook()
         if self.opt is not None:
             # (fusion_ops' optimizer post-step hook refreshes the bf16 weight shadows here)
-            if self._split_opt():
-                # (the fusion parameters were stepped on the aux stream)
-                self.opt.step(subset="rest", params=self._param_split()[1], advance=False)
-            else:
-                self.opt.step()
+            self.opt.step()
         st = self._state
         self.loss = st["det_loss"].detach() + st["fusion_loss"]
 
     # (phase, stream, memory pool): the image phases may sit on their own (CU-masked) stream but still alternate
     # strictly with the main stream's phases, so they share its pool
     _ORDER = (("det_fwd", "det", "det"), ("geometry", "det", "det"), ("image_fwd", "img", "main"),
-              ("fusion", "main", "main"), ("fusion_wgrad", "aux", "aux"), ("fusion_opt", "aux", "aux"),
+              ("fusion", "main", "main"),
               ("det_bwd", "det", "det"), ("image_bwd", "img", "main"), ("finish", "main", "main"))
 
     def _stream(self, which):
-        return {"main": self.s_main, "det": self.s_det, "img": self.s_img, "aux": self.s_aux}[which]
+        return {"main": self.s_main, "det": self.s_det, "img": self.s_img}[which]
 
     def _skipped(self, name):
-        return ((name == "geometry" and not self.prefetch) or
-                (name == "fusion_wgrad" and not (self.defer_wgrad and self.split_wgrad)) or
-                (name == "fusion_opt" and not self._split_opt()))
+        return name == "geometry" and not self.prefetch
 
     def phase_gpu_ms(self):
         """after a synchronize: {phase: (mean start, mean end)} in ms relative to the start of the step's first phase,
@@ -311,7 +233,7 @@ class PhasedTrainStep(object):
         Host ORDER matters: a graph launch blocks the host while its stream's hardware queue is full, so at every
         point the detector stream's launches (short, its queue is usually empty) are issued before the main
         stream's -- otherwise the detector only gets its packets once the main stream has drained (measured)."""
-        sm, sd, si, sa = self.s_main, self.s_det, self.s_img, self.s_aux
+        sm, sd, si = self.s_main, self.s_det, self.s_img
         # whatever the caller enqueued on ITS stream before this step -- solver.BatchStager.advance() copies the next
         # batch into the static buffers there -- happens before any phase reads the batch
         cur = torch.cuda.current_stream(self.dev)
@@ -338,21 +260,7 @@ class PhasedTrainStep(object):
         with torch.cuda.stream(sd):
             self._run("det_bwd", eager)
             self.e_det_bwd.record(sd)
-        # the fusion phase's tail, off the critical path (the detector / image backward only need e_fused)
-        fusion_grads = self.e_fused
-        if not self._skipped("fusion_wgrad"):
-            sa.wait_event(self.e_fused)
-            with torch.cuda.stream(sa):
-                self._run("fusion_wgrad", eager)
-                self.e_fusion_wgrad.record(sa)
-            fusion_grads = self.e_fusion_wgrad
-        ev = self._reduce("fusion", fusion_grads)
-        if not self._skipped("fusion_opt"):
-            if ev is not None:
-                sa.wait_event(ev)
-            with torch.cuda.stream(sa):
-                self._run("fusion_opt", eager)
-                self.e_fusion_opt.record(sa)
+        self._reduce("fusion", self.e_fused)
         self._reduce("det", self.e_det_bwd)
         si.wait_event(self.e_fused)
         with torch.cuda.stream(si):
@@ -362,10 +270,6 @@ class PhasedTrainStep(object):
         with torch.cuda.stream(sm):
             sm.wait_event(self.e_img_bwd)
             sm.wait_event(self.e_det_bwd)
-            if not self._skipped("fusion_wgrad"):
-                sm.wait_event(self.e_fusion_wgrad)
-            if not self._skipped("fusion_opt"):
-                sm.wait_event(self.e_fusion_opt)
             for ev in self._comm_events:
                 sm.wait_event(ev)
             del self._comm_events[:]
@@ -378,7 +282,7 @@ class PhasedTrainStep(object):
         (Parameters that get no gradient on this path -- unused BLIP heads -- are left out, as DDP's
         find_unused_parameters would discover every step.)"""
         cur = torch.cuda.current_stream(self.dev)
-        for s_ in (self.s_main, self.s_det, self.s_img, self.s_aux):
+        for s_ in (self.s_main, self.s_det, self.s_img):
             s_.wait_stream(cur)
         self.e_done.record(self.s_main)
         if self.prefetch and self._geo_next is None:
@@ -428,7 +332,7 @@ class PhasedTrainStep(object):
         running statistics), moments and the step count are put back afterwards, so training starts from the state
         the caller handed over."""
         cur = torch.cuda.current_stream(self.dev)
-        for s_ in (self.s_main, self.s_det, self.s_img, self.s_aux):
+        for s_ in (self.s_main, self.s_det, self.s_img):
             s_.wait_stream(cur)
         self.e_done.record(self.s_main)
         if self.prefetch and not _again:  # (a re-capture keeps the geometry the previous step prefetched)
@@ -472,8 +376,7 @@ class PhasedTrainStep(object):
             return self
         self.zero_grad()
         self._state = {}
-        pools = {"main": torch.cuda.graph_pool_handle(), "det": torch.cuda.graph_pool_handle(),
-                 "aux": torch.cuda.graph_pool_handle()}
+        pools = {"main": torch.cuda.graph_pool_handle(), "det": torch.cuda.graph_pool_handle()}
         self.graphs = {}
         self._bn_sig = self._bn_momenta()
         for name, which, pool in self._ORDER:

@@ -149,10 +149,10 @@ class _ConvBNReLUPointMajor(torch.autograd.Function):
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None, dcb
 
 
-_WGRAD_ROWS = os.environ.get("BQ_WGRAD_ROWS", "1") != "0"          # the whole-row weight-gradient kernel for long contractions
-_WGRAD_ROWS_MIN = int(os.environ.get("BQ_WGRAD_ROWS_MIN", "65536"))
-_WGRAD_ROWS_WGS = int(os.environ.get("BQ_WGRAD_ROWS_WGS", "0"))     # 0: the library's default per shape
-_WGRAD_WGS = int(os.environ.get("BQ_DET_WGRAD_WGS", "384"))
+_WGRAD_ROWS = True          # the whole-row weight-gradient kernel for long contractions
+_WGRAD_ROWS_MIN = 65536
+_WGRAD_ROWS_WGS = 0     # 0: the library's default per shape
+_WGRAD_WGS = 384   # (sweep in the c3 step: 398 / 405 / 406 / 406 / 404 / 388 samples/s at 128 / 256 / 384 / 512 / 1536 / 3072)
 
 
 def _wgrad_pieces(R, tiles):

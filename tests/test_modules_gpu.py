@@ -60,7 +60,9 @@ def test_sa_module_bf16_path_vs_reference_golden(golden, dev):
     assert nf.dtype == torch.float32
     np.testing.assert_array_equal(ni.cpu().numpy(), g["sa_inds"])
     rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
-    assert rel(nf.detach().cpu().numpy(), g["sa_train_new_features"]) < 1.5e-2
+    r_out = rel(nf.detach().cpu().numpy(), g["sa_train_new_features"])
+    print("SA module bf16 vs fp32 golden: output rel-L2 %.4g" % r_out)
+    assert r_out < 1e-2   # SURVEY §8a a8 (measured 4.8e-3)
     assert rel(feat.grad.cpu().numpy(), g["sa_train_grad_features"]) < 0.15  # bf16 re-rounding moves max-pool winners
 
 

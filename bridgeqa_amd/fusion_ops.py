@@ -99,7 +99,7 @@ class _LinearFn(torch.autograd.Function):
             ctx.save_for_backward(x2, wb)
             return out.view(*x.shape[:-1], N)
         bb = _shadow(bias) if bias is not None else None
-        xb = x if x.dtype == _COMPUTE_DTYPE else x.to(_COMPUTE_DTYPE)
+        xb = x if x.dtype == compute_dtype() else x.to(compute_dtype())
         y = F.linear(xb, wb, bb)
         if gelu:
             ctx.save_for_backward(xb.reshape(-1, K), wb, y.reshape(-1, N))
@@ -202,7 +202,7 @@ def _cat_shadow(weights, biases):
     key = tuple(id(w) for w in weights)
     params = list(weights) + list(biases)
     hit = _CAT_CACHE.get(key)
-    if (hit is not None and all(r() is w for r, w in zip(hit[0], params)) and hit[1].dtype == _COMPUTE_DTYPE
+    if (hit is not None and all(r() is w for r, w in zip(hit[0], params)) and hit[1].dtype == compute_dtype()
             and all(id(p) in _SHADOW and _SHADOW[id(p)][2].untyped_storage().data_ptr() ==
                     (hit[1] if p.dim() > 1 else hit[2]).untyped_storage().data_ptr() for p in params)):
         stale = [p for p in params if _SHADOW[id(p)][1] != p._version]
@@ -215,8 +215,8 @@ def _cat_shadow(weights, biases):
         return hit[1], hit[2]
     import weakref
     with torch.no_grad():
-        wc = torch.cat([w.detach().to(_COMPUTE_DTYPE) for w in weights], dim=0)
-        bc = torch.cat([b.detach().to(_COMPUTE_DTYPE) for b in biases], dim=0)
+        wc = torch.cat([w.detach().to(compute_dtype()) for w in weights], dim=0)
+        bc = torch.cat([b.detach().to(compute_dtype()) for b in biases], dim=0)
     off = 0
     for w, b in zip(weights, biases):
         n = w.shape[0]
@@ -246,7 +246,7 @@ class _MultiLinearFn(torch.autograd.Function):
             y = _ext.gemm_fwd(x2, wc, bc)  # (bc is the bf16 concatenation of the k biases: bias_bf16 form)
             ctx.save_for_backward(x2, wc)
             return y.view(*x.shape[:-1], k, wc.shape[0] // k)
-        xb = x if x.dtype == _COMPUTE_DTYPE else x.to(_COMPUTE_DTYPE)
+        xb = x if x.dtype == compute_dtype() else x.to(compute_dtype())
         y = F.linear(xb, wc, bc)
         ctx.save_for_backward(xb.reshape(-1, xb.shape[-1]), wc)
         return y.view(*y.shape[:-1], k, y.shape[-1] // k)
@@ -284,7 +284,7 @@ class _MultiLinearFn(torch.autograd.Function):
 def multi_linear(x, linears, tap=None):
     """[lin_i(x)] stacked on a new second-to-last axis: (..., k, N).  Fused on the bf16 CUDA path.  tap: see mlp()."""
     ws, bs = [l.weight for l in linears], [l.bias for l in linears]
-    if (_COMPUTE_DTYPE != torch.float32 and x.is_cuda and all(w.dtype == torch.float32 for w in ws)
+    if (compute_dtype() != torch.float32 and x.is_cuda and all(w.dtype == torch.float32 for w in ws)
             and all(b is not None for b in bs) and len({w.shape for w in ws}) == 1):
         return _MultiLinearFn.apply(x, tap, *ws, *bs)
     return torch.stack([linear(x, w, b, tap=(tap if i == 0 else None)) for i, (w, b) in enumerate(zip(ws, bs))], dim=-2)
@@ -313,7 +313,7 @@ def linear(x, weight, bias=None, act=None, tap=None):
     tap: see mlp()."""
     if act not in (None, "gelu"):
         raise ValueError(act)
-    if (_COMPUTE_DTYPE != torch.float32 and x.is_cuda and isinstance(weight, torch.nn.Parameter)
+    if (compute_dtype() != torch.float32 and x.is_cuda and isinstance(weight, torch.nn.Parameter)
             and weight.dtype == torch.float32 and (bias is None or isinstance(bias, torch.nn.Parameter))):
         return _LinearFn.apply(x, weight, bias, act == "gelu", tap)
     if tap is not None and torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled():
@@ -345,7 +345,7 @@ def attention(q, k, v, mask, scale, return_probs=False, dropout_p=0.0):
     (B,1,Lq,Lk).  Returns ctx (B,Lq,H,D) [compute dtype] and probs (B,H,Lq,Lk) fp32 or None.
     Order of operations follows med.py:179-217 (scores/sqrt(d) then + mask) and vit.py:75-83.
     """
-    if _COMPUTE_DTYPE == torch.bfloat16 and _kernel_attention_ok(_c(q), _c(k), mask, return_probs):
+    if compute_dtype() == torch.bfloat16 and _kernel_attention_ok(_c(q), _c(k), mask, return_probs):
         return _MaskedAttention.apply(_c(q), _c(k), _c(v), _mask_log2(mask, q.shape[0], k.shape[1]), scale,
                                       float(dropout_p)), None
     qh, kh, vh = _c(q).permute(0, 2, 1, 3), _c(k).permute(0, 2, 1, 3), _c(v).permute(0, 2, 1, 3)
@@ -445,7 +445,7 @@ class _DropAddLN(torch.autograd.Function):
 
 
 def _ln_kernel_ok(x, ln):
-    return (_COMPUTE_DTYPE == torch.bfloat16 and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 256 == 0
+    return (compute_dtype() == torch.bfloat16 and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 256 == 0
             and x.shape[-1] <= 1024 and x.is_contiguous() and ln.weight.dtype == torch.float32
             and tuple(ln.normalized_shape) == (x.shape[-1],))
 
@@ -495,7 +495,7 @@ def _mask_log2(mask, B, Lk):
 def prime_masks(*masks):
     """Convert key masks to kernel format NOW, on the current stream.  Called before any fork so that side
     streams (which wait for the current stream when they fork) never see a half-written cached mask."""
-    if _COMPUTE_DTYPE != torch.bfloat16:
+    if compute_dtype() != torch.bfloat16:
         return
     for m in masks:
         if m is not None and m.is_cuda and m.dim() == 4 and m.shape[1] == 1 and m.shape[2] == 1:
@@ -880,7 +880,7 @@ def twin_kernel_ok(hs, linears):
     """the stacked twin path needs the kernel formats: bf16 compute, CUDA, width % 256 (LayerNorm kernel) and fp32
     master parameters with biases"""
     D = hs.shape[-1]
-    return (_COMPUTE_DTYPE == torch.bfloat16 and _NATIVE_GEMM[0] and hs.is_cuda and hs.dtype == torch.bfloat16
+    return (compute_dtype() == torch.bfloat16 and _NATIVE_GEMM[0] and hs.is_cuda and hs.dtype == torch.bfloat16
             and D % 256 == 0 and D <= 1024 and hs.shape[0] % 2 == 0
             and all(l.bias is not None and _param_ok(l.weight, l.bias) and l.weight.shape[0] % 64 == 0
                     and l.weight.shape[1] % 64 == 0 for l in linears))
@@ -995,7 +995,7 @@ def _dx2(g2, w):
 class _HoistedKVFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, hold, *wb):
-        xb = x if x.dtype == _COMPUTE_DTYPE else x.to(_COMPUTE_DTYPE)
+        xb = x if x.dtype == compute_dtype() else x.to(compute_dtype())
         y = _fwd2(xb.reshape(-1, xb.shape[-1]), hold.wc, hold.bc).view(*xb.shape[:-1], hold.wc.shape[0])
         ctx.save_for_backward(xb)
         ctx.hold, ctx.x_dtype, ctx.k = hold, x.dtype, len(wb) // 2
@@ -1047,7 +1047,7 @@ class _TailKVFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, hold, i):
         w, b = hold.block(i)
-        tb = t if t.dtype == _COMPUTE_DTYPE else t.to(_COMPUTE_DTYPE)
+        tb = t if t.dtype == compute_dtype() else t.to(compute_dtype())
         ctx.save_for_backward(tb, w)
         ctx.hold, ctx.i, ctx.t_dtype = hold, i, t.dtype
         return _fwd2(tb.reshape(-1, tb.shape[-1]), w, b).view(*tb.shape[:-1], w.shape[0])
@@ -1294,7 +1294,7 @@ def lm_loss(hidden, decoder_weight, decoder_bias, labels, label_smoothing=0.1):
     Returns (logits (B,L,V), loss (B,)).
     """
     D = hidden.shape[-1]
-    if (_NATIVE_GEMM[0] and hidden.is_cuda and _COMPUTE_DTYPE == torch.bfloat16 and D % 64 == 0
+    if (_NATIVE_GEMM[0] and hidden.is_cuda and compute_dtype() == torch.bfloat16 and D % 64 == 0
             and isinstance(decoder_weight, torch.nn.Parameter) and decoder_weight.dtype == torch.float32
             and decoder_weight.is_contiguous() and hidden.dim() == 3):
         logits, row_loss = _LMHeadCE.apply(hidden, decoder_weight, decoder_bias, labels, float(label_smoothing))

@@ -29,12 +29,12 @@ def _rows(t):
 
 def _native_ok(t, N, K):
     """forward y (M, N) = x (M, K) w^T: the contraction K is K-contiguous in both operands => K % 64"""
-    return _NATIVE_GEMM[0] and t.is_cuda and _COMPUTE_DTYPE == torch.bfloat16 and K % 64 == 0 and N % 8 == 0
+    return _NATIVE_GEMM[0] and t.is_cuda and compute_dtype() == torch.bfloat16 and K % 64 == 0 and N % 8 == 0
 
 
 def _native_dx_ok(t, N, K):
     """input gradient dx (M, K) = dy (M, N) w: the contraction is N (K-contiguous in dy) => N % 64"""
-    return _NATIVE_GEMM[0] and t.is_cuda and _COMPUTE_DTYPE == torch.bfloat16 and N % 64 == 0 and K % 8 == 0
+    return _NATIVE_GEMM[0] and t.is_cuda and compute_dtype() == torch.bfloat16 and N % 64 == 0 and K % 8 == 0
 
 
 def _f32_bias(bias):

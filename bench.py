@@ -471,8 +471,15 @@ def main():
         # with HIP events INSIDE the timed steps, on the stream it is launched on
         # next_batch=batch: the benchmark replays ONE static synthetic batch, so "the next step's point clouds" are the
         # same buffers (a training loop passes the buffers its loader fills one step ahead)
+        bb = None
+        if dp:
+            # data parallel: the image backward in three block ranges (their gradient groups travel under the ranges that
+            # follow; only the last one is exposed) and DDP's per-step buffer broadcast (scripts/train.py:346-347)
+            from bridgeqa_amd.ddp import BufferBroadcaster
+            bb = BufferBroadcaster(model)
+            bb.force = args.dp_path
         pipe = PhasedTrainStep(model, batch, det_loss, fusion_loss, opt, use_graphs=use_graph, next_batch=batch,
-                               eager_phases=("geometry",))
+                               eager_phases=("geometry",), image_bwd_splits=3 if dp else 1, buffer_broadcaster=bb)
         eager_step = pipe.eager_step
         reducers = {}
         if dp:
@@ -647,7 +654,7 @@ def main():
                        "points": args.points,
                        "c_in": args.cin, "image": args.image if workload == "c3" else None,
                        "parallelism": "dp%d" % world, "hip_graph": graphed,
-                       "schedule": "phased: 6 graphs on 2 streams" if phased else "single graph",
+                       "schedule": ("phased: %d graphs on 2 streams" % (6 + (2 if dp else 0))) if phased else "single graph",
                        "grad_exchange": (("per-phase packed bf16 all-reduce on a comm stream, %d MB on the wire"
                                           % (sum(r.nbytes_on_wire() for r in reducers.values()) >> 20)) if phased
                                          else ("one packed bf16 all-reduce after the fwd+bwd graph, %d MB on the wire"

@@ -63,6 +63,45 @@ class PackedGradReducer(object):
         return self.comm.numel() * self.comm.element_size()
 
 
+class BufferBroadcaster(object):
+    """DDP's broadcast_buffers=True (the reference's default, scripts/train.py:346-347: before every forward rank 0's
+    buffers -- the BatchNorm running statistics and num_batches_tracked of the detector -- overwrite every other rank's):
+    ONE packed broadcast per dtype class per step instead of one per buffer (floating buffers travel as fp32, integer
+    ones as int64).  Without it every rank keeps the running statistics of its own shard of the data; they only matter in
+    eval mode, and the reference evaluates on rank 0's."""
+
+    def __init__(self, model, src=0, process_group=None):
+        self.group, self.src = process_group, src
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.force = False
+        bufs = [b for b in model.buffers() if b.numel() > 0]
+        self.f_bufs = [b for b in bufs if b.is_floating_point()]
+        self.i_bufs = [b for b in bufs if not b.is_floating_point()]
+        dev = bufs[0].device if bufs else torch.device("cpu")
+        self.f_flat = torch.empty(sum(b.numel() for b in self.f_bufs), dtype=torch.float32, device=dev)
+        self.i_flat = torch.empty(sum(b.numel() for b in self.i_bufs), dtype=torch.int64, device=dev)
+        self.f_views, self.i_views = self._views(self.f_flat, self.f_bufs), self._views(self.i_flat, self.i_bufs)
+
+    @staticmethod
+    def _views(flat, bufs):
+        out, off = [], 0
+        for b in bufs:
+            out.append(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+        return out
+
+    def broadcast(self):
+        if self.world == 1 and not (self.force and dist.is_initialized()):
+            return
+        with torch.no_grad():
+            for flat, views, bufs in ((self.f_flat, self.f_views, self.f_bufs), (self.i_flat, self.i_views, self.i_bufs)):
+                if not bufs:
+                    continue
+                torch._foreach_copy_(views, bufs)
+                dist.broadcast(flat, self.src, group=self.group)
+                torch._foreach_copy_(bufs, views)
+
+
 def check_coverage(model, reducers):
     """Raise if a parameter that no reducer exchanges holds a gradient: the reduced set was fixed by one dry run, and a
     parameter that starts receiving gradients later (a conditional path) would silently diverge between replicas."""

@@ -50,7 +50,7 @@ from . import fusion_ops as ops
 class PhasedTrainStep(object):
     def __init__(self, model, batch, det_loss, fusion_loss, optimizer=None, use_graphs=True, det_priority=0,
                  grad_hook=None, next_batch=None, prefetch_geometry=None, eager_phases=(), reducers=None,
-                 main_priority=-1):
+                 main_priority=-1, image_bwd_splits=1, buffer_broadcaster=None, coverage_every=50):
         """model: ScanQAHotPath (use_blip=True, train mode); batch: static device tensors (replayed in place);
         det_loss(data_dict) -> scalar over detector outputs; fusion_loss(data_dict) -> scalar over blip_loss /
         fused_feat; optimizer: stepped at the end of the step (None: the caller steps);
@@ -67,7 +67,15 @@ class PhasedTrainStep(object):
         gradients that phase produces}: each group is exchanged on a communication stream as soon as its backward
         phase has finished (the fusion group, 3/4 of the bytes, travels under the image and detector backward) and
         the optimizer waits for all of them;
-        main_priority: stream priority of the critical path (image forward -> fusion -> image backward -> optimizer)."""
+        main_priority: stream priority of the critical path (image forward -> fusion -> image backward -> optimizer);
+        image_bwd_splits: data parallel -- the image encoder's backward as this many block-range phases (autograd cut in
+        front of blocks depth * k / splits, vit.VisionTransformer.grad_cuts), each with its own weight-gradient flush and
+        its own reducer group "image_0" (last blocks, first to finish) ... "image_{splits-1}": only the last group's
+        exchange is exposed, the others travel under the rest of the image backward -- what DDP's buckets firing during
+        backward do (scripts/train.py:346-347).  1 (default, single GPU): one phase, one grouped weight-gradient flush;
+        buffer_broadcaster: ddp.BufferBroadcaster -- rank 0's buffers (BatchNorm running statistics) to every rank at the
+        start of every step, DDP's broadcast_buffers=True (the reference's default); None: statistics stay per rank;
+        coverage_every: run ddp.check_coverage every this many replayed steps (and after every capture)."""
         self.model, self.batch, self.det_loss, self.fusion_loss = model, batch, det_loss, fusion_loss
         self.opt, self.grad_hook = optimizer, grad_hook
         if prefetch_geometry and next_batch is None:
@@ -79,9 +87,19 @@ class PhasedTrainStep(object):
         # weight / bias gradients of every linear are parked during a backward phase and produced by ONE grouped GEMM
         # launch per tile class + one grouped column-sum launch at its end (fusion_ops.begin/flush_deferred_wgrad)
         self.defer_wgrad = True
+        self.image_splits = max(1, int(image_bwd_splits))
+        vit = model.blip_model.visual_encoder
+        depth = len(vit.blocks)
+        vit.grad_cuts = tuple(sorted({depth * k // self.image_splits for k in range(1, self.image_splits)} - {0}))
+        self.image_splits = len(vit.grad_cuts) + 1
+        if self.image_splits > 4:
+            raise ValueError("image_bwd_splits: at most 4 block ranges")
+        self._seg_probe = None   # attach_reducers: {segment: parameters whose gradient that segment produced}
+        self.buffer_broadcaster, self.coverage_every, self._steps = buffer_broadcaster, int(coverage_every), 0
         self.reducers = dict(reducers or {})
         self.s_comm = torch.cuda.Stream(device=batch["point_clouds"].device) if self.reducers else None
         self.e_img_bwd = torch.cuda.Event()
+        self.e_img_seg = [torch.cuda.Event() for _ in range(self.image_splits)]
         self._comm_events = []
         self._geo_next, self._geo_cur = None, None
         self.host_times = None  # set to {} to record the host time of every graph launch (ms, per phase)
@@ -106,6 +124,7 @@ class PhasedTrainStep(object):
     def _image_fwd(self):
         ops.new_step(self.dev)
         self._state["img"] = self.model.encode_image(self.batch)
+        self._state["img_cuts"] = list(self.model.blip_model.visual_encoder.cut_pairs)
 
     def _geometry(self):
         """sampling / grouping indices of the next batch, into the persistent `next` buffers"""
@@ -146,13 +165,33 @@ class PhasedTrainStep(object):
         st["img_grad"], st["obj_grad"] = img_leaf.grad, obj_leaf.grad
         st["fusion_loss"] = loss.detach()
 
-    def _image_bwd(self):
+    def _image_bwd(self, seg=0):
+        """block range `seg` of the image encoder's backward (0 = the last blocks; one range without splits)"""
+        st = self._state
+        cuts = st["img_cuts"]
         if self.defer_wgrad:
             ops.begin_deferred_wgrad()  # 48 ViT weight gradients -> one grouped launch of 1296 full-contraction tiles
         try:
-            self._state["img"].backward(self._state["img_grad"])
+            if seg == 0:
+                st["img"].backward(st["img_grad"])
+            else:
+                (x, n), (xl, nl) = cuts[len(cuts) - seg]
+                torch.autograd.backward([x, n], [xl.grad, nl.grad])
         finally:
             ops.flush_deferred_wgrad()
+        if self._seg_probe is not None:   # (dry eager step of attach_reducers)
+            seen = {id(p) for ps in self._seg_probe.values() for p in ps}
+            self._seg_probe[seg] = [p for p in self.model.blip_model.visual_encoder.parameters()
+                                    if p.grad is not None and id(p) not in seen]
+
+    def _image_bwd_1(self):
+        self._image_bwd(1)
+
+    def _image_bwd_2(self):
+        self._image_bwd(2)
+
+    def _image_bwd_3(self):
+        self._image_bwd(3)
 
     def _det_bwd(self):
         st = self._state
@@ -174,12 +213,15 @@ class PhasedTrainStep(object):
     # strictly with the main stream's phases, so they share its pool
     _ORDER = (("det_fwd", "det", "det"), ("geometry", "det", "det"), ("image_fwd", "img", "main"),
               ("fusion", "main", "main"),
-              ("det_bwd", "det", "det"), ("image_bwd", "img", "main"), ("finish", "main", "main"))
+              ("det_bwd", "det", "det"), ("image_bwd", "img", "main"), ("image_bwd_1", "img", "main"),
+              ("image_bwd_2", "img", "main"), ("image_bwd_3", "img", "main"), ("finish", "main", "main"))
 
     def _stream(self, which):
         return {"main": self.s_main, "det": self.s_det, "img": self.s_img}[which]
 
     def _skipped(self, name):
+        if name.startswith("image_bwd_"):
+            return int(name.rsplit("_", 1)[1]) >= self.image_splits
         return name == "geometry" and not self.prefetch
 
     def phase_gpu_ms(self):
@@ -237,6 +279,11 @@ class PhasedTrainStep(object):
         # whatever the caller enqueued on ITS stream before this step -- solver.BatchStager.advance() copies the next
         # batch into the static buffers there -- happens before any phase reads the batch
         cur = torch.cuda.current_stream(self.dev)
+        if self.buffer_broadcaster is not None:
+            # DDP's broadcast_buffers: rank 0's buffers to every rank before the forward (after the previous step's
+            # detector forward has written its BatchNorm statistics: e_done), on the caller's stream
+            cur.wait_event(self.e_done)
+            self.buffer_broadcaster.broadcast()
         for s_ in {sm, sd, si}:
             if s_ is not cur:
                 s_.wait_stream(cur)
@@ -263,10 +310,14 @@ class PhasedTrainStep(object):
         self._reduce("fusion", self.e_fused)
         self._reduce("det", self.e_det_bwd)
         si.wait_event(self.e_fused)
+        for seg in range(self.image_splits):
+            with torch.cuda.stream(si):
+                self._run("image_bwd" if seg == 0 else "image_bwd_%d" % seg, eager)
+                self.e_img_seg[seg].record(si)
+            # (one range: the group is called "image"; several: "image_0" travels under the ranges that follow it)
+            self._reduce("image" if self.image_splits == 1 else "image_%d" % seg, self.e_img_seg[seg])
         with torch.cuda.stream(si):
-            self._run("image_bwd", eager)
             self.e_img_bwd.record(si)
-        self._reduce("image", self.e_img_bwd)
         with torch.cuda.stream(sm):
             sm.wait_event(self.e_img_bwd)
             sm.wait_event(self.e_det_bwd)
@@ -278,7 +329,8 @@ class PhasedTrainStep(object):
 
     def attach_reducers(self, make_reducer):
         """Data parallel: one eager step to see which parameters receive a gradient in which phase, then
-        self.reducers[group] = make_reducer(list_of_parameters) for the groups "fusion", "image", "det".
+        self.reducers[group] = make_reducer(list_of_parameters) for the groups "fusion", "det" and "image" (or, with
+        image_bwd_splits > 1, "image_0" ... one per block range of the image backward).
         (Parameters that get no gradient on this path -- unused BLIP heads -- are left out, as DDP's
         find_unused_parameters would discover every step.)"""
         cur = torch.cuda.current_stream(self.dev)
@@ -289,19 +341,21 @@ class PhasedTrainStep(object):
             with torch.cuda.stream(self.s_det):
                 self._geometry()
         opt, self.opt = self.opt, None  # a dry step: no parameter update (replicas must not diverge)
+        self._seg_probe = {}
         self.eager_step()
+        probe, self._seg_probe = self._seg_probe, None
         self.opt = opt
         torch.cuda.synchronize(self.dev)
-        groups = {"fusion": [], "image": [], "det": []}
+        groups = {"fusion": [], "det": []}
+        if self.image_splits == 1:
+            groups["image"] = probe.get(0, [])
+        else:   # which block range produced which gradient was OBSERVED (a block's norm1 runs in the block before it)
+            for seg in range(self.image_splits):
+                groups["image_%d" % seg] = probe.get(seg, [])
         for name, p in self.model.named_parameters():
-            if p.grad is None:
+            if p.grad is None or name.startswith("blip_model.visual_encoder."):
                 continue
-            if name.startswith("blip_model.visual_encoder."):
-                groups["image"].append(p)
-            elif name.startswith("blip_model."):
-                groups["fusion"].append(p)
-            else:
-                groups["det"].append(p)
+            groups["fusion" if name.startswith("blip_model.") else "det"].append(p)
         self.reducers = {g: make_reducer(ps) for g, ps in groups.items() if ps}
         self.s_comm = torch.cuda.Stream(device=self.dev)
         return self.reducers
@@ -391,6 +445,9 @@ class PhasedTrainStep(object):
             self.graphs[name] = g
             torch.cuda.synchronize(self.dev)
         self.e_done.record(self.s_main)
+        if self.reducers:
+            from .ddp import check_coverage
+            check_coverage(self.model, self.reducers.values())   # the captured graphs' gradient set == the reducers' set
         return self
 
     def step(self):
@@ -405,6 +462,10 @@ class PhasedTrainStep(object):
             self.graphs = None
             self.capture(warmup=0, _again=True)
         self._schedule(eager=False)
+        self._steps += 1
+        if self.reducers and self.coverage_every > 0 and self._steps % self.coverage_every == 0:
+            from .ddp import check_coverage
+            check_coverage(self.model, self.reducers.values())   # (host-side: which .grad tensors exist)
         return self.loss
 
     def wait(self):

@@ -213,7 +213,16 @@ class VisionTransformer(nn.Module):
         if return_fm == -1 and all(blk.fusable(register_blk == i) for i, blk in enumerate(self.blocks)):
             # same arithmetic, 2 launches per block instead of 2 adds + 2 norms (+ casts)
             n = ops.layer_norm(x, self.blocks[0].norm1)
+            cuts = getattr(self, "grad_cuts", ())
+            self.cut_pairs = []
             for i, blk in enumerate(self.blocks):
+                if i in cuts and torch.is_grad_enabled() and x.requires_grad:
+                    # autograd cut in front of block i (pipeline.PhasedTrainStep(image_bwd_splits=...)): the backward then
+                    # runs in block ranges, last range first -- ((x, n) outputs of the earlier range, the leaves the later
+                    # range consumed): torch.autograd.backward([x, n], [xl.grad, nl.grad]) continues the chain
+                    xl, nl = x.detach().requires_grad_(True), n.detach().requires_grad_(True)
+                    self.cut_pairs.append(((x, n), (xl, nl)))
+                    x, n = xl, nl
                 x, n = blk.forward_fused(x, n, self.blocks[i + 1].norm1 if i < last else self.norm)
             return n
         for i, blk in enumerate(self.blocks):

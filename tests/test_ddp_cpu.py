@@ -126,3 +126,62 @@ def test_packed_grad_reducer_world2_gloo():
         assert p.exitcode == 0
     for rank, err, same_storage, wire_ok in res:
         assert err < 1e-6 and same_storage and wire_ok
+
+
+def _worker_groups_and_buffers(rank, world, port, out):
+    """reducer GROUPS exchanged one after the other (the image encoder's block ranges of pipeline.PhasedTrainStep) and
+    ddp.BufferBroadcaster (DDP's broadcast_buffers): rank 0's BatchNorm statistics reach every rank, packed"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
+    try:
+        from bridgeqa_amd.ddp import BufferBroadcaster, PackedGradReducer, check_coverage
+        from bridgeqa_amd.vit import VisionTransformer
+        torch.manual_seed(0)
+        m = VisionTransformer(img_size=32, patch_size=16, embed_dim=64, depth=4, num_heads=1, drop_path_rate=0.0).train()
+        m.grad_cuts = (2,)
+        bn = torch.nn.BatchNorm1d(8)                       # buffers: running_mean / running_var / num_batches_tracked
+        bn.running_mean.fill_(float(rank + 1)); bn.num_batches_tracked.fill_(10 * (rank + 1))
+        holder = torch.nn.ModuleList([m, bn])
+        torch.manual_seed(100 + rank)                      # every rank its own shard
+        x = torch.randn(2, 3, 32, 32)
+        y = m(x)
+        y.sum().backward()                                 # range 0: blocks 2-3
+        seg0 = [p for p in m.parameters() if p.grad is not None]
+        (xo, no), (xl, nl) = m.cut_pairs[0]
+        r0 = PackedGradReducer(seg0)
+        local0 = torch.cat([p.grad.reshape(-1) for p in seg0]).clone()
+        r0.all_reduce()                                    # ... exchanged while range 1 runs
+        torch.autograd.backward([xo, no], [xl.grad, nl.grad])
+        ids0 = {id(p) for p in seg0}
+        seg1 = [p for p in m.parameters() if p.grad is not None and id(p) not in ids0]
+        r1 = PackedGradReducer(seg1)
+        local1 = torch.cat([p.grad.reshape(-1) for p in seg1]).clone()
+        r1.all_reduce()
+        check_coverage(m, [r0, r1])
+        errs = []
+        for local, seg in ((local0, seg0), (local1, seg1)):
+            gathered = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(gathered, local)
+            errs.append(float((torch.cat([p.grad.reshape(-1) for p in seg]) - sum(gathered) / world).abs().max()))
+        bb = BufferBroadcaster(holder)
+        bb.broadcast()
+        out.put((rank, max(errs), float(bn.running_mean[0]), int(bn.num_batches_tracked), len(seg0), len(seg1)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_block_range_groups_and_buffer_broadcast_world2_gloo():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_groups_and_buffers, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=200) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, rm, nbt, n0, n1 in res:
+        assert err < 1e-6 and n0 > 0 and n1 > 0
+        assert rm == 1.0 and nbt == 10          # rank 0's statistics everywhere

@@ -339,6 +339,69 @@ def test_data_parallel_step_on_rccl_world_1_equals_the_plain_step(dev):
         dist.destroy_process_group()
 
 
+def test_split_image_backward_groups_and_buffer_broadcast_on_rccl_world_1(dev):
+    """image_bwd_splits=3: the image encoder's backward as three block-range phases with their own weight-gradient flush and
+    reducer group (only the last group's exchange is exposed), plus ddp.BufferBroadcaster at the start of the step -- over
+    RCCL at world 1 with forced collectives: same loss and gradients as the plain step, groups disjoint and complete, and
+    the same under graph replay."""
+    import os
+    import torch.distributed as dist
+    import bench
+    from bridgeqa_amd.ddp import BufferBroadcaster, PackedGradReducer, check_coverage
+    from bridgeqa_amd.pipeline import PhasedTrainStep
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29654", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group(backend="nccl", init_method="env://", rank=0, world_size=1)
+    try:
+        model = _small_model(dev)
+        batch = _batch(dev)
+        plain = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, optimizer=None, use_graphs=False)
+        plain.capture(warmup=0)
+        want_loss = plain.eager_step().item()
+        torch.cuda.synchronize()
+        want = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        bb = BufferBroadcaster(model)
+        bb.force = True
+        dp = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, optimizer=None, use_graphs=True,
+                             image_bwd_splits=3, buffer_broadcaster=bb, coverage_every=2)
+        assert model.blip_model.visual_encoder.grad_cuts == (4, 8)
+
+        def make(ps):
+            r = PackedGradReducer(ps)
+            r.force = True
+            return r
+        reds = dp.attach_reducers(make)
+        assert set(reds) == {"fusion", "det", "image_0", "image_1", "image_2"}
+        ids = [id(p) for r in reds.values() for p in r.params]
+        assert len(ids) == len(set(ids))                                    # disjoint
+        names = {id(p): n for n, p in model.named_parameters()}
+        g0 = {names[id(p)] for p in reds["image_0"].params}
+        g2 = {names[id(p)] for p in reds["image_2"].params}
+        assert any(".blocks.11." in n for n in g0) and any(".blocks.0." in n for n in g2)
+        assert any("patch_embed" in n for n in g2) and not any(".blocks.0." in n for n in g0)
+        got_loss = dp.eager_step().item()
+        dp.wait()
+        torch.cuda.synchronize()
+        check_coverage(model, reds.values())
+        got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+        assert set(got) == set(want)
+        assert abs(got_loss - want_loss) <= 1e-4 * abs(want_loss)
+        worst = max(((got[n] - want[n]).norm() / (want[n].norm() + 1e-12)).item() for n in want)
+        assert worst < 2e-3, worst
+        dp.capture(warmup=1)                                                # graphs: image_bwd, image_bwd_1, image_bwd_2
+        assert {"image_bwd", "image_bwd_1", "image_bwd_2"} <= set(dp.graphs) and "image_bwd_3" not in dp.graphs
+        for _ in range(4):                                                  # (coverage check every 2nd replayed step)
+            l = dp.step()
+        dp.wait()
+        torch.cuda.synchronize()
+        assert abs(l.item() - want_loss) <= 2e-3 * abs(want_loss)
+        got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+        worst = max(((got[n] - want[n]).norm() / (want[n].norm() + 1e-12)).item() for n in want)
+        assert worst < 2e-3, worst
+    finally:
+        model.blip_model.visual_encoder.grad_cuts = ()
+        dist.destroy_process_group()
+
+
 def test_bn_momentum_change_recaptures_the_graphs(dev):
     """BatchNorm momentum is baked into the captured launches; after a BN-momentum scheduler step the phased
     step must re-capture -- with momentum 0 the running statistics must stop moving, the loss keeps going down"""

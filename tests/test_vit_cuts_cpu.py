@@ -1,0 +1,50 @@
+"""vit.VisionTransformer.grad_cuts: the autograd cuts pipeline.PhasedTrainStep(image_bwd_splits=...) uses to run the image
+encoder's backward in block ranges (each range's gradients are exchanged while the next range runs -- what DDP's buckets
+firing during backward do, scripts/train.py:346-347).  The cut forward is the same function, and the backward continued
+range by range produces the same gradients as one backward."""
+import torch
+
+
+def _vit():
+    from bridgeqa_amd.vit import VisionTransformer
+    torch.manual_seed(0)
+    m = VisionTransformer(img_size=32, patch_size=16, embed_dim=64, depth=6, num_heads=1, drop_path_rate=0.0)
+    return m.train()
+
+
+def test_block_range_backward_equals_one_backward():
+    m = _vit()
+    x = torch.randn(2, 3, 32, 32)
+    w = torch.randn(2, 5, 64)
+    m.grad_cuts = ()
+    y0 = m(x)
+    (y0 * w).sum().backward()
+    want = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    for p in m.parameters():
+        p.grad = None
+    m.grad_cuts = (2, 4)
+    y1 = m(x)
+    assert torch.equal(y0, y1) and len(m.cut_pairs) == 2
+    y1.backward(w)                                            # blocks 4-5 (+ final norm, + block 4's norm1 owner: block 3)
+    seen = [{n for n, p in m.named_parameters() if p.grad is not None}]
+    for (xo, no), (xl, nl) in reversed(m.cut_pairs):          # blocks 2-3, then 0-1 + embeddings
+        torch.autograd.backward([xo, no], [xl.grad, nl.grad])
+        seen.append({n for n, p in m.named_parameters() if p.grad is not None})
+    got = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+    assert set(got) == set(want)
+    for n in want:
+        assert torch.allclose(got[n], want[n], rtol=1e-5, atol=1e-6), n
+    # every range produced gradients of its own, the first range (run last) the embeddings'
+    assert seen[0] < seen[1] < seen[2]
+    assert "blocks.5.attn.qkv.weight" in seen[0] and "blocks.0.attn.qkv.weight" not in seen[1]
+    assert "patch_embed.proj.weight" in seen[2] - seen[1]
+    # a block's norm1 is applied by the block BEFORE it (fused add + LayerNorm): its gradient comes from that range
+    assert "blocks.4.norm1.weight" in seen[1] - seen[0]
+
+
+def test_no_cut_without_grad():
+    m = _vit()
+    m.grad_cuts = (2,)
+    with torch.no_grad():
+        m(torch.randn(1, 3, 32, 32))
+    assert m.cut_pairs == []

@@ -1,4 +1,4 @@
-"""forward / backward error of the fused attention against an fp32 composition (set BQ_ATTN_FWD_MODE to compare modes)"""
+"""forward / backward error of the fused attention against an fp32 composition"""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -888,8 +888,9 @@ def gemm_grouped(problems, flags, epilogue=EPI_NONE, tile=None):
         d.p_bytes, d.q_bytes, d.ksplit = int(pr.get("p_bytes", 0)), int(pr.get("q_bytes", 0)), int(pr.get("ksplit", 1))
         if "Kc" in pr:  # contraction longer than the K-contiguous operand's rows (its partner is zero-padded)
             d.Kc = int(pr["Kc"])
-        mid_ok = (not qxc and not f32 and d.Kc >= 128 and colsum is None
-                  and epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_ADD))
+        mid_ok = d.Kc >= 128 and ((not qxc and not f32 and colsum is None
+                                   and epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_ADD))
+                                  or (pxc and qxc and f32 and epilogue == EPI_NONE))
         all_mid_ok = mid_ok if k == 0 else (all_mid_ok and mid_ok)
         t_auto = max(t_auto, pick_tile(Ni, Nj, qxc, True))
     if t_auto == 128 and not (all_mid_ok and GEMM_MID):

@@ -1042,12 +1042,8 @@ static int launch_gemm(const GemmArgs &ga, int flags, int epi, int tile, hipStre
   constexpr int long_k_tiles = 12;
   bool long_k = long_k_tiles > 0 && tile != 256 && ga.total_tiles <= 2048;
   for (int k = 0; k < ga.n; ++k) long_k = long_k && ga.p[k].Kc >= 64 * long_k_tiles;
-  if (tile == 128) {  // csrc/gemm_mid.hip: bf16 out, K-contiguous Q, no column sums
-    if (qxc || f32) return -1;
-    for (int k = 0; k < ga.n; ++k)
-      if (ga.p[k].colsum != nullptr) return -1;
-    return launch_gemm_mid(ga, pxc, epi, st);
-  }
+  if (tile == 128)  // csrc/gemm_mid.hip: forward / dX (bf16 out, K-contiguous Q) and the weight-gradient form
+    return launch_gemm_mid(ga, pxc, qxc, f32, epi, st);
   if (!pxc && !qxc && !f32) {
     if (epi == EPI_NONE) return launch_variant<false, false, EPI_NONE, false>(ga, tile, st, long_k);
     if (epi == EPI_BIAS) return launch_variant<false, false, EPI_BIAS, false>(ga, tile, st, long_k);
@@ -1099,7 +1095,7 @@ extern "C" int bq_gemm_bf16(const bq_gemm_desc *d, int n, int flags, int epilogu
       BQ_REQUIRE(epilogue != EPI_BIAS_GELU || s.out2, BQ_EINVAL, "bq_gemm_bf16: BIAS_GELU needs out2");
       BQ_REQUIRE(epilogue != EPI_DGELU || s.aux, BQ_EINVAL, "bq_gemm_bf16: DGELU needs aux");
       BQ_REQUIRE(epilogue != EPI_ADD || s.aux, BQ_EINVAL, "bq_gemm_bf16: ADD needs aux");
-      BQ_REQUIRE((epilogue != EPI_ADD && epilogue != EPI_DGELU && tile != 128) || ((long)s.Nj + 256) * s.ldo * 2 < 0x7FFFFFFFL,
+      BQ_REQUIRE((epilogue != EPI_ADD && epilogue != EPI_DGELU && tile != 128) || ((long)s.Nj + 256) * s.ldo * (f32 ? 4 : 2) < 0x7FFFFFFFL,
                  BQ_EINVAL, "bq_gemm_bf16: out / aux larger than 2 GB (problem %d)", done);
       const long pb = pxc ? ((long)(s.Kc - 1) * s.ldp + s.Ni) * 2 : ((long)(s.Ni - 1) * s.ldp + s.Kc) * 2;
       const long qb = qxc ? ((long)(s.Kc - 1) * s.ldq + s.Nj) * 2 : ((long)(s.Nj - 1) * s.ldq + s.Kc) * 2;

@@ -42,6 +42,12 @@
 // cursors park on the out-of-range sentinel (zeros, no traffic) so that the counts keep their meaning.
 #include "gemm_common.h"
 
+// measurement builds only (tools/bench_gemm_dw.py): 1 = no MFMAs (the memory stream alone), 2 = no LDS-DMAs
+// (matrix pipe + LDS reads alone; results are garbage)
+#ifndef BQ_MID_ABLATE
+#define BQ_MID_ABLATE 0
+#endif
+
 namespace bq {
 
 // ST_AUX: cache policy of the output stores (buffer-store aux bits: 0 default, 2 nt, 16 sc1 = write-through, the line is
@@ -50,8 +56,10 @@ typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
-template <bool P_XC, int EPI, int ST_AUX>
+template <bool P_XC, bool Q_XC, int EPI, bool OUT_F32, int ST_AUX>
 __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
+  static_assert(!OUT_F32 || (P_XC && Q_XC && EPI == EPI_NONE), "fp32 out = the weight-gradient form");
+  static_assert(!Q_XC || OUT_F32, "a contraction-major Q = the weight-gradient form");
   __shared__ __attribute__((aligned(16))) unsigned char smem[65536 + 4 * 2048];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
   // a unit = 8 DMAs of 1 KB (8 rows x 128 B), two per wave: unit rows (w + 4 d) * 8 + lane / 8
   unsigned vP[2], vQ[2];                // [half]: the next byte offset to stage of DMA (g = 0, d = 0); the other DMAs of
                                         // the group add wave-uniform deltas (in the bounds-checked vector offset)
-  unsigned stepP[2], dgP[2], ddP[2], ddQ[2];   // per group: bytes per K tile / per wave row g / per DMA d of the cursor's problem
+  unsigned stepP[2], dgP[2], ddP[2], ddQ[2], stepQ[2];   // per group: bytes per K tile / per wave row g / per DMA d of the cursor's problem
   int remP[2], remQ[2];                 // K tiles left before the cursor rolls over to the next tile
   int rsrcP_pi[2], rsrcQ_pi[2];         // problem of each cursor (its buffer descriptor)
   const unsigned DEAD = 0x80000000u;    // (+ a few deltas and steps stays out of range)
@@ -117,10 +125,19 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
   };
   auto set_q = [&](int half, const Tile &tt, bool live) {
     const GemmProblem &pr = args.p[tt.pi];
-    // unit row r -> j0 + (r >> 5) * 64 + half * 32 + (r & 31); d = 1 is r + 32: 64 rows further
-    const unsigned v = (unsigned)(((tt.j0 + half * 32 + ur0) * pr.ldq + (cp ^ (ur0 & 7)) * 8) * 2);
+    unsigned v;
+    if (!Q_XC) {
+      // unit row r -> j0 + (r >> 5) * 64 + half * 32 + (r & 31); d = 1 is r + 32: 64 rows further
+      v = (unsigned)(((tt.j0 + half * 32 + ur0) * pr.ldq + (cp ^ (ur0 & 7)) * 8) * 2);
+    } else {
+      // unit row r = contraction index; its 8 chunks of 8 columns: chunk c -> j0 + (c >> 2) * 64 + half * 32 + (c & 3) * 8
+      // (the `half` 32 columns of both wave columns); d = 1 is r + 32
+      const int c = cp ^ (xg(ur0) << 1);
+      v = (unsigned)((ur0 * pr.ldq + tt.j0 + (c >> 2) * 64 + half * 32 + (c & 3) * 8) * 2);
+    }
     vQ[half] = live ? v : DEAD;
-    ddQ[half] = (unsigned)(64 * pr.ldq * 2);
+    ddQ[half] = Q_XC ? (unsigned)(32 * pr.ldq * 2) : (unsigned)(64 * pr.ldq * 2);
+    stepQ[half] = Q_XC ? (unsigned)(64 * pr.ldq * 2) : 128u;
     remQ[half] = live ? tt.nkt : 0x40000000;
     rsrcQ_pi[half] = tt.pi;
   };
@@ -138,8 +155,9 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
     for (int g = 0; g < 2; ++g)
 #pragma unroll
       for (int d = 0; d < 2; ++d)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(smem + (half ? PA1 : PA0) + g * 8192 + (wave + 4 * d) * 1024),
-                                                 16, vP[half] + (g * dgP[half] + d * ddP[half]), 0, 0, 0);
+        if (BQ_MID_ABLATE != 2)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(smem + (half ? PA1 : PA0) + g * 8192 + (wave + 4 * d) * 1024),
+                                                   16, vP[half] + (g * dgP[half] + d * ddP[half]), 0, 0, 0);
     vP[half] += stepP[half];
     if (--remP[half] == 0) set_p(half, nxt, has_next);
   };
@@ -149,9 +167,10 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
     const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)pr.Q, 0, pr.q_bytes, 0x00020000);
 #pragma unroll
     for (int d = 0; d < 2; ++d)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(smem + QB + (par & 1) * 16384 + half * 8192 + (wave + 4 * d) * 1024),
-                                               16, vQ[half] + d * ddQ[half], 0, 0, 0);
-    vQ[half] += 128u;
+      if (BQ_MID_ABLATE != 2)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(smem + QB + (par & 1) * 16384 + half * 8192 + (wave + 4 * d) * 1024),
+                                                 16, vQ[half] + d * ddQ[half], 0, 0, 0);
+    vQ[half] += Q_XC ? stepQ[half] : 128u;
     if (--remQ[half] == 0) set_q(half, nxt, has_next);
   };
 
@@ -164,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
   bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
 #define BQ_MID_MFMA(AO, FB, BO)                                                                       \
   _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int a = 0; a < 4; ++a)      \
-      _Pragma("unroll") for (int b = 0; b < 2; ++b) acc[AO + a][BO + b] =                             \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) if (BQ_MID_ABLATE != 1 || (a == 0 && b == 0)) acc[AO + a][BO + b] =  \
           __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][kk], FB[b][kk], acc[AO + a][BO + b], 0, 0, 0);
 #define BQ_MID_COMPUTE_BEGIN()                              \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
@@ -174,7 +193,22 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
   __builtin_amdgcn_s_setprio(0);                            \
   __builtin_amdgcn_sched_barrier(0);
   constexpr int NPASS = (EPI == EPI_BIAS_GELU) ? 2 : 1;
-  constexpr int NSTORE = 16 * NPASS;   // epilogue stores per wave (4 j blocks x 2 i halves x 2): always issued
+  // epilogue stores per wave, always issued: bf16 4 j blocks x 2 i halves x 2 (x passes); fp32 8 x 4 accumulator blocks + 4
+  // of the column sums
+  constexpr int NSTORE = OUT_F32 ? 36 : 16 * NPASS;
+  // weight-gradient form with pr.colsum set: the column sums of Q over the contraction (the layer's BIAS gradient: sum over
+  // the rows of dY) from all-ones MFMAs on the B fragments, in the waves wr == 0 of the i = 0 tiles (as gemm256_kernel)
+  bf16x8 ones;
+  f32x4 qs[4];
+  if (OUT_F32) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  }
+#define BQ_MID_QSUM(FB, BO)                                                                           \
+  if (OUT_F32 && do_qsum) {                                                                           \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int b = 0; b < 2; ++b)    \
+        qs[BO + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, FB[b][kk], qs[BO + b], 0, 0, 0);   \
+  }
 
   for (bool first = true;; first = false) {
     const GemmProblem &pr = args.p[cur.pi];
@@ -185,6 +219,11 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
     for (int a = 0; a < 8; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_qsum = OUT_F32 && pr.colsum != nullptr && cur.i0 == 0 && wr == 0;   // wave-uniform
+    if (OUT_F32) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) qs[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     for (int kt = 0; kt < cur.nkt; ++kt, ++gk) {
       const unsigned char *qb = smem + QB + (gk & 1) * 16384;
@@ -202,20 +241,22 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fb0[b][kk] = read_frag<false>(qb, bsub + b, kk, kc_base, xc_base);
+        for (int kk = 0; kk < 2; ++kk) fb0[b][kk] = read_frag<Q_XC>(qb, bsub + b, kk, kc_base, xc_base);
       dma_q(1, gk + 1);
       BQ_MID_COMPUTE_BEGIN();
       if (vA0 && vB0) { BQ_MID_MFMA(0, fb0, 0) }
+      if (vB0) { BQ_MID_QSUM(fb0, 0) }
       BQ_MID_COMPUTE_END();
       // ---- p1: QB1 -> A0 x B1 ; restage PA0(t+1)
       BQ_BARRIER();
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fb1[b][kk] = read_frag<false>(qb + 8192, bsub + b, kk, kc_base, xc_base);
+        for (int kk = 0; kk < 2; ++kk) fb1[b][kk] = read_frag<Q_XC>(qb + 8192, bsub + b, kk, kc_base, xc_base);
       dma_p(0);
       BQ_MID_COMPUTE_BEGIN();
       if (vA0 && vB1) { BQ_MID_MFMA(0, fb1, 2) }
+      if (vB1) { BQ_MID_QSUM(fb1, 2) }
       BQ_MID_COMPUTE_END();
       // ---- p2: PA1 -> A1 x B1 ; restage QB0(t+2)
       if (after_stores) wait_vmcnt<6 + NSTORE>(); else wait_vmcnt<6>();
@@ -242,7 +283,32 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
     // chunk c of row j at j*128 + ((c ^ (j & 7)) << 4), one (j block, i half) at a time -- and leave as whole 128-B lines
     // (8 rows per store instruction; stores of 64-B row pieces straight from the accumulators measured 15 % slower on the
     // whole launch).  Bounds-checked buffer stores that ALWAYS issue: the next tile's counted waits know their number.
-    {
+    if (OUT_F32) {
+      // fp32 weight gradients straight from the accumulators (16 B per lane, 64-B row pieces; once per ~260 K tiles).  The
+      // last K tile's two youngest restages first; every store issues (out-of-range offsets are dropped)
+      __builtin_amdgcn_sched_barrier(0);
+      dma_q(0, gk + 1);
+      dma_p(1);
+      __builtin_amdgcn_sched_barrier(0);
+      const int ldo = pr.ldo;
+      const auto rsO = __builtin_amdgcn_make_buffer_rsrc(pr.out, 0, (unsigned)((long)Nj * ldo * 4), 0x00020000);
+      const auto rsS = __builtin_amdgcn_make_buffer_rsrc((void *)pr.colsum, 0, pr.colsum == nullptr ? 0u : (unsigned)(Nj * 4), 0x00020000);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {  // every row of the all-ones product holds the sums: lane row16 has column j's in element 0
+        const int j = jw + b * 16 + row16;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(qs[b][0]), rsS, (do_qsum && q4 == 0) ? (unsigned)(j * 4) : DEAD, 0, 0);
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int j = jw + b * 16 + row16;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+          const int i = iw + a * 16 + q4 * 4;   // Ni % 8 == 0 (host check): a lane's four i are valid together
+          const unsigned off = i < Ni ? (unsigned)((j * ldo + i) * 4) : DEAD;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[a][b]), rsO, off, 0, ST_AUX);
+        }
+      }
+    } else {
       const int ldo = pr.ldo;
       const unsigned obytes = (unsigned)((long)Nj * ldo * 2);
       const auto rsO = __builtin_amdgcn_make_buffer_rsrc(pr.out, 0, obytes, 0x00020000);
@@ -380,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the parked cursors' out-of-range DMAs have written their zeros
 }
 
-int launch_gemm_mid(const GemmArgs &ga, bool p_xc, int epi, hipStream_t stream) {
+int launch_gemm_mid(const GemmArgs &ga, bool p_xc, bool q_xc, bool out_f32, int epi, hipStream_t stream) {
   static int slots = 0;
   if (slots == 0) {
     int dev = 0, cus = 256;
@@ -396,10 +462,17 @@ int launch_gemm_mid(const GemmArgs &ga, bool p_xc, int epi, hipStream_t stream) 
   // 59.7 us, proj 26.6 -> 24.2, fc1 + GELU 104.5 -> 99.9, dX qkv 60.4 -> 57.3)
 #define BQ_MID_LAUNCH(PX, E)                                                                                        \
   do {                                                                                                              \
-    hipLaunchKernelGGL((gemm128_kernel<PX, E, 16>), grid, block, 0, st_, ga);                                       \
+    hipLaunchKernelGGL((gemm128_kernel<PX, false, E, false, 16>), grid, block, 0, st_, ga);                         \
     return 0;                                                                                                       \
   } while (0)
   hipStream_t st_ = stream;
+  if (q_xc || out_f32) {   // the weight-gradient form (fp32 out, column sums on request)
+    if (!(p_xc && q_xc && out_f32 && epi == EPI_NONE)) return -1;
+    hipLaunchKernelGGL((gemm128_kernel<true, true, EPI_NONE, true, 16>), grid, block, 0, st_, ga);
+    return 0;
+  }
+  for (int k = 0; k < ga.n; ++k)
+    if (ga.p[k].colsum != nullptr) return -1;
   if (!p_xc) {
     if (epi == EPI_NONE) BQ_MID_LAUNCH(false, EPI_NONE);
     if (epi == EPI_BIAS) BQ_MID_LAUNCH(false, EPI_BIAS);

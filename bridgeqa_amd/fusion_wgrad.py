@@ -112,6 +112,7 @@ _PLAN_CACHE = {}
 _PLAN_WGRAD = [True]
 _QSUM = [True]
 _QSUM64 = [True]
+_DW_TILE = [256]   # 256: gemm256_kernel (one workgroup per CU); 128: the 256 x 128 persistent kernel's weight-gradient form
 
 
 def plan_big_launches(tiles, cus, max_problems=36, moved_cost=0.011):
@@ -180,20 +181,21 @@ def flush_deferred_items(items):
         big.sort(key=lambda k: -items[k][0].shape[0])
     groups = [big] if big else []
     if big and _PLAN_WGRAD[0]:
-        tiles = [-(-items[k][0].shape[1] // 256) * -(-items[k][1].shape[1] // 256) for k in big]
+        tj = _DW_TILE[0]
+        tiles = [-(-items[k][0].shape[1] // tj) * -(-items[k][1].shape[1] // 256) for k in big]
         cus = torch.cuda.get_device_properties(items[big[0]][0].device).multi_processor_count
-        plan_groups, moved = plan_big_launches(tiles, cus)
+        plan_groups, moved = plan_big_launches(tiles, cus * (256 // tj))
         groups = [[big[j] for j in g] for g in plan_groups]
         small = small + [big[j] for j in moved]
     dbs = {}
-    for tile, idx_groups in ((256, groups), (64, [small] if small else [])):
+    for tile, idx_groups in ((_DW_TILE[0], groups), (64, [small] if small else [])):
         for idx in idx_groups:
             probs = []
             for k in idx:
                 g2, x2 = items[k][0], items[k][1]
                 dws[k] = torch.empty(g2.shape[1], x2.shape[1], dtype=torch.float32, device=g2.device)
                 pr = dict(P=x2, Q=g2, out=dws[k])
-                if items[k][3] is not None and _QSUM[0] and (tile == 256 or _QSUM64[0]):
+                if items[k][3] is not None and _QSUM[0] and (tile != 64 or _QSUM64[0]):
                     # the bias gradient (column sums of dY) from the same launch: four more MFMAs per K tile in a third
                     # of the workgroups instead of a second pass over dY (csrc/gemm.hip, QSUM)
                     dbs[k] = torch.empty(g2.shape[1], dtype=torch.float32, device=g2.device)

@@ -104,11 +104,13 @@ def test_dx_dgelu_colsum(dev, M, N, K, tile):
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 512, 768), (1024, 256, 256), (16400, 768, 768), (320, 3072, 768), (80, 768, 768), (20, 768, 1536)])
-@pytest.mark.parametrize("tile", [256, 64])
+@pytest.mark.parametrize("tile", [256, 128, 64])
 def test_dw(dev, M, N, K, tile):
     """dw = dy^T @ x (contraction over the M rows, any M: the ragged last K tile is zero-filled by the bounds-checked
     LDS-DMA), fp32 out"""
     from bridgeqa_amd import _ext
+    if tile == 128 and M < 128:
+        pytest.skip("the persistent 256 x 128 kernel needs two K tiles")
     dy, x = _rand((M, N), dev, 10), _rand((M, K), dev, 11)
     dw = _ext.gemm_dw(dy, x, tile=tile)
     _check(dw, dy.float().t() @ x.float(), f32=True)
@@ -172,17 +174,17 @@ def test_256x128_tile_grouped_ragged_and_repeatable_under_load(dev):
 
 
 def test_dw_with_bias_gradient_from_the_same_launch(dev):
-    """the weight-gradient form of the 256-tile kernel with colsum set: colsum[j] = sum over the contraction of Q (= the bias
+    """the weight-gradient form of the 256-tile / 256 x 128-tile kernels with colsum set: colsum[j] = sum over the contraction of Q (= the bias
     gradient, column sums of dY), from all-ones MFMAs in the i = 0 tiles; grouped problems of ragged sizes (rows not a
     multiple of 64, out features not a multiple of 256, several i tiles) -- and dW itself unchanged by it"""
     from bridgeqa_amd import _ext
     flags = _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32
     probs, dys = [], []
-    for k, (M, N, K) in enumerate([(1000, 768, 768), (16400, 2304, 768), (1025, 776, 3072), (4416, 1536, 768), (70, 8, 64)]):
+    for k, (M, N, K) in enumerate([(1000, 768, 768), (16400, 2304, 768), (1025, 776, 3072), (4416, 1536, 768), (130, 8, 64)]):
         dy, x = _rand((M, N), dev, 60 + k), _rand((M, K), dev, 80 + k)
         probs.append(dict(P=x, Q=dy, out=torch.empty(N, K, device=dev), colsum=torch.full((N,), float("nan"), device=dev)))
         dys.append(dy)
-    for tile in (256, 64):
+    for tile in (256, 128, 64):
         for p in probs:
             p["colsum"].fill_(float("nan"))
         _ext.gemm_grouped(probs, flags, _ext.EPI_NONE, tile)

@@ -812,7 +812,7 @@ def fuse_point_features(pix, feat, maxpool):
 
 
 # ---- MFMA bf16 GEMM family (csrc/gemm.hip) ------------------------------------------------------------
-GEMM_P_XC, GEMM_Q_XC, GEMM_OUT_F32 = 1, 2, 4
+GEMM_P_XC, GEMM_Q_XC, GEMM_OUT_F32, GEMM_BACKGROUND = 1, 2, 4, 8
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_BIAS_CE, EPI_ADD = 0, 1, 2, 3, 4, 5
 
 
@@ -888,31 +888,35 @@ def gemm_grouped(problems, flags, epilogue=EPI_NONE, tile=None):
         d.p_bytes, d.q_bytes, d.ksplit = int(pr.get("p_bytes", 0)), int(pr.get("q_bytes", 0)), int(pr.get("ksplit", 1))
         if "Kc" in pr:  # contraction longer than the K-contiguous operand's rows (its partner is zero-padded)
             d.Kc = int(pr["Kc"])
-        mid_ok = d.Kc >= 128 and ((not qxc and not f32 and colsum is None
-                                   and epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_ADD))
-                                  or (pxc and qxc and f32 and epilogue == EPI_NONE))
+        # (the 256 x 128 kernel also has a weight-gradient form -- tile=128 on request: measured equal to the 256 x 256 kernel
+        # alone and slower inside the step, so it is never the automatic choice)
+        mid_ok = (not qxc and not f32 and d.Kc >= 128 and colsum is None
+                  and epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_ADD))
         all_mid_ok = mid_ok if k == 0 else (all_mid_ok and mid_ok)
         t_auto = max(t_auto, pick_tile(Ni, Nj, qxc, True))
     if t_auto == 128 and not (all_mid_ok and GEMM_MID):
         t_auto = 256   # (one tile class per launch: every problem of the group must be able to take the 256 x 128 kernel)
     dev = problems[0]["out"].device
+    if (tile or t_auto) != 128:
+        flags &= ~GEMM_BACKGROUND   # (only the persistent 256 x 128 kernel has a reduced grid)
     with torch.cuda.device(dev):
         _check(_lib.bq_gemm_bf16(arr, n, int(flags), int(epilogue), int(tile or t_auto), _stream()), "gemm_bf16")
 
 
-def gemm_fwd(x, w, bias=None, gelu=False, tile=None):
-    """y = x @ w^T + bias (x (M,K), w (N,K) bf16; bias fp32 (N,)); gelu: returns (y_pre, gelu(y_pre))"""
+def gemm_fwd(x, w, bias=None, gelu=False, tile=None, out=None, background=False):
+    """y = x @ w^T + bias (x (M,K), w (N,K) bf16; bias fp32 (N,)); gelu: returns (y_pre, gelu(y_pre)); out: write y there;
+    background: GEMM_BACKGROUND (a side-stream launch that leaves room on every CU)"""
     _mat(x, "x"), _mat(w, "w")
     M, N = x.shape[0], w.shape[0]
     with torch.cuda.device(x.device):
-        y = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+        y = torch.empty(M, N, dtype=torch.bfloat16, device=x.device) if out is None else out
         act = torch.empty_like(y) if gelu else None
     epi = EPI_BIAS_GELU if gelu else (EPI_BIAS if bias is not None else EPI_NONE)
-    gemm_grouped([dict(P=w, Q=x, out=y, bias=bias, out2=act)], 0, epi, tile)
+    gemm_grouped([dict(P=w, Q=x, out=y, bias=bias, out2=act)], GEMM_BACKGROUND if background else 0, epi, tile)
     return (y, act) if gelu else y
 
 
-def gemm_dx(dy, w, pre_act=None, colsum=None, tile=None, add=None):
+def gemm_dx(dy, w, pre_act=None, colsum=None, tile=None, add=None, background=False):
     """dx = dy @ w (dy (M,N), w (N,K) bf16) [* gelu'(pre_act) (M,K)] [+ add (M,K) bf16]; colsum (K,) fp32 += column
     sums of dx"""
     _mat(dy, "dy"), _mat(w, "w")
@@ -921,7 +925,8 @@ def gemm_dx(dy, w, pre_act=None, colsum=None, tile=None, add=None):
         raise RuntimeError("gemm_dx: pre_act and add are exclusive")
     with torch.cuda.device(dy.device):
         dx = torch.empty(M, K, dtype=torch.bfloat16, device=dy.device)
-    gemm_grouped([dict(P=w, Q=dy, out=dx, aux=pre_act if add is None else add, colsum=colsum)], GEMM_P_XC,
+    gemm_grouped([dict(P=w, Q=dy, out=dx, aux=pre_act if add is None else add, colsum=colsum)],
+                 GEMM_P_XC | (GEMM_BACKGROUND if background else 0),
                  EPI_DGELU if pre_act is not None else (EPI_ADD if add is not None else EPI_NONE), tile)
     return dx
 

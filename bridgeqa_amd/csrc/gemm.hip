@@ -1043,7 +1043,7 @@ static int launch_gemm(const GemmArgs &ga, int flags, int epi, int tile, hipStre
   bool long_k = long_k_tiles > 0 && tile != 256 && ga.total_tiles <= 2048;
   for (int k = 0; k < ga.n; ++k) long_k = long_k && ga.p[k].Kc >= 64 * long_k_tiles;
   if (tile == 128)  // csrc/gemm_mid.hip: forward / dX (bf16 out, K-contiguous Q) and the weight-gradient form
-    return launch_gemm_mid(ga, pxc, qxc, f32, epi, st);
+    return launch_gemm_mid(ga, pxc, qxc, f32, epi, (flags & BQ_GEMM_BACKGROUND) != 0, st);
   if (!pxc && !qxc && !f32) {
     if (epi == EPI_NONE) return launch_variant<false, false, EPI_NONE, false>(ga, tile, st, long_k);
     if (epi == EPI_BIAS) return launch_variant<false, false, EPI_BIAS, false>(ga, tile, st, long_k);
@@ -1074,6 +1074,7 @@ extern "C" int bq_gemm_bf16(const bq_gemm_desc *d, int n, int flags, int epilogu
   BQ_REQUIRE(tile == 256 || tile == 128 || tile == 64 || tile == 32, BQ_EINVAL,
              "bq_gemm_bf16: tile must be 256, 128 (= 256 x 128), 64 or 32 (got %d)", tile);
   const bool pxc = flags & BQ_GEMM_P_XC, qxc = flags & BQ_GEMM_Q_XC, f32 = flags & BQ_GEMM_OUT_F32;
+  BQ_REQUIRE(!(flags & BQ_GEMM_BACKGROUND) || tile == 128, BQ_EINVAL, "bq_gemm_bf16: BQ_GEMM_BACKGROUND needs tile 128");
   hipStream_t st = (hipStream_t)stream;
   int done = 0;
   while (done < n) {

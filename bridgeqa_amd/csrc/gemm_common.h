@@ -147,6 +147,6 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // csrc/gemm_mid.hip: the 256 (i) x 128 (j) tile kernel (bf16 out, K-contiguous Q); -1 when it has no such form
-int launch_gemm_mid(const GemmArgs &ga, bool p_xc, bool q_xc, bool out_f32, int epi, hipStream_t st);
+int launch_gemm_mid(const GemmArgs &ga, bool p_xc, bool q_xc, bool out_f32, int epi, bool background, hipStream_t st);
 
 }  // namespace bq

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the parked cursors' out-of-range DMAs have written their zeros
 }
 
-int launch_gemm_mid(const GemmArgs &ga, bool p_xc, bool q_xc, bool out_f32, int epi, hipStream_t stream) {
+int launch_gemm_mid(const GemmArgs &ga, bool p_xc, bool q_xc, bool out_f32, int epi, bool background, hipStream_t stream) {
   static int slots = 0;
   if (slots == 0) {
     int dev = 0, cus = 256;
@@ -456,7 +456,9 @@ int launch_gemm_mid(const GemmArgs &ga, bool p_xc, bool q_xc, bool out_f32, int 
   }
   for (int k = 0; k < ga.n; ++k)
     if (ga.p[k].Kc < 128) return -1;   // (the QB0 cursor runs two K tiles ahead: a tile has at least two)
-  const dim3 grid(ga.total_tiles < slots ? ga.total_tiles : slots), block(256);
+  // background: one workgroup per CU (BQ_GEMM_BACKGROUND, include/bqhip_fusion.h)
+  const int use = background ? (slots + 1) / 2 : slots;
+  const dim3 grid(ga.total_tiles < use ? ga.total_tiles : use), block(256);
   // output stores write-through (sc1): the lines are dropped from the XCD's L2, which then keeps the weight / activation
   // panels the co-scheduled tiles share.  MEASURED against the default policy, every c3 shape: 3-9 % faster (qkv 60.5 ->
   // 59.7 us, proj 26.6 -> 24.2, fc1 + GELU 104.5 -> 99.9, dX qkv 60.4 -> 57.3)

@@ -574,6 +574,8 @@ class _QKVAttention(torch.autograd.Function):
         dkv = sink[0].grad_view(sink[1], kv) if sink is not None else torch.empty_like(kv)
         _ext.attn_bwd(qc, kv[:, :, 0], kv[:, :, 1], out, lse, grad_out.contiguous(), scale, dq, dkv[:, :, 0], dkv[:, :, 1],
                       mask_log2 if has_mask else None, p_drop, seed, st if has_st else None)
+        if sink is not None:
+            sink[0].push_dx(sink[1])
         return dq, dkv, None, None, None, None, None
 
 
@@ -934,10 +936,21 @@ def twin_split(hs):
 # strided slicing of its gradient), each layer's dK/dV for the image segment is written straight into its column block
 # of ONE gradient buffer, and the projection's backward is one dX GEMM (K = 2 * 768 * layers) + one dW GEMM.
 
+_HOIST_BACKGROUND = [False]  # side-stream launches of the hoisted projections with one workgroup per CU (BQ_GEMM_BACKGROUND): measured slower
+
+
 class HoistedKV(object):
-    """K/V projections of `x` (B, L1, 768) for the cross-attention of several layers at once.
-    kv(i): (B, L1, 2, H, 64) strided view for layer slot i; tail_kv(i, t): the same layer's projection of the
-    per-layer second segment t (B, L2, 768), through the same weights (their gradients join in one backward)."""
+    """K/V projections of `x` (B, L1, 768) -- the FIXED tokens of a cross-attention: image tokens / object tokens -- for
+    several layers at once, LEVEL-MAJOR: layer slot i's [key_i; value_i](x) is the contiguous block Y[i] (B, L1, 2, H, 64)
+    (the narrow attention kernels walk K / V rows 3 KB apart; the first version wrote ONE (B, L1, n * 1536) tensor whose
+    rows were 36 KB apart, which cost the attention kernels what the hoisting saved, DESIGN.md §5 c).
+    kv(i): that block; tail_kv(i, t): the same layer's projection of the per-layer second segment t (B, L2, 768), through
+    the same weights (their gradients join in one backward).
+
+    The projections depend on nothing the text levels compute, so on a GPU they run on a SIDE stream, one launch per
+    layer slot with an event each: the text chain (launch-latency bound, a fraction of the CUs) runs beside them and level
+    i's cross-attention waits for event i only.  Backward likewise: as soon as level i's attention backward has written
+    d(Y[i]) the side stream accumulates  dx += d(Y[i]) W_i  (ADD epilogue of the dX GEMM); _HoistedKVFn.backward joins."""
 
     def __init__(self, x, selfattns, heads):
         self.selfattns = list(selfattns)  # BertSelfAttention modules of the cross-attentions, in layer order
@@ -945,63 +958,124 @@ class HoistedKV(object):
         self.heads = heads
         ws = [w for sa in self.selfattns for w in (sa.key.weight, sa.value.weight)]
         bs = [b for sa in self.selfattns for b in (sa.key.bias, sa.value.bias)]
-        self.G = None          # (B, L1, n * 2 * 768) gradient of the hoisted projection, allocated by the first writer
+        self.G = None          # (n, B, L1, 2 * 768) gradient of the hoisted projections, allocated by the first writer
         self.written = set()
         self.tails = []        # (slot, dY (M, 1536), X (M, 768)) parked by the tail projections' backward
         self.wc, self.bc = _cat_shadow(ws, bs)
+        self.nb = self.wc.shape[0] // self.n
         self.x = x
-        outs = _HoistedKVFn.apply(x, self, *ws, *bs)
-        self.y_shape = (x.shape[0], x.shape[1], self.wc.shape[0])
-        self.outs = outs
+        self.want_dx = bool(x.requires_grad)
+        self.ready = None      # per-slot events of the side stream (forward)
+        self.side = None       # the side stream, when one is used
+        self.dx, self.pushed, self.pending = None, set(), None
+        self.y_shape = (self.n,) + tuple(x.shape[:-1]) + (self.nb,)
+        self.outs = _HoistedKVFn.apply(x, self, *ws, *bs)
 
     def kv(self, i):
+        if self.ready is not None and self.ready[i] is not None:
+            torch.cuda.current_stream(self.outs[i].device).wait_event(self.ready[i])
+            self.ready[i] = None
         return self.outs[i]
 
     def block(self, i):
         """rows of the concatenated weight / bias that belong to layer slot i: [key_i; value_i]"""
-        n = self.wc.shape[0] // self.n
+        n = self.nb
         return self.wc[i * n:(i + 1) * n], self.bc[i * n:(i + 1) * n]
 
     def grad_view(self, i, like):
-        """where layer slot i's attention backward writes d(kv(i)): a view of the shared gradient buffer with the
-        strides of kv(i)"""
+        """where layer slot i's attention backward writes d(kv(i)): block i of the shared gradient buffer"""
         if self.G is None:
             self.G = torch.empty(self.y_shape, dtype=like.dtype, device=like.device)
             self.written = set()
+            self.dx, self.pushed, self.pending = None, set(), None
         self.written.add(i)
-        B, L1 = self.y_shape[:2]
-        return self.G.view(B, L1, self.n, 2, self.heads, like.shape[-1])[:, :, i]
+        return self.G[i].view(*self.y_shape[1:-1], 2, self.heads, like.shape[-1])
+
+    def push_dx(self, i):
+        """block i of the gradient buffer is complete: dx += d(Y[i]) W_i (on the side stream when there is one)"""
+        if not self.want_dx or i in self.pushed:
+            return
+        self.pushed.add(i)
+        if self.side is not None:
+            # (the launch itself is issued one push later -- _flush_pending: the text chain's next kernel is then the FIRST
+            # successor of this level's attention backward in the captured graph and the GEMM a later one)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.G.device))
+            pend, self.pending = self.pending, (i, ev)
+            if pend is not None:
+                self._launch_dx(*pend)
+        else:
+            self.dx = _dx2(self.G[i].view(-1, self.nb), self.block(i)[0], add=self.dx)
+
+    def _launch_dx(self, i, ev):
+        self.side.wait_event(ev)
+        self.G.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            self.dx = _dx2(self.G[i].view(-1, self.nb), self.block(i)[0], add=self.dx, background=_HOIST_BACKGROUND[0])
+
+    def take_dx(self, shape):
+        if self.pending is not None:
+            pend, self.pending = self.pending, None
+            self._launch_dx(*pend)
+        dx, self.dx = self.dx, None
+        if self.side is not None and dx is not None:
+            main = torch.cuda.current_stream(dx.device)
+            main.wait_stream(self.side)
+            dx.record_stream(main)
+        return None if dx is None else dx.view(shape)
 
     def tail_kv(self, i, t):
         B, L2 = t.shape[:2]
         return _TailKVFn.apply(t, self, i).view(B, L2, 2, self.heads, -1)
 
 
-def _fwd2(x2, w, b):
+def _fwd2(x2, w, b, out=None, background=False):
     """x2 @ w^T + b for bf16 (M, K) rows and an (N, K) bf16 operand (b bf16 or fp32), native kernels when eligible"""
     if _native_ok(x2, w.shape[0], w.shape[1]):
         from . import _ext
-        return _ext.gemm_fwd(_rows(x2), w, b)
-    return F.linear(x2, w, b if b is None or b.dtype == x2.dtype else b.to(x2.dtype))
+        return _ext.gemm_fwd(_rows(x2), w, b, out=out, background=background)
+    y = F.linear(x2, w, b if b is None or b.dtype == x2.dtype else b.to(x2.dtype))
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
-def _dx2(g2, w):
+def _dx2(g2, w, add=None, background=False):
+    """g2 @ w (+ add)"""
     if _native_dx_ok(g2, w.shape[0], w.shape[1]):
         from . import _ext
-        return _ext.gemm_dx(_rows(g2), w)
-    return torch.mm(g2, w)
+        return _ext.gemm_dx(_rows(g2), w, add=add, background=background)
+    dx = torch.mm(g2, w)
+    return dx if add is None else dx + add
 
 
 class _HoistedKVFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, hold, *wb):
         xb = x if x.dtype == compute_dtype() else x.to(compute_dtype())
-        y = _fwd2(xb.reshape(-1, xb.shape[-1]), hold.wc, hold.bc).view(*xb.shape[:-1], hold.wc.shape[0])
+        x2 = xb.reshape(-1, xb.shape[-1])
+        n, nb = hold.n, hold.nb
+        y = torch.empty(hold.y_shape, dtype=xb.dtype, device=xb.device)
+        y2 = y.view(n, -1, nb)
+        if xb.is_cuda and overlap_enabled(xb) and _native_ok(x2, nb, x2.shape[1]):
+            f = fork("hoist", xb)
+            hold.side, hold.ready = f.side, []
+            with f:
+                f.uses(xb, y)
+                for i in range(n):
+                    _fwd2(x2, *hold.block(i), out=y2[i], background=_HOIST_BACKGROUND[0])
+                    ev = torch.cuda.Event()
+                    ev.record(f.side)
+                    hold.ready.append(ev)
+            y.record_stream(f.main)
+        else:
+            for i in range(n):
+                _fwd2(x2, *hold.block(i), out=y2[i])
         ctx.save_for_backward(xb)
         ctx.hold, ctx.x_dtype, ctx.k = hold, x.dtype, len(wb) // 2
-        B, L1 = y.shape[:2]
-        y6 = y.view(B, L1, hold.n, 2, hold.heads, -1)
-        return tuple(y6[:, :, i] for i in range(hold.n))
+        y6 = y.view(*hold.y_shape[:-1], 2, hold.heads, -1)
+        return tuple(y6[i] for i in range(n))
 
     @staticmethod
     def backward(ctx, *grads):
@@ -1009,35 +1083,39 @@ class _HoistedKVFn(torch.autograd.Function):
         (xb,) = ctx.saved_tensors
         like = next(g for g in grads if g is not None)
         for i, g in enumerate(grads):
-            slot = hold.grad_view(i, like) if (g is None or i not in hold.written) else None
             if g is None:
-                slot.zero_()
-            elif slot is not None or g.data_ptr() != hold.grad_view(i, like).data_ptr():
+                hold.grad_view(i, like).zero_()
+            elif i not in hold.written or g.data_ptr() != hold.grad_view(i, like).data_ptr():
                 hold.grad_view(i, like).copy_(g)  # the gradient did not come from attention_q_kv2's in-place writer
+        dx = None
+        if ctx.needs_input_grad[0]:
+            hold.want_dx = True
+            for i in range(hold.n):
+                hold.push_dx(i)      # (the blocks whose writer did not push them already)
+            dx = hold.take_dx(xb.shape).to(ctx.x_dtype)
         G = hold.G
         hold.G = None
-        G2 = G.view(-1, G.shape[-1])
         x2 = xb.reshape(-1, xb.shape[-1])
-        dx = _dx2(G2, hold.wc).view(xb.shape).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
-        if _defer_ok(G2, x2) and not hold.tails:
-            # inside a deferred-wgrad scope the [key_i; value_i] blocks are ONE parked record (the flush splits its rows
-            # evenly over the 2 n weights); the per-level tail projections parked theirs from _TailKVFn.backward
-            k = ctx.k
-            _park(G2, x2, [sa_w for sa in hold.selfattns for sa_w in (sa.key.weight, sa.value.weight)],
-                  [sa_b for sa in hold.selfattns for sa_b in (sa.key.bias, sa.value.bias)])
+        k, n, nb = ctx.k, hold.n, hold.nb
+        if _defer_ok(G[0].view(-1, nb), x2) and not hold.tails:
+            # inside a deferred-wgrad scope every slot's [key_i; value_i] block is ONE parked record (the flush splits its
+            # rows evenly over the two weights); the per-level tail projections parked theirs from _TailKVFn.backward
+            for i, sa in enumerate(hold.selfattns):
+                _park(G[i].view(-1, nb), x2, [sa.key.weight, sa.value.weight], [sa.key.bias, sa.value.bias])
             return (dx, None) + (None,) * (2 * k)
-        dw, db = _dw_db(G2, x2, True, True)
-        n = dw.shape[0] // hold.n
-        for slot, g2, t2 in hold.tails:  # the per-layer second segments went through the same weights
-            dwt, dbt = _dw_db(g2, t2, True, True)
-            dw[slot * n:(slot + 1) * n].add_(dwt)
-            db[slot * n:(slot + 1) * n].add_(dbt)
-        hold.tails = []
-        h = n // 2
-        k = ctx.k
-        dws = tuple(dw[j * h:(j + 1) * h] for j in range(k))
-        dbs = tuple(db[j * h:(j + 1) * h] for j in range(k))
-        return (dx, None) + dws + dbs
+        dws, dbs = [], []
+        h = nb // 2
+        tails, hold.tails = hold.tails, []
+        for i in range(n):
+            dw, db = _dw_db(G[i].view(-1, nb), x2, True, True)
+            for slot, g2, t2 in tails:  # the per-layer second segments went through the same weights
+                if slot == i:
+                    dwt, dbt = _dw_db(g2, t2, True, True)
+                    dw.add_(dwt)
+                    db.add_(dbt)
+            dws += [dw[:h], dw[h:]]
+            dbs += [db[:h], db[h:]]
+        return (dx, None) + tuple(dws) + tuple(dbs)
 
 
 class _TailKVFn(torch.autograd.Function):
@@ -1117,6 +1195,8 @@ class _QKV2Attention(torch.autograd.Function):
         _ext.attn_bwd2(qc, kv1[:, :, 0], kv1[:, :, 1], kv2[:, :, 0], kv2[:, :, 1], out, lse, grad_out, scale, dq,
                        dkv1[:, :, 0], dkv1[:, :, 1], dkv2[:, :, 0], dkv2[:, :, 1], mask_log2 if has_mask else None,
                        p_drop, seed, st if has_st else None)
+        if sink is not None:
+            sink[0].push_dx(sink[1])
         return dq, dkv1, dkv2, None, None, None, None
 
 
@@ -1159,6 +1239,8 @@ class _TwinQKV2Attention(torch.autograd.Function):
             _ext.attn_bwd2(q[sl], k1[:, :, 0], k1[:, :, 1], k2[:, :, 0], k2[:, :, 1], out[sl], lse, go[sl], scale, dq[sl],
                            d1[:, :, 0], d1[:, :, 1], d2[:, :, 0], d2[:, :, 1], m if has_m else None, p_drop, seeds[g],
                            st if has_st else None)
+        sink_a[0].push_dx(sink_a[1])
+        sink_b[0].push_dx(sink_b[1])
         return dq, d1a, d2a, d1b, d2b, None, None, None, None, None, None
 
 

@@ -234,13 +234,18 @@ BQ_API int bq_fuse_point_features(const int *pix, const float *feat, float *out,
  *   tile: 256 = 256x256 tiles, 8 waves, LDS-DMA pipeline (large M, long contractions: the weight gradients); 128 = 256 (i) x
  *     128 (j) tiles, 4 waves, two workgroups co-resident per CU (large M with SHORT contractions: the forward and
  *     input-gradient forms of the image encoder -- one workgroup's prologue / epilogue runs under the other's MFMAs; bf16
- *     out, K-contiguous Q, no colsum); 64 / 32 = 64 x {64,32} tiles (small M; 32 needs a K-contiguous Q).  All problems
+ *     out, K-contiguous Q, no colsum; also the weight-gradient form, colsum allowed); 64 / 32 = 64 x {64,32} tiles (small M; 32 needs a K-contiguous Q).  All problems
  *     of one call run in ONE launch (grouped GEMM) and must share flags / epilogue.
  * Requirements: 16-byte aligned operands, ldp / ldq / Ni / ldo multiples of 8 (ldo of 4 for fp32), Kc a multiple of
  * 64 for K-contiguous operands (any Kc for contraction-major ones), operands below 2 GB. */
 #define BQ_GEMM_P_XC 1
 #define BQ_GEMM_Q_XC 2
 #define BQ_GEMM_OUT_F32 4
+#define BQ_GEMM_BACKGROUND 8 /* tile 128 only: ONE persistent workgroup per CU instead of two (half the LDS, a quarter of the
+                               wave slots) -- for a large GEMM issued on a side stream beside a chain of short latency-bound
+                               kernels: a full persistent grid holds every CU's LDS until it ends and the chain's kernels
+                               queue behind it (measured: a 7 us projection took 60 us beside the K/V projection of the image
+                               tokens) */
 #define BQ_GEMM_EPI_NONE 0
 #define BQ_GEMM_EPI_BIAS 1
 #define BQ_GEMM_EPI_BIAS_GELU 2

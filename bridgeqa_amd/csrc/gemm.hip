@@ -1052,6 +1052,9 @@ static int launch_gemm(const GemmArgs &ga, int flags, int epi, int tile, hipStre
       hipLaunchKernelGGL((gemm256_kernel<false, false, EPI_BIAS_CE, false>), dim3(ga.total_tiles), dim3(512), 0, st, ga);
       return 0;
     }
+  } else if (!pxc && !qxc && f32) {  // forward with fp32 results (the detector's regression heads: 64 / 32 tiles)
+    if (epi == EPI_NONE && tile != 256) return launch_variant<false, false, EPI_NONE, true>(ga, tile, st);
+    if (epi == EPI_BIAS && tile != 256) return launch_variant<false, false, EPI_BIAS, true>(ga, tile, st);
   } else if (pxc && !qxc && f32) {
     if (epi == EPI_NONE && tile != 256) return launch_variant<true, false, EPI_NONE, true>(ga, tile, st);
   } else if (pxc && !qxc && !f32) {

@@ -71,7 +71,7 @@ class ProposalModule(nn.Module):
             B, C, K = features.shape
             h = pt_utils.rows_conv_bn_relu(pt_utils.to_rows(features), p[0], p[1])
             h = pt_utils.rows_conv_bn_relu(h, p[3], p[4])
-            net = torch.nn.functional.linear(h.float(), p[6].weight.squeeze(-1), p[6].bias)
+            net = pt_utils.rows_linear_f32(h, p[6].weight.squeeze(-1), p[6].bias)
             return net.view(B, K, -1).transpose(1, 2)
         return p(features)
 

@@ -186,6 +186,59 @@ def rows_conv_bn_relu(rows, conv, bn, relu=True):
                                        bn.num_batches_tracked, bn.eps, bn.momentum, relu, False, 1, conv.bias)
 
 
+class _RowsLinearF32(torch.autograd.Function):
+    """y (R, N) fp32 = rows (R, K) bf16 @ W^T + b for an output layer whose width is not a kernel-friendly number (the
+    voting module's 3 + 256 = 259 channels, voting_module.py:27-31; the proposal head's 2 + 3 + 2 NH + 4 NS + NC = 97,
+    proposal_module.py:48-56) through csrc/gemm.hip: the weight is zero-padded to a multiple of 8 output rows (64 for the
+    contraction of the input gradient), the result keeps fp32 (these are the regression outputs the losses read).
+    Backward: dX = dY W (bf16), dW = dY^T X and db = column sums of dY from ONE launch (cut contraction, fp32 atomics)."""
+
+    @staticmethod
+    def forward(ctx, rows, weight, bias):
+        from . import _ext
+        N, K = weight.shape
+        Np, Nc = (N + 7) // 8 * 8, (N + 63) // 64 * 64
+        wp = torch.zeros(Nc, K, dtype=torch.bfloat16, device=rows.device)
+        wp[:N].copy_(weight)
+        bp = None
+        if bias is not None:
+            bp = torch.zeros(Np, dtype=torch.float32, device=rows.device)
+            bp[:N].copy_(bias)
+        out = torch.empty(rows.shape[0], Np, dtype=torch.float32, device=rows.device)
+        _ext.gemm_grouped([dict(P=wp[:Np], Q=rows, out=out, bias=bp)], _ext.GEMM_OUT_F32,
+                          _ext.EPI_BIAS if bp is not None else _ext.EPI_NONE, 64)
+        ctx.save_for_backward(rows, wp)
+        ctx.dims = (N, K, Np, Nc, bias is not None)
+        return out[:, :N]
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _ext
+        rows, wp = ctx.saved_tensors
+        N, K, Np, Nc, has_bias = ctx.dims
+        R = rows.shape[0]
+        gp = torch.zeros(R, Np, dtype=torch.bfloat16, device=g.device)
+        gp[:, :N].copy_(g)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # contraction over the Nc zero-padded weight rows: a row of gp (Np elements) runs into the next one, finite
+            # values against zero weights (include/bqhip_fusion.h, p_bytes / q_bytes)
+            dx = torch.empty(R, K, dtype=torch.bfloat16, device=g.device)
+            _ext.gemm_grouped([dict(P=wp, Q=gp, out=dx, Kc=Nc, q_bytes=gp.numel() * 2)], _ext.GEMM_P_XC, _ext.EPI_NONE)
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dwp = torch.zeros(Np, K, dtype=torch.float32, device=g.device)
+            dbp = torch.zeros(Np, dtype=torch.float32, device=g.device)
+            _ext.gemm_grouped([dict(P=rows, Q=gp, out=dwp, colsum=dbp, ksplit=max(1, min(64, R // 512)))],
+                              _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32, _ext.EPI_NONE, 64)
+            dw, db = dwp[:N], (dbp[:N] if has_bias else None)
+        return dx, dw, db
+
+
+def rows_linear_f32(rows, weight, bias):
+    """fp32 (R, N) = bf16 rows (R, K) @ weight (N, K)^T + bias through the MFMA GEMM family (any N); see _RowsLinearF32"""
+    return _RowsLinearF32.apply(rows, weight, bias)
+
+
 def rows_layer_ok(conv, bn):
     """the layer-side preconditions of rows_conv_bn_relu: a caller that chains several layers checks ALL of them before
     running the first (a fallback after a native layer has run would update that layer's running statistics twice)"""

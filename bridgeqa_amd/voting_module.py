@@ -30,12 +30,12 @@ class VotingModule(nn.Module):
         if (pt_utils.native_rows_ok(seed_features) and self.training and seed_features.shape[1] % 8 == 0
                 and pt_utils.rows_layer_ok(self.conv1, self.bn1) and pt_utils.rows_layer_ok(self.conv2, self.bn2)):
             # point-major rows: conv + BatchNorm + ReLU twice on the native layer (csrc/gemm.hip pwconv + csrc/bn.hip),
-            # the last convolution (259 output channels, no BatchNorm) as a plain linear on the rows.  (Both layers'
+            # the last convolution (259 output channels, no BatchNorm) on the same GEMM family with fp32 results.  (Both layers'
             # preconditions are checked before either runs: no fallback after a BatchNorm update.)
             rows = pt_utils.to_rows(seed_features)
             h = pt_utils.rows_conv_bn_relu(rows, self.conv1, self.bn1)
             h = pt_utils.rows_conv_bn_relu(h, self.conv2, self.bn2)
-            net = F.linear(h.float(), self.conv3.weight.squeeze(-1), self.conv3.bias)
+            net = pt_utils.rows_linear_f32(h, self.conv3.weight.squeeze(-1), self.conv3.bias)
             net = net.view(B, S, -1).transpose(1, 2)
         if net is None:
             net = F.relu(self.bn1(self.conv1(seed_features)))

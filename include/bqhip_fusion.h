@@ -222,7 +222,8 @@ BQ_API int bq_fuse_point_features(const int *pix, const float *feat, float *out,
  * One formulation:  out[j][i] = epilogue( sum_kc P(i, kc) * Q(j, kc) ),  bf16 operands, fp32 accumulation
  * (v_mfma_f32_16x16x32_bf16), out row-major over j with i contiguous (leading dimension ldo).
  *   P: K-contiguous  P[i*ldp + kc]  or, with BQ_GEMM_P_XC, contraction-major  P[kc*ldp + i]  (same for Q / ldq / j):
- *     forward y = x W^T + b : P = W, Q = x            (flags 0,                  i = out feature, j = row)
+ *     forward y = x W^T + b : P = W, Q = x            (flags 0,                  i = out feature, j = row; with
+ *                                                      BQ_GEMM_OUT_F32 (tiles 64 / 32, epilogue NONE / BIAS) y is fp32)
  *     dX = dY W            : P = W (P_XC), Q = dY      (BQ_GEMM_P_XC,             i = in feature,  j = row)
  *     dW = dY^T X          : P = X (P_XC), Q = dY (Q_XC), fp32 out (P_XC|Q_XC|OUT_F32, i = in feature, j = out feature)
  *   epilogue: BQ_GEMM_EPI_NONE; _BIAS: + bias[i] (fp32); _BIAS_GELU: out = bf16(acc + bias), out2 = gelu(out) (exact

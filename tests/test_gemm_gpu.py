@@ -387,3 +387,28 @@ def test_long_contraction_two_k_tiles_per_step(dev, M, N, K, tile):
     # dX = dY W with the contraction over N: a long one needs a wide layer
     dy, w2 = _rand((M, K), dev, 23), _rand((K, N), dev, 24, 0.05)      # dY (M, K_out = K), W (K_out, N_in = N)
     _check(_ext.gemm_dx(dy, w2, tile=tile), dy.float() @ w2.float())
+
+
+@pytest.mark.parametrize("R,K,N", [(16384, 256, 259), (4096, 128, 97), (100, 128, 97), (1000, 64, 8)])
+def test_rows_linear_f32_odd_output_widths(dev, R, K, N):
+    """pytorch_utils.rows_linear_f32 (the detector's 259- / 97-channel output layers, voting_module.py:27-31 /
+    proposal_module.py:48-56, on the MFMA GEMM family with fp32 results) against F.linear on the same bf16-rounded
+    operands: output, input gradient, weight and bias gradients"""
+    from bridgeqa_amd import pytorch_utils as pt
+    torch.manual_seed(0)
+    rows = _rand((R, K), dev, 70).requires_grad_(True)
+    w = (torch.randn(N, K, device=dev) * 0.1).requires_grad_(True)
+    b = torch.randn(N, device=dev).requires_grad_(True)
+    gy = torch.randn(R, N, device=dev)
+    y = pt.rows_linear_f32(rows, w, b)
+    assert y.dtype == torch.float32 and y.shape == (R, N)
+    y.backward(gy)
+    r32 = rows.detach().float().requires_grad_(True)
+    w32 = w.detach().to(torch.bfloat16).float().requires_grad_(True)
+    b32 = b.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.linear(r32, w32, b32)
+    ref.backward(gy.to(torch.bfloat16).float())
+    rel = lambda a, c: ((a.float() - c).norm() / (c.norm() + 1e-20)).item()
+    assert rel(y, ref) < 1e-5
+    assert rel(rows.grad, r32.grad) < 4e-3          # bf16 result
+    assert rel(w.grad, w32.grad) < 1e-4 and rel(b.grad, b32.grad) < 1e-4

@@ -50,6 +50,12 @@ def parse():
     ap.add_argument("--image", type=int, default=None, help="view side in pixels (default 512; c5: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dp-path", action="store_true", help="use the data-parallel step structure even on one GPU")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend (nccl = RCCL; gloo only for --share-device validation runs)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="VALIDATION ONLY: every rank uses cuda:0 (with --backend gloo: RCCL refuses two ranks on one GPU) -- "
+                         "runs the N > 1 control flow (per-rank batches, per-phase gradient groups, buffer broadcast, replica "
+                         "check) on a 1-GPU box; the throughput of such a run means nothing")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the whole train step (forward + backward + fused AdamW) from one HIP graph; "
                          "auto = on for a single GPU")
@@ -410,7 +416,7 @@ def launch_ranks(args):
     import socket
     import subprocess
     have = torch.cuda.device_count()   # (counts devices without initialising the GPU on this image)
-    if have < args.gpus:
+    if have < args.gpus and not args.share_device:
         sys.stderr.write("bench.py: --gpus %d requested, %d visible device(s): refusing to run fewer ranks\n"
                          % (args.gpus, have))
         sys.exit(2)
@@ -436,12 +442,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU product path)"
+    if args.share_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1 or (args.dp_path and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend=args.backend, init_method="env://")
     workload = "c3" if args.workload in ("auto", "c5") else args.workload   # (c5 = the c3 path at the large sizes)
 
     from bridgeqa_amd import _ext, fusion_ops
@@ -620,10 +628,22 @@ def main():
         ev1.record()
         torch.cuda.synchronize()
         fps_alone_ms = ev0.elapsed_time(ev1) / 5
+    replicas_in_sync = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+        # data parallel invariant: after the same number of steps every rank holds the same PARAMETERS (reference: DDP's
+        # gradient averaging, scripts/train.py:346-347) -- one checksum per rank.  (Buffers -- BatchNorm running statistics
+        # -- legitimately differ between a step's forward and the broadcast that opens the next one, as under DDP.)
+        with torch.no_grad():
+            cs = torch.stack([p.detach().double().abs().sum() for p in model.parameters()]).sum().reshape(1)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_in_sync = bool(torch.equal(lo, hi))
+        if rank == 0 and not replicas_in_sync:
+            print("bench.py: parameter checksums differ between ranks: min %r max %r" % (lo.item(), hi.item()), file=sys.stderr)
     assert torch.isfinite(loss).item()
     if rank == 0 and pipe is not None and pipe.phase_events:
         print("GPU ms since the step's first launch, per phase [start -> end on its stream]: " +
@@ -702,6 +722,10 @@ def main():
             out["roofline"] = out["roofline_fps"]
         if world == 1 and not args.no_cpu_baseline and args.workload != "c5":   # (c3 is the headline: its baseline is the one reported)
             out["cpu_baseline"] = cpu_baseline(args, workload)
+        if replicas_in_sync is not None:
+            out["replicas_in_sync"] = replicas_in_sync
+        if args.share_device:
+            out["data"] += " [--share-device validation run: all ranks on one GPU, throughput not meaningful]"
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -1,0 +1,31 @@
+"""bench.py's N > 1 control flow on a ONE-GPU box: two ranks that share cuda:0 over gloo (RCCL refuses two ranks on one
+device).  What runs is what `--gpus 2` runs on two GPUs -- per-rank synthetic batches, the phased step with its per-phase
+packed gradient groups (the image backward in three block ranges), DDP's buffer broadcast, fused AdamW -- except the wire.
+Checked: one JSON line, n_gpus = 2, finite throughput, and the data-parallel invariant: both ranks hold the same parameters
+and buffers after the steps (reference: DistributedDataParallel, scripts/train.py:346-347)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,extra", [("c3", ["--batch", "2", "--points", "4096", "--image", "128"]),
+                                            ("c2", ["--batch", "2", "--points", "4096"])])
+def test_two_ranks_sharing_one_device_stay_in_sync(workload, extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device",
+                        "--workload", workload, "--steps", "3", "--warmup", "2", "--no-cpu-baseline"] + extra,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["replicas_in_sync"] is True, r.stderr[-1500:]
+    assert "validation run" in out["data"]

@@ -62,27 +62,33 @@ __device__ __forceinline__ int xg(int kc) { return ((kc >> 1) & 1) | (((kc >> 3)
 // is rounded to bf16.  Phi(x) = sigmoid(x * (a1 + a3 x^2 + a5 x^4)) on |x| <= 8 (clamped beyond: Phi is 0 / 1 to fp32
 // there): a minimax fit of the Gaussian CDF, max |Phi - Phi_erf| = 3.1e-5, max |gelu - gelu_erf| = 3.1e-5, and the
 // derivative of the fitted function differs from gelu_erf' by <= 1.2e-4 (fit and error scan: DESIGN.md §4.4) -- two
-// orders of magnitude below the bf16 rounding (2^-9 relative) applied to the result.  9 VALU operations per element
+// orders of magnitude below the bf16 rounding (2^-9 relative) applied to the result.  8 VALU operations per element
 // (one v_exp_f32, one v_rcp_f32) instead of ~20 for an erf polynomial: the epilogue runs with the matrix pipe idle.
 constexpr float GELU_A1 = 1.59525515f, GELU_A3 = 7.38511083e-2f, GELU_A5 = -6.82350683e-4f;
 __device__ __forceinline__ float gauss_cdf(float x, float &x2) {
   const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
   x2 = xc * xc;
-  const float z = xc * (GELU_A1 + x2 * (GELU_A3 + x2 * GELU_A5));
-  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
+  constexpr float L = -1.4426950408889634f;   // exp(-z) = exp2(L z): folded into the coefficients (explicit fmas: the
+                                              // library is built with -ffp-contract=off)
+  const float z = xc * __builtin_fmaf(x2, __builtin_fmaf(x2, GELU_A5 * L, GELU_A3 * L), GELU_A1 * L);
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
 }
 __device__ __forceinline__ float gelu_f(float x) {
   float x2;
   return x * gauss_cdf(x, x2);
 }
 __device__ __forceinline__ float dgelu_f(float x) {
-  float x2;
-  const float s = gauss_cdf(x, x2);
-  const float dz = GELU_A1 + x2 * (3.0f * GELU_A3 + x2 * (5.0f * GELU_A5));
-  // (a select of constants, not of the two results: hipcc turns the latter into a branch per element, and in a fully
-  // unrolled epilogue spills around every one of them)
-  const float inside = fabsf(x) <= 8.0f ? 1.0f : 0.0f;
-  return s + inside * (x * s * (1.0f - s) * dz);
+  // d/dx [x s(z(x))] = s + x z'(x) s (1 - s), evaluated at the CLAMPED argument: beyond |x| = 8 the second term is below
+  // 1e-11 and s is 0 / 1 to fp32, so no select is needed (a select of the two results became a branch per element under
+  // hipcc, a select of constants three more instructions); s (1 - s) = s - s^2 as one fma.  15 VALU operations.
+  const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
+  const float x2 = xc * xc;
+  constexpr float L = -1.4426950408889634f;   // exp(-z) = exp2(L z): folded into the coefficients
+  const float z = xc * __builtin_fmaf(x2, __builtin_fmaf(x2, GELU_A5 * L, GELU_A3 * L), GELU_A1 * L);
+  const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
+  const float u = xc * __builtin_fmaf(x2, __builtin_fmaf(x2, 5.0f * GELU_A5, 3.0f * GELU_A3), GELU_A1);
+  const float v = __builtin_fmaf(-s, s, s);
+  return __builtin_fmaf(u, v, s);
 }
 
 // Both functions above are applied to bf16 VALUES (the stored pre-activation), i.e. they have 65536 possible arguments:

@@ -27,7 +27,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short u16;
+typedef __attribute__((address_space(3))) void lds_void_t;
 
+#ifndef BQ_ATTN_DQ_MINW
+#define BQ_ATTN_DQ_MINW 4     // launch bound of the dQ pass: 128 VGPRs (two spilled), four workgroups per CU -- measured 2 / 3 / 4:
+                              // backward 0.331 / 0.307 / 0.297 ms at L = 1025, 6.18 / 6.19 / 5.99 ms at L = 4097 (tools/rebuild_with.sh)
+#endif
+#ifndef BQ_ATTN_FWD_MINW
+#define BQ_ATTN_FWD_MINW 3    // workgroups per CU the PLAIN forward is compiled for (measurement builds: 4)
+#endif
 constexpr int AT_D = 64;      // head dim
 constexpr int AT_QW = 32;     // query rows per wave
 constexpr int AT_NW = 4;      // waves per workgroup
@@ -154,6 +162,57 @@ __device__ __forceinline__ bf16x8 tfrag_tr(const unsigned char *img, int row0, i
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// Two row-major bf16 operands with 64-element rows (K and V of a (batch, head); Q and dO in the dK/dV pass), one 64-row tile
+// of each per step, from global memory straight into the swizzled LDS images by LDS-DMA (buffer_load ... lds: 16 B per
+// lane, lane-linear destination -- 8 lanes = one 128-B row, so the lane at position p of row r fetches chunk
+// p ^ swz_key(r) of that row).  No staging registers, no ds_write, one add of address arithmetic per tile: 16-32 VGPRs and
+// ~30 instructions per tile less than staging through registers.  The workgroup's four waves issue 2 + 2 DMAs of 8 rows
+// each per tile; rows past the operand's last row are outside the descriptor and arrive as zeros (the last tile masks
+// them).  Protocol (TileDma::turn): before tile kt is consumed every wave waits for its own DMAs, the barrier makes all of
+// them visible and says that tile kt - 1's image is no longer read, then tile kt + 1 is issued into that image.
+// A tile is four UNITS of 16 rows (2 DMAs of 8 rows per operand); unit u belongs to wave u, or -- in a ragged edge block
+// whose idle waves have ended (attn_live_waves) -- to the live waves round-robin.
+struct TileDma {
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+  unsigned voffA[2], voffB[2], stepA, stepB, unitA, unitB;   // voff: rows d * 8 + lane / 8 of unit 0
+  int first, stride;
+  __device__ __forceinline__ void init(const __bf16 *A, long a_rs, const __bf16 *B, long b_rs, int rows, int lane, int wid,
+                                       int live = AT_NW) {
+    rsA = __builtin_amdgcn_make_buffer_rsrc((void *)A, 0, (unsigned)((((long)rows - 1) * a_rs + AT_D) * 2), 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc((void *)B, 0, (unsigned)((((long)rows - 1) * b_rs + AT_D) * 2), 0x00020000);
+    first = __builtin_amdgcn_readfirstlane(wid);   // (the DMA's LDS base must be wave-uniform)
+    stride = live;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int row = d * 8 + (lane >> 3);   // (swz_key reads row bits 1-3: the same in every unit)
+      const unsigned ch = (unsigned)(((lane & 7) ^ swz_key(row)) << 4);
+      voffA[d] = (unsigned)(row * (int)a_rs * 2) + ch;
+      voffB[d] = (unsigned)(row * (int)b_rs * 2) + ch;
+    }
+    stepA = (unsigned)(AT_KB * (int)a_rs * 2);
+    stepB = (unsigned)(AT_KB * (int)b_rs * 2);
+    unitA = (unsigned)(16 * (int)a_rs * 2);
+    unitB = (unsigned)(16 * (int)b_rs * 2);
+  }
+  __device__ __forceinline__ void issue(int kt, unsigned char *imgA, unsigned char *imgB) const {
+    for (int u = first; u < AT_NW; u += stride) {   // (one trip when all four waves live)
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t *)(imgA + (u * 2 + d) * 1024), 16,
+                                                 voffA[d] + (unsigned)kt * stepA + (unsigned)u * unitA, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t *)(imgB + (u * 2 + d) * 1024), 16,
+                                                 voffB[d] + (unsigned)kt * stepB + (unsigned)u * unitB, 0, 0, 0);
+      }
+    }
+  }
+};
+
+// live waves of the 128-row block that starts at row `start` of `L`: a wave whose 32 rows all lie past the end has
+// nothing to compute.  It used to stay for the barriers and its share of the staging; now it ENDS at once (before any
+// barrier: an ended wave is not waited for) and the live waves stage its units, so a ragged edge block -- the 1025th
+// token of the ViT: one live wave -- holds one wave slot of its CU for the key loop instead of four.
+__device__ __forceinline__ int attn_live_waves(int L, int start) { return min(AT_NW, (L - start + AT_QW - 1) / AT_QW); }
+
 // One 64-key tile (two 32-key blocks) of the online-softmax forward for the 32 queries of a wave: S^T = K.Q^T from
 // the LDS image s_k, mask / causal / length clamp, running max + rescale, P (with dropout) straight from the
 // accumulator registers into O^T += V^T.P^T from the LDS image s_v.  qrow = this lane's query index.
@@ -264,12 +323,15 @@ __device__ __forceinline__ void fwd_tile(const unsigned char *s_k, const unsigne
 }
 
 // MODE 0: every option at run time; 1: PLAIN (no mask / causal / dropout), last tile peeled; 2: PLAIN + EARLY scores
+// (A ragged tail of 1 .. 32 queries -- L = 1025 = 8 x 128 + the CLS token -- costs a whole extra workgroup per (batch,
+// head) that keeps one wave busy for the full key loop: 14 % of the launch at B = 64, tools/bench_attn_shapes.py L = 1024
+// vs 1025.  Folding the tail into a FIFTH wave of query block 0 was built and measured in round 3: 320-thread workgroups
+// drop the CU from four resident workgroups to three and every shape ran 10-50 % slower; not kept.)
 template <int MINW, int MODE = 0>
 __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
                                                        const __bf16 *__restrict__ V, __bf16 *__restrict__ O,
                                                        float *__restrict__ LSE, AttnDims dm) {
-  // two LDS images per operand: tile kt+1 is committed to the other image while tile kt is consumed => ONE barrier
-  // per tile, and the global loads of tile kt+2 have a whole tile of compute to land
+  // two LDS images per operand: tile kt+1 lands in the other image while tile kt is consumed => ONE barrier per tile
   __shared__ __align__(16) unsigned char s_k[2][AT_KB * 128];
   __shared__ __align__(16) unsigned char s_v[2][AT_KB * 128];
   const float scale_log2e = dm.scale * 1.4426950408889634f;
@@ -277,6 +339,8 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__res
   const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
   const unsigned seed = eff_seed(dm);
   const int q0 = blockIdx.x * AT_QB + wid * AT_QW;  // first query row of this wave
+  const int live = attn_live_waves(dm.Lq, blockIdx.x * AT_QB);
+  if (wid >= live) return;
   const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
   const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
   const __bf16 *Vb = V + b * dm.k_bs + hd * dm.k_hs;
@@ -292,47 +356,31 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__res
   f32x16 o0 = {0}, o1 = {0};
   float m = -INFINITY, lsum = 0.0f;
   const int nkt = (dm.Lk + AT_KB - 1) / AT_KB;
-  uint4 ka, kb, va, vb;
-  const unsigned off_a = stage_off(dm.k_rs, t >> 3, t), off_b = stage_off(dm.k_rs, 32 + (t >> 3), t);
-  auto fetch = [&](int kt) {  // rows past the end repeat the last one (masked by the last tile)
-    const __bf16 *kbase = Kb + (long)kt * AT_KB * dm.k_rs, *vbase = Vb + (long)kt * AT_KB * dm.k_rs;
-    unsigned oa = off_a, ob = off_b;
-    if (kt == nkt - 1) {  // wave-uniform, once per kernel
-      const int lim = dm.Lk - 1 - kt * AT_KB;
-      oa = stage_off(dm.k_rs, min(t >> 3, lim), t);
-      ob = stage_off(dm.k_rs, min(32 + (t >> 3), lim), t);
-    }
-    ka = stage_ld(kbase, oa); kb = stage_ld(kbase, ob);
-    va = stage_ld(vbase, oa); vb = stage_ld(vbase, ob);
-  };
-  auto commit = [&](int buf) {
-    stage_store(s_k[buf], t, ka); stage_store(s_k[buf], t + 256, kb);
-    stage_store(s_v[buf], t, va); stage_store(s_v[buf], t + 256, vb);
-  };
-  auto advance = [&](int kt) {  // after tile kt: commit tile kt+1 (already in registers), fetch tile kt+2
-    if (kt + 1 < nkt) {
-      commit((kt + 1) & 1);
-      if (kt + 2 < nkt) fetch(kt + 2);
-    }
+  TileDma tdma;   // K / V tiles by LDS-DMA
+  tdma.init(Kb, dm.k_rs, Vb, dm.k_rs, dm.Lk, lane, wid, live);
+  auto dma = [&](int kt) { tdma.issue(kt, s_k[kt & 1], s_v[kt & 1]); };
+  // before tile kt: its DMAs (issued one tile earlier) have landed for every wave and every wave has finished reading the
+  // other image (tile kt - 1), which tile kt + 1 then overwrites while tile kt is consumed
+  auto turn = [&](int kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (kt + 1 < nkt) dma(kt + 1);
   };
-  fetch(0);
-  commit(0);
-  if (nkt > 1) fetch(1);
-  __syncthreads();
+  dma(0);
   const bool active = q0 < dm.Lq;  // wave-uniform: a wave whose 32 queries are all past the end only helps staging
   if (MODE == 0) {
     for (int kt = 0; kt < nkt; ++kt) {
+      turn(kt);
       if (active)
         fwd_tile(s_k[kt & 1], s_v[kt & 1], qf, dm, mrow, scale_log2e, seed, bh, q0 + r, kt, kt == nkt - 1, r, h, o0, o1, m, lsum);
-      advance(kt);
     }
   } else {
     for (int kt = 0; kt < nkt - 1; ++kt) {
+      turn(kt);
       if (active)
         fwd_tile<true, false, MODE == 2>(s_k[kt & 1], s_v[kt & 1], qf, dm, nullptr, scale_log2e, seed, bh, q0 + r, kt, false, r, h, o0, o1, m, lsum);
-      advance(kt);
     }
+    turn(nkt - 1);
     if (active)
       fwd_tile<true, true, MODE == 2>(s_k[(nkt - 1) & 1], s_v[(nkt - 1) & 1], qf, dm, nullptr, scale_log2e, seed, bh, q0 + r, nkt - 1, true, r, h, o0, o1, m, lsum);
   }
@@ -585,6 +633,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const __bf16 *__restrict__ Q, c
   const int b = bh / dm.H, hd = bh % dm.H;
   const unsigned seed = eff_seed(dm);
   const int q0 = bx * AT_QB + wid * AT_QW;
+  const int live = attn_live_waves(dm.Lq, bx * AT_QB);
+  if (wid >= live) return;
   const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
   const __bf16 *Gb = dO + b * dm.o_bs + hd * dm.o_hs;
   const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
@@ -616,47 +666,28 @@ __device__ __forceinline__ void attn_bwd_dq_body(const __bf16 *__restrict__ Q, c
   }
   f32x16 a0 = {0}, a1 = {0};
   const int nkt = (dm.Lk + AT_KB - 1) / AT_KB;
-  uint4 ka, kb, va, vb;
-  const unsigned off_a = stage_off(dm.k_rs, t >> 3, t), off_b = stage_off(dm.k_rs, 32 + (t >> 3), t);
-  auto fetch = [&](int kt) {
-    const __bf16 *kbase = Kb + (long)kt * AT_KB * dm.k_rs, *vbase = Vb + (long)kt * AT_KB * dm.k_rs;
-    unsigned oa = off_a, ob = off_b;
-    if (kt == nkt - 1) {  // wave-uniform, once per kernel
-      const int lim = dm.Lk - 1 - kt * AT_KB;
-      oa = stage_off(dm.k_rs, min(t >> 3, lim), t);
-      ob = stage_off(dm.k_rs, min(32 + (t >> 3), lim), t);
-    }
-    ka = stage_ld(kbase, oa); kb = stage_ld(kbase, ob);
-    va = stage_ld(vbase, oa); vb = stage_ld(vbase, ob);
-  };
-  auto commit = [&](int buf) {
-    stage_store(s_k[buf], t, ka); stage_store(s_k[buf], t + 256, kb);
-    stage_store(s_v[buf], t, va); stage_store(s_v[buf], t + 256, vb);
-  };
-  auto advance = [&](int kt) {
-    if (kt + 1 < nkt) {
-      commit((kt + 1) & 1);
-      if (kt + 2 < nkt) fetch(kt + 2);
-    }
+  TileDma tdma;   // K / V tiles by LDS-DMA (see attn_fwd_kernel)
+  tdma.init(Kb, dm.k_rs, Vb, dm.k_rs, dm.Lk, lane, wid, live);
+  auto turn = [&](int kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (kt + 1 < nkt) tdma.issue(kt + 1, s_k[(kt + 1) & 1], s_v[(kt + 1) & 1]);
   };
-  fetch(0);
-  commit(0);
-  if (nkt > 1) fetch(1);
-  __syncthreads();
+  tdma.issue(0, s_k[0], s_v[0]);
   const bool active = q0 < dm.Lq;  // wave-uniform
   if (!PLAIN) {
     for (int kt = 0; kt < nkt; ++kt) {
+      turn(kt);
       if (active)
         dq_tile(s_k[kt & 1], s_v[kt & 1], qf, gf, dm, mrow, c, scale, lse, delta, seed, bh, q0 + r, kt, kt == nkt - 1, r, h, a0, a1);
-      advance(kt);
     }
   } else {
     for (int kt = 0; kt < nkt - 1; ++kt) {
+      turn(kt);
       if (active)
         dq_tile<true, false>(s_k[kt & 1], s_v[kt & 1], qf, gf, dm, nullptr, c, scale, lse, delta, seed, bh, q0 + r, kt, false, r, h, a0, a1);
-      advance(kt);
     }
+    turn(nkt - 1);
     if (active)
       dq_tile<true, true>(s_k[(nkt - 1) & 1], s_v[(nkt - 1) & 1], qf, gf, dm, nullptr, c, scale, lse, delta, seed, bh, q0 + r, nkt - 1, true, r, h, a0, a1);
   }
@@ -859,6 +890,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const __bf16 *__restrict__ Q, 
   const bool seg2 = !PLAIN && bx >= nb1;   // wave-uniform (PLAIN is never used with two segments)
   const int k0 = (seg2 ? bx - nb1 : bx) * AT_QB + wid * AT_QW;  // first key of this wave, in its segment
   const int Lks = seg2 ? dm.Lk2 : dm.Lk;               // keys in this block's segment
+  const int live = attn_live_waves(Lks, (seg2 ? bx - nb1 : bx) * AT_QB);
+  if (wid >= live) return;
   const int kpad0 = seg2 ? dm.nkt1 * 64 : 0;           // padded key index (mask row, dropout hash) of the segment's key 0
   const long ks_rs = seg2 ? dm.k2_rs : dm.k_rs;
   const long ks_off = seg2 ? b * dm.k2_bs + hd * dm.k2_hs : b * dm.k_bs + hd * dm.k_hs;
@@ -880,20 +913,13 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const __bf16 *__restrict__ Q, 
   }
   f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
   const int nqt = (dm.Lq + AT_KB - 1) / AT_KB;
-  uint4 qa, qb, ga, gb;
+  // Q / dO tiles by LDS-DMA (TileDma); the 64 log-sum-exp / delta values of a tile still travel through two registers of
+  // the first wave and are written to LDS right after the barrier, BEFORE the next tile's DMAs are issued (hipcc fences a
+  // ds_write against LDS-DMAs in flight with vmcnt(0))
+  TileDma tdma;
+  tdma.init(Qb, dm.q_rs, Gb, dm.o_rs, dm.Lq, lane, wid, live);
   float rl = 0.f, rd = 0.f;
-  const unsigned offq_a = stage_off(dm.q_rs, t >> 3, t), offq_b = stage_off(dm.q_rs, 32 + (t >> 3), t);
-  const unsigned offg_a = stage_off(dm.o_rs, t >> 3, t), offg_b = stage_off(dm.o_rs, 32 + (t >> 3), t);
-  auto fetch = [&](int qt) {
-    const __bf16 *qbase = Qb + (long)qt * AT_KB * dm.q_rs, *gbase = Gb + (long)qt * AT_KB * dm.o_rs;
-    unsigned qoa = offq_a, qob = offq_b, goa = offg_a, gob = offg_b;
-    if (qt == nqt - 1) {  // wave-uniform, once per kernel: rows past the end repeat the last one
-      const int lim = dm.Lq - 1 - qt * AT_KB, ra = min(t >> 3, lim), rb = min(32 + (t >> 3), lim);
-      qoa = stage_off(dm.q_rs, ra, t); qob = stage_off(dm.q_rs, rb, t);
-      goa = stage_off(dm.o_rs, ra, t); gob = stage_off(dm.o_rs, rb, t);
-    }
-    qa = stage_ld(qbase, qoa); qb = stage_ld(qbase, qob);
-    ga = stage_ld(gbase, goa); gb = stage_ld(gbase, gob);
+  auto fetch = [&](int qt) {   // the row scalars of tile qt into registers
     if (t < AT_KB) {
       const int qq = min(qt * AT_KB + t, dm.Lq - 1);
       rl = lseb[qq];
@@ -913,36 +939,40 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const __bf16 *__restrict__ Q, 
     }
   };
   auto commit = [&](int buf) {
-    stage_store(s_q[buf], t, qa); stage_store(s_q[buf], t + 256, qb);
-    stage_store(s_g[buf], t, ga); stage_store(s_g[buf], t + 256, gb);
     if (t < AT_KB) { s_lse[buf][t] = rl; s_del[buf][t] = rd; }
   };
-  auto advance = [&](int qt) {
+  // before tile qt is consumed: own DMAs / scalar loads landed, barrier (all images visible, tile qt - 1's no longer read),
+  // then tile qt + 1: scalars committed, DMAs issued, the scalars of tile qt + 2 requested
+  auto turn = [&](int qt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (qt + 1 < nqt) {
       commit((qt + 1) & 1);
+      tdma.issue(qt + 1, s_q[(qt + 1) & 1], s_g[(qt + 1) & 1]);
       if (qt + 2 < nqt) fetch(qt + 2);
     }
-    __syncthreads();
   };
   fetch(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   commit(0);
+  tdma.issue(0, s_q[0], s_g[0]);
   if (nqt > 1) fetch(1);
-  __syncthreads();
   const bool active = k0 < Lks;  // wave-uniform: a wave whose 32 keys are all past the end only helps staging
   if (!PLAIN) {
     for (int qt = 0; qt < nqt; ++qt) {
+      turn(qt);
       if (active)
         dkv_tile(s_q[qt & 1], s_g[qt & 1], s_lse[qt & 1], s_del[qt & 1], kf, vf, dm, c, mkey, seed, bh, kpad0 + k0 + r, qt,
                  qt == nqt - 1, r, h, dk0, dk1, dv0, dv1);
-      advance(qt);
     }
   } else {
     for (int qt = 0; qt < nqt - 1; ++qt) {
+      turn(qt);
       if (active)
         dkv_tile<true, false>(s_q[qt & 1], s_g[qt & 1], s_lse[qt & 1], s_del[qt & 1], kf, vf, dm, c, 0.0f, seed, bh,
                               k0 + r, qt, false, r, h, dk0, dk1, dv0, dv1);
-      advance(qt);
     }
+    turn(nqt - 1);
     const int lb = (nqt - 1) & 1;
     if (active)
       dkv_tile<true, true>(s_q[lb], s_g[lb], s_lse[lb], s_del[lb], kf, vf, dm, c, 0.0f, seed, bh, k0 + r, nqt - 1, true,
@@ -1018,12 +1048,12 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_fwd(
                        (const __bf16 *)K, (const __bf16 *)V, (__bf16 *)O, LSE, dm);
     return check_launch("attn_fwd_narrow");
   }
+  const bool plain = !mask && !causal && dm.drop_thresh == 0;
   const dim3 grid((Lq + AT_QB - 1) / AT_QB, B * H);
   // 3 waves / SIMD, and for the ViT's case (no mask, not causal, no dropout) the PLAIN instantiation with the last tile
   // peeled: tools/bench_attn.py sweeps of round 1 / 2 (2 waves: slower; EARLY score issue: no gain)
-  const bool plain = !mask && !causal && dm.drop_thresh == 0;
   if (plain)
-    hipLaunchKernelGGL((attn_fwd_kernel<3, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Q, (const __bf16 *)K,
+    hipLaunchKernelGGL((attn_fwd_kernel<BQ_ATTN_FWD_MINW, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Q, (const __bf16 *)K,
                        (const __bf16 *)V, (__bf16 *)O, LSE, dm);
   else
     hipLaunchKernelGGL((attn_fwd_kernel<3, 0>), grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Q, (const __bf16 *)K,
@@ -1051,7 +1081,7 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_bwd(
              1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr, causal ? 1 : 0};
   dm.nkt1 = (Lk + AT_KB - 1) / AT_KB;  // single key/value segment
   hipStream_t st = (hipStream_t)stream;
-  constexpr int dq_w = 2, dkv_w = 2;   // waves / SIMD: measured (dK/dV at 2: 0.34 -> 0.25 ms, round 1)
+  constexpr int dq_w = BQ_ATTN_DQ_MINW, dkv_w = 2;   // waves / SIMD: measured (dK/dV at 2: 0.34 -> 0.25 ms, round 1)
   const bool plain = !mask && !causal && dm.drop_thresh == 0;
 #define BQ_DQ(W, P) hipLaunchKernelGGL((attn_bwd_dq_kernel<W, P>), dim3((Lq + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, \
                                        st, (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)dO, \

@@ -385,6 +385,27 @@ def gemm_roofline(args, dev):
     return out, tot_f, tot_t, traffic
 
 
+def _attn_pmc(path="profiles/r03_attn_pmc.txt"):
+    """MFMA-busy fractions of the three attention kernels at the c3 shape, read back from the committed counter summary
+    (tools/run_attn_pmc.sh -> tools/pmc_summary.py: per kernel a name line and a '=> MFMA utilisation X %' line; the c3
+    shape's launches come first in the file)"""
+    full = os.path.join(os.path.dirname(os.path.abspath(__file__)), path)
+    if not os.path.exists(full):
+        return None
+    out, cur = {"file": path}, None
+    for line in open(full):
+        for key, pat in (("fwd", "attn_fwd_kernel"), ("dq", "attn_bwd_dq_kernel"), ("dkv", "attn_bwd_dkv_kernel")):
+            if pat in line:
+                cur = key
+        if "MFMA utilisation" in line and cur is not None and cur + "_mfma_busy" not in out:
+            try:
+                out[cur + "_mfma_busy"] = float(line.split("MFMA utilisation")[1].split("%")[0]) / 100.0
+            except ValueError:
+                pass
+            cur = None
+    return out
+
+
 def attn_roofline(args, dev):
     """The fused attention kernels (csrc/attn.hip) at the ViT shape of this run: forward and backward of one block,
     flops = 4 B H L^2 64 forward, 2.5 x that backward (the minimal count; the kernels recompute S: 3.5 x executed)"""
@@ -405,7 +426,7 @@ def attn_roofline(args, dev):
             "bwd": {"us": round(tb * 1e3, 1), "achieved": round(2.5 * fl / tb / 1e9, 1),
                     "frac": round(2.5 * fl / tb / 1e9 / 2500.0, 4), "executed_flops_factor": 3.5},
             "achieved": round(3.5 * fl / (tf + tb) / 1e9, 1), "frac": round(3.5 * fl / (tf + tb) / 1e9 / 2500.0, 4),
-            "pmc_file": "profiles/r02_attn_pmc.txt (MFMA busy: fwd 25.5 %, dQ 34.4 %, dK/dV 32.4 % at this shape)",
+            "pmc": _attn_pmc(),
             "timed_on": "dedicated launches after the timed region, HIP events on the launch stream, median of 10"}
 
 

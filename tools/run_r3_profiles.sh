@@ -6,6 +6,8 @@ mkdir -p $R/gpurun_out/$OUT
 bash tools/run_gemm_pmc.sh $OUT/pmc > /dev/null 2>&1
 cp gpurun_out/$OUT/pmc/gemm_pmc.jsonl gpurun_out/$OUT/gemm_pmc.jsonl; cp gpurun_out/$OUT/pmc/gemm_pmc_summary.txt gpurun_out/$OUT/gemm_pmc_summary.txt
 cp gpurun_out/$OUT/gemm_pmc.jsonl profiles/r03_gemm_pmc.jsonl
+bash tools/run_attn_pmc.sh $OUT/attn > /dev/null 2>&1
+cp gpurun_out/$OUT/attn/attn_pmc_summary.txt profiles/r03_attn_pmc.txt
 bash tools/run_step_profile.sh $OUT/step > gpurun_out/$OUT/step_profile.log 2>&1
 cp gpurun_out/$OUT/step/kernel_stats.csv profiles/r03_c3_kernel_stats.csv
 BQ_PIPE_TRACE=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2> gpurun_out/$OUT/phases.err > /dev/null; grep -E "GPU ms|host ms" gpurun_out/$OUT/phases.err > gpurun_out/$OUT/c3_phases.txt

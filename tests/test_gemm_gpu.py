@@ -412,3 +412,24 @@ def test_rows_linear_f32_odd_output_widths(dev, R, K, N):
     assert rel(y, ref) < 1e-5
     assert rel(rows.grad, r32.grad) < 4e-3          # bf16 result
     assert rel(w.grad, w32.grad) < 1e-4 and rel(b.grad, b32.grad) < 1e-4
+
+
+def test_background_launch_equals_the_full_grid(dev):
+    """BQ_GEMM_BACKGROUND (one persistent workgroup per CU for a side-stream GEMM, include/bqhip_fusion.h): same tiles, same
+    order of accumulation -- bit-equal results for the forward, the ADD-epilogue dX and the weight-gradient forms; the flag is
+    refused for tiles that have no persistent grid"""
+    from bridgeqa_amd import _ext
+    x, w, b = _rand((16400, 768), dev, 90), _rand((1536, 768), dev, 91, 0.05), torch.randn(1536, device=dev)
+    assert torch.equal(_ext.gemm_fwd(x, w, b, background=True), _ext.gemm_fwd(x, w, b))
+    dy, add = _rand((16400, 1536), dev, 92), _rand((16400, 768), dev, 93)
+    assert torch.equal(_ext.gemm_dx(dy, w, add=add, background=True), _ext.gemm_dx(dy, w, add=add))
+    flags = _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32
+    o1, o2 = torch.empty(1536, 768, device=dev), torch.empty(1536, 768, device=dev)
+    _ext.gemm_grouped([dict(P=x, Q=dy, out=o1)], flags | _ext.GEMM_BACKGROUND, _ext.EPI_NONE, 128)
+    _ext.gemm_grouped([dict(P=x, Q=dy, out=o2)], flags, _ext.EPI_NONE, 128)
+    assert torch.equal(o1, o2)
+    import ctypes
+    d = (_ext._GemmDesc * 1)()
+    d[0].P, d[0].Q, d[0].out = x.data_ptr(), dy.data_ptr(), o1.data_ptr()
+    d[0].ldp, d[0].ldq, d[0].ldo, d[0].Ni, d[0].Nj, d[0].Kc = 768, 1536, 768, 768, 1536, 16400
+    assert _ext._lib.bq_gemm_bf16(d, 1, flags | _ext.GEMM_BACKGROUND, _ext.EPI_NONE, 256, None) != 0

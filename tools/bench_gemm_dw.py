@@ -18,8 +18,11 @@ SHAPES = [(2304, 768), (768, 768), (3072, 768), (768, 3072)]
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    args = [a for i, a in enumerate(sys.argv[1:]) if not a.startswith("--") and sys.argv[i] != "--rows"]
     reps = int(args[0]) if args else 5
+    global M
+    if "--rows" in sys.argv:           # contraction length (default: c3's 16400; c5: 131104)
+        M = int(sys.argv[sys.argv.index("--rows") + 1])
     quick = "--quick" in sys.argv      # the per-shape launches of the 256 x 128 kernel only (tools/ablate_gemm_mid.sh)
     alias = "--alias" in sys.argv      # every block's dY is the same tensor: the operands of a launch fit the MALL
     dev = torch.device("cuda:0")

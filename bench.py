@@ -288,8 +288,8 @@ VIT_GEMMS = (("qkv", 2304, 768), ("proj", 768, 768), ("fc1", 3072, 768), ("fc2",
 PROFILE_PMC = os.path.join(ROOT, "profiles", "r03_gemm_pmc.jsonl")       # tools/run_gemm_pmc.sh -> tools/pmc_summary.py --json
 PROFILE_STATS = os.path.join(ROOT, "profiles", "r03_c3_kernel_stats.csv")  # rocprofv3 --kernel-trace --stats of this bench
 # kernel instantiation each launch form runs as (for the in-step averages of the committed profile)
-GEMM_KERNELS = {"fwd": "gemm128_kernel<false, 1, 16>", "fwd_gelu": "gemm128_kernel<false, 2, 16>",
-                "dx": "gemm128_kernel<true, 0, 16>", "dx_dgelu": "gemm128_kernel<true, 3, 16>",
+GEMM_KERNELS = {"fwd": "gemm128_kernel<false, false, 1, false, 16>", "fwd_gelu": "gemm128_kernel<false, false, 2, false, 16>",
+                "dx": "gemm128_kernel<true, false, 0, false, 16>", "dx_dgelu": "gemm128_kernel<true, false, 3, false, 16>",
                 "dw": "gemm256_kernel<true, true, 0, true>"}
 
 
@@ -367,15 +367,25 @@ def gemm_roofline(args, dev):
         else:
             add("dx_" + name, "dx", lambda: _ext.gemm_dx(dy, w), fl, 2.0 * (M * N + N * K + M * K), N, K)
         del x, w, dy, pre
-    probs, fl, by = [], 0.0, 0.0
+    # the weight gradients exactly as the step issues them: the deferred flush of the image backward (fusion_wgrad: launch
+    # plan over the 256-tile problems, bias gradients from the same launches, the planner's small problems on the 64-tile kernel)
+    from bridgeqa_amd import fusion_wgrad
+    items, params, fl, by = [], [], 0.0, 0.0
     for blk in range(12):
         for name, N, K in VIT_GEMMS:
-            probs.append(dict(P=rnd(M, K), Q=rnd(M, N), out=torch.empty(N, K, device=dev)))
+            wp, bp = torch.nn.Parameter(torch.empty(N, K, device=dev)), torch.nn.Parameter(torch.empty(N, device=dev))
+            params += [wp, bp]
+            items.append((rnd(M, N), rnd(M, K), [wp], [bp]))
             fl += 2.0 * M * N * K
             by += 2.0 * M * (N + K) + 4.0 * N * K
-    flags = _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32
-    add("dw_grouped48", "dw", lambda: _ext.gemm_grouped(probs, flags, _ext.EPI_NONE, 256), fl, by, 0, 0)
-    out[-1]["note"] = "all 48 weight gradients of the 12 blocks, one grouped call (36 + 12 problems: two launches)"
+
+    def flush():
+        for p_ in params:
+            p_.grad = None
+        fusion_wgrad.flush_deferred_items(items)
+    add("dw_grouped48", "dw", flush, fl, by, 0, 0)
+    out[-1]["note"] = ("all 48 weight gradients (+ bias gradients) of the 12 blocks through fusion_wgrad.flush_deferred_items: "
+                       "the launch plan the step uses (two 256-tile launches + the planner's small problems on the 64-tile kernel)")
     traffic = ({"hbm_read_bytes": tot_fetch, "hbm_write_bytes": tot_write, "algorithmic_bytes": tot_alg,
                 "ratio": round((tot_fetch + tot_write) / tot_alg, 3), "file": "profiles/r03_gemm_pmc.jsonl",
                 "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, one launch form per process; read = 2 x "

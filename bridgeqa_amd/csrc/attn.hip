@@ -172,9 +172,11 @@ __device__ __forceinline__ bf16x8 tfrag_tr(const unsigned char *img, int row0, i
 // them visible and says that tile kt - 1's image is no longer read, then tile kt + 1 is issued into that image.
 // A tile is four UNITS of 16 rows (2 DMAs of 8 rows per operand); unit u belongs to wave u, or -- in a ragged edge block
 // whose idle waves have ended (attn_live_waves) -- to the live waves round-robin.
+// SAME: both operands have the same row stride (K and V): one set of offsets (two VGPRs less -- what the dQ pass spilled).
+template <bool SAME>
 struct TileDma {
   __amdgpu_buffer_rsrc_t rsA, rsB;
-  unsigned voffA[2], voffB[2], stepA, stepB, unitA, unitB;   // voff: rows d * 8 + lane / 8 of unit 0
+  unsigned voffA[2], voffB[SAME ? 1 : 2], stepA, stepB, unitA, unitB;   // voff: rows d * 8 + lane / 8 of unit 0
   int first, stride;
   __device__ __forceinline__ void init(const __bf16 *A, long a_rs, const __bf16 *B, long b_rs, int rows, int lane, int wid,
                                        int live = AT_NW) {
@@ -187,7 +189,7 @@ struct TileDma {
       const int row = d * 8 + (lane >> 3);   // (swz_key reads row bits 1-3: the same in every unit)
       const unsigned ch = (unsigned)(((lane & 7) ^ swz_key(row)) << 4);
       voffA[d] = (unsigned)(row * (int)a_rs * 2) + ch;
-      voffB[d] = (unsigned)(row * (int)b_rs * 2) + ch;
+      if (!SAME) voffB[d] = (unsigned)(row * (int)b_rs * 2) + ch;
     }
     stepA = (unsigned)(AT_KB * (int)a_rs * 2);
     stepB = (unsigned)(AT_KB * (int)b_rs * 2);
@@ -201,7 +203,7 @@ struct TileDma {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t *)(imgA + (u * 2 + d) * 1024), 16,
                                                  voffA[d] + (unsigned)kt * stepA + (unsigned)u * unitA, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t *)(imgB + (u * 2 + d) * 1024), 16,
-                                                 voffB[d] + (unsigned)kt * stepB + (unsigned)u * unitB, 0, 0, 0);
+                                                 (SAME ? voffA[d] : voffB[d]) + (unsigned)kt * stepB + (unsigned)u * unitB, 0, 0, 0);
       }
     }
   }
@@ -327,10 +329,10 @@ __device__ __forceinline__ void fwd_tile(const unsigned char *s_k, const unsigne
 // head) that keeps one wave busy for the full key loop: 14 % of the launch at B = 64, tools/bench_attn_shapes.py L = 1024
 // vs 1025.  Folding the tail into a FIFTH wave of query block 0 was built and measured in round 3: 320-thread workgroups
 // drop the CU from four resident workgroups to three and every shape ran 10-50 % slower; not kept.)
-template <int MINW, int MODE = 0>
-__global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
-                                                       const __bf16 *__restrict__ V, __bf16 *__restrict__ O,
-                                                       float *__restrict__ LSE, AttnDims dm) {
+template <int MODE>
+__device__ __forceinline__ void attn_fwd_body(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+                                              const __bf16 *__restrict__ V, __bf16 *__restrict__ O,
+                                              float *__restrict__ LSE, const AttnDims &dm) {
   // two LDS images per operand: tile kt+1 lands in the other image while tile kt is consumed => ONE barrier per tile
   __shared__ __align__(16) unsigned char s_k[2][AT_KB * 128];
   __shared__ __align__(16) unsigned char s_v[2][AT_KB * 128];
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__res
   f32x16 o0 = {0}, o1 = {0};
   float m = -INFINITY, lsum = 0.0f;
   const int nkt = (dm.Lk + AT_KB - 1) / AT_KB;
-  TileDma tdma;   // K / V tiles by LDS-DMA
+  TileDma<true> tdma;   // K / V tiles by LDS-DMA
   tdma.init(Kb, dm.k_rs, Vb, dm.k_rs, dm.Lk, lane, wid, live);
   auto dma = [&](int kt) { tdma.issue(kt, s_k[kt & 1], s_v[kt & 1]); };
   // before tile kt: its DMAs (issued one tile earlier) have landed for every wave and every wave has finished reading the
@@ -403,6 +405,15 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__res
     }
     if (h == 0) LSE[(long)bh * dm.Lq + q] = m + __builtin_amdgcn_logf(l);  // v_log_f32 = log2
   }
+}
+
+// (the body is a __device__ function: a __global__ body that instantiates TileDma<> loses its host launch stub -- the host
+// pass fails on the device builtins inside the template without a diagnostic)
+template <int MINW, int MODE = 0>
+__global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
+                                                       const __bf16 *__restrict__ V, __bf16 *__restrict__ O,
+                                                       float *__restrict__ LSE, AttnDims dm) {
+  attn_fwd_body<MODE>(Q, K, V, O, LSE, dm);
 }
 
 // (Round 2's second-generation PLAIN forward -- Q pre-multiplied by scale * log2(e) in bf16, the softmax reference subtracted
@@ -666,7 +677,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const __bf16 *__restrict__ Q, c
   }
   f32x16 a0 = {0}, a1 = {0};
   const int nkt = (dm.Lk + AT_KB - 1) / AT_KB;
-  TileDma tdma;   // K / V tiles by LDS-DMA (see attn_fwd_kernel)
+  TileDma<true> tdma;   // K / V tiles by LDS-DMA (see attn_fwd_kernel)
   tdma.init(Kb, dm.k_rs, Vb, dm.k_rs, dm.Lk, lane, wid, live);
   auto turn = [&](int kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -916,7 +927,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const __bf16 *__restrict__ Q, 
   // Q / dO tiles by LDS-DMA (TileDma); the 64 log-sum-exp / delta values of a tile still travel through two registers of
   // the first wave and are written to LDS right after the barrier, BEFORE the next tile's DMAs are issued (hipcc fences a
   // ds_write against LDS-DMAs in flight with vmcnt(0))
-  TileDma tdma;
+  TileDma<false> tdma;
   tdma.init(Qb, dm.q_rs, Gb, dm.o_rs, dm.Lq, lane, wid, live);
   float rl = 0.f, rd = 0.f;
   auto fetch = [&](int qt) {   // the row scalars of tile qt into registers
@@ -1097,7 +1108,7 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_bwd(
                        (const __bf16 *)V, (const __bf16 *)dO, LSE, (const __bf16 *)O, DELTA, (__bf16 *)dQ, dm);
   else
   {
-    if (plain) BQ_DQ(dq_w, true); else BQ_DQ(dq_w, false);
+    if (plain) BQ_DQ(dq_w, true); else BQ_DQ(2, false);   // (the general instantiation would spill 15 registers at four per CU)
   }
 #undef BQ_DQ
   int rc = check_launch("attn_bwd_dq");

@@ -49,13 +49,18 @@ def main():
     for name, (kind, layer) in LAUNCHES.items():
         if only and name != only:
             continue
-        if kind == "dw":
-            probs = []
+        if kind == "dw":   # exactly what the step issues: the deferred flush (launch plan, bias gradients in the same launches)
+            from bridgeqa_amd import fusion_wgrad
+            items, params = [], []
             for blk in range(12):
                 for n, k in SHAPES.values():
-                    probs.append(dict(P=rnd(M, k), Q=rnd(M, n), out=torch.empty(n, k, device=dev)))
+                    wp, bp = torch.nn.Parameter(torch.empty(n, k, device=dev)), torch.nn.Parameter(torch.empty(n, device=dev))
+                    params += [wp, bp]
+                    items.append((rnd(M, n), rnd(M, k), [wp], [bp]))
             for _ in range(max(1, reps // 2)):
-                _ext.gemm_grouped(probs, _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32, _ext.EPI_NONE, 256)
+                for p_ in params:
+                    p_.grad = None
+                fusion_wgrad.flush_deferred_items(items)
         elif kind == "text":
             x, w, b = rnd(320, 768), rnd(3072, 768, sc=0.05), torch.randn(3072, device=dev)
             for _ in range(reps):

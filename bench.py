@@ -347,7 +347,9 @@ def gemm_roofline(args, dev):
             rec["in_step_avg_us_all_shapes_of_this_kernel"] = round(stats[kn][0], 1)
         p = [r for r in pmc.get(label, []) if r.get("fetch_bytes") is not None]
         if p:
-            rec["pmc"] = {"us": sum(r["avg_us"] for r in p), "mfma_util": p[0].get("mfma_util"),
+            tsum = sum(r["avg_us"] for r in p)
+            rec["pmc"] = {"us": tsum,   # (several kernels per label: the weight-gradient flush; utilisation time-weighted)
+                          "mfma_util": round(sum((r.get("mfma_util") or 0.0) * r["avg_us"] for r in p) / tsum, 4),
                           "hbm_read_bytes": sum(r["fetch_bytes"] for r in p), "hbm_write_bytes": sum(r["write_bytes"] for r in p)}
             tot_fetch += rec["pmc"]["hbm_read_bytes"]
             tot_write += rec["pmc"]["hbm_write_bytes"]
@@ -395,18 +397,18 @@ def gemm_roofline(args, dev):
     return out, tot_f, tot_t, traffic
 
 
-def _attn_pmc(path="profiles/r03_attn_pmc.txt"):
-    """MFMA-busy fractions of the three attention kernels at the c3 shape, read back from the committed counter summary
-    (tools/run_attn_pmc.sh -> tools/pmc_summary.py: per kernel a name line and a '=> MFMA utilisation X %' line; the c3
-    shape's launches come first in the file)"""
+def _attn_pmc(threads, path="profiles/r03_attn_pmc.txt"):
+    """MFMA-busy fractions of the three attention kernels at THIS run's shape, read back from the committed counter summary
+    (tools/run_attn_pmc.sh -> tools/pmc_summary.py: per kernel and launch shape a '<name>  grid <threads>' line followed by
+    the counters and a '=> MFMA utilisation X %' line); `threads` = B * H * ceil(L / 128) workgroups * 256"""
     full = os.path.join(os.path.dirname(os.path.abspath(__file__)), path)
     if not os.path.exists(full):
         return None
-    out, cur = {"file": path}, None
+    out, cur = {"file": path, "grid_threads": threads}, None
     for line in open(full):
         for key, pat in (("fwd", "attn_fwd_kernel"), ("dq", "attn_bwd_dq_kernel"), ("dkv", "attn_bwd_dkv_kernel")):
             if pat in line:
-                cur = key
+                cur = key if line.rstrip().endswith("grid %d" % threads) else None
         if "MFMA utilisation" in line and cur is not None and cur + "_mfma_busy" not in out:
             try:
                 out[cur + "_mfma_busy"] = float(line.split("MFMA utilisation")[1].split("%")[0]) / 100.0
@@ -436,7 +438,7 @@ def attn_roofline(args, dev):
             "bwd": {"us": round(tb * 1e3, 1), "achieved": round(2.5 * fl / tb / 1e9, 1),
                     "frac": round(2.5 * fl / tb / 1e9 / 2500.0, 4), "executed_flops_factor": 3.5},
             "achieved": round(3.5 * fl / (tf + tb) / 1e9, 1), "frac": round(3.5 * fl / (tf + tb) / 1e9 / 2500.0, 4),
-            "pmc": _attn_pmc(),
+            "pmc": _attn_pmc(B * H * -(-L // 128) * 256),
             "timed_on": "dedicated launches after the timed region, HIP events on the launch stream, median of 10"}
 
 

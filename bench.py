@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--points", type=int, default=None, help="points per scene (default 40000; c5: 80000)")
     ap.add_argument("--image", type=int, default=None, help="view side in pixels (default 512; c5: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-geometry-prefetch", action="store_true",
+                    help="c2: compute the sampling / grouping indices inside the step instead of one step ahead on a second stream")
     ap.add_argument("--dp-path", action="store_true", help="use the data-parallel step structure even on one GPU")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend (nccl = RCCL; gloo only for --share-device validation runs)")
@@ -534,6 +536,41 @@ def main():
                 r.force = args.dp_path
                 return r
             reducers = pipe.attach_reducers(make_reducer)
+    geometry_ahead = None
+    if not phased and not args.no_geometry_prefetch:
+        # ---- c2: the sampling / grouping indices (FPS, ball query, three-NN: a latency chain on B workgroups, a quarter
+        # of the step) depend on the point coordinates only, so those of the NEXT batch are computed on a second stream
+        # while this step runs -- what pipeline.PhasedTrainStep does for c3 (next_batch = the static synthetic batch here; a
+        # training loop passes the buffers its loader fills one step ahead).  The captured step reads `geo_cur`.
+        bbone = model.detection_backbone
+        s_geo = torch.cuda.Stream()
+        with torch.no_grad():
+            geo0 = bbone.precompute_geometry(batch["point_clouds"])
+        geo_next = {k: v.clone() for k, v in geo0.items()}
+        geo_cur = {k: v.clone() for k, v in geo0.items()}
+        batch = dict(batch)
+        batch["geometry"] = geo_cur
+        e_geo, e_cur = torch.cuda.Event(), torch.cuda.Event()
+        e_geo.record(torch.cuda.current_stream())
+
+        def geometry_ahead(stage):
+            # stage 0 (before the step's graph is launched): next -> cur.  stage 1 (AFTER it is launched: the host issues
+            # these ~60 eager launches while the graph already runs): the following batch's indices on the second stream
+            if stage == 0:
+                cur_s = torch.cuda.current_stream()
+                cur_s.wait_event(e_geo)              # the indices computed while the previous step ran
+                for k in geo_cur:
+                    geo_cur[k].copy_(geo_next[k])
+                e_cur.record(cur_s)
+                return
+            s_geo.wait_event(e_cur)                  # (geo_next may be refilled now)
+            with torch.cuda.stream(s_geo), torch.no_grad():
+                gnew = bbone.precompute_geometry(batch["point_clouds"])
+                for k in geo_next:
+                    geo_next[k].copy_(gnew[k])
+                e_geo.record(s_geo)
+    if phased:
+        pass
     elif not dp:
         # ---- single GPU: forward + backward + fused AdamW replayed from ONE HIP graph -----------------------
         # (fused multi-tensor AdamW; NB the foreach implementation under capture makes hipStreamEndCapture segfault)
@@ -614,8 +651,12 @@ def main():
         torch.cuda.synchronize()
 
         def step():
+            if geometry_ahead is not None:
+                geometry_ahead(0)
             g.replay()
             after_replay()
+            if geometry_ahead is not None:
+                geometry_ahead(1)
             return static_loss
         graphed = True
         for _ in range(2):
@@ -707,7 +748,9 @@ def main():
                        "points": args.points,
                        "c_in": args.cin, "image": args.image if workload == "c3" else None,
                        "parallelism": "dp%d" % world, "hip_graph": graphed,
-                       "schedule": ("phased: %d graphs on 2 streams" % (6 + (2 if dp else 0))) if phased else "single graph",
+                       "schedule": (("phased: %d graphs on 2 streams" % (6 + (2 if dp else 0))) if phased else
+                                    ("single graph + the next batch's sampling / grouping indices on a second stream"
+                                     if geometry_ahead is not None else "single graph")),
                        "grad_exchange": (("per-phase packed bf16 all-reduce on a comm stream, %d MB on the wire"
                                           % (sum(r.nbytes_on_wire() for r in reducers.values()) >> 20)) if phased
                                          else ("one packed bf16 all-reduce after the fwd+bwd graph, %d MB on the wire"

@@ -30,37 +30,65 @@ int check_launch(const char *what) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// ball query: one wave per centre.  The wave sweeps the scene 64 points at a time; a ballot of
+// ball query: one wave per PAIR of centres.  The wave sweeps the scene 64 points at a time; a ballot of
 // the in-radius lanes plus a prefix popcount gives each hit its slot in ascending-id order, which
 // is exactly the order the reference's serial scan (ball_query_gpu.cu:28-42) produces.
+// A ball with fewer than S points scans the whole scene (625 chunks at N = 40000: the common case at SA1's radius), so
+// the kernel is a stream of the scene's coordinates through L2 per centre -- 15.7 GB per SA1 launch at one centre per
+// wave, 21.7 TB/s.  Hence (round 3): four chunks per trip with all loads issued before the first comparison (the
+// one-chunk loop was a chain of exposed L2 latencies: 1270 -> 720 us), and TWO centres per wave on the same loaded
+// points (half the traffic).  Chunks are consumed in order per centre, so slots, padding and the early exit are exactly
+// the serial scan's.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ball_query_wave_kernel(const float *__restrict__ new_xyz,
                                                               const float *__restrict__ xyz,
                                                               int32_t *__restrict__ idx, int N, int M, float radius2,
                                                               int S) {
   const int b = blockIdx.y;
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (j >= M) return;
+  const int j0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+  if (j0 >= M) return;
+  const bool two = j0 + 1 < M;   // (wave-uniform)
   const int lane = threadIdx.x & 63;
   const float *P = xyz + (size_t)b * N * 3;
-  const float *q = new_xyz + ((size_t)b * M + j) * 3;
-  int32_t *o = idx + ((size_t)b * M + j) * S;
-  const float qx = q[0], qy = q[1], qz = q[2];
-  int cnt = 0, first = 0;
-  for (int base = 0; base < N && cnt < S; base += 64) {
-    const int k = base + lane;
-    bool hit = false;
-    if (k < N) hit = sqdist(qx, qy, qz, P[k * 3 + 0], P[k * 3 + 1], P[k * 3 + 2]) < radius2;
-    const unsigned long long mask = __ballot(hit);
-    if (mask) {
-      if (cnt == 0) first = base + __builtin_ctzll(mask);
-      const int pos = cnt + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-      if (hit && pos < S) o[pos] = k;
-      cnt += __builtin_popcountll(mask);
+  const float *q = new_xyz + ((size_t)b * M + j0) * 3;
+  int32_t *o0 = idx + ((size_t)b * M + j0) * S, *o1 = o0 + S;
+  const float qx0 = q[0], qy0 = q[1], qz0 = q[2];
+  const float qx1 = two ? q[3] : qx0, qy1 = two ? q[4] : qy0, qz1 = two ? q[5] : qz0;
+  int cnt0 = 0, first0 = 0, cnt1 = two ? 0 : S, first1 = 0;
+  constexpr int U = 4;
+  for (int base = 0; base < N && (cnt0 < S || cnt1 < S); base += 64 * U) {
+    float px[U], py[U], pz[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = min(base + 64 * u + lane, N - 1);
+      px[u] = P[k * 3 + 0]; py[u] = P[k * 3 + 1]; pz[u] = P[k * 3 + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = base + 64 * u + lane;
+      const bool in = k < N;
+      const bool hit0 = in && cnt0 < S && sqdist(qx0, qy0, qz0, px[u], py[u], pz[u]) < radius2;
+      const bool hit1 = in && cnt1 < S && sqdist(qx1, qy1, qz1, px[u], py[u], pz[u]) < radius2;
+      const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
+      if (m0) {
+        if (cnt0 == 0) first0 = base + 64 * u + __builtin_ctzll(m0);
+        const int pos = cnt0 + __builtin_popcountll(m0 & ((1ull << lane) - 1ull));
+        if (hit0 && pos < S) o0[pos] = k;
+        cnt0 += __builtin_popcountll(m0);
+      }
+      if (m1) {
+        if (cnt1 == 0) first1 = base + 64 * u + __builtin_ctzll(m1);
+        const int pos = cnt1 + __builtin_popcountll(m1 & ((1ull << lane) - 1ull));
+        if (hit1 && pos < S) o1[pos] = k;
+        cnt1 += __builtin_popcountll(m1);
+      }
     }
   }
-  if (cnt > S) cnt = S;
-  for (int s = cnt + lane; s < S; s += 64) o[s] = first;  // pad with the first hit (0 if none)
+  if (cnt0 > S) cnt0 = S;
+  if (cnt1 > S) cnt1 = S;
+  for (int s = cnt0 + lane; s < S; s += 64) o0[s] = first0;  // pad with the first hit (0 if none)
+  if (two)
+    for (int s = cnt1 + lane; s < S; s += 64) o1[s] = first1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -411,7 +439,7 @@ extern "C" int bq_ball_query(const float *new_xyz, const float *xyz, int32_t *id
   BQ_REQUIRE(new_xyz && idx && (xyz || N == 0), BQ_EINVAL, "ball_query: null pointer");
   BQ_REQUIRE(B <= 65535, BQ_ELIMIT, "ball_query: B=%d > 65535", B);
   const float radius2 = radius * radius;  // ball_query_gpu.cu:22, rounded to fp32 on the host
-  hipLaunchKernelGGL(ball_query_wave_kernel, dim3(cdiv(M, 4), B), dim3(256), 0, (hipStream_t)stream, new_xyz, xyz,
+  hipLaunchKernelGGL(ball_query_wave_kernel, dim3(cdiv(M, 8), B), dim3(256), 0, (hipStream_t)stream, new_xyz, xyz,
                      idx, N, M, radius2, nsample);
   return check_launch("ball_query");
 }

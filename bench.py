@@ -564,7 +564,8 @@ def main():
                 e_cur.record(cur_s)
                 return
             s_geo.wait_event(e_cur)                  # (geo_next may be refilled now)
-            with torch.cuda.stream(s_geo), torch.no_grad():
+            from bridgeqa_amd.pointnet2_utils import background_geometry
+            with torch.cuda.stream(s_geo), torch.no_grad(), background_geometry():
                 gnew = bbone.precompute_geometry(batch["point_clouds"])
                 for k in geo_next:
                     geo_next[k].copy_(gnew[k])

@@ -33,6 +33,7 @@ _SIGS = {
     "bq_gather_points": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "bq_gather_points_grad": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "bq_ball_query": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
+    "bq_ball_query_background": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
     "bq_group_points": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "bq_group_points_grad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "bq_three_nn": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -148,14 +149,16 @@ def gather_points_grad(grad_out, idx, n):
     return out
 
 
-def ball_query(new_xyz, xyz, radius, nsample):
+def ball_query(new_xyz, xyz, radius, nsample, background=False):
+    """background: bq_ball_query_background (same results on about one workgroup per CU: for a query issued ahead of time on
+    a second stream, include/bqhip.h)"""
     _req(new_xyz, torch.float32, "new_xyz"); _req(xyz, torch.float32, "xyz"); _same_device(new_xyz, xyz)
     B, M, _ = new_xyz.shape
     N = xyz.shape[1]
     with torch.cuda.device(xyz.device):
         idx = torch.empty(B, M, nsample, dtype=torch.int32, device=xyz.device)
-        _check(_lib.bq_ball_query(_p(new_xyz), _p(xyz), _p(idx), B, N, M, float(radius), int(nsample), _stream()),
-               "ball_query")
+        fn = _lib.bq_ball_query_background if background else _lib.bq_ball_query
+        _check(fn(_p(new_xyz), _p(xyz), _p(idx), B, N, M, float(radius), int(nsample), _stream()), "ball_query")
     return idx
 
 

@@ -45,11 +45,12 @@ __global__ __launch_bounds__(256) void ball_query_wave_kernel(const float *__res
                                                               int32_t *__restrict__ idx, int N, int M, float radius2,
                                                               int S) {
   const int b = blockIdx.y;
-  const int j0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
-  if (j0 >= M) return;
-  const bool two = j0 + 1 < M;   // (wave-uniform)
   const int lane = threadIdx.x & 63;
   const float *P = xyz + (size_t)b * N * 3;
+  // (grid-stride over the centre pairs: bq_ball_query_background launches about one workgroup per CU, so that a large
+  // query running beside latency-bound kernels of another stream does not hold every wave slot of the chip)
+  for (int j0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2; j0 < M; j0 += gridDim.x * 8) {
+  const bool two = j0 + 1 < M;   // (wave-uniform)
   const float *q = new_xyz + ((size_t)b * M + j0) * 3;
   int32_t *o0 = idx + ((size_t)b * M + j0) * S, *o1 = o0 + S;
   const float qx0 = q[0], qy0 = q[1], qz0 = q[2];
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(256) void ball_query_wave_kernel(const float *__res
   for (int s = cnt0 + lane; s < S; s += 64) o0[s] = first0;  // pad with the first hit (0 if none)
   if (two)
     for (int s = cnt1 + lane; s < S; s += 64) o1[s] = first1;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -432,16 +434,37 @@ using namespace bq;
 extern "C" int bq_abi_version(void) { return BQHIP_ABI_VERSION; }
 extern "C" const char *bq_last_error(void) { return bq::g_err; }
 
-extern "C" int bq_ball_query(const float *new_xyz, const float *xyz, int32_t *idx, int B, int N, int M, float radius,
-                             int nsample, void *stream) {
+static int ball_query_launch(const float *new_xyz, const float *xyz, int32_t *idx, int B, int N, int M, float radius,
+                             int nsample, bool background, void *stream) {
   BQ_REQUIRE(B >= 0 && N >= 0 && M >= 0 && nsample >= 0, BQ_EINVAL, "ball_query: bad extents");
   if (B == 0 || M == 0 || nsample == 0) return BQ_OK;
   BQ_REQUIRE(new_xyz && idx && (xyz || N == 0), BQ_EINVAL, "ball_query: null pointer");
   BQ_REQUIRE(B <= 65535, BQ_ELIMIT, "ball_query: B=%d > 65535", B);
   const float radius2 = radius * radius;  // ball_query_gpu.cu:22, rounded to fp32 on the host
-  hipLaunchKernelGGL(ball_query_wave_kernel, dim3(cdiv(M, 8), B), dim3(256), 0, (hipStream_t)stream, new_xyz, xyz,
+  int gx = cdiv(M, 8);   // a workgroup = 4 waves = 8 centres
+  if (background) {      // about one workgroup per CU over the whole batch (bq_ball_query_background, include/bqhip.h)
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0;
+      cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    }
+    const int per_scene = cus / B > 0 ? cus / B : 1;
+    if (per_scene < gx) gx = per_scene;
+  }
+  hipLaunchKernelGGL(ball_query_wave_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, new_xyz, xyz,
                      idx, N, M, radius2, nsample);
   return check_launch("ball_query");
+}
+
+extern "C" int bq_ball_query(const float *new_xyz, const float *xyz, int32_t *idx, int B, int N, int M, float radius,
+                             int nsample, void *stream) {
+  return ball_query_launch(new_xyz, xyz, idx, B, N, M, radius, nsample, false, stream);
+}
+
+extern "C" int bq_ball_query_background(const float *new_xyz, const float *xyz, int32_t *idx, int B, int N, int M,
+                                        float radius, int nsample, void *stream) {
+  return ball_query_launch(new_xyz, xyz, idx, B, N, M, radius, nsample, true, stream);
 }
 
 extern "C" int bq_gather_points(const float *points, const int32_t *idx, float *out, int B, int C, int N, int M,

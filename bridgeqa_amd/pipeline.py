@@ -128,7 +128,9 @@ class PhasedTrainStep(object):
 
     def _geometry(self):
         """sampling / grouping indices of the next batch, into the persistent `next` buffers"""
-        geo = self.model.detection_backbone.precompute_geometry(self.next_batch["point_clouds"])
+        from .pointnet2_utils import background_geometry
+        with background_geometry():   # (the gentle ball-query grid: this phase runs beside the fusion chain)
+            geo = self.model.detection_backbone.precompute_geometry(self.next_batch["point_clouds"])
         if self._geo_next is None:
             self._geo_next = {k: v.clone() for k, v in geo.items()}
         else:

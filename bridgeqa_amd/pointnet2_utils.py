@@ -31,6 +31,23 @@ def backend_is_hip():
     return _ext is _hip_ext
 
 
+_BACKGROUND_GEOMETRY = [False]
+
+
+class background_geometry(object):
+    """with background_geometry(): ... -- the ball queries issued inside run on bq_ball_query_background's grid (about
+    one workgroup per CU, same results).  For geometry computed AHEAD of time on a second stream (pipeline.PhasedTrainStep's
+    prefetch of the next batch's indices under the fusion phase): the full grid holds every wave slot of the chip and the
+    other stream's latency-bound kernels queue behind it.  No effect on other backends (the CPU oracle in tests)."""
+
+    def __enter__(self):
+        self.prev, _BACKGROUND_GEOMETRY[0] = _BACKGROUND_GEOMETRY[0], backend_is_hip()
+        return self
+
+    def __exit__(self, *a):
+        _BACKGROUND_GEOMETRY[0] = self.prev
+
+
 class FurthestPointSampling(Function):
     """xyz (B,N,3) f32, npoint -> (B,npoint) i32   [pointnet2_utils.py:51-80]"""
 
@@ -129,7 +146,10 @@ class BallQuery(Function):
 
     @staticmethod
     def forward(ctx, radius, nsample, xyz, new_xyz):
-        inds = _ext.ball_query(new_xyz, xyz, radius, nsample)
+        if _BACKGROUND_GEOMETRY[0]:   # (inside background_geometry(): the HIP backend's gentle grid, same results)
+            inds = _ext.ball_query(new_xyz, xyz, radius, nsample, background=True)
+        else:
+            inds = _ext.ball_query(new_xyz, xyz, radius, nsample)
         ctx.mark_non_differentiable(inds)
         return inds
 

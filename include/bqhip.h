@@ -81,6 +81,13 @@ BQ_API int bq_gather_points_grad(const float *grad_out, const int32_t *idx, floa
  *   needed).  NB argument order follows `_ext.ball_query(new_xyz, xyz, radius, nsample)`. */
 BQ_API int bq_ball_query(const float *new_xyz, const float *xyz, int32_t *idx, int B, int N, int M,
                   float radius, int nsample, void *stream);
+/* The same query (same kernel, same results) on a grid of about ONE workgroup per CU instead of one per 8 centres: for a
+ * call that runs AHEAD of time on a second stream (the next batch's neighbourhoods under the current step,
+ * bridgeqa_amd/pipeline.py) beside chains of short latency-bound kernels.  The full grid holds every wave slot of the
+ * chip for the length of the scan and the other stream's kernels queue behind it; this one takes 4x as long and leaves
+ * three quarters of the slots free (measured in the c3 step: 38.1 -> 37.8 ms). */
+BQ_API int bq_ball_query_background(const float *new_xyz, const float *xyz, int32_t *idx, int B, int N, int M,
+                                    float radius, int nsample, void *stream);
 
 /* group_points  (group_points.cpp:12-36, group_points_gpu.cu:8-39)
  *   out[b,c,j,k] = points[b,c,idx[b,j,k]];  points (B,C,N), idx (B,M,S), out (B,C,M,S) */

@@ -257,3 +257,14 @@ def test_point_major_and_bf16_grouping_vs_oracle_composition(ext, oracle, dev):
             if C:
                 want_f = oracle.group_points_grad(go_ref[:, 3:].contiguous(), idx, N).transpose(1, 2)  # (B, N, C)
                 torch.testing.assert_close(gf.cpu(), want_f, rtol=tol, atol=tol)
+
+
+@pytest.mark.gpu
+def test_ball_query_background_grid_equals_the_full_grid(ext, dev):
+    """bq_ball_query_background (about one workgroup per CU, grid-stride over the centre pairs): the same indices as
+    bq_ball_query at SA1's size, with an odd centre count and batch sizes on both sides of the CU count"""
+    torch.manual_seed(3)
+    for B, N, M, r, S in ((16, 40000, 2048, 0.2, 64), (3, 5000, 777, 0.4, 32), (300, 200, 9, 0.5, 16)):
+        xyz = torch.rand(B, N, 3, device=dev) * 4.0
+        new_xyz = xyz[:, torch.randperm(N, device=dev)[:M]].contiguous()
+        assert torch.equal(ext.ball_query(new_xyz, xyz, r, S, background=True), ext.ball_query(new_xyz, xyz, r, S))

@@ -444,6 +444,17 @@ def attn_roofline(args, dev):
             "timed_on": "dedicated launches after the timed region, HIP events on the launch stream, median of 10"}
 
 
+def _json_safe(x):
+    """NaN / inf -> null: the bench line must be strict JSON"""
+    if isinstance(x, float):
+        return x if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _json_safe(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_json_safe(v) for v in x]
+    return x
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N fresh ranks (one process per GPU, RCCL) through
     torch.distributed.run as a CHILD process, before this process has made any GPU call, and exit with its code.  Never
@@ -564,12 +575,30 @@ def main():
                 e_cur.record(cur_s)
                 return
             s_geo.wait_event(e_cur)                  # (geo_next may be refilled now)
+            with torch.cuda.stream(s_geo):
+                if geo_graph[0] is not None:
+                    geo_graph[0].replay()            # (one launch: ~60 eager launches per step made the step host-sensitive)
+                else:
+                    geo_body()
+                e_geo.record(s_geo)
+
+        def geo_body():
             from bridgeqa_amd.pointnet2_utils import background_geometry
-            with torch.cuda.stream(s_geo), torch.no_grad(), background_geometry():
+            with torch.no_grad(), background_geometry():
                 gnew = bbone.precompute_geometry(batch["point_clouds"])
                 for k in geo_next:
                     geo_next[k].copy_(gnew[k])
-                e_geo.record(s_geo)
+        geo_graph = [None]
+        if use_graph:
+            with torch.cuda.stream(s_geo):
+                for _ in range(2):
+                    geo_body()
+            torch.cuda.synchronize()
+            gg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gg, stream=s_geo):
+                geo_body()
+            torch.cuda.synchronize()
+            geo_graph[0] = gg
     if phased:
         pass
     elif not dp:
@@ -687,6 +716,8 @@ def main():
         else:
             with torch.cuda.stream(side):
                 for _ in range(min(args.steps, 3)):
+                    if geometry_ahead is not None:
+                        geo_body()   # (the prefetched indices come from a replayed graph too: the same launches, eagerly)
                     eager_step()
         torch.cuda.synchronize()
     timer.unwrap()
@@ -803,7 +834,7 @@ def main():
             out["replicas_in_sync"] = replicas_in_sync
         if args.share_device:
             out["data"] += " [--share-device validation run: all ranks on one GPU, throughput not meaningful]"
-        print(json.dumps(out))
+        print(json.dumps(_json_safe(out)))
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -780,7 +780,7 @@ def main():
                        "points": args.points,
                        "c_in": args.cin, "image": args.image if workload == "c3" else None,
                        "parallelism": "dp%d" % world, "hip_graph": graphed,
-                       "schedule": (("phased: %d graphs on 2 streams" % (6 + (2 if dp else 0))) if phased else
+                       "schedule": (("phased: %d graphs on 2 streams" % (len(pipe.graphs or ()) if pipe is not None else 0)) if phased else
                                     ("single graph + the next batch's sampling / grouping indices on a second stream"
                                      if geometry_ahead is not None else "single graph")),
                        "grad_exchange": (("per-phase packed bf16 all-reduce on a comm stream, %d MB on the wire"

@@ -47,6 +47,9 @@ import torch
 from . import fusion_ops as ops
 
 
+_DET_LOSS_LATE = [True]   # the fusion waits for the detector's outputs only (False: also for its loss, as before round 3)
+
+
 class PhasedTrainStep(object):
     def __init__(self, model, batch, det_loss, fusion_loss, optimizer=None, use_graphs=True, det_priority=0,
                  grad_hook=None, next_batch=None, prefetch_geometry=None, eager_phases=(), reducers=None,
@@ -149,7 +152,11 @@ class PhasedTrainStep(object):
             dd["geometry"] = self._geo_cur
         dd = self.model.detect_objects(dd)
         self._state["dd"] = dd
-        self._state["det_loss"] = self.det_loss(dd)
+
+    def _det_loss(self):
+        """the detection loss (~200 short launches, 1 ms) as a phase of its own: the fusion waits for the detector's OUTPUTS
+        (e_det_fwd), not for its loss, which then runs on the detector stream beside the start of the fusion"""
+        self._state["det_loss"] = self.det_loss(self._state["dd"])
 
     def _fusion(self):
         st = self._state
@@ -213,7 +220,7 @@ class PhasedTrainStep(object):
 
     # (phase, stream, memory pool): the image phases may sit on their own (CU-masked) stream but still alternate
     # strictly with the main stream's phases, so they share its pool
-    _ORDER = (("det_fwd", "det", "det"), ("geometry", "det", "det"), ("image_fwd", "img", "main"),
+    _ORDER = (("det_fwd", "det", "det"), ("det_loss", "det", "det"), ("geometry", "det", "det"), ("image_fwd", "img", "main"),
               ("fusion", "main", "main"),
               ("det_bwd", "det", "det"), ("image_bwd", "img", "main"), ("image_bwd_1", "img", "main"),
               ("image_bwd_2", "img", "main"), ("image_bwd_3", "img", "main"), ("finish", "main", "main"))
@@ -292,7 +299,11 @@ class PhasedTrainStep(object):
         sd.wait_event(self.e_done)  # parameters of the previous step's optimizer
         with torch.cuda.stream(sd):
             self._run("det_fwd", eager)
-            self.e_det_fwd.record(sd)
+            if _DET_LOSS_LATE[0]:
+                self.e_det_fwd.record(sd)
+            self._run("det_loss", eager)
+            if not _DET_LOSS_LATE[0]:
+                self.e_det_fwd.record(sd)
             if self.prefetch:
                 self._run("geometry", eager)
         if si is not sm:

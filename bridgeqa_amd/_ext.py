@@ -22,8 +22,10 @@ if not os.path.exists(_LIB_PATH):
 _lib = ctypes.CDLL(_LIB_PATH)
 _lib.bq_last_error.restype = ctypes.c_char_p
 _lib.bq_abi_version.restype = ctypes.c_int
-if _lib.bq_abi_version() != 1:
-    raise ImportError("bridgeqa_amd: libbqhip.so ABI %d != 1" % _lib.bq_abi_version())
+ABI_VERSION = 2   # = BQHIP_ABI_VERSION of include/bqhip.h
+if _lib.bq_abi_version() != ABI_VERSION:
+    raise ImportError("bridgeqa_amd: libbqhip.so ABI %d != %d (stale library: python -m bridgeqa_amd.build --force)"
+                      % (_lib.bq_abi_version(), ABI_VERSION))
 
 _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 _SIGS = {
@@ -569,27 +571,6 @@ def colsum(g2d):
     return out
 
 
-_lib.bq_twin_mix_bf16.argtypes = [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]
-_lib.bq_twin_mix_bf16.restype = ctypes.c_int
-
-
-def twin_mix(fixed_a, tail_a, fixed_b, tail_b):
-    """(cat(fixed_a, tail_a), cat(fixed_b, tail_b)) along dim 1 for contiguous bf16 (B, *, D) tensors, one launch"""
-    B, Pa, D = fixed_a.shape
-    Pb, L = fixed_b.shape[1], tail_a.shape[1]
-    for t in (fixed_a, tail_a, fixed_b, tail_b):
-        if not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and t.shape[0] == B and t.shape[2] == D):
-            raise RuntimeError("twin_mix: contiguous bf16 CUDA tensors (B, *, D) expected")
-    if tail_b.shape[1] != L or D % 8:
-        raise RuntimeError("twin_mix: tails must have the same length and D % 8 == 0")
-    with torch.cuda.device(fixed_a.device):
-        oa = torch.empty(B, Pa + L, D, dtype=torch.bfloat16, device=fixed_a.device)
-        ob = torch.empty(B, Pb + L, D, dtype=torch.bfloat16, device=fixed_a.device)
-        _check(_lib.bq_twin_mix_bf16(_p(fixed_a), _p(tail_a), _p(oa), Pa, _p(fixed_b), _p(tail_b), _p(ob), Pb, B, L, D,
-                                     _stream()), "twin_mix")
-    return oa, ob
-
-
 _lib.bq_gelu_fwd_bf16.argtypes = [_vp, _vp, _l, _vp]
 _lib.bq_gelu_fwd_bf16.restype = ctypes.c_int
 
@@ -821,7 +802,8 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_BIAS_CE, EPI_ADD = 0, 1, 2, 3,
 
 class _GemmDesc(ctypes.Structure):
     _fields_ = [("P", _vp), ("Q", _vp), ("out", _vp), ("bias", _vp), ("out2", _vp), ("aux", _vp), ("colsum", _vp),
-                ("ldp", _i), ("ldq", _i), ("ldo", _i), ("Ni", _i), ("Nj", _i), ("Kc", _i), ("bias_bf16", _i), ("p_bytes", _l), ("q_bytes", _l), ("ksplit", _i)]
+                ("ldp", _i), ("ldq", _i), ("ldo", _i), ("Ni", _i), ("Nj", _i), ("Kc", _i), ("bias_bf16", _i), ("p_bytes", _l), ("q_bytes", _l), ("ksplit", _i),
+                ("q_rpb", _i), ("q_bstride", _i), ("o_rpb", _i), ("o_bstride", _i), ("accum", _i)]
 
 
 _lib.bq_gemm_bf16.argtypes = [ctypes.POINTER(_GemmDesc), _i, _i, _i, _i, _vp]
@@ -829,8 +811,7 @@ _lib.bq_gemm_bf16.restype = ctypes.c_int
 _lib.bq_gemm_max_problems.restype = ctypes.c_int
 GEMM_TILE_ROWS = 1024  # problems with at least this many j rows (and i columns >= 256) run on the large-tile kernels
 # Large problems whose output is bf16 with a K-contiguous Q (forward, input gradient) take the 256 x 128 persistent kernel
-# (csrc/gemm_mid.hip: two workgroups per CU); BQ_GEMM_MID=0 sends them back to the 256 x 256 one (A/B measurements).
-GEMM_MID = os.environ.get("BQ_GEMM_MID", "1") != "0"
+# (csrc/gemm_mid.hip: two workgroups per CU; round 3 A/B against the 256 x 256 one: 38.8 vs 39.2 ms per c3 step).
 
 
 def _mat(t, name):
@@ -839,6 +820,28 @@ def _mat(t, name):
     if t.dim() != 2 or t.stride(1) != 1:
         raise RuntimeError("%s must be a 2-D tensor with a contiguous last dimension" % name)
     return t
+
+
+def _mat_rows(t, name):
+    """Q / out / aux / out2 of a GEMM problem: a 2-D (rows, cols) tensor, or a 3-D (batch, rows_per_batch, cols) VIEW whose
+    batches are stride(0) elements apart -- the batched-row map of bq_gemm_desc (q_rpb / o_rpb), e.g. kv[:, :1025] of a
+    (B, 1045, 1536) key/value tensor.  Returns (shape2d, ld, rpb, bstride); a 3-D tensor that is plain rows comes back
+    with rpb = 0."""
+    if not t.is_cuda:
+        raise RuntimeError("%s: CPU not supported (bridgeqa_amd has no CPU path)" % name)
+    if t.dim() == 2:
+        if t.stride(1) != 1:
+            raise RuntimeError("%s must have a contiguous last dimension" % name)
+        return (t.shape[0], t.shape[1]), t.stride(0), 0, 0
+    if t.dim() != 3 or t.stride(2) != 1:
+        raise RuntimeError("%s must be (rows, cols) or a (batch, rows, cols) view with a contiguous last dimension" % name)
+    B, R, C = t.shape
+    ld, bs = t.stride(1), t.stride(0)
+    if B == 1 or bs == R * ld:
+        return (B * R, C), ld, 0, 0
+    if bs < R * ld or bs % 8 or R > 65535:
+        raise RuntimeError("%s: unsupported batched-row view (stride %s, shape %s)" % (name, t.stride(), tuple(t.shape)))
+    return (B * R, C), ld, R, bs
 
 
 def pick_tile(Ni, Nj, q_xc, mid_ok=False):
@@ -857,16 +860,20 @@ def gemm_grouped(problems, flags, epilogue=EPI_NONE, tile=None):
     arr = (_GemmDesc * n)()
     pxc, qxc, f32 = bool(flags & GEMM_P_XC), bool(flags & GEMM_Q_XC), bool(flags & GEMM_OUT_F32)
     t_auto = 32
+    any_map = False
     for k, pr in enumerate(problems):
-        P, Q, out = _mat(pr["P"], "P"), _mat(pr["Q"], "Q"), _mat(pr["out"], "out")
+        P, Q, out = _mat(pr["P"], "P"), pr["Q"], pr["out"]
+        qshape, ldq, q_rpb, q_bs = _mat_rows(Q, "Q")
+        oshape, ldo, o_rpb, o_bs = _mat_rows(out, "out")
+        any_map = any_map or bool(q_rpb or o_rpb)
         if P.dtype != torch.bfloat16 or Q.dtype != torch.bfloat16:
             raise RuntimeError("gemm: operands must be bf16")
         if out.dtype != (torch.float32 if f32 else torch.bfloat16):
             raise RuntimeError("gemm: out must be %s" % ("float32" if f32 else "bfloat16"))
         Ni, Kc = (P.shape[1], P.shape[0]) if pxc else (P.shape[0], P.shape[1])
-        Nj, Kq = (Q.shape[1], Q.shape[0]) if qxc else (Q.shape[0], Q.shape[1])
+        Nj, Kq = (qshape[1], qshape[0]) if qxc else (qshape[0], qshape[1])
         Ni = int(pr.get("Ni", Ni))  # output wider than P's rows (padded vocabulary): P's true extent goes in p_bytes
-        if (Kq != Kc and "Kc" not in pr) or tuple(out.shape) != (Nj, Ni):
+        if (Kq != Kc and "Kc" not in pr) or tuple(oshape) != (Nj, Ni):
             raise RuntimeError("gemm: shape mismatch P%s Q%s out%s" % (tuple(P.shape), tuple(Q.shape), tuple(out.shape)))
         d = arr[k]
         d.P, d.Q, d.out = P.data_ptr(), Q.data_ptr(), out.data_ptr()
@@ -882,11 +889,13 @@ def gemm_grouped(problems, flags, epilogue=EPI_NONE, tile=None):
                                                                or not colsum.is_contiguous()):
             raise RuntimeError("gemm: colsum must be a contiguous fp32 (%d,) tensor" % n_cs)
         for t, nm in ((out2, "out2"), (aux, "aux")):
-            if epilogue != EPI_BIAS_CE and t is not None and (t.dtype != torch.bfloat16 or tuple(t.shape) != (Nj, Ni)
+            if epilogue != EPI_BIAS_CE and t is not None and (t.dtype != torch.bfloat16 or t.shape != out.shape
                                                               or t.stride() != out.stride()):
                 raise RuntimeError("gemm: %s must be bf16 and laid out like out" % nm)
         d.bias, d.out2, d.aux, d.colsum = _p(bias), _p(out2), _p(aux), _p(colsum)
-        d.ldp, d.ldq, d.ldo = P.stride(0), Q.stride(0), out.stride(0)
+        d.ldp, d.ldq, d.ldo = P.stride(0), ldq, ldo
+        d.q_rpb, d.q_bstride, d.o_rpb, d.o_bstride = q_rpb, q_bs, o_rpb, o_bs
+        d.accum = int(bool(pr.get("accum", False)))
         d.Ni, d.Nj, d.Kc = Ni, Nj, Kc
         d.p_bytes, d.q_bytes, d.ksplit = int(pr.get("p_bytes", 0)), int(pr.get("q_bytes", 0)), int(pr.get("ksplit", 1))
         if "Kc" in pr:  # contraction longer than the K-contiguous operand's rows (its partner is zero-padded)
@@ -897,8 +906,10 @@ def gemm_grouped(problems, flags, epilogue=EPI_NONE, tile=None):
                   and epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_ADD))
         all_mid_ok = mid_ok if k == 0 else (all_mid_ok and mid_ok)
         t_auto = max(t_auto, pick_tile(Ni, Nj, qxc, True))
-    if t_auto == 128 and not (all_mid_ok and GEMM_MID):
+    if t_auto == 128 and not all_mid_ok:
         t_auto = 256   # (one tile class per launch: every problem of the group must be able to take the 256 x 128 kernel)
+    if t_auto == 256 and any_map and tile is None and not (pxc and qxc and f32):
+        t_auto = 64    # (the 256 x 256 kernel maps only the contraction rows of its weight-gradient form)
     dev = problems[0]["out"].device
     if (tile or t_auto) != 128:
         flags &= ~GEMM_BACKGROUND   # (only the persistent 256 x 128 kernel has a reduced grid)

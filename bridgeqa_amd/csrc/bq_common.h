@@ -10,6 +10,7 @@ namespace bq {
 
 void set_error(const char *fmt, ...);
 int check_launch(const char *what);
+int device_cus();   // compute units of the CURRENT device (cached per device ordinal, pn2_ops.hip)
 
 #define BQ_REQUIRE(cond, code, ...)   \
   do {                                \

@@ -91,6 +91,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
   const unsigned p_step = P_XC ? (unsigned)(64 * ldp * 2) : 128u;
   const unsigned q_step = Q_XC ? (unsigned)(64 * ldq * 2) : 128u;
   const unsigned lds_w = (unsigned)(wave * 1024);
+  // batched-row map on the CONTRACTION rows of a contraction-major Q (the weight-gradient form reading its row range of
+  // a (B, L1 + L2, N) gradient in place): the lane's row walks 64 rows per K tile; when it leaves its batch (q_rpb >= 64:
+  // at most once per step) the cursor jumps over the rows between the batches.  One row counter per unit pair (B0 / B1
+  // are staged in different phases).
+  const int q_rpb = Q_XC ? (int)pr.q_rpb : 0;
+  const unsigned q_gap = (unsigned)((pr.q_bstride - q_rpb * ldq) * 2);
+  int q_rl[2] = {ur, ur};
 
   // stage the unit pair (u, u+1) of K tile `kt` into buffer kt & 1; past the last tile: out-of-range DMAs (no
   // traffic, they keep the vmcnt bookkeeping uniform; the buffer they zero is never read again)
@@ -102,6 +109,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
       const unsigned vo = live ? voff[u + d] : 0x80000000u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(u < 4 ? rsP : rsQ, (lds_void_t *)(smem + base + d * 8192), 16, vo, 0, 0, 0);
       voff[u + d] += (u < 4) ? p_step : q_step;
+    }
+    if (Q_XC && u >= 4 && q_rpb != 0) {   // (workgroup-uniform branch)
+      int &rl = q_rl[(u - 4) >> 1];
+      rl += 64;
+      const bool wrap = rl >= q_rpb;
+      rl -= wrap ? q_rpb : 0;
+      voff[u] += wrap ? q_gap : 0u;
+      voff[u + 1] += wrap ? q_gap : 0u;
     }
   };
 
@@ -540,15 +555,20 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
   const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void *)pr.Q, 0, pr.q_bytes, 0x00020000);
   const int cp = lane & 7;
   // P unit: 2 DMAs per wave (rows (2w+d)*8 + lane/8); Q unit: 2 (BJ = 64) or 1 (BJ = 32: rows w*8 + lane/8)
-  unsigned vp[2], vq[2];
+  unsigned vp[2], vq[2], qcol[2];
+  int qrow[2];            // XC Q under a row map: the contraction row each DMA stages next, and its column offset
+  const bool q_xc_map = Q_XC && pr.q_rpb != 0;   // (workgroup-uniform)
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
     const int ur = (wave * 2 + d) * 8 + (lane >> 3);
     if (!P_XC) vp[d] = (unsigned)(((i0 + ur) * ldp + (cp ^ (ur & 7)) * 8) * 2);
     else vp[d] = (unsigned)((ur * ldp + i0 + (cp ^ (xg(ur) << 1)) * 8) * 2);
     const int uq = (BJ == 64) ? ur : wave * 8 + (lane >> 3);
-    if (!Q_XC) vq[d] = (unsigned)(((j0 + uq) * ldq + (cp ^ (uq & 7)) * 8) * 2);
+    // (batched-row map of Q, GemmProblem::q_rpb: on its j rows here, on its contraction rows in the XC form -- see stage())
+    if (!Q_XC) vq[d] = (mapped_row(j0 + uq, ldq, pr.q_rpb, pr.q_bstride) + (unsigned)((cp ^ (uq & 7)) * 8)) * 2u;
     else vq[d] = (unsigned)((uq * ldq + j0 + (cp ^ (xg(uq) << 1)) * 8) * 2);
+    qrow[d] = kt0 * 64 + uq;
+    qcol[d] = (unsigned)(j0 + (cp ^ (xg(uq) << 1)) * 8);
   }
   const unsigned p_step = P_XC ? (unsigned)(64 * ldp * 2) : 128u;
   const unsigned q_step = Q_XC ? (unsigned)(64 * ldq * 2) : 128u;
@@ -573,6 +593,10 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
 #pragma unroll
       for (int d = 0; d < (BJ == 64 ? 2 : 1); ++d) {
         const int blk = (BJ == 64) ? wave * 2 + d : wave;
+        if (q_xc_map) {   // short contractions over a strided (batch, rows) view: one division per DMA
+          vq[d] = (mapped_row(qrow[d], ldq, pr.q_rpb, pr.q_bstride) + qcol[d]) * 2u;
+          qrow[d] += 64;
+        }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_void_t *)(smem + base + 8192 + blk * 1024), 16,
                                                  live ? vq[d] : 0x80000000u, 0, 0, 0);
         vq[d] += q_step;
@@ -647,12 +671,13 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
   // ---- epilogue: straight from the accumulators (8-B bf16 / 16-B fp32 pieces of an output row) ---------------------
   const int ldo = pr.ldo;
   const int iw = i0 + wr * 32, jw = j0 + wc * (BJ / 2);
+  const bool atomic_out = ksplit > 1 || pr.accum;   // fp32 out: add to what is there (cut contraction / second row source)
   if (QSUM && do_qsum && q4 == 0) {
 #pragma unroll
     for (int b = 0; b < QF; ++b) {
       const int j = jw + b * 16 + row16;
       if (j < Nj) {
-        if (ksplit == 1) pr.colsum[j] = qs[b][0];
+        if (!atomic_out) pr.colsum[j] = qs[b][0];
         else atomicAdd(pr.colsum + j, qs[b][0]);   // (zero-initialised by the caller, as `out` is)
       }
     }
@@ -670,22 +695,24 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] + b4[r];
+      // element offset of row j of out / out2 / aux (64-bit on plain rows: outputs beyond 2 G elements exist)
+      const long jo = pr.o_rpb ? (long)mapped_row(j < Nj ? j : 0, ldo, pr.o_rpb, pr.o_bstride) : (long)j * ldo;
       if (OUT_F32) {
-        float *dst = reinterpret_cast<float *>(pr.out) + (long)j * ldo + i;
-        if (ok && ksplit == 1) *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-        if (ok && ksplit > 1) {
+        float *dst = reinterpret_cast<float *>(pr.out) + jo + i;
+        if (ok && !atomic_out) *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        if (ok && atomic_out) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) atomicAdd(dst + r, v[r]);
         }
         continue;
       }
       if (EPI == EPI_DGELU && ok) {
-        const bf16x4 y = *reinterpret_cast<const bf16x4 *>(pr.aux + (long)j * ldo + i);
+        const bf16x4 y = *reinterpret_cast<const bf16x4 *>(pr.aux + jo + i);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= dgelu_f((float)y[r]);
       }
       if (EPI == EPI_ADD && ok) {
-        const bf16x4 y = *reinterpret_cast<const bf16x4 *>(pr.aux + (long)j * ldo + i);
+        const bf16x4 y = *reinterpret_cast<const bf16x4 *>(pr.aux + jo + i);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += (float)y[r];
       }
@@ -695,11 +722,11 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
         uint2 pk;
         pk.x = pack_bf16x2(v[0], v[1]);
         pk.y = pack_bf16x2(v[2], v[3]);
-        *reinterpret_cast<uint2 *>(reinterpret_cast<__bf16 *>(pr.out) + (long)j * ldo + i) = pk;
+        *reinterpret_cast<uint2 *>(reinterpret_cast<__bf16 *>(pr.out) + jo + i) = pk;
         if (EPI == EPI_BIAS_GELU) {
           pk.x = pack_bf16x2(gelu_f(v[0]), gelu_f(v[1]));
           pk.y = pack_bf16x2(gelu_f(v[2]), gelu_f(v[3]));
-          *reinterpret_cast<uint2 *>(reinterpret_cast<__bf16 *>(pr.out2) + (long)j * ldo + i) = pk;
+          *reinterpret_cast<uint2 *>(reinterpret_cast<__bf16 *>(pr.out2) + jo + i) = pk;
         }
       }
 #pragma unroll
@@ -1102,28 +1129,58 @@ extern "C" int bq_gemm_bf16(const bq_gemm_desc *d, int n, int flags, int epilogu
       BQ_REQUIRE((epilogue != EPI_ADD && epilogue != EPI_DGELU && tile != 128) || ((long)s.Nj + 256) * s.ldo * (f32 ? 4 : 2) < 0x7FFFFFFFL,
                  BQ_EINVAL, "bq_gemm_bf16: out / aux larger than 2 GB (problem %d)", done);
       const long pb = pxc ? ((long)(s.Kc - 1) * s.ldp + s.Ni) * 2 : ((long)(s.Ni - 1) * s.ldp + s.Kc) * 2;
-      const long qb = qxc ? ((long)(s.Kc - 1) * s.ldq + s.Nj) * 2 : ((long)(s.Nj - 1) * s.ldq + s.Kc) * 2;
+      long qb = qxc ? ((long)(s.Kc - 1) * s.ldq + s.Nj) * 2 : ((long)(s.Nj - 1) * s.ldq + s.Kc) * 2;
       const int tj = tile == 256 ? 256 : tile, ti = (tile == 256 || tile == 128) ? 256 : 64;
+      // batched-row maps: the mapped rows of Q are its j rows, or its contraction rows when Q is contraction-major
+      BQ_REQUIRE(s.q_rpb >= 0 && s.o_rpb >= 0 && s.q_rpb <= 65535 && s.o_rpb <= 65535, BQ_EINVAL,
+                 "bq_gemm_bf16: q_rpb / o_rpb must be in 0..65535 (problem %d)", done);
+      long q_span = 0, o_span = 0;   // elements from the first mapped row to one past the last (map on: bounds of the views)
+      if (s.q_rpb > 0) {
+        const long rows = qxc ? s.Kc : s.Nj, cols = qxc ? s.Nj : s.Kc;
+        BQ_REQUIRE(rows % s.q_rpb == 0 && s.q_bstride % 8 == 0 && (long)s.q_bstride >= (long)s.q_rpb * s.ldq, BQ_EINVAL,
+                   "bq_gemm_bf16: q map: rows %ld must be whole batches of q_rpb = %d rows, q_bstride %% 8 == 0 and >= q_rpb * ldq",
+                   rows, s.q_rpb);
+        BQ_REQUIRE(tile != 256 || (qxc && s.q_rpb >= 64), BQ_EINVAL,
+                   "bq_gemm_bf16: tile 256 maps only the contraction rows of a contraction-major Q, q_rpb >= 64");
+        BQ_REQUIRE(tile != 128 || !qxc, BQ_EINVAL, "bq_gemm_bf16: tile 128 has no map on a contraction-major Q");
+        q_span = (rows / s.q_rpb - 1) * (long)s.q_bstride + (long)(s.q_rpb - 1) * s.ldq + cols;
+        qb = q_span * 2;   // rows past the last batch land beyond this bound and read zeros
+      }
+      if (s.o_rpb > 0) {
+        BQ_REQUIRE(s.Nj % s.o_rpb == 0 && s.o_bstride % 8 == 0 && (long)s.o_bstride >= (long)s.o_rpb * s.ldo, BQ_EINVAL,
+                   "bq_gemm_bf16: o map: Nj = %d must be whole batches of o_rpb = %d rows, o_bstride %% 8 == 0 and >= o_rpb * ldo",
+                   s.Nj, s.o_rpb);
+        BQ_REQUIRE(tile != 256 && epilogue != EPI_BIAS_CE && s.colsum == nullptr, BQ_EINVAL,
+                   "bq_gemm_bf16: an output map needs tile 128, 64 or 32 and no column sums");
+        o_span = (long)(s.Nj / s.o_rpb) * s.o_bstride;
+        BQ_REQUIRE((o_span + 256L * s.ldo) * (f32 ? 4 : 2) < 0x7FFFFFFFL, BQ_EINVAL, "bq_gemm_bf16: mapped out larger than 2 GB");
+      }
+      BQ_REQUIRE(!s.accum || (f32 && tile != 256 && tile != 128), BQ_EINVAL, "bq_gemm_bf16: accum needs fp32 out and tile 64 / 32");
       // operand bytes (plus the rows of a ragged edge tile) must stay below the out-of-range sentinel of the DMA offsets
-      BQ_REQUIRE(pb + (long)ti * s.ldp * 2 < 0x7FFFFFFFL && qb + (long)tj * s.ldq * 2 < 0x7FFFFFFFL, BQ_EINVAL,
-                 "bq_gemm_bf16: operand larger than 2 GB (problem %d)", done);
+      BQ_REQUIRE(pb + (long)ti * s.ldp * 2 < 0x7FFFFFFFL && qb + (long)tj * s.ldq * 2 + (s.q_rpb > 0 ? 2L * s.q_bstride * 2 : 0) < 0x7FFFFFFFL,
+                 BQ_EINVAL, "bq_gemm_bf16: operand larger than 2 GB (problem %d)", done);
       GemmProblem &g = ga.p[ga.n];
       g.P = (const __bf16 *)s.P; g.Q = (const __bf16 *)s.Q; g.out = s.out; g.bias = s.bias; g.out2 = s.out2;
       g.aux = (const __bf16 *)s.aux; g.colsum = s.colsum;
       g.ldp = s.ldp; g.ldq = s.ldq; g.ldo = s.ldo; g.Ni = s.Ni; g.Nj = s.Nj; g.Kc = s.Kc;
-      g.bias_bf16 = s.bias_bf16;
+      g.bias_bf16 = (unsigned char)(s.bias_bf16 != 0);
+      g.accum = (unsigned char)(s.accum != 0);
+      g.q_rpb = (unsigned short)s.q_rpb; g.o_rpb = (unsigned short)s.o_rpb;
+      g.q_bstride = s.q_bstride; g.o_bstride = s.o_bstride;
       g.p_bytes = (unsigned)(s.p_bytes > 0 ? s.p_bytes : pb);
-      g.q_bytes = (unsigned)(s.q_bytes > 0 ? s.q_bytes : qb);
+      g.q_bytes = (unsigned)((s.q_bytes > 0 && s.q_rpb == 0) ? s.q_bytes : qb);
       if (epilogue == EPI_BIAS_CE) {
-        BQ_REQUIRE(s.out2 && s.aux && s.colsum && s.ksplit > 0 && s.ksplit <= s.Ni && tile == 256, BQ_EINVAL,
+        BQ_REQUIRE(s.out2 && s.aux && s.colsum && s.ksplit > 0 && s.ksplit <= s.Ni && s.ksplit <= 65535 && tile == 256, BQ_EINVAL,
                    "bq_gemm_bf16: the cross-entropy epilogue needs out2 (partials), aux (targets), colsum (target logits), "
-                   "ksplit = valid vocabulary entries, tile 256");
-        g.ksplit = s.ksplit;
+                   "ksplit = valid vocabulary entries (<= 65535), tile 256");
+        g.ksplit = (unsigned short)s.ksplit;
       } else {
-        g.ksplit = (f32 && tile != 256 && s.ksplit > 1) ? s.ksplit : 1;
         BQ_REQUIRE(s.ksplit <= 1 || (f32 && tile != 256), BQ_EINVAL, "bq_gemm_bf16: ksplit needs fp32 out and tile 64");
+        BQ_REQUIRE(s.ksplit <= 65535, BQ_ELIMIT, "bq_gemm_bf16: ksplit = %d > 65535", s.ksplit);
+        g.ksplit = (unsigned short)((f32 && tile != 256 && s.ksplit > 1) ? s.ksplit : 1);
       }
-      g.tiles_i = (s.Ni + ti - 1) / ti;
+      BQ_REQUIRE((s.Ni + ti - 1) / ti <= 65535, BQ_ELIMIT, "bq_gemm_bf16: Ni = %d too wide", s.Ni);
+      g.tiles_i = (unsigned short)((s.Ni + ti - 1) / ti);
       g.tile0 = ga.total_tiles;
       ga.total_tiles += g.tiles_i * ((s.Nj + tj - 1) / tj) * (epilogue == EPI_BIAS_CE ? 1 : g.ksplit);
       ++ga.n;

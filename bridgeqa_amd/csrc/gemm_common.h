@@ -27,13 +27,30 @@ struct GemmProblem {
   float *colsum;       // optional fp32 [Ni]: += sum_j out[j][i] (bias gradient of the producing layer)
   int ldp, ldq, ldo;   // leading dimensions in elements
   int Ni, Nj, Kc;
-  int tile0, tiles_i;  // first workgroup of this problem in the launch; tiles along i
-  int bias_bf16;
+  int tile0;           // first workgroup of this problem in the launch
   unsigned p_bytes, q_bytes;  // bounds of the operand buffers (a K-contiguous operand whose rows are shorter than Kc:
                               // its partner is zero-padded, its own tail reads run into the next row)
-  int ksplit;          // > 1 (fp32 out, small-tile kernel): the contraction is cut into ksplit pieces, one workgroup
-                       // each, accumulated with fp32 atomics into a zero-initialised `out`
+  // batched-row maps (bq_gemm_desc, include/bqhip_fusion.h): logical row r of Q / of out (and aux / out2) lives at element
+  // (r / rpb) * bstride + (r % rpb) * ld -- a (batch, rows, cols) view with a batch stride, e.g. the first 1025 of every
+  // sample's 1045 key rows.  rpb = 0: plain rows.  On a contraction-major Q the map is on the CONTRACTION rows.
+  int q_bstride, o_bstride;
+  unsigned short q_rpb, o_rpb;
+  unsigned short tiles_i;     // tiles along i
+  unsigned short ksplit;      // > 1 (fp32 out, small-tile kernel): the contraction is cut into ksplit pieces, one workgroup
+                              // each, accumulated with fp32 atomics into a zero-initialised `out`
+  unsigned char bias_bf16;
+  unsigned char accum;        // fp32 out, small-tile kernel: add to `out` / `colsum` (fp32 atomics) instead of storing
 };
+// the descriptor table travels as a kernel argument (4 KB limit): 36 problems x 112 B + 8
+static_assert(sizeof(GemmProblem) == 112, "GemmProblem grew: GEMM_MAX_PROBLEMS x sizeof must stay below the 4 KB kernarg limit");
+
+// element offset of logical row r under a batched-row map (rpb = 0: r * ld).  A handful of calls per tile / per short
+// contraction step: the integer division is noise there.
+__device__ __forceinline__ unsigned mapped_row(int r, int ld, int rpb, int bstride) {
+  if (rpb == 0) return (unsigned)(r * ld);
+  const int b = r / rpb;
+  return (unsigned)(b * bstride + (r - b * rpb) * ld);
+}
 
 __device__ __forceinline__ void load_bias4(const GemmProblem &pr, int i, float (&bv)[4]) {
   if (pr.bias_bf16) {
@@ -51,6 +68,7 @@ struct GemmArgs {
   int total_tiles;
   GemmProblem p[GEMM_MAX_PROBLEMS];
 };
+static_assert(sizeof(GemmArgs) <= 4096, "kernel-argument limit");
 
 // ---- LDS images -----------------------------------------------------------------------------------------------------
 // KC unit: [64 rows][64 k] bf16, 128-B rows, 16-B chunk ch of row r at r*128 + ((ch ^ (r & 7)) << 4)

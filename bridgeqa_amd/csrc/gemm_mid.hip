@@ -127,16 +127,20 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
     const GemmProblem &pr = args.p[tt.pi];
     unsigned v;
     if (!Q_XC) {
-      // unit row r -> j0 + (r >> 5) * 64 + half * 32 + (r & 31); d = 1 is r + 32: 64 rows further
-      v = (unsigned)(((tt.j0 + half * 32 + ur0) * pr.ldq + (cp ^ (ur0 & 7)) * 8) * 2);
+      // unit row r -> j0 + (r >> 5) * 64 + half * 32 + (r & 31); d = 1 is r + 32: 64 rows further (under a batched-row
+      // map the two rows may lie in different batches: the d = 1 delta is per lane then)
+      const int row0 = tt.j0 + half * 32 + ur0;
+      const unsigned o0 = mapped_row(row0, pr.ldq, pr.q_rpb, pr.q_bstride);
+      v = (o0 + (unsigned)((cp ^ (ur0 & 7)) * 8)) * 2u;
+      ddQ[half] = pr.q_rpb ? (mapped_row(row0 + 64, pr.ldq, pr.q_rpb, pr.q_bstride) - o0) * 2u : (unsigned)(64 * pr.ldq * 2);
     } else {
       // unit row r = contraction index; its 8 chunks of 8 columns: chunk c -> j0 + (c >> 2) * 64 + half * 32 + (c & 3) * 8
       // (the `half` 32 columns of both wave columns); d = 1 is r + 32
       const int c = cp ^ (xg(ur0) << 1);
       v = (unsigned)((ur0 * pr.ldq + tt.j0 + (c >> 2) * 64 + half * 32 + (c & 3) * 8) * 2);
+      ddQ[half] = (unsigned)(32 * pr.ldq * 2);
     }
     vQ[half] = live ? v : DEAD;
-    ddQ[half] = Q_XC ? (unsigned)(32 * pr.ldq * 2) : (unsigned)(64 * pr.ldq * 2);
     stepQ[half] = Q_XC ? (unsigned)(64 * pr.ldq * 2) : 128u;
     remQ[half] = live ? tt.nkt : 0x40000000;
     rsrcQ_pi[half] = tt.pi;
@@ -310,7 +314,8 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
       }
     } else {
       const int ldo = pr.ldo;
-      const unsigned obytes = (unsigned)((long)Nj * ldo * 2);
+      const int orpb = pr.o_rpb, obs = pr.o_bstride;   // batched-row map of out / out2 / aux (0: plain rows)
+      const unsigned obytes = orpb ? (unsigned)((long)(Nj / orpb) * obs * 2) : (unsigned)((long)Nj * ldo * 2);
       const auto rsO = __builtin_amdgcn_make_buffer_rsrc(pr.out, 0, obytes, 0x00020000);
       const auto rsO2 = __builtin_amdgcn_make_buffer_rsrc(EPI == EPI_BIAS_GELU ? pr.out2 : pr.out, 0, obytes, 0x00020000);
       const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void *)((EPI == EPI_DGELU || EPI == EPI_ADD) ? (const void *)pr.aux : pr.out), 0, obytes, 0x00020000);
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
       } else if (EPI == EPI_DGELU || EPI == EPI_ADD) {
         uint2 yA[8], yB[8];   // the second operand in the accumulator's own map (8 B per lane), one j block each
         auto fetch = [&](int b, uint2(&dst)[8]) {
-          const unsigned off = (unsigned)(((jw + b * 16 + row16) * ldo + iw + q4 * 4) * 2);
+          const unsigned off = (mapped_row(jw + b * 16 + row16, ldo, orpb, obs) + (unsigned)(iw + q4 * 4)) * 2u;
 #pragma unroll
           for (int a = 0; a < 8; ++a)
             dst[a] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsX, off + a * 32, 0, 0));
@@ -395,6 +400,11 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
         deferred_dmas();
       }
       const unsigned ep_lds = (unsigned)(size_t)((lds_u8_t *)smem) + 65536u + (unsigned)(wave * 2048);
+      unsigned jrow[4][2];   // element offset of output row jw + b * 16 + t2 * 8 + lr
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) jrow[b][t2] = mapped_row(jw + b * 16 + t2 * 8 + lr, ldo, orpb, obs);
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
 #pragma unroll
@@ -427,9 +437,8 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
-              const int jr = t2 * 8 + lr;
-              const int j = jw + b * 16 + jr, i_st = iw + half * 64 + cp * 8;
-              const unsigned off = i_st < Ni ? (unsigned)((j * ldo + i_st) * 2) : DEAD;   // Ni % 8 == 0 (host check)
+              const int i_st = iw + half * 64 + cp * 8;
+              const unsigned off = i_st < Ni ? (jrow[b][t2] + (unsigned)i_st) * 2u : DEAD;   // Ni % 8 == 0 (host check)
               __builtin_amdgcn_raw_buffer_store_b128(d[t2], pass == 1 ? rsO2 : rsO, off, 0, ST_AUX);
             }
           }
@@ -447,13 +456,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
 }
 
 int launch_gemm_mid(const GemmArgs &ga, bool p_xc, bool q_xc, bool out_f32, int epi, bool background, hipStream_t stream) {
-  static int slots = 0;
-  if (slots == 0) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    slots = 2 * cus;   // two co-resident workgroups per CU (64 KB of LDS, <= 256 VGPRs each)
-    if (getenv("BQ_GEMM_MID_SLOTS")) slots = atoi(getenv("BQ_GEMM_MID_SLOTS"));   // (tools/bench_gemm_slots.py)
-  }
+  const int slots = 2 * device_cus();   // two co-resident workgroups per CU (64 KB of LDS, <= 256 VGPRs each)
   for (int k = 0; k < ga.n; ++k)
     if (ga.p[k].Kc < 128) return -1;   // (the QB0 cursor runs two K tiles ahead: a tile has at least two)
   // background: one workgroup per CU (BQ_GEMM_BACKGROUND, include/bqhip_fusion.h)

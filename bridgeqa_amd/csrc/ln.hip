@@ -410,45 +410,8 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const __bf16 *__restrict_
   }
 }
 
-// the two key / value sources of a twin level (reference med.py:549-562): out_g[b] = cat(fixed_g[b] (P_g rows), tail_g[b]
-// (L rows)) along the token axis, g = 0 (image tokens + the 3D stream's states) and 1 (object tokens + the 2D stream's),
-// rows of D bf16, D % 8 == 0.  One launch for both concatenations, 16-B copies (torch's cat moves the 25 MB of image tokens
-// at 2.5 TB/s; this is a plain streaming copy).
-struct TwinMixArgs {
-  const __bf16 *fixed[2], *tail[2];
-  __bf16 *out[2];
-  int P[2];
-  int B, L, D8;   // D8 = D / 8 (16-B vectors per row)
-};
-__global__ __launch_bounds__(256) void twin_mix_kernel(const TwinMixArgs a) {
-  const int g = blockIdx.y;
-  const long rows = (long)a.B * (a.P[g] + a.L), n = rows * a.D8, stride = (long)gridDim.x * 256;
-  const uint4 *fx = reinterpret_cast<const uint4 *>(a.fixed[g]), *tl = reinterpret_cast<const uint4 *>(a.tail[g]);
-  uint4 *out = reinterpret_cast<uint4 *>(a.out[g]);
-  const int Lk = a.P[g] + a.L;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    const long row = i / a.D8;
-    const int c = (int)(i - row * a.D8), b = (int)(row / Lk), t = (int)(row - (long)b * Lk);
-    out[i] = t < a.P[g] ? fx[((long)b * a.P[g] + t) * a.D8 + c] : tl[((long)b * a.L + (t - a.P[g])) * a.D8 + c];
-  }
-}
-
 }  // namespace bq
 using namespace bq;
-
-extern "C" __attribute__((visibility("default"))) int bq_twin_mix_bf16(const void *fixed_a, const void *tail_a, void *out_a,
-                                                                     int Pa, const void *fixed_b, const void *tail_b,
-                                                                     void *out_b, int Pb, int B, int L, int D, void *stream) {
-  BQ_REQUIRE(fixed_a && tail_a && out_a && fixed_b && tail_b && out_b, BQ_EINVAL, "twin_mix: null pointer");
-  BQ_REQUIRE(B > 0 && L > 0 && Pa > 0 && Pb > 0 && D > 0 && D % 8 == 0, BQ_EINVAL, "twin_mix: bad extents");
-  TwinMixArgs a{{(const __bf16 *)fixed_a, (const __bf16 *)fixed_b}, {(const __bf16 *)tail_a, (const __bf16 *)tail_b},
-                {(__bf16 *)out_a, (__bf16 *)out_b}, {Pa, Pb}, B, L, D / 8};
-  const long n = (long)B * ((Pa > Pb ? Pa : Pb) + L) * (D / 8);
-  long blocks = (n + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(twin_mix_kernel, dim3((unsigned)blocks, 2), dim3(256), 0, (hipStream_t)stream, a);
-  return check_launch("twin_mix");
-}
 
 // y = GELU(x) (exact), n bf16 elements, n % 8 == 0, 16-B aligned
 extern "C" __attribute__((visibility("default"))) int bq_gelu_fwd_bf16(const void *x, void *y, long n, void *stream) {

@@ -20,6 +20,19 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
+int device_cus() {
+  // per device ordinal (a function-static of the FIRST device would size every later device's grids with its count)
+  static int cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    cached[dev] = cus > 0 ? cus : 256;
+  }
+  return cached[dev];
+}
+
 int check_launch(const char *what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -443,12 +456,7 @@ static int ball_query_launch(const float *new_xyz, const float *xyz, int32_t *id
   const float radius2 = radius * radius;  // ball_query_gpu.cu:22, rounded to fp32 on the host
   int gx = cdiv(M, 8);   // a workgroup = 4 waves = 8 centres
   if (background) {      // about one workgroup per CU over the whole batch (bq_ball_query_background, include/bqhip.h)
-    static int cus = 0;
-    if (cus == 0) {
-      int dev = 0;
-      cus = 256;
-      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    }
+    const int cus = device_cus();
     const int per_scene = cus / B > 0 ? cus / B : 1;
     if (per_scene < gx) gx = per_scene;
   }

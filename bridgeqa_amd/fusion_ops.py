@@ -769,28 +769,133 @@ class _TwinDropAddLN(torch.autograd.Function):
         return dx, dres, dgb[0, 0], dgb[0, 1], dgb[1, 0], dgb[1, 1], None, None
 
 
-_TWIN_MIX_KERNEL = [True]
-
-
 class _TwinMixFn(torch.autograd.Function):
     """keys / values source of the two cross-attentions of one twin level from the stacked states hs (2B, L, D):
     mix2d = cat(image tokens, 3D-stream states), mix3d = cat(object tokens, 2D-stream states) (reference med.py:549-562);
-    the backward hands the states' gradient back STACKED (one cat) instead of two zero-filled slice gradients."""
+    the backward hands the states' gradient back STACKED (one cat) instead of two zero-filled slice gradients.
+    (The torch composition: CPU / fp32 runs.  On the bf16 kernel path nothing is concatenated: _TwinKVFn.)"""
 
     @staticmethod
     def forward(ctx, enc2d, enc3d, hs):
         B = hs.shape[0] // 2
         ctx.cfg = (enc2d.shape[1], enc3d.shape[1])
-        if (_TWIN_MIX_KERNEL[0] and hs.is_cuda and hs.dtype == torch.bfloat16 and enc2d.dtype == torch.bfloat16 and enc3d.dtype == torch.bfloat16
-                and hs.is_contiguous() and enc2d.is_contiguous() and enc3d.is_contiguous() and hs.shape[-1] % 8 == 0):
-            from . import _ext
-            return _ext.twin_mix(enc2d, hs[B:], enc3d, hs[:B])   # both concatenations in one streaming launch
         return torch.cat((enc2d, hs[B:]), dim=1), torch.cat((enc3d, hs[:B]), dim=1)
 
     @staticmethod
     def backward(ctx, g2d, g3d):
         P2, P3 = ctx.cfg
         return g2d[:, :P2], g3d[:, :P3], torch.cat((g3d[:, P3:], g2d[:, P2:]), dim=0)
+
+
+class GradSink(object):
+    """In-place accumulator for the gradient of ONE tensor that many nodes read (the image tokens / object tokens under the
+    12 twin levels): every reader adds its share in the epilogue of its dX GEMM (out = acc + out) and returns nothing to
+    autograd; the reader whose backward runs LAST hands the buffer over as the tensor's gradient.  `readers` counts the
+    nodes created in the forward; a reader that never runs its backward would hold the gradient back -- twin levels
+    always do (they form a chain)."""
+    __slots__ = ("buf", "readers")
+
+    def __init__(self):
+        self.buf, self.readers = None, 0
+
+
+class _TwinKVFn(torch.autograd.Function):
+    """Key / value projections of the two cross-attentions of one twin level WITHOUT the concatenations (reference
+    med.py:549-562: layer[i] attends to cat(image tokens, 3D-stream states), layer_twin[i] to cat(object tokens, 2D-stream
+    states); med.py:112-118 the projections).  One grouped GEMM of four problems writes each source's rows into its row
+    range of the (B, P + L, 2 D) key/value tensor of its stream (batched-row output map, bq_gemm_desc.o_rpb); the backward
+    reads its row range of the gradient in place (q_rpb): the fixed tokens' share is ADDED into the GradSink of enc2d /
+    enc3d by the dX epilogue, the states' share comes back stacked with the gradient that reached the states through the
+    level's other readers (tap) already added; the weight gradient has two row sources (fusion_wgrad._park_two).
+    No cat, no strided slice gradients, no accumulation kernels (12 + 46 + 27 launches per c3 step)."""
+
+    @staticmethod
+    def forward(ctx, enc2d, enc3d, hs, sink2d, sink3d, tap_holder, *wb):
+        from . import _ext
+        ws, bs = wb[:4], wb[4:]
+        wops, bops = _group_operands(ws, bs, 2, 2)
+        B, L, D = hs.shape[0] // 2, hs.shape[1], hs.shape[2]
+        P2, P3, N2 = enc2d.shape[1], enc3d.shape[1], wops[0].shape[0]
+        kv2d = torch.empty(B, P2 + L, N2, dtype=torch.bfloat16, device=hs.device)
+        kv3d = torch.empty(B, P3 + L, N2, dtype=torch.bfloat16, device=hs.device)
+        _ext.gemm_grouped([dict(P=wops[0], Q=enc2d.view(B * P2, D), out=kv2d[:, :P2], bias=bops[0]),
+                           dict(P=wops[1], Q=enc3d.view(B * P3, D), out=kv3d[:, :P3], bias=bops[1]),
+                           dict(P=wops[0], Q=hs[B:].view(B * L, D), out=kv2d[:, P2:], bias=bops[0]),
+                           dict(P=wops[1], Q=hs[:B].view(B * L, D), out=kv3d[:, P3:], bias=bops[1])], 0, _ext.EPI_BIAS)
+        ctx.save_for_backward(enc2d, enc3d, hs, *wops)
+        ctx.sinks, ctx.tap, ctx.params = (sink2d, sink3d), tap_holder, (ws, bs)
+        sink2d.readers += 1
+        sink3d.readers += 1
+        return kv2d, kv3d
+
+    @staticmethod
+    def backward(ctx, g2d, g3d):
+        from . import _ext
+        enc2d, enc3d, hs, w2d, w3d = ctx.saved_tensors
+        ws, bs = ctx.params
+        B, L, D = hs.shape[0] // 2, hs.shape[1], hs.shape[2]
+        P2, P3 = enc2d.shape[1], enc3d.shape[1]
+        g2d, g3d = g2d.contiguous(), g3d.contiguous()
+        outs = []
+        for sink, enc in zip(ctx.sinks, (enc2d, enc3d)):
+            if sink.buf is None:
+                sink.buf = torch.zeros(enc.shape[0] * enc.shape[1], D, dtype=torch.bfloat16, device=hs.device)
+            outs.append(sink.buf)
+        dhs = torch.empty(2 * B * L, D, dtype=torch.bfloat16, device=hs.device)
+        extra = _take_tap(ctx.tap, dhs)   # the states' gradient through the level's other readers, stacked rows
+        if extra is None:
+            extra = torch.zeros_like(dhs)
+        _ext.gemm_grouped([dict(P=w2d, Q=g2d[:, :P2], out=outs[0], aux=outs[0]),
+                           dict(P=w3d, Q=g3d[:, :P3], out=outs[1], aux=outs[1]),
+                           dict(P=w2d, Q=g2d[:, P2:], out=dhs[B * L:], aux=extra[B * L:]),
+                           dict(P=w3d, Q=g3d[:, P3:], out=dhs[:B * L], aux=extra[:B * L])], _ext.GEMM_P_XC, _ext.EPI_ADD)
+        hs2 = hs.view(2 * B * L, D)
+        src = ((g2d[:, :P2], enc2d.view(B * P2, D), g2d[:, P2:], hs2[B * L:]),
+               (g3d[:, :P3], enc3d.view(B * P3, D), g3d[:, P3:], hs2[:B * L]))
+        if _DEFER[0] is not None:
+            for g, (ga, xa, gb, xb) in enumerate(src):
+                _park_two(ga, xa, gb, xb, list(ws[2 * g:2 * g + 2]), list(bs[2 * g:2 * g + 2]))
+            gw = (None,) * 8
+        else:
+            dws, dbs = [], []
+            for g, (ga, xa, gb, xb) in enumerate(src):
+                dw = torch.empty(ga.shape[-1], D, dtype=torch.float32, device=hs.device)
+                db = torch.empty(ga.shape[-1], dtype=torch.float32, device=hs.device)
+                f = _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32
+                _ext.gemm_grouped([dict(P=xa, Q=ga, out=dw, colsum=db)], f, _ext.EPI_NONE,
+                                  256 if (B * ga.shape[1] >= _BIG_ROWS and ga.shape[1] >= 64) else 64)
+                _ext.gemm_grouped([dict(P=xb, Q=gb, out=dw, colsum=db, accum=True)], f, _ext.EPI_NONE, 64)
+                n = dw.shape[0] // 2
+                dws += [dw[:n], dw[n:]]
+                dbs += [db[:n], db[n:]]
+            gw = tuple(dws) + tuple(dbs)
+        grads = []
+        for sink in ctx.sinks:   # the last reader to run hands the accumulated gradient over
+            sink.readers -= 1
+            grads.append(None)
+            if sink.readers == 0:
+                grads[-1], sink.buf = sink.buf, None
+        d2d = grads[0].view(enc2d.shape) if grads[0] is not None else None
+        d3d = grads[1].view(enc3d.shape) if grads[1] is not None else None
+        return (d2d, d3d, dhs.view(hs.shape), None, None, None) + gw
+
+
+def twin_kv_ok(enc2d, enc3d, hs):
+    """the concatenation-free K/V node needs the kernel formats (bf16, CUDA, contiguous, widths the GEMM family takes) and
+    segments the batched-row maps can address"""
+    ok = lambda t: t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()
+    return (compute_dtype() == torch.bfloat16 and _NATIVE_GEMM[0] and ok(enc2d) and ok(enc3d) and ok(hs)
+            and hs.shape[-1] % 64 == 0 and max(enc2d.shape[1], enc3d.shape[1], hs.shape[1]) <= 65535)
+
+
+def twin_kv(enc2d, enc3d, hs, lins_a, lins_b, sink2d, sink3d, tap=None):
+    """-> kv2d (B, P2 + L, 2, D), kv3d (B, P3 + L, 2, D): [key; value] of stream a over (enc2d, 3D-stream states) and of
+    stream b over (enc3d, 2D-stream states); lins_* = (key, value) linears; tap: a GradTap whose tap(hs, .) feeds the
+    level's other readers of hs"""
+    ws = [l.weight for l in lins_a] + [l.weight for l in lins_b]
+    bs = [l.bias for l in lins_a] + [l.bias for l in lins_b]
+    ya, yb = _TwinKVFn.apply(enc2d, enc3d, hs, sink2d, sink3d, tap, *ws, *bs)
+    return ya.view(*ya.shape[:-1], 2, ya.shape[-1] // 2), yb.view(*yb.shape[:-1], 2, yb.shape[-1] // 2)
 
 
 class _TwinSplitFn(torch.autograd.Function):
@@ -929,12 +1034,12 @@ def twin_split(hs):
     return _TwinSplitFn.apply(hs)
 
 
-# ---- two-segment cross-attention over a hoisted K/V projection ----------------------------------------------
-# The twin encoder's layer i cross-attends to cat(image tokens, other stream's states of layer i-1) (reference
-# med.py:549-562).  The image tokens are the same in all layers, so their K/V projections for ALL layers are one GEMM
-# (HoistedKV), the attention kernels take the keys / values as two segments (bq_attn_fwd2: no concatenated tensor, no
-# strided slicing of its gradient), each layer's dK/dV for the image segment is written straight into its column block
-# of ONE gradient buffer, and the projection's backward is one dX GEMM (K = 2 * 768 * layers) + one dW GEMM.
+# ---- hoisted K/V projections: several layers' cross-attentions over the SAME encoder states -------------------------
+# The answer decoder's 12 cross-attentions read the same question states (reference med.py:112-118 per layer): their
+# key / value projections are one GEMM (HoistedKV), each layer's dK/dV is written straight into its block of ONE gradient
+# buffer, and the projection's backward is one dX chain + one parked weight-gradient record per layer.  (Rounds 1-3 also
+# wired the twin encoder's image / object tokens through this class with a two-segment attention: measured neutral to
+# slower three times, DESIGN.md changelog; round 4 replaced it by the concatenation-free _TwinKVFn above and deleted it.)
 
 _HOIST_BACKGROUND = [False]  # side-stream launches of the hoisted projections with one workgroup per CU (BQ_GEMM_BACKGROUND): measured slower
 
@@ -944,8 +1049,7 @@ class HoistedKV(object):
     several layers at once, LEVEL-MAJOR: layer slot i's [key_i; value_i](x) is the contiguous block Y[i] (B, L1, 2, H, 64)
     (the narrow attention kernels walk K / V rows 3 KB apart; the first version wrote ONE (B, L1, n * 1536) tensor whose
     rows were 36 KB apart, which cost the attention kernels what the hoisting saved, DESIGN.md §5 c).
-    kv(i): that block; tail_kv(i, t): the same layer's projection of the per-layer second segment t (B, L2, 768), through
-    the same weights (their gradients join in one backward).
+    kv(i): that block.
 
     The projections depend on nothing the text levels compute, so on a GPU they run on a SIDE stream, one launch per
     layer slot with an event each: the text chain (launch-latency bound, a fraction of the CUs) runs beside them and level
@@ -960,7 +1064,6 @@ class HoistedKV(object):
         bs = [b for sa in self.selfattns for b in (sa.key.bias, sa.value.bias)]
         self.G = None          # (n, B, L1, 2 * 768) gradient of the hoisted projections, allocated by the first writer
         self.written = set()
-        self.tails = []        # (slot, dY (M, 1536), X (M, 768)) parked by the tail projections' backward
         self.wc, self.bc = _cat_shadow(ws, bs)
         self.nb = self.wc.shape[0] // self.n
         self.x = x
@@ -1024,9 +1127,6 @@ class HoistedKV(object):
             dx.record_stream(main)
         return None if dx is None else dx.view(shape)
 
-    def tail_kv(self, i, t):
-        B, L2 = t.shape[:2]
-        return _TailKVFn.apply(t, self, i).view(B, L2, 2, self.heads, -1)
 
 
 def _fwd2(x2, w, b, out=None, background=False):
@@ -1086,7 +1186,7 @@ class _HoistedKVFn(torch.autograd.Function):
             if g is None:
                 hold.grad_view(i, like).zero_()
             elif i not in hold.written or g.data_ptr() != hold.grad_view(i, like).data_ptr():
-                hold.grad_view(i, like).copy_(g)  # the gradient did not come from attention_q_kv2's in-place writer
+                hold.grad_view(i, like).copy_(g)  # the gradient did not come from attention_q_kv's in-place writer
         dx = None
         if ctx.needs_input_grad[0]:
             hold.want_dx = True
@@ -1097,178 +1197,19 @@ class _HoistedKVFn(torch.autograd.Function):
         hold.G = None
         x2 = xb.reshape(-1, xb.shape[-1])
         k, n, nb = ctx.k, hold.n, hold.nb
-        if _defer_ok(G[0].view(-1, nb), x2) and not hold.tails:
+        if _defer_ok(G[0].view(-1, nb), x2):
             # inside a deferred-wgrad scope every slot's [key_i; value_i] block is ONE parked record (the flush splits its
-            # rows evenly over the two weights); the per-level tail projections parked theirs from _TailKVFn.backward
+            # rows evenly over the two weights)
             for i, sa in enumerate(hold.selfattns):
                 _park(G[i].view(-1, nb), x2, [sa.key.weight, sa.value.weight], [sa.key.bias, sa.value.bias])
             return (dx, None) + (None,) * (2 * k)
         dws, dbs = [], []
         h = nb // 2
-        tails, hold.tails = hold.tails, []
         for i in range(n):
             dw, db = _dw_db(G[i].view(-1, nb), x2, True, True)
-            for slot, g2, t2 in tails:  # the per-layer second segments went through the same weights
-                if slot == i:
-                    dwt, dbt = _dw_db(g2, t2, True, True)
-                    dw.add_(dwt)
-                    db.add_(dbt)
             dws += [dw[:h], dw[h:]]
             dbs += [db[:h], db[h:]]
         return (dx, None) + tuple(dws) + tuple(dbs)
-
-
-class _TailKVFn(torch.autograd.Function):
-    """[key_i; value_i](t) with the hoisted projection's shadows; the weight gradient is parked for _HoistedKVFn's
-    backward (which runs after every layer's backward: it needs all their gradients)."""
-
-    @staticmethod
-    def forward(ctx, t, hold, i):
-        w, b = hold.block(i)
-        tb = t if t.dtype == compute_dtype() else t.to(compute_dtype())
-        ctx.save_for_backward(tb, w)
-        ctx.hold, ctx.i, ctx.t_dtype = hold, i, t.dtype
-        return _fwd2(tb.reshape(-1, tb.shape[-1]), w, b).view(*tb.shape[:-1], w.shape[0])
-
-    @staticmethod
-    def backward(ctx, g):
-        tb, w = ctx.saved_tensors
-        g2 = g.reshape(-1, g.shape[-1])
-        if not g2.is_contiguous():
-            g2 = g2.contiguous()
-        t2 = tb.reshape(-1, tb.shape[-1])
-        if _defer_ok(g2, t2):
-            sa = ctx.hold.selfattns[ctx.i]
-            _park(g2, t2, [sa.key.weight, sa.value.weight], [sa.key.bias, sa.value.bias])
-        else:
-            ctx.hold.tails.append((ctx.i, g2, t2))
-        return _dx2(g2, w).view(tb.shape).to(ctx.t_dtype), None, None
-
-
-_MASK2_CACHE = {}
-
-
-def _mask_log2_two(mask, B, L1, L2):
-    if mask is None:
-        return None
-    import weakref
-    key = (id(mask), L1, L2)
-    hit = _MASK2_CACHE.get(key)
-    if hit is not None and hit[0]() is mask and hit[1] == mask._version:
-        return hit[2]
-    from . import _ext
-    if len(_MASK2_CACHE) > 64:
-        _MASK2_CACHE.clear()
-    m = _ext.key_mask_log2_two(mask, B, L1, L2)
-    _MASK2_CACHE[key] = (weakref.ref(mask), mask._version, m)
-    return m
-
-
-class _QKV2Attention(torch.autograd.Function):
-    """Cross-attention of q (B, Lq <= 32, H, 64) over the keys / values cat(kv1, kv2) given as two fused K/V tensors
-    (B, L1, 2, H, 64) (may be a strided view of a hoisted projection) and (B, L2, 2, H, 64) -- never concatenated."""
-
-    @staticmethod
-    def forward(ctx, q, kv1, kv2, scale, mask_log2, p_drop, sink):
-        from . import _ext
-        seed, st = _seed_args(p_drop, q.device)
-        out, lse = _ext.attn_fwd2(q, kv1[:, :, 0], kv1[:, :, 1], kv2[:, :, 0], kv2[:, :, 1], scale, mask_log2, p_drop,
-                                  seed, st)
-        ctx.save_for_backward(q, kv1, kv2, out, lse, mask_log2 if mask_log2 is not None else q.new_empty(0),
-                              st if st is not None else q.new_empty(0))
-        ctx.cfg = (scale, p_drop, seed, mask_log2 is not None, st is not None, sink)
-        return out
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        from . import _ext
-        q, kv1, kv2, out, lse, mask_log2, st = ctx.saved_tensors
-        scale, p_drop, seed, has_mask, has_st, sink = ctx.cfg
-        qc = q if q.is_contiguous() else q.contiguous()
-        dq, dkv2 = torch.empty_like(qc), torch.empty_like(kv2)
-        if sink is not None:
-            dkv1 = sink[0].grad_view(sink[1], kv1)  # this layer's column block of the hoisted projection's gradient
-        else:
-            if not kv1.is_contiguous():
-                raise RuntimeError("two-segment attention without a gradient sink needs a contiguous first segment")
-            dkv1 = torch.empty_like(kv1)
-        _ext.attn_bwd2(qc, kv1[:, :, 0], kv1[:, :, 1], kv2[:, :, 0], kv2[:, :, 1], out, lse, grad_out, scale, dq,
-                       dkv1[:, :, 0], dkv1[:, :, 1], dkv2[:, :, 0], dkv2[:, :, 1], mask_log2 if has_mask else None,
-                       p_drop, seed, st if has_st else None)
-        if sink is not None:
-            sink[0].push_dx(sink[1])
-        return dq, dkv1, dkv2, None, None, None, None
-
-
-class _TwinQKV2Attention(torch.autograd.Function):
-    """the two cross-attentions of one twin level over hoisted projections: queries stacked (2B, L, H, 64); stream g reads
-    the keys / values cat(kv1_g (hoisted, strided), kv2_g (B, L2, 2, H, 64)); context and dq come back stacked (no cat, no
-    slice gradients), d(kv1_g) goes straight into its hoisted gradient buffer"""
-
-    @staticmethod
-    def forward(ctx, q, kva1, kva2, kvb1, kvb2, scale, ma, mb, p_drop, sink_a, sink_b):
-        from . import _ext
-        B = q.shape[0] // 2
-        out = torch.empty_like(q)
-        seeds, lses = [], []
-        for g, (k1, k2, m) in enumerate(((kva1, kva2, ma), (kvb1, kvb2, mb))):
-            seed, st = _seed_args(p_drop, q.device)
-            _, lse = _ext.attn_fwd2(q[g * B:(g + 1) * B], k1[:, :, 0], k1[:, :, 1], k2[:, :, 0], k2[:, :, 1], scale, m, p_drop,
-                                    seed, st, out=out[g * B:(g + 1) * B])
-            seeds.append(seed)
-            lses.append(lse)
-        e = q.new_empty(0)
-        ctx.save_for_backward(q, kva1, kva2, kvb1, kvb2, out, lses[0], lses[1], ma if ma is not None else e,
-                              mb if mb is not None else e, st if st is not None else e)
-        ctx.cfg = (scale, p_drop, seeds, ma is not None, mb is not None, st is not None, sink_a, sink_b)
-        return out
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        from . import _ext
-        q, kva1, kva2, kvb1, kvb2, out, lsa, lsb, ma, mb, st = ctx.saved_tensors
-        scale, p_drop, seeds, has_ma, has_mb, has_st, sink_a, sink_b = ctx.cfg
-        B = q.shape[0] // 2
-        go = grad_out if grad_out.is_contiguous() else grad_out.contiguous()
-        dq = torch.empty_like(q)
-        d2a, d2b = torch.empty_like(kva2), torch.empty_like(kvb2)
-        d1a, d1b = sink_a[0].grad_view(sink_a[1], kva1), sink_b[0].grad_view(sink_b[1], kvb1)
-        for g, (k1, k2, d1, d2, lse, m, has_m) in enumerate(((kva1, kva2, d1a, d2a, lsa, ma, has_ma),
-                                                             (kvb1, kvb2, d1b, d2b, lsb, mb, has_mb))):
-            sl = slice(g * B, (g + 1) * B)
-            _ext.attn_bwd2(q[sl], k1[:, :, 0], k1[:, :, 1], k2[:, :, 0], k2[:, :, 1], out[sl], lse, go[sl], scale, dq[sl],
-                           d1[:, :, 0], d1[:, :, 1], d2[:, :, 0], d2[:, :, 1], m if has_m else None, p_drop, seeds[g],
-                           st if has_st else None)
-        sink_a[0].push_dx(sink_a[1])
-        sink_b[0].push_dx(sink_b[1])
-        return dq, d1a, d2a, d1b, d2b, None, None, None, None, None, None
-
-
-def twin_cross_attention2(q, h2d, h3d, slot, tail2d, tail3d, scale, dropout_p, mask2d, mask3d):
-    """stacked twin cross-attention over (hoisted projection slot, per-level tail) key segments; q (2B, L, H, 64) contiguous
-    bf16; tail2d / tail3d (B, L2, 2, H, 64) from HoistedKV.tail_kv"""
-    B = q.shape[0] // 2
-    kva1, kvb1 = h2d.kv(slot), h3d.kv(slot)
-    ma = _mask_log2_two(mask2d, B, kva1.shape[1], tail2d.shape[1])
-    mb = _mask_log2_two(mask3d, B, kvb1.shape[1], tail3d.shape[1])
-    return _TwinQKV2Attention.apply(q, kva1, tail2d, kvb1, tail3d, scale, ma, mb, float(dropout_p), (h2d, slot), (h3d, slot))
-
-
-def two_segment_ok(q, kv1, kv2, mask):
-    return (q.is_cuda and q.dtype == torch.bfloat16 and q.shape[1] <= 32 and q.shape[-1] == 64 and q.stride(-1) == 1
-            and kv1.dtype == torch.bfloat16 and kv2.dtype == torch.bfloat16 and kv2.is_contiguous()
-            and (mask is None or (mask.dim() == 4 and mask.shape[1] == 1 and mask.shape[2] == 1)))
-
-
-def attention_q_kv2(q, kv1, kv2, scale, dropout_p=0.0, mask=None, sink=None):
-    """Cross-attention over cat(kv1, kv2) along the key axis: q (B, Lq, H, D), kv1 (B, L1, 2, H, D), kv2 (B, L2, 2, H, D);
-    mask additive (B,1,1,L1+L2) or None.  sink = (HoistedKV, slot) when kv1 comes from a hoisted projection."""
-    if two_segment_ok(q, kv1, kv2, mask):
-        m = _mask_log2_two(mask, q.shape[0], kv1.shape[1], kv2.shape[1])
-        return _QKV2Attention.apply(q, kv1, kv2, scale, m, float(dropout_p), sink)
-    kv = torch.cat((kv1, kv2), dim=1)
-    ctx, _ = attention(q, kv[:, :, 0], kv[:, :, 1], mask, scale, dropout_p=dropout_p)
-    return ctx
 
 
 def _packed_ok(t, mask, strided=False):

@@ -166,23 +166,34 @@ def plan_big_launches(tiles, cus, max_problems=36, moved_cost=0.011):
     return plan
 
 
+def _nrows(t):
+    """rows of a GEMM row operand: (rows, cols), or a (batch, rows, cols) batched-row view (_ext._mat_rows)"""
+    return t.shape[0] if t.dim() == 2 else t.shape[0] * t.shape[1]
+
+
 def flush_deferred_items(items):
+    """items: (dY, X, weights, biases[, primary]) records.  `primary` (optional) = index of ANOTHER record of the same
+    weights: this record's rows are a second row source of that weight gradient (the twin K/V projection reads image
+    tokens and the other stream's states, _TwinKVFn) and are ADDED to it by a launch behind the primary one."""
     if not items:
         return
     from . import _ext
     flags = _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32
+    items = [tuple(it) + (None,) * (5 - len(it)) for it in items]
     dws = [None] * len(items)
-    big = [k for k, it in enumerate(items) if it[0].shape[0] >= _BIG_ROWS]
-    small = [k for k, it in enumerate(items) if it[0].shape[0] < _BIG_ROWS]
+    prim = [k for k, it in enumerate(items) if it[4] is None]
+    second = [k for k, it in enumerate(items) if it[4] is not None]
+    big = [k for k in prim if _nrows(items[k][0]) >= _BIG_ROWS]
+    small = [k for k in prim if _nrows(items[k][0]) < _BIG_ROWS]
     if _PLAN_WGRAD[0]:
         # longest contractions first: a launch's workgroups start in tile order, so the long tiles (16 720-row image
         # tokens) run from the beginning and the short ones (4 416-row object tokens) fill in behind them (A/B x4: 40.88 vs
         # 40.91 ms -- inside the noise; kept because it cannot hurt)
-        big.sort(key=lambda k: -items[k][0].shape[0])
+        big.sort(key=lambda k: -_nrows(items[k][0]))
     groups = [big] if big else []
     if big and _PLAN_WGRAD[0]:
         tj = _DW_TILE[0]
-        tiles = [-(-items[k][0].shape[1] // tj) * -(-items[k][1].shape[1] // 256) for k in big]
+        tiles = [-(-items[k][0].shape[-1] // tj) * -(-items[k][1].shape[-1] // 256) for k in big]
         cus = torch.cuda.get_device_properties(items[big[0]][0].device).multi_processor_count
         plan_groups, moved = plan_big_launches(tiles, cus * (256 // tj))
         groups = [[big[j] for j in g] for g in plan_groups]
@@ -193,20 +204,32 @@ def flush_deferred_items(items):
             probs = []
             for k in idx:
                 g2, x2 = items[k][0], items[k][1]
-                dws[k] = torch.empty(g2.shape[1], x2.shape[1], dtype=torch.float32, device=g2.device)
+                dws[k] = torch.empty(g2.shape[-1], x2.shape[-1], dtype=torch.float32, device=g2.device)
                 pr = dict(P=x2, Q=g2, out=dws[k])
                 if items[k][3] is not None and _QSUM[0] and (tile != 64 or _QSUM64[0]):
                     # the bias gradient (column sums of dY) from the same launch: four more MFMAs per K tile in a third
                     # of the workgroups instead of a second pass over dY (csrc/gemm.hip, QSUM)
-                    dbs[k] = torch.empty(g2.shape[1], dtype=torch.float32, device=g2.device)
+                    dbs[k] = torch.empty(g2.shape[-1], dtype=torch.float32, device=g2.device)
                     pr["colsum"] = dbs[k]
                 probs.append(pr)
             _ext.gemm_grouped(probs, flags, _ext.EPI_NONE, tile)
-    with_b = [k for k, it in enumerate(items) if it[3] is not None and k not in dbs]
+    with_b = [k for k in prim if items[k][3] is not None and k not in dbs]
     if with_b:
-        dbs.update(zip(with_b, _ext.colsum_grouped([items[k][0] for k in with_b])))
-    for k, (g2, x2, ws, bs) in enumerate(items):
-        n = g2.shape[1] // len(ws)
+        dbs.update(zip(with_b, _ext.colsum_grouped([items[k][0].reshape(-1, items[k][0].shape[-1]) for k in with_b])))
+    if second:
+        # second row sources: added onto the stored gradient of their primary record (same stream: ordered behind it) by
+        # the small-tile kernel's atomic epilogue -- short contractions (B x 20 text rows)
+        probs = []
+        for k in second:
+            g2, x2, pk = items[k][0], items[k][1], items[k][4]
+            pr = dict(P=x2, Q=g2, out=dws[pk], accum=True)
+            if items[pk][3] is not None:
+                pr["colsum"] = dbs[pk]
+            probs.append(pr)
+        _ext.gemm_grouped(probs, flags, _ext.EPI_NONE, 64)
+    for k in prim:
+        g2, x2, ws, bs = items[k][:4]
+        n = g2.shape[-1] // len(ws)
         for j, w in enumerate(ws):
             _accumulate_grad(w, dws[k][j * n:(j + 1) * n] if len(ws) > 1 else dws[k].view(w.shape))
             if bs is not None:
@@ -220,6 +243,14 @@ def _defer_ok(g2, x2):
 
 def _park(g2, x2, ws, bs):
     _DEFER[0].append((_rows(g2), _rows(x2), ws, bs))
+
+
+def _park_two(g_a, x_a, g_b, x_b, ws, bs):
+    """one weight gradient from TWO row sources: dW = g_a^T x_a + g_b^T x_b (g_*: (rows, N) or batched-row views
+    (batch, rows, N) read in place; x_*: (rows, K)); the second source is added behind the first (flush_deferred_items)"""
+    d = _DEFER[0]
+    d.append((g_a, _rows(x_a), ws, bs))
+    d.append((g_b, _rows(x_b), ws, bs, len(d) - 1))
 
 
 

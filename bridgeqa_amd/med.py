@@ -97,15 +97,6 @@ class BertEmbeddings(nn.Module):
         return self.dropout(ops.layer_norm(embeddings, self.LayerNorm))
 
 
-class TwoSegmentStates(object):
-    """encoder_hidden_states of a twin cross-attention in factored form: cat(fixed tokens, tail) along the sequence,
-    where the fixed tokens' K/V for this layer come from `hoisted` (ops.HoistedKV, slot `slot`) and `tail`
-    (B, L2, hidden) is the other stream's state of the previous layer (reference med.py:549-562)."""
-
-    def __init__(self, hoisted, slot, tail):
-        self.hoisted, self.slot, self.tail = hoisted, slot, tail
-
-
 class HoistedStates(object):
     """encoder_hidden_states whose K/V projection for this layer is slot `slot` of `hoisted` (ops.HoistedKV): the
     decoder's 12 cross-attentions read the same question states, so their key / value linears run as one GEMM."""
@@ -158,29 +149,18 @@ class BertSelfAttention(nn.Module):
         want = output_attentions or (is_cross and self.save_attention)
         H, D = self.num_attention_heads, self.attention_head_size
         p_drop = self.dropout.p if self.training else 0.0
-        two_seg = isinstance(encoder_hidden_states, TwoSegmentStates)     # (its kernels have no attention-map output)
         hoisted_kv = isinstance(encoder_hidden_states, HoistedStates)
         # the fused kernels also serve output_attentions (the map is rebuilt from the LSE, detached); a caller that
         # differentiates through the map -- save_attention + the attn_gradients hook -- gets the reference composition
         hooked = is_cross and self.save_attention
-        if (not hooked and (not output_attentions or not two_seg) and past_key_value is None
-                and ops.compute_dtype() == torch.bfloat16 and (hidden_states.is_cuda or two_seg or hoisted_kv)):
+        if (not hooked and past_key_value is None
+                and ops.compute_dtype() == torch.bfloat16 and (hidden_states.is_cuda or hoisted_kv)):
             # fused projections: Q/K/V (self) or K/V (cross) as ONE GEMM over the shared input, and the attention
             # kernels read / write the packed tensors in place
             B, L = hidden_states.shape[:2]
             rp = bool(output_attentions)
             probs = None
-            if is_cross and isinstance(encoder_hidden_states, TwoSegmentStates):
-                # keys / values = cat(hoisted projection of the fixed tokens, this layer's projection of the other
-                # stream's states) -- handed to the kernels as two segments, never concatenated
-                es = encoder_hidden_states
-                q = self._heads(ops.linear(hidden_states, self.query.weight, self.query.bias, tap=tap))
-                kv1 = es.hoisted.kv(es.slot)
-                kv2 = es.hoisted.tail_kv(es.slot, es.tail)
-                ctx = ops.attention_q_kv2(q, kv1, kv2, 1.0 / math.sqrt(D), p_drop, encoder_attention_mask,
-                                          sink=(es.hoisted, es.slot))
-                present = None
-            elif is_cross and isinstance(encoder_hidden_states, HoistedStates):
+            if is_cross and isinstance(encoder_hidden_states, HoistedStates):
                 es = encoder_hidden_states
                 q = self._heads(ops.linear(hidden_states, self.query.weight, self.query.bias, tap=tap))
                 kv = es.hoisted.kv(es.slot)
@@ -210,7 +190,7 @@ class BertSelfAttention(nn.Module):
                 ctx, probs = ctx
                 return (ctx.reshape(B, L, self.all_head_size), probs, present)
             return (ctx.reshape(B, L, self.all_head_size), present)
-        if two_seg or hoisted_kv:
+        if hoisted_kv:
             raise RuntimeError("factored encoder states (hoisted K/V projections) reached the reference composition: "
                                "they need the kernel path (bf16 compute, no past_key_value, no save_attention hook)")
         q = self._heads(ops.linear(hidden_states, self.query.weight, self.query.bias, tap=tap))
@@ -352,8 +332,6 @@ class BertLayer(nn.Module):
 
 _TWIN_BATCH = [True]  # both text streams of a twin level as one stacked batch
 _HOIST_CROSS_KV = True  # plain encoder / decoder: all layers' cross K/V in one GEMM
-_TWO_SEGMENT = False   # (measured neutral, DESIGN.md §5 c: kept as a tested alternative wiring, off)
-_TWO_SEGMENT_FORK = False  # also when the twin branches run on two streams
 
 
 def _wants(output_attentions, i, last):
@@ -442,19 +420,26 @@ class BertEncoderTwin(BertEncoder):
             lins += [l.intermediate.dense, l.output.dense]
         return ops.twin_kernel_ok(hs, lins)
 
-    def _twin_level(self, i, hs, mask2, enc2d, enc3d, mask2d, mask3d, layernorm_idx, want=False, hoist=None):
+    def _twin_level(self, i, hs, mask2, enc2d, enc3d, mask2d, mask3d, layernorm_idx, want=False, sinks=None):
         """one level of BOTH streams on the stacked states hs (2B, L, D) (rows [0,B) = 2D stream through layer[i], rows
         [B,2B) = 3D stream through layer_twin[i]); the arithmetic per stream is BertLayer.forward's (self-attention ->
         cross-attention over cat(fixed tokens, other stream's previous states) -> FFN, post-LN; reference
-        med.py:549-614), with one launch per projection / LayerNorm for the pair."""
+        med.py:549-614), with one launch per projection / LayerNorm for the pair.  sinks: (GradSink, GradSink) of enc2d /
+        enc3d -- the kernel path: the K/V projections read their two row sources in place (ops.twin_kv), nothing is
+        concatenated."""
         a, b = self.layer[i], self.layer_twin[i]
         sa, sb = a.attention.self, b.attention.self
+        ca, cb = a.crossattention.self, b.crossattention.self
         B2, L, D = hs.shape
         B, H, hd = B2 // 2, sa.num_attention_heads, sa.attention_head_size
         scale = 1.0 / math.sqrt(hd)
         p_att = sa.dropout.p if self.training else 0.0
         # keys / values of the cross-attentions come from the PREVIOUS states of the other stream
-        if hoist is None:
+        if sinks is not None:
+            t0 = ops.GradTap()   # (the gradient of hs through its other readers joins the K/V node's dX launch)
+            kv2d, kv3d = ops.twin_kv(enc2d, enc3d, hs, (ca.key, ca.value), (cb.key, cb.value), sinks[0], sinks[1], tap=t0)
+            hs = ops.tap(hs, t0)
+        else:
             mix2d, mix3d = ops.twin_mix(enc2d, enc3d, hs)
         # (t1-t3: the residual-branch gradient of each sub-block's input rides on the dX GEMM of its first linear)
         t1, t2, t3 = ops.GradTap(), ops.GradTap(), ops.GradTap()
@@ -465,23 +450,14 @@ class BertEncoderTwin(BertEncoder):
         h = ops.twin_linear(ctx.reshape(B2, L, D), a.attention.output.dense, b.attention.output.dense)
         att = ops.twin_dropout_add_layer_norm(h, ops.tap(hs, t1), a.attention.output.LayerNorm,
                                               b.attention.output.LayerNorm, a.attention.output.dropout.p, self.training)
-        ca, cb = a.crossattention.self, b.crossattention.self
         q = ops.twin_linear(att, ca.query, cb.query, tap=t2).view(B2, L, H, hd)
         p_c = ca.dropout.p if self.training else 0.0
-        if hoist is not None:
-            # BQ_TWO_SEGMENT_KV=1: the fixed tokens' K/V of this level are a column block of ONE hoisted projection (no
-            # cat, no per-level K/V GEMM over the image tokens, its gradient written in place), the other stream's
-            # states go through the same weights as a 20-row second key segment
-            h2d, h3d, slot = hoist
-            hs3, hs2 = ops.twin_split(hs)[::-1]   # (3D-stream states, 2D-stream states): backward = one cat
-            c = ops.twin_cross_attention2(q, h2d, h3d, slot, h2d.tail_kv(slot, hs3), h3d.tail_kv(slot, hs2), scale, p_c,
-                                          mask2d, mask3d)
-        else:
+        if sinks is None:
             kv2d, kv3d = ops.twin_multi_linear_var(mix2d, mix3d, (ca.key, ca.value), (cb.key, cb.value))
-            c = ops.twin_cross_attention(q, kv2d.view(B, mix2d.shape[1], 2, H, hd), kv3d.view(B, mix3d.shape[1], 2, H, hd),
-                                         scale, p_c, mask2d, mask3d, return_probs=want)
-            if want:
-                c, p_c2d, p_c3d = c
+        c = ops.twin_cross_attention(q, kv2d.view(B, kv2d.shape[1], 2, H, hd), kv3d.view(B, kv3d.shape[1], 2, H, hd),
+                                     scale, p_c, mask2d, mask3d, return_probs=want)
+        if want:
+            c, p_c2d, p_c3d = c
         h = ops.twin_linear(c.reshape(B2, L, D), a.crossattention.output.dense, b.crossattention.output.dense)
         att = ops.twin_dropout_add_layer_norm(h, ops.tap(att, t2), a.crossattention.output.LayerNorm,
                                               b.crossattention.output.LayerNorm, a.crossattention.output.dropout.p,
@@ -506,23 +482,9 @@ class BertEncoderTwin(BertEncoder):
         ops.prime_masks(attention_mask, encoder_attention_mask, encoder_attention_mask_twin)
         enc2d = ops._c(encoder_hidden_states)
         enc3d = ops._c(encoder_hidden_states_twin)
-        # BQ_TWO_SEGMENT_KV=1: the image / object tokens' K/V of ALL layers from one hoisted GEMM per stream, the
-        # cross-attention over two key segments (no per-layer cat, no strided slicing of its gradient)
-        # Layers that must return their attention probabilities (output_attentions=True, or the last layer under
-        # "last" as BLIP_VQA3D asks) keep the concatenated wiring.
-        hoisted_layers = []
-        if (_TWO_SEGMENT and mode == "multimodal" and ops.compute_dtype() == torch.bfloat16
-                and hidden_states.shape[1] <= 32
-                and (_TWO_SEGMENT_FORK or not ops.overlap_enabled(hidden_states))):
-            hoisted_layers = [i for i in layers if i < self.num_hidden_layers_twin
-                              and not _wants(output_attentions, i, layers[-1])
-                              and not self.layer[i].crossattention.self.save_attention
-                              and not self.layer_twin[i].crossattention.self.save_attention]
-        slot_of = {i: s_ for s_, i in enumerate(hoisted_layers)}
-        if hoisted_layers:
-            heads = self.config.num_attention_heads
-            h2d = ops.HoistedKV(enc2d, [self.layer[i].crossattention.self for i in hoisted_layers], heads)
-            h3d = ops.HoistedKV(enc3d, [self.layer_twin[i].crossattention.self for i in hoisted_layers], heads)
+        # kernel path: the cross-attention K/V projections read (fixed tokens, other stream's states) in place and the
+        # fixed tokens' gradient accumulates in ONE buffer per stream over the levels (ops.twin_kv / ops.GradSink)
+        sinks = (ops.GradSink(), ops.GradSink())
         stacked = mask2 = None   # the two streams as one (2B, L, D) tensor while consecutive levels run paired
         for i in layers:
             if output_hidden_states:
@@ -533,7 +495,7 @@ class BertEncoderTwin(BertEncoder):
             want = _wants(output_attentions, i, layers[-1])
             twin = self.layer_twin[i] if i < self.num_hidden_layers_twin else None
             key_only = lambda m: m is None or (m.dim() == 4 and m.shape[1] == 1 and m.shape[2] == 1)
-            if ((not hoisted_layers or (i in slot_of and not want)) and mode == "multimodal" and attention_mask is not None
+            if (mode == "multimodal" and attention_mask is not None
                     and key_only(attention_mask) and key_only(encoder_attention_mask)
                     and key_only(encoder_attention_mask_twin)
                     and self._pairable(i, ops._c(hidden_states) if stacked is None else stacked)):
@@ -544,7 +506,7 @@ class BertEncoderTwin(BertEncoder):
                     ops.prime_masks(mask2)
                 stacked = self._twin_level(i, stacked, mask2, enc2d, enc3d, encoder_attention_mask,
                                            encoder_attention_mask_twin, layernorm_idx, want,
-                                           hoist=(h2d, h3d, slot_of[i]) if i in slot_of else None)
+                                           sinks=sinks if ops.twin_kv_ok(enc2d, enc3d, stacked) else None)
                 if want:
                     stacked, self_att, cross_att = stacked
                     all_self_attentions = all_self_attentions + (self_att,)
@@ -554,17 +516,12 @@ class BertEncoderTwin(BertEncoder):
             if stacked is not None:
                 hidden_states, hidden_states_twin = ops.twin_split(stacked)
                 stacked = None
-            if i in slot_of:
-                mix2d = TwoSegmentStates(h2d, slot_of[i], ops._c(hidden_states_twin))
-                mix3d = TwoSegmentStates(h3d, slot_of[i], ops._c(hidden_states))
-            else:
-                mix2d = torch.cat((enc2d, ops._c(hidden_states_twin)), dim=1)
-                mix3d = torch.cat((enc3d, ops._c(hidden_states)), dim=1)
+            mix2d = torch.cat((enc2d, ops._c(hidden_states_twin)), dim=1)
+            mix3d = torch.cat((enc3d, ops._c(hidden_states)), dim=1)
             if twin is not None and ops.overlap_enabled(hidden_states):
                 # the two streams of a layer only depend on each other's PREVIOUS state: run them side by side
                 with ops.fork("twin", hidden_states) as f:
-                    f.uses(hidden_states_twin, attention_mask, encoder_attention_mask_twin,
-                           *([mix3d] if torch.is_tensor(mix3d) else [mix3d.tail, mix3d.hoisted.outs[mix3d.slot]]))
+                    f.uses(hidden_states_twin, attention_mask, encoder_attention_mask_twin, mix3d)
                     out3d = twin(hidden_states_twin, attention_mask, None, mix3d, encoder_attention_mask_twin, None,
                                  want, mode=mode, layernorm_idx=layernorm_idx)
                 out2d = self.layer[i](hidden_states, attention_mask, None, mix2d, encoder_attention_mask, None, want,

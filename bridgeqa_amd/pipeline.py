@@ -93,8 +93,10 @@ class PhasedTrainStep(object):
         self.image_splits = max(1, int(image_bwd_splits))
         vit = model.blip_model.visual_encoder
         depth = len(vit.blocks)
-        vit.grad_cuts = tuple(sorted({depth * k // self.image_splits for k in range(1, self.image_splits)} - {0}))
-        self.image_splits = len(vit.grad_cuts) + 1
+        # (kept HERE, not on the module: the cuts are switched on around this step's image forward only, so a plain
+        # model(data_dict) + loss.backward() outside PhasedTrainStep still differentiates down to patch_embed)
+        self._vit_cuts = tuple(sorted({depth * k // self.image_splits for k in range(1, self.image_splits)} - {0}))
+        self.image_splits = len(self._vit_cuts) + 1
         if self.image_splits > 4:
             raise ValueError("image_bwd_splits: at most 4 block ranges")
         self._seg_probe = None   # attach_reducers: {segment: parameters whose gradient that segment produced}
@@ -126,8 +128,14 @@ class PhasedTrainStep(object):
     # ---- phases (each runs entirely on one stream) -----------------------------------------------------------
     def _image_fwd(self):
         ops.new_step(self.dev)
-        self._state["img"] = self.model.encode_image(self.batch)
-        self._state["img_cuts"] = list(self.model.blip_model.visual_encoder.cut_pairs)
+        vit = self.model.blip_model.visual_encoder
+        with vit.autograd_cuts(self._vit_cuts):
+            self._state["img"] = self.model.encode_image(self.batch)
+        self._state["img_cuts"], vit.cut_pairs = list(vit.cut_pairs), []   # (the module does not keep them alive)
+        if len(self._state["img_cuts"]) != self.image_splits - 1:
+            raise RuntimeError("image_bwd_splits=%d needs the image encoder's fused block path (no grad checkpointing, "
+                               "no register_blk / return_fm): the forward made %d of %d autograd cuts"
+                               % (self.image_splits, len(self._state["img_cuts"]), self.image_splits - 1))
 
     def _geometry(self):
         """sampling / grouping indices of the next batch, into the persistent `next` buffers"""
@@ -188,6 +196,8 @@ class PhasedTrainStep(object):
                 torch.autograd.backward([x, n], [xl.grad, nl.grad])
         finally:
             ops.flush_deferred_wgrad()
+        if seg == self.image_splits - 1 and not torch.cuda.is_current_stream_capturing():
+            st["img_cuts"] = []   # (eager steps: the cut activations die with the step; captured ones live in the pool)
         if self._seg_probe is not None:   # (dry eager step of attach_reducers)
             seen = {id(p) for ps in self._seg_probe.values() for p in ps}
             self._seg_probe[seg] = [p for p in self.model.blip_model.visual_encoder.parameters()

@@ -186,6 +186,9 @@ class VisionTransformer(nn.Module):
                   use_grad_checkpointing=(use_grad_checkpointing and i >= depth - ckpt_layer))
             for i in range(depth)])
         self.norm = norm_layer(embed_dim)
+        # autograd cuts (pipeline.PhasedTrainStep(image_bwd_splits=...)): scoped to ONE forward by autograd_cuts() --
+        # never persistent state, a plain forward + loss.backward() must reach patch_embed
+        self.grad_cuts, self.cut_pairs = (), []
         nn.init.trunc_normal_(self.pos_embed, std=0.02)
         nn.init.trunc_normal_(self.cls_token, std=0.02)
         self.apply(self._init_weights)
@@ -203,8 +206,14 @@ class VisionTransformer(nn.Module):
     def no_weight_decay(self):
         return {"pos_embed", "cls_token"}
 
+    def autograd_cuts(self, cuts):
+        """context manager: forwards run inside it detach the residual stream in front of blocks `cuts` and leave the
+        (outputs, leaves) pairs in self.cut_pairs; outside it grad_cuts is () again"""
+        return _AutogradCuts(self, cuts)
+
     def forward(self, x, register_blk=-1, return_fm=-1):
         B = x.shape[0]
+        self.cut_pairs = []
         x = self.patch_embed(x)
         x = torch.cat((self.cls_token.expand(B, -1, -1).to(x.dtype), x), dim=1)
         x = x + self.pos_embed[:, :x.size(1), :].to(x.dtype)
@@ -213,8 +222,7 @@ class VisionTransformer(nn.Module):
         if return_fm == -1 and all(blk.fusable(register_blk == i) for i, blk in enumerate(self.blocks)):
             # same arithmetic, 2 launches per block instead of 2 adds + 2 norms (+ casts)
             n = ops.layer_norm(x, self.blocks[0].norm1)
-            cuts = getattr(self, "grad_cuts", ())
-            self.cut_pairs = []
+            cuts = self.grad_cuts
             for i, blk in enumerate(self.blocks):
                 if i in cuts and torch.is_grad_enabled() and x.requires_grad:
                     # autograd cut in front of block i (pipeline.PhasedTrainStep(image_bwd_splits=...)): the backward then
@@ -230,6 +238,19 @@ class VisionTransformer(nn.Module):
             if len(self.blocks) + return_fm == i:
                 break
         return ops.layer_norm(x, self.norm)
+
+
+class _AutogradCuts(object):
+    def __init__(self, vit, cuts):
+        self.vit, self.cuts = vit, tuple(cuts)
+
+    def __enter__(self):
+        self.prev, self.vit.grad_cuts = self.vit.grad_cuts, self.cuts
+        return self.vit
+
+    def __exit__(self, *exc):
+        self.vit.grad_cuts = self.prev
+        return False
 
 
 def interpolate_pos_embed(pos_embed_checkpoint, visual_encoder):

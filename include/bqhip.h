@@ -33,7 +33,10 @@ extern "C" {
 #define BQ_EINVAL (-1)   /* bad extent / null pointer */
 #define BQ_ELIMIT (-2)   /* extent beyond what the kernels support (see each function) */
 
-#define BQHIP_ABI_VERSION 1
+/* 2 (round 4): bq_gemm_desc grew the batched-row maps (q_rpb / q_bstride / o_rpb / o_bstride), bq_ball_query_background,
+ * tile 128 and BQ_GEMM_BACKGROUND arrived after 1 without a bump: a stale libbqhip.so must fail the version check, not a
+ * symbol lookup or an EINVAL at its first launch */
+#define BQHIP_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define BQ_API __attribute__((visibility("default")))

@@ -151,12 +151,6 @@ BQ_API int bq_bn_backward(const void *dy, const void *x, const float *scale, con
 
 /* exact (erf) GELU, bf16 (vit.py:23-41 Mlp act_layer=nn.GELU); n % 8 == 0, 16-B aligned */
 BQ_API int bq_gelu_fwd_bf16(const void *x, void *y, long n, void *stream);
-/* The key / value sources of the two cross-attentions of a twin level (med.py:549-562), both concatenations in one
- * launch: out_g (B, P_g + L, D) = cat(fixed_g (B, P_g, D), tail_g (B, L, D)) along the token axis, bf16, D % 8 == 0,
- * contiguous tensors. */
-BQ_API int bq_twin_mix_bf16(const void *fixed_a, const void *tail_a, void *out_a, int Pa, const void *fixed_b,
-                            const void *tail_b, void *out_b, int Pb, int B, int L, int D, void *stream);
-
 /* The same over TWO row groups with their own LayerNorm parameters -- the 2D and the 3D text stream of the twin encoder
  * (models/med.py:549-614) stacked in one (M, H) tensor: rows [0, M/2) use gamma / beta, rows [M/2, M) gamma2 / beta2; one
  * launch for both streams' BertSelfOutput / BertOutput tails.  zero_out / dgb: f32 (2, 2, H) = per group dgamma, dbeta. */
@@ -275,6 +269,17 @@ typedef struct bq_gemm_desc {
                             the head of the next one (finite values times zeros), bounded by this size */
   int ksplit;            /* > 1 (fp32 out, tile 64): the contraction runs in ksplit pieces accumulated with fp32 atomics
                             into `out`, which the caller zero-fills (weight gradients over millions of rows) */
+  /* Batched-row maps (ABI 2).  q_rpb > 0: Q's logical row r (a j row, or a CONTRACTION row when Q is contraction-major)
+   * is read at element (r / q_rpb) * q_bstride + (r % q_rpb) * ldq -- a (batch, rows, cols) view whose batches are
+   * q_bstride elements apart; o_rpb / o_bstride: the same for the rows of out (and of out2 / aux, laid out like out).
+   * Replaces the torch.cat((image tokens, other stream's states), dim=1) in front of every cross-attention K/V
+   * projection of the twin text encoder (models/med.py:549-562) and the strided slicing of its gradient: the
+   * projection writes each source's rows into its row range of ONE (B, L1 + L2, 2 * D) key/value tensor, the input
+   * gradient and the weight gradient read their row range of its gradient.  Maps need: tile 128, 64 or 32 (tile 256:
+   * only on a contraction-major Q with q_rpb >= 64); rpb-mapped buffers below 2 GB; q_bstride % 8 == 0, o_bstride % 8. */
+  int q_rpb, q_bstride, o_rpb, o_bstride;
+  int accum;             /* 1 (fp32 out, tile 64 / 32 only): out += result and colsum += sums with fp32 atomics -- a second
+                            row source of a weight gradient an earlier launch on the same stream has stored */
 } bq_gemm_desc;
 BQ_API int bq_gemm_max_problems(void); /* problems per launch; longer lists are split into several launches */
 BQ_API int bq_gemm_bf16(const bq_gemm_desc *problems, int n, int flags, int epilogue, int tile, void *stream);

@@ -138,13 +138,13 @@ def _worker_groups_and_buffers(rank, world, port, out):
         from bridgeqa_amd.vit import VisionTransformer
         torch.manual_seed(0)
         m = VisionTransformer(img_size=32, patch_size=16, embed_dim=64, depth=4, num_heads=1, drop_path_rate=0.0).train()
-        m.grad_cuts = (2,)
         bn = torch.nn.BatchNorm1d(8)                       # buffers: running_mean / running_var / num_batches_tracked
         bn.running_mean.fill_(float(rank + 1)); bn.num_batches_tracked.fill_(10 * (rank + 1))
         holder = torch.nn.ModuleList([m, bn])
         torch.manual_seed(100 + rank)                      # every rank its own shard
         x = torch.randn(2, 3, 32, 32)
-        y = m(x)
+        with m.autograd_cuts((2,)):
+            y = m(x)
         y.sum().backward()                                 # range 0: blocks 2-3
         seg0 = [p for p in m.parameters() if p.grad is not None]
         (xo, no), (xl, nl) = m.cut_pairs[0]

@@ -211,14 +211,73 @@ def test_twin_layer_norm_kernel_equals_two_single_launches(dev):
                 assert 0.85 < kept < 0.95, kept
 
 
-def test_twin_mix_kernel_equals_torch_cat(dev):
-    from bridgeqa_amd import _ext
-    g = torch.Generator().manual_seed(3)
-    for B, Pa, Pb, L, D in ((16, 1025, 256, 20, 768), (2, 7, 300, 5, 256), (1, 1, 1, 1, 8)):
-        mk = lambda *s: torch.randn(*s, generator=g).to(dev).to(torch.bfloat16)
-        fa, fb, hs = mk(B, Pa, D), mk(B, Pb, D), mk(2 * B, L, D)
-        oa, ob = _ext.twin_mix(fa, hs[B:], fb, hs[:B])
-        assert torch.equal(oa, torch.cat((fa, hs[B:]), 1)) and torch.equal(ob, torch.cat((fb, hs[:B]), 1))
+@pytest.mark.parametrize("B,P2,P3,L,D", [(16, 1025, 256, 20, 768), (2, 70, 9, 5, 256), (1, 64, 64, 20, 256)])
+def test_twin_kv_equals_concatenated_projections(dev, bf16, B, P2, P3, L, D):
+    """ops.twin_kv (reference med.py:549-562 + :112-118: K/V projections of cat(fixed tokens, other stream's states)) reads
+    both row sources in place and writes ONE key/value tensor per stream (batched-row maps of bq_gemm_bf16): against the
+    torch composition cat -> F.linear in fp32 on the same bf16 operands -- outputs, the fixed tokens' gradient ACCUMULATED
+    over two levels in the GradSink, the states' gradient with the tapped share added, weight / bias gradients from two
+    row sources, immediate and deferred (grouped flush)."""
+    from bridgeqa_amd import fusion_ops as ops
+    g = torch.Generator().manual_seed(5)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    enc2d, enc3d = mk(B, P2, D).to(torch.bfloat16), mk(B, P3, D).to(torch.bfloat16)
+    lins = [[torch.nn.Linear(D, D).to(dev) for _ in range(4)] for _ in range(2)]   # per level: key_a, value_a, key_b, value_b
+    for lv in lins:
+        for l in lv:
+            l.weight.data.copy_(mk(D, D, sc=0.05)); l.bias.data.copy_(mk(D, sc=0.1))
+    hs = [mk(2 * B, L, D).to(torch.bfloat16) for _ in range(2)]
+    gk = [(mk(B, P2 + L, 2, D).to(torch.bfloat16), mk(B, P3 + L, 2, D).to(torch.bfloat16)) for _ in range(2)]
+    gtap = [mk(2 * B, L, D).to(torch.bfloat16) for _ in range(2)]   # what reaches hs through the level's other readers
+
+    def reference():
+        e2, e3 = enc2d.float().requires_grad_(True), enc3d.float().requires_grad_(True)
+        hl = [h.float().requires_grad_(True) for h in hs]
+        ws = [[l.weight.detach().to(torch.bfloat16).float().requires_grad_(True) for l in lv] for lv in lins]
+        bs = [[l.bias.detach().clone().requires_grad_(True) for l in lv] for lv in lins]
+        outs, loss = [], 0.0
+        for lv in range(2):
+            m2, m3 = torch.cat((e2, hl[lv][B:]), 1), torch.cat((e3, hl[lv][:B]), 1)
+            k2 = torch.stack((F.linear(m2, ws[lv][0], bs[lv][0]), F.linear(m2, ws[lv][1], bs[lv][1])), 2)
+            k3 = torch.stack((F.linear(m3, ws[lv][2], bs[lv][2]), F.linear(m3, ws[lv][3], bs[lv][3])), 2)
+            outs.append((k2, k3))
+            loss = loss + (k2 * gk[lv][0].float()).sum() + (k3 * gk[lv][1].float()).sum() + (hl[lv] * gtap[lv].float()).sum()
+        loss.backward()
+        return outs, e2.grad, e3.grad, [h.grad for h in hl], [[w.grad for w in wl] for wl in ws], [[b.grad for b in bl] for bl in bs]
+
+    import torch.nn.functional as F
+    want = reference()
+    rel = lambda a, b: ((a.float() - b.float()).norm() / (b.float().norm() + 1e-12)).item()
+    for deferred in (False, True):
+        for lv in lins:
+            for l in lv:
+                l.weight.grad = l.bias.grad = None
+        e2, e3 = enc2d.clone().requires_grad_(True), enc3d.clone().requires_grad_(True)
+        hl = [h.clone().requires_grad_(True) for h in hs]
+        sinks = (ops.GradSink(), ops.GradSink())
+        loss, outs = 0.0, []
+        for lv in range(2):
+            t0 = ops.GradTap()
+            k2, k3 = ops.twin_kv(e2, e3, hl[lv], lins[lv][0:2], lins[lv][2:4], sinks[0], sinks[1], tap=t0)
+            assert k2.shape == (B, P2 + L, 2, D) and k3.shape == (B, P3 + L, 2, D)
+            outs.append((k2, k3))
+            loss = loss + (k2.float() * gk[lv][0].float()).sum() + (k3.float() * gk[lv][1].float()).sum() \
+                + (ops.tap(hl[lv], t0).float() * gtap[lv].float()).sum()
+        if deferred:
+            ops.begin_deferred_wgrad()
+        loss.backward()
+        if deferred:
+            ops.flush_deferred_wgrad()
+        torch.cuda.synchronize()
+        for lv in range(2):
+            assert rel(outs[lv][0], want[0][lv][0]) < 6e-3 and rel(outs[lv][1], want[0][lv][1]) < 6e-3
+            assert rel(hl[lv].grad, want[3][lv]) < 1e-2, (deferred, lv)
+            for j in range(4):
+                assert rel(lins[lv][j].weight.grad, want[4][lv][j]) < 1e-2, (deferred, lv, j)
+                assert rel(lins[lv][j].bias.grad, want[5][lv][j]) < 1e-2, (deferred, lv, j)
+        # (bf16 accumulation over the levels in the sink: one rounding per level)
+        assert rel(e2.grad, want[1]) < 1.5e-2 and rel(e3.grad, want[2]) < 1.5e-2, deferred
+        assert sinks[0].buf is None and sinks[0].readers == 0
 
 
 def test_decoder_hoisted_cross_kv_equals_per_layer_projections(dev, bf16):

@@ -433,3 +433,82 @@ def test_background_launch_equals_the_full_grid(dev):
     d[0].P, d[0].Q, d[0].out = x.data_ptr(), dy.data_ptr(), o1.data_ptr()
     d[0].ldp, d[0].ldq, d[0].ldo, d[0].Ni, d[0].Nj, d[0].Kc = 768, 1536, 768, 768, 1536, 16400
     assert _ext._lib.bq_gemm_bf16(d, 1, flags | _ext.GEMM_BACKGROUND, _ext.EPI_NONE, 256, None) != 0
+
+
+# ---- batched-row maps (bq_gemm_desc q_rpb / o_rpb, ABI 2): a (batch, rows, cols) view with a batch stride as the row
+# operand or the output -- what replaced torch.cat in front of the twin encoder's K/V projections (med.py:549-562) -----
+MAP_CASES = [(16, 1025, 20, 768, 1536), (3, 130, 7, 256, 512), (2, 64, 64, 128, 256), (5, 20, 300, 192, 320)]
+
+
+@pytest.mark.parametrize("B,R1,R2,K,N", MAP_CASES)
+@pytest.mark.parametrize("tile", [128, 64, 32])
+def test_forward_writes_row_ranges_of_one_output(dev, B, R1, R2, K, N, tile):
+    """two row sources (B, R1, K) and (B, R2, K) through the same weights into ONE (B, R1 + R2, N) tensor: each problem's
+    output rows are a batched-row view of it; equals the projection of the concatenation"""
+    from bridgeqa_amd import _ext
+    if tile < 128 and B * R1 * N > 4e6:
+        pytest.skip("small-tile kernels are for small problems")
+    xa, xb, w = _rand((B, R1, K), dev, 21), _rand((B, R2, K), dev, 22), _rand((N, K), dev, 23, 0.1)
+    b = torch.randn(N, device=dev)
+    out = torch.full((B, R1 + R2, N), float("nan"), device=dev, dtype=torch.bfloat16)
+    _ext.gemm_grouped([dict(P=w, Q=xa.view(B * R1, K), out=out[:, :R1], bias=b),
+                       dict(P=w, Q=xb.view(B * R2, K), out=out[:, R1:], bias=b)], 0, _ext.EPI_BIAS, tile)
+    ref = torch.cat((xa, xb), 1).float() @ w.float().t() + b
+    _check(out, ref)
+
+
+@pytest.mark.parametrize("B,R1,R2,K,N", MAP_CASES)
+@pytest.mark.parametrize("tile", [128, 64, 32])
+def test_dx_reads_row_ranges_and_accumulates_in_place(dev, B, R1, R2, K, N, tile):
+    """input gradient of the same: Q = the row range of the (B, R1 + R2, N) gradient read in place (q map); the first
+    source's dX is ADDED into an existing buffer (EPI_ADD, aux = out), the second's to a tapped gradient"""
+    from bridgeqa_amd import _ext
+    if tile < 128 and B * R1 * N > 4e6:
+        pytest.skip("small-tile kernels are for small problems")
+    g, w = _rand((B, R1 + R2, N), dev, 31), _rand((N, K), dev, 32, 0.1)
+    acc0, tapg = _rand((B * R1, K), dev, 33), _rand((B * R2, K), dev, 34)
+    acc = acc0.clone()
+    dxb = torch.empty(B * R2, K, device=dev, dtype=torch.bfloat16)
+    _ext.gemm_grouped([dict(P=w, Q=g[:, :R1], out=acc, aux=acc), dict(P=w, Q=g[:, R1:], out=dxb, aux=tapg)],
+                      _ext.GEMM_P_XC, _ext.EPI_ADD, tile)
+    _check(acc, g[:, :R1].reshape(-1, N).float() @ w.float() + acc0.float())
+    _check(dxb, g[:, R1:].reshape(-1, N).float() @ w.float() + tapg.float())
+    # a mapped OUTPUT with a second operand laid out like it (aux under the same map)
+    base = _rand((B, R1 + R2, K), dev, 35)
+    out = base.clone()
+    x = _rand((B * R1, N), dev, 36)
+    _ext.gemm_grouped([dict(P=w, Q=x, out=out[:, :R1], aux=out[:, :R1])], _ext.GEMM_P_XC, _ext.EPI_ADD, tile)
+    _check(out[:, :R1], (x.float() @ w.float()).view(B, R1, K) + base[:, :R1].float())
+    assert torch.equal(out[:, R1:], base[:, R1:])                       # the other row range is untouched
+
+
+@pytest.mark.parametrize("B,R1,R2,K,N", MAP_CASES)
+def test_dw_from_two_row_sources(dev, B, R1, R2, K, N):
+    """weight gradient over the rows of BOTH sources: the first stored by the tile its size picks (256: the contraction-row
+    map walks the batches incrementally; 64: one division per DMA), the second ADDED by the small-tile kernel's atomic
+    epilogue (accum), column sums (bias gradient) likewise"""
+    from bridgeqa_amd import _ext
+    g = _rand((B, R1 + R2, N), dev, 41)
+    xa, xb = _rand((B * R1, K), dev, 42), _rand((B * R2, K), dev, 43)
+    f = _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32
+    ref = g[:, :R1].reshape(-1, N).float().t() @ xa.float() + g[:, R1:].reshape(-1, N).float().t() @ xb.float()
+    refb = g.float().sum((0, 1))
+    for tile in ([256, 64] if R1 >= 64 else [64]):
+        dw = torch.empty(N, K, device=dev)
+        db = torch.empty(N, device=dev)
+        _ext.gemm_grouped([dict(P=xa, Q=g[:, :R1], out=dw, colsum=db)], f, _ext.EPI_NONE, tile)
+        _ext.gemm_grouped([dict(P=xb, Q=g[:, R1:], out=dw, colsum=db, accum=True)], f, _ext.EPI_NONE, 64)
+        _check(dw, ref, f32=True)
+        _check(db, refb, f32=True)
+
+
+def test_row_maps_reject_what_the_kernels_cannot_address(dev):
+    from bridgeqa_amd import _ext
+    w, x = _rand((256, 128), dev, 51), _rand((4, 100, 128), dev, 52)
+    out = torch.empty(4, 120, 256, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):     # tile 256 maps only the contraction rows of its weight-gradient form
+        _ext.gemm_grouped([dict(P=w, Q=x.view(400, 128), out=out[:, :100])], 0, _ext.EPI_NONE, 256)
+    dw = torch.empty(256, 128, device=dev)
+    with pytest.raises(RuntimeError):     # accum needs the small-tile kernel
+        _ext.gemm_grouped([dict(P=x.view(400, 128), Q=_rand((400, 256), dev, 53), out=dw, accum=True)],
+                          _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32, _ext.EPI_NONE, 256)

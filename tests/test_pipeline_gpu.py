@@ -363,7 +363,7 @@ def test_split_image_backward_groups_and_buffer_broadcast_on_rccl_world_1(dev):
         bb.force = True
         dp = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, optimizer=None, use_graphs=True,
                              image_bwd_splits=3, buffer_broadcaster=bb, coverage_every=2)
-        assert model.blip_model.visual_encoder.grad_cuts == (4, 8)
+        assert dp._vit_cuts == (4, 8) and model.blip_model.visual_encoder.grad_cuts == ()   # scoped, not module state
 
         def make(ps):
             r = PackedGradReducer(ps)
@@ -397,8 +397,14 @@ def test_split_image_backward_groups_and_buffer_broadcast_on_rccl_world_1(dev):
         got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
         worst = max(((got[n] - want[n]).norm() / (want[n].norm() + 1e-12)).item() for n in want)
         assert worst < 2e-3, worst
+        # a plain forward + backward AFTER the split step was built still reaches the patch embedding
+        model.zero_grad(set_to_none=True)
+        dd = model(dict(batch))
+        (bench.det_loss(dd) + bench.fusion_loss(dd)).backward()
+        torch.cuda.synchronize()
+        assert model.blip_model.visual_encoder.patch_embed.proj.weight.grad is not None
+        assert model.blip_model.visual_encoder.blocks[0].attn.qkv.weight.grad is not None
     finally:
-        model.blip_model.visual_encoder.grad_cuts = ()
         dist.destroy_process_group()
 
 

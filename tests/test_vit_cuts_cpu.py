@@ -16,14 +16,14 @@ def test_block_range_backward_equals_one_backward():
     m = _vit()
     x = torch.randn(2, 3, 32, 32)
     w = torch.randn(2, 5, 64)
-    m.grad_cuts = ()
     y0 = m(x)
     (y0 * w).sum().backward()
     want = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
     for p in m.parameters():
         p.grad = None
-    m.grad_cuts = (2, 4)
-    y1 = m(x)
+    with m.autograd_cuts((2, 4)):
+        y1 = m(x)
+    assert m.grad_cuts == ()                                  # scoped to the forward inside the context
     assert torch.equal(y0, y1) and len(m.cut_pairs) == 2
     y1.backward(w)                                            # blocks 4-5 (+ final norm, + block 4's norm1 owner: block 3)
     seen = [{n for n, p in m.named_parameters() if p.grad is not None}]
@@ -44,7 +44,25 @@ def test_block_range_backward_equals_one_backward():
 
 def test_no_cut_without_grad():
     m = _vit()
-    m.grad_cuts = (2,)
-    with torch.no_grad():
+    with m.autograd_cuts((2,)), torch.no_grad():
         m(torch.randn(1, 3, 32, 32))
     assert m.cut_pairs == []
+
+
+def test_cuts_are_scoped_and_a_plain_backward_reaches_patch_embed():
+    """the cuts were persistent module state -- after a cut forward, an ordinary forward + backward must
+    differentiate down to the embeddings again, and a per-block (non fused) forward leaves no stale pairs"""
+    m = _vit()
+    x = torch.randn(2, 3, 32, 32)
+    with m.autograd_cuts((2, 4)):
+        m(x)
+    assert len(m.cut_pairs) == 2
+    m(x).sum().backward()
+    assert m.cut_pairs == [] and m.grad_cuts == ()
+    assert m.patch_embed.proj.weight.grad is not None and m.pos_embed.grad is not None
+    assert m.blocks[0].attn.qkv.weight.grad.abs().sum() > 0
+    with m.autograd_cuts((2,)):
+        m(x)
+        assert len(m.cut_pairs) == 1
+        m(x, return_fm=-2)                                    # per-block path: no cuts, and no stale ones either
+        assert m.cut_pairs == []

@@ -880,11 +880,14 @@ class _TwinKVFn(torch.autograd.Function):
         return (d2d, d3d, dhs.view(hs.shape), None, None, None) + gw
 
 
+_TWIN_KV = [True]   # (tools/ab_bench.py flips it to time the concatenating composition inside the whole step)
+
+
 def twin_kv_ok(enc2d, enc3d, hs):
     """the concatenation-free K/V node needs the kernel formats (bf16, CUDA, contiguous, widths the GEMM family takes) and
     segments the batched-row maps can address"""
     ok = lambda t: t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()
-    return (compute_dtype() == torch.bfloat16 and _NATIVE_GEMM[0] and ok(enc2d) and ok(enc3d) and ok(hs)
+    return (_TWIN_KV[0] and compute_dtype() == torch.bfloat16 and _NATIVE_GEMM[0] and ok(enc2d) and ok(enc3d) and ok(hs)
             and hs.shape[-1] % 64 == 0 and max(enc2d.shape[1], enc3d.shape[1], hs.shape[1]) <= 65535)
 
 

@@ -181,8 +181,16 @@ def test_twin_levels_stacked_equal_per_stream_path(dev, bf16):
     assert rel(b["h2d"], a["h2d"]) <= 5e-3 and rel(b["h3d"], a["h3d"]) <= 5e-3
     assert rel(b["img"], a["img"]) <= 2e-2 and rel(b["obj"], a["obj"]) <= 2e-2
     assert a["grads"].keys() == b["grads"].keys() and len(a["grads"]) > 80
-    worst = max((rel(b["grads"][n], a["grads"][n]), n) for n in a["grads"])
-    assert worst[0] <= 2e-2, worst
+    # a KEY bias shifts every score of a query by the same amount: its gradient is exactly zero in exact arithmetic and
+    # what a kernel path computes for it is the sum of its dK rounding errors -- compared on the scale of the VALUE bias'
+    # gradient of the same attention (the two paths only agreed on that noise while their dK were bit-identical)
+    def err(n):
+        if n.endswith(".key.bias"):
+            scale = a["grads"][n.replace(".key.bias", ".value.bias")].norm().item()
+            return (b["grads"][n] - a["grads"][n]).norm().item() / (scale + 1e-20)
+        return rel(b["grads"][n], a["grads"][n])
+    worst = sorted(((err(n), n) for n in a["grads"]), reverse=True)[:4]
+    assert worst[0][0] <= 2e-2, worst
 
 
 def test_twin_layer_norm_kernel_equals_two_single_launches(dev):
@@ -319,5 +327,13 @@ def test_decoder_hoisted_cross_kv_equals_per_layer_projections(dev, bf16):
     assert a["cross"].shape == (3, B, 4, L, Lk) and rel(b["cross"], a["cross"]) <= 5e-3   # maps asked of the hoisted path
     assert a["grads"].keys() == b["grads"].keys()
     assert any("crossattention.self.key.weight" in n for n in a["grads"])
-    worst = max((rel(b["grads"][n], a["grads"][n]), n) for n in a["grads"])
-    assert worst[0] <= 2e-2, worst
+    # a KEY bias shifts every score of a query by the same amount: its gradient is exactly zero in exact arithmetic and
+    # what a kernel path computes for it is the sum of its dK rounding errors -- compared on the scale of the VALUE bias'
+    # gradient of the same attention (the two paths only agreed on that noise while their dK were bit-identical)
+    def err(n):
+        if n.endswith(".key.bias"):
+            scale = a["grads"][n.replace(".key.bias", ".value.bias")].norm().item()
+            return (b["grads"][n] - a["grads"][n]).norm().item() / (scale + 1e-20)
+        return rel(b["grads"][n], a["grads"][n])
+    worst = sorted(((err(n), n) for n in a["grads"]), reverse=True)[:4]
+    assert worst[0][0] <= 2e-2, worst

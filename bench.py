@@ -65,6 +65,13 @@ def parse():
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the whole train step (forward + backward + fused AdamW) from one HIP graph; "
                          "auto = on for a single GPU")
+    ap.add_argument("--loop", choices=["phased", "reference"], default="phased",
+                    help="c3: phased = pipeline.PhasedTrainStep (the measured step structure, the headline); reference = the "
+                         "reference's own loop, unchanged -- data_dict = model(data_dict); loss = get_loss(...); "
+                         "optimizer.zero_grad(); loss.backward(); optimizer.step() (lib/solver.py:463-595) -- with HIP-graph "
+                         "replay behind model() and loss.backward() (bridgeqa_amd/graphed.py; --graph off: kernel by kernel)")
+    ap.add_argument("--no-wrap-loss", dest="wrap_loss", action="store_false",
+                    help="--loop reference: leave the loss function eager (default: graphed.wrap_loss around it)")
     ap.add_argument("--cpu-scenes", type=int, default=2, help="scenes in the bounded CPU-baseline sample")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
                     help="arithmetic of the dense layers: bf16 = the HIP kernel path (MFMA GEMMs, point-major detector); "
@@ -448,6 +455,74 @@ def attn_roofline(args, dev):
             "timed_on": "dedicated launches after the timed region, HIP events on the launch stream, median of 10"}
 
 
+def reference_loop(args, model, batch, dev, use_graph):
+    """`--loop reference`: the reference's training iteration as its solver writes it (lib/solver.py:463-595 _forward /
+    _backward, scripts/train.py:410-417), nothing rewritten around the step: forward through the module API, the loss
+    outside the model, zero_grad / backward / (clip inside) optimizer.step.  With --graph on/auto, graphed.enable(model)
+    replays HIP graphs behind model() and loss.backward(); the loss and the optimizer launch eagerly."""
+    from bridgeqa_amd import graphed
+    from bridgeqa_amd.optim import FusedAdamW
+    opt = FusedAdamW(model.parameters(), lr=5e-4, weight_decay=1e-5, grad_clip_value=1.0)
+    loss_fn = total_loss
+    if use_graph:
+        graphed.enable(model)
+        # (the solver's `from lib.loss_helper import get_loss` becomes `get_loss = graphed.wrap_loss(model, get_loss)`)
+        loss_fn = graphed.wrap_loss(model, total_loss) if args.wrap_loss else total_loss
+
+    seg = {"forward": 0.0, "loss": 0.0, "backward": 0.0, "optimizer": 0.0}
+
+    def step():
+        t = [time.perf_counter()]
+        dd = model(dict(batch)); t.append(time.perf_counter())
+        loss = loss_fn(dd); t.append(time.perf_counter())
+        opt.zero_grad(set_to_none=True)
+        loss.backward(); t.append(time.perf_counter())
+        opt.step(); t.append(time.perf_counter())
+        for k, a, b in zip(seg, t[:-1], t[1:]):
+            seg[k] += (b - a) * 1e3
+        return loss
+    for _ in range(max(args.warmup, 3)):
+        step()
+    for k in seg:
+        seg[k] = 0.0
+    if use_graph and os.environ.get("BQ_PIPE_TRACE") == "1":
+        model._graphed.host_times = {}
+        model._graphed.phase_events = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    host = []
+    for _ in range(args.steps):
+        h0 = time.perf_counter()
+        loss = step()
+        host.append((time.perf_counter() - h0) * 1e3)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(loss).item()
+    print("host-side time per step: %.2f ms  (%s)" % (sum(host) / len(host), "  ".join("%s %.2f" % (k, v / args.steps) for k, v in seg.items())),
+          file=sys.stderr)
+    if use_graph and model._graphed.phase_events:
+        print("GPU ms since the step's first launch, per graph [start -> end on its stream]: " +
+              "  ".join("%s %.1f->%.1f" % (k, a, b) for k, (a, b) in model._graphed.phase_gpu_ms().items()), file=sys.stderr)
+    if use_graph and model._graphed.host_times:
+        print("host ms per graph launch: " + "  ".join("%s %.2f" % (k, sum(v) / len(v)) for k, v in model._graphed.host_times.items()),
+              file=sys.stderr)
+    out = {"metric": "train samples/s (%dk-pt scene + %d^2 view, bs%d)" % (args.points // 1000, args.image, args.batch),
+           "value": round(args.batch * args.steps / dt, 3), "unit": "samples/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": WORKLOADS["c5" if args.workload == "c5" else "c3"], "global_batch": args.batch,
+                      "points": args.points, "c_in": args.cin, "image": args.image, "parallelism": "dp1",
+                      "loop": "reference: model(data_dict) -> loss -> zero_grad -> backward -> optimizer.step, unchanged "
+                              "(lib/solver.py:463-595)",
+                      "hip_graph": bool(use_graph),
+                      "schedule": (("graphed.enable: 6 graphs (3 forward, 3 backward) on 2 streams behind the module API; "
+                                    + ("loss wrapped (graphed.wrap_loss: 2 more graphs), optimizer eager" if args.wrap_loss
+                                       else "loss + optimizer eager")) if use_graph else "eager, kernel by kernel")},
+           "host_ms_per_step": round(sum(host) / len(host), 2),
+           "note": "NOT the headline line: the drop-in loop of INTEGRATION.md §3 (the headline is --loop phased)"}
+    print(json.dumps(_json_safe(out)))
+
+
 def _json_safe(x):
     """NaN / inf -> null: the bench line must be strict JSON"""
     if isinstance(x, float):
@@ -515,6 +590,10 @@ def main():
     side = torch.cuda.Stream()
     graphed = False
 
+    if args.loop == "reference":
+        if workload != "c3" or world > 1:
+            raise SystemExit("bench.py: --loop reference is the single-GPU c3 / c5 drop-in loop")
+        return reference_loop(args, model, batch, dev, use_graph)
     phased = workload == "c3"  # one HIP graph per phase on two streams (bridgeqa_amd/pipeline.py); c2: one graph
     pipe = None
     if phased:

@@ -123,6 +123,9 @@ class ScanQAHotPath(nn.Module):
     def forward(self, data_dict):
         """data_dict: point_clouds (B,N,3+C); with use_blip also images (B,V,3,H,W), question / answer
         (token dicts or strings).  Adds the detector outputs and, with BLIP, `blip_loss`, `fused_feat`."""
+        runner = getattr(self, "_graphed", None)
+        if runner is not None and runner.usable(data_dict):
+            return runner.forward(data_dict)   # graphed.enable(model): HIP-graph replay behind the plain training loop
         image_embeds = None
         if self.use_blip and "images" in data_dict:
             from . import fusion_ops as ops

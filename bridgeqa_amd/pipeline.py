@@ -513,19 +513,27 @@ class PhasedTrainStep(object):
         self._state = {}
         pools = {"main": torch.cuda.graph_pool_handle(), "det": torch.cuda.graph_pool_handle(),
                  "wg": torch.cuda.graph_pool_handle()}
+        # every phase graph SINGLE-STREAM (no fusion_ops.fork inside: the decoder's hoisted K/V projection stays on the
+        # chain's stream): this runtime enqueues a graph with an internal fork node by node -- the fusion graph's launch held
+        # the host for 35-38 ms and the phase ran 14.2 ms; without the fork 2.2 ms of host time and 12.7-13.4 ms (round 4,
+        # A/B/A on one box: 39.5 / 40.7 / 38.6 ms per step)
+        prev_overlap = ops.set_overlap(False)
         self.graphs = {}
         self._bn_sig = self._bn_momenta()
-        for name, which, pool in self._ORDER:
-            if self._skipped(name) or name in self.eager_phases:
-                continue
-            g = torch.cuda.CUDAGraph()
-            try:
-                with torch.cuda.graph(g, pool=pools[pool], stream=self._stream(which)):
-                    getattr(self, "_" + name)()
-            except Exception as e:
-                raise RuntimeError("PhasedTrainStep.capture: phase '%s' could not be captured: %s" % (name, e)) from e
-            self.graphs[name] = g
-            torch.cuda.synchronize(self.dev)
+        try:
+            for name, which, pool in self._ORDER:
+                if self._skipped(name) or name in self.eager_phases:
+                    continue
+                g = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(g, pool=pools[pool], stream=self._stream(which)):
+                        getattr(self, "_" + name)()
+                except Exception as e:
+                    raise RuntimeError("PhasedTrainStep.capture: phase '%s' could not be captured: %s" % (name, e)) from e
+                self.graphs[name] = g
+                torch.cuda.synchronize(self.dev)
+        finally:
+            ops.set_overlap(prev_overlap)
         self.e_done.record(self.s_main)
         if self.reducers:
             from .ddp import check_coverage

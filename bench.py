@@ -58,6 +58,9 @@ def parse():
                          "parked above it are flushed on a third stream beside the rest of the chain (-1: one fusion phase)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend (nccl = RCCL; gloo only for --share-device validation runs)")
+    ap.add_argument("--grad-exchange", choices=["all_reduce", "reduce_scatter"], default="all_reduce",
+                    help="data parallel: one all-reduce per gradient group (RCCL picks the algorithm), or reduce-scatter + "
+                         "all-gather written out (SURVEY §8e)")
     ap.add_argument("--share-device", action="store_true",
                     help="VALIDATION ONLY: every rank uses cuda:0 (with --backend gloo: RCCL refuses two ranks on one GPU) -- "
                          "runs the N > 1 control flow (per-rank batches, per-phase gradient groups, buffer broadcast, replica "
@@ -220,10 +223,13 @@ class OpTimer(object):
             setattr(self._ext, n, f)
 
     def summary(self):
+        """{(op, shape): (median ms, count)} -- the median: in an eager re-run the stream can run dry between the two events
+        of a launch (the host allocating, a first-use initialisation), and one such pair moved a 16 us launch's MEAN to
+        10 ms on the c2 line of round 3"""
         agg = {}
         for n, shape, s, e in self.records:
             agg.setdefault((n, shape), []).append(s.elapsed_time(e))
-        return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+        return {k: (sorted(v)[len(v) // 2], len(v)) for k, v in agg.items()}
 
 
 def make_batch(args, workload, B, seed, device):
@@ -298,8 +304,10 @@ def cpu_info():
 
 
 VIT_GEMMS = (("qkv", 2304, 768), ("proj", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072))
-PROFILE_PMC = os.path.join(ROOT, "profiles", "r03_gemm_pmc.jsonl")       # tools/run_gemm_pmc.sh -> tools/pmc_summary.py --json
-PROFILE_STATS = os.path.join(ROOT, "profiles", "r03_c3_kernel_stats.csv")  # rocprofv3 --kernel-trace --stats of this bench
+PROFILE_PMC = os.path.join(ROOT, "profiles", "r04_gemm_pmc.jsonl")       # tools/run_gemm_pmc.sh -> tools/pmc_summary.py --json
+PROFILE_STATS = os.path.join(ROOT, "profiles", "r04_c3_kernel_stats.csv")  # rocprofv3 --kernel-trace --stats of this bench
+PROFILE_ROWS = 16400   # the committed counter / in-step records were taken at c3's token count (B = 16 x 1025): they are
+#                        attached to a bench line only when the run has the same M (the c5 line divided c3's bytes)
 # kernel instantiation each launch form runs as (for the in-step averages of the committed profile)
 GEMM_KERNELS = {"fwd": "gemm128_kernel<false, false, 1, false, 16>", "fwd_gelu": "gemm128_kernel<false, false, 2, false, 16>",
                 "dx": "gemm128_kernel<true, false, 0, false, 16>", "dx_dgelu": "gemm128_kernel<true, false, 3, false, 16>",
@@ -347,11 +355,12 @@ def gemm_roofline(args, dev):
     M = args.batch * ((args.image // 16) ** 2 + 1)
     g = torch.Generator().manual_seed(5)
     rnd = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(dev).to(torch.bfloat16)
-    pmc, stats = _profile_records()
-    out, tot_f, tot_t, tot_alg, tot_fetch, tot_write = [], 0.0, 0.0, 0.0, 0.0, 0.0
+    pmc, stats = _profile_records() if M == PROFILE_ROWS else ({}, {})
+    out, tot_f, tot_t, tot_alg, tot_fetch, tot_write, tot_prof = [], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0
+    prof_missing = []
 
     def add(label, form, fn, fl, alg_bytes, N, K):
-        nonlocal tot_f, tot_t, tot_alg, tot_fetch, tot_write
+        nonlocal tot_f, tot_t, tot_alg, tot_fetch, tot_write, tot_prof
         ms = _event_median_ms(fn)
         rec = {"launch": label, "M": M, "N": N, "K": K, "us": round(ms * 1e3, 1), "TFLOPs": round(fl / ms / 1e9, 1),
                "frac": round(fl / ms / 1e9 / 2500.0, 4), "algorithmic_bytes": alg_bytes}
@@ -366,6 +375,9 @@ def gemm_roofline(args, dev):
                           "hbm_read_bytes": sum(r["fetch_bytes"] for r in p), "hbm_write_bytes": sum(r["write_bytes"] for r in p)}
             tot_fetch += rec["pmc"]["hbm_read_bytes"]
             tot_write += rec["pmc"]["hbm_write_bytes"]
+            tot_prof += tsum
+        else:
+            prof_missing.append(label)
         out.append(rec)
         tot_f += fl; tot_t += ms; tot_alg += alg_bytes
 
@@ -374,7 +386,10 @@ def gemm_roofline(args, dev):
         b = torch.randn(N, generator=g).to(dev)
         fl = 2.0 * M * N * K
         if name == "fc1":
-            add("fwd_fc1_gelu", "fwd_gelu", lambda: _ext.gemm_fwd(x, w, b, gelu=True), fl, 2.0 * (M * K + N * K + 2 * M * N), N, K)
+            # (algorithmic bytes count ONE output: the activation is what the layer computes; the launch also stores the
+            # pre-activation for the backward -- the counter bytes show it)
+            add("fwd_fc1_gelu", "fwd_gelu", lambda: _ext.gemm_fwd(x, w, b, gelu=True), fl, 2.0 * (M * K + N * K + M * N), N, K)
+            out[-1]["note"] = "writes two (M, N) outputs (pre-activation for the backward + activation); algorithmic bytes count one"
         else:
             add("fwd_" + name, "fwd", lambda: _ext.gemm_fwd(x, w, b), fl, 2.0 * (M * K + N * K + M * N), N, K)
         if name == "fc2":
@@ -402,15 +417,19 @@ def gemm_roofline(args, dev):
     out[-1]["note"] = ("all 48 weight gradients (+ bias gradients) of the 12 blocks through fusion_wgrad.flush_deferred_items: "
                        "the launch plan the step uses (two 256-tile launches + the planner's small problems on the 64-tile kernel)")
     traffic = ({"hbm_read_bytes": tot_fetch, "hbm_write_bytes": tot_write, "algorithmic_bytes": tot_alg,
-                "ratio": round((tot_fetch + tot_write) / tot_alg, 3), "file": "profiles/r03_gemm_pmc.jsonl",
+                "ratio": round((tot_fetch + tot_write) / tot_alg, 3), "file": "profiles/r04_gemm_pmc.jsonl",
                 "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, one launch form per process; read = 2 x "
                           "FETCH_SIZE x 1024 (gfx950 tallies a 128-B request as 64 B), write = WRITE_SIZE x 1024 "
                           "(MI355X_MICROARCH.md, HBM); fabric-side counters: Infinity-Cache hits are included"}
-               if tot_fetch else None)
-    return out, tot_f, tot_t, traffic
+               if (tot_fetch and not prof_missing) else None)
+    # the same fraction from the DURATIONS of the committed trace pass (rocprofv3 kernel trace, one launch form per
+    # process) next to the live HIP-event medians `frac` uses: a reader can recompute either from its own source
+    prof = ({"us_total": round(tot_prof, 1), "frac": round(tot_f / (tot_prof * 1e-6) / 1e12 / 2500.0, 4),
+             "file": "profiles/r04_gemm_pmc.jsonl (avg_us of the trace pass)"} if (tot_prof and not prof_missing) else None)
+    return out, tot_f, tot_t, traffic, prof
 
 
-def _attn_pmc(threads, path="profiles/r03_attn_pmc.txt"):
+def _attn_pmc(threads, path="profiles/r04_attn_pmc.txt"):
     """MFMA-busy fractions of the three attention kernels at THIS run's shape, read back from the committed counter summary
     (tools/run_attn_pmc.sh -> tools/pmc_summary.py: per kernel and launch shape a '<name>  grid <threads>' line followed by
     the counters and a '=> MFMA utilisation X %' line); `threads` = B * H * ceil(L / 128) workgroups * 256"""
@@ -523,6 +542,37 @@ def reference_loop(args, model, batch, dev, use_graph):
     print(json.dumps(_json_safe(out)))
 
 
+def ballquery_roofline(args, ops, alone_ms, alone_bg_ms, phased):
+    """SA1's ball query (north_star names the op): SURVEY §8d's streaming-equivalent 12 N M B bytes per launch -- what the
+    reference's kernel streams (every centre reads every point) -- over the launch's duration in the step and alone, next to
+    the physical HBM traffic of the committed counter pass (the scene is L2-resident: 16 x 480 KB).  Like roofline_fps this
+    is NOT a physical bandwidth: the kernel is bound by its vector instructions (kernel table)."""
+    B, N, M = args.batch, args.points, 2048
+    alg = 12.0 * N * M * B
+    ms, cnt = ops.get(("ball_query", (B, M, 3)), (float("nan"), 0))
+    eq = lambda t: round(alg / (t * 1e-3) / 1e9, 1) if t == t and t > 0 else None
+    pmc = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_ballquery_pmc.json")))
+        if (pmc.get("B"), pmc.get("N"), pmc.get("M")) != (B, N, M):
+            pmc = None   # (taken at another shape: not this run's traffic)
+    except (OSError, ValueError):
+        pass
+    return {"kernel": "bq::ball_query_wave_kernel (csrc/pn2_ops.hip), SA1: %d centres x %d points, radius 0.2, nsample 64, B=%d" % (M, N, B),
+            "bound": "hbm", "convention": "streaming-equivalent (SURVEY §8d): 12*N*M*B bytes per launch = what the reference's "
+                                          "kernel streams; physical traffic is the L2-resident scene read once per XCD",
+            "algorithmic_bytes_per_launch": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "achieved": eq(ms), "frac": round(eq(ms) / HBM_PEAK_GBS, 4) if eq(ms) else None, "ms_per_launch": round(ms, 4),
+            "launches_timed": cnt,
+            "timed_on": ("the timed steps: the geometry phase of the NEXT batch (bq_ball_query_background: about one workgroup "
+                         "per CU, running under the fusion chain)" if phased else "eager re-run after the graph replay"),
+            "alone": {"ms_per_launch": round(alone_ms, 4), "achieved": eq(alone_ms),
+                      "frac": round(eq(alone_ms) / HBM_PEAK_GBS, 4) if eq(alone_ms) else None,
+                      "background_grid_ms_per_launch": round(alone_bg_ms, 4),
+                      "note": "5 back-to-back launches after the timed region, idle GPU, full grid / background grid"},
+            "traffic": pmc}
+
+
 def _json_safe(x):
     """NaN / inf -> null: the bench line must be strict JSON"""
     if isinstance(x, float):
@@ -627,7 +677,7 @@ def main():
             broadcast_parameters(model)
 
             def make_reducer(ps):
-                r = PackedGradReducer(ps, comm_dtype=torch.bfloat16)
+                r = PackedGradReducer(ps, comm_dtype=torch.bfloat16, algo=args.grad_exchange)
                 r.force = args.dp_path
                 return r
             reducers = pipe.attach_reducers(make_reducer)
@@ -713,7 +763,7 @@ def main():
         with torch.cuda.stream(side):
             used = used_parameters(model, dry)
         torch.cuda.synchronize()
-        reducer = PackedGradReducer(used, comm_dtype=torch.bfloat16)
+        reducer = PackedGradReducer(used, comm_dtype=torch.bfloat16, algo=args.grad_exchange)
         reducer.force = args.dp_path
         opt = torch.optim.AdamW(used, lr=5e-4, weight_decay=1e-5, fused=True)
 
@@ -744,9 +794,22 @@ def main():
         if os.environ.get("BQ_PIPE_TRACE") == "1":
             pipe.host_times = {}
             pipe.phase_events = {}
+        if reducers:   # per-group communication time and the exposed part of it, measured inside the timed steps
+            pipe.comm_stall = []
+            for r_ in reducers.values():
+                r_.timing = []
         use_graph = False  # (the single-graph capture below is the other schedule)
     else:
         step = eager_step
+        if geometry_ahead is not None:
+            # --graph off: the same schedule kernel by kernel (stage 0: next -> cur, the step, stage 1: the following
+            # batch's indices on the second stream) -- without this the timed region would consume indices computed once
+            # before it
+            def step():
+                geometry_ahead(0)
+                loss_ = eager_step()
+                geometry_ahead(1)
+                return loss_
     # Every eager step before a capture runs on the SAME side stream: autograd's AccumulateGrad nodes remember the
     # stream they were created on, and nodes born on the default stream make hipStreamEndCapture segfault (ROCm 7).
     if not phased:
@@ -799,7 +862,10 @@ def main():
             pass  # the geometry phase was launched eagerly inside the timed steps: its kernels are already timed
         else:
             with torch.cuda.stream(side):
-                for _ in range(min(args.steps, 3)):
+                for it in range(min(args.steps, 3) + 1):
+                    if it == 1:
+                        torch.cuda.synchronize()
+                        del timer.records[:]   # (the first eager pass after the replays re-grows the eager allocator's pool)
                     if geometry_ahead is not None:
                         geo_body()   # (the prefetched indices come from a replayed graph too: the same launches, eagerly)
                     eager_step()
@@ -818,6 +884,23 @@ def main():
         ev1.record()
         torch.cuda.synchronize()
         fps_alone_ms = ev0.elapsed_time(ev1) / 5
+    # SA1's ball query (2048 centres x all points, radius 0.2, 64 samples) alone: the full grid and the background grid
+    bq_alone_ms = bq_alone_bg_ms = float("nan")
+    if rank == 0:
+        ctr = xyz_alone[:, :2048].contiguous()   # (any 2048 points serve as centres for the timing: the scan is exhaustive)
+        for bg in (False, True):
+            _ext.ball_query(ctr, xyz_alone, 0.2, 64, background=bg)
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(5):
+                _ext.ball_query(ctr, xyz_alone, 0.2, 64, background=bg)
+            ev1.record()
+            torch.cuda.synchronize()
+            if bg:
+                bq_alone_bg_ms = ev0.elapsed_time(ev1) / 5
+            else:
+                bq_alone_ms = ev0.elapsed_time(ev1) / 5
     replicas_in_sync = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -826,14 +909,19 @@ def main():
         # data parallel invariant: after the same number of steps every rank holds the same PARAMETERS (reference: DDP's
         # gradient averaging, scripts/train.py:346-347) -- one checksum per rank.  (Buffers -- BatchNorm running statistics
         # -- legitimately differ between a step's forward and the broadcast that opens the next one, as under DDP.)
+        # (one checksum PER PARAMETER, two moments each: a single global sum |p| would not see compensating differences)
         with torch.no_grad():
-            cs = torch.stack([p.detach().double().abs().sum() for p in model.parameters()]).sum().reshape(1)
+            cs = torch.stack([torch.stack((p.detach().double().sum(), p.detach().double().abs().sum()))
+                              for p in model.parameters()]).reshape(-1)
         lo, hi = cs.clone(), cs.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         replicas_in_sync = bool(torch.equal(lo, hi))
         if rank == 0 and not replicas_in_sync:
-            print("bench.py: parameter checksums differ between ranks: min %r max %r" % (lo.item(), hi.item()), file=sys.stderr)
+            bad = (lo != hi).reshape(-1, 2).any(1).nonzero().reshape(-1).tolist()
+            names = [n for n, _ in model.named_parameters()]
+            print("bench.py: %d parameter(s) differ between ranks, first: %s" % (len(bad), [names[i] for i in bad[:5]]),
+                  file=sys.stderr)
     assert torch.isfinite(loss).item()
     if rank == 0 and pipe is not None and pipe.phase_events:
         print("GPU ms since the step's first launch, per phase [start -> end on its stream]: " +
@@ -891,24 +979,27 @@ def main():
                                        "achieved": round(alg / (fps_alone_ms * 1e-3) / 1e9, 1),
                                        "frac": round(alg / (fps_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                        "note": "5 back-to-back launches after the timed region, idle GPU"}},
+            "roofline_ballquery": ballquery_roofline(args, ops, bq_alone_ms, bq_alone_bg_ms, phased),
             "op_ms": {"%s%s" % (k[0], list(k[1])): round(v[0], 4) for k, v in sorted(ops.items())},
             "path_roofline": (lambda tm, det: {"t_min_ms": round(tm, 3), "frac": round(tm / (dt / args.steps * 1e3), 4),
                                                **det})(*path_roofline(args, workload)),
         }
         if workload == "c3":
-            per, tot_f, tot_ms, traffic = gemm_roofline(args, dev)
+            per, tot_f, tot_ms, traffic, prof_frac = gemm_roofline(args, dev)
             out["roofline"] = {"kernel": "bq::gemm128_kernel (csrc/gemm_mid.hip: forward / input-gradient forms, 256x128 tiles, "
                                          "persistent, 2 workgroups per CU) + bq::gemm256_kernel (csrc/gemm.hip: weight gradients): "
                                          "the 8 launches of one ViT block (forward + dX, with the epilogues the step uses) + "
                                          "the grouped dW launch of all 12 blocks", "bound": "mfma",
                                "achieved": round(tot_f / tot_ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
                                "frac": round(tot_f / tot_ms / 1e9 / 2500.0, 4),
+                               "frac_uses": "sum of the live HIP-event medians below (per_gemm[].us)",
+                               "from_profile_durations": prof_frac,
                                "traffic": traffic,
                                "algorithmic_flops": tot_f, "ms_total": round(tot_ms, 4), "per_gemm": per,
                                "timed_on": "dedicated launches after the timed region, HIP events on the launch stream, "
                                            "median of 10 (inside the step the same kernels replay from HIP graphs; the "
-                                           "in-step averages come from profiles/r03_c3_kernel_stats.csv, the counters from "
-                                           "profiles/r03_gemm_pmc.jsonl)"}
+                                           "in-step averages come from profiles/r04_c3_kernel_stats.csv, the counters from "
+                                           "profiles/r04_gemm_pmc.jsonl; both only at M = 16400, the shape they were taken at)"}
             out["roofline_attn"] = attn_roofline(args, dev)
         else:
             out["roofline"] = out["roofline_fps"]
@@ -916,11 +1007,15 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, workload)
         if replicas_in_sync is not None:
             out["replicas_in_sync"] = replicas_in_sync
+        if pipe is not None and reducers:
+            out["comm"] = pipe.comm_report()
         if args.share_device:
             out["data"] += " [--share-device validation run: all ranks on one GPU, throughput not meaningful]"
         print(json.dumps(_json_safe(out)))
     if dist.is_initialized():
         dist.destroy_process_group()
+    if replicas_in_sync is False:
+        sys.exit(3)   # (diverged replicas must fail a scaling / CI run, not only print -- ADVICE r3)
 
 
 if __name__ == "__main__":

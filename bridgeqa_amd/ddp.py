@@ -30,34 +30,64 @@ class PackedGradReducer(object):
     issued on whatever stream is current (PhasedTrainStep uses a communication stream, so the exchange of the
     fusion gradients runs under the image / detector backward)."""
 
-    def __init__(self, params, comm_dtype=torch.float32, process_group=None):
-        self.group = process_group
+    def __init__(self, params, comm_dtype=torch.float32, process_group=None, algo="all_reduce"):
+        """algo: "all_reduce" -- one dist.all_reduce of the flat buffer (the algorithm is RCCL's choice), or
+        "reduce_scatter" -- reduce-scatter + all-gather written out (on the fully connected xGMI mesh each rank
+        owns 1 / world of the buffer, every link carries 2 S / world bytes and all 7 links work at once; also the form that
+        lets an optimizer shard the update between the two collectives).  Same result either way."""
+        if algo not in ("all_reduce", "reduce_scatter"):
+            raise ValueError("PackedGradReducer: algo must be 'all_reduce' or 'reduce_scatter'")
+        self.group, self.algo = process_group, algo
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.force = False  # run the collective even for a single rank (exercises the RCCL path on a 1-GPU box)
         self._avg = None    # ReduceOp.AVG available (decided at the first exchange from the group's backend)
         self.params = [p for p in params]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.comm = torch.empty(n, dtype=comm_dtype, device=dev)
+        # (reduce-scatter needs equal shards: the flat buffer is padded to a multiple of the world size)
+        self.n = n
+        npad = -(-n // self.world) * self.world if algo == "reduce_scatter" else n
+        self.comm = torch.zeros(npad, dtype=comm_dtype, device=dev)
         self.views, off = [], 0
         for p in self.params:
             self.views.append(self.comm[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self.timing = None   # set to [] to collect (start, end) event pairs of every exchange on the stream it runs on
 
     def all_reduce(self):
         if self.world == 1 and not (self.force and dist.is_initialized()):
             return
+        ev = None
+        if self.timing is not None and self.comm.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         grads = [p.grad for p in self.params]
         torch._foreach_copy_(self.views, grads)
         if self._avg is None:
             self._avg = dist.get_backend(self.group) == "nccl"
-        if self._avg:
-            dist.all_reduce(self.comm, op=dist.ReduceOp.AVG, group=self.group)
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        if self.algo == "reduce_scatter":
+            rank = dist.get_rank(self.group)
+            per = self.comm.numel() // self.world
+            shard = self.comm[rank * per:(rank + 1) * per]
+            dist.reduce_scatter_tensor(shard, self.comm, op=op, group=self.group)
+            if not self._avg and self.world > 1:
+                shard.mul_(1.0 / self.world)     # (scaling the owned shard only: 1 / world of the buffer)
+            dist.all_gather_into_tensor(self.comm, shard, group=self.group)
         else:
-            dist.all_reduce(self.comm, op=dist.ReduceOp.SUM, group=self.group)
-            if self.world > 1:
+            dist.all_reduce(self.comm, op=op, group=self.group)
+            if not self._avg and self.world > 1:
                 self.comm.mul_(1.0 / self.world)
         torch._foreach_copy_(grads, self.views)
+        if ev is not None:
+            ev[1].record()
+            self.timing.append(ev)
+
+    def comm_ms(self):
+        """after a synchronize: mean duration of an exchange (pack + collective(s) + unpack) on its stream, or None"""
+        if not self.timing:
+            return None
+        return sum(a.elapsed_time(b) for a, b in self.timing) / len(self.timing)
 
     def nbytes_on_wire(self):
         return self.comm.numel() * self.comm.element_size()

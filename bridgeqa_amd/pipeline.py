@@ -114,6 +114,7 @@ class PhasedTrainStep(object):
         self.e_img_bwd = torch.cuda.Event()
         self.e_img_seg = [torch.cuda.Event() for _ in range(self.image_splits)]
         self._comm_events = []
+        self.comm_stall = None   # set to [] to time how long the main stream waits for the gradient exchanges (exposed time)
         self._geo_next, self._geo_cur = None, None
         self.host_times = None  # set to {} to record the host time of every graph launch (ms, per phase)
         self.phase_events = None  # set to {} to bracket every phase with events on its stream (phase_gpu_ms())
@@ -402,8 +403,17 @@ class PhasedTrainStep(object):
         with torch.cuda.stream(sm):
             sm.wait_event(self.e_img_bwd)
             sm.wait_event(self.e_det_bwd)
-            for ev in self._comm_events:
-                sm.wait_event(ev)
+            if self.comm_stall is not None and self._comm_events:
+                # exposed communication = how long the critical path stands at this point for the exchanges alone
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(sm)
+                for ev in self._comm_events:
+                    sm.wait_event(ev)
+                e1.record(sm)
+                self.comm_stall.append((e0, e1))
+            else:
+                for ev in self._comm_events:
+                    sm.wait_event(ev)
             del self._comm_events[:]
             self._run("finish", eager)
             self.e_done.record(sm)
@@ -449,6 +459,19 @@ class PhasedTrainStep(object):
         self.zero_grad()
         self._schedule(eager=True)
         return self.loss
+
+    def comm_report(self):
+        """after a synchronize, data parallel with timing switched on (reducer.timing = [], self.comm_stall = []):
+        {"groups": {name: {"bytes_on_wire", "ms"}}, "exposed_ms"} -- per-group duration of pack + collective + unpack on the
+        communication stream, and the mean time the critical path stood waiting for them in front of the optimizer"""
+        groups = {g: {"bytes_on_wire": r.nbytes_on_wire(), "ms": (round(r.comm_ms(), 3) if r.comm_ms() is not None else None),
+                      "algo": r.algo} for g, r in self.reducers.items()}
+        stall = None
+        if self.comm_stall:
+            stall = round(sum(a.elapsed_time(b) for a, b in self.comm_stall) / len(self.comm_stall), 3)
+        return {"groups": groups, "exposed_ms": stall,
+                "note": "ms = pack + collective + unpack on the communication stream (HIP events); exposed_ms = the main "
+                        "stream's wait for all groups in front of the optimizer phase"}
 
     def _bn_momenta(self):
         """BatchNorm momentum is a HOST scalar baked into the captured launches (F.batch_norm and the bq BN kernels take

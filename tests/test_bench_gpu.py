@@ -15,6 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("workload,extra", [("c3", ["--batch", "2", "--points", "4096", "--image", "128"]),
+                                            ("c3", ["--batch", "2", "--points", "4096", "--image", "128", "--grad-exchange",
+                                                    "reduce_scatter"]),
                                             ("c2", ["--batch", "2", "--points", "4096"])])
 def test_two_ranks_sharing_one_device_stay_in_sync(workload, extra):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
@@ -29,3 +31,12 @@ def test_two_ranks_sharing_one_device_stay_in_sync(workload, extra):
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
     assert out["replicas_in_sync"] is True, r.stderr[-1500:]
     assert "validation run" in out["data"]
+    if workload == "c3":
+        # per-group communication time and its exposed part, from events on the communication / main stream: the fields the
+        # first real multi-GPU run turns DESIGN §6's predicted table into (their VALUES mean nothing on a shared device)
+        comm = out["comm"]
+        assert set(comm["groups"]) == {"fusion", "det", "image_0", "image_1", "image_2"}
+        assert all(g["ms"] is not None and g["ms"] > 0 and g["bytes_on_wire"] > 0 for g in comm["groups"].values())
+        assert comm["exposed_ms"] is not None and comm["exposed_ms"] >= 0
+        want = "reduce_scatter" if "reduce_scatter" in extra else "all_reduce"
+        assert all(g["algo"] == want for g in comm["groups"].values())

@@ -111,6 +111,55 @@ def _worker_packed(rank, world, port, out):
         dist.destroy_process_group()
 
 
+def _worker_rs_and_wire(rank, world, port, out):
+    """the reduce-scatter + all-gather form of the exchange equals the all-reduce form (odd sizes: the flat buffer is padded
+    to whole shards), and a bf16 wire stays within 4e-3 rel-L2 of the fp32 wire's rank mean"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bridgeqa_amd.ddp import PackedGradReducer
+        g = torch.Generator().manual_seed(7 + rank)
+        shapes = [(33, 17), (129,), (5, 3, 7), (1,)]                      # 561 + 129 + 105 + 1 = 796 (+ an odd total below)
+        shapes.append((3,))
+        res = {}
+        for algo in ("all_reduce", "reduce_scatter"):
+            for dt in (torch.float32, torch.bfloat16):
+                ps = [torch.nn.Parameter(torch.zeros(*sh)) for sh in shapes]
+                gg = torch.Generator().manual_seed(7 + rank)
+                for p in ps:
+                    p.grad = torch.randn(*p.shape, generator=gg) * (10.0 ** float(torch.randint(-3, 2, (1,), generator=gg)))
+                r = PackedGradReducer(ps, comm_dtype=dt, algo=algo)
+                ptrs = [p.grad.data_ptr() for p in ps]
+                r.all_reduce()
+                assert ptrs == [p.grad.data_ptr() for p in ps]
+                res[(algo, dt)] = torch.cat([p.grad.reshape(-1) for p in ps])
+        ref = res[("all_reduce", torch.float32)]
+        rel = lambda a: float((a - ref).norm() / ref.norm())
+        out.put((rank, rel(res[("reduce_scatter", torch.float32)]), rel(res[("all_reduce", torch.bfloat16)]),
+                 rel(res[("reduce_scatter", torch.bfloat16)]), float(ref.abs().sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_reduce_scatter_form_and_bf16_wire_world2_gloo():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rs_and_wire, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=200) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert abs(res[0][4] - res[1][4]) < 1e-6 * res[0][4]                  # both ranks hold the same mean
+    for rank, rs32, ar16, rs16, _ in res:
+        assert rs32 < 1e-6, rs32                                          # same arithmetic, different collective
+        assert ar16 < 4e-3 and rs16 < 4e-3, (ar16, rs16)                  # what a bf16 wire costs (two roundings)
+
+
 @pytest.mark.timeout(300)
 def test_packed_grad_reducer_world2_gloo():
     """per-phase exchange: gradients stay in autograd's own tensors, pack -> all-reduce -> unpack gives the rank mean"""

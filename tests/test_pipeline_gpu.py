@@ -117,8 +117,11 @@ def test_fusion_backward_cut_with_side_stream_flush_equals_the_single_phase(dev)
             def err(n):   # (a key bias' gradient is exactly zero in exact arithmetic: compared on the value bias' scale)
                 ref = want[n.replace(".key.bias", ".value.bias")] if n.endswith(".key.bias") else want[n]
                 return ((got[n] - want[n]).norm() / (ref.norm() + 1e-12)).item()
-            worst = sorted(((err(n), n) for n in want), reverse=True)[:3]
-            assert worst[0][0] < 2e-2, (mode, worst)   # (bf16 kernels; fp32 atomics in the detector backward)
+            # the cut only touches the fusion half (blip_model.*): 2e-2 there (bf16 kernels, differently ordered sums); the
+            # detector's scatter gradients use fp32 atomics -- two executions of the SAME step differ by up to 3e-2 on its
+            # deep BatchNorm biases (control in tests/test_graphed_gpu.py)
+            worst = sorted(((err(n) / (1.0 if n.startswith("blip_model.") else 3.0), n, err(n)) for n in want), reverse=True)[:3]
+            assert worst[0][0] < 2e-2, (mode, worst)
         enc = model.blip_model.text_encoder.encoder
         assert enc.grad_cut is None and enc.cut_pair is None     # scoped to the phased step's fusion forward
     finally:
@@ -337,6 +340,38 @@ def test_capture_hands_a_resumed_optimizer_back_unchanged(dev):
         assert torch.equal(w.detach(), want_w)
     finally:
         ops.set_compute_dtype(prev)
+
+
+def test_bf16_wire_against_fp32_wire_through_rccl(dev):
+    """what bench.py's bf16 wire does to a gradient group, bounded: PackedGradReducer over the real RCCL backend (world 1,
+    forced collectives), fp32 wire = the gradients bit for bit, bf16 wire within 4e-3 rel-L2 of them (one rounding on the
+    way in; the reference's DDP reduces in fp32) -- both exchange forms (all-reduce, reduce-scatter + all-gather)"""
+    import os
+    import torch.distributed as dist
+    from bridgeqa_amd.ddp import PackedGradReducer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group(backend="nccl", init_method="env://", rank=0, world_size=1)
+    try:
+        g = torch.Generator().manual_seed(11)
+        shapes = [(768, 3072), (3072,), (2304, 768), (30524, 768), (5, 3, 7), (1,)]
+        for algo in ("all_reduce", "reduce_scatter"):
+            for dt, bound in ((torch.float32, 0.0), (torch.bfloat16, 4e-3)):
+                ps = [torch.nn.Parameter(torch.zeros(*sh, device=dev)) for sh in shapes]
+                want = []
+                for p in ps:
+                    p.grad = (torch.randn(*p.shape, generator=g) * 10.0 ** float(torch.randint(-4, 1, (1,), generator=g))).to(dev)
+                    want.append(p.grad.clone())
+                r = PackedGradReducer(ps, comm_dtype=dt, algo=algo)
+                r.force = True
+                r.timing = []
+                r.all_reduce()
+                torch.cuda.synchronize()
+                num = sum((p.grad - w).double().pow(2).sum().item() for p, w in zip(ps, want))
+                den = sum(w.double().pow(2).sum().item() for w in want)
+                assert (num / den) ** 0.5 <= bound, (algo, dt, (num / den) ** 0.5)
+                assert r.comm_ms() is not None and r.comm_ms() > 0
+    finally:
+        dist.destroy_process_group()
 
 
 def test_data_parallel_step_on_rccl_world_1_equals_the_plain_step(dev):

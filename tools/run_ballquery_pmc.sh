@@ -1,0 +1,25 @@
+# SA1's ball query under rocprofv3: trace pass + FETCH_SIZE / WRITE_SIZE in separate passes (MI355X_MICROARCH.md, HBM section),
+# summarised into profiles-style JSON for bench.py's roofline_ballquery.traffic.  usage: bash tools/run_ballquery_pmc.sh <outdir-under-gpurun_out>
+OUT=${1:-bq_pmc}
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+D=$R/gpurun_out/$OUT
+mkdir -p $D
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $D/t -- python3 $R/tools/time_ball_query.py > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/b -- python3 $R/tools/time_ball_query.py > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/c -- python3 $R/tools/time_ball_query.py > /dev/null 2>&1
+cd $R
+rm -f $D/bq.jsonl
+python tools/pmc_summary.py $D/t $D/b $D/c --match ball_query --json $D/bq.jsonl --label ball_query_sa1 > $D/ballquery_pmc.txt 2>&1
+python - <<PY
+import json
+r = [json.loads(l) for l in open("$D/bq.jsonl")][0]
+out = {"B": 16, "N": 40000, "M": 2048, "avg_us": r["avg_us"], "hbm_read_bytes": r["fetch_bytes"], "hbm_write_bytes": r["write_bytes"],
+       "file": "profiles/r04_ballquery_pmc.json",
+       "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/time_ball_query.py; read = 2 x FETCH_SIZE x 1024 "
+                 "(gfx950), write = WRITE_SIZE x 1024; fabric side, per launch"}
+json.dump(out, open("$D/ballquery_pmc.json", "w"))
+print(out)
+PY
+rm -rf $D/t $D/b $D/c

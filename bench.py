@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the whole train step (forward + backward + fused AdamW) from one HIP graph; "
                          "auto = on for a single GPU")
+    ap.add_argument("--no-text-prologue", dest="text_prologue", action="store_false",
+                    help="A/B: the question / answer embeddings inside the fusion phase (as before round 4) instead of as phases "
+                         "of their own beside the image encoder / the image backward")
     ap.add_argument("--loop", choices=["phased", "reference"], default="phased",
                     help="c3: phased = pipeline.PhasedTrainStep (the measured step structure, the headline); reference = the "
                          "reference's own loop, unchanged -- data_dict = model(data_dict); loss = get_loss(...); "
@@ -667,7 +670,8 @@ def main():
             bb.force = args.dp_path
         pipe = PhasedTrainStep(model, batch, det_loss, fusion_loss, opt, use_graphs=use_graph, next_batch=batch,
                                eager_phases=("geometry",), image_bwd_splits=3 if dp else 1, buffer_broadcaster=bb,
-                               fusion_bwd_cut=args.fusion_cut if args.fusion_cut >= 0 else None)
+                               fusion_bwd_cut=args.fusion_cut if args.fusion_cut >= 0 else None,
+                               text_prologue=args.text_prologue)
         eager_step = pipe.eager_step
         reducers = {}
         if dp:

@@ -174,20 +174,46 @@ class BLIP_VQA3D(nn.Module):
                 self.text_decoder_scene.load_state_dict(self.text_decoder.state_dict(), strict=False)
 
     # ------------------------------------------------------------------------------------------
+    def prepare_text(self, question, answer=None, device=None):
+        """Everything of the train-mode forward that depends on the TOKEN IDS only -- question tokens with [ENC] set and their
+        embeddings (word + position -> LayerNorm -> dropout, med.py:81-98), and for the shared answer decoder the answer
+        tokens with [BOS], the -100 targets, both stacked for the two streams, and the decoder's embeddings -- so that a
+        scheduler can run it BESIDE the image encoder / detector instead of at the head of the fusion chain, and its backward
+        (LayerNorm + two embedding tables of 30 524 x 768, one of them tied to the LM head) beside the image backward
+        (pipeline.PhasedTrainStep's text_prep / text_prep_bwd phases: ~50 launches of 5 us off the critical chain).
+        forward(..., text_prep=<this dict>) consumes it; values identical to computing them in place."""
+        dev = device if device is not None else self.text_encoder.embeddings.word_embeddings.weight.device
+        q = _tokens(question, self.tokenizer, dev, padding="longest", truncation=True, max_length=80)
+        q.input_ids[:, 0] = self.tokenizer.enc_token_id
+        prep = {"question": q, "q_embeds": self.text_encoder.embeddings(input_ids=q.input_ids)}
+        if answer is not None and self.use_text_decoder and self.share_decoder and not self.use_scene_classifier:
+            a = _tokens(answer, self.tokenizer, dev, padding="longest")
+            a.input_ids[:, 0] = self.tokenizer.bos_token_id
+            targets = a.input_ids.masked_fill(a.input_ids == self.tokenizer.pad_token_id, -100)
+            two = lambda t: torch.cat((t, t), dim=0)
+            ids2 = two(a.input_ids)
+            prep.update(answer=a, ids2=ids2, att2=two(a.attention_mask), targets2=two(targets),
+                        a_embeds=self.text_decoder.bert.embeddings(input_ids=ids2))
+        return prep
+
     def _encode(self, image, question, image_embeds, scene_object_embeds, scene_object_mask, image_pose,
-                image_per_sample, data_dict):
+                image_per_sample, data_dict, text_prep=None):
         if image_per_sample > 1:
             B, P, H = image_embeds.size()
             image_embeds = image_embeds.view(B // P, P * image_per_sample, H)
         dev = image_embeds.device
         image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=dev)
-        question = _tokens(question, self.tokenizer, dev, padding="longest", truncation=True, max_length=80)
-        question.input_ids[:, 0] = self.tokenizer.enc_token_id
+        if text_prep is not None:
+            question = text_prep["question"]
+        else:
+            question = _tokens(question, self.tokenizer, dev, padding="longest", truncation=True, max_length=80)
+            question.input_ids[:, 0] = self.tokenizer.enc_token_id
         if self.use_scene_weight:
             scene_object_mask = scene_object_mask * torch.clamp(self.scene_weight, min=0, max=1)
         if scene_object_embeds is not None:
             scene_object_embeds = _run_adapter(self.linear_scene_object, scene_object_embeds)
-        out = self.text_encoder(question.input_ids, attention_mask=question.attention_mask,
+        out = self.text_encoder(question.input_ids if text_prep is None else None, attention_mask=question.attention_mask,
+                                encoder_embeds=None if text_prep is None else text_prep["q_embeds"],
                                 encoder_hidden_states=image_embeds, encoder_attention_mask=image_atts,
                                 encoder_hidden_states_twin=scene_object_embeds,
                                 encoder_attention_mask_twin=scene_object_mask, return_dict=True,
@@ -201,13 +227,14 @@ class BLIP_VQA3D(nn.Module):
 
     def forward(self, image, question, answer=None, n=None, weights=None, train=True, inference="rank",
                 k_test=128, image_embeds=None, scene_object_embeds=None, scene_object_mask=None, image_pose=None,
-                image_per_sample=1, embed_image=False, depth_map=None, data_dict=None):
+                image_per_sample=1, embed_image=False, depth_map=None, data_dict=None, text_prep=None):
+        """text_prep (extension): the dict prepare_text() returned for the same question / answer"""
         if image_embeds is None:
             image_embeds = self.visual_encoder(image)
         if embed_image:
             return image_embeds, self.projection_head(image_embeds[:, 0].float())
         q2d, q3d, q_mask, image_embeds = self._encode(image, question, image_embeds, scene_object_embeds,
-                                                      scene_object_mask, image_pose, image_per_sample, data_dict)
+                                                      scene_object_mask, image_pose, image_per_sample, data_dict, text_prep)
         B = image_embeds.size(0)
         dev = image_embeds.device
 
@@ -226,6 +253,13 @@ class BLIP_VQA3D(nn.Module):
 
         if train:
             assert answer is not None, "answer must be specified if use text decoder (free-form answer mode)"
+            if text_prep is not None and "a_embeds" in text_prep:
+                # (token-only work done ahead of time: stacked ids / masks / targets and the decoder's embeddings)
+                out = self.text_decoder(None, attention_mask=text_prep["att2"], encoder_embeds=text_prep["a_embeds"],
+                                        encoder_hidden_states=torch.cat((q2d.last_hidden_state, q3d.last_hidden_state), dim=0),
+                                        encoder_attention_mask=torch.cat((q_mask, q_mask), dim=0),
+                                        labels=text_prep["targets2"], return_dict=True, reduction="none")
+                return out.loss.sum() / B, self.fuse_2d3d(q2d, q3d), q_mask
             answer = _tokens(answer, self.tokenizer, dev, padding="longest")
             answer.input_ids[:, 0] = self.tokenizer.bos_token_id
             targets = answer.input_ids.masked_fill(answer.input_ids == self.tokenizer.pad_token_id, -100)
@@ -320,16 +354,19 @@ class BLIP_VQA3D(nn.Module):
         """Low-rank bilinear + mean (blip_vqa_3d.py:502-507)."""
         h2d = question_output.last_hidden_state.float()
         h3d = question_output_scene.last_hidden_state.float()
-        a, b = self.lowrank_2d(h2d), self.lowrank_3d(h3d)  # (B, L, r)
-        # nn.Bilinear as two dense contractions: out[.,o] = sum_ij a_i W[o,i,j] b_j + bias_o.  (torch's bilinear
-        # runs one small GEMM pair PER OUTPUT FEATURE on the GPU -- 768 x 3 launches per call.)
         W = self.bilinear_fusion.weight  # (out, r, r)
-        if ops.compute_dtype() == torch.bfloat16 and a.is_cuda:
-            # one contraction over the r * r outer-product features: out = (a (x) b) . W^T with W viewed (out, r*r) -- a
-            # single MFMA GEMM (M = B L rows, K = r^2 = 9216) instead of a 94 MB fp32 intermediate and library GEMMs
+        if ops.compute_dtype() == torch.bfloat16 and h2d.is_cuda:
+            # the two low-rank projections on the MFMA GEMM family too (they were the step's last fp32 library GEMMs on
+            # the critical stream), then one contraction over the r * r outer-product features: out = (a (x) b) . W^T with
+            # W viewed (out, r*r) -- a single GEMM (M = B L rows, K = r^2 = 9216) instead of a 94 MB fp32 intermediate
+            a = ops.linear(question_output.last_hidden_state, self.lowrank_2d.weight, self.lowrank_2d.bias).float()
+            b = ops.linear(question_output_scene.last_hidden_state, self.lowrank_3d.weight, self.lowrank_3d.bias).float()
             x = (a.unsqueeze(-1) * b.unsqueeze(-2)).flatten(-2)                  # (B, L, r * r), row-major (i, j) as W
             out = ops.linear(x, W, self.bilinear_fusion.bias).float()
             return out + (h2d + h3d) / 2.0
+        a, b = self.lowrank_2d(h2d), self.lowrank_3d(h3d)  # (B, L, r)
+        # nn.Bilinear as two dense contractions: out[.,o] = sum_ij a_i W[o,i,j] b_j + bias_o.  (torch's bilinear
+        # runs one small GEMM pair PER OUTPUT FEATURE on the GPU -- 768 x 3 launches per call.)
         t = torch.matmul(a, W.permute(1, 0, 2).reshape(W.shape[1], -1))          # (B, L, out * r)
         out = (t.view(*a.shape[:-1], W.shape[0], W.shape[2]) * b.unsqueeze(-2)).sum(-1)
         if self.bilinear_fusion.bias is not None:

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
   const int tl = t - pr.tile0;
   const int tiles_j = (pr.Nj + 255) >> 8;
   // ragged last j block first: it is the cheapest tile, and late-starting workgroups should be the full ones
-  const int bj = tiles_j - 1 - tl / pr.tiles_i, bi = tl % pr.tiles_i;
+  const int bj = tiles_j - 1 - tl / pr.tiles_i(), bi = tl % pr.tiles_i();
   const int i0 = bi * 256, j0 = bj * 256;
   const int Ni = pr.Ni, Nj = pr.Nj, Kc = pr.Kc;
   const int ldp = pr.ldp, ldq = pr.ldq;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
   // a (B, L1 + L2, N) gradient in place): the lane's row walks 64 rows per K tile; when it leaves its batch (q_rpb >= 64:
   // at most once per step) the cursor jumps over the rows between the batches.  One row counter per unit pair (B0 / B1
   // are staged in different phases).
-  const int q_rpb = Q_XC ? (int)pr.q_rpb : 0;
+  const int q_rpb = Q_XC ? (int)pr.q_rpb() : 0;
   const unsigned q_gap = (unsigned)((pr.q_bstride - q_rpb * ldq) * 2);
   int q_rl[2] = {ur, ur};
 
@@ -265,10 +265,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
   if (EPI == EPI_BIAS_CE) {
     // Cross-entropy partials of the LM head (csrc/lmhead.hip combines them): for every row j of this wave and the 128
     // vocabulary entries i of its half tile -- the fp32 logits acc + bias, before any rounding -- the running maximum,
-    // sum exp(z - max) and sum z over the VALID entries (i < n_valid = pr.ksplit), and the target's logit where this lane
+    // sum exp(z - max) and sum z over the VALID entries (i < n_valid = pr.ksplit()), and the target's logit where this lane
     // holds it.  Field reuse for this epilogue: out2 = partial f32 [tiles_i * 2][Nj][3], aux = int32 targets [Nj]
     // (-100 = ignore), colsum = f32 [Nj] target logits, ksplit = number of valid vocabulary entries.
-    const int n_valid = pr.ksplit;
+    const int n_valid = pr.ksplit();
     float *part = reinterpret_cast<float *>(pr.out2) + (long)(bi * 2 + wr) * Nj * 3;
     const int *tgt = reinterpret_cast<const int *>(pr.aux);
 #pragma unroll
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
   for (int k = 1; k < args.n; ++k)
     if (t >= args.p[k].tile0) pi = k;
   const GemmProblem &pr = args.p[pi];
-  const int ksplit = OUT_F32 ? pr.ksplit : 1;
+  const int ksplit = OUT_F32 ? pr.ksplit() : 1;
   const int Ni = pr.Ni, Nj = pr.Nj, Kc = pr.Kc;
   int tl = t - pr.tile0, ks = 0;
   if (ksplit > 1) {
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
     // round-robin by blockIdx) and meet in its L2 (PMC: operands fetched once) -- 170 -> 125 us on SA2's first layer
     // against the piece-major order that spreads them over the XCDs
     const int lt = t - pr.tile0;
-    const int ntl = pr.tiles_i * ((Nj + BJ - 1) / BJ);
+    const int ntl = pr.tiles_i() * ((Nj + BJ - 1) / BJ);
     if ((ksplit & 7) == 0 && (pr.tile0 & 7) == 0) {
       const int slot = lt >> 3;
       tl = slot % ntl;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
       ks = lt / ntl;
     }
   }
-  const int bj = tl / pr.tiles_i, bi = tl % pr.tiles_i;
+  const int bj = tl / pr.tiles_i(), bi = tl % pr.tiles_i();
   const int i0 = bi * 64, j0 = bj * BJ;
   const int ldp = pr.ldp, ldq = pr.ldq;
   const int nkt_all = (Kc + 63) >> 6;
@@ -555,9 +555,13 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
   const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void *)pr.Q, 0, pr.q_bytes, 0x00020000);
   const int cp = lane & 7;
   // P unit: 2 DMAs per wave (rows (2w+d)*8 + lane/8); Q unit: 2 (BJ = 64) or 1 (BJ = 32: rows w*8 + lane/8)
-  unsigned vp[2], vq[2], qcol[2];
-  int qrow[2];            // XC Q under a row map: the contraction row each DMA stages next, and its column offset
-  const bool q_xc_map = Q_XC && pr.q_rpb != 0;   // (workgroup-uniform)
+  unsigned vp[2], vq[2];
+  // XC Q under a row map (short contractions over a strided (batch, rows) view): the contraction row each DMA stages next
+  // and its column offset.  SCALARS on purpose: as small arrays hipcc promoted them to LDS (+ 4 KB per workgroup) and every
+  // gemm64 launch of the step got 10-20 us slower (profiles/r04: 15.2 -> 27.1 us on the text side's dX form)
+  const bool q_xc_map = Q_XC && pr.q_rpb() != 0;   // (workgroup-uniform)
+  int qrow0 = 0, qrow1 = 0;
+  unsigned qcol0 = 0, qcol1 = 0;
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
     const int ur = (wave * 2 + d) * 8 + (lane >> 3);
@@ -565,10 +569,13 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
     else vp[d] = (unsigned)((ur * ldp + i0 + (cp ^ (xg(ur) << 1)) * 8) * 2);
     const int uq = (BJ == 64) ? ur : wave * 8 + (lane >> 3);
     // (batched-row map of Q, GemmProblem::q_rpb: on its j rows here, on its contraction rows in the XC form -- see stage())
-    if (!Q_XC) vq[d] = (mapped_row(j0 + uq, ldq, pr.q_rpb, pr.q_bstride) + (unsigned)((cp ^ (uq & 7)) * 8)) * 2u;
+    if (!Q_XC) vq[d] = (mapped_row(j0 + uq, ldq, pr.q_rpb(), pr.q_bstride) + (unsigned)((cp ^ (uq & 7)) * 8)) * 2u;
     else vq[d] = (unsigned)((uq * ldq + j0 + (cp ^ (xg(uq) << 1)) * 8) * 2);
-    qrow[d] = kt0 * 64 + uq;
-    qcol[d] = (unsigned)(j0 + (cp ^ (xg(uq) << 1)) * 8);
+    if (Q_XC) {
+      const int row = kt0 * 64 + uq;
+      const unsigned col = (unsigned)(j0 + (cp ^ (xg(uq) << 1)) * 8);
+      if (d == 0) { qrow0 = row; qcol0 = col; } else { qrow1 = row; qcol1 = col; }
+    }
   }
   const unsigned p_step = P_XC ? (unsigned)(64 * ldp * 2) : 128u;
   const unsigned q_step = Q_XC ? (unsigned)(64 * ldq * 2) : 128u;
@@ -593,9 +600,9 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
 #pragma unroll
       for (int d = 0; d < (BJ == 64 ? 2 : 1); ++d) {
         const int blk = (BJ == 64) ? wave * 2 + d : wave;
-        if (q_xc_map) {   // short contractions over a strided (batch, rows) view: one division per DMA
-          vq[d] = (mapped_row(qrow[d], ldq, pr.q_rpb, pr.q_bstride) + qcol[d]) * 2u;
-          qrow[d] += 64;
+        if (Q_XC && q_xc_map) {   // short contractions over a strided (batch, rows) view: one division per DMA
+          if (d == 0) { vq[0] = (mapped_row(qrow0, ldq, pr.q_rpb(), pr.q_bstride) + qcol0) * 2u; qrow0 += 64; }
+          else { vq[1] = (mapped_row(qrow1, ldq, pr.q_rpb(), pr.q_bstride) + qcol1) * 2u; qrow1 += 64; }
         }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_void_t *)(smem + base + 8192 + blk * 1024), 16,
                                                  live ? vq[d] : 0x80000000u, 0, 0, 0);
@@ -606,12 +613,9 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
 
   const int row16 = lane & 15, q4 = lane >> 4;
   const int kc_base = row16 * 128 + ((q4 ^ (row16 & 7)) << 4);
-  int xc_base[4];
-  {
-    const int q = (lane & 15) >> 2, p = lane & 3, g = (q >> 1) | ((q4 & 1) << 1);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) xc_base[s] = (8 * q4 + q) * 128 + ((s ^ g) << 5) + 8 * p;
-  }
+  // (XC fragment addresses in closed form: read_frag_cf, gemm_common.h -- sub16 depends on the wave here)
+  const int xc_q = (lane & 15) >> 2, xcg = (xc_q >> 1) | ((q4 & 1) << 1);
+  const int xc0 = (8 * q4 + xc_q) * 128 + 8 * (lane & 3);
 
   f32x4 acc[2][QF];
 #pragma unroll
@@ -646,11 +650,11 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag<P_XC>(buf, wr * 2 + a, kk, kc_base, xc_base);
+        for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag_cf<P_XC>(buf, wr * 2 + a, kk, kc_base, xc0, xcg);
 #pragma unroll
       for (int b = 0; b < QF; ++b)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fb[b][kk] = read_frag<Q_XC>(buf + 8192, wc * QF + b, kk, kc_base, xc_base);
+        for (int kk = 0; kk < 2; ++kk) fb[b][kk] = read_frag_cf<Q_XC>(buf + 8192, wc * QF + b, kk, kc_base, xc0, xcg);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -671,7 +675,7 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
   // ---- epilogue: straight from the accumulators (8-B bf16 / 16-B fp32 pieces of an output row) ---------------------
   const int ldo = pr.ldo;
   const int iw = i0 + wr * 32, jw = j0 + wc * (BJ / 2);
-  const bool atomic_out = ksplit > 1 || pr.accum;   // fp32 out: add to what is there (cut contraction / second row source)
+  const bool atomic_out = ksplit > 1 || pr.accum();   // fp32 out: add to what is there (cut contraction / second row source)
   if (QSUM && do_qsum && q4 == 0) {
 #pragma unroll
     for (int b = 0; b < QF; ++b) {
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] + b4[r];
       // element offset of row j of out / out2 / aux (64-bit on plain rows: outputs beyond 2 G elements exist)
-      const long jo = pr.o_rpb ? (long)mapped_row(j < Nj ? j : 0, ldo, pr.o_rpb, pr.o_bstride) : (long)j * ldo;
+      const long jo = pr.o_rpb() ? (long)mapped_row(j < Nj ? j : 0, ldo, pr.o_rpb(), pr.o_bstride) : (long)j * ldo;
       if (OUT_F32) {
         float *dst = reinterpret_cast<float *>(pr.out) + jo + i;
         if (ok && !atomic_out) *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
@@ -1163,26 +1167,26 @@ extern "C" int bq_gemm_bf16(const bq_gemm_desc *d, int n, int flags, int epilogu
       g.P = (const __bf16 *)s.P; g.Q = (const __bf16 *)s.Q; g.out = s.out; g.bias = s.bias; g.out2 = s.out2;
       g.aux = (const __bf16 *)s.aux; g.colsum = s.colsum;
       g.ldp = s.ldp; g.ldq = s.ldq; g.ldo = s.ldo; g.Ni = s.Ni; g.Nj = s.Nj; g.Kc = s.Kc;
-      g.bias_bf16 = (unsigned char)(s.bias_bf16 != 0);
-      g.accum = (unsigned char)(s.accum != 0);
-      g.q_rpb = (unsigned short)s.q_rpb; g.o_rpb = (unsigned short)s.o_rpb;
+      g.flags = (s.bias_bf16 != 0 ? 1 : 0) | (s.accum != 0 ? 2 : 0);
+      g.rpb_pack = (int)((unsigned)s.q_rpb | ((unsigned)s.o_rpb << 16));
       g.q_bstride = s.q_bstride; g.o_bstride = s.o_bstride;
       g.p_bytes = (unsigned)(s.p_bytes > 0 ? s.p_bytes : pb);
       g.q_bytes = (unsigned)((s.q_bytes > 0 && s.q_rpb == 0) ? s.q_bytes : qb);
+      int ks_ = 1;
       if (epilogue == EPI_BIAS_CE) {
         BQ_REQUIRE(s.out2 && s.aux && s.colsum && s.ksplit > 0 && s.ksplit <= s.Ni && s.ksplit <= 65535 && tile == 256, BQ_EINVAL,
                    "bq_gemm_bf16: the cross-entropy epilogue needs out2 (partials), aux (targets), colsum (target logits), "
                    "ksplit = valid vocabulary entries (<= 65535), tile 256");
-        g.ksplit = (unsigned short)s.ksplit;
+        ks_ = s.ksplit;
       } else {
         BQ_REQUIRE(s.ksplit <= 1 || (f32 && tile != 256), BQ_EINVAL, "bq_gemm_bf16: ksplit needs fp32 out and tile 64");
         BQ_REQUIRE(s.ksplit <= 65535, BQ_ELIMIT, "bq_gemm_bf16: ksplit = %d > 65535", s.ksplit);
-        g.ksplit = (unsigned short)((f32 && tile != 256 && s.ksplit > 1) ? s.ksplit : 1);
+        ks_ = (f32 && tile != 256 && s.ksplit > 1) ? s.ksplit : 1;
       }
       BQ_REQUIRE((s.Ni + ti - 1) / ti <= 65535, BQ_ELIMIT, "bq_gemm_bf16: Ni = %d too wide", s.Ni);
-      g.tiles_i = (unsigned short)((s.Ni + ti - 1) / ti);
+      g.tiles_ks = (int)((unsigned)((s.Ni + ti - 1) / ti) | ((unsigned)ks_ << 16));
       g.tile0 = ga.total_tiles;
-      ga.total_tiles += g.tiles_i * ((s.Nj + tj - 1) / tj) * (epilogue == EPI_BIAS_CE ? 1 : g.ksplit);
+      ga.total_tiles += g.tiles_i() * ((s.Nj + tj - 1) / tj) * (epilogue == EPI_BIAS_CE ? 1 : g.ksplit());
       ++ga.n;
       ++done;
     }

@@ -34,12 +34,20 @@ struct GemmProblem {
   // (r / rpb) * bstride + (r % rpb) * ld -- a (batch, rows, cols) view with a batch stride, e.g. the first 1025 of every
   // sample's 1045 key rows.  rpb = 0: plain rows.  On a contraction-major Q the map is on the CONTRACTION rows.
   int q_bstride, o_bstride;
-  unsigned short q_rpb, o_rpb;
-  unsigned short tiles_i;     // tiles along i
-  unsigned short ksplit;      // > 1 (fp32 out, small-tile kernel): the contraction is cut into ksplit pieces, one workgroup
-                              // each, accumulated with fp32 atomics into a zero-initialised `out`
-  unsigned char bias_bf16;
-  unsigned char accum;        // fp32 out, small-tile kernel: add to `out` / `colsum` (fp32 atomics) instead of storing
+  // 32-bit words only: the table is indexed by a run-time problem number, and with 8- / 16-bit members hipcc could no longer
+  // read it with scalar loads from the kernel-argument segment -- it copied the whole 4 KB table into LDS in every workgroup
+  // (+ 4 KB of LDS, + 10-20 us on every small-tile launch of the step: round 4's first version of this struct)
+  int rpb_pack;        // q_rpb | o_rpb << 16
+  int tiles_ks;        // tiles along i | ksplit << 16.  ksplit > 1 (fp32 out, small-tile kernel): the contraction is cut
+                       // into ksplit pieces, one workgroup each, accumulated with fp32 atomics into a zero-initialised `out`
+  int flags;           // bit 0: bias is bf16; bit 1: accum (fp32 out, small-tile kernel: add to `out` / `colsum` with fp32
+                       // atomics instead of storing)
+  __host__ __device__ __forceinline__ int q_rpb() const { return rpb_pack & 0xffff; }
+  __host__ __device__ __forceinline__ int o_rpb() const { return (int)((unsigned)rpb_pack >> 16); }
+  __host__ __device__ __forceinline__ int tiles_i() const { return tiles_ks & 0xffff; }
+  __host__ __device__ __forceinline__ int ksplit() const { return (int)((unsigned)tiles_ks >> 16); }
+  __host__ __device__ __forceinline__ int bias_bf16() const { return flags & 1; }
+  __host__ __device__ __forceinline__ int accum() const { return (flags >> 1) & 1; }
 };
 // the descriptor table travels as a kernel argument (4 KB limit): 36 problems x 112 B + 8
 static_assert(sizeof(GemmProblem) == 112, "GemmProblem grew: GEMM_MAX_PROBLEMS x sizeof must stay below the 4 KB kernarg limit");
@@ -53,7 +61,7 @@ __device__ __forceinline__ unsigned mapped_row(int r, int ld, int rpb, int bstri
 }
 
 __device__ __forceinline__ void load_bias4(const GemmProblem &pr, int i, float (&bv)[4]) {
-  if (pr.bias_bf16) {
+  if (pr.bias_bf16()) {
     const bf16x4 b = *reinterpret_cast<const bf16x4 *>(reinterpret_cast<const __bf16 *>(pr.bias) + i);
     bv[0] = (float)b[0]; bv[1] = (float)b[1]; bv[2] = (float)b[2]; bv[3] = (float)b[3];
   } else {
@@ -152,6 +160,21 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char *unit, int sub16
   } else {
     // XC: xc_base[s] = (8*gq + q)*128 + ((s ^ g) << 5) + 8*p ; rows +kk*32, second read +4 rows
     const unsigned char *a0 = unit + xc_base[sub16] + kk * 4096;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)a0);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(a0 + 512));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+
+// the same with the XC lane term in CLOSED FORM (xc0 = (8*gq + q)*128 + 8*p, xcg = g: xc_base[s] = xc0 + ((s ^ g) << 5)) for
+// kernels whose sub16 is a run-time value (gemm64_kernel: wave row / column): indexing the int[4] table dynamically makes it
+// an alloca, which hipcc may promote to LDS (+ 4 KB per workgroup and an LDS round trip per fragment address)
+template <bool XC>
+__device__ __forceinline__ bf16x8 read_frag_cf(const unsigned char *unit, int sub16, int kk, int kc_base, int xc0, int xcg) {
+  if (!XC) {
+    return *reinterpret_cast<const bf16x8 *>(unit + sub16 * 2048 + (kc_base ^ (kk << 6)));
+  } else {
+    const unsigned char *a0 = unit + xc0 + ((sub16 ^ xcg) << 5) + kk * 4096;
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)a0);
     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(a0 + 512));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);

@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
     const int tiles_j = (pr.Nj + 127) >> 7;
     Tile tt;
     tt.pi = pi;
-    tt.j0 = (tiles_j - 1 - tl / pr.tiles_i) * 128;   // ragged last j block first
-    tt.i0 = (tl % pr.tiles_i) * 256;
+    tt.j0 = (tiles_j - 1 - tl / pr.tiles_i()) * 128;   // ragged last j block first
+    tt.i0 = (tl % pr.tiles_i()) * 256;
     tt.nkt = (pr.Kc + 63) >> 6;
     return tt;
   };
@@ -130,9 +130,9 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
       // unit row r -> j0 + (r >> 5) * 64 + half * 32 + (r & 31); d = 1 is r + 32: 64 rows further (under a batched-row
       // map the two rows may lie in different batches: the d = 1 delta is per lane then)
       const int row0 = tt.j0 + half * 32 + ur0;
-      const unsigned o0 = mapped_row(row0, pr.ldq, pr.q_rpb, pr.q_bstride);
+      const unsigned o0 = mapped_row(row0, pr.ldq, pr.q_rpb(), pr.q_bstride);
       v = (o0 + (unsigned)((cp ^ (ur0 & 7)) * 8)) * 2u;
-      ddQ[half] = pr.q_rpb ? (mapped_row(row0 + 64, pr.ldq, pr.q_rpb, pr.q_bstride) - o0) * 2u : (unsigned)(64 * pr.ldq * 2);
+      ddQ[half] = pr.q_rpb() ? (mapped_row(row0 + 64, pr.ldq, pr.q_rpb(), pr.q_bstride) - o0) * 2u : (unsigned)(64 * pr.ldq * 2);
     } else {
       // unit row r = contraction index; its 8 chunks of 8 columns: chunk c -> j0 + (c >> 2) * 64 + half * 32 + (c & 3) * 8
       // (the `half` 32 columns of both wave columns); d = 1 is r + 32
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
       }
     } else {
       const int ldo = pr.ldo;
-      const int orpb = pr.o_rpb, obs = pr.o_bstride;   // batched-row map of out / out2 / aux (0: plain rows)
+      const int orpb = pr.o_rpb(), obs = pr.o_bstride;   // batched-row map of out / out2 / aux (0: plain rows)
       const unsigned obytes = orpb ? (unsigned)((long)(Nj / orpb) * obs * 2) : (unsigned)((long)Nj * ldo * 2);
       const auto rsO = __builtin_amdgcn_make_buffer_rsrc(pr.out, 0, obytes, 0x00020000);
       const auto rsO2 = __builtin_amdgcn_make_buffer_rsrc(EPI == EPI_BIAS_GELU ? pr.out2 : pr.out, 0, obytes, 0x00020000);
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
       };
       if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
         float bias_r[8][4];
-        const bool bb = pr.bias_bf16 != 0;
+        const bool bb = pr.bias_bf16() != 0;
         const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void *)pr.bias, 0, pr.bias == nullptr ? 0 : Ni * (bb ? 2 : 4), 0x00020000);
         const unsigned bo = (unsigned)(iw + q4 * 4);
         if (bb) {

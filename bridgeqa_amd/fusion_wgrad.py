@@ -205,7 +205,10 @@ def flush_deferred_items(items):
     dbs = {}
     mid = []
     if _SHORT_DW_TILE[0] == 128:
-        ok = lambda it: (128 <= _nrows(it[0]) and it[0].dim() == 2 and it[0].shape[-1] >= 128 and it[1].shape[-1] >= 256)
+        # (only the SHORT contractions: the planner's moved problems -- full 16 400-row contractions of 9 tiles -- stay on
+        # the 64-tile kernel, whose cut contraction spreads them over the chip: the 256 x 128 form ran them at 5 % MFMA busy)
+        ok = lambda it: (128 <= _nrows(it[0]) < _BIG_ROWS and it[0].dim() == 2 and it[0].shape[-1] >= 128
+                         and it[1].shape[-1] >= 256)
         mid = [k for k in small if ok(items[k])]
         small = [k for k in small if not ok(items[k])]
     for tile, idx_groups in ((_DW_TILE[0], groups), (128, [mid] if mid else []), (64, [small] if small else [])):

@@ -98,18 +98,28 @@ class ScanQAHotPath(nn.Module):
     def detect_objects(self, data_dict):
         """detector + the proposal-feature projection the fusion consumes (qa_module.py:438-479, 219-221)"""
         data_dict = self.detect(data_dict)
-        data_dict["object_feat"] = self.object_feat_linear(data_dict["aggregated_vote_features"])
+        feats = data_dict["aggregated_vote_features"]
+        lin = self.object_feat_linear[0]
+        from . import fusion_ops as ops
+        if feats.is_cuda and ops.compute_dtype() == torch.bfloat16 and self.use_blip:
+            # Linear + GELU as one launch of the MFMA GEMM family (bias + GELU epilogue): the fusion reads these tokens in
+            # bf16 anyway; this was the detector stream's last library GEMM
+            data_dict["object_feat"] = ops.linear(feats, lin.weight, lin.bias, act="gelu")
+        else:
+            data_dict["object_feat"] = self.object_feat_linear(feats)
         return data_dict
 
-    def fuse(self, data_dict, image_embeds, object_feat=None):
-        """twin 2D/3D cross-attention encoder + answer decoder over the detector's proposals and the image tokens"""
+    def fuse(self, data_dict, image_embeds, object_feat=None, text_prep=None):
+        """twin 2D/3D cross-attention encoder + answer decoder over the detector's proposals and the image tokens;
+        text_prep: BLIP_VQA3D.prepare_text(question, answer) computed ahead of time (pipeline.PhasedTrainStep)"""
         if object_feat is None:
             object_feat = data_dict["object_feat"]
         object_mask = ~data_dict["bbox_mask"].bool().detach()  # True = not an object
         train = data_dict.get("phase", "train") == "train"
         out = self.blip_model(data_dict["images"][:, 0], data_dict["question"], image_embeds=image_embeds,
                               scene_object_embeds=object_feat.clone(), scene_object_mask=~object_mask,
-                              answer=data_dict["answer"], train=train, k_test=256, data_dict=data_dict)
+                              answer=data_dict["answer"], train=train, k_test=256, data_dict=data_dict,
+                              text_prep=text_prep if train else None)
         if train:
             data_dict["blip_loss"], data_dict["fused_feat"], data_dict["fused_mask"] = out
             data_dict["decoder_loss"] = data_dict["blip_loss"]  # the name lib/loss_helper.py reads (qa_module.py:696)

@@ -837,11 +837,15 @@ class BertLMHeadModel(BertPreTrainedModel):
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, head_mask=None, inputs_embeds=None,
                 encoder_hidden_states=None, encoder_attention_mask=None, labels=None, past_key_values=None,
                 use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None,
-                return_logits=False, is_decoder=True, reduction="mean", mode="multimodal", layernorm_idx=0):
+                return_logits=False, is_decoder=True, reduction="mean", mode="multimodal", layernorm_idx=0,
+                encoder_embeds=None):
+        """encoder_embeds (extension): the output of self.bert.embeddings computed ahead of time -- the text prologue of
+        pipeline.PhasedTrainStep (BLIP_VQA3D.prepare_text); BertModel.forward takes it as the reference's does"""
         if labels is not None:
             use_cache = False
         outputs = self.bert(input_ids, attention_mask=attention_mask, position_ids=position_ids,
-                            inputs_embeds=inputs_embeds, encoder_hidden_states=encoder_hidden_states,
+                            inputs_embeds=inputs_embeds, encoder_embeds=encoder_embeds,
+                            encoder_hidden_states=encoder_hidden_states,
                             encoder_attention_mask=encoder_attention_mask, past_key_values=past_key_values,
                             use_cache=use_cache, output_attentions=output_attentions,
                             output_hidden_states=output_hidden_states, is_decoder=is_decoder, mode=mode,

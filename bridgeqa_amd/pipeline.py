@@ -48,12 +48,14 @@ from . import fusion_ops as ops
 
 
 _DET_LOSS_LATE = [True]   # the fusion waits for the detector's outputs only (False: also for its loss, as before round 3)
+_SINGLE_STREAM = [True]   # capture every phase graph without fusion_ops.fork (tools/ab_bench.py flips it)
 
 
 class PhasedTrainStep(object):
     def __init__(self, model, batch, det_loss, fusion_loss, optimizer=None, use_graphs=True, det_priority=0,
                  grad_hook=None, next_batch=None, prefetch_geometry=None, eager_phases=(), reducers=None,
-                 main_priority=-1, image_bwd_splits=1, buffer_broadcaster=None, coverage_every=50, fusion_bwd_cut=None):
+                 main_priority=-1, image_bwd_splits=1, buffer_broadcaster=None, coverage_every=50, fusion_bwd_cut=None,
+                 text_prologue=True):
         """model: ScanQAHotPath (use_blip=True, train mode); batch: static device tensors (replayed in place);
         det_loss(data_dict) -> scalar over detector outputs; fusion_loss(data_dict) -> scalar over blip_loss /
         fused_feat; optimizer: stepped at the end of the step (None: the caller steps);
@@ -79,6 +81,9 @@ class PhasedTrainStep(object):
         buffer_broadcaster: ddp.BufferBroadcaster -- rank 0's buffers (BatchNorm running statistics) to every rank at the
         start of every step, DDP's broadcast_buffers=True (the reference's default); None: statistics stay per rank;
         coverage_every: run ddp.check_coverage every this many replayed steps (and after every capture);
+        text_prologue: the token-only head of the fusion (question / answer embeddings, BLIP_VQA3D.prepare_text) and its
+        backward as phases of their own on the detector stream, beside the image encoder / the image backward, instead of on
+        the critical chain (~50 launches of 5 us);
         fusion_bwd_cut: twin-encoder level index c (None: off).  The fusion backward is cut in front of level c: the phase
         "fusion" ends when the backward of the answer decoder and of levels >= c has run, the weight gradients parked so far
         are flushed by the graph "fusion_wg" on a THIRD stream while "fusion_b" (levels < c, embeddings, and their own
@@ -106,6 +111,9 @@ class PhasedTrainStep(object):
         if self.image_splits > 4:
             raise ValueError("image_bwd_splits: at most 4 block ranges")
         self.fusion_cut = None if fusion_bwd_cut is None else int(fusion_bwd_cut)
+        bm = getattr(model, "blip_model", None)
+        self.text_prologue = bool(text_prologue) and bm is not None and hasattr(bm, "prepare_text") \
+            and isinstance(batch.get("question"), dict)
         self._wg_keep = None     # the records "fusion_wg" reads live in the main pool: never handed back while the graphs exist
         self._seg_probe = None   # attach_reducers: {segment: parameters whose gradient that segment produced}
         self.buffer_broadcaster, self.coverage_every, self._steps = buffer_broadcaster, int(coverage_every), 0
@@ -128,7 +136,7 @@ class PhasedTrainStep(object):
         self.e_img_fwd = torch.cuda.Event()
         self.s_det = torch.cuda.Stream(device=dev, priority=int(det_priority))
         self.s_wg = torch.cuda.Stream(device=dev, priority=0) if self.fusion_cut is not None else None
-        self.e_mid, self.e_wg = torch.cuda.Event(), torch.cuda.Event()
+        self.e_mid, self.e_wg, self.e_text_bwd = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
         self.e_det_fwd, self.e_fused, self.e_det_bwd, self.e_done = (torch.cuda.Event() for _ in range(4))
         self._bn_modules, self._bn_sig = None, None
         self.use_graphs = use_graphs
@@ -172,6 +180,25 @@ class PhasedTrainStep(object):
         dd = self.model.detect_objects(dd)
         self._state["dd"] = dd
 
+    def _text_prep(self):
+        """the token-only head of the fusion (question / answer embeddings, targets): detector stream, beside the image
+        encoder -- BLIP_VQA3D.prepare_text"""
+        bm = self.model.blip_model
+        self._state["prep"] = bm.prepare_text(self.batch["question"], self.batch.get("answer"), self.dev)
+
+    def _text_prep_bwd(self):
+        """its backward (LayerNorm + embedding tables; the decoder's table is tied to the LM head: this adds to the gradient
+        the fusion phase left there): detector stream, after the fusion, beside the image backward"""
+        st = self._state
+        roots, seeds = [], []
+        for k in ("q_embeds", "a_embeds"):
+            leaf = st["prep_leaves"].get(k)
+            if leaf is not None and leaf.grad is not None:
+                roots.append(st["prep"][k])
+                seeds.append(leaf.grad)
+        if roots:
+            torch.autograd.backward(roots, seeds)
+
     def _det_loss(self):
         """the detection loss (~200 short launches, 1 ms) as a phase of its own: the fusion waits for the detector's OUTPUTS
         (e_det_fwd), not for its loss, which then runs on the detector stream beside the start of the fusion"""
@@ -186,13 +213,19 @@ class PhasedTrainStep(object):
         img_leaf = st["img"].detach().requires_grad_(True)
         obj_leaf = st["dd"]["object_feat"].detach().requires_grad_(True)
         dd = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in st["dd"].items()}
+        prep = None
+        if self.text_prologue:
+            # the embeddings computed by the text_prep phase enter as leaves; text_prep_bwd continues from their gradients
+            prep = dict(st["prep"])
+            st["prep_leaves"] = {k: prep[k].detach().requires_grad_(True) for k in ("q_embeds", "a_embeds") if k in prep}
+            prep.update(st["prep_leaves"])
         enc = self._twin_encoder() if self.fusion_cut is not None else None
         if enc is not None:
             with enc.autograd_cut(self.fusion_cut):
-                dd = self.model.fuse(dd, img_leaf, obj_leaf)
+                dd = self.model.fuse(dd, img_leaf, obj_leaf, text_prep=prep)
             pair, enc.cut_pair = enc.cut_pair, None
         else:
-            dd, pair = self.model.fuse(dd, img_leaf, obj_leaf), None
+            dd, pair = self.model.fuse(dd, img_leaf, obj_leaf, text_prep=prep), None
         loss = self.fusion_loss(dd)
         if self.defer_wgrad:
             ops.begin_deferred_wgrad()  # dW / db of the linears: parked, then one grouped launch after the chain
@@ -277,9 +310,10 @@ class PhasedTrainStep(object):
 
     # (phase, stream, memory pool): the image phases may sit on their own (CU-masked) stream but still alternate
     # strictly with the main stream's phases, so they share its pool
-    _ORDER = (("det_fwd", "det", "det"), ("det_loss", "det", "det"), ("geometry", "det", "det"), ("image_fwd", "img", "main"),
+    _ORDER = (("text_prep", "det", "det"), ("det_fwd", "det", "det"), ("det_loss", "det", "det"), ("geometry", "det", "det"),
+              ("image_fwd", "img", "main"),
               ("fusion", "main", "main"), ("fusion_wg", "wg", "wg"), ("fusion_b", "main", "main"),
-              ("det_bwd", "det", "det"), ("image_bwd", "img", "main"), ("image_bwd_1", "img", "main"),
+              ("text_prep_bwd", "det", "det"), ("det_bwd", "det", "det"), ("image_bwd", "img", "main"), ("image_bwd_1", "img", "main"),
               ("image_bwd_2", "img", "main"), ("image_bwd_3", "img", "main"), ("finish", "main", "main"))
 
     def _stream(self, which):
@@ -290,6 +324,8 @@ class PhasedTrainStep(object):
             return int(name.rsplit("_", 1)[1]) >= self.image_splits
         if name in ("fusion_wg", "fusion_b"):   # only when this step's fusion forward really made the cut
             return self._state.get("fusion_cut") is None
+        if name in ("text_prep", "text_prep_bwd"):
+            return not self.text_prologue
         return name == "geometry" and not self.prefetch
 
     def phase_gpu_ms(self):
@@ -357,6 +393,8 @@ class PhasedTrainStep(object):
                 s_.wait_stream(cur)
         sd.wait_event(self.e_done)  # parameters of the previous step's optimizer
         with torch.cuda.stream(sd):
+            if self.text_prologue:
+                self._run("text_prep", eager)
             self._run("det_fwd", eager)
             if _DET_LOSS_LATE[0]:
                 self.e_det_fwd.record(sd)
@@ -387,8 +425,13 @@ class PhasedTrainStep(object):
             self.e_fused.record(sm)
         sd.wait_event(self.e_fused)
         with torch.cuda.stream(sd):
+            if self.text_prologue:
+                self._run("text_prep_bwd", eager)     # (the embeddings' gradients: part of the fusion group)
+                self.e_text_bwd.record(sd)
             self._run("det_bwd", eager)
             self.e_det_bwd.record(sd)
+        if self.text_prologue and self.s_comm is not None:
+            self.s_comm.wait_event(self.e_text_bwd)
         self._reduce("fusion", self.e_fused)
         self._reduce("det", self.e_det_bwd)
         si.wait_event(self.e_fused)
@@ -540,7 +583,7 @@ class PhasedTrainStep(object):
         # chain's stream): this runtime enqueues a graph with an internal fork node by node -- the fusion graph's launch held
         # the host for 35-38 ms and the phase ran 14.2 ms; without the fork 2.2 ms of host time and 12.7-13.4 ms (round 4,
         # A/B/A on one box: 39.5 / 40.7 / 38.6 ms per step)
-        prev_overlap = ops.set_overlap(False)
+        prev_overlap = ops.set_overlap(not _SINGLE_STREAM[0])
         self.graphs = {}
         self._bn_sig = self._bn_momenta()
         try:

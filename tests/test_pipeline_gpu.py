@@ -64,7 +64,8 @@ def test_phased_step_graph_replay_trains(dev, optimizer):
             from bridgeqa_amd.optim import FusedAdamW
             opt = FusedAdamW(model.parameters(), lr=1e-3)
         pipe = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, opt, use_graphs=True).capture(warmup=3)
-        assert set(pipe.graphs) == {"det_fwd", "det_loss", "image_fwd", "fusion", "det_bwd", "image_bwd", "finish"}
+        assert set(pipe.graphs) == {"text_prep", "det_fwd", "det_loss", "image_fwd", "fusion", "text_prep_bwd", "det_bwd",
+                                    "image_bwd", "finish"}
         w = model.blip_model.visual_encoder.blocks[0].attn.qkv.weight
         w0 = w.detach().clone()
         losses = []

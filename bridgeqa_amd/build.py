@@ -69,7 +69,7 @@ def build(force=False, verbose=False):
         raise RuntimeError("hipcc failed for: %s" % ", ".join(failed))
     for src, _ in procs:   # compiler diagnostics other than the remarks still reach the terminal
         for line in open(os.path.join(objdir, os.path.basename(src) + ".o.res")):
-            if "remark:" not in line and "Rpass-analysis" not in line and line.strip():
+            if "warning:" in line or "error:" in line:
                 sys.stderr.write(line)
     if force or procs or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

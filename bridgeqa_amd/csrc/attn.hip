@@ -426,10 +426,15 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const __bf16 *__res
 __device__ __forceinline__ void attn_fwd_narrow_body(const __bf16 *__restrict__ Q, const __bf16 *__restrict__ K,
                                                      const __bf16 *__restrict__ V, __bf16 *__restrict__ O,
                                                      float *__restrict__ LSE, const AttnDims &dm, const int bh) {
-  __shared__ __align__(16) unsigned char s_k[AT_NW][AT_KB * 128];
-  __shared__ __align__(16) unsigned char s_v[AT_NW][AT_KB * 128];
+  // every wave owns one K and one V image; the merge buffer s_o (33 KB) ALIASES them (it is written after the key loop,
+  // behind a workgroup barrier): 65 KB instead of 100 KB of LDS => TWO workgroups per CU -- the pair launch's 2 x 192
+  // workgroups are resident at once (they were 1.5 rounds of one per CU) and a SIMD has a second wave to issue from
+  __shared__ __align__(16) unsigned char s_kv[2 * AT_NW * AT_KB * 128];
   __shared__ float s_m[AT_NW][32], s_l[AT_NW][32];
-  __shared__ float s_o[AT_NW][AT_D][33];
+  unsigned char (*s_k)[AT_KB * 128] = reinterpret_cast<unsigned char (*)[AT_KB * 128]>(s_kv);
+  unsigned char (*s_v)[AT_KB * 128] = reinterpret_cast<unsigned char (*)[AT_KB * 128]>(s_kv + AT_NW * AT_KB * 128);
+  float (*s_o)[AT_D][33] = reinterpret_cast<float (*)[AT_D][33]>(s_kv);
+  static_assert(sizeof(float) * AT_NW * AT_D * 33 <= 2 * AT_NW * AT_KB * 128, "merge buffer fits in the tile images");
   const float scale_log2e = dm.scale * 1.4426950408889634f;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
   const int b = bh / dm.H, hd = bh % dm.H;
@@ -449,27 +454,43 @@ __device__ __forceinline__ void attn_fwd_narrow_body(const __bf16 *__restrict__ 
   const __bf16 *K2b = dm.K2 ? dm.K2 + b * dm.k2_bs + hd * dm.k2_hs : nullptr;  // second key/value segment (AttnDims)
   const __bf16 *V2b = dm.V2 ? dm.V2 + b * dm.k2_bs + hd * dm.k2_hs : nullptr;
   const int nkt = dm.nkt1 + (dm.Lk2 + AT_KB - 1) / AT_KB;
-  for (int kt0 = 0; kt0 < nkt; kt0 += AT_NW) {
-    const int kt = kt0 + wid;
-    KeyTile kt_ = key_tile(dm, Kb, Vb, K2b, V2b, min(kt, nkt - 1));
-    if (kt < nkt) {  // this wave stages its own tile: 512 chunks of 16 B per image, 8 per lane
-      uint4 kr[8], vr[8];
+  // a wave stages, consumes and re-stages ITS OWN images: no workgroup barrier inside the loop (a wave's LDS operations
+  // complete in order; the wave-level wait + barrier makes the lanes' stores visible to each other), and the NEXT tile's
+  // global loads are in flight while this one is consumed
+  {
+    uint4 kr[8], vr[8];
+    int kt = wid;
+    KeyTile nx_ = key_tile(dm, Kb, Vb, K2b, V2b, min(kt, nkt - 1));
+    if (kt < nkt) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        kr[j] = stage_load(kt_.k, kt_.rs, kt_.row0, kt_.nrows, lane + 64 * j);
-        vr[j] = stage_load(kt_.v, kt_.rs, kt_.row0, kt_.nrows, lane + 64 * j);
+        kr[j] = stage_load(nx_.k, nx_.rs, nx_.row0, nx_.nrows, lane + 64 * j);
+        vr[j] = stage_load(nx_.v, nx_.rs, nx_.row0, nx_.nrows, lane + 64 * j);
       }
+    }
+    for (; kt < nkt; kt += AT_NW) {
+      const KeyTile kt_ = nx_;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         stage_store(s_k[wid], lane + 64 * j, kr[j]);
         stage_store(s_v[wid], lane + 64 * j, vr[j]);
       }
-    }
-    __syncthreads();
-    if (kt < nkt)
+      if (kt + AT_NW < nkt) {
+        nx_ = key_tile(dm, Kb, Vb, K2b, V2b, kt + AT_NW);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          kr[j] = stage_load(nx_.k, nx_.rs, nx_.row0, nx_.nrows, lane + 64 * j);
+          vr[j] = stage_load(nx_.v, nx_.rs, nx_.row0, nx_.nrows, lane + 64 * j);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
       fwd_tile(s_k[wid], s_v[wid], qf, dm, mrow, scale_log2e, seed, bh, r, kt, kt_.last, r, h, o0, o1, m, lsum, kt_.kend);
-    __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this tile's fragment reads are done before it is overwritten)
+      __builtin_amdgcn_wave_barrier();
+    }
   }
+  __syncthreads();   // every wave has finished with its images: the merge buffer aliases them
   const float lw = xhalf_sum(lsum);
   if (h == 0) { s_m[wid][r] = m; s_l[wid][r] = lw; }
 #pragma unroll
@@ -521,7 +542,7 @@ struct AttnPair {
   AttnDims dm[2];
 };
 
-__global__ __launch_bounds__(256) void attn_fwd_narrow_pair_kernel(const AttnPair a) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_narrow_pair_kernel(const AttnPair a) {
   const int g = blockIdx.z;
   attn_fwd_narrow_body(a.Q[g], a.K[g], a.V[g], a.out[g], a.LSEw[g], a.dm[g], blockIdx.y);
 }
@@ -721,9 +742,11 @@ __device__ __forceinline__ void attn_bwd_dq_narrow_body(const __bf16 *__restrict
                                                         const float *__restrict__ LSE, const __bf16 *__restrict__ O,
                                                         float *__restrict__ DELTA, __bf16 *__restrict__ dQ,
                                                         const BwdDims &dm, const int bh) {
-  __shared__ __align__(16) unsigned char s_k[AT_NW][AT_KB * 128];
-  __shared__ __align__(16) unsigned char s_v[AT_NW][AT_KB * 128];
-  __shared__ float s_o[AT_NW][AT_D][33];
+  // (LDS: the merge buffer aliases the tile images, as in attn_fwd_narrow_body: two workgroups per CU)
+  __shared__ __align__(16) unsigned char s_kv[2 * AT_NW * AT_KB * 128];
+  unsigned char (*s_k)[AT_KB * 128] = reinterpret_cast<unsigned char (*)[AT_KB * 128]>(s_kv);
+  unsigned char (*s_v)[AT_KB * 128] = reinterpret_cast<unsigned char (*)[AT_KB * 128]>(s_kv + AT_NW * AT_KB * 128);
+  float (*s_o)[AT_D][33] = reinterpret_cast<float (*)[AT_D][33]>(s_kv);
   const float scale = dm.scale;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
   const int b = bh / dm.H, hd = bh % dm.H;
@@ -758,28 +781,41 @@ __device__ __forceinline__ void attn_bwd_dq_narrow_body(const __bf16 *__restrict
   const __bf16 *K2b = dm.K2 ? dm.K2 + b * dm.k2_bs + hd * dm.k2_hs : nullptr;  // second key/value segment (AttnDims)
   const __bf16 *V2b = dm.V2 ? dm.V2 + b * dm.k2_bs + hd * dm.k2_hs : nullptr;
   const int nkt = dm.nkt1 + (dm.Lk2 + AT_KB - 1) / AT_KB;
-  for (int kt0 = 0; kt0 < nkt; kt0 += AT_NW) {
-    const int kt = kt0 + wid;
-    KeyTile kt_ = key_tile(dm, Kb, Vb, K2b, V2b, min(kt, nkt - 1));
+  {  // (per-wave pipeline without workgroup barriers, next tile's loads in flight: see attn_fwd_narrow_body)
+    uint4 kr[8], vr[8];
+    int kt = wid;
+    KeyTile nx_ = key_tile(dm, Kb, Vb, K2b, V2b, min(kt, nkt - 1));
     if (kt < nkt) {
-      uint4 kr[8], vr[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        kr[j] = stage_load(kt_.k, kt_.rs, kt_.row0, kt_.nrows, lane + 64 * j);
-        vr[j] = stage_load(kt_.v, kt_.rs, kt_.row0, kt_.nrows, lane + 64 * j);
+        kr[j] = stage_load(nx_.k, nx_.rs, nx_.row0, nx_.nrows, lane + 64 * j);
+        vr[j] = stage_load(nx_.v, nx_.rs, nx_.row0, nx_.nrows, lane + 64 * j);
       }
+    }
+    for (; kt < nkt; kt += AT_NW) {
+      const KeyTile kt_ = nx_;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         stage_store(s_k[wid], lane + 64 * j, kr[j]);
         stage_store(s_v[wid], lane + 64 * j, vr[j]);
       }
-    }
-    __syncthreads();
-    if (kt < nkt)
+      if (kt + AT_NW < nkt) {
+        nx_ = key_tile(dm, Kb, Vb, K2b, V2b, kt + AT_NW);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          kr[j] = stage_load(nx_.k, nx_.rs, nx_.row0, nx_.nrows, lane + 64 * j);
+          vr[j] = stage_load(nx_.v, nx_.rs, nx_.row0, nx_.nrows, lane + 64 * j);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
       dq_tile(s_k[wid], s_v[wid], qf, gf, dm, mrow, c, scale, lse, delta, seed, bh, r, kt, kt_.last, r, h, a0, a1,
               kt_.kend);
-    __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
   }
+  __syncthreads();   // every wave has finished with its images: the merge buffer aliases them
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     s_o[wid][crow(i, h)][r] = a0[i];
@@ -804,7 +840,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_narrow_kernel(const __bf16 *_
   attn_bwd_dq_narrow_body(Q, K, V, dO, LSE, O, DELTA, dQ, dm, blockIdx.y);
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_narrow_pair_kernel(const AttnPair a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_narrow_pair_kernel(const AttnPair a) {
   const int g = blockIdx.z;
   attn_bwd_dq_narrow_body(a.Q[g], a.K[g], a.V[g], a.dO[g], a.LSE[g], a.O[g], a.DELTA[g], a.out[g], a.dm[g], blockIdx.y);
 }

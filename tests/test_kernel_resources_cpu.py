@@ -32,6 +32,8 @@ def test_no_kernel_grew_its_lds_or_started_to_spill():
 
 
 if __name__ == "__main__":
+    import sys
+    sys.path.insert(0, ROOT)
     from bridgeqa_amd import build
     r = build.kernel_resources()
     json.dump({k: {"lds": v.get("lds", 0), "scratch": v.get("scratch", 0)} for k, v in sorted(r.items())}, open(GOLD, "w"),

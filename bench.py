@@ -34,7 +34,6 @@ WORKLOADS = {
 WORKLOADS["c5"] = ("c5 (one rank's share): " + WORKLOADS["c3"][4:] + " -- at B=32 x 80000 points + one 1024x1024 view "
                    "(4097 image tokens) per scene")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FUSION_CUT = -1        # pipeline.PhasedTrainStep(fusion_bwd_cut=...): see --fusion-cut
 
 
 def parse():
@@ -53,9 +52,6 @@ def parse():
     ap.add_argument("--no-geometry-prefetch", action="store_true",
                     help="c2: compute the sampling / grouping indices inside the step instead of one step ahead on a second stream")
     ap.add_argument("--dp-path", action="store_true", help="use the data-parallel step structure even on one GPU")
-    ap.add_argument("--fusion-cut", type=int, default=FUSION_CUT,
-                    help="c3 / c5: twin-encoder level in front of which the fusion backward is cut -- the weight gradients "
-                         "parked above it are flushed on a third stream beside the rest of the chain (-1: one fusion phase)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend (nccl = RCCL; gloo only for --share-device validation runs)")
     ap.add_argument("--grad-exchange", choices=["all_reduce", "reduce_scatter"], default="all_reduce",
@@ -670,7 +666,6 @@ def main():
             bb.force = args.dp_path
         pipe = PhasedTrainStep(model, batch, det_loss, fusion_loss, opt, use_graphs=use_graph, next_batch=batch,
                                eager_phases=("geometry",), image_bwd_splits=3 if dp else 1, buffer_broadcaster=bb,
-                               fusion_bwd_cut=args.fusion_cut if args.fusion_cut >= 0 else None,
                                text_prologue=args.text_prologue)
         eager_step = pipe.eager_step
         reducers = {}

@@ -399,30 +399,6 @@ class BertEncoderTwin(BertEncoder):
         super().__init__(config)
         self.num_hidden_layers_twin = getattr(config, "num_hidden_layers_twin", config.num_hidden_layers)
         self.layer_twin = nn.ModuleList([BertLayer(config, i) for i in range(self.num_hidden_layers_twin)])
-        # autograd cut in front of a stacked level (pipeline.PhasedTrainStep(fusion_bwd_cut=...)): the backward of the
-        # levels above it then ends at leaves and their parked weight gradients can be flushed on another stream while the
-        # levels below run.  Scoped to one forward by autograd_cut(); cut_pair: what continue_backward() needs.
-        self.grad_cut, self.cut_pair = None, None
-
-    def autograd_cut(self, level):
-        return _TwinAutogradCut(self, level)
-
-    @staticmethod
-    def continue_backward(cut):
-        """the second half of a cut backward (cut = the cut_pair a forward under autograd_cut() left): seeds the graph
-        below the cut with the gradients the first backward left on the leaves; the fixed tokens' gradient keeps
-        accumulating IN PLACE in the buffer the upper levels filled (ops.GradSink)"""
-        roots, seeds = [cut["pre"]], [cut["leaf"].grad]
-        for e, el, sink in zip(cut["enc"], cut["enc_leaves"], cut["sinks_below"]):
-            g = el.grad
-            if g is None or not e.requires_grad:
-                continue
-            if sink.readers > 0 and sink.buf is None and g.dtype == torch.bfloat16 and g.is_contiguous():
-                sink.buf = g.view(-1, g.shape[-1])    # the last reader below the cut hands the total over
-            else:
-                roots.append(e)
-                seeds.append(g)
-        torch.autograd.backward(roots, seeds)
 
     def init_twin(self):
         for i in range(self.num_hidden_layers_twin):
@@ -509,7 +485,6 @@ class BertEncoderTwin(BertEncoder):
         # kernel path: the cross-attention K/V projections read (fixed tokens, other stream's states) in place and the
         # fixed tokens' gradient accumulates in ONE buffer per stream over the levels (ops.twin_kv / ops.GradSink)
         sinks = (ops.GradSink(), ops.GradSink())
-        self.cut_pair = None
         stacked = mask2 = None   # the two streams as one (2B, L, D) tensor while consecutive levels run paired
         for i in layers:
             if output_hidden_states:
@@ -529,15 +504,6 @@ class BertEncoderTwin(BertEncoder):
                 if mask2 is None:
                     mask2 = torch.cat((attention_mask, attention_mask), dim=0)
                     ops.prime_masks(mask2)
-                if i == self.grad_cut and i != layers[0] and torch.is_grad_enabled() and stacked.requires_grad:
-                    # EVERY path from the levels above into the graph below is cut -- the states and the two fixed-token
-                    # tensors (autograd executes a node it reaches even when all its incoming gradients are None, so an
-                    # uncut edge would run the producers of enc2d / enc3d once per backward call); the levels above
-                    # accumulate the fixed tokens' gradient in sinks of their own, the second backward continues in place
-                    leaf = stacked.detach().requires_grad_(True)
-                    e_leaves = tuple(e.detach().requires_grad_(e.requires_grad) for e in (enc2d, enc3d))
-                    self.cut_pair = dict(pre=stacked, leaf=leaf, enc=(enc2d, enc3d), enc_leaves=e_leaves, sinks_below=sinks)
-                    stacked, (enc2d, enc3d), sinks = leaf, e_leaves, (ops.GradSink(), ops.GradSink())
                 stacked = self._twin_level(i, stacked, mask2, enc2d, enc3d, encoder_attention_mask,
                                            encoder_attention_mask_twin, layernorm_idx, want,
                                            sinks=sinks if ops.twin_kv_ok(enc2d, enc3d, stacked) else None)
@@ -584,19 +550,6 @@ class BertEncoderTwin(BertEncoder):
         return ModelOutput(last_hidden_state=(hidden_states, hidden_states_twin),
                            past_key_values=() if use_cache else None, hidden_states=all_hidden_states,
                            attentions=all_self_attentions, cross_attentions=all_cross_attentions)
-
-
-class _TwinAutogradCut(object):
-    def __init__(self, enc, level):
-        self.enc, self.level = enc, level
-
-    def __enter__(self):
-        self.prev, self.enc.grad_cut = self.enc.grad_cut, self.level
-        return self.enc
-
-    def __exit__(self, *exc):
-        self.enc.grad_cut = self.prev
-        return False
 
 
 class BertPooler(nn.Module):

@@ -54,8 +54,7 @@ _SINGLE_STREAM = [True]   # capture every phase graph without fusion_ops.fork (t
 class PhasedTrainStep(object):
     def __init__(self, model, batch, det_loss, fusion_loss, optimizer=None, use_graphs=True, det_priority=0,
                  grad_hook=None, next_batch=None, prefetch_geometry=None, eager_phases=(), reducers=None,
-                 main_priority=-1, image_bwd_splits=1, buffer_broadcaster=None, coverage_every=50, fusion_bwd_cut=None,
-                 text_prologue=True):
+                 main_priority=-1, image_bwd_splits=1, buffer_broadcaster=None, coverage_every=50, text_prologue=True):
         """model: ScanQAHotPath (use_blip=True, train mode); batch: static device tensors (replayed in place);
         det_loss(data_dict) -> scalar over detector outputs; fusion_loss(data_dict) -> scalar over blip_loss /
         fused_feat; optimizer: stepped at the end of the step (None: the caller steps);
@@ -83,13 +82,7 @@ class PhasedTrainStep(object):
         coverage_every: run ddp.check_coverage every this many replayed steps (and after every capture);
         text_prologue: the token-only head of the fusion (question / answer embeddings, BLIP_VQA3D.prepare_text) and its
         backward as phases of their own on the detector stream, beside the image encoder / the image backward, instead of on
-        the critical chain (~50 launches of 5 us);
-        fusion_bwd_cut: twin-encoder level index c (None: off).  The fusion backward is cut in front of level c: the phase
-        "fusion" ends when the backward of the answer decoder and of levels >= c has run, the weight gradients parked so far
-        are flushed by the graph "fusion_wg" on a THIRD stream while "fusion_b" (levels < c, embeddings, and their own
-        flush) continues on the main stream -- the chain's small-M kernels leave most of the chip idle and the flush is
-        2 ms of the 12 ms phase that nothing needs before the optimizer (separate graphs on separate
-        streams do run concurrently, forks inside one graph do not reliably)."""
+        the critical chain (~50 launches of 5 us)."""
         self.model, self.batch, self.det_loss, self.fusion_loss = model, batch, det_loss, fusion_loss
         self.opt, self.grad_hook = optimizer, grad_hook
         if prefetch_geometry and next_batch is None:
@@ -110,11 +103,9 @@ class PhasedTrainStep(object):
         self.image_splits = len(self._vit_cuts) + 1
         if self.image_splits > 4:
             raise ValueError("image_bwd_splits: at most 4 block ranges")
-        self.fusion_cut = None if fusion_bwd_cut is None else int(fusion_bwd_cut)
         bm = getattr(model, "blip_model", None)
         self.text_prologue = bool(text_prologue) and bm is not None and hasattr(bm, "prepare_text") \
             and isinstance(batch.get("question"), dict)
-        self._wg_keep = None     # the records "fusion_wg" reads live in the main pool: never handed back while the graphs exist
         self._seg_probe = None   # attach_reducers: {segment: parameters whose gradient that segment produced}
         self.buffer_broadcaster, self.coverage_every, self._steps = buffer_broadcaster, int(coverage_every), 0
         self.reducers = dict(reducers or {})
@@ -135,8 +126,7 @@ class PhasedTrainStep(object):
         self.s_img = self.s_main
         self.e_img_fwd = torch.cuda.Event()
         self.s_det = torch.cuda.Stream(device=dev, priority=int(det_priority))
-        self.s_wg = torch.cuda.Stream(device=dev, priority=0) if self.fusion_cut is not None else None
-        self.e_mid, self.e_wg, self.e_text_bwd = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        self.e_text_bwd = torch.cuda.Event()
         self.e_det_fwd, self.e_fused, self.e_det_bwd, self.e_done = (torch.cuda.Event() for _ in range(4))
         self._bn_modules, self._bn_sig = None, None
         self.use_graphs = use_graphs
@@ -204,10 +194,6 @@ class PhasedTrainStep(object):
         (e_det_fwd), not for its loss, which then runs on the detector stream beside the start of the fusion"""
         self._state["det_loss"] = self.det_loss(self._state["dd"])
 
-    def _twin_encoder(self):
-        te = getattr(getattr(self.model, "blip_model", None), "text_encoder", None)
-        return getattr(te, "encoder", None)
-
     def _fusion(self):
         st = self._state
         img_leaf = st["img"].detach().requires_grad_(True)
@@ -219,48 +205,16 @@ class PhasedTrainStep(object):
             prep = dict(st["prep"])
             st["prep_leaves"] = {k: prep[k].detach().requires_grad_(True) for k in ("q_embeds", "a_embeds") if k in prep}
             prep.update(st["prep_leaves"])
-        enc = self._twin_encoder() if self.fusion_cut is not None else None
-        if enc is not None:
-            with enc.autograd_cut(self.fusion_cut):
-                dd = self.model.fuse(dd, img_leaf, obj_leaf, text_prep=prep)
-            pair, enc.cut_pair = enc.cut_pair, None
-        else:
-            dd, pair = self.model.fuse(dd, img_leaf, obj_leaf, text_prep=prep), None
+        dd = self.model.fuse(dd, img_leaf, obj_leaf, text_prep=prep)
         loss = self.fusion_loss(dd)
         if self.defer_wgrad:
             ops.begin_deferred_wgrad()  # dW / db of the linears: parked, then one grouped launch after the chain
         try:
-            loss.backward()             # (with a cut: down to the leaf in front of twin level `fusion_cut`)
-        finally:
-            if pair is None:
-                ops.flush_deferred_wgrad()
-            else:
-                st["wg_items"] = ops.take_deferred_wgrad()
-        st["fusion_cut"], st["fusion_leaves"] = pair, (img_leaf, obj_leaf)
-        if pair is None:
-            st["img_grad"], st["obj_grad"] = img_leaf.grad, obj_leaf.grad
-        st["fusion_loss"] = loss.detach()
-
-    def _fusion_wg(self):
-        """weight gradients of the answer decoder and of the twin levels above the cut (third stream, beside fusion_b)"""
-        items = self._state.pop("wg_items")
-        ops.flush_deferred_items(items)
-        if torch.cuda.is_current_stream_capturing():
-            self._wg_keep = items
-
-    def _fusion_b(self):
-        """the rest of the fusion backward: twin levels below the cut, embeddings, the leaves' gradients, their flush"""
-        st = self._state
-        img_leaf, obj_leaf = st["fusion_leaves"]
-        if self.defer_wgrad:
-            ops.begin_deferred_wgrad()
-        try:
-            self._twin_encoder().continue_backward(st["fusion_cut"])
+            loss.backward()
         finally:
             ops.flush_deferred_wgrad()
         st["img_grad"], st["obj_grad"] = img_leaf.grad, obj_leaf.grad
-        if not torch.cuda.is_current_stream_capturing():
-            st["fusion_cut"] = {}   # (eager: the cut activations die with the step; not None = "this step was split")
+        st["fusion_loss"] = loss.detach()
 
     def _image_bwd(self, seg=0):
         """block range `seg` of the image encoder's backward (0 = the last blocks; one range without splits)"""
@@ -312,18 +266,15 @@ class PhasedTrainStep(object):
     # strictly with the main stream's phases, so they share its pool
     _ORDER = (("text_prep", "det", "det"), ("det_fwd", "det", "det"), ("det_loss", "det", "det"), ("geometry", "det", "det"),
               ("image_fwd", "img", "main"),
-              ("fusion", "main", "main"), ("fusion_wg", "wg", "wg"), ("fusion_b", "main", "main"),
-              ("text_prep_bwd", "det", "det"), ("det_bwd", "det", "det"), ("image_bwd", "img", "main"), ("image_bwd_1", "img", "main"),
+              ("fusion", "main", "main"), ("text_prep_bwd", "det", "det"), ("det_bwd", "det", "det"), ("image_bwd", "img", "main"), ("image_bwd_1", "img", "main"),
               ("image_bwd_2", "img", "main"), ("image_bwd_3", "img", "main"), ("finish", "main", "main"))
 
     def _stream(self, which):
-        return {"main": self.s_main, "det": self.s_det, "img": self.s_img, "wg": self.s_wg}[which]
+        return {"main": self.s_main, "det": self.s_det, "img": self.s_img}[which]
 
     def _skipped(self, name):
         if name.startswith("image_bwd_"):
             return int(name.rsplit("_", 1)[1]) >= self.image_splits
-        if name in ("fusion_wg", "fusion_b"):   # only when this step's fusion forward really made the cut
-            return self._state.get("fusion_cut") is None
         if name in ("text_prep", "text_prep_bwd"):
             return not self.text_prologue
         return name == "geometry" and not self.prefetch
@@ -412,16 +363,6 @@ class PhasedTrainStep(object):
             sm.wait_event(self.e_img_fwd)
             sm.wait_event(self.e_det_fwd)
             self._run("fusion", eager)
-            if not self._skipped("fusion_b"):
-                # the parked weight gradients of the decoder and of the upper twin levels on the third stream, beside
-                # the rest of the chain; the main stream takes them back before it hands the phase over
-                self.e_mid.record(sm)
-                self.s_wg.wait_event(self.e_mid)
-                with torch.cuda.stream(self.s_wg):
-                    self._run("fusion_wg", eager)
-                    self.e_wg.record(self.s_wg)
-                self._run("fusion_b", eager)
-                sm.wait_event(self.e_wg)
             self.e_fused.record(sm)
         sd.wait_event(self.e_fused)
         with torch.cuda.stream(sd):
@@ -577,8 +518,7 @@ class PhasedTrainStep(object):
             return self
         self.zero_grad()
         self._state = {}
-        pools = {"main": torch.cuda.graph_pool_handle(), "det": torch.cuda.graph_pool_handle(),
-                 "wg": torch.cuda.graph_pool_handle()}
+        pools = {"main": torch.cuda.graph_pool_handle(), "det": torch.cuda.graph_pool_handle()}
         # every phase graph SINGLE-STREAM (no fusion_ops.fork inside: the decoder's hoisted K/V projection stays on the
         # chain's stream): this runtime enqueues a graph with an internal fork node by node -- the fusion graph's launch held
         # the host for 35-38 ms and the phase ran 14.2 ms; without the fork 2.2 ms of host time and 12.7-13.4 ms (round 4,

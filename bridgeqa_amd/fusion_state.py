@@ -85,8 +85,20 @@ def set_compute_dtype(dtype):
         # (optim.FusedAdamW writes most shadows in its own kernel and lists them in `shadow_ids`: they are never re-cast
         # here -- without this a SUBSET step re-cast the other subsets' 399 M weights, 2.3 ms)
         _OPT_HOOK[0] = register_optimizer_step_post_hook(
-            lambda opt, args, kwargs: refresh_shadows(skip=getattr(opt, "shadow_ids", None)))
+            lambda opt, args, kwargs: refresh_shadows(skip=getattr(opt, "shadow_ids", None), only=_opt_param_ids(opt)))
     return prev
+
+
+def _opt_param_ids(opt):
+    """ids of the parameters `opt` steps (cached on it): the post-step hook refreshes THEIR shadows only -- a second model
+    alive in the process (tests; an EMA copy) must not have its shadows re-cast, least of all inside another model's
+    graph capture"""
+    ids = getattr(opt, "_bq_param_ids", None)
+    n = sum(len(g["params"]) for g in opt.param_groups)
+    if ids is None or ids[0] != n:
+        ids = (n, frozenset(id(p) for g in opt.param_groups for p in g["params"]))
+        opt._bq_param_ids = ids
+    return ids[1]
 
 
 def compute_dtype():
@@ -174,19 +186,21 @@ def shadows_written(params):
             _FRESH.add(id(p))
 
 
-def refresh_shadows(only_with_grad=True, skip=None):
+def refresh_shadows(only_with_grad=True, skip=None, only=None):
     """Bring every registered bf16 shadow (and, through them, the concatenated QKV / KV operands, whose row blocks ARE
     the per-weight shadows) up to date with ONE multi-tensor cast.  Runs as a global optimizer post-step hook
     (set_compute_dtype); call it yourself after any other in-place parameter update.  It does NOT consult version
     counters: torch's fused multi-tensor optimizers update parameters without bumping them (the lazy check in
     _shadow() only catches ordinary in-place ops and load_state_dict).  only_with_grad: skip parameters that have no
     gradient, i.e. that the optimizer did not touch.  skip: ids of parameters whose shadows the stepping optimizer writes
-    itself."""
+    itself.  only: ids of the parameters to consider (the stepping optimizer's own)."""
     dst, src = [], []
     for key, (ref, ver, c) in list(_SHADOW.items()):
         t = ref()
         if t is None:
             del _SHADOW[key]
+            continue
+        if only is not None and key not in only:
             continue
         if skip is not None and key in skip and ver == t._version:
             continue
@@ -199,7 +213,10 @@ def refresh_shadows(only_with_grad=True, skip=None):
         dst.append(c)
         src.append(t.detach())
         _SHADOW[key] = (ref, t._version, c)
-    _FRESH.clear()
+    if only is None:
+        _FRESH.clear()
+    else:
+        _FRESH.difference_update(only)
     if dst:
         with torch.no_grad():
             torch._foreach_copy_(dst, src)

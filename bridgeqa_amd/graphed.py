@@ -22,7 +22,9 @@ graphs behind the two calls that carry the work:
 
 What the captured path assumes (checked where it can be): fixed input shapes (a change re-captures), one backward per
 forward, gradients OVERWRITTEN per step (no accumulation over several backward calls; the reference zeroes them every
-iteration), outputs valid until the next forward (they are rewritten in place).  Eval mode and `torch.no_grad()` take the
+iteration), outputs valid until the next forward (they are rewritten in place); at the FIRST graphed forward no autograd
+graph of an earlier eager forward may still be alive (drop the previous outputs / loss: its AccumulateGrad nodes were born on
+the caller's stream and this runtime's hipStreamEndCapture faults on them).  Eval mode and `torch.no_grad()` take the
 ordinary eager path.  Without the next batch nothing can be prefetched: the sampling / grouping indices are computed
 inside the detector forward (PhasedTrainStep hides them under the fusion of the previous step; `prefetch()` below offers
 the same to a loop that can name its next point clouds).
@@ -177,6 +179,11 @@ class GraphedRunner(object):
 
     def _det_fwd(self, st):
         dd = self._inputs()
+        # the token-only head of the fusion (question / answer embeddings, BLIP_VQA3D.prepare_text) rides on the detector
+        # stream, beside the image encoder; its backward opens the detector's backward phase (as pipeline.PhasedTrainStep's
+        # text_prep / text_prep_bwd phases)
+        bm = self.model.blip_model
+        st["prep"] = bm.prepare_text(dd["question"], dd.get("answer"), self.dev) if hasattr(bm, "prepare_text") else None
         if self._geo_next is not None:
             dd["geometry"] = self._geo_next
         st["dd"] = self.model.detect_objects(dd)
@@ -185,7 +192,12 @@ class GraphedRunner(object):
         st["img_leaf"] = st["img"].detach().requires_grad_(True)
         st["obj_leaf"] = st["dd"]["object_feat"].detach().requires_grad_(True)
         dd = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in st["dd"].items()}
-        st["fd"] = self.model.fuse(dd, st["img_leaf"], st["obj_leaf"])
+        prep = None
+        if st.get("prep") is not None:
+            prep = dict(st["prep"])
+            st["prep_leaves"] = {k: prep[k].detach().requires_grad_(True) for k in ("q_embeds", "a_embeds") if k in prep}
+            prep.update(st["prep_leaves"])
+        st["fd"] = self.model.fuse(dd, st["img_leaf"], st["obj_leaf"], text_prep=prep)
 
     def _diff_outputs(self, st):
         """(key, tensor, phase) of every output a loss can differentiate: the detector's own outputs and what the fusion
@@ -209,6 +221,10 @@ class GraphedRunner(object):
         st["img_grad"], st["obj_grad"] = st["img_leaf"].grad, st["obj_leaf"].grad
 
     def _det_bwd(self, st):
+        if st.get("prep") is not None:
+            roots = [(st["prep"][k], leaf.grad) for k, leaf in st["prep_leaves"].items() if leaf.grad is not None]
+            if roots:
+                torch.autograd.backward([t for t, _ in roots], [g for _, g in roots])
         outs = [(t, g) for (k, t, ph), g in zip(self.diff, self.static_grads) if ph == "det"]
         torch.autograd.backward([t for t, _ in outs] + [st["dd"]["object_feat"]], [g for _, g in outs] + [st["obj_grad"]])
 
@@ -308,6 +324,11 @@ class GraphedRunner(object):
 
     def _capture(self, data_dict):
         m = self.model
+        # an earlier eager forward can survive as a reference CYCLE (fusion_ops.HoistedKV <-> its autograd node): its
+        # AccumulateGrad nodes -- born on the caller's stream -- would be reused by the capture and hipStreamEndCapture faults
+        # on them; collect before capturing
+        import gc
+        gc.collect()
         self.dev = dev = data_dict["point_clouds"].device
         self.static_in = {k: ({kk: (t.clone() if torch.is_tensor(t) else t) for kk, t in v.items()} if isinstance(v, dict)
                               else v.clone()) for k, v in ((k, data_dict[k]) for k in _INPUT_KEYS)}

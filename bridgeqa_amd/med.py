@@ -385,6 +385,11 @@ class BertEncoder(nn.Module):
                     all_cross_attentions = all_cross_attentions + (layer_outputs[2],)
         if output_hidden_states:
             all_hidden_states = all_hidden_states + (hidden_states,)
+        if hoisted is not None:
+            # (HoistedKV -> its outputs -> their autograd node -> ctx.hold -> HoistedKV is a reference cycle through C++
+            # autograd nodes that Python's collector cannot see: the whole autograd graph of a forward -- and the
+            # AccumulateGrad nodes of every parameter under it -- stayed alive after its outputs were dropped)
+            hoisted.outs = None
         return ModelOutput(last_hidden_state=hidden_states, past_key_values=next_decoder_cache,
                            hidden_states=all_hidden_states, attentions=all_self_attentions,
                            cross_attentions=all_cross_attentions)

@@ -473,6 +473,9 @@ class PhasedTrainStep(object):
         optimizer state must exist before the capture); unless keep_warmup_updates, parameters, buffers (BatchNorm
         running statistics), moments and the step count are put back afterwards, so training starts from the state
         the caller handed over."""
+        import gc
+        gc.collect()   # (dead autograd graphs of earlier eager forwards -- reference cycles -- must not lend their
+        #                AccumulateGrad nodes, born on another stream, to the capture: hipStreamEndCapture faults on them)
         cur = torch.cuda.current_stream(self.dev)
         for s_ in (self.s_main, self.s_det, self.s_img):
             s_.wait_stream(cur)

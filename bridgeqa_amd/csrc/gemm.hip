@@ -1295,12 +1295,9 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const WgradRowsArgs ar)
 
   const int row16 = lane & 15, q4 = lane >> 4;
   const int kc_base = 0;  // (K-contiguous form unused here)
-  int xc_base[4];
-  {
-    const int q = (lane & 15) >> 2, p = lane & 3, g = (q >> 1) | ((q4 & 1) << 1);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) xc_base[s] = (8 * q4 + q) * 128 + ((s ^ g) << 5) + 8 * p;
-  }
+  // (closed-form fragment address: a table indexed by the wave row / column would be promoted to LDS, gemm_common.h)
+  const int xc_q = (lane & 15) >> 2;
+  const int xcg = (xc_q >> 1) | ((q4 & 1) << 1), xc0 = (8 * q4 + xc_q) * 128 + 8 * (lane & 3);
 
   f32x4 acc[TI][TJ][2][2];
 #pragma unroll
@@ -1325,14 +1322,14 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const WgradRowsArgs ar)
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fb[b][kk] = read_frag<true>(buf + (TI + v) * 8192, wc * 2 + b, kk, kc_base, xc_base);
+        for (int kk = 0; kk < 2; ++kk) fb[b][kk] = read_frag_cf<true>(buf + (TI + v) * 8192, wc * 2 + b, kk, kc_base, xc0, xcg);
 #pragma unroll
       for (int u = 0; u < TI; ++u) {
         bf16x8 fa[2][2];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag<true>(buf + u * 8192, wr * 2 + a, kk, kc_base, xc_base);
+          for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag_cf<true>(buf + u * 8192, wr * 2 + a, kk, kc_base, xc0, xcg);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll

@@ -70,12 +70,10 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
   // ---- lane-dependent constants ---------------------------------------------------------------------------------------
   const int row16 = lane & 15, q4 = lane >> 4, cp = lane & 7, lr = lane >> 3;
   const int kc_base = row16 * 128 + ((q4 ^ (row16 & 7)) << 4);
-  int xc_base[4];
-  {
-    const int q = (lane & 15) >> 2, p = lane & 3, g = (q >> 1) | ((q4 & 1) << 1);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) xc_base[s] = (8 * q4 + q) * 128 + ((s ^ g) << 5) + 8 * p;
-  }
+  // contraction-major fragment address in closed form (read_frag_cf): a per-lane int[4] table indexed by the wave column
+  // is an alloca that hipcc promotes to LDS (+ 4 KB per workgroup, an LDS round trip per fragment address -- DESIGN.md §5.7)
+  const int xc_q = (lane & 15) >> 2;
+  const int xcg = (xc_q >> 1) | ((q4 & 1) << 1), xc0 = (8 * q4 + xc_q) * 128 + 8 * (lane & 3);
   constexpr int PA0 = 0, PA1 = 16384, QB = 32768;   // QB + buf * 16384 + half * 8192
   const int uA0 = PA0 + wr * 8192, uA1 = PA1 + wr * 8192;
   const int bsub = wc * 2;
@@ -241,11 +239,11 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag<P_XC>(smem + uA0, a, kk, kc_base, xc_base);
+        for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag_cf<P_XC>(smem + uA0, a, kk, kc_base, xc0, xcg);
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fb0[b][kk] = read_frag<Q_XC>(qb, bsub + b, kk, kc_base, xc_base);
+        for (int kk = 0; kk < 2; ++kk) fb0[b][kk] = read_frag_cf<Q_XC>(qb, bsub + b, kk, kc_base, xc0, xcg);
       dma_q(1, gk + 1);
       BQ_MID_COMPUTE_BEGIN();
       if (vA0 && vB0) { BQ_MID_MFMA(0, fb0, 0) }
@@ -256,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fb1[b][kk] = read_frag<Q_XC>(qb + 8192, bsub + b, kk, kc_base, xc_base);
+        for (int kk = 0; kk < 2; ++kk) fb1[b][kk] = read_frag_cf<Q_XC>(qb + 8192, bsub + b, kk, kc_base, xc0, xcg);
       dma_p(0);
       BQ_MID_COMPUTE_BEGIN();
       if (vA0 && vB1) { BQ_MID_MFMA(0, fb1, 2) }
@@ -268,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag<P_XC>(smem + uA1, a, kk, kc_base, xc_base);
+        for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag_cf<P_XC>(smem + uA1, a, kk, kc_base, xc0, xcg);
       if (!last) dma_q(0, gk + 2);
       BQ_MID_COMPUTE_BEGIN();
       if (vA1 && vB1) { BQ_MID_MFMA(4, fb1, 2) }

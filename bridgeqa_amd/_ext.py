@@ -600,6 +600,38 @@ def adamw_multi(table, chunks, step, beta1, beta2, eps, grad_clip_value=0.0):
                                    float(eps), float(grad_clip_value or 0.0), _stream()), "adamw")
 
 
+# ---- multi-tensor bf16 transpose (csrc/transpose.hip): the K-contiguous copies of the text side's weights -------
+_lib.bq_transpose_tensor_bytes.restype = ctypes.c_int
+_lib.bq_transpose_multi_bf16.argtypes = [_vp, _vp, _i, _i, _vp]
+_lib.bq_transpose_multi_bf16.restype = ctypes.c_int
+TRANSPOSE_TENSOR_BYTES = _lib.bq_transpose_tensor_bytes()
+
+
+def transpose_table(pairs, device):
+    """pairs: [(src (N, K) bf16 with a contiguous last dim, dst (K, N) bf16 contiguous)], N and K multiples of 64 ->
+    (table, chunks) device tensors for transpose_multi"""
+    import struct
+    assert TRANSPOSE_TENSOR_BYTES == 32
+    rec, chunks = [], []
+    for i, (src, dst) in enumerate(pairs):
+        N, K = src.shape
+        if (src.dtype != torch.bfloat16 or dst.dtype != torch.bfloat16 or src.stride(1) != 1 or not dst.is_contiguous()
+                or tuple(dst.shape) != (K, N) or N % 64 or K % 64 or src.stride(0) % 8 or src.data_ptr() % 16
+                or dst.data_ptr() % 16):
+            raise RuntimeError("transpose_table: unsupported pair %s -> %s" % (tuple(src.shape), tuple(dst.shape)))
+        rec.append(struct.pack("<QQiiii", src.data_ptr(), dst.data_ptr(), N, K, src.stride(0), K // 64))
+        chunks.append(torch.stack([torch.full((N // 64 * (K // 64),), i, dtype=torch.int32),
+                                   torch.arange(N // 64 * (K // 64), dtype=torch.int32)], dim=1))
+    table = torch.frombuffer(bytearray(b"".join(rec)), dtype=torch.uint8).to(device)
+    return table, torch.cat(chunks, dim=0).contiguous().to(device)
+
+
+def transpose_multi(table, chunks, max_wgs=0):
+    """max_wgs > 0: at most that many workgroups walk the tiles (beside a latency-bound chain); 0: one per tile"""
+    with torch.cuda.device(table.device):
+        _check(_lib.bq_transpose_multi_bf16(_p(table), _p(chunks), chunks.shape[0], int(max_wgs), _stream()), "transpose_multi")
+
+
 # ---- training-mode BatchNorm + ReLU (+ max over nsample) on point-major bf16 rows (csrc/bn.hip) -------
 _lib.bq_bn_chunks.argtypes = [_l, _i, _i]
 _lib.bq_bn_chunks.restype = ctypes.c_int
@@ -930,17 +962,20 @@ def gemm_fwd(x, w, bias=None, gelu=False, tile=None, out=None, background=False)
     return (y, act) if gelu else y
 
 
-def gemm_dx(dy, w, pre_act=None, colsum=None, tile=None, add=None, background=False):
+def gemm_dx(dy, w, pre_act=None, colsum=None, tile=None, add=None, background=False, wt=None):
     """dx = dy @ w (dy (M,N), w (N,K) bf16) [* gelu'(pre_act) (M,K)] [+ add (M,K) bf16]; colsum (K,) fp32 += column
-    sums of dx"""
+    sums of dx.  wt: w's transpose (K,N), contiguous -- the launch then reads it K-contiguous like a forward (the small-M
+    launches of the text side: fusion_state.transposed_shadow) instead of walking w's rows contraction-major"""
     _mat(dy, "dy"), _mat(w, "w")
     M, K = dy.shape[0], w.shape[1]
     if pre_act is not None and add is not None:
         raise RuntimeError("gemm_dx: pre_act and add are exclusive")
+    if wt is not None and (colsum is not None or tuple(wt.shape) != (K, w.shape[0])):
+        wt = None
     with torch.cuda.device(dy.device):
         dx = torch.empty(M, K, dtype=torch.bfloat16, device=dy.device)
-    gemm_grouped([dict(P=w, Q=dy, out=dx, aux=pre_act if add is None else add, colsum=colsum)],
-                 GEMM_P_XC | (GEMM_BACKGROUND if background else 0),
+    gemm_grouped([dict(P=w if wt is None else wt, Q=dy, out=dx, aux=pre_act if add is None else add, colsum=colsum)],
+                 (GEMM_P_XC if wt is None else 0) | (GEMM_BACKGROUND if background else 0),
                  EPI_DGELU if pre_act is not None else (EPI_ADD if add is not None else EPI_NONE), tile)
     return dx
 

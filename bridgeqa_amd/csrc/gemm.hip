@@ -1034,7 +1034,11 @@ template <bool P_XC, bool Q_XC, int EPI, bool OUT_F32>
 static int launch_variant(const GemmArgs &ga, int tile, hipStream_t st, bool long_k = false) {
   constexpr bool KT2_OK = !OUT_F32 && !Q_XC && EPI != EPI_BIAS_CE;
   if (tile == 256) {
-    hipLaunchKernelGGL((gemm256_kernel<P_XC, Q_XC, EPI, OUT_F32>), dim3(ga.total_tiles), dim3(512), 0, st, ga);
+    // (the K-contiguous dX forms -- a pre-transposed weight, csrc/transpose.hip -- exist for the small tiles and 256 x 128)
+    if constexpr (P_XC || (EPI != EPI_DGELU && EPI != EPI_ADD))
+      hipLaunchKernelGGL((gemm256_kernel<P_XC, Q_XC, EPI, OUT_F32>), dim3(ga.total_tiles), dim3(512), 0, st, ga);
+    else
+      return -1;
   } else if (tile == 64) {
     if constexpr (KT2_OK) {
       if (long_k) {
@@ -1079,6 +1083,8 @@ static int launch_gemm(const GemmArgs &ga, int flags, int epi, int tile, hipStre
     if (epi == EPI_NONE) return launch_variant<false, false, EPI_NONE, false>(ga, tile, st, long_k);
     if (epi == EPI_BIAS) return launch_variant<false, false, EPI_BIAS, false>(ga, tile, st, long_k);
     if (epi == EPI_BIAS_GELU) return launch_variant<false, false, EPI_BIAS_GELU, false>(ga, tile, st, long_k);
+    if (epi == EPI_DGELU) return launch_variant<false, false, EPI_DGELU, false>(ga, tile, st, long_k);
+    if (epi == EPI_ADD) return launch_variant<false, false, EPI_ADD, false>(ga, tile, st, long_k);
     if (epi == EPI_BIAS_CE && tile == 256) {
       hipLaunchKernelGGL((gemm256_kernel<false, false, EPI_BIAS_CE, false>), dim3(ga.total_tiles), dim3(512), 0, st, ga);
       return 0;

@@ -480,6 +480,8 @@ int launch_gemm_mid(const GemmArgs &ga, bool p_xc, bool q_xc, bool out_f32, int 
     if (epi == EPI_NONE) BQ_MID_LAUNCH(false, EPI_NONE);
     if (epi == EPI_BIAS) BQ_MID_LAUNCH(false, EPI_BIAS);
     if (epi == EPI_BIAS_GELU) BQ_MID_LAUNCH(false, EPI_BIAS_GELU);
+    if (epi == EPI_DGELU) BQ_MID_LAUNCH(false, EPI_DGELU);
+    if (epi == EPI_ADD) BQ_MID_LAUNCH(false, EPI_ADD);
   } else {
     if (epi == EPI_NONE) BQ_MID_LAUNCH(true, EPI_NONE);
     if (epi == EPI_DGELU) BQ_MID_LAUNCH(true, EPI_DGELU);

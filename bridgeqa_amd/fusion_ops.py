@@ -75,6 +75,26 @@ def _take_tap(holder, like_rows):
     return g2 if g2.is_contiguous() else g2.contiguous()
 
 
+def _dx_wt(params, wb, rows):
+    """the (K, N) transposed copy of the weight operand wb for a dX launch over `rows` gradient rows, or None: the text
+    side's small launches run on the forward's K-contiguous operand form (fusion_state.transposed_shadow); the large ones
+    (image / object tokens: 256 x 128 tiles) read wb contraction-major at the same speed and need no second copy"""
+    if rows >= 1024 or not wb.is_cuda:
+        return None
+    return transposed_shadow(tuple(params), wb)
+
+
+def _dx_operands(param_groups, wops, rows):
+    """(P operands, operand flag) of a GROUPED dX launch: every group's transposed copy and the K-contiguous form when all
+    of them are small and have one, else the operands themselves read contraction-major"""
+    from . import _ext
+    if max(rows) < 1024:
+        wts = [_dx_wt(ps, w, max(rows)) for ps, w in zip(param_groups, wops)]
+        if all(t is not None for t in wts):
+            return wts, 0
+    return list(wops), _ext.GEMM_P_XC
+
+
 class _LinearFn(torch.autograd.Function):
     """bf16-operand linear with fp32 master weights: the forward reads the bf16 shadow of W and the fp32 bias itself
     (bias / GELU in the GEMM epilogue), the backward produces dX with the same kernel family and dW / db in fp32
@@ -130,7 +150,7 @@ class _LinearFn(torch.autograd.Function):
             extra = _take_tap(ctx.tap, g2)
             if native:
                 from . import _ext
-                dx = _ext.gemm_dx(g2, wb, add=extra)
+                dx = _ext.gemm_dx(g2, wb, add=extra, wt=_dx_wt((w,), wb, g2.shape[0]))
             else:
                 dx = torch.mm(g2, wb)
                 if extra is not None:
@@ -167,8 +187,9 @@ class _MlpFn(torch.autograd.Function):
         x2, y1, h, w1b, w2b = ctx.saved_tensors
         w1, b1, w2, b2 = ctx.params
         g2 = _rows(g)
-        dy1 = _ext.gemm_dx(g2, w2b, pre_act=y1)
-        dx = _ext.gemm_dx(dy1, w1b, add=_take_tap(ctx.tap, dy1)).view(ctx.x_shape).to(ctx.x_dtype) \
+        M = g2.shape[0]
+        dy1 = _ext.gemm_dx(g2, w2b, pre_act=y1, wt=_dx_wt((w2,), w2b, M))
+        dx = _ext.gemm_dx(dy1, w1b, add=_take_tap(ctx.tap, dy1), wt=_dx_wt((w1,), w1b, M)).view(ctx.x_shape).to(ctx.x_dtype) \
             if ctx.needs_input_grad[0] else None
         if _DEFER[0] is not None:
             _park(g2, h, [w2], [b2] if b2 is not None else None)
@@ -266,7 +287,7 @@ class _MultiLinearFn(torch.autograd.Function):
             extra = _take_tap(ctx.tap, g2)
             if native:
                 from . import _ext
-                dx = _ext.gemm_dx(g2, wc, add=extra)
+                dx = _ext.gemm_dx(g2, wc, add=extra, wt=_dx_wt(ctx.params[0], wc, g2.shape[0]))
             else:
                 dx = torch.mm(g2, wc)
                 if extra is not None:
@@ -672,11 +693,12 @@ class _GroupedLinearFn(torch.autograd.Function):
         if need:
             sel = range(G) if stacked else need
             extra = _take_tap(ctx.tap, g2) if stacked else None
+            pops, pflag = _dx_operands([ws[g * k:(g + 1) * k] for g in range(G)], wops, [gg[g].shape[0] for g in sel])
             if extra is not None:
-                _ext.gemm_grouped([dict(P=wops[g], Q=gg[g], out=dxg[g], aux=extra[g * M:(g + 1) * M]) for g in sel],
-                                  _ext.GEMM_P_XC, _ext.EPI_ADD)
+                _ext.gemm_grouped([dict(P=pops[g], Q=gg[g], out=dxg[g], aux=extra[g * M:(g + 1) * M]) for g in sel],
+                                  pflag, _ext.EPI_ADD)
             else:
-                _ext.gemm_grouped([dict(P=wops[g], Q=gg[g], out=dxg[g]) for g in sel], _ext.GEMM_P_XC, _ext.EPI_NONE)
+                _ext.gemm_grouped([dict(P=pops[g], Q=gg[g], out=dxg[g]) for g in sel], pflag, _ext.EPI_NONE)
         if stacked:
             dxs = (dx.view(shapes[0]).to(dtypes[0]) if need else None,)
         else:
@@ -721,18 +743,19 @@ class _GroupedMlpFn(torch.autograd.Function):
         M = g2.shape[0] // G
         rows = lambda t, i: t[i * M:(i + 1) * M]
         dy1 = torch.empty_like(y1)
-        _ext.gemm_grouped([dict(P=w2o[i], Q=rows(g2, i), out=rows(dy1, i), aux=rows(y1, i)) for i in range(G)],
-                          _ext.GEMM_P_XC, _ext.EPI_DGELU)
+        p2, f2 = _dx_operands([(w,) for w in w2], w2o, [M] * G)
+        _ext.gemm_grouped([dict(P=p2[i], Q=rows(g2, i), out=rows(dy1, i), aux=rows(y1, i)) for i in range(G)],
+                          f2, _ext.EPI_DGELU)
         dx = None
         if ctx.needs_input_grad[2]:
             dx = torch.empty_like(x2)
             extra = _take_tap(ctx.tap, dy1)
+            p1, f1 = _dx_operands([(w,) for w in w1], w1o, [M] * G)
             if extra is not None:
-                _ext.gemm_grouped([dict(P=w1o[i], Q=rows(dy1, i), out=rows(dx, i), aux=rows(extra, i)) for i in range(G)],
-                                  _ext.GEMM_P_XC, _ext.EPI_ADD)
+                _ext.gemm_grouped([dict(P=p1[i], Q=rows(dy1, i), out=rows(dx, i), aux=rows(extra, i)) for i in range(G)],
+                                  f1, _ext.EPI_ADD)
             else:
-                _ext.gemm_grouped([dict(P=w1o[i], Q=rows(dy1, i), out=rows(dx, i)) for i in range(G)], _ext.GEMM_P_XC,
-                                  _ext.EPI_NONE)
+                _ext.gemm_grouped([dict(P=p1[i], Q=rows(dy1, i), out=rows(dx, i)) for i in range(G)], f1, _ext.EPI_NONE)
             dx = dx.view(ctx.x_shape).to(ctx.x_dtype)
         gw2 = _grouped_wgrad([rows(g2, i) for i in range(G)], [rows(h, i) for i in range(G)], w2, b2, 1)
         gw1 = _grouped_wgrad([rows(dy1, i) for i in range(G)], [rows(x2, i) for i in range(G)], w1, b1, 1)
@@ -1068,6 +1091,7 @@ class HoistedKV(object):
         self.G = None          # (n, B, L1, 2 * 768) gradient of the hoisted projections, allocated by the first writer
         self.written = set()
         self.wc, self.bc = _cat_shadow(ws, bs)
+        self.ws = tuple(ws)
         self.nb = self.wc.shape[0] // self.n
         self.x = x
         self.want_dx = bool(x.requires_grad)
@@ -1111,7 +1135,13 @@ class HoistedKV(object):
             if pend is not None:
                 self._launch_dx(*pend)
         else:
-            self.dx = _dx2(self.G[i].view(-1, self.nb), self.block(i)[0], add=self.dx)
+            self.dx = _dx2(self.G[i].view(-1, self.nb), self.block(i)[0], add=self.dx, wt=self.block_t(i))
+
+    def block_t(self, i):
+        """columns of the transposed concatenated weight that belong to layer slot i (the K-contiguous operand of its dX
+        launch when the fixed tokens are few: the decoder's 320 question states), or None"""
+        wt = _dx_wt(self.ws, self.wc, self.G[i].numel() // self.nb)
+        return None if wt is None else wt[:, i * self.nb:(i + 1) * self.nb]
 
     def _launch_dx(self, i, ev):
         self.side.wait_event(ev)
@@ -1144,11 +1174,11 @@ def _fwd2(x2, w, b, out=None, background=False):
     return y
 
 
-def _dx2(g2, w, add=None, background=False):
-    """g2 @ w (+ add)"""
+def _dx2(g2, w, add=None, background=False, wt=None):
+    """g2 @ w (+ add); wt: w's transpose (see _ext.gemm_dx)"""
     if _native_dx_ok(g2, w.shape[0], w.shape[1]):
         from . import _ext
-        return _ext.gemm_dx(_rows(g2), w, add=add, background=background)
+        return _ext.gemm_dx(_rows(g2), w, add=add, background=background, wt=wt)
     dx = torch.mm(g2, w)
     return dx if add is None else dx + add
 

@@ -85,7 +85,8 @@ def set_compute_dtype(dtype):
         # (optim.FusedAdamW writes most shadows in its own kernel and lists them in `shadow_ids`: they are never re-cast
         # here -- without this a SUBSET step re-cast the other subsets' 399 M weights, 2.3 ms)
         _OPT_HOOK[0] = register_optimizer_step_post_hook(
-            lambda opt, args, kwargs: refresh_shadows(skip=getattr(opt, "shadow_ids", None), only=_opt_param_ids(opt)))
+            lambda opt, args, kwargs: (refresh_shadows(skip=getattr(opt, "shadow_ids", None), only=_opt_param_ids(opt)),
+                                       mark_transposed_stale()))
     return prev
 
 
@@ -222,6 +223,78 @@ def refresh_shadows(only_with_grad=True, skip=None, only=None):
             torch._foreach_copy_(dst, src)
     return len(dst)
 
+
+
+# ---- transposed shadows: the K-contiguous operand of the small-M input-gradient GEMMs ---------------------------------
+# dX = dY W contracts over the ROWS of the (N, K) weight operand.  Read contraction-major, the text side's small launches
+# (80-640 rows: latency chains) take up to twice as long as their forward twins (csrc/transpose.hip header); a second
+# bf16 copy W^T (K, N) lets them run on the forward's operand form.  Entries are keyed by the parameters a fused operand
+# is made of; all of them are refreshed by ONE launch -- lazily at the first use after an optimizer step, or explicitly
+# (refresh_transposed) by a caller that wants the launch somewhere else (pipeline.PhasedTrainStep: the text_prep phase,
+# beside the image encoder; under graph replay that captured launch is the refresh).
+TRANSPOSED_DX = [True]
+_TSHADOW = {}
+_T_STATE = {"stale": True, "tables": {}, "dirty": True, "keep": []}
+
+
+def mark_transposed_stale():
+    _T_STATE["stale"] = True
+
+
+def transposed_shadow(params, wb):
+    """(K, N) bf16 contiguous transpose of the (N, K) operand `wb` built from the fp32 parameters `params` (a tuple: the
+    k fused linears whose shadows are wb's row blocks), kept current across optimizer steps; None when unavailable (odd
+    shapes, or a first use inside a stream capture -- the caller then reads wb contraction-major)."""
+    if not TRANSPOSED_DX[0] or wb.dim() != 2 or wb.shape[0] % 64 or wb.shape[1] % 64 or wb.stride(1) != 1 \
+            or wb.stride(0) % 8 or wb.dtype != torch.bfloat16:
+        return None
+    key = tuple(id(p) for p in params)
+    ent = _TSHADOW.get(key)
+    capturing = wb.is_cuda and torch.cuda.is_current_stream_capturing()
+    if ent is not None and all(r() is p for r, p in zip(ent[0], params)) and ent[1].data_ptr() == wb.data_ptr() \
+            and ent[1].shape == wb.shape:
+        if _T_STATE["stale"]:
+            # (inside a stream capture the refresh launch becomes part of the graph -- as it must: the replayed step needs
+            # it too; a registry that changed since its device table was built cannot be rebuilt there)
+            if capturing and _T_STATE["dirty"]:
+                return None
+            refresh_transposed()
+        return ent[2]
+    if capturing:
+        return None
+    import weakref
+    with torch.no_grad():
+        wt = wb.t().contiguous()
+    _TSHADOW[key] = ([weakref.ref(p) for p in params], wb.detach(), wt)
+    _T_STATE["dirty"] = True
+    return wt
+
+
+def refresh_transposed(device=None, max_wgs=0):
+    """re-transpose every registered operand (one launch per device); called with the shadows already current on the
+    calling stream (after the optimizer step / refresh_shadows).  max_wgs: see _ext.transpose_multi"""
+    from . import _ext
+    capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+    dead = [] if capturing else [k for k, e in _TSHADOW.items() if any(r() is None for r in e[0])]
+    if capturing and _T_STATE["dirty"]:
+        raise RuntimeError("refresh_transposed: operands were registered since the last refresh; run one eager step (or "
+                           "call refresh_transposed()) before capturing")
+    if _T_STATE["dirty"] or dead:
+        for key in dead:
+            del _TSHADOW[key]
+        by_dev = {}
+        for ent in _TSHADOW.values():
+            by_dev.setdefault(ent[1].device, []).append((ent[1], ent[2]))
+        # (the device tables a captured graph may still launch with stay alive; the operands they point at live as long as
+        # their parameters do, through the registry)
+        _T_STATE["keep"].append(_T_STATE["tables"])
+        _T_STATE["tables"] = {dev: _ext.transpose_table(pairs, dev) for dev, pairs in by_dev.items()}
+        _T_STATE["dirty"] = False
+    for dev, (table, chunks) in _T_STATE["tables"].items():
+        if device is None or dev == device:
+            with torch.cuda.device(dev):
+                _ext.transpose_multi(table, chunks, max_wgs)
+    _T_STATE["stale"] = False
 
 
 __all__ = [n for n in list(globals()) if not n.startswith("__")]

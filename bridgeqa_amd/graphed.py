@@ -176,6 +176,11 @@ class GraphedRunner(object):
     def _image_fwd(self, st):
         ops.new_step(self.dev)
         st["img"] = self.model.encode_image(self._inputs())
+        # the K-contiguous weight copies of this step's text-side input-gradient GEMMs (fusion_state.transposed_shadow),
+        # re-transposed from what the caller's optimizer.step() left: here the main phase stream idles until the detector
+        # forward (the longer of the two in this loop) hands over
+        if ops.TRANSPOSED_DX[0] and not (torch.cuda.is_current_stream_capturing() and ops._T_STATE["dirty"]):
+            ops.refresh_transposed(self.dev)
 
     def _det_fwd(self, st):
         dd = self._inputs()
@@ -358,6 +363,8 @@ class GraphedRunner(object):
             for k, v in m.state_dict().items():
                 if k in saved_buf:
                     v.copy_(saved_buf[k])
+        if ops.TRANSPOSED_DX[0]:
+            ops.refresh_transposed(dev)   # (builds the device table of what the warm-up registered: not possible inside a capture)
         # capture: one graph per phase, a pool per stream (the two streams' graphs run concurrently)
         pools = self._pools = {"main": torch.cuda.graph_pool_handle(), "det": torch.cuda.graph_pool_handle()}
         self.losses = {}

@@ -48,6 +48,7 @@ from . import fusion_ops as ops
 
 
 _DET_LOSS_LATE = [True]   # the fusion waits for the detector's outputs only (False: also for its loss, as before round 3)
+_T_REFRESH_WGS = [256]    # workgroups of the t_refresh phase's transpose launch (0: one per 64 x 64 tile, ~66 000)
 _SINGLE_STREAM = [True]   # capture every phase graph without fusion_ops.fork (tools/ab_bench.py flips it)
 
 
@@ -126,7 +127,8 @@ class PhasedTrainStep(object):
         self.s_img = self.s_main
         self.e_img_fwd = torch.cuda.Event()
         self.s_det = torch.cuda.Stream(device=dev, priority=int(det_priority))
-        self.e_text_bwd = torch.cuda.Event()
+        self.e_text_bwd, self.e_t_refresh = torch.cuda.Event(), torch.cuda.Event()
+        self.t_refresh = bool(ops.TRANSPOSED_DX[0]) and bm is not None
         self.e_det_fwd, self.e_fused, self.e_det_bwd, self.e_done = (torch.cuda.Event() for _ in range(4))
         self._bn_modules, self._bn_sig = None, None
         self.use_graphs = use_graphs
@@ -176,6 +178,15 @@ class PhasedTrainStep(object):
         bm = self.model.blip_model
         self._state["prep"] = bm.prepare_text(self.batch["question"], self.batch.get("answer"), self.dev)
 
+    def _t_refresh(self):
+        """the K-contiguous copies of the text side's weights that this step's small input-gradient GEMMs read
+        (fusion_state.transposed_shadow): ONE launch re-transposes all of them from the operands the previous step's
+        optimizer left.  Detector stream, after the detection loss: it runs beside the fusion's FORWARD chain, the
+        fusion's backward waits for it (at the head of the step it cost the image encoder 0.3 ms; left to the first use
+        it would sit on the critical chain)."""
+        if not (torch.cuda.is_current_stream_capturing() and ops._T_STATE["dirty"]):
+            ops.refresh_transposed(self.dev, max_wgs=_T_REFRESH_WGS[0])
+
     def _text_prep_bwd(self):
         """its backward (LayerNorm + embedding tables; the decoder's table is tied to the LM head: this adds to the gradient
         the fusion phase left there): detector stream, after the fusion, beside the image backward"""
@@ -206,7 +217,15 @@ class PhasedTrainStep(object):
             st["prep_leaves"] = {k: prep[k].detach().requires_grad_(True) for k in ("q_embeds", "a_embeds") if k in prep}
             prep.update(st["prep_leaves"])
         dd = self.model.fuse(dd, img_leaf, obj_leaf, text_prep=prep)
-        loss = self.fusion_loss(dd)
+        st["fusion_loss_t"] = self.fusion_loss(dd)
+        st["fusion_leaves"] = (img_leaf, obj_leaf)
+
+    def _fusion_bwd(self):
+        """the fusion's backward, a phase (graph) of its own behind the forward on the same stream: a captured graph can
+        only wait for another stream at its head, and this one waits for t_refresh"""
+        st = self._state
+        loss = st.pop("fusion_loss_t")
+        img_leaf, obj_leaf = st.pop("fusion_leaves")
         if self.defer_wgrad:
             ops.begin_deferred_wgrad()  # dW / db of the linears: parked, then one grouped launch after the chain
         try:
@@ -264,9 +283,9 @@ class PhasedTrainStep(object):
 
     # (phase, stream, memory pool): the image phases may sit on their own (CU-masked) stream but still alternate
     # strictly with the main stream's phases, so they share its pool
-    _ORDER = (("text_prep", "det", "det"), ("det_fwd", "det", "det"), ("det_loss", "det", "det"), ("geometry", "det", "det"),
-              ("image_fwd", "img", "main"),
-              ("fusion", "main", "main"), ("text_prep_bwd", "det", "det"), ("det_bwd", "det", "det"), ("image_bwd", "img", "main"), ("image_bwd_1", "img", "main"),
+    _ORDER = (("text_prep", "det", "det"), ("det_fwd", "det", "det"), ("det_loss", "det", "det"), ("t_refresh", "det", "det"),
+              ("geometry", "det", "det"), ("image_fwd", "img", "main"),
+              ("fusion", "main", "main"), ("fusion_bwd", "main", "main"), ("text_prep_bwd", "det", "det"), ("det_bwd", "det", "det"), ("image_bwd", "img", "main"), ("image_bwd_1", "img", "main"),
               ("image_bwd_2", "img", "main"), ("image_bwd_3", "img", "main"), ("finish", "main", "main"))
 
     def _stream(self, which):
@@ -277,6 +296,8 @@ class PhasedTrainStep(object):
             return int(name.rsplit("_", 1)[1]) >= self.image_splits
         if name in ("text_prep", "text_prep_bwd"):
             return not self.text_prologue
+        if name == "t_refresh":
+            return not self.t_refresh
         return name == "geometry" and not self.prefetch
 
     def phase_gpu_ms(self):
@@ -352,6 +373,9 @@ class PhasedTrainStep(object):
             self._run("det_loss", eager)
             if not _DET_LOSS_LATE[0]:
                 self.e_det_fwd.record(sd)
+            if self.t_refresh:
+                self._run("t_refresh", eager)
+                self.e_t_refresh.record(sd)
             if self.prefetch:
                 self._run("geometry", eager)
         if si is not sm:
@@ -363,6 +387,9 @@ class PhasedTrainStep(object):
             sm.wait_event(self.e_img_fwd)
             sm.wait_event(self.e_det_fwd)
             self._run("fusion", eager)
+            if self.t_refresh:
+                sm.wait_event(self.e_t_refresh)
+            self._run("fusion_bwd", eager)
             self.e_fused.record(sm)
         sd.wait_event(self.e_fused)
         with torch.cuda.stream(sd):
@@ -521,6 +548,8 @@ class PhasedTrainStep(object):
             return self
         self.zero_grad()
         self._state = {}
+        if self.t_refresh:
+            ops.refresh_transposed(self.dev)   # (builds the device table of what the warm-up registered: not possible inside a capture)
         pools = {"main": torch.cuda.graph_pool_handle(), "det": torch.cuda.graph_pool_handle()}
         # every phase graph SINGLE-STREAM (no fusion_ops.fork inside: the decoder's hoisted K/V projection stays on the
         # chain's stream): this runtime enqueues a graph with an internal fork node by node -- the fusion graph's launch held

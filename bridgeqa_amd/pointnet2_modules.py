@@ -66,7 +66,7 @@ class PointnetSAModuleVotes(nn.Module):
         # max over nsample == F.max_pool2d(kernel=[1, nsample]).squeeze(-1) (pointnet2_modules.py:259-262, 272); a row
         # reduction instead of the generic NCHW pooling kernel.  Tie routing in backward is immaterial.
         if grouped_features.dtype == torch.bfloat16 and (
-                pt_utils._rows_view(grouped_features) is not None
+                pt_utils._rows_view_ok(grouped_features) is not None
                 or (grouped_features.is_contiguous(memory_format=torch.channels_last)
                     and not grouped_features.is_contiguous())):
             # NHWC fast path: the last layer's BatchNorm+ReLU kernel also reduces over S; the result stays

@@ -162,16 +162,49 @@ def _wgrad_pieces(R, tiles):
     return ks - ks % 8 if ks >= 8 else ks
 
 
-def _rows_view(x):
-    """(B, C, M, S) logical NCHW tensor that is physically point-major rows (b, m, s) of a uniform stride ld >= C with
-    contiguous channels -> the (B*M*S, C) rows view with stride (ld, 1), or None"""
+def _rows_view_ok(x):
+    """the uniform row stride of a (B, C, M, S) logical NCHW tensor that is physically point-major rows (b, m, s) with
+    contiguous channels (ld >= C, a multiple of 8 elements, 16-byte aligned base), or None"""
     if x.dim() != 4 or x.stride(1) != 1:
         return None
     B, C, M, S = x.shape
     ld = x.stride(3)
     if ld < C or ld % 8 or x.stride(2) != S * ld or x.stride(0) != M * S * ld or x.data_ptr() % 16:
         return None
+    return ld
+
+
+def _rows_view(x):
+    """-> the (B*M*S, C) rows view with stride (ld, 1) of such a tensor, or None"""
+    ld = _rows_view_ok(x)
+    if ld is None:
+        return None
+    B, C, M, S = x.shape
+    if x.requires_grad and torch.is_grad_enabled():
+        return _RowsViewFn.apply(x, ld)
     return torch.as_strided(x, (B * M * S, C), (ld, 1))
+
+
+class _RowsViewFn(torch.autograd.Function):
+    """the (B*M*S, C) rows view of _rows_view with a backward that is a VIEW too: the rows' gradient arrives as the first C
+    columns of the padded (R, ld') buffer the first layer's dX GEMM wrote and goes on as (B, C, M, S) strides over that same
+    buffer (pointnet2_utils._GroupConcatPM's gradient kernel reads padded rows).  torch.as_strided's own backward
+    zero-fills a tensor of the base's size and copies the gradient into it: 142 + 35 + 17 MB of fills and three full copies
+    per c3 step on the detector stream."""
+
+    @staticmethod
+    def forward(ctx, x, ld):
+        B, C, M, S = x.shape
+        ctx.dims = (B, C, M, S)
+        return torch.as_strided(x, (B * M * S, C), (ld, 1))
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, M, S = ctx.dims
+        if g.stride(1) != 1 or g.stride(0) < C:
+            g = g.contiguous()
+        lg = g.stride(0)
+        return torch.as_strided(g, (B, C, M, S), (M * S * lg, 1, S * lg, lg)), None
 
 
 def rows_conv_bn_relu(rows, conv, bn, relu=True):

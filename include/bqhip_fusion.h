@@ -294,6 +294,16 @@ typedef struct bq_colsum_desc {
 } bq_colsum_desc;
 BQ_API int bq_colsum_grouped_bf16(const bq_colsum_desc *problems, int n, void *stream);
 
+/* ---- multi-tensor bf16 transpose (csrc/transpose.hip) ----
+ * dst_t (K, N) = src_t (N, K)^T for a list of weight operands in ONE launch: the K-contiguous second copy of the text
+ * side's weights, which lets the input-gradient GEMMs of models/med.py's linears (autograd: grad_output.mm(weight)) run
+ * on the forward's operand form.  table: DEVICE array of {const void *src; void *dst; int N, K, ld, tiles_k;} records
+ * (bq_transpose_tensor_bytes() each; N, K multiples of 64, ld of 8, tiles_k = K / 64); chunks: DEVICE int32 pairs
+ * {tensor, tile} covering every 64 x 64 tile, tile = (n / 64) * tiles_k + k / 64.  max_wgs > 0: a grid of at most that many
+ * workgroups walking the tiles (a launch beside a latency-bound chain); <= 0: one workgroup per tile. */
+BQ_API int bq_transpose_tensor_bytes(void);
+BQ_API int bq_transpose_multi_bf16(const void *table, const void *chunks, int n_chunks, int max_wgs, void *stream);
+
 /* ---- weight gradient of a SharedMLP layer over whole rows (csrc/gemm.hip wgrad_rows_kernel + reduce) ----
  * Replaces the conv weight gradient of autograd for the 1x1 convolutions of lib/pointnet2/pytorch_utils.py:104-157 on
  * point-major rows:  out[j][i] = sum_r Q[r][j] P[r][i]  (P = the layer's input rows (R, ldp) bf16, Q = the gradient

@@ -337,3 +337,53 @@ def test_decoder_hoisted_cross_kv_equals_per_layer_projections(dev, bf16):
         return rel(b["grads"][n], a["grads"][n])
     worst = sorted(((err(n), n) for n in a["grads"]), reverse=True)[:4]
     assert worst[0][0] <= 2e-2, worst
+
+
+@pytest.mark.parametrize("optimizer", ["torch", "torch_fused", "bq"])
+def test_transposed_weight_copies_follow_the_optimizer(dev, bf16, optimizer):
+    """fusion_state.transposed_shadow: the input gradient of a small-M linear / fused QKV / fused MLP read through the
+    K-contiguous copy equals the contraction-major read of the operand itself -- bit for bit, on every step of a run in
+    which the optimizer keeps changing the weights"""
+    ops = bf16
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(768, 768).to(dev)
+    qkv = [torch.nn.Linear(768, 768).to(dev) for _ in range(3)]
+    fc1, fc2 = torch.nn.Linear(768, 3072).to(dev), torch.nn.Linear(3072, 768).to(dev)
+    params = [p for m in [lin, fc1, fc2] + qkv for p in m.parameters()]
+    if optimizer == "bq":
+        from bridgeqa_amd.optim import FusedAdamW
+        opt = FusedAdamW(params, lr=3e-2)
+    else:
+        opt = torch.optim.AdamW(params, lr=3e-2, fused=(optimizer == "torch_fused"))
+
+    def dxs(x, g):
+        out = []
+        for fn in (lambda t: ops.linear(t, lin.weight, lin.bias),
+                   lambda t: ops.multi_linear(t, qkv).flatten(-2)[..., :768],
+                   lambda t: ops.mlp(t, fc1, fc2)):
+            xi = x.clone().requires_grad_(True)
+            fn(xi).backward(g)
+            out.append(xi.grad)
+        return out
+
+    x = torch.randn(16, 20, 768, device=dev).bfloat16()
+    g = torch.randn(16, 20, 768, device=dev).bfloat16()
+    prev = ops.TRANSPOSED_DX[0]
+    try:
+        last = None
+        for step in range(3):
+            opt.zero_grad(set_to_none=True)
+            ops.TRANSPOSED_DX[0] = True
+            a = dxs(x, g)
+            ops.TRANSPOSED_DX[0] = False
+            b = dxs(x, g)
+            for u, v in zip(a, b):
+                assert torch.isfinite(u.float()).all() and torch.equal(u, v), step
+            if last is not None:
+                assert not torch.equal(a[0], last)   # the weights did move
+            last = a[0]
+            ops.TRANSPOSED_DX[0] = True
+            opt.step()
+        assert any(len(k) == 3 for k in ops._TSHADOW)   # the fused QKV operand is registered as one entry
+    finally:
+        ops.TRANSPOSED_DX[0] = prev

@@ -512,3 +512,46 @@ def test_row_maps_reject_what_the_kernels_cannot_address(dev):
     with pytest.raises(RuntimeError):     # accum needs the small-tile kernel
         _ext.gemm_grouped([dict(P=x.view(400, 128), Q=_rand((400, 256), dev, 53), out=dw, accum=True)],
                           _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32, _ext.EPI_NONE, 256)
+
+
+@pytest.mark.parametrize("M,N,K", [(640, 768, 768), (640, 2304, 768), (640, 3072, 768), (640, 768, 3072), (80, 1536, 768),
+                                   (16400, 768, 768)])
+@pytest.mark.parametrize("epi", ["none", "add", "dgelu"])
+def test_dx_on_a_transposed_weight_equals_the_contraction_major_read(dev, M, N, K, epi):
+    """the text side's input gradients read a K-contiguous copy W^T of the weight (csrc/transpose.hip,
+    fusion_state.transposed_shadow): same products in the same order as the contraction-major read of W -- identical bits"""
+    from bridgeqa_amd import _ext
+    dy, w = _rand((M, N), dev, 51), _rand((N, K), dev, 52, 0.1)
+    aux = _rand((M, K), dev, 53, 1.5) if epi != "none" else None
+    kw = {"add": aux} if epi == "add" else ({"pre_act": aux} if epi == "dgelu" else {})
+    a = _ext.gemm_dx(dy, w, **kw)
+    b = _ext.gemm_dx(dy, w, wt=w.t().contiguous(), **kw)
+    assert torch.equal(a, b)
+    ref = dy.float() @ w.float()
+    if epi == "add":
+        ref = ref + aux.float()
+    elif epi == "dgelu":
+        p32 = aux.float().requires_grad_(True)
+        _gelu(p32).backward(ref)
+        ref = p32.grad
+    _check(b, ref)
+
+
+def test_multi_tensor_transpose(dev):
+    """bq_transpose_multi_bf16: every registered (N, K) operand -> its (K, N) copy in one launch, row blocks of a
+    concatenated buffer (a strided source) included"""
+    from bridgeqa_amd import _ext
+    cat = _rand((2304, 768), dev, 61)
+    srcs = [_rand((768, 768), dev, 62), cat[768:2304], _rand((3072, 768), dev, 63), _rand((768, 3072), dev, 64),
+            _rand((64, 128), dev, 65), _rand((1536, 832), dev, 66)[:, :768]]
+    dsts = [torch.zeros(s.shape[1], s.shape[0], dtype=torch.bfloat16, device=dev) for s in srcs]
+    table, chunks = _ext.transpose_table(list(zip(srcs, dsts)), dev)
+    assert chunks.shape[0] == sum(s.shape[0] // 64 * (s.shape[1] // 64) for s in srcs)
+    for max_wgs in (0, 7, 100000):   # one workgroup per tile; a small grid walking the tiles; a limit above the tile count
+        for d in dsts:
+            d.zero_()
+        _ext.transpose_multi(table, chunks, max_wgs)
+        for s, d in zip(srcs, dsts):
+            assert torch.equal(d, s.t())
+    with pytest.raises(RuntimeError):
+        _ext.transpose_table([(_rand((100, 128), dev, 67), torch.zeros(128, 100, dtype=torch.bfloat16, device=dev))], dev)

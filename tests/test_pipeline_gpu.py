@@ -64,7 +64,7 @@ def test_phased_step_graph_replay_trains(dev, optimizer):
             from bridgeqa_amd.optim import FusedAdamW
             opt = FusedAdamW(model.parameters(), lr=1e-3)
         pipe = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, opt, use_graphs=True).capture(warmup=3)
-        assert set(pipe.graphs) == {"text_prep", "det_fwd", "det_loss", "image_fwd", "fusion", "text_prep_bwd", "det_bwd",
+        assert set(pipe.graphs) == {"text_prep", "det_fwd", "det_loss", "t_refresh", "image_fwd", "fusion", "fusion_bwd", "text_prep_bwd", "det_bwd",
                                     "image_bwd", "finish"}
         w = model.blip_model.visual_encoder.blocks[0].attn.qkv.weight
         w0 = w.detach().clone()
@@ -79,6 +79,16 @@ def test_phased_step_graph_replay_trains(dev, optimizer):
         # one fixed batch, dropout off: the loss must go DOWN -- i.e. the optimizer's updates reach the bf16 operands
         # the next replay multiplies with (torch's fused AdamW does not bump version counters; see fusion_ops)
         assert min(losses[-3:]) < 0.9 * losses[0], losses
+        # ... and the K-contiguous copies the text side's input-gradient GEMMs read (fusion_state.transposed_shadow): the
+        # replayed text_prep phase re-transposes every one of them from the operands as they are at the START of the step
+        regs = [e for e in ops._TSHADOW.values() if all(r() is not None for r in e[0]) and e[1].device == dev]
+        assert len(regs) >= 12, len(regs)
+        before = [e[1].clone() for e in regs]
+        pipe.step()
+        pipe.wait()
+        torch.cuda.synchronize()
+        assert all(torch.equal(e[2], b.t()) for e, b in zip(regs, before))
+        assert any(not torch.equal(e[1], b) for e, b in zip(regs, before))   # (the step then moved the operands on)
     finally:
         ops.set_compute_dtype(prev)
 

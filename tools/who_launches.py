@@ -54,7 +54,7 @@ for e in evs:
         continue
     for k in kern:
         kn = k.name
-        if not any(p in kn for p in ("elementwise", "Fill", "copy", "reduce_kernel", "CatArray")):
+        if not any(p in kn for p in ("at::native", "rocclr", "Cijk")):
             continue
         short = kn.split("<")[0][-40:] + "|" + (kn.split("at::native::")[2][:40] if kn.count("at::native::") > 1 else "")
         frames = [f for f in (e.stack or []) if "bridgeqa_amd" in f or "bench.py" in f]
@@ -70,5 +70,9 @@ for e in evs:
         key = (short, e.name, str(e.input_shapes)[:60], site if not node else node[:60])
         agg[key][0] += 1
         agg[key][1] += k.duration
-for k, v in sorted(agg.items(), key=lambda x: -x[1][1])[:70]:
+TOP = int(sys.argv[2]) if len(sys.argv) > 2 else 70
+SKIP = sys.argv[3].split(",") if len(sys.argv) > 3 else []   # drop call sites containing any of these (e.g. loss_helper,pointnet2)
+items = [(k, v) for k, v in agg.items() if not any(x in k[3] for x in SKIP)]
+print("%d launches, %.1f us in the listed classes" % (sum(v[0] for _, v in items), sum(v[1] for _, v in items)))
+for k, v in sorted(items, key=lambda x: -x[1][1])[:TOP]:
     print("%4d %8.1fus  %-60s %-28s %-60s %s" % (v[0], v[1], k[0], k[1][:28], k[2], k[3]))

@@ -48,7 +48,7 @@ from . import fusion_ops as ops
 
 
 _DET_LOSS_LATE = [True]   # the fusion waits for the detector's outputs only (False: also for its loss, as before round 3)
-_T_REFRESH_WGS = [256]    # workgroups of the t_refresh phase's transpose launch (0: one per 64 x 64 tile, ~66 000)
+_T_REFRESH_WGS = [0]      # workgroups of the t_refresh launch (0: one per 64 x 64 tile, ~66 000; 256 / 96 walking the tiles measured 0.1-0.3 % slower)
 _SINGLE_STREAM = [True]   # capture every phase graph without fusion_ops.fork (tools/ab_bench.py flips it)
 
 

@@ -1,7 +1,7 @@
 // Multi-tensor bf16 transpose: the K-contiguous operand of the text side's input-gradient GEMMs.
 //
-// dX = dY W (reference models/med.py BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput under autograd:
-// grad_input = grad_output.mm(weight)) contracts over W's ROWS.  Reading the (N, K) operand "down" costs the small-M
+// dX = dY W (reference models/med.py:112-118,226-232,292-317 -- the linears of BertSelfAttention / BertSelfOutput /
+// BertIntermediate / BertOutput under autograd: grad_input = grad_output.mm(weight)) contracts over W's ROWS.  Reading the (N, K) operand "down" costs the small-M
 // launches of the fusion backward twice the time of their forward twins (tools/bench_small_gemm.py: 25.2 vs 13.8 us at a
 // 3072-row contraction, 15.1 vs 10.9 at 2304; every K tile touches a new 98 KB region, 64-B pieces per row), so the text
 // side keeps a second bf16 copy W^T (K, N) of each such weight and runs dX on the forward's K-contiguous form.  This

@@ -75,11 +75,14 @@ def _take_tap(holder, like_rows):
     return g2 if g2.is_contiguous() else g2.contiguous()
 
 
+_DX_T_ROWS = [1024]   # launches with fewer gradient rows read the transposed copy
+
+
 def _dx_wt(params, wb, rows):
     """the (K, N) transposed copy of the weight operand wb for a dX launch over `rows` gradient rows, or None: the text
     side's small launches run on the forward's K-contiguous operand form (fusion_state.transposed_shadow); the large ones
     (image / object tokens: 256 x 128 tiles) read wb contraction-major at the same speed and need no second copy"""
-    if rows >= 1024 or not wb.is_cuda:
+    if rows >= _DX_T_ROWS[0] or not wb.is_cuda:
         return None
     return transposed_shadow(tuple(params), wb)
 
@@ -88,7 +91,7 @@ def _dx_operands(param_groups, wops, rows):
     """(P operands, operand flag) of a GROUPED dX launch: every group's transposed copy and the K-contiguous form when all
     of them are small and have one, else the operands themselves read contraction-major"""
     from . import _ext
-    if max(rows) < 1024:
+    if max(rows) < _DX_T_ROWS[0]:
         wts = [_dx_wt(ps, w, max(rows)) for ps, w in zip(param_groups, wops)]
         if all(t is not None for t in wts):
             return wts, 0

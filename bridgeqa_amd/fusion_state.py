@@ -291,7 +291,7 @@ def refresh_transposed(device=None, max_wgs=0):
         _T_STATE["tables"] = {dev: _ext.transpose_table(pairs, dev) for dev, pairs in by_dev.items()}
         _T_STATE["dirty"] = False
     for dev, (table, chunks) in _T_STATE["tables"].items():
-        if device is None or dev == device:
+        if device is None or dev == device or (device.index is None and dev.type == device.type):
             with torch.cuda.device(dev):
                 _ext.transpose_multi(table, chunks, max_wgs)
     _T_STATE["stale"] = False

@@ -428,18 +428,18 @@ def test_split_image_backward_groups_and_buffer_broadcast_on_rccl_world_1(dev):
         got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
         assert set(got) == set(want)
         assert abs(got_loss - want_loss) <= 1e-4 * abs(want_loss)
-        worst = max(((got[n] - want[n]).norm() / (want[n].norm() + 1e-12)).item() for n in want)
-        assert worst < 2e-3, worst
+        worst = max((((got[n] - want[n]).norm() / (want[n].norm() + 1e-12)).item(), n) for n in want)
+        assert worst[0] < 4e-3, worst   # (fp32 atomics in the detector's scatter gradients: 1-2e-3 between two eager executions)
         dp.capture(warmup=1)                                                # graphs: image_bwd, image_bwd_1, image_bwd_2
         assert {"image_bwd", "image_bwd_1", "image_bwd_2"} <= set(dp.graphs) and "image_bwd_3" not in dp.graphs
         for _ in range(4):                                                  # (coverage check every 2nd replayed step)
             l = dp.step()
         dp.wait()
         torch.cuda.synchronize()
-        assert abs(l.item() - want_loss) <= 2e-3 * abs(want_loss)
+        assert abs(l.item() - want_loss) <= 2e-3 * abs(want_loss), (l.item(), want_loss)
         got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
-        worst = max(((got[n] - want[n]).norm() / (want[n].norm() + 1e-12)).item() for n in want)
-        assert worst < 2e-3, worst
+        worst = max((((got[n] - want[n]).norm() / (want[n].norm() + 1e-12)).item(), n) for n in want)
+        assert worst[0] < 4e-3, worst
         # a plain forward + backward AFTER the split step was built still reaches the patch embedding
         model.zero_grad(set_to_none=True)
         dd = model(dict(batch))

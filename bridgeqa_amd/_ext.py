@@ -22,7 +22,7 @@ if not os.path.exists(_LIB_PATH):
 _lib = ctypes.CDLL(_LIB_PATH)
 _lib.bq_last_error.restype = ctypes.c_char_p
 _lib.bq_abi_version.restype = ctypes.c_int
-ABI_VERSION = 2   # = BQHIP_ABI_VERSION of include/bqhip.h
+ABI_VERSION = 3   # = BQHIP_ABI_VERSION of include/bqhip.h
 if _lib.bq_abi_version() != ABI_VERSION:
     raise ImportError("bridgeqa_amd: libbqhip.so ABI %d != %d (stale library: python -m bridgeqa_amd.build --force)"
                       % (_lib.bq_abi_version(), ABI_VERSION))
@@ -1050,16 +1050,18 @@ def wgrad_rows(x, dy, out, workgroups=0):
 _lib.bq_pwconv_records.argtypes = [_l, _i]
 _lib.bq_pwconv_records.restype = ctypes.c_int
 _lib.bq_pwconv_bn_fwd.argtypes = [_vp, _l, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp,
-                                  _vp]
+                                  _vp, _vp]
 _lib.bq_pwconv_bn_fwd.restype = ctypes.c_int
 
 
 def pwconv_bn_relu_fwd(x, K, w_pad, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, S, relu,
-                       pool):
+                       pool, center=None):
     """x: bf16 rows (R, ldx) view with contiguous elements (ldx = x.stride(0) >= K, the first K of a row are the input
     channels); w_pad: bf16 (N, Kc) contiguous, zero beyond K, Kc % 64 == 0.  y_raw = x @ w^T (bf16 (R, N)), its
     training-mode BatchNorm statistics from the fp32 accumulators (running buffers updated in place), then
     out = relu?(bn(y_raw)) as bf16 (R, N), or (R // S, N) = max over every run of S rows when pool.
+    center (f32 (N,), e.g. running_mean itself): y_raw holds x @ w^T - center and stats describe the stored values (same
+    `out`; the bf16 rounding of y_raw then applies to the deviation from the channel mean -- bq_pwconv_bn_fwd).
     Returns out, y_raw, stats (f32 (4, N): scale, shift, mean, rstd)."""
     if not x.is_cuda:
         raise RuntimeError("x: CPU not supported")
@@ -1071,7 +1073,7 @@ def pwconv_bn_relu_fwd(x, K, w_pad, gamma, beta, running_mean, running_var, num_
         _check(_lib.bq_pwconv_bn_fwd(_p(x), R, int(K), x.stride(0), _p(w_pad), w_pad.stride(0), Kc, N, _p(y_raw), _p(part),
                                      _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(num_batches_tracked),
                                      float(eps), float(momentum), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]),
-                                     _stream()), "pwconv_bn_fwd")
+                                     _p(center), _stream()), "pwconv_bn_fwd")
         out = torch.empty(R // S if pool else R, N, dtype=torch.bfloat16, device=x.device)
         _check(_lib.bq_bn_apply(_p(y_raw), _p(stats[0]), _p(stats[1]), _p(out), R, N, int(S), int(bool(relu)),
                                 int(bool(pool)), _stream()), "bn_apply")

@@ -769,6 +769,7 @@ struct PwconvArgs {
   const __bf16 *X;    // [R][ldx]
   __bf16 *Y;          // [R][Ni]
   float *partial;     // [Gj * 2][3][Ni]: pivot | sum (y - pivot) | sum (y - pivot)^2, per (row walker, wave column)
+  const float *center;  // [Ni] or null: Y holds y - center (see bq_pwconv_bn_fwd); the statistics are those of y
   int ldw, ldx, Ni, R, Kc, Gj, tiles_i;
   unsigned w_bytes, x_bytes;
 };
@@ -798,6 +799,11 @@ __global__ __launch_bounds__(256) void pwconv64_kernel(const PwconvArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { piv[x][r] = 0.f; s1[x][r] = 0.f; s2[x][r] = 0.f; }
   bool have_pivot = false;
+  float ctr[2][4];   // this lane's eight channels of the centre
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ctr[x][r] = a.center ? a.center[iw + x * 16 + q4 * 4 + r] : 0.f;
 
   for (int bj = gj; bj < tiles_j; bj += a.Gj) {
     const int j0 = bj * 64;
@@ -873,8 +879,8 @@ __global__ __launch_bounds__(256) void pwconv64_kernel(const PwconvArgs a) {
         const bool ok = j < a.R;
         if (ok) {
           uint2 pk;
-          pk.x = pack_bf16x2(acc[x][b][0], acc[x][b][1]);
-          pk.y = pack_bf16x2(acc[x][b][2], acc[x][b][3]);
+          pk.x = pack_bf16x2(acc[x][b][0] - ctr[x][0], acc[x][b][1] - ctr[x][1]);
+          pk.y = pack_bf16x2(acc[x][b][2] - ctr[x][2], acc[x][b][3] - ctr[x][3]);
           *reinterpret_cast<uint2 *>(a.Y + (long)j * a.Ni + i) = pk;
         }
 #pragma unroll
@@ -925,6 +931,7 @@ struct PwconvBnParams {
   float eps, momentum;
   int C, nrec, Gj;
   long R;
+  const float *center;   // what the stored y had subtracted (null: nothing): shift / mean describe the STORED values
 };
 
 // 16 threads per channel: thread phase ph merges the records g = ph (mod 16) in index order, then the sixteen partial
@@ -969,9 +976,10 @@ __global__ __launch_bounds__(1024) void pwconv_bn_finalize_kernel(const PwconvBn
   const float var = m2 / n;
   const float rstd = rsqrtf(var + p.eps);
   const float sc = p.gamma[c] * rstd;
+  const float stored_mean = mean - (p.center ? p.center[c] : 0.f);   // (read before running_mean -- the usual centre -- moves)
   p.scale[c] = sc;
-  p.shift[c] = p.beta[c] - mean * sc;
-  p.mean[c] = mean;
+  p.shift[c] = p.beta[c] - stored_mean * sc;
+  p.mean[c] = stored_mean;
   p.rstd[c] = rstd;
   if (p.running_mean) {
     const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
@@ -1479,7 +1487,7 @@ extern "C" int bq_pwconv_records(long R, int N) {
 extern "C" int bq_pwconv_bn_fwd(const void *x, long R, int K, int ldx, const void *w, int ldw, int Kc, int N, void *y,
                                 float *partial, const float *gamma, const float *beta, float *running_mean,
                                 float *running_var, long long *num_batches_tracked, float eps, float momentum,
-                                float *scale, float *shift, float *mean, float *rstd, void *stream) {
+                                float *scale, float *shift, float *mean, float *rstd, const float *center, void *stream) {
   using namespace bq;
   BQ_REQUIRE(x && w && y && partial && gamma && beta && scale && shift && mean && rstd, BQ_EINVAL, "pwconv_bn_fwd: null pointer");
   BQ_REQUIRE(R > 0 && K > 0 && N > 0, BQ_EINVAL, "pwconv_bn_fwd: empty problem");
@@ -1490,7 +1498,7 @@ extern "C" int bq_pwconv_bn_fwd(const void *x, long R, int K, int ldx, const voi
              "pwconv_bn_fwd: operands must be 16-byte aligned");
   BQ_REQUIRE(R * (long)ldx * 2 < 0x7FFFFFFFL - 64L * ldx * 2, BQ_ELIMIT, "pwconv_bn_fwd: x larger than 2 GB");
   PwconvArgs a;
-  a.W = (const __bf16 *)w; a.X = (const __bf16 *)x; a.Y = (__bf16 *)y; a.partial = partial;
+  a.W = (const __bf16 *)w; a.X = (const __bf16 *)x; a.Y = (__bf16 *)y; a.partial = partial; a.center = center;
   a.ldw = ldw; a.ldx = ldx; a.Ni = N; a.R = (int)R; a.Kc = Kc;
   a.tiles_i = N / 64;
   a.Gj = bq_pwconv_records(R, N) / 2;
@@ -1499,7 +1507,7 @@ extern "C" int bq_pwconv_bn_fwd(const void *x, long R, int K, int ldx, const voi
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(pwconv64_kernel, dim3(a.tiles_i * a.Gj), dim3(256), 0, st, a);
   PwconvBnParams p{partial, gamma, beta, running_mean, running_var, num_batches_tracked, scale, shift, mean, rstd,
-                   eps, momentum, N, a.Gj * 2, a.Gj, R};
+                   eps, momentum, N, a.Gj * 2, a.Gj, R, center};
   hipLaunchKernelGGL(pwconv_bn_finalize_kernel, dim3((N + 63) / 64), dim3(1024), 0, st, p);
   return check_launch("pwconv_bn_fwd");
 }

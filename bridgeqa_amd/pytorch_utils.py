@@ -104,8 +104,11 @@ class _ConvBNReLUPointMajor(torch.autograd.Function):
         from . import _ext, fusion_ops
         K = conv_weight.shape[1]
         w_pad = fusion_ops.padded_conv_shadow(conv_weight)
+        # (the pre-activation is stored as its deviation from running_mean -- last steps' estimate of the channel mean:
+        # BatchNorm's output does not depend on the offset, the bf16 rounding of the stored tensor does; CENTER_PREACT)
         out, y_raw, stats = _ext.pwconv_bn_relu_fwd(x, K, w_pad, gamma, beta, running_mean, running_var,
-                                                    num_batches_tracked, eps, momentum, S, relu, pool)
+                                                    num_batches_tracked, eps, momentum, S, relu, pool,
+                                                    center=running_mean if CENTER_PREACT[0] else None)
         if conv_bias is not None and running_mean is not None:
             # a convolution bias in front of a training-mode BatchNorm cancels in the normalised output (it shifts the
             # batch mean by itself) and its gradient is identically zero; the only trace it leaves is in running_mean
@@ -149,6 +152,7 @@ class _ConvBNReLUPointMajor(torch.autograd.Function):
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None, dcb
 
 
+CENTER_PREACT = [True]      # SharedMLP pre-activations stored relative to running_mean (tools/loss_gap_probe.py)
 _WGRAD_ROWS = True          # the whole-row weight-gradient kernel for long contractions
 _WGRAD_ROWS_MIN = 65536
 _WGRAD_ROWS_WGS = 0     # 0: the library's default per shape

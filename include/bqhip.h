@@ -35,8 +35,9 @@ extern "C" {
 
 /* 2 (round 4): bq_gemm_desc grew the batched-row maps (q_rpb / q_bstride / o_rpb / o_bstride), bq_ball_query_background,
  * tile 128 and BQ_GEMM_BACKGROUND arrived after 1 without a bump: a stale libbqhip.so must fail the version check, not a
- * symbol lookup or an EINVAL at its first launch */
-#define BQHIP_ABI_VERSION 2
+ * symbol lookup or an EINVAL at its first launch.
+ * 3 (round 4): bq_pwconv_bn_fwd took `center`, bq_transpose_multi_bf16 / bq_transpose_tensor_bytes arrived. */
+#define BQHIP_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define BQ_API __attribute__((visibility("default")))

@@ -327,12 +327,17 @@ BQ_API int bq_wgrad_rows_bf16(const void *P, const void *Q, float *out, float *p
  * statistics: scale = gamma * rstd, shift = beta - mean * scale, mean, rstd (f32 N each), running_mean / running_var
  * (momentum, unbiased) and num_batches_tracked updated when non-NULL -- what bq_bn_stats computes from a second pass
  * over y.  bq_bn_apply / bq_bn_backward consume scale / shift / mean / rstd unchanged.
+ * center (f32 N, may be NULL; may alias running_mean): the stored y is  conv - center[n]  and shift / mean are those of the
+ * STORED values (the normalised output is the same function: training-mode BatchNorm does not see a per-channel offset
+ * of its input; running_mean still receives the mean of the convolution itself).  With center = running_mean the bf16
+ * rounding of y applies to the deviation from the channel mean instead of to the value: where |mean| >> std the
+ * normalised activations keep 8 bits of their OWN scale (the pre-BatchNorm rounding finding).
  * partial: bq_pwconv_records(R, N) * 3 * N floats of scratch. */
 BQ_API int bq_pwconv_records(long R, int N);
 BQ_API int bq_pwconv_bn_fwd(const void *x, long R, int K, int ldx, const void *w, int ldw, int Kc, int N, void *y,
                             float *partial, const float *gamma, const float *beta, float *running_mean,
                             float *running_var, long long *num_batches_tracked, float eps, float momentum,
-                            float *scale, float *shift, float *mean, float *rstd, void *stream);
+                            float *scale, float *shift, float *mean, float *rstd, const float *center, void *stream);
 
 /* ---- LM head + label-smoothed cross entropy (csrc/lmhead.hip, with BQ_GEMM_EPI_BIAS_CE of bq_gemm_bf16) -------------
  * Replaces prediction_scores = cls(sequence_output) -> .float() -> CrossEntropyLoss(reduction='none',

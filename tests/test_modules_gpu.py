@@ -204,6 +204,48 @@ def test_pwconv_bn_kernel_vs_torch_fp32(dev):
         assert rel(out.float(), ref) < 5e-3, (R, K, N, rel(out.float(), ref))
 
 
+def test_pwconv_preactivation_stored_relative_to_a_centre(dev):
+    """bq_pwconv_bn_fwd(center=c): the stored pre-activation is conv - c, the statistics describe the stored values, the
+    running mean still tracks the convolution -- and relu(bn(.)) is the same function.  With channel means 50x the spread
+    (offset 25, std ~0.5) a bf16 pre-activation has an ulp of 0.125-0.25: a quarter of the spread; stored relative to
+    the mean it keeps 8 bits of the spread itself (tools/loss_gap_probe.py: rounding in front of BatchNorm is the one
+    rounding class that reproduces the bf16 detector path's convergence gap)."""
+    from bridgeqa_amd import _ext
+    g = torch.Generator().manual_seed(1)
+    R, K, N, S = 20000, 64, 64, 16
+    x = torch.randn(R, K, generator=g) * 0.5
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    x[:, 0] = 1.0
+    w[:, 0] = 25.0
+    x_d, w_d = x.to(dev).to(torch.bfloat16), w.to(dev).to(torch.bfloat16)
+    gamma, beta = (torch.rand(N, generator=g) + 0.5).to(dev), (torch.randn(N, generator=g) * 0.1).to(dev)
+    y = x_d.float() @ w_d.float().t()
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    want = torch.relu((y - mean) * (var + 1e-5).rsqrt() * gamma + beta)
+    rel = lambda a, b: ((a - b).norm() / (b.norm() + 1e-20)).item()
+    errs = {}
+    for name, centre in (("plain", None), ("centred", (mean + 0.3 * torch.randn(N, device=dev)).contiguous())):
+        rm, rv = torch.zeros(N, device=dev), torch.ones(N, device=dev)
+        nbt = torch.zeros((), dtype=torch.int64, device=dev)
+        out, y_raw, stats = _ext.pwconv_bn_relu_fwd(x_d, K, w_d, gamma, beta, rm, rv, nbt, 1e-5, 0.1, S, True, False,
+                                                    center=centre)
+        c = centre if centre is not None else torch.zeros(N, device=dev)
+        assert rel(stats[2], mean - c) < 1e-4 and rel(rm, 0.1 * mean) < 1e-5       # stored mean / the convolution's own
+        assert rel(y_raw.float() + c, y) < 3e-3
+        ref = torch.relu((y_raw.float() - stats[2]) * stats[3] * gamma + beta)    # apply = the stored values' statistics
+        assert rel(out.float(), ref) < 5e-3
+        errs[name] = rel(out.float(), want)
+    assert errs["centred"] < 1e-2 and errs["plain"] > 5 * errs["centred"], errs
+    # aliasing the centre with running_mean (what the SharedMLP layer passes): read before the update
+    rm = (mean + 0.1).contiguous()
+    rm0 = rm.clone()
+    out, y_raw, stats = _ext.pwconv_bn_relu_fwd(x_d, K, w_d, gamma, beta, rm, torch.ones(N, device=dev),
+                                                torch.zeros((), dtype=torch.int64, device=dev), 1e-5, 0.1, S, True, False,
+                                                center=rm)
+    assert rel(stats[2], mean - rm0) < 1e-3 and rel(rm, 0.9 * rm0 + 0.1 * mean) < 1e-5
+    assert rel(out.float(), want) < 1e-2
+
+
 def test_native_sharedmlp_sa_module_vs_fp32_reference(dev):
     """A set-abstraction module at SA2's shape through the native layers (point-major grouping with padded rows ->
     pwconv + BN statistics -> normalise / ReLU / pool; backward through the GEMM family) against the same module in

@@ -9,6 +9,11 @@
 // pipeline.PhasedTrainStep, beside the image encoder): 64 x 64 tiles through LDS, 128-B rows in, 128-B rows out.
 #include "bq_common.h"
 
+// measurement builds only (tools/rebuild_with.sh transpose -DBQ_TRANSPOSE_NT=0): plain loads / stores
+#ifndef BQ_TRANSPOSE_NT
+#define BQ_TRANSPOSE_NT 1
+#endif
+
 namespace bq {
 
 struct TransposeTensor {
@@ -31,7 +36,13 @@ __global__ __launch_bounds__(256) void transpose_multi_bf16_kernel(const Transpo
   const int n0 = (ck.y / T.tiles_k) * 64, k0 = (ck.y % T.tiles_k) * 64;
   {
     const __bf16 *s = T.src + (long)(n0 + r) * T.ld + k0 + seg;
+    // (nontemporal: 1.1 GB streamed once per step beside a kernel chain that lives on its cache-resident operands)
+#if BQ_TRANSPOSE_NT
+    const u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s));
+    const u32x4 b = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s + 8));
+#else
     const u32x4 a = *reinterpret_cast<const u32x4 *>(s), b = *reinterpret_cast<const u32x4 *>(s + 8);
+#endif
     unsigned *d = reinterpret_cast<unsigned *>(tile + r * TR_PAD + seg);   // (4-byte aligned: TR_PAD and seg are even)
 #pragma unroll
     for (int e = 0; e < 4; ++e) { d[e] = a[e]; d[4 + e] = b[e]; }
@@ -50,8 +61,13 @@ __global__ __launch_bounds__(256) void transpose_multi_bf16_kernel(const Transpo
       b[e] = (unsigned)v[8 + 2 * e] | ((unsigned)v[8 + 2 * e + 1] << 16);
     }
     __bf16 *o = T.dst + (long)(k0 + r) * T.N + n0 + seg;
+#if BQ_TRANSPOSE_NT
+    __builtin_nontemporal_store(a, reinterpret_cast<u32x4 *>(o));
+    __builtin_nontemporal_store(b, reinterpret_cast<u32x4 *>(o + 8));
+#else
     *reinterpret_cast<u32x4 *>(o) = a;
     *reinterpret_cast<u32x4 *>(o + 8) = b;
+#endif
   }
   __syncthreads();   // (the next tile overwrites the image)
   }

@@ -309,7 +309,7 @@ PROFILE_ROWS = 16400   # the committed counter / in-step records were taken at c
 #                        attached to a bench line only when the run has the same M (the c5 line divided c3's bytes)
 # kernel instantiation each launch form runs as (for the in-step averages of the committed profile)
 GEMM_KERNELS = {"fwd": "gemm128_kernel<false, false, 1, false, 16>", "fwd_gelu": "gemm128_kernel<false, false, 2, false, 16>",
-                "dx": "gemm128_kernel<true, false, 0, false, 16>", "dx_dgelu": "gemm128_kernel<true, false, 3, false, 16>",
+                "dx": "gemm128_kernel<false, false, 0, false, 16>", "dx_dgelu": "gemm128_kernel<false, false, 3, false, 16>",
                 "dw": "gemm256_kernel<true, true, 0, true>"}
 
 
@@ -382,6 +382,7 @@ def gemm_roofline(args, dev):
 
     for name, N, K in VIT_GEMMS:
         x, w, dy, pre = rnd(M, K), rnd(N, K, sc=0.05), rnd(M, N), rnd(M, K)
+        wt = w.t().contiguous()   # the step's input-gradient launches read the K-contiguous copy (fusion_state.transposed_shadow)
         b = torch.randn(N, generator=g).to(dev)
         fl = 2.0 * M * N * K
         if name == "fc1":
@@ -392,10 +393,10 @@ def gemm_roofline(args, dev):
         else:
             add("fwd_" + name, "fwd", lambda: _ext.gemm_fwd(x, w, b), fl, 2.0 * (M * K + N * K + M * N), N, K)
         if name == "fc2":
-            add("dx_fc2_dgelu", "dx_dgelu", lambda: _ext.gemm_dx(dy, w, pre_act=pre), fl, 2.0 * (M * N + N * K + 2 * M * K), N, K)
+            add("dx_fc2_dgelu", "dx_dgelu", lambda: _ext.gemm_dx(dy, w, pre_act=pre, wt=wt), fl, 2.0 * (M * N + N * K + 2 * M * K), N, K)
         else:
-            add("dx_" + name, "dx", lambda: _ext.gemm_dx(dy, w), fl, 2.0 * (M * N + N * K + M * K), N, K)
-        del x, w, dy, pre
+            add("dx_" + name, "dx", lambda: _ext.gemm_dx(dy, w, wt=wt), fl, 2.0 * (M * N + N * K + M * K), N, K)
+        del x, w, dy, pre, wt
     # the weight gradients exactly as the step issues them: the deferred flush of the image backward (fusion_wgrad: launch
     # plan over the 256-tile problems, bias gradients from the same launches, the planner's small problems on the 64-tile kernel)
     from bridgeqa_amd import fusion_wgrad

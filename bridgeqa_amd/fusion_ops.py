@@ -75,13 +75,16 @@ def _take_tap(holder, like_rows):
     return g2 if g2.is_contiguous() else g2.contiguous()
 
 
-_DX_T_ROWS = [1024]   # launches with fewer gradient rows read the transposed copy
+# launches with fewer gradient rows read the transposed copy.  Round 4 first limited this to the text side (< 1024 rows: the
+# latency chains, where the contraction-major read costs up to 2x); with the ViT's and the K/V projections' weights included
+# the image backward window shrank by another 0.6 ms (A/B x2: 444.7 / 446.3 against 440.6 / 440.4 samples/s) for 0.1 ms more
+# of transposes: in the step, beside the detector's backward, the contraction-major read loses more than alone (3-6 %)
+_DX_T_ROWS = [1 << 30]
 
 
 def _dx_wt(params, wb, rows):
-    """the (K, N) transposed copy of the weight operand wb for a dX launch over `rows` gradient rows, or None: the text
-    side's small launches run on the forward's K-contiguous operand form (fusion_state.transposed_shadow); the large ones
-    (image / object tokens: 256 x 128 tiles) read wb contraction-major at the same speed and need no second copy"""
+    """the (K, N) transposed copy of the weight operand wb for a dX launch over `rows` gradient rows, or None: the launch then
+    runs on the forward's K-contiguous operand form (fusion_state.transposed_shadow)"""
     if rows >= _DX_T_ROWS[0] or not wb.is_cuda:
         return None
     return transposed_shadow(tuple(params), wb)
@@ -871,10 +874,11 @@ class _TwinKVFn(torch.autograd.Function):
         extra = _take_tap(ctx.tap, dhs)   # the states' gradient through the level's other readers, stacked rows
         if extra is None:
             extra = torch.zeros_like(dhs)
-        _ext.gemm_grouped([dict(P=w2d, Q=g2d[:, :P2], out=outs[0], aux=outs[0]),
-                           dict(P=w3d, Q=g3d[:, :P3], out=outs[1], aux=outs[1]),
-                           dict(P=w2d, Q=g2d[:, P2:], out=dhs[B * L:], aux=extra[B * L:]),
-                           dict(P=w3d, Q=g3d[:, P3:], out=dhs[:B * L], aux=extra[:B * L])], _ext.GEMM_P_XC, _ext.EPI_ADD)
+        (p2d, p3d), pflag = _dx_operands([ws[0:2], ws[2:4]], [w2d, w3d], [B * max(P2, P3)])
+        _ext.gemm_grouped([dict(P=p2d, Q=g2d[:, :P2], out=outs[0], aux=outs[0]),
+                           dict(P=p3d, Q=g3d[:, :P3], out=outs[1], aux=outs[1]),
+                           dict(P=p2d, Q=g2d[:, P2:], out=dhs[B * L:], aux=extra[B * L:]),
+                           dict(P=p3d, Q=g3d[:, P3:], out=dhs[:B * L], aux=extra[:B * L])], pflag, _ext.EPI_ADD)
         hs2 = hs.view(2 * B * L, D)
         src = ((g2d[:, :P2], enc2d.view(B * P2, D), g2d[:, P2:], hs2[B * L:]),
                (g3d[:, :P3], enc3d.view(B * P3, D), g3d[:, P3:], hs2[:B * L]))

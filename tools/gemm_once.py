@@ -68,17 +68,18 @@ def main():
         else:
             n, k = SHAPES[layer]
             x, w, dy, b, pre = rnd(M, k), rnd(n, k, sc=0.05), rnd(M, n), torch.randn(n, device=dev), rnd(M, k)
+            wt = w.t().contiguous()   # the step's input-gradient launches read the K-contiguous copy (fusion_state.transposed_shadow)
             for _ in range(reps):
                 if kind == "fwd":
                     _ext.gemm_fwd(x, w, b)
                 elif kind == "fwdg":
                     _ext.gemm_fwd(x, w, b, gelu=True)
                 elif kind == "dx":
-                    _ext.gemm_dx(dy, w)
+                    _ext.gemm_dx(dy, w, wt=wt)
                 elif kind == "dxa":
-                    _ext.gemm_dx(dy, w, add=pre)      # (the residual-branch gradient rides on the dX epilogue)
+                    _ext.gemm_dx(dy, w, add=pre, wt=wt)      # (the residual-branch gradient rides on the dX epilogue)
                 else:
-                    _ext.gemm_dx(dy, w, pre_act=pre)
+                    _ext.gemm_dx(dy, w, pre_act=pre, wt=wt)
         torch.cuda.synchronize()
     print("done")
 

@@ -428,6 +428,9 @@ class PhasedTrainStep(object):
             del self._comm_events[:]
             self._run("finish", eager)
             self.e_done.record(sm)
+        # the caller's stream is ordered behind the step (a stream-side wait, the host does not block): the returned loss /
+        # the gradients can be read from it -- `pipe.eager_step().item()` used to race with the main phase stream
+        cur.wait_event(self.e_done)
 
     def attach_reducers(self, make_reducer):
         """Data parallel: one eager step to see which parameters receive a gradient in which phase, then
@@ -579,7 +582,8 @@ class PhasedTrainStep(object):
         return self
 
     def step(self):
-        """one optimisation step; returns the (device) loss of this step without synchronising"""
+        """one optimisation step; returns the (device) loss of this step without synchronising the host (the caller's
+        current stream is ordered behind the step: reading the loss from it is safe)"""
         if self.graphs is None:
             return self.eager_step()
         if self.opt is not None and hasattr(self.opt, "sync_hyperparams"):

@@ -49,11 +49,12 @@ from . import fusion_ops as ops
 
 _DET_LOSS_LATE = [True]   # the fusion waits for the detector's outputs only (False: also for its loss, as before round 3)
 _T_REFRESH_WGS = [0]      # workgroups of the t_refresh launch (0: one per 64 x 64 tile, ~66 000; 256 / 96 walking the tiles measured 0.1-0.3 % slower)
+_DET_PRIORITY = [0]       # default stream priority of the detector stream (the main stream: -1, higher)
 _SINGLE_STREAM = [True]   # capture every phase graph without fusion_ops.fork (tools/ab_bench.py flips it)
 
 
 class PhasedTrainStep(object):
-    def __init__(self, model, batch, det_loss, fusion_loss, optimizer=None, use_graphs=True, det_priority=0,
+    def __init__(self, model, batch, det_loss, fusion_loss, optimizer=None, use_graphs=True, det_priority=None,
                  grad_hook=None, next_batch=None, prefetch_geometry=None, eager_phases=(), reducers=None,
                  main_priority=-1, image_bwd_splits=1, buffer_broadcaster=None, coverage_every=50, text_prologue=True):
         """model: ScanQAHotPath (use_blip=True, train mode); batch: static device tensors (replayed in place);
@@ -126,7 +127,7 @@ class PhasedTrainStep(object):
         self.s_main = torch.cuda.Stream(device=dev, priority=int(main_priority))
         self.s_img = self.s_main
         self.e_img_fwd = torch.cuda.Event()
-        self.s_det = torch.cuda.Stream(device=dev, priority=int(det_priority))
+        self.s_det = torch.cuda.Stream(device=dev, priority=int(_DET_PRIORITY[0] if det_priority is None else det_priority))
         self.e_text_bwd, self.e_t_refresh = torch.cuda.Event(), torch.cuda.Event()
         self.t_refresh = bool(ops.TRANSPOSED_DX[0]) and bm is not None
         self.e_det_fwd, self.e_fused, self.e_det_bwd, self.e_done = (torch.cuda.Event() for _ in range(4))

@@ -68,3 +68,31 @@ def test_bad_extents_return_status_not_exit():
     assert lib.bq_furthest_point_sampling(None, None, 0, None, 0, 8, 4, None) == 0
     assert lib.bq_fps_workspace_bytes(16, 40000) == 16 * 40000 * 20 and lib.bq_fps_workspace_bytes(16, 2048) == 0
     assert lib.bq_opt_n_threads(40000) == 512 and lib.bq_opt_n_threads(300) == 256
+
+
+def test_transpose_table_packing_matches_the_header_record():
+    """_ext.transpose_table: 32-byte records {src, dst, N, K, ld, tiles_k} as bq_transpose_multi_bf16 reads them, one
+    {tensor, tile} chunk per 64 x 64 tile; unsupported pairs are refused on the host (no GPU needed: pointers only)"""
+    import struct
+    import pytest
+    import torch
+    from bridgeqa_amd import _ext
+    assert _ext.TRANSPOSE_TENSOR_BYTES == 32
+    cat = torch.zeros(256, 128, dtype=torch.bfloat16)
+    pairs = [(torch.zeros(128, 192, dtype=torch.bfloat16), torch.zeros(192, 128, dtype=torch.bfloat16)),
+             (cat[64:192], torch.zeros(128, 128, dtype=torch.bfloat16)),
+             (torch.zeros(64, 320, dtype=torch.bfloat16)[:, :256], torch.zeros(256, 64, dtype=torch.bfloat16))]
+    table, chunks = _ext.transpose_table(pairs, torch.device("cpu"))
+    raw = bytes(table.numpy().tobytes())
+    assert len(raw) == 32 * len(pairs)
+    for i, (src, dst) in enumerate(pairs):
+        p_src, p_dst, N, K, ld, tk = struct.unpack("<QQiiii", raw[32 * i:32 * (i + 1)])
+        assert (p_src, p_dst, N, K, ld, tk) == (src.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1], src.stride(0), src.shape[1] // 64)
+    want = [(i, t) for i, (s, _) in enumerate(pairs) for t in range(s.shape[0] // 64 * (s.shape[1] // 64))]
+    assert [tuple(r) for r in chunks.tolist()] == want and chunks.dtype == torch.int32
+    for bad in ((torch.zeros(100, 128, dtype=torch.bfloat16), torch.zeros(128, 100, dtype=torch.bfloat16)),     # N % 64
+                (torch.zeros(128, 128), torch.zeros(128, 128)),                                                # dtype
+                (torch.zeros(128, 128, dtype=torch.bfloat16), torch.zeros(128, 192, dtype=torch.bfloat16)),    # dst shape
+                (torch.zeros(128, 256, dtype=torch.bfloat16)[:, ::2], torch.zeros(128, 128, dtype=torch.bfloat16))):  # stride
+        with pytest.raises(RuntimeError):
+            _ext.transpose_table([bad], torch.device("cpu"))

@@ -234,7 +234,17 @@ def refresh_shadows(only_with_grad=True, skip=None, only=None):
 # beside the image encoder; under graph replay that captured launch is the refresh).
 TRANSPOSED_DX = [True]
 _TSHADOW = {}
+_T_VERSIONS = {}
 _T_STATE = {"stale": True, "tables": {}, "dirty": True, "keep": []}
+
+
+def _cast_versions(params):
+    """the parameter versions the bf16 shadows (what the copies are transposed FROM) were cast at"""
+    out = []
+    for p in params:
+        ent = _SHADOW.get(id(p))
+        out.append(ent[1] if (ent is not None and ent[0]() is p) else p._version)
+    return tuple(out)
 
 
 def mark_transposed_stale():
@@ -253,6 +263,10 @@ def transposed_shadow(params, wb):
     capturing = wb.is_cuda and torch.cuda.is_current_stream_capturing()
     if ent is not None and all(r() is p for r, p in zip(ent[0], params)) and ent[1].data_ptr() == wb.data_ptr() \
             and ent[1].shape == wb.shape:
+        # an in-place update nobody announced (load_state_dict, a plain copy_): the version counters moved since the last
+        # refresh -- fused optimizers do not bump them, which is what the post-step hook's mark_transposed_stale() is for
+        if not capturing and _T_VERSIONS.get(key) != tuple(p._version for p in params):
+            _T_STATE["stale"] = True
         if _T_STATE["stale"]:
             # (inside a stream capture the refresh launch becomes part of the graph -- as it must: the replayed step needs
             # it too; a registry that changed since its device table was built cannot be rebuilt there)
@@ -266,6 +280,7 @@ def transposed_shadow(params, wb):
     with torch.no_grad():
         wt = wb.t().contiguous()
     _TSHADOW[key] = ([weakref.ref(p) for p in params], wb.detach(), wt)
+    _T_VERSIONS[key] = _cast_versions(params)
     _T_STATE["dirty"] = True
     return wt
 
@@ -282,6 +297,7 @@ def refresh_transposed(device=None, max_wgs=0):
     if _T_STATE["dirty"] or dead:
         for key in dead:
             del _TSHADOW[key]
+            _T_VERSIONS.pop(key, None)
         by_dev = {}
         for ent in _TSHADOW.values():
             by_dev.setdefault(ent[1].device, []).append((ent[1], ent[2]))
@@ -294,6 +310,11 @@ def refresh_transposed(device=None, max_wgs=0):
         if device is None or dev == device or (device.index is None and dev.type == device.type):
             with torch.cuda.device(dev):
                 _ext.transpose_multi(table, chunks, max_wgs)
+    if not capturing:
+        for key, ent in _TSHADOW.items():
+            ps = [r() for r in ent[0]]
+            if all(p is not None for p in ps):
+                _T_VERSIONS[key] = _cast_versions(ps)
     _T_STATE["stale"] = False
 
 

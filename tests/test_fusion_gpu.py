@@ -385,5 +385,16 @@ def test_transposed_weight_copies_follow_the_optimizer(dev, bf16, optimizer):
             ops.TRANSPOSED_DX[0] = True
             opt.step()
         assert any(len(k) == 3 for k in ops._TSHADOW)   # the fused QKV operand is registered as one entry
+        # an update no optimizer announced (load_state_dict / copy_): the copies follow the version counters
+        with torch.no_grad():
+            for m in [lin, fc1, fc2] + qkv:
+                m.weight.copy_(torch.randn_like(m.weight) * 0.05)
+        ops.TRANSPOSED_DX[0] = True
+        a = dxs(x, g)
+        ops.TRANSPOSED_DX[0] = False
+        b = dxs(x, g)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+        assert not torch.equal(a[0], last)
     finally:
         ops.TRANSPOSED_DX[0] = prev

@@ -308,8 +308,7 @@ def refresh_transposed(device=None, max_wgs=0):
         _T_STATE["dirty"] = False
     for dev, (table, chunks) in _T_STATE["tables"].items():
         if device is None or dev == device or (device.index is None and dev.type == device.type):
-            with torch.cuda.device(dev):
-                _ext.transpose_multi(table, chunks, max_wgs)
+            _ext.transpose_multi(table, chunks, max_wgs)   # (sets the device of `table` itself)
     if not capturing:
         for key, ent in _TSHADOW.items():
             ps = [r() for r in ent[0]]

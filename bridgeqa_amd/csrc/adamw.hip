@@ -27,7 +27,10 @@ struct AdamWTensor {
   float lr, wd;
 };
 
-constexpr int ADAMW_CHUNK = 8192;  // elements per workgroup
+#ifndef BQ_ADAMW_CHUNK
+#define BQ_ADAMW_CHUNK 8192   // (measurement builds: tools/rebuild_with.sh adamw -DBQ_ADAMW_CHUNK=...)
+#endif
+constexpr int ADAMW_CHUNK = BQ_ADAMW_CHUNK;  // elements per workgroup
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 

@@ -306,15 +306,18 @@ def refresh_transposed(device=None, max_wgs=0):
         _T_STATE["keep"].append(_T_STATE["tables"])
         _T_STATE["tables"] = {dev: _ext.transpose_table(pairs, dev) for dev, pairs in by_dev.items()}
         _T_STATE["dirty"] = False
+    skipped = False
     for dev, (table, chunks) in _T_STATE["tables"].items():
         if device is None or dev == device or (device.index is None and dev.type == device.type):
             _ext.transpose_multi(table, chunks, max_wgs)   # (sets the device of `table` itself)
+        else:
+            skipped = True   # (several devices in one process: the others' copies stay stale)
     if not capturing:
         for key, ent in _TSHADOW.items():
             ps = [r() for r in ent[0]]
             if all(p is not None for p in ps):
                 _T_VERSIONS[key] = _cast_versions(ps)
-    _T_STATE["stale"] = False
+    _T_STATE["stale"] = skipped
 
 
 __all__ = [n for n in list(globals()) if not n.startswith("__")]

@@ -1,6 +1,6 @@
 """A/B of module-level switches inside the whole step: runs bench.main() with attributes set first.
 
-    python tools/ab_bench.py med._TWO_SEGMENT=True med._TWO_SEGMENT_FORK=True -- --steps 30 --warmup 8
+    python tools/ab_bench.py fusion_state.TRANSPOSED_DX[0]=False pipeline._T_REFRESH_WGS[0]=256 -- --steps 30 --warmup 8
 
 Each NAME=VALUE names an attribute of a bridgeqa_amd module (list-valued switches take NAME[0]=VALUE); what follows `--`
 goes to bench.py.  Prints bench.py's JSON line.  (These switches are constants of the product path; this tool exists so

@@ -35,6 +35,34 @@ def lib():
     return _lib
 
 
+class FmaVariant:
+    """The index-producing operators of the SAME C file built with its squared distances FMA-contracted (`ORACLE_FMA` = 1 or 2,
+    oracle/Makefile).  Sensitivity study only (tests/test_oracle.py::test_fma_contraction_sensitivity): how many indices move
+    if the reference's nvcc build contracted `a*a + b*b + c*c` (sampling_gpu.cu:97-107 under the default -fmad=true)."""
+
+    def __init__(self, variant):
+        assert variant in (1, 2)
+        path = os.path.join(_HERE, "libpn2oracle_fma%d.so" % variant)
+        src = os.path.join(_HERE, "pointnet2_oracle.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            # -mfma (when the host has it) inlines fmaf; without it libm's correctly rounded fmaf is called: same results
+            has_fma = " fma " in open("/proc/cpuinfo").read() if os.path.exists("/proc/cpuinfo") else False
+            subprocess.check_call(["make", "-C", _HERE, "-s", "-B", os.path.basename(path)] +
+                                  (["CFLAGS_EXTRA=-mfma"] if has_fma else []))
+        self._l = ctypes.CDLL(path)
+        self._l.oracle_fma_variant.restype = ctypes.c_int
+        assert self._l.oracle_fma_variant() == variant
+
+    def furthest_point_sampling(self, points, nsamples):
+        return furthest_point_sampling(points, nsamples, _l=self._l)
+
+    def ball_query(self, new_xyz, xyz, radius, nsample):
+        return ball_query(new_xyz, xyz, radius, nsample, _l=self._l)
+
+    def three_nn(self, unknowns, knows):
+        return three_nn(unknowns, knows, _l=self._l)
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
@@ -52,12 +80,12 @@ def opt_n_threads(n):
     return lib().oracle_opt_n_threads(int(n))
 
 
-def furthest_point_sampling(points, nsamples):
+def furthest_point_sampling(points, nsamples, _l=None):
     _chk(points, torch.float32, "points")
     B, N, _ = points.shape
     out = torch.zeros(B, nsamples, dtype=torch.int32)
     tmp = torch.full((B, N), 1e10, dtype=torch.float32)
-    lib().oracle_furthest_point_sampling(B, N, int(nsamples), _p(points), _p(tmp), _p(out))
+    (_l or lib()).oracle_furthest_point_sampling(B, N, int(nsamples), _p(points), _p(tmp), _p(out))
     return out
 
 
@@ -78,12 +106,12 @@ def gather_points_grad(grad_out, idx, n):
     return out
 
 
-def ball_query(new_xyz, xyz, radius, nsample):
+def ball_query(new_xyz, xyz, radius, nsample, _l=None):
     _chk(new_xyz, torch.float32, "new_xyz"); _chk(xyz, torch.float32, "xyz")
     B, M, _ = new_xyz.shape
     N = xyz.shape[1]
     idx = torch.zeros(B, M, nsample, dtype=torch.int32)
-    lib().oracle_ball_query(B, N, M, ctypes.c_float(radius), int(nsample), _p(new_xyz), _p(xyz), _p(idx))
+    (_l or lib()).oracle_ball_query(B, N, M, ctypes.c_float(radius), int(nsample), _p(new_xyz), _p(xyz), _p(idx))
     return idx
 
 
@@ -104,13 +132,13 @@ def group_points_grad(grad_out, idx, n):
     return out
 
 
-def three_nn(unknowns, knows):
+def three_nn(unknowns, knows, _l=None):
     _chk(unknowns, torch.float32, "unknowns"); _chk(knows, torch.float32, "knows")
     B, n, _ = unknowns.shape
     m = knows.shape[1]
     idx = torch.zeros(B, n, 3, dtype=torch.int32)
     dist2 = torch.zeros(B, n, 3, dtype=torch.float32)
-    lib().oracle_three_nn(B, n, m, _p(unknowns), _p(knows), _p(dist2), _p(idx))
+    (_l or lib()).oracle_three_nn(B, n, m, _p(unknowns), _p(knows), _p(dist2), _p(idx))
     return [dist2, idx]
 
 

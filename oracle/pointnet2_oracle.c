@@ -31,6 +31,26 @@
 
 #define ORACLE_API __attribute__((visibility("default")))
 
+/* Squared distance.  ORACLE_FMA selects how `a*a + b*b + c*c` is rounded (a build-time variant of this same file,
+ * oracle/Makefile targets libpn2oracle_fma1.so / _fma2.so; used ONLY by tests/test_oracle.py's sensitivity study of the
+ * risk named above -- sampling_gpu.cu:97-107, ball_query_gpu.cu:31-33, interpolate_gpu.cu:33-35 under nvcc -fmad=true):
+ *   0 (canonical)  fl(fl(fl(a*a) + fl(b*b)) + fl(c*c))        -- every product and sum rounded
+ *   1              fma(c, c, fma(b, b, fl(a*a)))              -- the left-to-right chain nvcc emits for ((a*a + b*b) + c*c)
+ *   2              fma(c, c, fma(a, a, fl(b*b)))              -- the other legal contraction of the inner sum */
+#ifndef ORACLE_FMA
+#define ORACLE_FMA 0
+#endif
+static inline float sq3(float a, float b, float c) {
+#if ORACLE_FMA == 1
+  return fmaf(c, c, fmaf(b, b, a * a));
+#elif ORACLE_FMA == 2
+  return fmaf(c, c, fmaf(a, a, b * b));
+#else
+  return (a * a) + (b * b) + (c * c);
+#endif
+}
+ORACLE_API int oracle_fma_variant(void) { return ORACLE_FMA; }
+
 /* include/cuda_utils.h:13-19 -- TOTAL_THREADS=512; opt_n_threads(w) = clamp(2^trunc(log(w)/log(2)), 1, 512) */
 ORACLE_API int oracle_opt_n_threads(int work_size) {
   const int pow_2 = (int)(log((double)work_size) / log(2.0));
@@ -68,9 +88,9 @@ ORACLE_API void oracle_furthest_point_sampling(int b, int n, int m, const float 
       for (int k = 0; k < n; ++k) {
         const int t = k % bs;
         const float x2 = pts[k * 3 + 0], y2 = pts[k * 3 + 1], z2 = pts[k * 3 + 2];
-        const float mag = (x2 * x2) + (y2 * y2) + (z2 * z2);
+        const float mag = sq3(x2, y2, z2);
         if ((double)mag <= 1e-3) continue; /* :100-101 float promoted against a double literal */
-        const float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+        const float d = sq3(x2 - x1, y2 - y1, z2 - z1);
         const float d2 = d < tmp[k] ? d : tmp[k]; /* min(d, temp[k]) */
         tmp[k] = d2;
         if (d2 > dists[t]) { dists_i[t] = k; dists[t] = d2; } /* :108-109 */
@@ -130,7 +150,7 @@ ORACLE_API void oracle_ball_query(int b, int n, int m, float radius, int nsample
       const float nx = q[0], ny = q[1], nz = q[2];
       for (int k = 0, cnt = 0; k < n && cnt < nsample; ++k) {
         const float x = p[k * 3 + 0], y = p[k * 3 + 1], z = p[k * 3 + 2];
-        const float d2 = (nx - x) * (nx - x) + (ny - y) * (ny - y) + (nz - z) * (nz - z);
+        const float d2 = sq3(nx - x, ny - y, nz - z);
         if (d2 < radius2) {
           if (cnt == 0)
             for (int l = 0; l < nsample; ++l) o[l] = k;
@@ -184,7 +204,7 @@ ORACLE_API void oracle_three_nn(int b, int n, int m, const float *unknown, const
       int besti1 = 0, besti2 = 0, besti3 = 0;
       for (int k = 0; k < m; ++k) {
         const float x = kn[k * 3 + 0], y = kn[k * 3 + 1], z = kn[k * 3 + 2];
-        const float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+        const float d = sq3(ux - x, uy - y, uz - z);
         if (d < best1) {
           best3 = best2; besti3 = besti2;
           best2 = best1; besti2 = besti1;

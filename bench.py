@@ -74,6 +74,13 @@ def parse():
                          "replay behind model() and loss.backward() (bridgeqa_amd/graphed.py; --graph off: kernel by kernel)")
     ap.add_argument("--no-wrap-loss", dest="wrap_loss", action="store_false",
                     help="--loop reference: leave the loss function eager (default: graphed.wrap_loss around it)")
+    ap.add_argument("--no-prefetch", dest="no_prefetch", action="store_true",
+                    help="reference loop: no graphed.prefetch_loader (every step computes its own sampling / grouping indices)")
+    ap.add_argument("--eager-optimizer", dest="eager_optimizer", action="store_true",
+                    help="reference loop: optimizer.step() launched eagerly (default: graphed.wrap_optimizer)")
+    ap.add_argument("--no-loop-reference", dest="no_loop_reference", action="store_true",
+                    help="default c3 run: skip the second measurement (the reference's unchanged loop under graphed, "
+                         "reported as `loop_reference` on the same JSON line)")
     ap.add_argument("--cpu-scenes", type=int, default=2, help="scenes in the bounded CPU-baseline sample")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
                     help="arithmetic of the dense layers: bf16 = the HIP kernel path (MFMA GEMMs, point-major detector); "
@@ -276,7 +283,15 @@ def cpu_baseline(args, workload):
             "cpu_model": model_name, "physical_cores": phys, "logical_cpus": os.cpu_count(), "threads_used": cores,
             "sample": "%s hot path fwd+bwd+clip+AdamW, %d scenes x %d pts, C_in=%d, fp32, mean of 3 timed steps after "
                       "1 warm-up (oracle ops with OpenMP + torch-CPU dense layers on %d threads)"
-                      % (workload, B, args.points, args.cin, cores)}
+                      % (workload, B, args.points, args.cin, cores),
+            "deviation_from_BASELINE_md_2": "BASELINE.md section 2 plans os.cpu_count() threads at B = 16.  Bounded here on purpose: "
+                                            "4 steps at B = 16 take ~150 s of host time on this path (the contract asks for a "
+                                            "10-30 s sample inside the default run), and samples/s does not depend on B on the "
+                                            "CPU (every operator and dense layer is per-sample work; --cpu-scenes 16 runs the "
+                                            "planned size); threads are capped at 32 because the oracle's OpenMP loops and "
+                                            "torch-CPU's GEMMs at these sizes get SLOWER beyond ~32 threads on the 128-core host "
+                                            "(memory-bound, cross-CCD traffic): 32 is the fastest setting measured, i.e. the "
+                                            "baseline is not handicapped"}
 
 
 def cpu_info():
@@ -474,25 +489,43 @@ def attn_roofline(args, dev):
             "timed_on": "dedicated launches after the timed region, HIP events on the launch stream, median of 10"}
 
 
-def reference_loop(args, model, batch, dev, use_graph):
-    """`--loop reference`: the reference's training iteration as its solver writes it (lib/solver.py:463-595 _forward /
-    _backward, scripts/train.py:410-417), nothing rewritten around the step: forward through the module API, the loss
-    outside the model, zero_grad / backward / (clip inside) optimizer.step.  With --graph on/auto, graphed.enable(model)
-    replays HIP graphs behind model() and loss.backward(); the loss and the optimizer launch eagerly."""
+class _StaticLoader(object):
+    """the benchmark's stand-in for the reference's DataLoader: the same synthetic batch `n` times (what the headline
+    replays too); a fresh dict per iteration, as a loader's collate function returns"""
+
+    def __init__(self, batch, n):
+        self.batch, self.n = batch, n
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        for _ in range(self.n):
+            yield dict(self.batch)
+
+
+def run_reference_loop(args, model, batch, dev, use_graph, steps, warmup, trace=False):
+    """The reference's training iteration as its solver writes it (lib/solver.py:463-595 _feed / _forward / _backward,
+    scripts/train.py:410-417), the loop BODY unchanged: forward through the module API, the loss outside the model,
+    zero_grad / backward / (clip inside) optimizer.step.  With graphs: graphed.enable(model, optimizer) replays HIP graphs
+    behind model(), loss.backward() and optimizer.step(); graphed.wrap_loss around the loss function;
+    graphed.prefetch_loader around the loader (the next batch's sampling / grouping indices under this step's fusion).
+    -> dict for the JSON line"""
     from bridgeqa_amd import graphed
     from bridgeqa_amd.optim import FusedAdamW
     opt = FusedAdamW(model.parameters(), lr=5e-4, weight_decay=1e-5, grad_clip_value=1.0)
     loss_fn = total_loss
+    prefetch = use_graph and not getattr(args, "no_prefetch", False)
     if use_graph:
-        graphed.enable(model)
+        graphed.enable(model, optimizer=None if getattr(args, "eager_optimizer", False) else opt)
         # (the solver's `from lib.loss_helper import get_loss` becomes `get_loss = graphed.wrap_loss(model, get_loss)`)
         loss_fn = graphed.wrap_loss(model, total_loss) if args.wrap_loss else total_loss
 
     seg = {"forward": 0.0, "loss": 0.0, "backward": 0.0, "optimizer": 0.0}
 
-    def step():
+    def body(data_dict):
         t = [time.perf_counter()]
-        dd = model(dict(batch)); t.append(time.perf_counter())
+        dd = model(data_dict); t.append(time.perf_counter())
         loss = loss_fn(dd); t.append(time.perf_counter())
         opt.zero_grad(set_to_none=True)
         loss.backward(); t.append(time.perf_counter())
@@ -500,44 +533,65 @@ def reference_loop(args, model, batch, dev, use_graph):
         for k, a, b in zip(seg, t[:-1], t[1:]):
             seg[k] += (b - a) * 1e3
         return loss
-    for _ in range(max(args.warmup, 3)):
-        step()
+
+    def loader(n):
+        ld = _StaticLoader(batch, n)
+        return graphed.prefetch_loader(model, ld) if prefetch else ld
+    for data_dict in loader(max(warmup, 5)):
+        body(data_dict)
     for k in seg:
         seg[k] = 0.0
-    if use_graph and os.environ.get("BQ_PIPE_TRACE") == "1":
+    if use_graph and trace:
         model._graphed.host_times = {}
         model._graphed.phase_events = {}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     host = []
-    for _ in range(args.steps):
-        h0 = time.perf_counter()
-        loss = step()
+    h0 = time.perf_counter()
+    for data_dict in loader(steps):
+        loss = body(data_dict)
         host.append((time.perf_counter() - h0) * 1e3)
+        h0 = time.perf_counter()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert torch.isfinite(loss).item()
-    print("host-side time per step: %.2f ms  (%s)" % (sum(host) / len(host), "  ".join("%s %.2f" % (k, v / args.steps) for k, v in seg.items())),
+    print("reference loop, host-side time per step: %.2f ms  (%s)" % (sum(host) / len(host), "  ".join("%s %.2f" % (k, v / steps) for k, v in seg.items())),
           file=sys.stderr)
     if use_graph and model._graphed.phase_events:
-        print("GPU ms since the step's first launch, per graph [start -> end on its stream]: " +
+        print("reference loop, GPU ms since the step's first launch, per graph [start -> end on its stream]: " +
               "  ".join("%s %.1f->%.1f" % (k, a, b) for k, (a, b) in model._graphed.phase_gpu_ms().items()), file=sys.stderr)
     if use_graph and model._graphed.host_times:
-        print("host ms per graph launch: " + "  ".join("%s %.2f" % (k, sum(v) / len(v)) for k, v in model._graphed.host_times.items()),
+        print("reference loop, host ms per graph launch: " + "  ".join("%s %.2f" % (k, sum(v) / len(v)) for k, v in model._graphed.host_times.items()),
               file=sys.stderr)
+    runner = getattr(model, "_graphed", None)
+    n_graphs = (len(runner.graphs) + 2 * len(runner.losses) + len(runner.opt_graphs)) if (use_graph and runner.graphs) else 0
+    res = {"ms_per_step": round(dt / steps * 1e3, 3), "samples_per_s": round(args.batch * steps / dt, 3), "steps": steps,
+           "loop": "reference: for data_dict in loader: model(data_dict) -> loss -> zero_grad -> backward -> optimizer.step, "
+                   "body unchanged (lib/solver.py:463-595)",
+           "hip_graph": bool(use_graph),
+           "schedule": (("graphed.enable: %d graphs on 2 streams behind the module API (forward, backward%s%s%s)"
+                         % (n_graphs, ", loss (graphed.wrap_loss)" if args.wrap_loss else "; loss eager",
+                            ", optimizer (graphed.wrap_optimizer)" if runner.opt_graphs else "; optimizer eager",
+                            ", next batch's FPS / ball query / three-NN under the fusion (graphed.prefetch_loader)" if prefetch else ""))
+                        if use_graph else "eager, kernel by kernel"),
+           "host_ms_per_step": round(sum(host) / len(host), 2)}
+    if use_graph:
+        graphed.disable(model)
+    return res
+
+
+def reference_loop(args, model, batch, dev, use_graph):
+    """`--loop reference`: ONLY the drop-in loop, as its own JSON line"""
+    res = run_reference_loop(args, model, batch, dev, use_graph, args.steps, args.warmup,
+                             trace=os.environ.get("BQ_PIPE_TRACE") == "1")
     out = {"metric": "train samples/s (%dk-pt scene + %d^2 view, bs%d)" % (args.points // 1000, args.image, args.batch),
-           "value": round(args.batch * args.steps / dt, 3), "unit": "samples/s", "n_gpus": 1, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "value": res["samples_per_s"], "unit": "samples/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": WORKLOADS["c5" if args.workload == "c5" else "c3"], "global_batch": args.batch,
                       "points": args.points, "c_in": args.cin, "image": args.image, "parallelism": "dp1",
-                      "loop": "reference: model(data_dict) -> loss -> zero_grad -> backward -> optimizer.step, unchanged "
-                              "(lib/solver.py:463-595)",
-                      "hip_graph": bool(use_graph),
-                      "schedule": (("graphed.enable: 6 graphs (3 forward, 3 backward) on 2 streams behind the module API; "
-                                    + ("loss wrapped (graphed.wrap_loss: 2 more graphs), optimizer eager" if args.wrap_loss
-                                       else "loss + optimizer eager")) if use_graph else "eager, kernel by kernel")},
-           "host_ms_per_step": round(sum(host) / len(host), 2),
+                      "loop": res["loop"], "hip_graph": bool(use_graph), "schedule": res["schedule"]},
+           "host_ms_per_step": res["host_ms_per_step"],
            "note": "NOT the headline line: the drop-in loop of INTEGRATION.md §3 (the headline is --loop phased)"}
     print(json.dumps(_json_safe(out)))
 
@@ -1005,10 +1059,25 @@ def main():
             out["roofline"] = out["roofline_fps"]
         if world == 1 and not args.no_cpu_baseline and args.workload != "c5":   # (c3 is the headline: its baseline is the one reported)
             out["cpu_baseline"] = cpu_baseline(args, workload)
+        if phased and world == 1 and not args.no_loop_reference and args.workload != "c5" and not dp:
+            # the same model behind the reference's UNCHANGED loop, timed in this process after the headline
+            # (INTEGRATION.md section 3a): the phased step's graphs are dropped first
+            n_graphs = len(pipe.graphs or ())
+            pipe.graphs, pipe._state = None, {}
+            step = None
+            pipe = None
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            try:
+                out["loop_reference"] = run_reference_loop(args, model, batch, dev, use_graph, args.steps, args.warmup)
+            except Exception as e:    # (the headline line must not be lost to the second measurement)
+                out["loop_reference"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if replicas_in_sync is not None:
             out["replicas_in_sync"] = replicas_in_sync
         if pipe is not None and reducers:
             out["comm"] = pipe.comm_report()
+        out["config"]["batches"] = "one static synthetic batch replayed every step (the geometry is recomputed every step)"
         if args.share_device:
             out["data"] += " [--share-device validation run: all ranks on one GPU, throughput not meaningful]"
         print(json.dumps(_json_safe(out)))

@@ -827,6 +827,20 @@ class GradSink(object):
     def __init__(self):
         self.buf, self.readers = None, 0
 
+    def opened(self):
+        """called by the reader that allocates the buffer in a backward pass: at the END of that pass the buffer must have
+        been handed over.  It is not when some reader never ran -- a loss on an intermediate level only
+        (output_hidden_states), or a second backward over a retained graph --: the fixed tokens' gradient would silently be
+        None (the reference's cat-based autograd has no such failure mode), so fail loudly instead."""
+        def check():
+            if self.buf is not None:
+                n, self.buf, self.readers = self.readers, None, 0
+                raise RuntimeError("GradSink: the backward pass ended with %d twin level(s) that never ran their backward; the "
+                                   "image / object tokens' gradient would be lost.  The concatenation-free K/V node assumes ONE "
+                                   "backward through ALL twin levels (no loss on intermediate levels only, no retain_graph "
+                                   "re-runs): set fusion_ops._TWIN_KV[0] = False for such uses." % n)
+        torch.autograd.Variable._execution_engine.queue_callback(check)
+
 
 class _TwinKVFn(torch.autograd.Function):
     """Key / value projections of the two cross-attentions of one twin level WITHOUT the concatenations (reference
@@ -867,8 +881,13 @@ class _TwinKVFn(torch.autograd.Function):
         g2d, g3d = g2d.contiguous(), g3d.contiguous()
         outs = []
         for sink, enc in zip(ctx.sinks, (enc2d, enc3d)):
+            if sink.readers <= 0:
+                raise RuntimeError("GradSink: a twin level's backward ran a second time (retain_graph re-run?): the "
+                                   "concatenation-free K/V node supports one backward per forward "
+                                   "(fusion_ops._TWIN_KV[0] = False restores the cat-based composition)")
             if sink.buf is None:
                 sink.buf = torch.zeros(enc.shape[0] * enc.shape[1], D, dtype=torch.bfloat16, device=hs.device)
+                sink.opened()
             outs.append(sink.buf)
         dhs = torch.empty(2 * B * L, D, dtype=torch.bfloat16, device=hs.device)
         extra = _take_tap(ctx.tap, dhs)   # the states' gradient through the level's other readers, stacked rows

@@ -236,6 +236,24 @@ TRANSPOSED_DX = [True]
 _TSHADOW = {}
 _T_VERSIONS = {}
 _T_STATE = {"stale": True, "tables": {}, "dirty": True, "keep": []}
+_T_KEEP_MAX = 4   # generations kept alive without an owner (eager launches in flight, hand-made captures)
+
+
+class TransposedGeneration(object):
+    """One build of the refresh launch's device tables TOGETHER with the (src, dst) tensors its records point at.  A capture
+    that recorded the launch holds the generation it used (transposed_generation(): pipeline.PhasedTrainStep and
+    graphed.GraphedRunner keep it next to their graphs), so the operands a replayed refresh reads and writes cannot return to
+    the caching allocator while the graph lives -- a re-registration (load_state_dict allocates a new bf16 shadow) only makes
+    a NEW generation.  `_T_STATE["keep"]` holds the last few generations for launches nobody owns."""
+
+    def __init__(self, tables, pairs):
+        self.tables, self.pairs = tables, pairs
+
+
+def transposed_generation():
+    """the current generation object (None before the first build): keep a reference for as long as a captured graph may
+    replay the refresh launch"""
+    return _T_STATE.get("generation")
 
 
 def _cast_versions(params):
@@ -278,7 +296,15 @@ def transposed_shadow(params, wb):
         return None
     import weakref
     with torch.no_grad():
-        wt = wb.t().contiguous()
+        if ent is not None and all(r() is p for r, p in zip(ent[0], params)) and ent[2].shape == (wb.shape[1], wb.shape[0]) \
+                and ent[2].device == wb.device:
+            # the same parameters behind a NEW operand tensor (load_state_dict: _shadow() re-cast into a fresh tensor): the
+            # existing copy is rewritten in place -- whoever holds it (a captured graph's dX launches) keeps reading a live,
+            # current tensor; only the refresh table's source pointer changes (a new generation)
+            wt = ent[2]
+            wt.copy_(wb.t())
+        else:
+            wt = wb.t().contiguous()
     _TSHADOW[key] = ([weakref.ref(p) for p in params], wb.detach(), wt)
     _T_VERSIONS[key] = _cast_versions(params)
     _T_STATE["dirty"] = True
@@ -301,10 +327,13 @@ def refresh_transposed(device=None, max_wgs=0):
         by_dev = {}
         for ent in _TSHADOW.values():
             by_dev.setdefault(ent[1].device, []).append((ent[1], ent[2]))
-        # (the device tables a captured graph may still launch with stay alive; the operands they point at live as long as
-        # their parameters do, through the registry)
-        _T_STATE["keep"].append(_T_STATE["tables"])
+        # the previous generation (tables AND the tensors they point at) stays alive for whoever captured its launch
+        # (TransposedGeneration); without an owner it lives on in a bounded history
+        if _T_STATE.get("generation") is not None:
+            _T_STATE["keep"].append(_T_STATE["generation"])
+            del _T_STATE["keep"][:-_T_KEEP_MAX]
         _T_STATE["tables"] = {dev: _ext.transpose_table(pairs, dev) for dev, pairs in by_dev.items()}
+        _T_STATE["generation"] = TransposedGeneration(_T_STATE["tables"], [pr for prs in by_dev.values() for pr in prs])
         _T_STATE["dirty"] = False
     skipped = False
     for dev, (table, chunks) in _T_STATE["tables"].items():

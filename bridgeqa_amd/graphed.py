@@ -25,9 +25,20 @@ forward, gradients OVERWRITTEN per step (no accumulation over several backward c
 iteration), outputs valid until the next forward (they are rewritten in place); at the FIRST graphed forward no autograd
 graph of an earlier eager forward may still be alive (drop the previous outputs / loss: its AccumulateGrad nodes were born on
 the caller's stream and this runtime's hipStreamEndCapture faults on them).  Eval mode and `torch.no_grad()` take the
-ordinary eager path.  Without the next batch nothing can be prefetched: the sampling / grouping indices are computed
-inside the detector forward (PhasedTrainStep hides them under the fusion of the previous step; `prefetch()` below offers
-the same to a loop that can name its next point clouds).
+ordinary eager path.
+
+Round 5 additions, all outside the loop BODY:
+  * `prefetch_loader(model, dataloader)` around the loop's iterable (or `model._graphed.prefetch(next_point_clouds)`): the
+    NEXT batch's sampling / grouping indices (FPS, ball query, three-NN: coordinates only, no parameters) run on the
+    detector stream under THIS step's fusion, as pipeline.PhasedTrainStep does; without an announcement a step computes its
+    own geometry in front of its detector forward, as before.
+  * `wrap_optimizer(model, optimizer)`: `optimizer.step()` replays a captured graph of the fused update (and
+    `optimizer.zero_grad()` launches nothing: the captured backward overwrites every gradient).
+  * data parallel (`torchrun`, scripts/train.py:346-347 wraps the model in DistributedDataParallel): the replayed backward
+    runs no AccumulateGrad node, so DDP's reducer hooks would never fire and the replicas would silently diverge.
+    `enable()` therefore refuses a DDP-wrapped model and, when a process group with more than one rank is initialised,
+    exchanges the static gradients itself (ddp.PackedGradReducer: the fusion group under the image / detector backward,
+    the rest at the end of the backward), broadcasts rank 0's parameters once and its buffers before every forward.
 """
 import torch
 
@@ -37,11 +48,100 @@ from . import fusion_ops as ops
 _INPUT_KEYS = ("point_clouds", "images", "question", "answer")
 
 
-def enable(model, warmup=2):
+def enable(model, warmup=2, optimizer=None, comm_dtype=torch.float32, process_group=None, max_cached=2):
     """Put graph replay behind `model(data_dict)` / `loss.backward()` of a train-mode ScanQAHotPath (use_blip=True).
-    Returns the model (the runner is attached outside the module tree: state_dict keys do not change)."""
-    object.__setattr__(model, "_graphed", GraphedRunner(model, warmup=warmup))
+    Returns the model (the runner is attached outside the module tree: state_dict keys do not change).
+    optimizer: also wrap_optimizer(model, optimizer).  comm_dtype / process_group: the gradient exchange under
+    torch.distributed with more than one rank (fp32 on the wire = what the reference's DDP reduces in).
+    max_cached: captured graph sets kept per input signature (token length, batch size of a last partial batch): a change
+    of signature switches sets instead of re-capturing."""
+    from torch.nn.parallel import DistributedDataParallel
+    if isinstance(model, (DistributedDataParallel, torch.nn.DataParallel)):
+        raise TypeError("graphed.enable: the model is wrapped in DistributedDataParallel -- the replayed backward runs no "
+                        "AccumulateGrad node, so DDP's reducer would see every parameter as unused and the replicas would "
+                        "diverge without an error.  Call graphed.enable(model) on the plain module INSTEAD of the DDP wrap: "
+                        "under an initialised process group it exchanges the gradients itself (INTEGRATION.md section 3a).")
+    object.__setattr__(model, "_graphed", GraphedRunner(model, warmup=warmup, comm_dtype=comm_dtype,
+                                                        process_group=process_group, max_cached=max_cached))
+    if optimizer is not None:
+        wrap_optimizer(model, optimizer)
     return model
+
+
+def wrap_optimizer(model, optimizer):
+    """`optimizer.step()` of the unchanged loop as ONE graph replay (lib/solver.py:407-411: clip_grad_value_ +
+    optimizer.step(); optim.FusedAdamW(grad_clip_value=...) has the clip inside the update kernel), and
+    `optimizer.zero_grad()` without launches.  Only for optimizers whose step is capture-safe -- optim.FusedAdamW (step
+    count on the device, lr / weight decay re-read from a pinned table at every replay) or a torch optimizer constructed
+    with capturable=True; anything else is returned untouched.  The first wrapped step after a capture runs eagerly (the
+    optimizer state must exist before a graph can be recorded), the second records, later ones replay; a step that does
+    not follow a replayed backward (eval, an eager fallback) calls the optimizer itself."""
+    from .optim import FusedAdamW
+    runner = getattr(model, "_graphed", None)
+    capturable = isinstance(optimizer, FusedAdamW) or all(g.get("capturable", False) for g in optimizer.param_groups)
+    if runner is None or not capturable or getattr(optimizer, "_bq_graphed", None) is not None:
+        return optimizer
+    orig_step, orig_zero = optimizer.step, optimizer.zero_grad
+
+    def step(closure=None, **kw):
+        if closure is not None or kw or not runner.replayed_backward_pending():
+            return orig_step(closure, **kw) if (closure is not None or kw) else orig_step()
+        return runner.optimizer_step(optimizer, orig_step)
+
+    def zero_grad(set_to_none=True):
+        if runner.graphs is None:
+            return orig_zero(set_to_none=set_to_none)
+        # the captured backward OVERWRITES every gradient it produces (first write is an assignment): nothing to clear on
+        # the device; parameters outside the captured set keep torch's semantics
+        static = runner.static_grad_ids()
+        for g in optimizer.param_groups:
+            for p in g["params"]:
+                if id(p) not in static and p.grad is not None:
+                    if set_to_none:
+                        p.grad = None
+                    else:
+                        p.grad.zero_()
+    optimizer.step, optimizer.zero_grad = step, zero_grad
+    optimizer._bq_graphed = (orig_step, orig_zero)
+    return optimizer
+
+
+class prefetch_loader(object):
+    """`for data_dict in graphed.prefetch_loader(model, dataloader):` -- the loop body stays the reference's
+    (lib/solver.py:475-545).  Looks ONE batch ahead and announces its point clouds to the runner, which computes their
+    sampling / grouping indices on the detector stream under the fusion of the step that is about to run; every yielded
+    dict carries a string key (`"_bq_geometry_key"`; the solver's `.cuda()` loop leaves strings alone, :480-483) by which
+    the forward recognises the batch the prefetched indices belong to.  Attribute access (`.dataset`, `len()`) falls
+    through to the wrapped loader."""
+
+    def __init__(self, model, loader):
+        self._model, self._loader, self._epoch = model, loader, 0
+
+    def __len__(self):
+        return len(self._loader)
+
+    def __getattr__(self, name):
+        return getattr(self._loader, name)
+
+    def __iter__(self):
+        self._epoch += 1
+        it = iter(self._loader)
+        try:
+            cur = next(it)
+        except StopIteration:
+            return
+        n = 0
+        while True:
+            nxt = next(it, None)
+            runner = getattr(self._model, "_graphed", None)
+            if isinstance(cur, dict):
+                cur["_bq_geometry_key"] = "%d:%d:%d" % (id(self), self._epoch, n)
+                if runner is not None and isinstance(nxt, dict) and torch.is_tensor(nxt.get("point_clouds")):
+                    runner.prefetch(nxt["point_clouds"], key="%d:%d:%d" % (id(self), self._epoch, n + 1))
+            yield cur
+            if nxt is None:
+                return
+            cur, n = nxt, n + 1
 
 
 def wrap_loss(model, fn):
@@ -127,16 +227,37 @@ def _rebuild(x, repl, path=()):
 
 
 class GraphedRunner(object):
-    def __init__(self, model, warmup=2):
+    # what one capture owns (a change of input signature stashes the set and restores / captures another: `_cache`)
+    _BUNDLE = ("graphs", "sig", "static_in", "diff", "static_grads", "_st", "static_param_grads", "out_keys", "losses", "_pools",
+               "anchor", "_geo_next", "_geo_cur", "next_xyz", "_geo_key", "_t_generation", "opt_graphs", "_static_ids")
+
+    def __init__(self, model, warmup=2, comm_dtype=torch.float32, process_group=None, max_cached=2):
         self.model, self.warmup = model, int(warmup)
         self.graphs = None
         self.sig = None
         self.step_id = 0
         self._bwd_done = True
-        self._geo_next = None
+        self._opt_pending = False
         self.losses = {}      # wrap_loss: signature -> captured loss (graphs, static label buffers, result template)
         self.host_times = None   # set to {} to record the host time of every graph launch (ms, per graph)
         self.phase_events = None # set to {} to bracket every graph with events on its stream (phase_gpu_ms())
+        # geometry prefetch (prefetch() / prefetch_loader): off until the first announcement
+        self.prefetching = False
+        self._geo_next = self._geo_cur = self.next_xyz = None
+        self._geo_key = None        # which batch the indices in `_geo_next` belong to
+        self._announced = None      # (point clouds, key) of the batch to compute under the NEXT forward's fusion
+        self._t_generation = None
+        self.opt_graphs = {}
+        self._static_ids = frozenset()
+        # signature -> stashed capture (LRU); `captures` counts them (a loader with varying token length re-captures on
+        # every new length: pad to a fixed length, or raise max_cached)
+        import collections
+        self._cache, self.max_cached, self.captures = collections.OrderedDict(), max(1, int(max_cached)), 0
+        # data parallel: the replayed backward fires no DDP hook -- the runner exchanges the static gradients itself
+        self.comm_dtype, self.process_group = comm_dtype, process_group
+        self.reducers, self.broadcaster, self.force_comm = None, None, False
+        self.s_comm, self._comm_events = None, []
+        self._streams_ready = False
 
     # ---- what can be replayed --------------------------------------------------------------------------------------
     def usable(self, data_dict):
@@ -176,11 +297,26 @@ class GraphedRunner(object):
     def _image_fwd(self, st):
         ops.new_step(self.dev)
         st["img"] = self.model.encode_image(self._inputs())
-        # the K-contiguous weight copies of this step's text-side input-gradient GEMMs (fusion_state.transposed_shadow),
-        # re-transposed from what the caller's optimizer.step() left: here the main phase stream idles until the detector
-        # forward (the longer of the two in this loop) hands over
+
+    def _t_refresh(self, st):
+        """the K-contiguous weight copies of this step's input-gradient GEMMs (fusion_state.transposed_shadow),
+        re-transposed from what the caller's optimizer.step() left: detector stream, behind the detector forward, beside the
+        fusion's forward chain (pipeline.PhasedTrainStep's t_refresh phase); the fusion backward waits for it"""
         if ops.TRANSPOSED_DX[0] and not (torch.cuda.is_current_stream_capturing() and ops._T_STATE["dirty"]):
             ops.refresh_transposed(self.dev)
+
+    def _geometry(self, st):
+        """sampling / grouping indices of the point clouds in `next_xyz` into the persistent `_geo_next` set
+        (Pointnet2Backbone.precompute_geometry: FPS picks, centres, ball-query groups of the four SA levels, three-NN of
+        the two FP levels -- coordinates only)"""
+        from .pointnet2_utils import background_geometry
+        with background_geometry():   # (the gentle ball-query grid: this phase runs beside the fusion chain)
+            geo = self.model.detection_backbone.precompute_geometry(self.next_xyz)
+        if self._geo_next is None:
+            self._geo_next = {k: v.clone() for k, v in geo.items()}
+        else:
+            for k, v in geo.items():
+                self._geo_next[k].copy_(v)
 
     def _det_fwd(self, st):
         dd = self._inputs()
@@ -189,8 +325,14 @@ class GraphedRunner(object):
         # text_prep / text_prep_bwd phases)
         bm = self.model.blip_model
         st["prep"] = bm.prepare_text(dd["question"], dd.get("answer"), self.dev) if hasattr(bm, "prepare_text") else None
-        if self._geo_next is not None:
-            dd["geometry"] = self._geo_next
+        if self.prefetching:
+            # next -> cur: this step's backward keeps reading `cur` while the prefetch under its fusion refills `next`
+            if self._geo_cur is None:
+                self._geo_cur = {k: v.clone() for k, v in self._geo_next.items()}
+            else:
+                for k, v in self._geo_next.items():
+                    self._geo_cur[k].copy_(v)
+            dd["geometry"] = self._geo_cur
         st["dd"] = self.model.detect_objects(dd)
 
     def _fusion_fwd(self, st):
@@ -247,13 +389,31 @@ class GraphedRunner(object):
         detector forward -- ~490 nodes with its sampling chain -- launched first, the image encoder's graph reached its
         queue 8.5 ms later and the two ran back to back).  The shorter graph of each concurrent pair goes first."""
         cur = torch.cuda.current_stream(self.dev)
+        if self.broadcaster is not None:
+            self.broadcaster.broadcast()   # DDP's broadcast_buffers=True: rank 0's BatchNorm statistics before the forward
         for s_ in (self.s_main, self.s_det):
             s_.wait_stream(cur)
         with torch.cuda.stream(self.s_main):
             run("image_fwd")
         with torch.cuda.stream(self.s_det):
+            if self.prefetching and not self._geo_ready:
+                # nobody announced THIS batch a step ahead (first step, an epoch's first batch, a loop without
+                # prefetch_loader): its indices are computed here, in front of the detector forward
+                self.next_xyz.copy_(self.static_in["point_clouds"][..., :3])
+                run("geometry")
             run("det_fwd")
             self.e_det_fwd.record(self.s_det)
+            if self.prefetching and self._announced is not None:
+                nxt, key = self._announced
+                self._announced = None
+                self.next_xyz.copy_(nxt[..., :3], non_blocking=True)
+                run("geometry")              # the NEXT batch's indices, under this step's fusion
+                self._geo_key = key
+            elif self.prefetching:
+                self._geo_key = None         # `_geo_next` still holds this batch's indices: nothing announced
+            if ops.TRANSPOSED_DX[0]:
+                run("t_refresh")
+            self.e_t_refresh.record(self.s_det)
         with torch.cuda.stream(self.s_main):
             self.s_main.wait_event(self.e_det_fwd)
             run("fusion_fwd")
@@ -275,6 +435,7 @@ class GraphedRunner(object):
                     else:
                         buf.copy_(g, non_blocking=True)
             self.e_grads.record(self.s_main)
+            self.s_main.wait_event(self.e_t_refresh)
             run("fusion_bwd")
             self.e_fused.record(self.s_main)
             run("image_bwd")      # (before the detector's: see _forward_phases)
@@ -284,11 +445,33 @@ class GraphedRunner(object):
         with torch.cuda.stream(self.s_det):
             run("det_bwd")
             self.e_det_bwd.record(self.s_det)
+        if self._probe is not None:
+            self._probe("end")
         cur.wait_event(self.e_img_bwd)
         cur.wait_event(self.e_det_bwd)
+        if self.reducers:
+            # data parallel: the fusion group (3/4 of the bytes: gradients complete when fusion_bwd ends) travels on the
+            # communication stream under the image / detector backward, the rest when both have finished
+            sc = self.s_comm
+            sc.wait_event(self.e_fused)
+            with torch.cuda.stream(sc):
+                if "fusion" in self.reducers:
+                    self.reducers["fusion"].all_reduce()
+                sc.wait_event(self.e_img_bwd)
+                sc.wait_event(self.e_det_bwd)
+                if "rest" in self.reducers:
+                    self.reducers["rest"].all_reduce()
+                self.e_comm.record(sc)
+            cur.wait_event(self.e_comm)
+
+    _probe = None   # capture(): called with the phase name after every eager phase of the last warm-up pass
 
     def _eager(self, st):
-        return lambda name: getattr(self, "_" + name)(st)
+        def run(name):
+            getattr(self, "_" + name)(st)
+            if self._probe is not None:
+                self._probe(name)
+        return run
 
     def _replay(self, name):
         if self.host_times is None and self.phase_events is None:
@@ -322,10 +505,12 @@ class GraphedRunner(object):
         # side stream) is enqueued node by node by this runtime -- 8.8 ms of host time for the fusion forward, which then
         # ran 12.2 ms on the GPU instead of ~4.5
         prev = ops.set_overlap(False)
+        announced, self._announced = self._announced, None   # (the warm-up passes must not consume the announcement)
         try:
             self._capture(data_dict)
         finally:
             ops.set_overlap(prev)
+            self._announced = announced
 
     def _capture(self, data_dict):
         m = self.model
@@ -337,10 +522,18 @@ class GraphedRunner(object):
         self.dev = dev = data_dict["point_clouds"].device
         self.static_in = {k: ({kk: (t.clone() if torch.is_tensor(t) else t) for kk, t in v.items()} if isinstance(v, dict)
                               else v.clone()) for k, v in ((k, data_dict[k]) for k in _INPUT_KEYS)}
-        self.s_main = torch.cuda.Stream(device=dev, priority=-1)
-        self.s_det = torch.cuda.Stream(device=dev, priority=0)
-        (self.e_det_fwd, self.e_fwd, self.e_grads, self.e_fused, self.e_det_bwd, self.e_img_bwd, self.e_loss) = (torch.cuda.Event() for _ in range(7))
+        if not self._streams_ready:   # (streams and events are shared by every captured set of this runner)
+            self.s_main = torch.cuda.Stream(device=dev, priority=-1)
+            self.s_det = torch.cuda.Stream(device=dev, priority=0)
+            (self.e_det_fwd, self.e_fwd, self.e_grads, self.e_fused, self.e_det_bwd, self.e_img_bwd, self.e_loss,
+             self.e_t_refresh, self.e_opt, self.e_comm) = (torch.cuda.Event() for _ in range(10))
+            self._streams_ready = True
+            self._setup_data_parallel(dev)
         self.anchor = torch.zeros(1, device=dev, requires_grad=True)
+        self._geo_next = self._geo_cur = None
+        self._geo_key, self._geo_ready = None, False
+        self.next_xyz = data_dict["point_clouds"][..., :3].contiguous().clone() if self.prefetching else None
+        self.opt_graphs = {}
         params = [p for p in m.parameters() if p.requires_grad]
         # warm-up: eager steps on the phase streams (autograd's AccumulateGrad nodes remember the stream they were born on;
         # kernels compile / caches fill), seeded with ones; buffers (BatchNorm statistics) and gradients put back afterwards
@@ -350,12 +543,25 @@ class GraphedRunner(object):
         for p in params:
             p.grad = None
         st = {}
-        for _ in range(max(1, self.warmup)):
+        seen = {}     # data parallel: which gradients exist when the fusion backward ends, and which of them a LATER phase
+        #               accumulates into (the token embeddings: text_prep's backward runs inside det_bwd)
+
+        def probe(name):
+            if name == "fusion_bwd":
+                seen["fusion"] = {id(p): p.grad._version for p in params if p.grad is not None}
+            elif name == "end":
+                seen["late"] = {id(p) for p in params if p.grad is not None
+                                and seen["fusion"].get(id(p), -1) != p.grad._version}
+                seen["all"] = [p for p in params if p.grad is not None]
+        n_warm = max(1, self.warmup)
+        for it in range(n_warm):
             st = {}
+            self._probe = probe if it == n_warm - 1 else None
             self._forward_phases(self._eager(st))
             self.diff = self._diff_outputs(st)
             self.static_grads = [torch.ones_like(t) * 1e-3 for _, t, _ in self.diff]
             self._backward_phases(self._eager(st), None)
+            self._probe = None
             for p in params:
                 p.grad = None
         torch.cuda.synchronize(dev)
@@ -365,20 +571,25 @@ class GraphedRunner(object):
                     v.copy_(saved_buf[k])
         if ops.TRANSPOSED_DX[0]:
             ops.refresh_transposed(dev)   # (builds the device table of what the warm-up registered: not possible inside a capture)
-        # capture: one graph per phase, a pool per stream (the two streams' graphs run concurrently)
-        pools = self._pools = {"main": torch.cuda.graph_pool_handle(), "det": torch.cuda.graph_pool_handle()}
+            self._t_generation = ops.transposed_generation()   # (its tables and operands live as long as these graphs)
+        # capture: one graph per phase, a pool per stream (the two streams' graphs run concurrently); the geometry and the
+        # weight-copy refresh in pools of their own (they replay out of capture order: before OR after the detector forward)
+        pools = self._pools = {"main": torch.cuda.graph_pool_handle(), "det": torch.cuda.graph_pool_handle(),
+                               "geo": torch.cuda.graph_pool_handle(), "aux": torch.cuda.graph_pool_handle()}
         self.losses = {}
-        order = (("image_fwd", "main"), ("det_fwd", "det"), ("fusion_fwd", "main"), ("fusion_bwd", "main"), ("image_bwd", "main"),
-                 ("det_bwd", "det"))
+        order = (("image_fwd", "main", "main"),) + ((("geometry", "det", "geo"),) if self.prefetching else ()) + (
+            ("det_fwd", "det", "det"),) + ((("t_refresh", "det", "aux"),) if ops.TRANSPOSED_DX[0] else ()) + (
+            ("fusion_fwd", "main", "main"),
+            ("fusion_bwd", "main", "main"), ("image_bwd", "main", "main"), ("det_bwd", "det", "det"))
         st, graphs = {}, {}
         streams = {"main": self.s_main, "det": self.s_det}
-        for name, which in order:
+        for name, which, pool in order:
             if name == "fusion_bwd":
                 self.diff = self._diff_outputs(st)
                 self.static_grads = [torch.zeros_like(t) for _, t, _ in self.diff]
             g = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(g, pool=pools[which], stream=streams[which]):
+                with torch.cuda.graph(g, pool=pools[pool], stream=streams[which]):
                     getattr(self, "_" + name)(st)
             except Exception as e:
                 raise RuntimeError("graphed.enable: phase '%s' could not be captured: %s" % (name, e)) from e
@@ -387,20 +598,95 @@ class GraphedRunner(object):
         self._st = st                       # keeps the captured autograd graph and the static outputs alive
         self.graphs = graphs
         self.static_param_grads = [(p, p.grad) for p in params if p.grad is not None]
+        self._static_ids = frozenset(id(p) for p, _ in self.static_param_grads)
         for p, g in zip(params, saved_grad):
             p.grad = g
         self.out_keys = [k for k, _, _ in self.diff]
         self.sig = self._signature(data_dict)
+        self.captures += 1
+        if self.captures == 4:
+            import warnings
+            warnings.warn("graphed: %d captures so far -- every new input signature (token length under padding='longest', a "
+                          "last partial batch, a BatchNorm-momentum step) costs warm-up steps, eight captures and a memory pool "
+                          "of its own; pad the tokens to a fixed length / drop_last, or raise enable(max_cached=)" % self.captures)
+        if self._comm_on() and self.reducers is None:
+            self._build_reducers(seen)
+        elif self.reducers:
+            covered = {id(p) for r in self.reducers.values() for p in r.params}
+            if covered != set(self._static_ids):
+                raise RuntimeError("graphed: this capture produces gradients for a different parameter set than the one the "
+                                   "gradient exchange was built for")
+
+    # ---- data parallel ------------------------------------------------------------------------------------------------
+    def _comm_on(self):
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.process_group) > 1 or self.force_comm)
+
+    def _setup_data_parallel(self, dev):
+        """what DDP's constructor does once (scripts/train.py:346-347): every replica starts from rank 0's parameters and
+        buffers; and its broadcast_buffers=True: rank 0's buffers before every forward"""
+        if not self._comm_on():
+            return
+        from . import ddp
+        ddp.broadcast_parameters(self.model, 0, self.process_group)
+        ops.refresh_shadows(only_with_grad=False)
+        self.broadcaster = ddp.BufferBroadcaster(self.model, 0, self.process_group)
+        self.broadcaster.force = self.force_comm
+        self.s_comm = torch.cuda.Stream(device=dev)
+
+    def _build_reducers(self, seen):
+        from . import ddp
+        fusion = [p for p in seen["all"] if id(p) in seen["fusion"] and id(p) not in seen["late"]]
+        fid = {id(p) for p in fusion}
+        rest = [p for p in seen["all"] if id(p) not in fid]
+        missing = set(self._static_ids) ^ {id(p) for p in seen["all"]}
+        if missing:
+            raise RuntimeError("graphed: the warm-up pass and the captured pass disagree on which parameters receive gradients")
+        self.reducers = {}
+        for name, ps in (("fusion", fusion), ("rest", rest)):
+            if ps:
+                r = ddp.PackedGradReducer(ps, comm_dtype=self.comm_dtype, process_group=self.process_group)
+                r.force = self.force_comm
+                self.reducers[name] = r
+
+    # ---- capture cache ------------------------------------------------------------------------------------------------
+    def _stash(self):
+        if self.graphs is not None and self.sig is not None:
+            self._cache[self.sig] = {k: getattr(self, k, None) for k in self._BUNDLE}
+            self._cache.move_to_end(self.sig)
+            while len(self._cache) > self.max_cached:
+                self._cache.popitem(last=False)
+
+    def _switch(self, data_dict):
+        """the captured set for this input signature: the current one, a cached one, or a new capture"""
+        sig = self._signature(data_dict)
+        if self.graphs is not None and sig == self.sig:
+            return
+        self._stash()
+        hit = self._cache.pop(sig, None)
+        if hit is not None and (hit.get("next_xyz") is not None) == self.prefetching:
+            for k, v in hit.items():
+                setattr(self, k, v)
+            self._geo_key = None          # (its prefetched indices are from another time)
+            return
+        self.graphs = None
+        self.capture(data_dict)
 
     # ---- the two calls ------------------------------------------------------------------------------------------------
     def forward(self, data_dict):
-        if self.graphs is None or self._signature(data_dict) != self.sig:
-            self.graphs = None
-            self.capture(data_dict)
+        self._switch(data_dict)
         if not self._bwd_done:
             pass   # (a forward without a backward -- e.g. a skipped step -- is fine: the next replay overwrites everything)
         self.step_id += 1
         self._bwd_done = False
+        self._opt_pending = False
+        if self.prefetching:
+            # do the indices in `_geo_next` belong to THIS batch?  prefetch_loader's string key, or the very tensor that
+            # was announced (same object, not written since)
+            pc = data_dict["point_clouds"]
+            key = data_dict.get("_bq_geometry_key")
+            self._geo_ready = self._geo_key is not None and (
+                (key is not None and key == self._geo_key) or self._geo_key == ("tensor", id(pc), pc._version))
         self._copy_inputs(data_dict)
         self._forward_phases(self._replay)
         # (DETACHED inputs: an edge into the captured autograd graph would make this backward walk it eagerly)
@@ -538,10 +824,9 @@ class GraphedRunner(object):
                     seed.copy_(g, non_blocking=True)
             rec["g_b"].replay()
         self._bwd_done = True
+        self._point_grads()
         self._backward_phases(self._replay, None, seeded=True)
-        for p, g in self.static_param_grads:
-            if p.grad is not g:
-                p.grad = g
+        self._opt_pending = True
 
     def run_backward(self, step_id, grads):
         if step_id != self.step_id:
@@ -549,12 +834,79 @@ class GraphedRunner(object):
         if self._bwd_done:
             raise RuntimeError("graphed: one backward per forward (the captured graphs overwrite the gradients)")
         self._bwd_done = True
+        self._point_grads()
         self._backward_phases(self._replay, grads)
-        for p, g in self.static_param_grads:   # (an optimizer.zero_grad() before the backward set them to None)
+        self._opt_pending = True
+
+    def _point_grads(self):
+        """`p.grad` = the static gradient the captured backward writes (an optimizer.zero_grad() before the backward set it
+        to None); done BEFORE the replay is enqueued: the gradient exchange reads p.grad when it is issued"""
+        for p, g in self.static_param_grads:
             if p.grad is not g:
                 p.grad = g
 
-    def prefetch(self, next_point_clouds):
-        """optional: the NEXT step's sampling / grouping indices now, on the detector stream (beside whatever runs) -- the
-        following forward uses them instead of computing them in its detector phase.  Needs a re-capture the first time."""
-        raise NotImplementedError("graphed.prefetch: use pipeline.PhasedTrainStep(next_batch=...) for the prefetching schedule")
+    def static_grad_ids(self):
+        return self._static_ids
+
+    # ---- the caller's optimizer under replay (wrap_optimizer) -------------------------------------------------------------
+    def replayed_backward_pending(self):
+        return self.graphs is not None and self._bwd_done and self._opt_pending
+
+    def optimizer_step(self, opt, orig_step):
+        self._opt_pending = False
+        rec = self.opt_graphs.setdefault(id(opt), {"n": 0, "g": None})
+        cur = torch.cuda.current_stream(self.dev)
+        if rec["g"] is None:
+            rec["n"] += 1
+            if rec["n"] < 2:
+                return orig_step()            # eager: the optimizer's state (moments, device tables) comes into being
+            self.s_main.wait_stream(cur)
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            if "opt" not in self._pools:
+                self._pools["opt"] = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(g, pool=self._pools["opt"], stream=self.s_main):
+                orig_step()
+            rec["g"] = g
+        if hasattr(opt, "sync_hyperparams"):
+            opt.sync_hyperparams()            # LR schedulers act on param_groups; the captured launch reads the pinned table
+        self.s_main.wait_stream(cur)
+        with torch.cuda.stream(self.s_main):
+            self._replay_named("optimizer", rec["g"])
+            self.e_opt.record(self.s_main)
+        cur.wait_event(self.e_opt)
+        # (no Python runs in a replay: the post-step hook that marks the K-contiguous weight copies stale did not fire)
+        ops.mark_transposed_stale()
+        return None
+
+    def _replay_named(self, name, g):
+        if self.host_times is None and self.phase_events is None:
+            g.replay()
+            return
+        saved, self.graphs = self.graphs, dict(self.graphs, **{name: g})
+        try:
+            self._replay(name)
+        finally:
+            self.graphs = saved
+
+    # ---- geometry prefetch ------------------------------------------------------------------------------------------------
+    def prefetch(self, next_point_clouds, key=None):
+        """Announce the point clouds of the NEXT step ((B, N, 3 + C) or (B, N, 3), host or device): their sampling /
+        grouping indices are computed on the detector stream behind the detector forward of the forward that is called
+        next, i.e. under its fusion -- and used by the forward after that instead of being computed in front of its
+        detector phase (3.7 ms of the c3 step).  key: how that later forward recognises its batch -- `data_dict
+        ["_bq_geometry_key"]` (prefetch_loader sets it); default: the announced tensor object itself.  The first
+        announcement switches the runner to the prefetching schedule (one re-capture: the detector forward then takes
+        the indices as an input)."""
+        if not torch.is_tensor(next_point_clouds) or next_point_clouds.dim() != 3 or next_point_clouds.shape[-1] < 3:
+            raise ValueError("graphed.prefetch: point clouds of shape (B, N, >= 3) expected")
+        if key is None:
+            key = ("tensor", id(next_point_clouds), next_point_clouds._version)
+        if not self.prefetching:
+            self.prefetching = True
+            self._stash()
+            self._cache.clear()
+            self.graphs = None               # re-capture with the geometry as a phase of its own
+        if self.next_xyz is not None and tuple(next_point_clouds.shape[:2]) != tuple(self.next_xyz.shape[:2]):
+            return                            # (a batch of another shape: its forward computes its own indices)
+        self._announced = (next_point_clouds, key)

@@ -554,6 +554,9 @@ class PhasedTrainStep(object):
         self._state = {}
         if self.t_refresh:
             ops.refresh_transposed(self.dev)   # (builds the device table of what the warm-up registered: not possible inside a capture)
+            # the captured t_refresh launch reads this generation's tables: they (and the operands they point at) live as
+            # long as these graphs do
+            self._t_generation = ops.transposed_generation()
         pools = {"main": torch.cuda.graph_pool_handle(), "det": torch.cuda.graph_pool_handle()}
         # every phase graph SINGLE-STREAM (no fusion_ops.fork inside: the decoder's hoisted K/V projection stays on the
         # chain's stream): this runtime enqueues a graph with an internal fork node by node -- the fusion graph's launch held
@@ -595,6 +598,11 @@ class PhasedTrainStep(object):
             self.graphs = None
             self.capture(warmup=0, _again=True)
         self._schedule(eager=False)
+        if self.opt is not None:
+            # the captured optimizer launch runs no Python: the post-step hook that marks the K-contiguous weight copies
+            # stale did not fire, and an EAGER backward between two replays would read copies one update old
+            # (tests/test_pipeline_gpu.py::test_transposed_copies_after_replayed_steps)
+            ops.mark_transposed_stale()
         self._steps += 1
         if self.reducers and self.coverage_every > 0 and self._steps % self.coverage_every == 0:
             from .ddp import check_coverage

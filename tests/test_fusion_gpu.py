@@ -288,6 +288,23 @@ def test_twin_kv_equals_concatenated_projections(dev, bf16, B, P2, P3, L, D):
         assert sinks[0].buf is None and sinks[0].readers == 0
 
 
+def test_grad_sink_fails_loudly_when_a_level_never_runs_its_backward(dev, bf16):
+    """a loss that depends on an intermediate twin level only (output_hidden_states) leaves a reader of the
+    GradSink without a backward -- the fixed tokens' gradient used to come back as None with no error"""
+    from bridgeqa_amd import fusion_ops as ops
+    B, P2, P3, L, D = 2, 70, 9, 5, 256
+    g = torch.Generator().manual_seed(3)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev)
+    e2, e3 = mk(B, P2, D).to(torch.bfloat16).requires_grad_(True), mk(B, P3, D).to(torch.bfloat16).requires_grad_(True)
+    lins = [[torch.nn.Linear(D, D).to(dev) for _ in range(4)] for _ in range(2)]
+    hl = [mk(2 * B, L, D).to(torch.bfloat16).requires_grad_(True) for _ in range(2)]
+    sinks = (ops.GradSink(), ops.GradSink())
+    outs = [ops.twin_kv(e2, e3, hl[lv], lins[lv][0:2], lins[lv][2:4], sinks[0], sinks[1]) for lv in range(2)]
+    with pytest.raises(RuntimeError, match="GradSink"):
+        (outs[0][0].float().sum() + outs[0][1].float().sum()).backward()   # level 1 never differentiated
+    assert sinks[0].buf is None and sinks[0].readers == 0                # (reset: the sink does not poison later passes)
+
+
 def test_decoder_hoisted_cross_kv_equals_per_layer_projections(dev, bf16):
     """plain encoder / decoder: the key / value projections of all layers' cross-attentions as ONE GEMM over the shared
     encoder states (ops.HoistedKV, gradients written in place into one buffer) against the per-layer projections"""

@@ -187,3 +187,166 @@ def test_graphed_forward_keeps_the_module_api(dev):
         assert model(dict(batch))["blip_loss"].grad_fn is not None
     finally:
         ops.set_compute_dtype(prev)
+
+
+def _batches(dev, n, B=2):
+    import bench
+
+    class A(object):
+        points, cin, image = 4096, 4, 64
+    return [bench.make_batch(A, "c3", B, 20 + i, dev) for i in range(n)]
+
+
+def test_prefetch_loader_feeds_the_next_batchs_geometry_with_changing_batches(dev):
+    """graphed.prefetch_loader around the loop's iterable: with a DIFFERENT batch every step the
+    prefetched sampling / grouping indices must be the announced batch's -- every index output equals the eager forward of
+    that batch exactly, losses agree -- also for a batch nobody announced (the first, and one fed around the loader) and
+    across two epochs; the loop body is the reference's (lib/solver.py:475-545), including its `.cuda()` sweep that leaves
+    the string key alone"""
+    import bench
+    from bridgeqa_amd import fusion_ops as ops, graphed
+    prev = ops.set_compute_dtype(torch.bfloat16)
+    try:
+        model, _ = _setup(dev)
+        batches = _batches(dev, 4)
+        idx_keys = ("fp2_inds", "sa1_inds", "sa2_inds", "aggregated_vote_inds")
+        want = []
+        for b in batches:
+            with torch.no_grad():
+                dd = model(dict(b))
+            want.append(({k: dd[k].clone() for k in idx_keys}, dd["blip_loss"].item(), dd["fp2_xyz"].clone()))
+        del dd
+        graphed.enable(model)
+        loss_fn = graphed.wrap_loss(model, bench.total_loss)
+        seen = 0
+        for epoch in range(2):
+            for i, data_dict in enumerate(graphed.prefetch_loader(model, [dict(b) for b in batches])):
+                for key in data_dict:                       # the solver's "move to cuda" sweep (solver.py:477-485)
+                    if type(data_dict[key]) is dict:
+                        data_dict[key] = {k: v.cuda() for k, v in data_dict[key].items()}
+                    elif type(data_dict[key]) is list or type(data_dict[key]) is str:
+                        pass
+                    else:
+                        data_dict[key] = data_dict[key].cuda()
+                dd = model(data_dict)
+                for k in idx_keys:
+                    assert torch.equal(dd[k], want[i][0][k]), (epoch, i, k)
+                assert torch.equal(dd["fp2_xyz"], want[i][2]), (epoch, i)
+                assert abs(dd["blip_loss"].item() - want[i][1]) <= 2e-2 * abs(want[i][1]), (epoch, i)
+                loss_fn(dd).backward()
+                seen += 1
+        runner = model._graphed
+        assert seen == 8 and runner.prefetching and "geometry" in runner.graphs and runner.captures <= 2
+        # a batch fed AROUND the loader (no key, never announced): computes its own indices in front of its detector forward
+        dd = model(dict(batches[2]))
+        assert torch.equal(dd["fp2_inds"], want[2][0]["fp2_inds"])
+        bench.total_loss(dd).backward()
+        # the announcement by tensor identity (runner.prefetch without a key)
+        runner.prefetch(batches[1]["point_clouds"])
+        dd = model(dict(batches[3])); bench.total_loss(dd).backward()
+        dd = model(dict(batches[1]))
+        assert runner._geo_ready and torch.equal(dd["sa2_inds"], want[1][0]["sa2_inds"])
+        bench.total_loss(dd).backward()
+        torch.cuda.synchronize()
+        graphed.disable(model)
+    finally:
+        ops.set_compute_dtype(prev)
+
+
+def test_wrapped_optimizer_replays_the_same_update(dev):
+    """graphed.wrap_optimizer: optimizer.step() of the unchanged loop as one graph replay -- bit-identical to the eager
+    launch of the same FusedAdamW step from the same parameters, gradients and moments; zero_grad launches nothing and
+    leaves the static gradients attached; the K-contiguous weight copies are marked stale after a replayed update"""
+    import bench
+    from bridgeqa_amd import fusion_ops as ops, graphed
+    from bridgeqa_amd.optim import FusedAdamW
+    prev = ops.set_compute_dtype(torch.bfloat16)
+    try:
+        model, batch = _setup(dev)
+        opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=1e-2, grad_clip_value=1.0)
+        graphed.enable(model, optimizer=opt)
+        loss_fn = graphed.wrap_loss(model, bench.total_loss)
+        runner = model._graphed
+
+        def fwd_bwd():
+            loss = loss_fn(model(dict(batch)))
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            return loss
+        for _ in range(3):                      # eager update, recorded update, first pure replay
+            fwd_bwd(); opt.step()
+        assert runner.opt_graphs[id(opt)]["g"] is not None
+        fwd_bwd()
+        torch.cuda.synchronize()
+        params = [p for p in model.parameters() if p.grad is not None]
+        assert len(params) == len(runner.static_param_grads)
+        snap = [(p.detach().clone(), opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()) for p in params]
+        step0 = opt._step_t.clone()
+        ops._T_STATE["stale"] = False
+        opt.step()                              # replay
+        torch.cuda.synchronize()
+        assert ops._T_STATE["stale"] and float(opt._step_t) == float(step0) + 1
+        got = [p.detach().clone() for p in params]
+        with torch.no_grad():
+            for p, (p0, m0, v0) in zip(params, snap):
+                p.copy_(p0); opt.state[p]["exp_avg"].copy_(m0); opt.state[p]["exp_avg_sq"].copy_(v0)
+            opt._step_t.copy_(step0)
+        opt._bq_graphed[0]()                    # the optimizer's own step, launched eagerly on the same inputs
+        torch.cuda.synchronize()
+        for p, g in zip(params, got):
+            assert torch.equal(p.detach(), g)
+        # zero_grad under replay: nothing launched, static gradients stay attached
+        gid = [id(p.grad) for p in params]
+        opt.zero_grad(set_to_none=True)
+        assert [id(p.grad) for p in params] == gid
+        graphed.disable(model)
+    finally:
+        ops.set_compute_dtype(prev)
+
+
+def test_enable_refuses_a_ddp_wrap_and_exchanges_gradients_itself_on_rccl_world_1(dev):
+    """the replayed backward runs no AccumulateGrad node, so DistributedDataParallel's reducer never
+    fires -- enable() refuses a DDP-wrapped model, and under an initialised process group the runner exchanges the static
+    gradients itself (forced at world 1 over the real RCCL backend: same gradients as without any exchange, every gradient
+    covered by exactly one group, the token embeddings in the late group)"""
+    import os
+    import torch.distributed as dist
+    import bench
+    from bridgeqa_amd import fusion_ops as ops, graphed
+    prev = ops.set_compute_dtype(torch.bfloat16)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group(backend="nccl", init_method="env://", rank=0, world_size=1)
+    try:
+        model, batch = _setup(dev)
+        with pytest.raises(TypeError, match="DistributedDataParallel"):
+            graphed.enable(torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=True))
+        graphed.enable(model)
+        for _ in range(2):
+            bench.total_loss(model(dict(batch))).backward()
+        torch.cuda.synchronize()
+        assert model._graphed.reducers is None          # one rank: no exchange
+        want = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        graphed.disable(model)
+        graphed.enable(model)
+        model._graphed.force_comm = True                 # the world-1 collectives run for real
+        for _ in range(2):
+            bench.total_loss(model(dict(batch))).backward()
+        torch.cuda.synchronize()
+        runner = model._graphed
+        assert set(runner.reducers) == {"fusion", "rest"} and runner.broadcaster is not None
+        ids = [id(p) for r in runner.reducers.values() for p in r.params]
+        assert len(ids) == len(set(ids)) == len(want)
+        late = {id(p) for p in runner.reducers["rest"].params}
+        names = {id(p): n for n, p in model.named_parameters()}
+        assert any("embeddings" in names[i] for i in late) and any("visual_encoder" in names[i] for i in late)
+        assert all(names[id(p)].startswith("blip_model.") and "visual_encoder" not in names[id(p)]
+                   for p in runner.reducers["fusion"].params)
+        got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+        assert set(got) == set(want)
+        # (fp32 wire at world 1 is exact; what differs between two executions is the detector's fp32 atomics)
+        worst = max(((got[n] - want[n]).norm() / (want[n].norm() + 1e-12)).item() for n in want if n.startswith("blip_model."))
+        assert worst < 2e-2, worst
+        graphed.disable(model)
+    finally:
+        dist.destroy_process_group()
+        ops.set_compute_dtype(prev)

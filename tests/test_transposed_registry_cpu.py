@@ -24,7 +24,7 @@ def reg(monkeypatch):
     monkeypatch.setattr(_ext, "transpose_multi", multi)
     saved = (dict(ops._TSHADOW), dict(ops._T_VERSIONS), dict(ops._T_STATE))
     ops._TSHADOW.clear(); ops._T_VERSIONS.clear()
-    ops._T_STATE.update(stale=True, tables={}, dirty=True, keep=[])
+    ops._T_STATE.update(stale=True, tables={}, dirty=True, keep=[], generation=None)
     prev = ops.set_compute_dtype(torch.bfloat16)
     yield ops, launches
     ops.set_compute_dtype(prev)
@@ -79,3 +79,32 @@ def test_unsupported_operands_are_left_to_the_contraction_major_read(reg):
     finally:
         ops.TRANSPOSED_DX[0] = prev
     assert not ops._TSHADOW and not launches
+
+
+def test_a_generation_owns_its_operands_and_a_reregistration_rewrites_the_copy_in_place(reg):
+    """the refresh launch's table holds raw pointers -- the generation a capture used must keep the tensors behind
+    them alive, a re-registered operand (load_state_dict: a new bf16 shadow) must not orphan the copy a graph still reads,
+    and the history of unowned generations is bounded"""
+    ops, launches = reg
+    b = torch.nn.Parameter(torch.randn(64, 192))
+    wb = ops._shadow(b)
+    tb = ops.transposed_shadow((b,), wb)
+    ops.refresh_transposed()
+    gen = ops.transposed_generation()
+    assert gen is not None and any(src.data_ptr() == wb.data_ptr() and dst is tb for src, dst in gen.pairs)
+    with torch.no_grad():
+        b.copy_(torch.randn_like(b))                     # an update nobody announced: _shadow() re-casts into a NEW tensor
+    wb2 = ops._shadow(b)
+    assert wb2.data_ptr() != wb.data_ptr()
+    tb2 = ops.transposed_shadow((b,), wb2)
+    assert tb2 is tb and torch.equal(tb, wb2.t())       # the copy was rewritten in place, not replaced
+    ops.refresh_transposed()
+    gen2 = ops.transposed_generation()
+    assert gen2 is not gen and any(src.data_ptr() == wb2.data_ptr() for src, _ in gen2.pairs)
+    assert any(src.data_ptr() == wb.data_ptr() for src, _ in gen.pairs)   # the old generation still owns the old operand
+    for _ in range(10):                                  # unowned generations do not pile up
+        with torch.no_grad():
+            b.copy_(torch.randn_like(b))
+        ops.transposed_shadow((b,), ops._shadow(b))
+        ops.refresh_transposed()
+    assert len(ops._T_STATE["keep"]) <= ops._T_KEEP_MAX

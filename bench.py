@@ -1070,7 +1070,7 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             try:
-                out["loop_reference"] = run_reference_loop(args, model, batch, dev, use_graph, args.steps, args.warmup)
+                out["loop_reference"] = run_reference_loop(args, model, batch, dev, args.graph in ("on", "auto"), args.steps, args.warmup)
             except Exception as e:    # (the headline line must not be lost to the second measurement)
                 out["loop_reference"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if replicas_in_sync is not None:

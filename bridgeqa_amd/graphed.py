@@ -46,6 +46,9 @@ from . import fusion_ops as ops
 
 
 _INPUT_KEYS = ("point_clouds", "images", "question", "answer")
+# data_dict entries (host values) that change every iteration and that the loss does not depend on: left out of wrap_loss'
+# capture signature.  Callers whose loop adds more of them extend the set.
+VOLATILE_KEYS = {"iteration"}
 
 
 def enable(model, warmup=2, optimizer=None, comm_dtype=torch.float32, process_group=None, max_cached=2):
@@ -403,6 +406,9 @@ class GraphedRunner(object):
                 run("geometry")
             run("det_fwd")
             self.e_det_fwd.record(self.s_det)
+            if ops.TRANSPOSED_DX[0]:
+                run("t_refresh")             # (0.4 ms; the fusion backward waits for it: in FRONT of the long prefetch)
+            self.e_t_refresh.record(self.s_det)
             if self.prefetching and self._announced is not None:
                 nxt, key = self._announced
                 self._announced = None
@@ -411,9 +417,6 @@ class GraphedRunner(object):
                 self._geo_key = key
             elif self.prefetching:
                 self._geo_key = None         # `_geo_next` still holds this batch's indices: nothing announced
-            if ops.TRANSPOSED_DX[0]:
-                run("t_refresh")
-            self.e_t_refresh.record(self.s_det)
         with torch.cuda.stream(self.s_main):
             self.s_main.wait_event(self.e_det_fwd)
             run("fusion_fwd")
@@ -491,9 +494,11 @@ class GraphedRunner(object):
 
     def phase_gpu_ms(self):
         """after a synchronize: {graph: (mean start, mean end)} in ms from the start of the step's first graph"""
-        out, ref = {}, self.phase_events["image_fwd"]
+        out = {}
         steps = min(len(v) for v in self.phase_events.values())
+        ref = self.phase_events["image_fwd"][-steps:]
         for name, evs in self.phase_events.items():
+            evs = evs[-steps:]     # (aligned at the END: a step that computed its own geometry has an extra, earlier entry)
             a = [ref[i][0].elapsed_time(evs[i][0]) for i in range(steps)]
             b = [ref[i][0].elapsed_time(evs[i][1]) for i in range(steps)]
             out[name] = (sum(a) / steps, sum(b) / steps)
@@ -538,7 +543,12 @@ class GraphedRunner(object):
         # warm-up: eager steps on the phase streams (autograd's AccumulateGrad nodes remember the stream they were born on;
         # kernels compile / caches fill), seeded with ones; buffers (BatchNorm statistics) and gradients put back afterwards
         torch.cuda.synchronize(dev)
-        saved_buf = {k: v.detach().clone() for k, v in m.state_dict().items() if not isinstance(v, torch.nn.Parameter)}
+        # BUFFERS only (BatchNorm statistics, num_batches_tracked).  Round 4 filtered m.state_dict() by isinstance(Parameter):
+        # state_dict() hands out DETACHED tensors, so every parameter was "restored" too -- a copy_ that bumps its version
+        # counter, which made every bf16 operand copy look stale at capture time: the captured graphs re-cast ~250 weights per
+        # replay (1.3 ms of multi-tensor copies + 188 casts in the fusion forward alone) and their input-gradient GEMMs fell
+        # back to the contraction-major weight read (+1.6 ms in the image backward)
+        saved_buf = {k: v.detach().clone() for k, v in m.named_buffers()}
         saved_grad = [p.grad for p in params]
         for p in params:
             p.grad = None
@@ -566,9 +576,8 @@ class GraphedRunner(object):
                 p.grad = None
         torch.cuda.synchronize(dev)
         with torch.no_grad():
-            for k, v in m.state_dict().items():
-                if k in saved_buf:
-                    v.copy_(saved_buf[k])
+            for k, v in m.named_buffers():
+                v.copy_(saved_buf[k])
         if ops.TRANSPOSED_DX[0]:
             ops.refresh_transposed(dev)   # (builds the device table of what the warm-up registered: not possible inside a capture)
             self._t_generation = ops.transposed_generation()   # (its tables and operands live as long as these graphs)
@@ -712,8 +721,12 @@ class GraphedRunner(object):
     def _loss_signature(self, fn, data_dict, args, kw):
         own = set(self._st["dd"]) | set(self._st["fd"]) | {"_bq_graphed_step"}
         ext = tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in data_dict.items() if k not in own and torch.is_tensor(v)))
+        # host constants the captured loss may branch on ("phase", flags) are part of the signature; entries that change
+        # every step and that no loss reads -- the solver's data_dict["iteration"] (lib/solver.py:488), this module's own
+        # "_bq_*" keys -- must not be: each new value would re-capture the loss (two eager passes + two captures per step)
         const = tuple(sorted((k, repr(v)) for k, v in data_dict.items()
-                             if k not in own and not torch.is_tensor(v) and not isinstance(v, dict)))
+                             if k not in own and not torch.is_tensor(v) and not isinstance(v, dict)
+                             and not (isinstance(k, str) and (k.startswith("_bq_") or k in VOLATILE_KEYS))))
         return (id(fn), ext, const, repr(args), repr(sorted(kw.items())))
 
     def _capture_loss(self, fn, data_dict, args, kw):
@@ -791,7 +804,7 @@ class GraphedRunner(object):
                 t = data_dict[k]
                 if t.data_ptr() != buf.data_ptr():
                     buf.copy_(t, non_blocking=True)
-            rec["g_f"].replay()
+            self._replay_named("loss_fwd", rec["g_f"])
             self.e_loss.record(self.s_main)
         cur.wait_event(self.e_loss)
         st = rec["state"]
@@ -822,7 +835,7 @@ class GraphedRunner(object):
                     seed.zero_()
                 else:
                     seed.copy_(g, non_blocking=True)
-            rec["g_b"].replay()
+            self._replay_named("loss_bwd", rec["g_b"])
         self._bwd_done = True
         self._point_grads()
         self._backward_phases(self._replay, None, seeded=True)

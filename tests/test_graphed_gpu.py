@@ -209,7 +209,9 @@ def test_prefetch_loader_feeds_the_next_batchs_geometry_with_changing_batches(de
     try:
         model, _ = _setup(dev)
         batches = _batches(dev, 4)
-        idx_keys = ("fp2_inds", "sa1_inds", "sa2_inds", "aggregated_vote_inds")
+        # (geometry outputs only: aggregated_vote_inds is an FPS over PREDICTED votes, whose near-ties move with the rounding
+        # of the network's outputs)
+        idx_keys = ("fp2_inds", "sa1_inds", "sa2_inds")
         want = []
         for b in batches:
             with torch.no_grad():
@@ -237,6 +239,7 @@ def test_prefetch_loader_feeds_the_next_batchs_geometry_with_changing_batches(de
                 seen += 1
         runner = model._graphed
         assert seen == 8 and runner.prefetching and "geometry" in runner.graphs and runner.captures <= 2
+        assert len(runner.losses) == 1          # the per-batch key string did not re-capture the loss
         # a batch fed AROUND the loader (no key, never announced): computes its own indices in front of its detector forward
         dd = model(dict(batches[2]))
         assert torch.equal(dd["fp2_inds"], want[2][0]["fp2_inds"])

@@ -986,6 +986,23 @@ def main():
     if rank == 0:
         print("host-side launch time per step: %.2f ms  [%s]" % (host_ms / args.steps, " ".join("%.1f" % h for h in host_each)), file=sys.stderr)
 
+    # the same model behind the reference's UNCHANGED loop, timed in this process right after the headline (INTEGRATION.md
+    # section 3a; before the CPU baseline, whose 32 OpenMP threads keep spinning on the host): the phased step's graphs are
+    # dropped first
+    loop_ref_res, n_phase_graphs = None, (len(pipe.graphs or ()) if pipe is not None else 0)
+    if rank == 0 and phased and world == 1 and not args.no_loop_reference and args.workload != "c5" and not dp:
+        pipe.graphs, pipe._state = None, {}
+        step = None
+        pipe = None
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            loop_ref_res = run_reference_loop(args, model, batch, dev, args.graph in ("on", "auto"), args.steps, args.warmup,
+                                              trace=os.environ.get("BQ_PIPE_TRACE") == "1")
+        except Exception as e:    # (the headline line must not be lost to the second measurement)
+            loop_ref_res = {"error": "%s: %s" % (type(e).__name__, e)}
+
     if rank == 0:
         ops = timer.summary()
         # dominant native kernel: SA1 furthest point sampling; algorithmic bytes 20*N*(m-1) per scene
@@ -1006,7 +1023,7 @@ def main():
                        "points": args.points,
                        "c_in": args.cin, "image": args.image if workload == "c3" else None,
                        "parallelism": "dp%d" % world, "hip_graph": graphed,
-                       "schedule": (("phased: %d graphs on 2 streams" % (len(pipe.graphs or ()) if pipe is not None else 0)) if phased else
+                       "schedule": (("phased: %d graphs on 2 streams" % n_phase_graphs) if phased else
                                     ("single graph + the next batch's sampling / grouping indices on a second stream"
                                      if geometry_ahead is not None else "single graph")),
                        "grad_exchange": (("per-phase packed bf16 all-reduce on a comm stream, %d MB on the wire"
@@ -1059,20 +1076,8 @@ def main():
             out["roofline"] = out["roofline_fps"]
         if world == 1 and not args.no_cpu_baseline and args.workload != "c5":   # (c3 is the headline: its baseline is the one reported)
             out["cpu_baseline"] = cpu_baseline(args, workload)
-        if phased and world == 1 and not args.no_loop_reference and args.workload != "c5" and not dp:
-            # the same model behind the reference's UNCHANGED loop, timed in this process after the headline
-            # (INTEGRATION.md section 3a): the phased step's graphs are dropped first
-            n_graphs = len(pipe.graphs or ())
-            pipe.graphs, pipe._state = None, {}
-            step = None
-            pipe = None
-            import gc
-            gc.collect()
-            torch.cuda.empty_cache()
-            try:
-                out["loop_reference"] = run_reference_loop(args, model, batch, dev, args.graph in ("on", "auto"), args.steps, args.warmup)
-            except Exception as e:    # (the headline line must not be lost to the second measurement)
-                out["loop_reference"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if loop_ref_res is not None:
+            out["loop_reference"] = loop_ref_res
         if replicas_in_sync is not None:
             out["replicas_in_sync"] = replicas_in_sync
         if pipe is not None and reducers:

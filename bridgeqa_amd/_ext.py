@@ -22,7 +22,7 @@ if not os.path.exists(_LIB_PATH):
 _lib = ctypes.CDLL(_LIB_PATH)
 _lib.bq_last_error.restype = ctypes.c_char_p
 _lib.bq_abi_version.restype = ctypes.c_int
-ABI_VERSION = 3   # = BQHIP_ABI_VERSION of include/bqhip.h
+ABI_VERSION = 4   # = BQHIP_ABI_VERSION of include/bqhip.h
 if _lib.bq_abi_version() != ABI_VERSION:
     raise ImportError("bridgeqa_amd: libbqhip.so ABI %d != %d (stale library: python -m bridgeqa_amd.build --force)"
                       % (_lib.bq_abi_version(), ABI_VERSION))
@@ -1115,3 +1115,160 @@ def lmhead_ce_dlogits(logits, lse, target, grad_loss, V, label_smoothing):
         _check(_lib.bq_lmhead_ce_dlogits(_p(logits), _p(lse), _p(target), _p(grad_loss), R, int(V), logits.stride(0),
                                          float(label_smoothing), _stream()), "lmhead_ce_dlogits")
     return logits
+
+
+# ---- detection loss + gradient in two launches (csrc/detloss.hip) ---------------------------------------------------------
+_DET_SCORES = ("objectness_scores", "heading_scores", "heading_residuals_normalized", "size_scores",
+               "size_residuals_normalized", "sem_cls_scores")
+_DET_TERM = {"vote_xyz": 0, "objectness_scores": 1, "center": 2, "heading_scores": 3, "heading_residuals_normalized": 4,
+             "size_scores": 5, "size_residuals_normalized": 6, "sem_cls_scores": 7}
+
+
+class _DetLossDesc(ctypes.Structure):
+    _fields_ = ([(n, _vp) for n in (
+        "seed_xyz", "vote_xyz", "aggregated_vote_xyz", "objectness_scores", "center", "heading_scores",
+        "heading_residuals_normalized", "size_scores", "size_residuals_normalized", "sem_cls_scores", "seed_inds", "vote_label",
+        "vote_label_mask", "center_label", "box_label_mask", "heading_class_label", "size_class_label", "sem_cls_label",
+        "heading_residual_label", "size_residual_label", "mean_size_arr", "terms", "objectness_label", "objectness_mask",
+        "object_assignment", "g_vote_xyz", "g_objectness_scores", "g_center", "g_heading_scores",
+        "g_heading_residuals_normalized", "g_size_scores", "g_size_residuals_normalized", "g_sem_cls_scores", "scratch")]
+        + [(n, _i) for n in ("B", "S", "VF", "N", "K", "G", "NH", "NS", "NC", "cl_ld", "seed_inds_i64")]
+        + [("ld_" + n, _i) for n in _DET_SCORES]
+        + [(n, _f) for n in ("near_threshold", "far_threshold", "objectness_weight_neg", "objectness_weight_pos")])
+
+
+class _DetLossSeg(ctypes.Structure):
+    _fields_ = [("g", _vp), ("out", _vp), ("rows", _i), ("width", _i), ("ld", _i), ("term", _i)]
+
+
+_lib.bq_det_loss_fwd.argtypes = [ctypes.POINTER(_DetLossDesc), _vp]
+_lib.bq_det_loss_fwd.restype = ctypes.c_int
+_lib.bq_det_loss_bwd.argtypes = [ctypes.POINTER(_DetLossSeg), _i, _vp, _vp]
+_lib.bq_det_loss_bwd.restype = ctypes.c_int
+
+
+def det_score_ld(v, K):
+    """row stride (floats per proposal) of a score tensor (B, K, w) or (B, K, NS, 3) the kernel can read in place: unit stride
+    inside a row, rows `ld` apart, batches K * ld apart (a contiguous tensor, or a channel slice of the head output); else None"""
+    w = v.shape[2] * (v.shape[3] if v.dim() == 4 else 1)
+    ld = v.stride(1)
+    if v.stride(-1) != 1 or ld < w or v.stride(0) != K * ld or (v.dim() == 4 and v.stride(2) != v.shape[3]):
+        return None
+    return ld
+
+
+def det_loss_packing(t):
+    """The six score tensors of the proposal head are slices of ONE (B, K, channels) tensor (proposal_module.decode_scores):
+    -> (base, {name: (channel offset, width)}, channels) when they all are views, INSIDE the autograd graph, of the same
+    contiguous base with one row stride -- the gradient is then produced for the base in one buffer; else None (the tensors
+    are differentiated one by one, e.g. graphed.wrap_loss' fresh leaves)"""
+    base = getattr(t[_DET_SCORES[0]], "_base", None)
+    if base is None or not base.is_contiguous() or base.dtype != torch.float32 or not base.requires_grad:
+        return None
+    B, K = t["center"].shape[:2]
+    if base.numel() % (B * K):
+        return None
+    ld = base.numel() // (B * K)
+    off = {}
+    for n in _DET_SCORES:
+        v = t[n]
+        if getattr(v, "_base", None) is not base or v.grad_fn is None or det_score_ld(v, K) != ld:
+            return None
+        o = v.storage_offset() - base.storage_offset()
+        width = v.shape[2] * (v.shape[3] if v.dim() == 4 else 1)
+        if o < 0 or o + width > ld:
+            return None
+        off[n] = (o, width)
+    return base, off, ld
+
+
+def det_loss_fwd(t, mean_size, near, far, w_neg, w_pos, packing=None):
+    """t: dict of the tensors named in bq_det_loss_desc (fp32 outputs / labels, int64 class labels and masks; seed_inds int32
+    or int64).  packing: det_loss_packing(t) -- the score tensors as slices of one head output: their gradients then land in
+    ONE buffer shaped like it.  -> terms f32 (16,), objectness_label i64 (B,K), objectness_mask f32 (B,K), object_assignment
+    i64 (B,K), grads {name or "packed": tensor}"""
+    dev = t["center"].device
+    B, K = t["center"].shape[:2]
+    S = t["seed_xyz"].shape[1]
+    VF = t["vote_xyz"].shape[1] // S
+    N, G = t["vote_label"].shape[1], t["center_label"].shape[1]
+    NH, NS, NC = t["heading_scores"].shape[2], t["size_scores"].shape[2], t["sem_cls_scores"].shape[2]
+    d = _DetLossDesc()
+    plain = ["seed_xyz", "vote_xyz", "aggregated_vote_xyz", "center", "vote_label", "center_label", "box_label_mask",
+             "heading_residual_label", "size_residual_label"]
+    for n in plain:
+        _req(t[n], torch.float32, n)
+        setattr(d, n, _p(t[n]))
+    for n in ("vote_label_mask", "heading_class_label", "size_class_label", "sem_cls_label"):
+        if t[n].dtype != torch.int64 or not t[n].is_contiguous() or not t[n].is_cuda:
+            raise RuntimeError("%s must be a contiguous int64 device tensor" % n)
+        setattr(d, n, _p(t[n]))
+    si = t["seed_inds"]
+    if si.dtype not in (torch.int32, torch.int64) or not si.is_contiguous():
+        raise RuntimeError("seed_inds must be a contiguous int32 / int64 tensor")
+    d.seed_inds, d.seed_inds_i64 = _p(si), int(si.dtype == torch.int64)
+    _req(mean_size, torch.float32, "mean_size_arr")
+    d.mean_size_arr = _p(mean_size)
+    with torch.cuda.device(dev):
+        terms = torch.zeros(16, dtype=torch.float32, device=dev)
+        lab = torch.empty(B, K, dtype=torch.int64, device=dev)
+        msk = torch.empty(B, K, dtype=torch.float32, device=dev)
+        asg = torch.empty(B, K, dtype=torch.int64, device=dev)
+        scratch = torch.empty(B * G, dtype=torch.int32, device=dev)
+        grads = {"vote_xyz": torch.empty_like(t["vote_xyz"]), "center": torch.empty_like(t["center"])}
+        d.g_vote_xyz, d.g_center = _p(grads["vote_xyz"]), _p(grads["center"])
+        if packing:
+            base, off, ld = packing
+            gp = grads["packed"] = torch.empty_like(base)
+            for n in _DET_SCORES:
+                setattr(d, n, t[n].data_ptr())
+                setattr(d, "g_" + n, gp.data_ptr() + 4 * off[n][0])
+                setattr(d, "ld_" + n, ld)
+        else:
+            for n in _DET_SCORES:
+                v = t[n]
+                ld = det_score_ld(v, K)
+                if ld is None or v.dtype != torch.float32 or not v.is_cuda:
+                    raise RuntimeError("%s: fp32 device rows with unit stride expected" % n)
+                grads[n] = torch.empty_strided(v.shape, v.stride(), dtype=torch.float32, device=dev)   # (same row stride)
+                setattr(d, n, v.data_ptr())
+                setattr(d, "g_" + n, grads[n].data_ptr())
+                setattr(d, "ld_" + n, ld)
+        d.terms, d.objectness_label, d.objectness_mask, d.object_assignment, d.scratch = _p(terms), _p(lab), _p(msk), _p(asg), _p(scratch)
+        d.B, d.S, d.VF, d.N, d.K, d.G, d.NH, d.NS, d.NC = B, S, VF, N, K, G, NH, NS, NC
+        d.cl_ld = t["center_label"].shape[2]
+        d.near_threshold, d.far_threshold, d.objectness_weight_neg, d.objectness_weight_pos = near, far, w_neg, w_pos
+        _check(_lib.bq_det_loss_fwd(ctypes.byref(d), _stream()), "det_loss_fwd")
+    return terms, lab, msk, asg, grads
+
+
+def det_loss_bwd(grads, upstream, packing=None):
+    """grads: det_loss_fwd's buffers, upstream f32 (8,) -> {name or "packed": g * upstream[term]}, ONE launch"""
+    outs = {k: torch.empty_strided(g.shape, g.stride(), dtype=g.dtype, device=g.device) for k, g in grads.items()}
+    segs = []
+
+    def seg(g, o, g_off, rows, width, ld, term):
+        segs.append(_DetLossSeg(g.data_ptr() + 4 * g_off, o.data_ptr() + 4 * g_off, rows, width, ld, term))
+    for n in ("vote_xyz", "center"):
+        seg(grads[n], outs[n], 0, grads[n].numel() // 3, 3, 3, _DET_TERM[n])
+    if packing:
+        base, off, ld = packing
+        rows = base.numel() // ld
+        covered = sorted((o, w, n) for n, (o, w) in off.items())
+        pos = 0
+        for o, w, n in covered:
+            if o > pos:
+                seg(grads["packed"], outs["packed"], pos, rows, o - pos, ld, -1)   # channels no term reads (the centre offsets)
+            seg(grads["packed"], outs["packed"], o, rows, w, ld, _DET_TERM[n])
+            pos = o + w
+        if pos < ld:
+            seg(grads["packed"], outs["packed"], pos, rows, ld - pos, ld, -1)
+    else:
+        for n in _DET_SCORES:
+            g = grads[n]
+            w = g.shape[2] * (g.shape[3] if g.dim() == 4 else 1)
+            seg(g, outs[n], 0, g.shape[0] * g.shape[1], w, g.stride(1), _DET_TERM[n])
+    arr = (_DetLossSeg * len(segs))(*segs)
+    with torch.cuda.device(upstream.device):
+        _check(_lib.bq_det_loss_bwd(arr, len(segs), _p(upstream), _stream()), "det_loss_bwd")
+    return outs

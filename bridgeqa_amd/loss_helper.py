@@ -118,21 +118,121 @@ def compute_box_and_sem_cls_loss(data_dict, config):
             size_residual_normalized_loss, sem_cls_loss)
 
 
+# ---- the same three functions as ONE forward launch + ONE backward launch (csrc/detloss.hip) ------------------------------
+FUSED_DET_LOSS = [True]   # device tensors only; the torch composition above stays the golden-pinned definition (and the CPU path)
+_FUSED_FLOAT = ("seed_xyz", "vote_xyz", "aggregated_vote_xyz", "objectness_scores", "center", "heading_scores",
+                "heading_residuals_normalized", "size_scores", "size_residuals_normalized", "sem_cls_scores", "vote_label",
+                "center_label", "box_label_mask", "heading_residual_label", "size_residual_label")
+_FUSED_INT = ("vote_label_mask", "heading_class_label", "size_class_label", "sem_cls_label")
+
+
+class _DetLossFn(torch.autograd.Function):
+    """(labels, packing, vote_xyz, center, scores...) -> (terms (8,), objectness_label, objectness_mask, object_assignment,
+    ratios (2,)).  scores = the six score tensors, or -- packing -- the ONE (B, K, channels) head output they are slices of
+    (proposal_module.decode_scores): its gradient then comes back as one tensor instead of six slice gradients that autograd
+    would zero-pad and add.  The gradient of every term w.r.t. its input is produced by the forward launch (the loss is a
+    few dozen flops per proposal: cheaper to finish than to revisit); the backward scales the buffers by the upstream
+    gradient of their term, one launch."""
+
+    @staticmethod
+    def forward(ctx, labels, mean_size, packing, vote_xyz, center, *scores):
+        from . import _ext
+        t = dict(labels)
+        t["vote_xyz"], t["center"] = vote_xyz, center
+        if packing is None:
+            t.update(zip(_ext._DET_SCORES, scores))
+        terms, lab, msk, asg, grads = _ext.det_loss_fwd(t, mean_size, NEAR_THRESHOLD, FAR_THRESHOLD, OBJECTNESS_CLS_WEIGHTS[0],
+                                                        OBJECTNESS_CLS_WEIGHTS[1], packing=packing)
+        ctx.grads, ctx.packing = grads, packing
+        ctx.mark_non_differentiable(lab, msk, asg)
+        return terms[:8], lab, msk, asg, terms[8:10].detach()
+
+    @staticmethod
+    def backward(ctx, g_terms, g_lab, g_msk, g_asg, g_ratio):
+        from . import _ext
+        outs = _ext.det_loss_bwd(ctx.grads, g_terms.contiguous().float(), packing=ctx.packing)
+        tail = (outs["packed"],) if ctx.packing is not None else tuple(outs[n] for n in _ext._DET_SCORES)
+        return (None, None, None, outs["vote_xyz"], outs["center"]) + tail
+
+
+def _fused_ok(data_dict):
+    """-> None (torch composition) or (packing or False): device fp32 tensors in the layouts csrc/detloss.hip reads"""
+    if not FUSED_DET_LOSS[0]:
+        return None
+    try:
+        from . import _ext
+        c = data_dict["center"]
+        if not (c.is_cuda and c.dtype == torch.float32):
+            return None
+        packing = _ext.det_loss_packing(data_dict)
+        K = c.shape[1]
+        for k in _FUSED_FLOAT:
+            v = data_dict[k]
+            if not (v.is_cuda and v.dtype == torch.float32):
+                return None
+            if k in _ext._DET_SCORES:
+                if _ext.det_score_ld(v, K) is None:
+                    return None
+            elif not v.is_contiguous():
+                return None
+        for k in _FUSED_INT:
+            v = data_dict[k]
+            if not (v.is_cuda and v.dtype == torch.int64 and v.is_contiguous()):
+                return None
+        si = data_dict["seed_inds"]
+        if not (si.is_cuda and si.dtype in (torch.int32, torch.int64) and si.is_contiguous()
+                and max(data_dict["heading_scores"].shape[2], data_dict["size_scores"].shape[2],
+                        data_dict["sem_cls_scores"].shape[2]) <= 32
+                and data_dict["vote_label"].shape[2] == 3 * GT_VOTE_FACTOR
+                and data_dict["vote_xyz"].shape[1] % data_dict["seed_xyz"].shape[1] == 0):
+            return None
+        return packing or False
+    except (KeyError, ImportError):
+        return None
+
+
+def _fused_detection_terms(data_dict, config, packing):
+    from . import _ext
+    msa = np.ascontiguousarray(np.asarray(config.mean_size_arr, dtype=np.float32))
+    dev = data_dict["center"].device
+    mean_sizes = _const(("mean_size", msa.tobytes()), dev, lambda: torch.from_numpy(msa.copy()))
+    diff = ("vote_xyz", "center") + _ext._DET_SCORES
+    labels = {k: data_dict[k] for k in _FUSED_FLOAT + _FUSED_INT + ("seed_inds",) if k not in diff}
+    if packing:
+        # (the slices themselves are still read by the kernel -- through the base's memory)
+        labels.update({k: data_dict[k].detach() for k in _ext._DET_SCORES})
+        scores = (packing[0],)
+    else:
+        scores = tuple(data_dict[k] for k in _ext._DET_SCORES)
+    return _DetLossFn.apply(labels, mean_sizes, packing or None, data_dict["vote_xyz"], data_dict["center"], *scores)
+
+
 def get_detection_loss(data_dict, config, loss_weights=None, amplify=10.0):
     """The detection terms of get_loss (loss_helper.py:355-464, `detection=True`): vote + objectness + box + sem-cls with
     the reference's weights dict (default 1.0 each, scripts/train.py passes 1.0 / 0.5 / 1.0 / 0.1) and the x10 at the
     end; fills the same data_dict entries.  Returns (loss, data_dict)."""
     w = loss_weights or {}
-    vote_loss = compute_vote_loss(data_dict)
-    objectness_loss, objectness_label, objectness_mask, object_assignment = compute_objectness_loss(data_dict)
-    total = float(objectness_label.shape[0] * objectness_label.shape[1])
-    data_dict["objectness_label"] = objectness_label
-    data_dict["objectness_mask"] = objectness_mask
-    data_dict["object_assignment"] = object_assignment
-    data_dict["pos_ratio"] = torch.sum(objectness_label.float()) / total
-    data_dict["neg_ratio"] = torch.sum(objectness_mask.float()) / total - data_dict["pos_ratio"]
-    center_loss, heading_cls_loss, heading_reg_loss, size_cls_loss, size_reg_loss, sem_cls_loss = \
-        compute_box_and_sem_cls_loss(data_dict, config)
+    fused = _fused_ok(data_dict)
+    if fused is not None:
+        # device tensors: the three functions below and their autograd as two launches (csrc/detloss.hip); same entries
+        terms, objectness_label, objectness_mask, object_assignment, ratio = _fused_detection_terms(data_dict, config, fused)
+        (vote_loss, objectness_loss, center_loss, heading_cls_loss, heading_reg_loss, size_cls_loss, size_reg_loss,
+         sem_cls_loss) = terms.unbind(0)
+        data_dict["objectness_label"] = objectness_label
+        data_dict["objectness_mask"] = objectness_mask
+        data_dict["object_assignment"] = object_assignment
+        data_dict["pos_ratio"], data_dict["neg_ratio"] = ratio.unbind(0)
+    else:
+        vote_loss = compute_vote_loss(data_dict)
+        objectness_loss, objectness_label, objectness_mask, object_assignment = compute_objectness_loss(data_dict)
+        total = float(objectness_label.shape[0] * objectness_label.shape[1])
+        data_dict["objectness_label"] = objectness_label
+        data_dict["objectness_mask"] = objectness_mask
+        data_dict["object_assignment"] = object_assignment
+        data_dict["pos_ratio"] = torch.sum(objectness_label.float()) / total
+        data_dict["neg_ratio"] = torch.sum(objectness_mask.float()) / total - data_dict["pos_ratio"]
+        center_loss, heading_cls_loss, heading_reg_loss, size_cls_loss, size_reg_loss, sem_cls_loss = \
+            compute_box_and_sem_cls_loss(data_dict, config)
     box_loss = center_loss + 0.1 * heading_cls_loss + heading_reg_loss + 0.1 * size_cls_loss + size_reg_loss
     data_dict.update(vote_loss=vote_loss, objectness_loss=objectness_loss, center_loss=center_loss,
                      heading_cls_loss=heading_cls_loss, heading_reg_loss=heading_reg_loss, size_cls_loss=size_cls_loss,

@@ -351,6 +351,51 @@ BQ_API int bq_lmhead_ce_combine(const float *partial, const float *target_logit,
 BQ_API int bq_lmhead_ce_dlogits(void *logits, const float *lse, const int *target, const float *grad_loss, int R, int V,
                                 int ld, float label_smoothing, void *stream);
 
+/* ---- detection loss and its gradient (csrc/detloss.hip) -------------------------------------------------------------------
+ * Replaces compute_vote_loss + compute_objectness_loss + compute_box_and_sem_cls_loss of lib/loss_helper.py:25-193 (over
+ * utils/nn_distance.py:6-52) and what autograd derives from them: ~460 torch launches on B x 256 proposals -> two.
+ * All float tensors fp32 and contiguous, class labels / masks int64 as the reference's dataset produces them
+ * (lib/dataset.py:553-577); seed_inds int32 or int64 (seed_inds_i64).  terms f32 [16]: vote_loss, objectness_loss,
+ * center_loss, heading_cls_loss, heading_reg_loss, size_cls_loss, size_reg_loss, sem_cls_loss, pos_ratio, neg_ratio (the
+ * data_dict entries of loss_helper.py:400-430, before the caller's weights and the x10).  g_*: d term / d input, the term named
+ * by bq_det_loss_bwd's order, shaped like the input; scratch: int32 [B * G]. */
+typedef struct bq_det_loss_desc {
+  const float *seed_xyz, *vote_xyz, *aggregated_vote_xyz, *objectness_scores, *center, *heading_scores,
+      *heading_residuals_normalized, *size_scores, *size_residuals_normalized, *sem_cls_scores;
+  const void *seed_inds;
+  const float *vote_label;
+  const void *vote_label_mask; /* int64 (B, N) */
+  const float *center_label, *box_label_mask;
+  const void *heading_class_label, *size_class_label, *sem_cls_label; /* int64 (B, G) */
+  const float *heading_residual_label, *size_residual_label, *mean_size_arr;
+  float *terms;
+  void *objectness_label; /* int64 (B, K) out */
+  float *objectness_mask;
+  void *object_assignment; /* int64 (B, K) out */
+  float *g_vote_xyz, *g_objectness_scores, *g_center, *g_heading_scores, *g_heading_residuals_normalized, *g_size_scores,
+      *g_size_residuals_normalized, *g_sem_cls_scores;
+  int *scratch;
+  int B, S, VF, N, K, G, NH, NS, NC; /* seeds, votes per seed, points, proposals, GT slots, heading bins, size clusters, classes */
+  int cl_ld;                         /* floats per center_label row (>= 3) */
+  int seed_inds_i64;
+  /* floats per proposal row of the six score tensors and of their g_* buffers: the natural widths (2, NH, NH, NS, 3 NS, NC)
+   * for separate tensors, the channel count when they are slices of one (B, K, channels) head output
+   * (models/proposal_module.py:19-48 decode_scores) -- the g_* pointers then address one buffer of that shape */
+  int ld_objectness_scores, ld_heading_scores, ld_heading_residuals_normalized, ld_size_scores, ld_size_residuals_normalized,
+      ld_sem_cls_scores;
+  float near_threshold, far_threshold, objectness_weight_neg, objectness_weight_pos; /* 0.3, 0.6, 0.2, 0.8 (loss_helper.py:18-22) */
+} bq_det_loss_desc;
+BQ_API int bq_det_loss_fwd(const bq_det_loss_desc *d, void *stream);
+/* backward: segment i: out[r * ld + c] = g[r * ld + c] * upstream[term] for r < rows, c < width (term < 0: out = 0 -- channels of
+ * a packed buffer that no term reads); terms 0..7 = vote, objectness, center, heading_cls, heading_reg, size_cls, size_reg,
+ * sem_cls; at most 16 segments, one launch */
+typedef struct bq_det_loss_seg {
+  const float *g;
+  float *out;
+  int rows, width, ld, term;
+} bq_det_loss_seg;
+BQ_API int bq_det_loss_bwd(const bq_det_loss_seg *segments, int n, const float *upstream, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

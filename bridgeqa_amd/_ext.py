@@ -946,7 +946,38 @@ def gemm_grouped(problems, flags, epilogue=EPI_NONE, tile=None):
     if (tile or t_auto) != 128:
         flags &= ~GEMM_BACKGROUND   # (only the persistent 256 x 128 kernel has a reduced grid)
     with torch.cuda.device(dev):
+        if (tile or t_auto) == 128 and n == 1 and STREAMK[0]:
+            _streamk_workspace(dev)
         _check(_lib.bq_gemm_bf16(arr, n, int(flags), int(epilogue), int(tile or t_auto), _stream()), "gemm_bf16")
+
+
+# ---- stream-K workspaces (bq_gemm_set_workspace): one per (device, stream), allocated at the first tile-128 single-problem
+# launch on that stream OUTSIDE a capture (the warm-up steps of pipeline.py / graphed.py run on the phase streams first); a
+# launch on a stream without one runs on whole tiles
+STREAMK = [True]
+_SK_WS = {}
+_lib.bq_gemm_workspace_bytes.restype = ctypes.c_long
+_lib.bq_gemm_set_workspace.argtypes = [_vp, ctypes.c_long, _vp]
+_lib.bq_gemm_set_workspace.restype = ctypes.c_int
+
+
+def streamk_enable(flag):
+    """measurement / test switch: with False every registered workspace is withdrawn (the launches run on whole tiles)"""
+    STREAMK[0] = bool(flag)
+    for (d, sp), (ws, st) in _SK_WS.items():
+        with torch.cuda.device(d):
+            _check(_lib.bq_gemm_set_workspace(_p(ws) if flag else None, ws.numel() if flag else 0, sp), "gemm_set_workspace")
+
+
+def _streamk_workspace(dev):
+    st = torch.cuda.current_stream(dev)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), st.cuda_stream)
+    if key in _SK_WS or torch.cuda.is_current_stream_capturing():
+        return
+    nbytes = int(_lib.bq_gemm_workspace_bytes())
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)     # (the tickets at its head must start at zero)
+    _check(_lib.bq_gemm_set_workspace(_p(ws), nbytes, st.cuda_stream), "gemm_set_workspace")
+    _SK_WS[key] = (ws, st)      # (the stream object is kept: its handle must not be recycled for another stream)
 
 
 def gemm_fwd(x, w, bias=None, gelu=False, tile=None, out=None, background=False):
@@ -1214,7 +1245,7 @@ def det_loss_fwd(t, mean_size, near, far, w_neg, w_pos, packing=None):
         lab = torch.empty(B, K, dtype=torch.int64, device=dev)
         msk = torch.empty(B, K, dtype=torch.float32, device=dev)
         asg = torch.empty(B, K, dtype=torch.int64, device=dev)
-        scratch = torch.empty(B * G, dtype=torch.int32, device=dev)
+        scratch = torch.empty(B * G + 1024, dtype=torch.int32, device=dev)
         grads = {"vote_xyz": torch.empty_like(t["vote_xyz"]), "center": torch.empty_like(t["center"])}
         d.g_vote_xyz, d.g_center = _p(grads["vote_xyz"]), _p(grads["center"])
         if packing:

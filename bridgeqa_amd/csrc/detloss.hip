@@ -4,11 +4,13 @@
 // autograd are ~460 launches of 2-6 us on B x 256 proposals: 1.0 ms of the detector stream in front of the fusion and 1.5 ms
 // at the head of the detector's backward, which is the phase that ends the step (profiles/r04_c3_phases.txt).
 //
-// det_loss_kernel: ONE workgroup of 1024 threads walks all scenes (the terms are normalised by batch-wide sums --
-// sum(mask), npos, sum(box_label_mask) -- so a grid would need a second pass anyway; the whole job is ~1 M distance
-// evaluations).  Pass 1: per seed / per proposal / per ground-truth box the quantities of the reference, the numerators and
-// denominators reduced over the workgroup in a FIXED order (bitwise reproducible), the gradient of every term with respect
-// to the network's outputs written UNNORMALISED; pass 2: the same threads scale what they wrote by 1 / denominator.
+// The terms are normalised by batch-wide sums -- sum(mask), npos, sum(box_label_mask) --, so the forward is two launches of
+// the same 64 x 256-thread grid (the whole job is ~1 M distance evaluations; ONE workgroup, the first version, took 0.9 ms):
+// det_loss_kernel: per seed / per proposal / per ground-truth box the quantities of the reference, the numerators and
+// denominators as per-workgroup partial sums, the gradient of every term with respect to the network's outputs written
+// UNNORMALISED; det_loss_finish_kernel: every thread adds the partial sums in block order (bitwise reproducible: no
+// atomics), block 0 writes the terms, all scale the gradients by 1 / denominator and add the GT -> proposal share of the
+// centre gradient in ground-truth order.
 // det_loss_bwd_kernel: gradient buffers x the upstream gradient of their term (the terms are returned separately, so the
 // caller's weights -- scripts/train.py:97-103 -- and the x10 stay ordinary autograd arithmetic on eight scalars).
 //
@@ -49,14 +51,14 @@ struct DetLossArgs {
   float *obj_mask;              // (B, K)
   long long *assignment;        // (B, K)
   float *g_vote, *g_obj, *g_center, *g_head_scores, *g_head_res, *g_size_scores, *g_size_res, *g_sem;   // like their inputs
-  int *scratch;                 // (B, G) int: nearest proposal of every ground-truth centre
+  int *scratch;                 // (B, G) int: nearest proposal of every ground-truth centre; then DL_BLOCKS x 16 float partial sums
   int B, S, VF, N, K, G, NH, NS, NC, cl_ld, seed_inds_i64;
   int ld_obj, ld_hs, ld_hr, ld_ss, ld_sr, ld_sem;   // floats per proposal row of the six score tensors AND of their gradient buffers
                                                     // (slices of one (B, K, channels) head output: all = channels)
   float near_thr, far_thr, w_neg, w_pos, head_bin;   // head_bin = pi / NH
 };
 
-constexpr int DL_THREADS = 1024;
+constexpr int DL_THREADS = 256, DL_BLOCKS = 64, DL_ALL = DL_THREADS * DL_BLOCKS;
 constexpr int DL_SUMS = 12;
 enum { S_VOTE = 0, S_VMASK, S_OBJ, S_OMASK, S_NPOS, S_C1, S_C2, S_BM, S_HC, S_HR, S_SC, S_SR };   // + S_SEM kept apart
 constexpr int S_SEM = 12;
@@ -79,14 +81,13 @@ __device__ __forceinline__ float ce_row(const float *x, int n, int y, float *p) 
 
 __global__ __launch_bounds__(DL_THREADS) void det_loss_kernel(const DetLossArgs a) {
   __shared__ float s_part[DL_THREADS / 64][DL_SUMS + 1];
-  __shared__ float s_tot[DL_SUMS + 1];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, gtid = blockIdx.x * DL_THREADS + threadIdx.x;
   float sum[DL_SUMS + 1];
 #pragma unroll
   for (int i = 0; i <= DL_SUMS; ++i) sum[i] = 0.f;
 
   // ---- A. vote loss (loss_helper.py:25-70): per seed, min over (predicted vote, GT vote) of the L1 distance ----------
-  for (int it = tid; it < a.B * a.S; it += DL_THREADS) {
+  for (int it = gtid; it < a.B * a.S; it += DL_ALL) {
     const int b = it / a.S;
     const long ind = a.seed_inds_i64 ? (long)((const long long *)a.seed_inds)[it] : (long)((const int *)a.seed_inds)[it];
     const float m = (float)a.vote_mask[(long)b * a.N + ind];
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(DL_THREADS) void det_loss_kernel(const DetLossArgs 
   }
 
   // ---- B. per proposal: objectness (:72-115), box terms and semantic class (:118-193) ----------------------------------
-  for (int it = tid; it < a.B * a.K; it += DL_THREADS) {
+  for (int it = gtid; it < a.B * a.K; it += DL_ALL) {
     const int b = it / a.K;
     const float *gt = a.center_label + (long)b * a.G * a.cl_ld;
     const float *q = a.agg_xyz + (long)it * 3, *c = a.center + (long)it * 3;
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(DL_THREADS) void det_loss_kernel(const DetLossArgs 
   }
 
   // ---- C. centre, GT -> nearest proposal (dist2 of nn_distance(pred_center, gt_center)) ------------------------------------
-  for (int it = tid; it < a.B * a.G; it += DL_THREADS) {
+  for (int it = gtid; it < a.B * a.G; it += DL_ALL) {
     const int b = it / a.G, g = it - b * a.G;
     const float *gt = a.center_label + ((long)b * a.G + g) * a.cl_ld;
     const float *c = a.center + (long)b * a.K * 3;
@@ -211,23 +212,34 @@ __global__ __launch_bounds__(DL_THREADS) void det_loss_kernel(const DetLossArgs 
     a.scratch[it] = k2;
   }
 
-  // ---- workgroup sums, fixed order: lanes (butterfly), then waves in index order ---------------------------------------
+  // ---- per-workgroup partial sums, fixed order: lanes (butterfly), then waves in index order ------------------------------
 #pragma unroll
   for (int i = 0; i <= DL_SUMS; ++i) {
     float v = sum[i];
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     if ((tid & 63) == 0) s_part[tid >> 6][i] = v;
   }
-  __syncthreads();   // (also orders the scratch / gradient stores of passes A-C before the reads below: one workgroup, one CU)
+  __syncthreads();
   if (tid <= DL_SUMS) {
     float v = 0.f;
     for (int w = 0; w < DL_THREADS / 64; ++w) v += s_part[w][tid];
+    ((float *)(a.scratch + a.B * a.G))[blockIdx.x * 16 + tid] = v;
+  }
+}
+
+__global__ __launch_bounds__(DL_THREADS) void det_loss_finish_kernel(const DetLossArgs a) {
+  __shared__ float s_tot[DL_SUMS + 1];
+  const int tid = threadIdx.x, gtid = blockIdx.x * DL_THREADS + threadIdx.x;
+  if (tid <= DL_SUMS) {   // the same additions in the same order in every workgroup
+    const float *part = (const float *)(a.scratch + a.B * a.G);
+    float v = 0.f;
+    for (int w = 0; w < DL_BLOCKS; ++w) v += part[w * 16 + tid];
     s_tot[tid] = v;
   }
   __syncthreads();
   const float inv_vm = 1.0f / (s_tot[S_VMASK] + 1e-6f), inv_om = 1.0f / (s_tot[S_OMASK] + 1e-6f);
   const float inv_np = 1.0f / (s_tot[S_NPOS] + 1e-6f), inv_bm = 1.0f / (s_tot[S_BM] + 1e-6f);
-  if (tid == 0) {
+  if (gtid == 0) {
     const float total = (float)(a.B * a.K);
     a.terms[0] = s_tot[S_VOTE] * inv_vm;
     a.terms[1] = s_tot[S_OBJ] * inv_om;
@@ -241,10 +253,10 @@ __global__ __launch_bounds__(DL_THREADS) void det_loss_kernel(const DetLossArgs 
     a.terms[9] = s_tot[S_OMASK] / total - s_tot[S_NPOS] / total;    // neg_ratio
   }
 
-  // ---- pass 2: normalise the gradients (each thread revisits the items it wrote) ----------------------------------------
-  for (int it = tid; it < a.B * a.S; it += DL_THREADS)
+  // ---- normalise the gradients ---------------------------------------------------------------------------------------------
+  for (int it = gtid; it < a.B * a.S; it += DL_ALL)
     for (int e = 0; e < a.VF * 3; ++e) a.g_vote[(long)it * a.VF * 3 + e] *= inv_vm;
-  for (int it = tid; it < a.B * a.K; it += DL_THREADS) {
+  for (int it = gtid; it < a.B * a.K; it += DL_ALL) {
     const int b = it / a.K, k = it - b * a.K;
     a.g_obj[(long)it * a.ld_obj] *= inv_om;
     a.g_obj[(long)it * a.ld_obj + 1] *= inv_om;
@@ -323,7 +335,8 @@ extern "C" int bq_det_loss_fwd(const bq_det_loss_desc *d, void *stream) {
              BQ_EINVAL, "bq_det_loss_fwd: a row stride is shorter than its row");
   a.near_thr = d->near_threshold; a.far_thr = d->far_threshold; a.w_neg = d->objectness_weight_neg; a.w_pos = d->objectness_weight_pos;
   a.head_bin = 3.14159265358979323846f / (float)d->NH;
-  hipLaunchKernelGGL(det_loss_kernel, dim3(1), dim3(DL_THREADS), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(det_loss_kernel, dim3(DL_BLOCKS), dim3(DL_THREADS), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(det_loss_finish_kernel, dim3(DL_BLOCKS), dim3(DL_THREADS), 0, (hipStream_t)stream, a);
   return check_launch("bq_det_loss_fwd");
 }
 

@@ -75,7 +75,11 @@ struct GemmArgs {
   int n;
   int total_tiles;
   GemmProblem p[GEMM_MAX_PROBLEMS];
+  // stream-K form of gemm128_kernel (csrc/gemm_mid.hip) only: tickets ({arrive, done} u32 pairs per tile, zero between
+  // launches) in the first SK_TICKET_BYTES, fp32 partial-tile slabs (2 per workgroup, 128 KB each) behind them
+  void *sk_ws;
 };
+constexpr long SK_TICKET_BYTES = 65536, SK_SLAB_BYTES = 256 * 128 * 4;
 static_assert(sizeof(GemmArgs) <= 4096, "kernel-argument limit");
 
 // ---- LDS images -----------------------------------------------------------------------------------------------------
@@ -195,5 +199,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // csrc/gemm_mid.hip: the 256 (i) x 128 (j) tile kernel (bf16 out, K-contiguous Q); -1 when it has no such form
 int launch_gemm_mid(const GemmArgs &ga, bool p_xc, bool q_xc, bool out_f32, int epi, bool background, hipStream_t st);
+// the stream-K workspace registered for `st` (bq_gemm_set_workspace), or nullptr
+void *gemm_sk_workspace(hipStream_t st, long *bytes);
 
 }  // namespace bq

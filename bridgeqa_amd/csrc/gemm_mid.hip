@@ -40,6 +40,20 @@
 // barrier that follows makes every wave's DMAs visible to all.  In the FIRST K tile of a continuing tile the previous
 // tile's S epilogue stores sit between those DMAs and the wait: vmcnt(6 + S) there.  Past the workgroup's last tile the
 // cursors park on the out-of-range sentinel (zeros, no traffic) so that the counts keep their meaning.
+//
+// STREAM-K form (template flag SK, round 5).  The N = 768 / K = 3072 launches of the image encoder (fc2
+// forward, the input gradient through fc1) are 387 tiles of 48 K tiles on 512 workgroup slots: one ragged round, the CUs
+// that hold two tiles set the makespan at 96 K-tile executions while the balanced share is 72.6.  With SK a workgroup walks
+// a contiguous range of K-TILE UNITS [b(s), b(s+1)), b(s) = s U / G snapped so that no segment is a single K tile
+// (U = tiles x K tiles, G = grid, s = the XCD-aware slot of the block): a tail of one tile, whole tiles, a head of the next --
+// the same continuous LDS-DMA stream, the cursors simply start a segment at its first K tile.  A tile cut across n
+// workgroups is finished by whichever of them ARRIVES LAST (no workgroup ever waits for one that has not run yet, so the
+// scheme cannot deadlock under any dispatch order): at the end of its segment a workgroup draws a ticket (agent-scope atomic
+// on tick[t].arrive); not last -> it writes its fp32 accumulators to its slab with write-through (sc1) stores, drains them,
+// and counts itself in tick[t].done; last -> it waits until done == n - 1 (the others are already past their K loops: a wait
+// of microseconds), reads their slabs with sc1 loads, resets the two ticket words and runs the ordinary epilogue.  Protocol
+// after MI355X_MICROARCH.md "Valid forms" (sc1 payload, every storing wave's vmcnt(0), workgroup barrier, one lane's
+// agent-scope atomic; the reader: one lane polls with relaxed agent loads, workgroup barrier, sc1 loads of every byte).
 #include "gemm_common.h"
 
 // measurement builds only (tools/bench_gemm_dw.py): 1 = no MFMAs (the memory stream alone), 2 = no LDS-DMAs
@@ -56,11 +70,12 @@ typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
-template <bool P_XC, bool Q_XC, int EPI, bool OUT_F32, int ST_AUX>
+template <bool P_XC, bool Q_XC, int EPI, bool OUT_F32, int ST_AUX, bool SK = false>
 __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
   static_assert(!OUT_F32 || (P_XC && Q_XC && EPI == EPI_NONE), "fp32 out = the weight-gradient form");
   static_assert(!Q_XC || OUT_F32, "a contraction-major Q = the weight-gradient form");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[65536 + 4 * 2048];
+  static_assert(!SK || (!OUT_F32 && EPI != EPI_BIAS_GELU), "stream-K: bf16 out, one output");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[65536 + 4 * 2048 + (SK ? 16 : 0)];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,10 +95,13 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
 
   // ---- virtual block id -> (problem, tile): XCD-aware as in gemm256_kernel (blocks b, b + 8, ... share an XCD's L2; G is
   // a multiple of 8 or the whole grid, so v = b + n G stays on b's XCD) -------------------------------------------------
-  struct Tile { int pi, i0, j0, nkt; };
-  auto decode = [&](int v) {
-    const int q = nwg >> 3, r = nwg & 7, x = v & 7;
-    const int t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (v >> 3);
+  // nkt: K tiles of this work item (a whole tile, or -- SK -- a segment starting at K tile kt0 of tile t)
+  struct Tile { int pi, i0, j0, nkt, kt0, t; };
+  auto xcd_order = [](int v, int n) {   // bijection blocks -> positions: the blocks of one XCD (b, b + 8, ...) are neighbours
+    const int q = n >> 3, r = n & 7, x = v & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (v >> 3);
+  };
+  auto decode_t = [&](int t) {
     int pi = 0;
     for (int k = 1; k < args.n; ++k)
       if (t >= args.p[k].tile0) pi = k;
@@ -95,8 +113,30 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
     tt.j0 = (tiles_j - 1 - tl / pr.tiles_i()) * 128;   // ragged last j block first
     tt.i0 = (tl % pr.tiles_i()) * 256;
     tt.nkt = (pr.Kc + 63) >> 6;
+    tt.kt0 = 0;
+    tt.t = t;
     return tt;
   };
+  auto decode = [&](int v) { return decode_t(xcd_order(v, nwg)); };
+  // ---- stream-K: unit ranges (one problem per launch; every tile has nkt_full K tiles) -----------------------------------
+  const int nkt_full = SK ? (args.p[0].Kc + 63) >> 6 : 1;   // (1: the lambdas below are dead code without SK)
+  const int U = SK ? nwg * nkt_full : 0;
+  auto bound = [&](int x) {   // first unit of slot x; never 1 K tile away from a tile edge (a segment has >= 2 K tiles)
+    int b = (int)((long)x * U / G);
+    const int r = b % nkt_full;
+    return r == 1 ? b - 1 : (r == nkt_full - 1 ? b + 1 : b);
+  };
+  auto seg = [&](int u, int ue) {   // the work item starting at unit u of the range that ends at ue
+    const int t = u / nkt_full;
+    Tile tt = decode_t(t);
+    tt.kt0 = u - t * nkt_full;
+    const int left = nkt_full - tt.kt0;
+    tt.nkt = left < ue - u ? left : ue - u;
+    return tt;
+  };
+  const int slot = SK ? xcd_order((int)blockIdx.x, G) : 0;
+  int su = SK ? bound(slot) : 0;
+  const int sue = SK ? bound(slot + 1) : 0;
 
   // ---- the DMA stream: one cursor per staging group, (tile, K tile) advancing independently of the compute side ------
   // a unit = 8 DMAs of 1 KB (8 rows x 128 B), two per wave: unit rows (w + 4 d) * 8 + lane / 8
@@ -114,8 +154,9 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
     unsigned v;
     if (!P_XC) v = (unsigned)(((tt.i0 + half * 64 + ur0) * ldp + (cp ^ (ur0 & 7)) * 8) * 2);
     else v = (unsigned)((ur0 * ldp + tt.i0 + half * 64 + (cp ^ (xg(ur0) << 1)) * 8) * 2);
-    vP[half] = live ? v : DEAD;
     stepP[half] = P_XC ? (unsigned)(64 * ldp * 2) : 128u;
+    if (SK) v += (unsigned)tt.kt0 * stepP[half];
+    vP[half] = live ? v : DEAD;
     dgP[half] = P_XC ? 256u : (unsigned)(128 * ldp * 2);
     ddP[half] = (unsigned)(32 * ldp * 2);
     remP[half] = live ? tt.nkt : 0x40000000;
@@ -138,16 +179,17 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
       v = (unsigned)((ur0 * pr.ldq + tt.j0 + (c >> 2) * 64 + half * 32 + (c & 3) * 8) * 2);
       ddQ[half] = (unsigned)(32 * pr.ldq * 2);
     }
-    vQ[half] = live ? v : DEAD;
     stepQ[half] = Q_XC ? (unsigned)(64 * pr.ldq * 2) : 128u;
+    if (SK) v += (unsigned)tt.kt0 * stepQ[half];
+    vQ[half] = live ? v : DEAD;
     remQ[half] = live ? tt.nkt : 0x40000000;
     rsrcQ_pi[half] = tt.pi;
   };
 
   int v = blockIdx.x;
-  Tile cur = decode(v);
-  bool has_next = v + G < nwg;
-  Tile nxt = has_next ? decode(v + G) : cur;
+  Tile cur = SK ? seg(su, sue) : decode(v);
+  bool has_next = SK ? (su + cur.nkt < sue) : (v + G < nwg);
+  Tile nxt = has_next ? (SK ? seg(su + cur.nkt, sue) : decode(v + G)) : cur;
 
   // stage P unit pair `half` (PA0 / PA1: both wave rows, 4 DMAs per wave) at its cursor, advance the cursor
   auto dma_p = [&](int half) {
@@ -280,12 +322,80 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
       BQ_MID_COMPUTE_END();
     }
 
+    // ---- stream-K: a tile cut across several workgroups is finished by the one that arrives last (header) ------------------
+    bool sk_partial = false;
+    if (SK && cur.nkt != nkt_full) {
+      unsigned *tick = (unsigned *)args.sk_ws + 2 * cur.t;
+      float *slabs = (float *)((char *)args.sk_ws + SK_TICKET_BYTES);
+      // participants: the slots whose unit range meets [t nkt, (t + 1) nkt) -- a run of consecutive slots around this one
+      const int t0 = cur.t * nkt_full, t1 = t0 + nkt_full;
+      int s_lo = slot, s_hi = slot;
+      while (s_lo > 0 && bound(s_lo) > t0) --s_lo;
+      while (s_hi + 1 < G && bound(s_hi + 1) < t1) ++s_hi;
+      const int n_part = s_hi - s_lo + 1;
+      const unsigned flag_lds = (unsigned)(size_t)((lds_u8_t *)smem) + 65536u + 4u * 2048u;
+      if (wave == 0) {
+        unsigned old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+        asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(flag_lds), "v"(old) : "memory");
+      }
+      BQ_BARRIER();
+      unsigned arrived;
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(arrived) : "v"(flag_lds) : "memory");
+      arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
+      const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void *)slabs, 0, (unsigned)(2 * G) * (unsigned)SK_SLAB_BYTES > 0x7fffffffu
+                                                         ? 0x7fffffffu : (unsigned)(2 * G) * (unsigned)SK_SLAB_BYTES, 0x00020000);
+      // slab of (slot, which of its two possible partial segments): the first one iff the slot's range starts inside the tile
+      auto slab_off = [&](int sl) { return (unsigned)((2 * sl + (bound(sl) >= t0 ? 0 : 1))) * (unsigned)SK_SLAB_BYTES; };
+      if (arrived != (unsigned)(n_part - 1)) {
+        // not last: park the accumulators.  The last K tile's two youngest restages first (they belong to the next item)
+        sk_partial = true;
+        __builtin_amdgcn_sched_barrier(0);
+        dma_q(0, gk + 1);
+        dma_p(1);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned base = slab_off(slot) + (unsigned)(wave * 32 * 1024 + lane * 16);
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[a][b]), rsW, base + (unsigned)((a * 4 + b) * 1024), 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BQ_BARRIER();
+        if (wave == 0 && lane == 0) __hip_atomic_fetch_add(tick + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        // last: every other participant is past its K loop; wait for their slabs, take the tickets back, fold
+        if (wave == 0 && lane == 0) {
+          while (__hip_atomic_load(tick + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(n_part - 1)) __builtin_amdgcn_s_sleep(4);
+          __hip_atomic_store(tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(tick + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        BQ_BARRIER();
+        for (int sl = s_lo; sl <= s_hi; ++sl) {
+          if (sl == slot) continue;
+          const unsigned base = slab_off(sl) + (unsigned)(wave * 32 * 1024 + lane * 16);
+#pragma unroll
+          for (int a = 0; a < 8; ++a) {
+            u32x4_t part[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) part[b] = __builtin_amdgcn_raw_buffer_load_b128(rsW, base + (unsigned)((a * 4 + b) * 1024), 0, 16);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(part[0]), "+v"(part[1]), "+v"(part[2]), "+v"(part[3])::"memory");
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] += __builtin_bit_cast(f32x4, part[b]);
+          }
+        }
+      }
+    }
+
     // ---- epilogue.  accumulator (a, b)[r]: i = iw + a*16 + q4*4 + r, j = jw + b*16 + row16.  The staging buffers belong
     // to the next tile by now, so the bf16 results go through a wave-private 2 KB image of their own -- [16 j][64 i], 16-B
     // chunk c of row j at j*128 + ((c ^ (j & 7)) << 4), one (j block, i half) at a time -- and leave as whole 128-B lines
     // (8 rows per store instruction; stores of 64-B row pieces straight from the accumulators measured 15 % slower on the
     // whole launch).  Bounds-checked buffer stores that ALWAYS issue: the next tile's counted waits know their number.
-    if (OUT_F32) {
+    if (SK && sk_partial) {
+      // (parked: the tile's last arriver stores it)
+    } else if (OUT_F32) {
       // fp32 weight gradients straight from the accumulators (16 B per lane, 64-B row pieces; once per ~260 K tiles).  The
       // last K tile's two youngest restages first; every store issues (out-of-range offsets are dropped)
       __builtin_amdgcn_sched_barrier(0);
@@ -444,19 +554,76 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
       }
     }
 
-    v += G;
-    if (v >= nwg) break;
-    cur = nxt;
-    has_next = v + G < nwg;
-    if (has_next) nxt = decode(v + G);
+    if (SK) {
+      su += cur.nkt;
+      if (su >= sue) break;
+      cur = nxt;
+      has_next = su + cur.nkt < sue;
+      if (has_next) nxt = seg(su + cur.nkt, sue);
+    } else {
+      v += G;
+      if (v >= nwg) break;
+      cur = nxt;
+      has_next = v + G < nwg;
+      if (has_next) nxt = decode(v + G);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the parked cursors' out-of-range DMAs have written their zeros
 }
 
-int launch_gemm_mid(const GemmArgs &ga, bool p_xc, bool q_xc, bool out_f32, int epi, bool background, hipStream_t stream) {
+// ---- stream-K workspaces: one per stream (launches of one stream are serialised; a captured launch keeps the pointer, so a
+// graph must replay on the stream it was captured on, which is how pipeline.py and graphed.py replay) -------------------------
+struct SkWorkspace { int device; hipStream_t stream; void *ptr; long bytes; };
+static SkWorkspace g_sk_ws[16];
+static int g_sk_n = 0;
+
+void *gemm_sk_workspace(hipStream_t st, long *bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  for (int i = 0; i < g_sk_n; ++i)
+    if (g_sk_ws[i].device == dev && g_sk_ws[i].stream == st) {
+      *bytes = g_sk_ws[i].bytes;
+      return g_sk_ws[i].ptr;
+    }
+  return nullptr;
+}
+
+// measurement switch (tools/bench_gemm2.py --no-streamk): BQ_GEMM_STREAMK=0 in the environment keeps every launch on whole tiles
+static bool sk_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("BQ_GEMM_STREAMK");
+    on = (e == nullptr || e[0] != '0') ? 1 : 0;
+  }
+  return on == 1;
+}
+
+int launch_gemm_mid(const GemmArgs &ga_in, bool p_xc, bool q_xc, bool out_f32, int epi, bool background, hipStream_t stream) {
   const int slots = 2 * device_cus();   // two co-resident workgroups per CU (64 KB of LDS, <= 256 VGPRs each)
-  for (int k = 0; k < ga.n; ++k)
-    if (ga.p[k].Kc < 128) return -1;   // (the QB0 cursor runs two K tiles ahead: a tile has at least two)
+  for (int k = 0; k < ga_in.n; ++k)
+    if (ga_in.p[k].Kc < 128) return -1;   // (the QB0 cursor runs two K tiles ahead: a tile has at least two)
+  GemmArgs ga = ga_in;
+  ga.sk_ws = nullptr;
+  // stream-K (header): one problem, a K-contiguous P (forward, or dX on the transposed weight copy), bf16 out, a long
+  // contraction cut across a grid that whole tiles would fill unevenly -- the N = 768 / K = 3072 launches of the ViT MLP
+  if (sk_enabled() && !background && ga.n == 1 && !p_xc && !q_xc && !out_f32 && (epi == EPI_NONE || epi == EPI_BIAS || epi == EPI_ADD)) {
+    const int nkt = (ga.p[0].Kc + 63) >> 6, tiles = ga.total_tiles;
+    const long units = (long)tiles * nkt;
+    const int rounds = (tiles + slots - 1) / slots;
+    long ws_bytes = 0;
+    void *ws = gemm_sk_workspace(stream, &ws_bytes);
+    // worth it when whole tiles leave >= 15 % of the makespan idle and a share is still >= 16 K tiles (the hand-off moves
+    // 128 KB per cut: ~1/3 of a 48-K-tile share's gain at 36 K tiles, more than the gain of a 12-K-tile contraction)
+    if (ws != nullptr && nkt >= 24 && tiles >= slots / 2 && units / slots >= 16 && (long)rounds * nkt * slots >= units * 115 / 100
+        && 8L * tiles <= SK_TICKET_BYTES && ws_bytes >= SK_TICKET_BYTES + 2L * slots * SK_SLAB_BYTES) {
+      ga.sk_ws = ws;
+      const dim3 grid(slots), block(256);
+      if (epi == EPI_NONE) hipLaunchKernelGGL((gemm128_kernel<false, false, EPI_NONE, false, 16, true>), grid, block, 0, stream, ga);
+      else if (epi == EPI_BIAS) hipLaunchKernelGGL((gemm128_kernel<false, false, EPI_BIAS, false, 16, true>), grid, block, 0, stream, ga);
+      else hipLaunchKernelGGL((gemm128_kernel<false, false, EPI_ADD, false, 16, true>), grid, block, 0, stream, ga);
+      return 0;
+    }
+  }
   // background: one workgroup per CU (BQ_GEMM_BACKGROUND, include/bqhip_fusion.h)
   const int use = background ? (slots + 1) / 2 : slots;
   const dim3 grid(ga.total_tiles < use ? ga.total_tiles : use), block(256);
@@ -491,3 +658,24 @@ int launch_gemm_mid(const GemmArgs &ga, bool p_xc, bool q_xc, bool out_f32, int 
 }
 
 }  // namespace bq
+
+extern "C" long bq_gemm_workspace_bytes(void) {
+  return bq::SK_TICKET_BYTES + 2L * 2L * bq::device_cus() * bq::SK_SLAB_BYTES;
+}
+
+extern "C" int bq_gemm_set_workspace(void *ws, long bytes, void *stream) {
+  using namespace bq;
+  int dev = 0;
+  BQ_REQUIRE(hipGetDevice(&dev) == hipSuccess, BQ_EINVAL, "bq_gemm_set_workspace: no device");
+  BQ_REQUIRE(ws == nullptr || bytes >= bq_gemm_workspace_bytes(), BQ_EINVAL, "bq_gemm_set_workspace: %ld bytes < %ld", bytes,
+             bq_gemm_workspace_bytes());
+  for (int i = 0; i < g_sk_n; ++i)
+    if (g_sk_ws[i].device == dev && g_sk_ws[i].stream == (hipStream_t)stream) {
+      g_sk_ws[i].ptr = ws;
+      g_sk_ws[i].bytes = bytes;
+      return 0;
+    }
+  BQ_REQUIRE(g_sk_n < 16, BQ_ELIMIT, "bq_gemm_set_workspace: more than 16 (device, stream) pairs");
+  g_sk_ws[g_sk_n++] = SkWorkspace{dev, (hipStream_t)stream, ws, bytes};
+  return 0;
+}

@@ -41,6 +41,23 @@ def side_stream(name, device):
     return _SIDE_STREAMS[key]
 
 
+_PHASE_STREAMS = {}
+
+
+def phase_streams(device, main_priority=-1, det_priority=0):
+    """(main, detector) phase streams of `device`, created ONCE per process and priority pair: pipeline.PhasedTrainStep and
+    graphed.GraphedRunner replay their phase graphs on these.  Streams are a scarce per-process resource on this runtime (a
+    handful of hardware queues; streams beyond them share queues, and two phase streams that land on one queue execute
+    their graphs packet by packet behind each other): a second runner in the same process -- bench.py's reference-loop
+    measurement after the phased one -- ran its latency-bound phases 3x slower on freshly created streams (fusion forward
+    11.1 against 3.9 ms) than on the first runner's."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), int(main_priority), int(det_priority))
+    if key not in _PHASE_STREAMS:
+        _PHASE_STREAMS[key] = (torch.cuda.Stream(device=device, priority=int(main_priority)),
+                               torch.cuda.Stream(device=device, priority=int(det_priority)))
+    return _PHASE_STREAMS[key]
+
+
 class fork(object):
     """with fork("name", tensor) as s: ... runs the body on a side stream that first waits for the current one.
     Call .join(*tensors) afterwards: the current stream waits for the side stream and the tensors produced on it

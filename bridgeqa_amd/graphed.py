@@ -528,8 +528,7 @@ class GraphedRunner(object):
         self.static_in = {k: ({kk: (t.clone() if torch.is_tensor(t) else t) for kk, t in v.items()} if isinstance(v, dict)
                               else v.clone()) for k, v in ((k, data_dict[k]) for k in _INPUT_KEYS)}
         if not self._streams_ready:   # (streams and events are shared by every captured set of this runner)
-            self.s_main = torch.cuda.Stream(device=dev, priority=-1)
-            self.s_det = torch.cuda.Stream(device=dev, priority=0)
+            self.s_main, self.s_det = ops.phase_streams(dev, -1, 0)   # (the process-wide pair, shared with PhasedTrainStep)
             (self.e_det_fwd, self.e_fwd, self.e_grads, self.e_fused, self.e_det_bwd, self.e_img_bwd, self.e_loss,
              self.e_t_refresh, self.e_opt, self.e_comm) = (torch.cuda.Event() for _ in range(10))
             self._streams_ready = True
@@ -558,10 +557,12 @@ class GraphedRunner(object):
 
         def probe(name):
             if name == "fusion_bwd":
-                seen["fusion"] = {id(p): p.grad._version for p in params if p.grad is not None}
+                seen["fusion"] = {id(p): (id(p.grad), p.grad._version) for p in params if p.grad is not None}
+                seen["keep"] = [p.grad for p in params if p.grad is not None]   # (ids stay unique while these live)
             elif name == "end":
                 seen["late"] = {id(p) for p in params if p.grad is not None
-                                and seen["fusion"].get(id(p), -1) != p.grad._version}
+                                and seen["fusion"].get(id(p)) != (id(p.grad), p.grad._version)}
+                seen.pop("keep", None)
                 seen["all"] = [p for p in params if p.grad is not None]
         n_warm = max(1, self.warmup)
         for it in range(n_warm):

@@ -124,10 +124,11 @@ class PhasedTrainStep(object):
         # the critical path (image forward -> fusion -> image backward -> optimizer) on a HIGH-priority stream: its
         # kernels win the dispatch whenever both streams have work (measured, c3: 46.5 -> 45.5 ms; the detector stream at
         # high priority instead: 47.3 ms; this stack offers two levels, 0 and -1)
-        self.s_main = torch.cuda.Stream(device=dev, priority=int(main_priority))
+        # (the process-wide pair: fusion_state.phase_streams -- a second runner must not open more streams)
+        self.s_main, self.s_det = ops.phase_streams(dev, int(main_priority),
+                                                    int(_DET_PRIORITY[0] if det_priority is None else det_priority))
         self.s_img = self.s_main
         self.e_img_fwd = torch.cuda.Event()
-        self.s_det = torch.cuda.Stream(device=dev, priority=int(_DET_PRIORITY[0] if det_priority is None else det_priority))
         self.e_text_bwd, self.e_t_refresh = torch.cuda.Event(), torch.cuda.Event()
         self.t_refresh = bool(ops.TRANSPOSED_DX[0]) and bm is not None
         self.e_det_fwd, self.e_fused, self.e_det_bwd, self.e_done = (torch.cuda.Event() for _ in range(4))

@@ -283,6 +283,15 @@ typedef struct bq_gemm_desc {
 } bq_gemm_desc;
 BQ_API int bq_gemm_max_problems(void); /* problems per launch; longer lists are split into several launches */
 BQ_API int bq_gemm_bf16(const bq_gemm_desc *problems, int n, int flags, int epilogue, int tile, void *stream);
+/* Stream-K form of the 256 x 128 tile kernel (ABI 4; csrc/gemm_mid.hip header): single-problem forward / K-contiguous dX
+ * launches with a long contraction whose whole tiles would fill the grid unevenly (the ViT MLP's N = 768 / K = 3072
+ * launches: 387 tiles of 48 K tiles on 512 workgroups) are cut into equal runs of K tiles; a cut tile is finished by the
+ * workgroup that arrives last, through fp32 slabs in a caller-provided workspace.  bq_gemm_set_workspace registers the
+ * workspace the launches of `stream` may use (device memory of >= bq_gemm_workspace_bytes(), its first 64 KB ZEROED once --
+ * the kernel leaves the tickets zero); without one, or with ws = NULL, those launches run on whole tiles as before.  At most
+ * one launch at a time may use a workspace: one workspace per stream, and a captured launch replays on its capture stream. */
+BQ_API long bq_gemm_workspace_bytes(void);
+BQ_API int bq_gemm_set_workspace(void *ws, long bytes, void *stream);
 
 /* Column sums of a list of bf16 matrices in ONE launch: out[n] += sum_m g[m*ld + n] (fp32 atomics: out must be zeroed
  * by the caller).  Replaces grad.sum(0), the bias gradient of nn.Linear, for every parked linear of a backward pass.
@@ -358,7 +367,7 @@ BQ_API int bq_lmhead_ce_dlogits(void *logits, const float *lse, const int *targe
  * (lib/dataset.py:553-577); seed_inds int32 or int64 (seed_inds_i64).  terms f32 [16]: vote_loss, objectness_loss,
  * center_loss, heading_cls_loss, heading_reg_loss, size_cls_loss, size_reg_loss, sem_cls_loss, pos_ratio, neg_ratio (the
  * data_dict entries of loss_helper.py:400-430, before the caller's weights and the x10).  g_*: d term / d input, the term named
- * by bq_det_loss_bwd's order, shaped like the input; scratch: int32 [B * G]. */
+ * by bq_det_loss_bwd's order, shaped like the input; scratch: int32 [B * G + 1024]. */
 typedef struct bq_det_loss_desc {
   const float *seed_xyz, *vote_xyz, *aggregated_vote_xyz, *objectness_scores, *center, *heading_scores,
       *heading_residuals_normalized, *size_scores, *size_residuals_normalized, *sem_cls_scores;

@@ -555,3 +555,67 @@ def test_multi_tensor_transpose(dev):
             assert torch.equal(d, s.t())
     with pytest.raises(RuntimeError):
         _ext.transpose_table([(_rand((100, 128), dev, 67), torch.zeros(128, 100, dtype=torch.bfloat16, device=dev))], dev)
+
+
+@pytest.mark.parametrize("M,N,K", [(16400, 768, 3072), (16384, 768, 3072), (16400, 768, 1536), (9000, 1024, 2048),
+                                   (16720, 768, 3072)])
+def test_stream_k_equals_whole_tiles(dev, M, N, K):
+    """the stream-K form of the 256 x 128 kernel (csrc/gemm_mid.hip header: a tile cut across workgroups, finished by the
+    last arriver through fp32 slabs) on the ViT MLP's long-contraction launches -- forward + bias, dX on the transposed
+    weight copy with and without the ADD epilogue -- against torch fp32 and against the same launches on whole tiles
+    (different fp32 summation order: equal up to one bf16 rounding on a few elements), five times over (tickets must
+    come back to zero), ragged row blocks included"""
+    from bridgeqa_amd import _ext
+    x, w = _rand((M, K), dev, 71), _rand((N, K), dev, 72, 0.05)
+    b = torch.randn(N, device=dev)
+    ref = x.float() @ w.float().t() + b
+    _ext.streamk_enable(False)
+    whole = _ext.gemm_fwd(x, w, b, tile=128)
+    _ext.streamk_enable(True)
+    outs = [_ext.gemm_fwd(x, w, b, tile=128) for _ in range(5)]
+    torch.cuda.synchronize()
+    for y in outs:
+        _check(y, ref)
+        assert torch.equal(y, outs[0])                    # same cuts, same order of additions: reproducible
+        assert ((y.float() - whole.float()).abs() > 0).float().mean().item() < 0.05
+        assert ((y.float() - whole.float()).abs().max() / ref.abs().max()).item() < 1e-2
+    # dX of the same layer shape: dy (M, K_out = N) through W (N, K) read as W^T K-contiguous
+    dy, w2 = _rand((M, K), dev, 73), _rand((K, N), dev, 74, 0.05)      # contraction K, out features N
+    aux = _rand((M, N), dev, 75)
+    wt = w2.t().contiguous()
+    for add in (None, aux):
+        got = [_ext.gemm_dx(dy, w2, add=add, wt=wt, tile=128) for _ in range(3)]
+        r = dy.float() @ w2.float() + (add.float() if add is not None else 0.0)
+        torch.cuda.synchronize()
+        for g in got:
+            _check(g, r)
+            assert torch.equal(g, got[0])
+
+
+def test_stream_k_under_load_and_graph_replay(dev):
+    """the hand-off protocol with the chip busy (a second stream keeps launching bandwidth-bound kernels, so workgroups of
+    one launch are not all resident at once and arrive in every order) and replayed from a HIP graph"""
+    from bridgeqa_amd import _ext
+    M, N, K = 16400, 768, 3072
+    x, w = _rand((M, K), dev, 81), _rand((N, K), dev, 82, 0.05)
+    b = torch.randn(N, device=dev)
+    ref = x.float() @ w.float().t() + b
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    junk = torch.empty(64 << 20, device=dev)
+    want = _ext.gemm_fwd(x, w, b, tile=128)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        _ext.gemm_fwd(x, w, b, tile=128)                 # (registers the stream's workspace outside the capture)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s1):
+        y = _ext.gemm_fwd(x, w, b, tile=128)
+    for it in range(6):
+        with torch.cuda.stream(s2):
+            for _ in range(8):
+                junk.mul_(1.0001)
+        with torch.cuda.stream(s1):
+            g.replay()
+        torch.cuda.synchronize()
+        _check(y, ref)
+        assert torch.equal(y, want), it

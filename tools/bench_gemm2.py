@@ -20,8 +20,13 @@ def rnd(*shape, scale=1.0):
     return (torch.randn(*shape, device=dev) * scale).to(torch.bfloat16)
 
 
+_STREAM = []
+
+
 def graph_time(fn, reps=20, rounds=5):
-    s = torch.cuda.Stream()
+    if not _STREAM:
+        _STREAM.append(torch.cuda.Stream())   # (one capture stream: the stream-K workspace is registered per stream)
+    s = _STREAM[0]
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
         for _ in range(3):
@@ -78,7 +83,23 @@ def main():
         if kind == "dw":
             tiles = [256, 64] if m >= 1024 else [64]
         res = {}
-        for tile in tiles:
+        wt = w.t().contiguous() if kind in ("dx", "dxg") else None
+        arms = list(tiles)
+        if m >= 1024 and kind in ("dx", "dxg"):
+            arms.append("128t")            # what the step launches: the K-contiguous transposed weight copy (fusion_state)
+        if m >= 1024 and kind in ("fwd", "dx") and k * (n if kind == "dx" else 1) >= 1536 and (n if kind == "fwd" else k) <= 1024:
+            arms.append("128t-wholetiles" if kind == "dx" else "128-wholetiles")   # the same launch with stream-K withdrawn
+        for arm in arms:
+            tile = 128 if isinstance(arm, str) else arm
+            use_wt = isinstance(arm, str) and arm.startswith("128t")
+            _ext.streamk_enable(not (isinstance(arm, str) and arm.endswith("wholetiles")))
+            if use_wt:
+                if kind == "dx":
+                    mine = lambda: _ext.gemm_dx(dy, w, tile=tile, wt=wt)
+                else:
+                    mine = lambda: _ext.gemm_dx(dy, w, pre_act=pre, tile=tile, wt=wt)
+                res[arm] = graph_time(mine)
+                continue
             if kind == "fwd":
                 mine = lambda: _ext.gemm_fwd(x, w, b, tile=tile)
             elif kind == "fwdg":
@@ -89,7 +110,8 @@ def main():
                 mine = lambda: _ext.gemm_dx(dy, w, pre_act=pre, tile=tile)
             else:
                 mine = lambda: _ext.gemm_dw(dy, x, tile=tile)
-            res[tile] = graph_time(mine)
+            res[arm] = graph_time(mine)
+        _ext.streamk_enable(True)
         if kind == "fwd":
             ref = lambda: torch.nn.functional.linear(x, w, bb)
         elif kind == "fwdg":

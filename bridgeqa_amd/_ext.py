@@ -159,9 +159,23 @@ def ball_query(new_xyz, xyz, radius, nsample, background=False):
     N = xyz.shape[1]
     with torch.cuda.device(xyz.device):
         idx = torch.empty(B, M, nsample, dtype=torch.int32, device=xyz.device)
+        if N >= BALL_QUERY_GRID_MIN_N[0] and B > 0 and M > 0 and nsample > 0 and radius > 0:
+            # large scenes: the same indices through a uniform grid (csrc/ball_query_grid.hip), ~400x fewer distance tests
+            nbytes = int(_lib.bq_ball_query_grid_workspace_bytes(B, N))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device)
+            _check(_lib.bq_ball_query_grid(_p(new_xyz), _p(xyz), _p(idx), B, N, M, float(radius), int(nsample), _p(ws), nbytes,
+                                           _stream()), "ball_query_grid")
+            return idx
         fn = _lib.bq_ball_query_background if background else _lib.bq_ball_query
         _check(fn(_p(new_xyz), _p(xyz), _p(idx), B, N, M, float(radius), int(nsample), _stream()), "ball_query")
     return idx
+
+
+BALL_QUERY_GRID_MIN_N = [8192]   # scenes from this size on go through the grid (tests / tools set it to compare the two paths)
+_lib.bq_ball_query_grid_workspace_bytes.argtypes = [_i, _i]
+_lib.bq_ball_query_grid_workspace_bytes.restype = ctypes.c_size_t
+_lib.bq_ball_query_grid.argtypes = [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, ctypes.c_size_t, _vp]
+_lib.bq_ball_query_grid.restype = ctypes.c_int
 
 
 def group_points(points, idx):

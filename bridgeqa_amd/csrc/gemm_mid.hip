@@ -367,7 +367,10 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
       } else {
         // last: every other participant is past its K loop; wait for their slabs, take the tickets back, fold
         if (wave == 0 && lane == 0) {
-          while (__hip_atomic_load(tick + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(n_part - 1)) __builtin_amdgcn_s_sleep(4);
+          // (bounded: ~0.5 s; the others are already writing their slabs -- a timeout can only mean a protocol bug, and a
+          // wrong tile fails a test where a hang would lose the GPU)
+          for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(tick + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(n_part - 1); ++spin)
+            __builtin_amdgcn_s_sleep(4);
           __hip_atomic_store(tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(tick + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -375,14 +378,17 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
         for (int sl = s_lo; sl <= s_hi; ++sl) {
           if (sl == slot) continue;
           const unsigned base = slab_off(sl) + (unsigned)(wave * 32 * 1024 + lane * 16);
+          // 16 loads (16 KB per wave) in flight per round trip: the fragment registers are free here
 #pragma unroll
-          for (int a = 0; a < 8; ++a) {
-            u32x4_t part[4];
+          for (int a0 = 0; a0 < 8; a0 += 4) {
+            u32x4_t part[16];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) part[b] = __builtin_amdgcn_raw_buffer_load_b128(rsW, base + (unsigned)((a * 4 + b) * 1024), 0, 16);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(part[0]), "+v"(part[1]), "+v"(part[2]), "+v"(part[3])::"memory");
+            for (int e = 0; e < 16; ++e)
+              part[e] = __builtin_amdgcn_raw_buffer_load_b128(rsW, base + (unsigned)((a0 * 4 + e) * 1024), 0, 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] += __builtin_bit_cast(f32x4, part[b]);
+            for (int e = 0; e < 16; ++e) acc[a0 + (e >> 2)][e & 3] += __builtin_bit_cast(f32x4, part[e]);
           }
         }
       }

@@ -268,3 +268,63 @@ def test_ball_query_background_grid_equals_the_full_grid(ext, dev):
         xyz = torch.rand(B, N, 3, device=dev) * 4.0
         new_xyz = xyz[:, torch.randperm(N, device=dev)[:M]].contiguous()
         assert torch.equal(ext.ball_query(new_xyz, xyz, r, S, background=True), ext.ball_query(new_xyz, xyz, r, S))
+
+
+def _grid_vs_scan(ext, new_xyz, xyz, r, S):
+    """the same call through the grid (csrc/ball_query_grid.hip) and through the exhaustive scan"""
+    prev = ext.BALL_QUERY_GRID_MIN_N[0]
+    try:
+        ext.BALL_QUERY_GRID_MIN_N[0] = 1
+        a = ext.ball_query(new_xyz, xyz, r, S)
+        ext.BALL_QUERY_GRID_MIN_N[0] = 1 << 30
+        b = ext.ball_query(new_xyz, xyz, r, S)
+    finally:
+        ext.BALL_QUERY_GRID_MIN_N[0] = prev
+    return a, b
+
+
+@pytest.mark.parametrize("B,N,M,r,S", [(2, 8192, 512, 0.2, 64), (3, 40000, 2048, 0.2, 64), (1, 8193, 100, 0.05, 16),
+                                       (2, 20000, 777, 0.4, 32), (1, 40000, 256, 3.0, 64), (2, 9000, 300, 1.2, 16),
+                                       (1, 100, 7, 0.5, 8), (1, 80000, 2048, 0.2, 64)])
+def test_grid_ball_query_index_exact(ext, oracle, dev, B, N, M, r, S):
+    """bq_ball_query_grid against the oracle (ball_query_gpu.cu:9-44 restated) and against the exhaustive kernel: identical
+    indices -- few-hit balls (ranked in LDS), empty balls, centres far outside the scene's bounding box, radii from a
+    fraction of a cell to the whole scene (the grid collapses to a few cells and every ball overflows into the fallback scan)"""
+    xyz = scene(B, N, 0, seed=N + M)
+    new_xyz = xyz[:, torch.randperm(N, generator=torch.Generator().manual_seed(1))[:M]].contiguous()
+    new_xyz[:, : M // 8] += 0.37           # centres that are not points
+    new_xyz[:, M // 8: M // 4] += 50.0     # far outside: empty balls, all-zero rows
+    new_xyz[:, M // 4: M // 4 + 3] -= 7.0
+    got, scan = _grid_vs_scan(ext, new_xyz.to(dev), xyz.to(dev), r, S)
+    assert torch.equal(got, scan)
+    if N * M <= 2e8:
+        assert torch.equal(got.cpu(), oracle.ball_query(new_xyz, xyz, r, S))
+
+
+def test_grid_ball_query_dense_clusters_ties_and_degenerate_scenes(ext, oracle, dev):
+    """what a uniform random scene does not exercise: thousands of points inside one ball (more hits than the LDS list
+    holds: the per-centre fallback), hit counts on both sides of nsample and of the list capacity, points exactly ON the
+    sphere (d2 == r^2 is outside: strict '<'), duplicated points, a planar scene (zero extent along z), all points equal"""
+    g = torch.Generator().manual_seed(3)
+    N = 12000
+    base = torch.rand(1, N, 3, generator=g) * torch.tensor([6.0, 6.0, 2.5])
+    xyz = base.clone()
+    xyz[0, :3000] = torch.tensor([1.0, 1.0, 1.0]) + 0.05 * torch.randn(3000, 3, generator=g)      # 3000 points in one ball
+    xyz[0, 3000:3300] = torch.tensor([4.0, 4.0, 1.0]) + 0.08 * torch.randn(300, 3, generator=g)   # ~256 hits: the list's edge
+    xyz[0, 3300:3360] = torch.tensor([2.0, 5.0, 1.0]) + 0.05 * torch.randn(60, 3, generator=g)    # ~60 hits: nsample's edge
+    xyz[0, 5000:5100] = xyz[0, 4000:4100]                                                           # duplicates
+    ctr = torch.cat([xyz[:, [10, 3010, 3310, 4000, 5000, 7777]], torch.tensor([[[1.0, 1.0, 1.0], [4.0, 4.0, 1.0], [2.0, 5.0, 1.0]]])], 1)
+    # points exactly on the sphere of the last centre: offsets whose squared length is exactly r^2 = 0.25 in fp32
+    c = torch.tensor([3.0, 2.0, 0.5])
+    xyz[0, 6000] = c + torch.tensor([0.5, 0.0, 0.0]); xyz[0, 6001] = c + torch.tensor([0.3, 0.4, 0.0]); xyz[0, 6002] = c - torch.tensor([0.0, 0.3, 0.4])
+    ctr = torch.cat([ctr, c.view(1, 1, 3)], 1).contiguous()
+    for r, S in ((0.2, 64), (0.5, 64), (0.2, 8), (0.5, 300)):
+        got, scan = _grid_vs_scan(ext, ctr.to(dev), xyz.to(dev), r, S)
+        assert torch.equal(got, scan), (r, S)
+        assert torch.equal(got.cpu(), oracle.ball_query(ctr, xyz.contiguous(), r, S)), (r, S)
+    flat = base.clone(); flat[..., 2] = 0.7
+    same = torch.full((1, N, 3), 1.5)
+    for pts in (flat, same):
+        q = pts[:, :50].contiguous() + 0.01
+        got, scan = _grid_vs_scan(ext, q.to(dev), pts.to(dev), 0.2, 16)
+        assert torch.equal(got, scan) and torch.equal(got.cpu(), oracle.ball_query(q, pts.contiguous(), 0.2, 16))

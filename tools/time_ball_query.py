@@ -23,3 +23,14 @@ e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 100
 print("ball query SA1 (16 x 40000 -> 2048 x 64): %.1f us  = %.2f TB/s of point coordinates read through L2" % (us, 16 * 2048 * 40000 * 12 / us / 1e6))
+# round 5: the same query with the grid withdrawn (exhaustive scan), and the two launches of the grid path apart
+_ext.BALL_QUERY_GRID_MIN_N[0] = 1 << 30
+for _ in range(2):
+    _ext.ball_query(new_xyz, xyz, 0.2, 64)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(10):
+    idx2 = _ext.ball_query(new_xyz, xyz, 0.2, 64)
+e1.record()
+torch.cuda.synchronize()
+print("exhaustive scan: %.1f us; identical indices: %s" % (e0.elapsed_time(e1) * 100, bool(torch.equal(idx, idx2))))

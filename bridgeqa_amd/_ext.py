@@ -968,7 +968,7 @@ def gemm_grouped(problems, flags, epilogue=EPI_NONE, tile=None):
 # ---- stream-K workspaces (bq_gemm_set_workspace): one per (device, stream), allocated at the first tile-128 single-problem
 # launch on that stream OUTSIDE a capture (the warm-up steps of pipeline.py / graphed.py run on the phase streams first); a
 # launch on a stream without one runs on whole tiles
-STREAMK = [True]
+STREAMK = [False]   # round 5: built, parity-green, SLOWER on every shape measured -- off by default
 _SK_WS = {}
 _lib.bq_gemm_workspace_bytes.restype = ctypes.c_long
 _lib.bq_gemm_set_workspace.argtypes = [_vp, ctypes.c_long, _vp]
@@ -1095,7 +1095,7 @@ def wgrad_rows(x, dy, out, workgroups=0):
 _lib.bq_pwconv_records.argtypes = [_l, _i]
 _lib.bq_pwconv_records.restype = ctypes.c_int
 _lib.bq_pwconv_bn_fwd.argtypes = [_vp, _l, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp,
-                                  _vp, _vp]
+                                  _vp, _vp, _vp]
 _lib.bq_pwconv_bn_fwd.restype = ctypes.c_int
 
 
@@ -1113,16 +1113,28 @@ def pwconv_bn_relu_fwd(x, K, w_pad, gamma, beta, running_mean, running_var, num_
     R, N, Kc = x.shape[0], w_pad.shape[0], w_pad.shape[1]
     with torch.cuda.device(x.device):
         y_raw = torch.empty(R, N, dtype=torch.bfloat16, device=x.device)
-        stats = torch.empty(4, N, dtype=torch.float32, device=x.device)
+        stats = torch.empty(5, N, dtype=torch.float32, device=x.device)   # scale, shift, mean, rstd (of the stored y) | shift_acc
         part = torch.empty(_lib.bq_pwconv_records(R, N) * 3 * N, dtype=torch.float32, device=x.device)
         _check(_lib.bq_pwconv_bn_fwd(_p(x), R, int(K), x.stride(0), _p(w_pad), w_pad.stride(0), Kc, N, _p(y_raw), _p(part),
                                      _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(num_batches_tracked),
                                      float(eps), float(momentum), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]),
-                                     _p(center), _stream()), "pwconv_bn_fwd")
+                                     _p(center), _p(stats[4]), _stream()), "pwconv_bn_fwd")
         out = torch.empty(R // S if pool else R, N, dtype=torch.bfloat16, device=x.device)
-        _check(_lib.bq_bn_apply(_p(y_raw), _p(stats[0]), _p(stats[1]), _p(out), R, N, int(S), int(bool(relu)),
-                                int(bool(pool)), _stream()), "bn_apply")
+        if FP32_PREACT[0] and (not pool or (int(S) in (16, 32, 64) and R % int(S) == 0)):
+            # BatchNorm + ReLU (+ max-pool) on the fp32 accumulators of the product computed once more: the output never
+            # passes through the bf16 y_raw (which the backward still reads)
+            _check(_lib.bq_pwconv_bn_apply(_p(x), R, int(K), x.stride(0), _p(w_pad), w_pad.stride(0), Kc, N, _p(stats[0]),
+                                           _p(stats[4]), _p(out), int(S), int(bool(relu)), int(bool(pool)),
+                                           _stream()), "pwconv_bn_apply")
+        else:
+            _check(_lib.bq_bn_apply(_p(y_raw), _p(stats[0]), _p(stats[1]), _p(out), R, N, int(S), int(bool(relu)),
+                                    int(bool(pool)), _stream()), "bn_apply")
     return out, y_raw, stats
+
+
+FP32_PREACT = [True]   # SharedMLP outputs from the fp32 accumulators (bq_pwconv_bn_apply) instead of from the stored bf16 y
+_lib.bq_pwconv_bn_apply.argtypes = [_vp, _l, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]
+_lib.bq_pwconv_bn_apply.restype = ctypes.c_int
 
 
 # ---- LM head + label-smoothed cross entropy (csrc/lmhead.hip + the cross-entropy epilogue of csrc/gemm.hip) -----------

@@ -767,13 +767,21 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
 struct PwconvArgs {
   const __bf16 *W;    // [Ni][ldw], zero beyond K
   const __bf16 *X;    // [R][ldx]
-  __bf16 *Y;          // [R][Ni]
+  __bf16 *Y;          // [R][Ni]  (MODE 1: the layer's output; MODE 2: [R / S][Ni], the maxima over every run of S rows)
   float *partial;     // [Gj * 2][3][Ni]: pivot | sum (y - pivot) | sum (y - pivot)^2, per (row walker, wave column)
   const float *center;  // [Ni] or null: Y holds y - center (see bq_pwconv_bn_fwd); the statistics are those of y
   int ldw, ldx, Ni, R, Kc, Gj, tiles_i;
   unsigned w_bytes, x_bytes;
+  // MODE 1 / 2 (bq_pwconv_bn_apply): BatchNorm's affine map of the STORED values (v = (acc - center) scale + shift), ReLU
+  const float *scale, *shift;
+  int relu, S;
 };
 
+// MODE 0: y and its statistics (the first pass of a SharedMLP layer).  MODE 1 / 2 (round 5): the SAME
+// product once more with BatchNorm + ReLU (+ the max over nsample) applied to the fp32 ACCUMULATORS: the layer's output no
+// longer passes through a bf16 pre-activation -- the one rounding class that reproduced the detector's convergence gap
+// (tools/loss_gap_probe.py) -- for the price of reading x (ldx elements per row) instead of the stored y (Ni elements).
+template <int MODE>
 __global__ __launch_bounds__(256) void pwconv64_kernel(const PwconvArgs a) {
   constexpr int STAGE = 16384, NS = 3;
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
@@ -861,8 +869,108 @@ __global__ __launch_bounds__(256) void pwconv64_kernel(const PwconvArgs a) {
             acc[x][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[x][kk], fb[b][kk], acc[x][b], 0, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // ---- epilogue: y (bf16) and the statistics of the fp32 values ---------------------------------------------------
     const int jw = j0 + wc * 32;
+    if constexpr (MODE != 0) {
+      // ---- epilogue of the apply pass: v = (acc - centre) scale + shift, ReLU, bf16; MODE 2: max over runs of S rows -----
+      float v[2][2][4];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        const int i = iw + x * 16 + q4 * 4;
+        const float4 sc = *reinterpret_cast<const float4 *>(a.scale + i), sh = *reinterpret_cast<const float4 *>(a.shift + i);
+        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float t = __builtin_fmaf(acc[x][b][r], scv[r], shv[r]);   // shift = beta - mean scale of the product itself
+            v[x][b][r] = a.relu ? fmaxf(t, 0.f) : t;
+          }
+      }
+      if constexpr (MODE == 1) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          const int i = iw + x * 16 + q4 * 4;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int j = jw + b * 16 + row16;
+            if (j < a.R) {
+              uint2 pk;
+              pk.x = pack_bf16x2(v[x][b][0], v[x][b][1]);
+              pk.y = pack_bf16x2(v[x][b][2], v[x][b][3]);
+              *reinterpret_cast<uint2 *>(a.Y + (long)j * a.Ni + i) = pk;
+            }
+          }
+        }
+      } else {
+        // rows past R never win (R is a multiple of S: a run is wholly inside or wholly outside)
+        float *s_max = reinterpret_cast<float *>(smem);   // [wc][wr][x][q4][r]: the staging buffers are idle here
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const bool ok = jw + b * 16 + row16 < a.R;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float m = ok ? v[x][b][r] : -3.0e38f;
+              m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2));
+              m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 8));
+              v[x][b][r] = m;   // the maximum over the 16 rows of block b, in every lane of the q4 group
+            }
+          }
+        if (a.S == 16) {
+#pragma unroll
+          for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              const int j = jw + b * 16;
+              if (row16 == 0 && j < a.R) {
+                uint2 pk;
+                pk.x = pack_bf16x2(v[x][b][0], v[x][b][1]);
+                pk.y = pack_bf16x2(v[x][b][2], v[x][b][3]);
+                *reinterpret_cast<uint2 *>(a.Y + (long)(j >> 4) * a.Ni + iw + x * 16 + q4 * 4) = pk;
+              }
+            }
+        } else {
+#pragma unroll
+          for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[x][0][r] = fmaxf(v[x][0][r], v[x][1][r]);   // the wave column's 32 rows
+          if (a.S == 32) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+              if (row16 == 0 && jw < a.R) {
+                uint2 pk;
+                pk.x = pack_bf16x2(v[x][0][0], v[x][0][1]);
+                pk.y = pack_bf16x2(v[x][0][2], v[x][0][3]);
+                *reinterpret_cast<uint2 *>(a.Y + (long)(jw >> 5) * a.Ni + iw + x * 16 + q4 * 4) = pk;
+              }
+          } else {   // S == 64: the two wave columns meet in LDS
+            BQ_BARRIER();   // (every wave is done with this tile's fragment reads)
+            if (wc == 1 && row16 == 0) {
+#pragma unroll
+              for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_max[((wr * 2 + x) * 4 + q4) * 4 + r] = v[x][0][r];
+            }
+            __syncthreads();
+            if (wc == 0 && row16 == 0 && j0 < a.R) {
+#pragma unroll
+              for (int x = 0; x < 2; ++x) {
+                float m[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m[r] = fmaxf(v[x][0][r], s_max[((wr * 2 + x) * 4 + q4) * 4 + r]);
+                uint2 pk;
+                pk.x = pack_bf16x2(m[0], m[1]);
+                pk.y = pack_bf16x2(m[2], m[3]);
+                *reinterpret_cast<uint2 *>(a.Y + (long)(j0 >> 6) * a.Ni + iw + x * 16 + q4 * 4) = pk;
+              }
+            }
+          }
+        }
+      }
+      continue;
+    }
+    // ---- epilogue: y (bf16) and the statistics of the fp32 values ---------------------------------------------------
     if (!have_pivot) {  // this wave's first row: the value every lane of a 16-lane group subtracts from its channels
 #pragma unroll
       for (int x = 0; x < 2; ++x)
@@ -892,6 +1000,7 @@ __global__ __launch_bounds__(256) void pwconv64_kernel(const PwconvArgs a) {
       }
     }
   }
+  if constexpr (MODE != 0) return;
   // ---- one record per (row walker gj, wave column wc): the 16 lanes of a q4 group hold different rows ---------------
   float *rec = a.partial + (long)(gj * 2 + wc) * 3 * a.Ni;
 #pragma unroll
@@ -932,6 +1041,8 @@ struct PwconvBnParams {
   int C, nrec, Gj;
   long R;
   const float *center;   // what the stored y had subtracted (null: nothing): shift / mean describe the STORED values
+  float *shift_acc;      // optional [C]: beta - mean scale for the UNcentred product (bq_pwconv_bn_apply reads the fp32
+                         // accumulators; the centre -- usually running_mean itself -- has moved by then)
 };
 
 // 16 threads per channel: thread phase ph merges the records g = ph (mod 16) in index order, then the sixteen partial
@@ -981,6 +1092,7 @@ __global__ __launch_bounds__(1024) void pwconv_bn_finalize_kernel(const PwconvBn
   p.shift[c] = p.beta[c] - stored_mean * sc;
   p.mean[c] = stored_mean;
   p.rstd[c] = rstd;
+  if (p.shift_acc) p.shift_acc[c] = p.beta[c] - mean * sc;
   if (p.running_mean) {
     const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
     p.running_mean[c] = (1.0f - p.momentum) * p.running_mean[c] + p.momentum * mean;
@@ -1487,7 +1599,8 @@ extern "C" int bq_pwconv_records(long R, int N) {
 extern "C" int bq_pwconv_bn_fwd(const void *x, long R, int K, int ldx, const void *w, int ldw, int Kc, int N, void *y,
                                 float *partial, const float *gamma, const float *beta, float *running_mean,
                                 float *running_var, long long *num_batches_tracked, float eps, float momentum,
-                                float *scale, float *shift, float *mean, float *rstd, const float *center, void *stream) {
+                                float *scale, float *shift, float *mean, float *rstd, const float *center, float *shift_acc,
+                                void *stream) {
   using namespace bq;
   BQ_REQUIRE(x && w && y && partial && gamma && beta && scale && shift && mean && rstd, BQ_EINVAL, "pwconv_bn_fwd: null pointer");
   BQ_REQUIRE(R > 0 && K > 0 && N > 0, BQ_EINVAL, "pwconv_bn_fwd: empty problem");
@@ -1505,9 +1618,35 @@ extern "C" int bq_pwconv_bn_fwd(const void *x, long R, int K, int ldx, const voi
   a.w_bytes = (unsigned)((long)N * ldw * 2);
   a.x_bytes = (unsigned)(R * (long)ldx * 2);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(pwconv64_kernel, dim3(a.tiles_i * a.Gj), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(pwconv64_kernel<0>, dim3(a.tiles_i * a.Gj), dim3(256), 0, st, a);
   PwconvBnParams p{partial, gamma, beta, running_mean, running_var, num_batches_tracked, scale, shift, mean, rstd,
-                   eps, momentum, N, a.Gj * 2, a.Gj, R, center};
+                   eps, momentum, N, a.Gj * 2, a.Gj, R, center, shift_acc};
   hipLaunchKernelGGL(pwconv_bn_finalize_kernel, dim3((N + 63) / 64), dim3(1024), 0, st, p);
   return check_launch("pwconv_bn_fwd");
+}
+
+extern "C" int bq_pwconv_bn_apply(const void *x, long R, int K, int ldx, const void *w, int ldw, int Kc, int N, const float *scale,
+                                  const float *shift_acc, void *out, int S, int relu, int pool, void *stream) {
+  const float *shift = shift_acc, *center = nullptr;
+  using namespace bq;
+  BQ_REQUIRE(x && w && out && scale && shift, BQ_EINVAL, "pwconv_bn_apply: null pointer");
+  BQ_REQUIRE(R > 0 && K > 0 && N > 0, BQ_EINVAL, "pwconv_bn_apply: empty problem");
+  BQ_REQUIRE(N % 64 == 0 && Kc % 64 == 0 && Kc >= K && ldw >= Kc && ldx >= K && ldx % 8 == 0 && ldw % 8 == 0, BQ_EINVAL,
+             "pwconv_bn_apply: need N %% 64 == 0, Kc %% 64 == 0 >= K, ldw >= Kc, ldx >= K, ld %% 8 == 0");
+  BQ_REQUIRE(!pool || ((S == 16 || S == 32 || S == 64) && R % S == 0), BQ_ELIMIT, "pwconv_bn_apply: pooling over S = %d rows", S);
+  BQ_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)out % 16 == 0), BQ_EINVAL,
+             "pwconv_bn_apply: operands must be 16-byte aligned");
+  BQ_REQUIRE(R * (long)ldx * 2 < 0x7FFFFFFFL - 64L * ldx * 2, BQ_ELIMIT, "pwconv_bn_apply: x larger than 2 GB");
+  PwconvArgs a;
+  a.W = (const __bf16 *)w; a.X = (const __bf16 *)x; a.Y = (__bf16 *)out; a.partial = nullptr; a.center = center;
+  a.ldw = ldw; a.ldx = ldx; a.Ni = N; a.R = (int)R; a.Kc = Kc;
+  a.tiles_i = N / 64;
+  a.Gj = bq_pwconv_records(R, N) / 2;
+  a.w_bytes = (unsigned)((long)N * ldw * 2);
+  a.x_bytes = (unsigned)(R * (long)ldx * 2);
+  a.scale = scale; a.shift = shift; a.relu = relu; a.S = S;
+  hipStream_t st = (hipStream_t)stream;
+  if (pool) hipLaunchKernelGGL(pwconv64_kernel<2>, dim3(a.tiles_i * a.Gj), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(pwconv64_kernel<1>, dim3(a.tiles_i * a.Gj), dim3(256), 0, st, a);
+  return check_launch("pwconv_bn_apply");
 }

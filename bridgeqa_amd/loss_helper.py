@@ -180,7 +180,7 @@ def _fused_ok(data_dict):
             if not (v.is_cuda and v.dtype == torch.int64 and v.is_contiguous()):
                 return None
         si = data_dict["seed_inds"]
-        if not (si.is_cuda and si.dtype in (torch.int32, torch.int64) and si.is_contiguous()
+        if not (si.is_cuda and si.dtype in (torch.int32, torch.int64)
                 and max(data_dict["heading_scores"].shape[2], data_dict["size_scores"].shape[2],
                         data_dict["sem_cls_scores"].shape[2]) <= 32
                 and data_dict["vote_label"].shape[2] == 3 * GT_VOTE_FACTOR
@@ -198,6 +198,7 @@ def _fused_detection_terms(data_dict, config, packing):
     mean_sizes = _const(("mean_size", msa.tobytes()), dev, lambda: torch.from_numpy(msa.copy()))
     diff = ("vote_xyz", "center") + _ext._DET_SCORES
     labels = {k: data_dict[k] for k in _FUSED_FLOAT + _FUSED_INT + ("seed_inds",) if k not in diff}
+    labels["seed_inds"] = labels["seed_inds"].contiguous()   # (a column slice of sa1_inds in the model: one small copy)
     if packing:
         # (the slices themselves are still read by the kernel -- through the base's memory)
         labels.update({k: data_dict[k].detach() for k in _ext._DET_SCORES})

@@ -346,7 +346,16 @@ BQ_API int bq_pwconv_records(long R, int N);
 BQ_API int bq_pwconv_bn_fwd(const void *x, long R, int K, int ldx, const void *w, int ldw, int Kc, int N, void *y,
                             float *partial, const float *gamma, const float *beta, float *running_mean,
                             float *running_var, long long *num_batches_tracked, float eps, float momentum,
-                            float *scale, float *shift, float *mean, float *rstd, const float *center, void *stream);
+                            float *scale, float *shift, float *mean, float *rstd, const float *center, float *shift_acc,
+                            void *stream);
+/* The second pass of such a layer WITHOUT a bf16 pre-activation in between (ABI 4): the product x W^T once more, BatchNorm's
+ * affine map (scale and shift_acc = beta - mean scale as bq_pwconv_bn_fwd wrote them -- shift_acc: optional f32 [N] output of
+ * that call, ABI 4, the shift for the UNcentred product), ReLU and -- pool != 0 -- the maximum over every run
+ * of S (16, 32 or 64) rows applied to the fp32 accumulators; out bf16 (R, N) or (R / S, N).  Replaces bq_bn_apply on the
+ * stored y: same traffic class (reads x instead of y), and the layer's output carries one bf16 rounding instead of two
+ * (reference: fp32 throughout, lib/pointnet2/pytorch_utils.py:104-157). */
+BQ_API int bq_pwconv_bn_apply(const void *x, long R, int K, int ldx, const void *w, int ldw, int Kc, int N, const float *scale,
+                              const float *shift_acc, void *out, int S, int relu, int pool, void *stream);
 
 /* ---- LM head + label-smoothed cross entropy (csrc/lmhead.hip, with BQ_GEMM_EPI_BIAS_CE of bq_gemm_bf16) -------------
  * Replaces prediction_scores = cls(sequence_output) -> .float() -> CrossEntropyLoss(reduction='none',

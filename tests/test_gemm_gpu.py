@@ -590,12 +590,14 @@ def test_stream_k_equals_whole_tiles(dev, M, N, K):
         for g in got:
             _check(g, r)
             assert torch.equal(g, got[0])
+    _ext.streamk_enable(False)   # (the product default: DESIGN.md section 4.5 -- measured slower than whole tiles)
 
 
 def test_stream_k_under_load_and_graph_replay(dev):
     """the hand-off protocol with the chip busy (a second stream keeps launching bandwidth-bound kernels, so workgroups of
     one launch are not all resident at once and arrive in every order) and replayed from a HIP graph"""
     from bridgeqa_amd import _ext
+    _ext.streamk_enable(True)
     M, N, K = 16400, 768, 3072
     x, w = _rand((M, K), dev, 81), _rand((N, K), dev, 82, 0.05)
     b = torch.randn(N, device=dev)
@@ -619,3 +621,4 @@ def test_stream_k_under_load_and_graph_replay(dev):
         torch.cuda.synchronize()
         _check(y, ref)
         assert torch.equal(y, want), it
+    _ext.streamk_enable(False)

@@ -310,8 +310,11 @@ def test_wrapped_optimizer_replays_the_same_update(dev):
 def test_enable_refuses_a_ddp_wrap_and_exchanges_gradients_itself_on_rccl_world_1(dev):
     """the replayed backward runs no AccumulateGrad node, so DistributedDataParallel's reducer never
     fires -- enable() refuses a DDP-wrapped model, and under an initialised process group the runner exchanges the static
-    gradients itself (forced at world 1 over the real RCCL backend: same gradients as without any exchange, every gradient
-    covered by exactly one group, the token embeddings in the late group)"""
+    gradients itself (forced at world 1 over the real RCCL backend): every gradient is covered by exactly one group, the
+    token embeddings (whose gradient the detector-stream phase still adds to) travel in the late group, and every group is
+    exchanged only once its gradients are FINAL -- what each reducer packed equals the gradient the step ends with, bit for
+    bit (fp32 wire, one rank).  (Two executions of this small random-init model are not comparable gradient by gradient:
+    its loss moves by 5 % between two eager steps -- fp32 atomics under a discontinuous detection loss.)"""
     import os
     import torch.distributed as dist
     import bench
@@ -324,31 +327,39 @@ def test_enable_refuses_a_ddp_wrap_and_exchanges_gradients_itself_on_rccl_world_
         with pytest.raises(TypeError, match="DistributedDataParallel"):
             graphed.enable(torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=True))
         graphed.enable(model)
-        for _ in range(2):
-            bench.total_loss(model(dict(batch))).backward()
+        bench.total_loss(model(dict(batch))).backward()
         torch.cuda.synchronize()
         assert model._graphed.reducers is None          # one rank: no exchange
-        want = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        n_grads = sum(1 for p in model.parameters() if p.grad is not None)
         graphed.disable(model)
         graphed.enable(model)
         model._graphed.force_comm = True                 # the world-1 collectives run for real
-        for _ in range(2):
-            bench.total_loss(model(dict(batch))).backward()
+        bench.total_loss(model(dict(batch))).backward()  # (captures; builds the groups)
         torch.cuda.synchronize()
         runner = model._graphed
         assert set(runner.reducers) == {"fusion", "rest"} and runner.broadcaster is not None
         ids = [id(p) for r in runner.reducers.values() for p in r.params]
-        assert len(ids) == len(set(ids)) == len(want)
+        assert len(ids) == len(set(ids)) == n_grads
         late = {id(p) for p in runner.reducers["rest"].params}
         names = {id(p): n for n, p in model.named_parameters()}
         assert any("embeddings" in names[i] for i in late) and any("visual_encoder" in names[i] for i in late)
         assert all(names[id(p)].startswith("blip_model.") and "visual_encoder" not in names[id(p)]
                    for p in runner.reducers["fusion"].params)
-        got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
-        assert set(got) == set(want)
-        # (fp32 wire at world 1 is exact; what differs between two executions is the detector's fp32 atomics)
-        worst = max(((got[n] - want[n]).norm() / (want[n].norm() + 1e-12)).item() for n in want if n.startswith("blip_model."))
-        assert worst < 2e-2, worst
+        # what every group packs (on the communication stream, when its turn comes) against the step's final gradients
+        packed = {}
+        for name, r in runner.reducers.items():
+            orig = r.all_reduce
+
+            def spy(r=r, orig=orig, name=name):
+                packed[name] = [p.grad.detach().clone() for p in r.params]
+                orig()
+            r.all_reduce = spy
+        bench.total_loss(model(dict(batch))).backward()  # a pure replay
+        torch.cuda.synchronize()
+        assert set(packed) == {"fusion", "rest"}
+        for name, r in runner.reducers.items():
+            for p, g in zip(r.params, packed[name]):
+                assert torch.isfinite(p.grad).all() and torch.equal(p.grad, g), (name, names[id(p)])
         graphed.disable(model)
     finally:
         dist.destroy_process_group()

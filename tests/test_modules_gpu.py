@@ -211,6 +211,7 @@ def test_pwconv_preactivation_stored_relative_to_a_centre(dev):
     the mean it keeps 8 bits of the spread itself (tools/loss_gap_probe.py: rounding in front of BatchNorm is the one
     rounding class that reproduces the bf16 detector path's convergence gap)."""
     from bridgeqa_amd import _ext
+    prev_fp32, _ext.FP32_PREACT[0] = _ext.FP32_PREACT[0], False   # (this test is about the STORED pre-activation's apply path)
     g = torch.Generator().manual_seed(1)
     R, K, N, S = 20000, 64, 64, 16
     x = torch.randn(R, K, generator=g) * 0.5
@@ -244,6 +245,58 @@ def test_pwconv_preactivation_stored_relative_to_a_centre(dev):
                                                 center=rm)
     assert rel(stats[2], mean - rm0) < 1e-3 and rel(rm, 0.9 * rm0 + 0.1 * mean) < 1e-5
     assert rel(out.float(), want) < 1e-2
+    _ext.FP32_PREACT[0] = prev_fp32
+
+
+@pytest.mark.parametrize("R,K,N,S,pool", [(20000, 64, 64, 16, False), (20032, 131, 128, 64, True), (8192 + 32, 7, 64, 32, True),
+                                          (4096 + 16, 64, 256, 16, True), (64 * 1031, 128, 128, 64, True)])
+def test_sharedmlp_output_from_the_fp32_accumulators(dev, R, K, N, S, pool):
+    """bq_pwconv_bn_apply: BatchNorm + ReLU (+ the max over nsample) taken from the fp32 accumulators of
+    the product computed once more -- the layer's output carries ONE bf16 rounding (its own), whatever the channel means:
+    with means 50x the spread the stored-pre-activation path is off by 7e-2, this one by the output rounding only; pooled
+    and unpooled, the three run lengths, ragged last tiles, a centre that finalize has already moved (running_mean)"""
+    from bridgeqa_amd import _ext
+    g = torch.Generator().manual_seed(R + N)
+    ld = (K + 7) // 8 * 8
+    x = torch.zeros(R, ld)
+    x[:, :K] = torch.randn(R, K, generator=g) * 0.5
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    x[:, 0] = 1.0
+    w[:, 0] = 25.0                                  # channel means ~25, spread ~0.5
+    Kc = (K + 63) // 64 * 64
+    w_pad = torch.zeros(N, Kc)
+    w_pad[:, :K] = w
+    x_d, w_d = x.to(dev).to(torch.bfloat16), w_pad.to(dev).to(torch.bfloat16)
+    gamma, beta = (torch.rand(N, generator=g) + 0.5).to(dev), (torch.randn(N, generator=g) * 0.1).to(dev)
+    y = x_d[:, :K].float() @ w_d[:, :K].float().t()
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    want = torch.relu((y - mean) * (var + 1e-5).rsqrt() * gamma + beta)
+    if pool:
+        want = want.view(R // S, S, N).max(1).values
+    rel = lambda a, b: ((a - b).norm() / (b.norm() + 1e-20)).item()
+    errs = {}
+    for fp32 in (True, False):
+        prev, _ext.FP32_PREACT[0] = _ext.FP32_PREACT[0], fp32
+        try:
+            rm = (mean + 0.2).contiguous()          # the centre = running_mean, which the finalize kernel updates in place
+            out, y_raw, stats = _ext.pwconv_bn_relu_fwd(x_d, K, w_d, gamma, beta, rm, torch.ones(N, device=dev),
+                                                        torch.zeros((), dtype=torch.int64, device=dev), 1e-5, 0.1, S, True, pool,
+                                                        center=rm)
+        finally:
+            _ext.FP32_PREACT[0] = prev
+        assert out.shape == want.shape
+        errs[fp32] = rel(out.float(), want)
+    assert errs[True] < 3.5e-3, errs                # one bf16 rounding of the output
+    no_centre = {}
+    for fp32 in (True, False):
+        prev, _ext.FP32_PREACT[0] = _ext.FP32_PREACT[0], fp32
+        try:
+            out, _, _ = _ext.pwconv_bn_relu_fwd(x_d, K, w_d, gamma, beta, torch.zeros(N, device=dev), torch.ones(N, device=dev),
+                                                torch.zeros((), dtype=torch.int64, device=dev), 1e-5, 0.1, S, True, pool)
+        finally:
+            _ext.FP32_PREACT[0] = prev
+        no_centre[fp32] = rel(out.float(), want)
+    assert no_centre[True] < 3.5e-3 and no_centre[False] > 5 * no_centre[True], (errs, no_centre)
 
 
 def test_native_sharedmlp_sa_module_vs_fp32_reference(dev):

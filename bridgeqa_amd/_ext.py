@@ -1132,7 +1132,10 @@ def pwconv_bn_relu_fwd(x, K, w_pad, gamma, beta, running_mean, running_var, num_
     return out, y_raw, stats
 
 
-FP32_PREACT = [True]   # SharedMLP outputs from the fp32 accumulators (bq_pwconv_bn_apply) instead of from the stored bf16 y
+# SharedMLP outputs from the fp32 accumulators (bq_pwconv_bn_apply) instead of from the stored bf16 y.  OFF: measured in round 5
+#  -- the layer output's error drops to one bf16 rounding, the 200-step convergence gap to fp32 does NOT
+# close (+7.2 % against +3.3 % with the stored pre-activation, fp32's own spread 13 %) and the c3 step costs 1.3 ms more
+FP32_PREACT = [False]
 _lib.bq_pwconv_bn_apply.argtypes = [_vp, _l, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]
 _lib.bq_pwconv_bn_apply.restype = ctypes.c_int
 
@@ -1329,3 +1332,58 @@ def det_loss_bwd(grads, upstream, packing=None):
     with torch.cuda.device(upstream.device):
         _check(_lib.bq_det_loss_bwd(arr, len(segs), _p(upstream), _stream()), "det_loss_bwd")
     return outs
+
+
+# ---- deterministic scatter gradients through an inverted index (csrc/invert.hip) ---------------------------------------------
+DETERMINISTIC_SCATTER = [True]
+_lib.bq_invert_index_workspace_bytes.argtypes = [_l]
+_lib.bq_invert_index_workspace_bytes.restype = ctypes.c_size_t
+_lib.bq_invert_index.argtypes = [_vp, _i, _l, _i, _vp, _vp, _vp, ctypes.c_size_t, _vp]
+_lib.bq_invert_index.restype = ctypes.c_int
+_lib.bq_group_concat_pm_grad_gather.argtypes = [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]
+_lib.bq_group_concat_pm_grad_gather.restype = ctypes.c_int
+_lib.bq_three_interpolate_grad_gather.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]
+_lib.bq_three_interpolate_grad_gather.restype = ctypes.c_int
+
+
+def invert_index(idx, N):
+    """idx int32 (B, ...) with values in [0, N) -> (start int32 (B * N + 1,), slots int32-sized uint32 (B * L,)): for scene b
+    and value v the positions b * L + l with idx[b].flatten()[l] == v are slots[start[b * N + v] : start[b * N + v + 1]],
+    ascending"""
+    _req(idx, torch.int32, "idx")
+    B = idx.shape[0]
+    L = idx.numel() // max(B, 1)
+    with torch.cuda.device(idx.device):
+        start = torch.empty(B * int(N) + 1, dtype=torch.int32, device=idx.device)
+        slots = torch.empty(max(B * L, 1), dtype=torch.int32, device=idx.device)
+        nbytes = int(_lib.bq_invert_index_workspace_bytes(B * L))
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=idx.device)
+        _check(_lib.bq_invert_index(_p(idx), B, L, int(N), _p(start), _p(slots), _p(ws), nbytes, _stream()), "invert_index")
+    return start, slots
+
+
+def group_concat_pm_grad_gather(grad_out, inv, n):
+    """the feature gradient of group_concat_pm as a gather over inv = invert_index(idx, n): grad_out (B, M, S, 3 + C) rows
+    (contiguous or padded rows of a uniform stride % 8 == 0) -> f32 (B, n, C); None when the layout is not the kernel's"""
+    B, M, S, CT = grad_out.shape
+    C = CT - 3
+    ld = grad_out.stride(2)
+    if (grad_out.stride(3) != 1 or grad_out.stride(1) != S * ld or grad_out.stride(0) != M * S * ld or ld < CT or ld % 8
+            or grad_out.data_ptr() % 16 or grad_out.dtype not in (torch.bfloat16, torch.float32) or C <= 0):
+        return None
+    with torch.cuda.device(grad_out.device):
+        gf = torch.empty(B, int(n), C, dtype=torch.float32, device=grad_out.device)
+        _check(_lib.bq_group_concat_pm_grad_gather(_p(grad_out), int(grad_out.dtype == torch.bfloat16), _p(inv[0]), _p(inv[1]),
+                                                   _p(gf), B, C, int(n), ld, _stream()), "group_concat_pm_grad_gather")
+    return gf
+
+
+def three_interpolate_grad_gather(grad_out, inv, weight, m):
+    """grad_out f32 (B, C, n) contiguous, inv = invert_index(idx (B, n, 3), m), weight f32 (B, n, 3) -> f32 (B, C, m)"""
+    _req(grad_out, torch.float32, "grad_out"); _req(weight, torch.float32, "weight")
+    B, C, n = grad_out.shape
+    with torch.cuda.device(grad_out.device):
+        out = torch.empty(B, C, int(m), dtype=torch.float32, device=grad_out.device)
+        _check(_lib.bq_three_interpolate_grad_gather(_p(grad_out), _p(inv[0]), _p(inv[1]), _p(weight), _p(out), B, C, n, int(m),
+                                                     _stream()), "three_interpolate_grad_gather")
+    return out

@@ -1,0 +1,193 @@
+// Deterministic scatter gradients through an INVERTED INDEX.
+//
+// group_points_grad / three_interpolate_grad of the reference (lib/pointnet2/_ext_src/src/group_points_gpu.cu:43-75,
+// interpolate_gpu.cu:116-154) scatter with fp32 atomics: the order of the additions -- and with it the rounding of every sum --
+// changes from launch to launch.  Those sums feed the deepest layers of the detector; two executions of the same step
+// differed by 2.6-7.9 % on BatchNorm bias gradients that are sums of nearly cancelling terms.  Here the scatter is turned
+// around: bq_invert_index sorts the positions of an index tensor by the point they name (a STABLE radix sort of
+// (scene * N + point, position) pairs: rocPRIM through hipCUB -- within a point the positions stay ascending) into a CSR
+// table, and the gradient kernels GATHER: one sum per destination, its terms added in ascending position order.  Same terms as
+// the reference, a fixed order, no atomics, no zero-fill; bitwise reproducible.
+#include <hipcub/hipcub.hpp>
+
+#include "bq_common.h"
+#include "bqhip_fusion.h"
+
+namespace bq {
+
+__global__ __launch_bounds__(256) void invert_keys_kernel(const int32_t *__restrict__ idx, unsigned *__restrict__ keys,
+                                                          unsigned *__restrict__ vals, long L, int N, long total) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / L;
+    int v = idx[i];
+    v = v < 0 ? 0 : (v >= N ? N - 1 : v);   // (the operators clamp nothing; an index outside [0, N) is the caller's bug)
+    keys[i] = (unsigned)(b * N + v);
+    vals[i] = (unsigned)i;
+  }
+}
+
+// start[k] = first sorted position whose key is >= k, for k = 0 .. K (K = B * N): entry i fills the keys it opens
+__global__ __launch_bounds__(256) void invert_starts_kernel(const unsigned *__restrict__ keys, int32_t *__restrict__ start,
+                                                            long total, long K) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i <= total; i += (long)gridDim.x * 256) {
+    const long lo = i == 0 ? 0 : (long)keys[i - 1] + 1;
+    const long hi = i == total ? K : (long)keys[i];
+    for (long k = lo; k <= hi; ++k) start[k] = (int32_t)i;
+  }
+}
+
+// grad_feats[b][n][c] = sum over the positions p = (b, m, s) with idx[p] == n, ascending, of grad_out[p][3 + c].
+// grad_out rows of `ld` elements (bf16 or fp32), the three offset channels first (group_concat_pm's layout).
+// LP lanes per point, one 8-element chunk of the row per lane and trip (chunk j covers channels 8 j - 3 .. 8 j + 4).
+template <typename OT, int LP>
+__global__ __launch_bounds__(256) void group_concat_pm_grad_gather_kernel(const OT *__restrict__ grad_out,
+                                                                          const int32_t *__restrict__ start,
+                                                                          const unsigned *__restrict__ slots,
+                                                                          float *__restrict__ grad_feats, int C, long points, int ld) {
+  const int sub = threadIdx.x % LP;
+  const int chunks = ld >> 3;
+  for (long pt = ((long)blockIdx.x * 256 + threadIdx.x) / LP; pt < points; pt += (long)gridDim.x * 256 / LP) {
+    const int e0 = start[pt], e1 = start[pt + 1];
+    for (int j = sub; j < chunks; j += LP) {
+      float acc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+      for (int e = e0; e < e1; ++e) {
+        const OT *g = grad_out + (long)slots[e] * ld + j * 8;
+        if constexpr (sizeof(OT) == 2) {
+          const uint4 raw = *reinterpret_cast<const uint4 *>(g);
+          const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[2 * q] += __uint_as_float(w[q] << 16);
+            acc[2 * q + 1] += __uint_as_float(w[q] & 0xffff0000u);
+          }
+        } else {
+          const float4 a = *reinterpret_cast<const float4 *>(g), b = *reinterpret_cast<const float4 *>(g + 4);
+          acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+          acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+        }
+      }
+      float *o = grad_feats + pt * C;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = j * 8 + e - 3;
+        if (c >= 0 && c < C) o[c] = acc[e];
+      }
+    }
+  }
+}
+
+// grad_points[b][c][m] = sum over the positions p = (b, j, k) with idx[p] == m, ascending, of grad_out[b][c][j] * weight[b][j][k]
+__global__ __launch_bounds__(256) void three_interpolate_grad_gather_kernel(const float *__restrict__ grad_out,
+                                                                            const int32_t *__restrict__ start,
+                                                                            const unsigned *__restrict__ slots,
+                                                                            const float *__restrict__ weight,
+                                                                            float *__restrict__ grad_points, int C, int n, int m,
+                                                                            long total) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int mi = (int)(t % m);
+    const long bc = t / m;
+    const int c = (int)(bc % C);
+    const long b = bc / C;
+    const int e0 = start[b * m + mi], e1 = start[b * m + mi + 1];
+    const float *go = grad_out + (b * C + c) * (long)n;
+    float acc = 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const unsigned p = slots[e];             // = (b * n + j) * 3 + k
+      const long j = (long)(p / 3u) - b * n;
+      acc += go[j] * weight[p];
+    }
+    grad_points[t] = acc;
+  }
+}
+
+}  // namespace bq
+
+extern "C" size_t bq_invert_index_workspace_bytes(long total) {
+  if (total <= 0) return 0;
+  size_t temp = 0;
+  hipcub::DoubleBuffer<unsigned> k(nullptr, nullptr), v(nullptr, nullptr);
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, k, v, (int)total, 0, 32, (hipStream_t) nullptr);
+  return ((temp + 255) & ~(size_t)255) + 3 * (size_t)total * sizeof(unsigned) + 256;
+}
+
+// idx int32 (B, L) with values in [0, N): -> start int32 [B * N + 1] (CSR over scene * N + value), slots uint32 [B * L] = the
+// positions b * L + l of every value in ascending order.  workspace: bq_invert_index_workspace_bytes(B * L) bytes.
+extern "C" int bq_invert_index(const int32_t *idx, int B, long L, int N, int32_t *start, unsigned *slots, void *workspace,
+                               size_t workspace_bytes, void *stream) {
+  using namespace bq;
+  BQ_REQUIRE(B >= 0 && L >= 0 && N > 0, BQ_EINVAL, "invert_index: bad extents");
+  const long total = (long)B * L, K = (long)B * N;
+  BQ_REQUIRE(total < (1L << 31) && K < (1L << 31), BQ_ELIMIT, "invert_index: more than 2^31 entries");
+  BQ_REQUIRE(start, BQ_EINVAL, "invert_index: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (total == 0) {
+    hipLaunchKernelGGL(invert_starts_kernel, dim3(1), dim3(256), 0, st, (const unsigned *)nullptr, start, 0L, K);
+    return check_launch("invert_index");
+  }
+  BQ_REQUIRE(idx && slots && workspace && workspace_bytes >= bq_invert_index_workspace_bytes(total), BQ_EINVAL,
+             "invert_index: workspace of %zu bytes required", bq_invert_index_workspace_bytes(total));
+  size_t temp = 0;
+  {
+    hipcub::DoubleBuffer<unsigned> k(nullptr, nullptr), v(nullptr, nullptr);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, k, v, (int)total, 0, 32, st);
+  }
+  temp = (temp + 255) & ~(size_t)255;
+  unsigned char *w = (unsigned char *)workspace;
+  unsigned *keys_a = (unsigned *)(w + temp), *keys_b = keys_a + total, *vals_a = keys_b + total;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(invert_keys_kernel, dim3(blocks), dim3(256), 0, st, idx, keys_a, vals_a, L, N, total);
+  int bits = 1;
+  while ((1L << bits) < K) ++bits;
+  // (plain pointer form: keys_a -> keys_b, vals_a -> slots; radix sort is stable, so equal keys keep ascending positions)
+  hipError_t e = hipcub::DeviceRadixSort::SortPairs((void *)w, temp, (const unsigned *)keys_a, keys_b, (const unsigned *)vals_a, slots,
+                                                    (int)total, 0, bits, st);
+  if (e != hipSuccess) { set_error("invert_index: radix sort failed: %s", hipGetErrorString(e)); return (int)e; }
+  hipLaunchKernelGGL(invert_starts_kernel, dim3(blocks), dim3(256), 0, st, (const unsigned *)keys_b, start, total, K);
+  return check_launch("invert_index");
+}
+
+extern "C" int bq_group_concat_pm_grad_gather(const void *grad_out, int in_bf16, const int32_t *start, const unsigned *slots,
+                                              float *grad_feats, int B, int C, int N, int ld, void *stream) {
+  using namespace bq;
+  BQ_REQUIRE(grad_out && start && slots && grad_feats, BQ_EINVAL, "group_concat_pm_grad_gather: null pointer");
+  BQ_REQUIRE(B >= 0 && C > 0 && N > 0 && ld >= C + 3 && ld % 8 == 0, BQ_EINVAL, "group_concat_pm_grad_gather: ld = %d must be a multiple of 8 >= 3 + C", ld);
+  BQ_REQUIRE(((uintptr_t)grad_out % 16) == 0, BQ_EINVAL, "group_concat_pm_grad_gather: grad_out must be 16-byte aligned");
+  const long points = (long)B * N;
+  if (points == 0) return BQ_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = ld / 8;
+  long blocks;
+  if (chunks <= 16) {
+    blocks = (points * 16 + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (in_bf16) hipLaunchKernelGGL((group_concat_pm_grad_gather_kernel<__bf16, 16>), dim3((unsigned)blocks), dim3(256), 0, st,
+                                    (const __bf16 *)grad_out, start, slots, grad_feats, C, points, ld);
+    else hipLaunchKernelGGL((group_concat_pm_grad_gather_kernel<float, 16>), dim3((unsigned)blocks), dim3(256), 0, st,
+                            (const float *)grad_out, start, slots, grad_feats, C, points, ld);
+  } else {
+    blocks = (points * 32 + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (in_bf16) hipLaunchKernelGGL((group_concat_pm_grad_gather_kernel<__bf16, 32>), dim3((unsigned)blocks), dim3(256), 0, st,
+                                    (const __bf16 *)grad_out, start, slots, grad_feats, C, points, ld);
+    else hipLaunchKernelGGL((group_concat_pm_grad_gather_kernel<float, 32>), dim3((unsigned)blocks), dim3(256), 0, st,
+                            (const float *)grad_out, start, slots, grad_feats, C, points, ld);
+  }
+  return check_launch("group_concat_pm_grad_gather");
+}
+
+extern "C" int bq_three_interpolate_grad_gather(const float *grad_out, const int32_t *start, const unsigned *slots,
+                                                const float *weight, float *grad_points, int B, int C, int n, int m, void *stream) {
+  using namespace bq;
+  BQ_REQUIRE(grad_out && start && slots && weight && grad_points, BQ_EINVAL, "three_interpolate_grad_gather: null pointer");
+  BQ_REQUIRE(B >= 0 && C >= 0 && n >= 0 && m > 0, BQ_EINVAL, "three_interpolate_grad_gather: bad extents");
+  const long total = (long)B * C * m;
+  if (total == 0) return BQ_OK;
+  long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(three_interpolate_grad_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grad_out, start,
+                     slots, weight, grad_points, C, n, m, total);
+  return check_launch("three_interpolate_grad_gather");
+}

@@ -116,6 +116,10 @@ class ThreeInterpolate(Function):
     @staticmethod
     def backward(ctx, grad_out):
         idx, weight = ctx.saved_tensors
+        if _det_scatter(grad_out):
+            # gather over the inverted index: one sum per known point, terms in ascending order (no fp32 atomics)
+            inv = _ext.invert_index(idx, ctx.m)
+            return _ext.three_interpolate_grad_gather(grad_out.contiguous().float(), inv, weight.contiguous(), ctx.m), None, None
         return _ext.three_interpolate_grad(grad_out.contiguous(), idx, weight, ctx.m), None, None
 
 
@@ -161,6 +165,10 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
+def _det_scatter(t):
+    return t.is_cuda and _ext is _hip_ext and getattr(_ext, "DETERMINISTIC_SCATTER", [False])[0]
+
+
 class _GroupConcat(Function):
     """Fused tail of QueryAndGroup (pointnet2_utils.py:348-359): one kernel writes
     cat([(xyz[idx]-centre)/radius, features[idx]], dim=1) instead of 2 gathers + sub + div + cat."""
@@ -197,8 +205,14 @@ class _GroupConcatPM(Function):
     def backward(ctx, grad_out):
         (idx,) = ctx.saved_tensors
         need = ctx.needs_input_grad
-        gf, gx, gn = _ext.group_concat_pm_grad(grad_out, idx, ctx.n, ctx.radius, ctx.normalize,
-                                               ctx.has_features and need[2], need[0], need[1])
+        want_f = ctx.has_features and need[2]
+        if want_f and not need[0] and not need[1] and _det_scatter(grad_out):
+            # the feature gradient as a GATHER over the inverted group index: bitwise reproducible (the coordinates of a
+            # training step carry no gradient; a caller that asks for one takes the atomic scatter below)
+            gf = _ext.group_concat_pm_grad_gather(grad_out, _ext.invert_index(idx, ctx.n), ctx.n)
+            if gf is not None:
+                return None, None, gf, None, None, None, None, None
+        gf, gx, gn = _ext.group_concat_pm_grad(grad_out, idx, ctx.n, ctx.radius, ctx.normalize, want_f, need[0], need[1])
         return gx, gn, gf, None, None, None, None, None
 
 

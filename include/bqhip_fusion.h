@@ -369,6 +369,25 @@ BQ_API int bq_lmhead_ce_combine(const float *partial, const float *target_logit,
 BQ_API int bq_lmhead_ce_dlogits(void *logits, const float *lse, const int *target, const float *grad_loss, int R, int V,
                                 int ld, float label_smoothing, void *stream);
 
+/* ---- deterministic scatter gradients through an inverted index (csrc/invert.hip, ABI 4) ---------------------------------------
+ * Replaces the fp32-atomic scatters of group_points_grad / three_interpolate_grad (lib/pointnet2/_ext_src/src/
+ * group_points_gpu.cu:43-75, interpolate_gpu.cu:116-154) by gathers: one sum per destination, terms in ascending position
+ * order -- same terms, a fixed order, bitwise reproducible.
+ * bq_invert_index: idx int32 (B, L), values in [0, N) -> start int32 [B * N + 1] (CSR over scene * N + value), slots uint32
+ *   [B * L]: the positions b * L + l naming each value, ascending (stable radix sort); workspace of
+ *   bq_invert_index_workspace_bytes(B * L) bytes.
+ * bq_group_concat_pm_grad_gather: the FEATURE gradient of bq_group_concat_pm from the inverted group index (idx (B, M, S) ->
+ *   L = M * S): grad_out rows of ld elements (bf16 / fp32), grad_feats f32 (B, N, C) written whole (no zero-fill).
+ * bq_three_interpolate_grad_gather: idx (B, n, 3) inverted over m known points (L = 3 n); grad_out f32 (B, C, n), weight f32
+ *   (B, n, 3) -> grad_points f32 (B, C, m). */
+BQ_API size_t bq_invert_index_workspace_bytes(long total);
+BQ_API int bq_invert_index(const int32_t *idx, int B, long L, int N, int32_t *start, unsigned *slots, void *workspace,
+                           size_t workspace_bytes, void *stream);
+BQ_API int bq_group_concat_pm_grad_gather(const void *grad_out, int in_bf16, const int32_t *start, const unsigned *slots,
+                                          float *grad_feats, int B, int C, int N, int ld, void *stream);
+BQ_API int bq_three_interpolate_grad_gather(const float *grad_out, const int32_t *start, const unsigned *slots,
+                                            const float *weight, float *grad_points, int B, int C, int n, int m, void *stream);
+
 /* ---- detection loss and its gradient (csrc/detloss.hip) -------------------------------------------------------------------
  * Replaces compute_vote_loss + compute_objectness_loss + compute_box_and_sem_cls_loss of lib/loss_helper.py:25-193 (over
  * utils/nn_distance.py:6-52) and what autograd derives from them: ~460 torch launches on B x 256 proposals -> two.

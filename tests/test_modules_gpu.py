@@ -198,7 +198,9 @@ def test_pwconv_bn_kernel_vs_torch_fp32(dev):
         assert rel(stats[3], (var + 1e-5).rsqrt()) < 1e-4, (R, K, N, rel(stats[3], (var + 1e-5).rsqrt()))
         assert rel(rm, 0.1 * mean) < 1e-5 and rel(rv, 0.9 + 0.1 * y.var(0, unbiased=True)) < 1e-4
         assert nbt.item() == 1
-        ref = torch.relu((y_raw.float() - mean) * (var + 1e-5).rsqrt() * gamma + beta)
+        # (the default apply pass normalises the STORED bf16 pre-activation; with _ext.FP32_PREACT the fp32 product itself)
+        src = y if _ext.FP32_PREACT[0] else y_raw.float()
+        ref = torch.relu((src - mean) * (var + 1e-5).rsqrt() * gamma + beta)
         if pool:
             ref = ref.view(R // S, S, N).max(1)[0]
         assert rel(out.float(), ref) < 5e-3, (R, K, N, rel(out.float(), ref))

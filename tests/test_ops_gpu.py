@@ -328,3 +328,45 @@ def test_grid_ball_query_dense_clusters_ties_and_degenerate_scenes(ext, oracle, 
         q = pts[:, :50].contiguous() + 0.01
         got, scan = _grid_vs_scan(ext, q.to(dev), pts.to(dev), 0.2, 16)
         assert torch.equal(got, scan) and torch.equal(got.cpu(), oracle.ball_query(q, pts.contiguous(), 0.2, 16))
+
+
+def test_inverted_index_and_deterministic_scatter_gradients(ext, oracle, dev):
+    """csrc/invert.hip: bq_invert_index is a CSR of the positions naming every point, ascending inside a
+    point; the feature gradient of the point-major grouping and the gradient of three_interpolate as GATHERS over it equal
+    the oracle's (group_points_gpu.cu:43-75, interpolate_gpu.cu:116-154 restated) and are bitwise reproducible -- the atomic
+    scatters are not"""
+    g = torch.Generator().manual_seed(5)
+    B, N, M, S, C = 3, 5000, 256, 32, 61
+    idx = torch.randint(0, N, (B, M, S), generator=g, dtype=torch.int32)
+    idx[:, :, S // 2:] = idx[:, :, :1]                      # the padding pattern of a sparse ball: one index repeated
+    idx[0, :40] = 7                                         # one point named by 1280 slots
+    d_idx = idx.to(dev)
+    start, slots = ext.invert_index(d_idx, N)
+    start, slots = start.cpu().long(), slots.cpu().long()
+    flat = idx.view(B, -1).long()
+    assert start[0] == 0 and start[-1] == B * M * S and (start[1:] >= start[:-1]).all()
+    for b, v in ((0, 7), (1, int(flat[1, 5])), (2, int(flat[2, -1])), (2, N - 1)):
+        got = slots[start[b * N + v]:start[b * N + v + 1]]
+        want = (flat[b] == v).nonzero().flatten() + b * M * S
+        assert torch.equal(got, want), (b, v)
+    # feature gradient of group_concat_pm: padded bf16 rows (ld = 64) and contiguous fp32 rows
+    for dt, ld in ((torch.bfloat16, 64), (torch.float32, 64)):
+        go = torch.zeros(B, M, S, ld, dtype=dt, device=dev)
+        go[..., :3 + C] = torch.randn(B, M, S, 3 + C, generator=g).to(dev).to(dt)
+        rows = go[..., :3 + C]
+        inv = ext.invert_index(d_idx, N)
+        outs = [ext.group_concat_pm_grad_gather(rows, inv, N) for _ in range(3)]
+        assert outs[0] is not None and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        want = oracle.group_points_grad(rows.float().cpu().permute(0, 3, 1, 2)[:, 3:].contiguous(), idx, N).transpose(1, 2)
+        torch.testing.assert_close(outs[0].cpu(), want, rtol=2e-5, atol=2e-4)
+        atomic, _, _ = ext.group_concat_pm_grad(rows, d_idx, N, 0.2, True, True, False, False)
+        torch.testing.assert_close(outs[0], atomic, rtol=2e-5, atol=2e-4)
+    # three_interpolate: n unknown points over m known ones
+    n, m, Cf = 700, 90, 33
+    idx3 = torch.randint(0, m, (B, n, 3), generator=g, dtype=torch.int32)
+    w3 = torch.rand(B, n, 3, generator=g)
+    go3 = torch.randn(B, Cf, n, generator=g)
+    inv3 = ext.invert_index(idx3.to(dev), m)
+    got = [ext.three_interpolate_grad_gather(go3.to(dev), inv3, w3.to(dev), m) for _ in range(2)]
+    assert torch.equal(got[0], got[1])
+    torch.testing.assert_close(got[0].cpu(), oracle.three_interpolate_grad(go3, idx3, w3, m), rtol=2e-5, atol=2e-5)

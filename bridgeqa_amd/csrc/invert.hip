@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256) void three_interpolate_grad_gather_kernel(cons
 extern "C" size_t bq_invert_index_workspace_bytes(long total) {
   if (total <= 0) return 0;
   size_t temp = 0;
-  hipcub::DoubleBuffer<unsigned> k(nullptr, nullptr), v(nullptr, nullptr);
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, k, v, (int)total, 0, 32, (hipStream_t) nullptr);
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const unsigned *)nullptr, (unsigned *)nullptr, (const unsigned *)nullptr,
+                                           (unsigned *)nullptr, (int)total, 0, 32, (hipStream_t) nullptr);
   return ((temp + 255) & ~(size_t)255) + 3 * (size_t)total * sizeof(unsigned) + 256;
 }
 
@@ -129,21 +129,20 @@ extern "C" int bq_invert_index(const int32_t *idx, int B, long L, int N, int32_t
   BQ_REQUIRE(idx && slots && workspace && workspace_bytes >= bq_invert_index_workspace_bytes(total), BQ_EINVAL,
              "invert_index: workspace of %zu bytes required", bq_invert_index_workspace_bytes(total));
   size_t temp = 0;
-  {
-    hipcub::DoubleBuffer<unsigned> k(nullptr, nullptr), v(nullptr, nullptr);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, k, v, (int)total, 0, 32, st);
-  }
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const unsigned *)nullptr, (unsigned *)nullptr, (const unsigned *)nullptr,
+                                           (unsigned *)nullptr, (int)total, 0, 32, st);
+  const size_t temp_exact = temp;
   temp = (temp + 255) & ~(size_t)255;
   unsigned char *w = (unsigned char *)workspace;
   unsigned *keys_a = (unsigned *)(w + temp), *keys_b = keys_a + total, *vals_a = keys_b + total;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(invert_keys_kernel, dim3(blocks), dim3(256), 0, st, idx, keys_a, vals_a, L, N, total);
-  int bits = 1;
-  while ((1L << bits) < K) ++bits;
-  // (plain pointer form: keys_a -> keys_b, vals_a -> slots; radix sort is stable, so equal keys keep ascending positions)
-  hipError_t e = hipcub::DeviceRadixSort::SortPairs((void *)w, temp, (const unsigned *)keys_a, keys_b, (const unsigned *)vals_a, slots,
-                                                    (int)total, 0, bits, st);
+  // (plain pointer form: keys_a -> keys_b, vals_a -> slots; radix sort is stable, so equal keys keep ascending positions.
+  // All 32 key bits, as in the size query: rocPRIM's temporary-storage requirement depends on the bit range)
+  size_t temp_use = temp_exact;
+  hipError_t e = hipcub::DeviceRadixSort::SortPairs((void *)w, temp_use, (const unsigned *)keys_a, keys_b, (const unsigned *)vals_a, slots,
+                                                    (int)total, 0, 32, st);
   if (e != hipSuccess) { set_error("invert_index: radix sort failed: %s", hipGetErrorString(e)); return (int)e; }
   hipLaunchKernelGGL(invert_starts_kernel, dim3(blocks), dim3(256), 0, st, (const unsigned *)keys_b, start, total, K);
   return check_launch("invert_index");

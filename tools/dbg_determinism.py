@@ -9,7 +9,10 @@ class A: points, cin, image, batch = 40000, 132, 512, 16
 torch.manual_seed(0)
 model = bench.build_model("c2", A.cin, A.image).to(dev).train()
 batch = bench.make_batch(A, "c2", 16, 42, dev)
+bufs = {k: v.clone() for k, v in model.named_buffers()}
 def run():
+    with torch.no_grad():
+        for k, v in model.named_buffers(): v.copy_(bufs[k])   # (the running statistics are the centre the stored pre-activations are rounded around)
     for p in model.parameters(): p.grad = None
     l = bench.det_loss(model(dict(batch))); l.backward(); torch.cuda.synchronize()
     return l.item(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}

@@ -1340,7 +1340,7 @@ _lib.bq_invert_index_workspace_bytes.argtypes = [_l]
 _lib.bq_invert_index_workspace_bytes.restype = ctypes.c_size_t
 _lib.bq_invert_index.argtypes = [_vp, _i, _l, _i, _vp, _vp, _vp, ctypes.c_size_t, _vp]
 _lib.bq_invert_index.restype = ctypes.c_int
-_lib.bq_group_concat_pm_grad_gather.argtypes = [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]
+_lib.bq_group_concat_pm_grad_gather.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]
 _lib.bq_group_concat_pm_grad_gather.restype = ctypes.c_int
 _lib.bq_three_interpolate_grad_gather.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]
 _lib.bq_three_interpolate_grad_gather.restype = ctypes.c_int
@@ -1362,20 +1362,29 @@ def invert_index(idx, N):
     return start, slots
 
 
-def group_concat_pm_grad_gather(grad_out, inv, n):
-    """the feature gradient of group_concat_pm as a gather over inv = invert_index(idx, n): grad_out (B, M, S, 3 + C) rows
-    (contiguous or padded rows of a uniform stride % 8 == 0) -> f32 (B, n, C); None when the layout is not the kernel's"""
+def group_concat_pm_grad_gather(grad_out, inv, n, radius=1.0, normalize=False, need_features=True, need_xyz=False,
+                                need_new_xyz=False):
+    """the gradients of group_concat_pm as gathers over inv = invert_index(idx, n): grad_out (B, M, S, 3 + C) rows (contiguous
+    or padded rows of a uniform stride % 8 == 0) -> (grad_feats f32 (B, n, C) | None, grad_xyz f32 (B, n, 3) | None,
+    grad_new_xyz f32 (B, M, 3) | None); None (a single value) when the layout is not the kernel's"""
     B, M, S, CT = grad_out.shape
     C = CT - 3
     ld = grad_out.stride(2)
     if (grad_out.stride(3) != 1 or grad_out.stride(1) != S * ld or grad_out.stride(0) != M * S * ld or ld < CT or ld % 8
-            or grad_out.data_ptr() % 16 or grad_out.dtype not in (torch.bfloat16, torch.float32) or C <= 0):
+            or grad_out.data_ptr() % 16 or grad_out.dtype not in (torch.bfloat16, torch.float32)):
         return None
-    with torch.cuda.device(grad_out.device):
-        gf = torch.empty(B, int(n), C, dtype=torch.float32, device=grad_out.device)
+    need_features = bool(need_features) and C > 0
+    if not (need_features or need_xyz or need_new_xyz):
+        return None, None, None
+    dev = grad_out.device
+    with torch.cuda.device(dev):
+        gf = torch.empty(B, int(n), C, dtype=torch.float32, device=dev) if need_features else None
+        gx = torch.empty(B, int(n), 3, dtype=torch.float32, device=dev) if need_xyz else None
+        gn = torch.empty(B, M, 3, dtype=torch.float32, device=dev) if need_new_xyz else None
         _check(_lib.bq_group_concat_pm_grad_gather(_p(grad_out), int(grad_out.dtype == torch.bfloat16), _p(inv[0]), _p(inv[1]),
-                                                   _p(gf), B, C, int(n), ld, _stream()), "group_concat_pm_grad_gather")
-    return gf
+                                                   _p(gf), _p(gx), _p(gn), B, C, int(n), M, S, ld, float(radius),
+                                                   int(bool(normalize)), _stream()), "group_concat_pm_grad_gather")
+    return gf, gx, gn
 
 
 def three_interpolate_grad_gather(grad_out, inv, weight, m):

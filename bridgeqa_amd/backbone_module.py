@@ -52,8 +52,14 @@ class Pointnet2Backbone(nn.Module):
         level_xyz = {}
         with torch.no_grad():
             for i in (1, 2, 3, 4):
+                n_in = xyz.shape[1]
                 inds, xyz, idx = getattr(self, "sa%d" % i).sample_and_query(xyz)
                 geo["sa%d_inds" % i], geo["sa%d_xyz" % i], geo["sa%d_group_idx" % i] = inds, xyz, idx
+                # the inverted group index the deterministic grouping gradient gathers over (csrc/invert.hip): coordinates
+                # only as well, so it is sorted here, ahead of time, instead of inside the backward
+                inv = pointnet2_utils.invert_groups(idx, n_in)
+                if inv is not None:
+                    geo["sa%d_inv_start" % i], geo["sa%d_inv_slots" % i] = inv
                 level_xyz[i] = xyz
             geo["fp1_dist"], geo["fp1_idx"] = pointnet2_utils.three_nn(level_xyz[3], level_xyz[4])
             geo["fp2_dist"], geo["fp2_idx"] = pointnet2_utils.three_nn(level_xyz[2], level_xyz[3])
@@ -66,6 +72,8 @@ class Pointnet2Backbone(nn.Module):
         geo = data_dict.get("geometry")
         for i in (1, 2, 3, 4):
             g = (geo["sa%d_inds" % i], geo["sa%d_xyz" % i], geo["sa%d_group_idx" % i]) if geo is not None else None
+            if g is not None and ("sa%d_inv_start" % i) in geo:
+                g = g + ((geo["sa%d_inv_start" % i], geo["sa%d_inv_slots" % i]),)
             xyz, features, inds = getattr(self, "sa%d" % i)(xyz, features, geometry=g)
             if i <= 2:
                 data_dict["sa%d_inds" % i] = inds

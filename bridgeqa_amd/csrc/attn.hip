@@ -215,17 +215,6 @@ struct TileDma {
 // token of the ViT: one live wave -- holds one wave slot of its CU for the key loop instead of four.
 __device__ __forceinline__ int attn_live_waves(int L, int start) { return min(AT_NW, (L - start + AT_QW - 1) / AT_QW); }
 
-// (row block, batch x head) of this workgroup.  2-D launches: (blockIdx.x, blockIdx.y).  1-D launches (round 5, the PLAIN
-// kernels at a ragged length such as the ViT's L = 1025 = 8 x 128 + 1): the FULL 128-row blocks of all heads first, head by
-// head (neighbours in dispatch order share a head's K / V in L2), the ragged blocks -- one live wave each -- LAST, so that
-// they fill the tail of the launch instead of taking a full-block slot every ninth dispatch.
-__device__ __forceinline__ void attn_item(int L, int BH, int &bx, int &bh) {
-  if (gridDim.y != 1) { bx = blockIdx.x; bh = blockIdx.y; return; }
-  const int nfull = L / AT_QB, id = blockIdx.x;
-  if (id < nfull * BH) { bh = id / nfull; bx = id - bh * nfull; }
-  else { bh = id - nfull * BH; bx = nfull; }
-}
-
 // One 64-key tile (two 32-key blocks) of the online-softmax forward for the 32 queries of a wave: S^T = K.Q^T from
 // the LDS image s_k, mask / causal / length clamp, running max + rescale, P (with dropout) straight from the
 // accumulator registers into O^T += V^T.P^T from the LDS image s_v.  qrow = this lane's query index.
@@ -349,12 +338,10 @@ __device__ __forceinline__ void attn_fwd_body(const __bf16 *__restrict__ Q, cons
   __shared__ __align__(16) unsigned char s_v[2][AT_KB * 128];
   const float scale_log2e = dm.scale * 1.4426950408889634f;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 31, h = lane >> 5;
-  int bx, bh;
-  attn_item(dm.Lq, dm.B * dm.H, bx, bh);
-  const int b = bh / dm.H, hd = bh % dm.H;
+  const int bh = blockIdx.y, b = bh / dm.H, hd = bh % dm.H;
   const unsigned seed = eff_seed(dm);
-  const int q0 = bx * AT_QB + wid * AT_QW;  // first query row of this wave
-  const int live = attn_live_waves(dm.Lq, bx * AT_QB);
+  const int q0 = blockIdx.x * AT_QB + wid * AT_QW;  // first query row of this wave
+  const int live = attn_live_waves(dm.Lq, blockIdx.x * AT_QB);
   if (wid >= live) return;
   const __bf16 *Qb = Q + b * dm.q_bs + hd * dm.q_hs;
   const __bf16 *Kb = K + b * dm.k_bs + hd * dm.k_hs;
@@ -745,9 +732,7 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const __bf16 *__
                                                           const __bf16 *__restrict__ dO, const float *__restrict__ LSE,
                                                           const __bf16 *__restrict__ O, float *__restrict__ DELTA,
                                                           __bf16 *__restrict__ dQ, BwdDims dm) {
-  int bx, bh;
-  attn_item(dm.Lq, dm.B * dm.H, bx, bh);
-  attn_bwd_dq_body<PLAIN>(Q, K, V, dO, LSE, O, DELTA, dQ, dm, bx, bh);
+  attn_bwd_dq_body<PLAIN>(Q, K, V, dO, LSE, O, DELTA, dQ, dm, blockIdx.x, blockIdx.y);
 }
 
 // Lq <= 32: the four waves share the queries and split the key tiles (see attn_fwd_narrow_kernel); dQ^T partials are
@@ -1053,9 +1038,7 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dkv_kernel(const __bf16 *_
                                                            const __bf16 *__restrict__ dO,
                                                            const float *__restrict__ LSE, const float *__restrict__ DELTA,
                                                            __bf16 *__restrict__ dK, __bf16 *__restrict__ dV, BwdDims dm) {
-  int bx, bh;
-  attn_item(dm.Lk, dm.B * dm.H, bx, bh);
-  attn_bwd_dkv_body<PLAIN>(Q, K, V, dO, LSE, DELTA, dK, dV, dm, bx, bh);
+  attn_bwd_dkv_body<PLAIN>(Q, K, V, dO, LSE, DELTA, dK, dV, dm, blockIdx.x, blockIdx.y);
 }
 
 // the dK / dV passes of an AttnPair: the grid's x extent is the larger of the two key-block counts
@@ -1093,15 +1076,6 @@ using namespace bq;
 // dropout on the attention probabilities (stateless hash, regenerated by the backward); the effective seed is
 // seed_ptr[0] * 2654435761 + seed when seed_ptr (a device counter the caller bumps once per step) is given.
 // causal != 0 (Lq == Lk): keys after the query are masked as well.
-static bool attn_ragged_last() {
-  static int on = -1;
-  if (on < 0) {
-    const char *e = getenv("BQ_ATTN_RAGGED_LAST");
-    on = (e == nullptr || e[0] != '0') ? 1 : 0;
-  }
-  return on == 1;
-}
-
 extern "C" __attribute__((visibility("default"))) int bq_attn_fwd(
     const void *Q, const void *K, const void *V, void *O, float *LSE, const float *mask, int B, int H, int Lq, int Lk,
     int Lkp, long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long o_bs, long o_rs, long o_hs,
@@ -1122,9 +1096,7 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_fwd(
     return check_launch("attn_fwd_narrow");
   }
   const bool plain = !mask && !causal && dm.drop_thresh == 0;
-  // (1-D: attn_item's order, ragged blocks last -- BQ_ATTN_RAGGED_LAST=0 in the environment keeps the 2-D order, for A/B runs)
-  const bool ragged_last = plain && attn_ragged_last() && Lq % AT_QB != 0 && Lq > AT_QB;
-  const dim3 grid = ragged_last ? dim3((unsigned)(((Lq + AT_QB - 1) / AT_QB) * B * H), 1) : dim3((Lq + AT_QB - 1) / AT_QB, B * H);
+  const dim3 grid((Lq + AT_QB - 1) / AT_QB, B * H);
   // 3 waves / SIMD, and for the ViT's case (no mask, not causal, no dropout) the PLAIN instantiation with the last tile
   // peeled: tools/bench_attn.py sweeps of round 1 / 2 (2 waves: slower; EARLY score issue: no gain)
   if (plain)
@@ -1158,10 +1130,7 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_bwd(
   hipStream_t st = (hipStream_t)stream;
   constexpr int dq_w = BQ_ATTN_DQ_MINW, dkv_w = 2;   // waves / SIMD: measured (dK/dV at 2: 0.34 -> 0.25 ms, round 1)
   const bool plain = !mask && !causal && dm.drop_thresh == 0;
-  const bool rl_q = plain && attn_ragged_last() && Lq % AT_QB != 0 && Lq > AT_QB, rl_k = plain && attn_ragged_last() && Lk % AT_QB != 0 && Lk > AT_QB;
-  const dim3 grid_q = rl_q ? dim3((unsigned)(((Lq + AT_QB - 1) / AT_QB) * B * H), 1) : dim3((Lq + AT_QB - 1) / AT_QB, B * H);
-  const dim3 grid_k = rl_k ? dim3((unsigned)(((Lk + AT_QB - 1) / AT_QB) * B * H), 1) : dim3((Lk + AT_QB - 1) / AT_QB, B * H);
-#define BQ_DQ(W, P) hipLaunchKernelGGL((attn_bwd_dq_kernel<W, P>), grid_q, dim3(256), 0, \
+#define BQ_DQ(W, P) hipLaunchKernelGGL((attn_bwd_dq_kernel<W, P>), dim3((Lq + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, \
                                        st, (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)dO, \
                                        LSE, (const __bf16 *)O, DELTA, (__bf16 *)dQ, dm)
   if (!plain && Lq <= AT_QB && Lk <= AT_QB) {
@@ -1180,7 +1149,7 @@ extern "C" __attribute__((visibility("default"))) int bq_attn_bwd(
 #undef BQ_DQ
   int rc = check_launch("attn_bwd_dq");
   if (rc) return rc;
-#define BQ_DKV(W, P) hipLaunchKernelGGL((attn_bwd_dkv_kernel<W, P>), grid_k, dim3(256), 0, \
+#define BQ_DKV(W, P) hipLaunchKernelGGL((attn_bwd_dkv_kernel<W, P>), dim3((Lk + AT_QB - 1) / AT_QB, B * H), dim3(256), 0, \
                                         st, (const __bf16 *)Q, (const __bf16 *)K, (const __bf16 *)V, (const __bf16 *)dO,  \
                                         LSE, DELTA, (__bf16 *)dK, (__bf16 *)dV, dm)
   if (plain) BQ_DKV(dkv_w, true); else BQ_DKV(dkv_w, false);

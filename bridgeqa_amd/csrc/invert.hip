@@ -39,11 +39,14 @@ __global__ __launch_bounds__(256) void invert_starts_kernel(const unsigned *__re
 // grad_feats[b][n][c] = sum over the positions p = (b, m, s) with idx[p] == n, ascending, of grad_out[p][3 + c].
 // grad_out rows of `ld` elements (bf16 or fp32), the three offset channels first (group_concat_pm's layout).
 // LP lanes per point, one 8-element chunk of the row per lane and trip (chunk j covers channels 8 j - 3 .. 8 j + 4).
+// grad_xyz (optional): f32 (B, N, 3) = the same sum over channels 0..2, times xyz_scale (1 / radius under normalize_xyz) --
+// the grouped offsets are (xyz[idx] - centre) / radius, so the point receives +g, its centre -g (kernel below).
 template <typename OT, int LP>
 __global__ __launch_bounds__(256) void group_concat_pm_grad_gather_kernel(const OT *__restrict__ grad_out,
                                                                           const int32_t *__restrict__ start,
                                                                           const unsigned *__restrict__ slots,
-                                                                          float *__restrict__ grad_feats, int C, long points, int ld) {
+                                                                          float *__restrict__ grad_feats, int C, long points, int ld,
+                                                                          float *__restrict__ grad_xyz, float xyz_scale) {
   const int sub = threadIdx.x % LP;
   const int chunks = ld >> 3;
   for (long pt = ((long)blockIdx.x * 256 + threadIdx.x) / LP; pt < points; pt += (long)gridDim.x * 256 / LP) {
@@ -68,13 +71,33 @@ __global__ __launch_bounds__(256) void group_concat_pm_grad_gather_kernel(const 
           acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
         }
       }
-      float *o = grad_feats + pt * C;
+      if (grad_feats) {
+        float *o = grad_feats + pt * C;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int c = j * 8 + e - 3;
-        if (c >= 0 && c < C) o[c] = acc[e];
+        for (int e = 0; e < 8; ++e) {
+          const int c = j * 8 + e - 3;
+          if (c >= 0 && c < C) o[c] = acc[e];
+        }
+      }
+      if (grad_xyz && j == 0) {
+        grad_xyz[pt * 3 + 0] = acc[0] * xyz_scale;
+        grad_xyz[pt * 3 + 1] = acc[1] * xyz_scale;
+        grad_xyz[pt * 3 + 2] = acc[2] * xyz_scale;
       }
     }
+  }
+}
+
+// grad_new_xyz[b][m][:] = - scale * sum_s grad_out[b][m][s][0..2], s ascending: a centre's own S rows, no collision to begin with
+template <typename OT>
+__global__ __launch_bounds__(256) void group_concat_pm_grad_centres_kernel(const OT *__restrict__ grad_out, float *__restrict__ grad_new_xyz,
+                                                                           long centres, int S, int ld, float scale) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < centres * 3; t += (long)gridDim.x * 256) {
+    const long cm = t / 3;
+    const int a = (int)(t - cm * 3);
+    float acc = 0.f;
+    for (int sidx = 0; sidx < S; ++sidx) acc += (float)grad_out[(cm * S + sidx) * ld + a];
+    grad_new_xyz[t] = -acc * scale;
   }
 }
 
@@ -149,10 +172,14 @@ extern "C" int bq_invert_index(const int32_t *idx, int B, long L, int N, int32_t
 }
 
 extern "C" int bq_group_concat_pm_grad_gather(const void *grad_out, int in_bf16, const int32_t *start, const unsigned *slots,
-                                              float *grad_feats, int B, int C, int N, int ld, void *stream) {
+                                              float *grad_feats, float *grad_xyz, float *grad_new_xyz, int B, int C, int N, int M,
+                                              int S, int ld, float radius, int normalize, void *stream) {
   using namespace bq;
-  BQ_REQUIRE(grad_out && start && slots && grad_feats, BQ_EINVAL, "group_concat_pm_grad_gather: null pointer");
-  BQ_REQUIRE(B >= 0 && C > 0 && N > 0 && ld >= C + 3 && ld % 8 == 0, BQ_EINVAL, "group_concat_pm_grad_gather: ld = %d must be a multiple of 8 >= 3 + C", ld);
+  BQ_REQUIRE(grad_out && start && slots && (grad_feats || grad_xyz || grad_new_xyz), BQ_EINVAL, "group_concat_pm_grad_gather: null pointer");
+  BQ_REQUIRE(B >= 0 && C >= 0 && N > 0 && ld >= C + 3 && ld % 8 == 0, BQ_EINVAL, "group_concat_pm_grad_gather: ld = %d must be a multiple of 8 >= 3 + C", ld);
+  BQ_REQUIRE(!grad_feats || C > 0, BQ_EINVAL, "group_concat_pm_grad_gather: no feature channels");
+  BQ_REQUIRE(!grad_new_xyz || (M > 0 && S > 0), BQ_EINVAL, "group_concat_pm_grad_gather: grad_new_xyz needs M, S");
+  const float xs = normalize ? 1.0f / radius : 1.0f;
   BQ_REQUIRE(((uintptr_t)grad_out % 16) == 0, BQ_EINVAL, "group_concat_pm_grad_gather: grad_out must be 16-byte aligned");
   const long points = (long)B * N;
   if (points == 0) return BQ_OK;
@@ -163,16 +190,25 @@ extern "C" int bq_group_concat_pm_grad_gather(const void *grad_out, int in_bf16,
     blocks = (points * 16 + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     if (in_bf16) hipLaunchKernelGGL((group_concat_pm_grad_gather_kernel<__bf16, 16>), dim3((unsigned)blocks), dim3(256), 0, st,
-                                    (const __bf16 *)grad_out, start, slots, grad_feats, C, points, ld);
+                                    (const __bf16 *)grad_out, start, slots, grad_feats, C, points, ld, grad_xyz, xs);
     else hipLaunchKernelGGL((group_concat_pm_grad_gather_kernel<float, 16>), dim3((unsigned)blocks), dim3(256), 0, st,
-                            (const float *)grad_out, start, slots, grad_feats, C, points, ld);
+                            (const float *)grad_out, start, slots, grad_feats, C, points, ld, grad_xyz, xs);
   } else {
     blocks = (points * 32 + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     if (in_bf16) hipLaunchKernelGGL((group_concat_pm_grad_gather_kernel<__bf16, 32>), dim3((unsigned)blocks), dim3(256), 0, st,
-                                    (const __bf16 *)grad_out, start, slots, grad_feats, C, points, ld);
+                                    (const __bf16 *)grad_out, start, slots, grad_feats, C, points, ld, grad_xyz, xs);
     else hipLaunchKernelGGL((group_concat_pm_grad_gather_kernel<float, 32>), dim3((unsigned)blocks), dim3(256), 0, st,
-                            (const float *)grad_out, start, slots, grad_feats, C, points, ld);
+                            (const float *)grad_out, start, slots, grad_feats, C, points, ld, grad_xyz, xs);
+  }
+  if (grad_new_xyz) {
+    const long centres = (long)B * M;
+    long cb = (centres * 3 + 255) / 256;
+    if (cb > 65536) cb = 65536;
+    if (in_bf16) hipLaunchKernelGGL(group_concat_pm_grad_centres_kernel<__bf16>, dim3((unsigned)cb), dim3(256), 0, st,
+                                    (const __bf16 *)grad_out, grad_new_xyz, centres, S, ld, xs);
+    else hipLaunchKernelGGL(group_concat_pm_grad_centres_kernel<float>, dim3((unsigned)cb), dim3(256), 0, st, (const float *)grad_out,
+                            grad_new_xyz, centres, S, ld, xs);
   }
   return check_launch("group_concat_pm_grad_gather");
 }

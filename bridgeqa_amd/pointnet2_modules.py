@@ -40,20 +40,25 @@ class PointnetSAModuleVotes(nn.Module):
             mlp_spec[0] += 3
         self.mlp_module = pt_utils.SharedMLP(mlp_spec, bn=bn)
 
-    def sample_and_query(self, xyz):
-        """the parameter-free part of forward: (inds, new_xyz, group_idx) for coordinates xyz (B, N, 3)"""
+    def sample_and_query(self, xyz, inverted=False):
+        """the parameter-free part of forward: (inds, new_xyz, group_idx) for coordinates xyz (B, N, 3); inverted: also the
+        inverted group index (start, slots) the deterministic grouping gradient gathers over (pointnet2_utils.invert_groups)"""
         with torch.no_grad():
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
             new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds) \
                 .transpose(1, 2).contiguous()
             idx = pointnet2_utils.ball_query(self.grouper.radius, self.grouper.nsample, xyz, new_xyz)
+            if inverted:
+                return inds, new_xyz, idx, pointnet2_utils.invert_groups(idx, xyz.shape[1])
         return inds, new_xyz, idx
 
     def forward(self, xyz, features=None, inds=None, geometry=None):
-        """geometry: optional (inds, new_xyz, group_idx) from sample_and_query(xyz), computed ahead of time"""
-        group_idx = None
+        """geometry: optional (inds, new_xyz, group_idx[, (inv_start, inv_slots)]) from sample_and_query(xyz), computed
+        ahead of time"""
+        group_idx = inv = None
         if geometry is not None:
-            inds, new_xyz, group_idx = geometry
+            inds, new_xyz, group_idx = geometry[:3]
+            inv = geometry[3] if len(geometry) > 3 else None
             assert inds.shape[1] == self.npoint
         else:
             if inds is None:
@@ -62,7 +67,7 @@ class PointnetSAModuleVotes(nn.Module):
                 assert inds.shape[1] == self.npoint
             new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds) \
                 .transpose(1, 2).contiguous()
-        grouped_features, _grouped_xyz = self.grouper(xyz, new_xyz, features, idx=group_idx)  # (B, 3+C, npoint, nsample)
+        grouped_features, _grouped_xyz = self.grouper(xyz, new_xyz, features, idx=group_idx, inv=inv)  # (B, 3+C, npoint, nsample)
         # max over nsample == F.max_pool2d(kernel=[1, nsample]).squeeze(-1) (pointnet2_modules.py:259-262, 272); a row
         # reduction instead of the generic NCHW pooling kernel.  Tie routing in backward is immaterial.
         if grouped_features.dtype == torch.bfloat16 and (

@@ -165,6 +165,14 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
+def invert_groups(idx, n):
+    """inverted group index of ball_query's idx (B, M, S) over n points for the deterministic grouping gradient
+    (csrc/invert.hip): (start, slots), or None where the gather path does not apply (CPU oracle backend, switch off)"""
+    if not (idx.is_cuda and _ext is _hip_ext and getattr(_ext, "DETERMINISTIC_SCATTER", [False])[0]):
+        return None
+    return _ext.invert_index(idx, n)
+
+
 def _det_scatter(t):
     return t.is_cuda and _ext is _hip_ext and getattr(_ext, "DETERMINISTIC_SCATTER", [False])[0]
 
@@ -195,10 +203,11 @@ class _GroupConcatPM(Function):
     """Point-major grouping (csrc/pn2_ops.hip group_concat_pm_kernel): feats_pm (B,N,C) rows -> (B,M,S,3+C)."""
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, feats_pm, idx, radius, normalize, out_dtype, pad_to=1):
+    def forward(ctx, xyz, new_xyz, feats_pm, idx, radius, normalize, out_dtype, pad_to=1, inv=None):
         ctx.save_for_backward(idx)
         ctx.n, ctx.radius, ctx.normalize = xyz.size(1), radius, normalize
         ctx.has_features = feats_pm is not None
+        ctx.inv = inv    # (start, slots) of invert_groups(idx, N) when the caller has it (the geometry prefetch), else None
         return _ext.group_concat_pm(xyz, new_xyz, feats_pm, idx, radius, normalize, out_dtype, pad_to)
 
     @staticmethod
@@ -206,14 +215,16 @@ class _GroupConcatPM(Function):
         (idx,) = ctx.saved_tensors
         need = ctx.needs_input_grad
         want_f = ctx.has_features and need[2]
-        if want_f and not need[0] and not need[1] and _det_scatter(grad_out):
-            # the feature gradient as a GATHER over the inverted group index: bitwise reproducible (the coordinates of a
-            # training step carry no gradient; a caller that asks for one takes the atomic scatter below)
-            gf = _ext.group_concat_pm_grad_gather(grad_out, _ext.invert_index(idx, ctx.n), ctx.n)
-            if gf is not None:
-                return None, None, gf, None, None, None, None, None
+        if _det_scatter(grad_out) and (want_f or need[0] or need[1]):
+            # GATHERS over the inverted group index: one sum per point in ascending position order, bitwise reproducible
+            # (the vote-aggregation level differentiates through its coordinates too: predicted votes)
+            inv = ctx.inv if ctx.inv is not None else _ext.invert_index(idx, ctx.n)
+            res = _ext.group_concat_pm_grad_gather(grad_out, inv, ctx.n, ctx.radius, ctx.normalize, want_f, need[0], need[1])
+            if res is not None:
+                gf, gx, gn = res
+                return gx, gn, gf, None, None, None, None, None, None
         gf, gx, gn = _ext.group_concat_pm_grad(grad_out, idx, ctx.n, ctx.radius, ctx.normalize, want_f, need[0], need[1])
-        return gx, gn, gf, None, None, None, None, None
+        return gx, gn, gf, None, None, None, None, None, None
 
 
 def point_major(features):
@@ -244,9 +255,10 @@ class QueryAndGroup(nn.Module):
         self.ret_grouped_xyz = ret_grouped_xyz
         self.normalize_xyz = normalize_xyz
 
-    def forward(self, xyz, new_xyz, features=None, idx=None):
+    def forward(self, xyz, new_xyz, features=None, idx=None, inv=None):
         """idx: optional precomputed ball_query(radius, nsample, xyz, new_xyz) (geometry prefetch: the indices depend
-        on coordinates only, not on parameters -- Pointnet2Backbone.precompute_geometry)"""
+        on coordinates only, not on parameters -- Pointnet2Backbone.precompute_geometry); inv: its inverted form
+        (invert_groups) when that was precomputed too"""
         if idx is None:
             idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
         from . import fusion_ops
@@ -254,7 +266,7 @@ class QueryAndGroup(nn.Module):
                 and fusion_ops.compute_dtype() == torch.bfloat16):
             # rows padded to a multiple of 8 elements (16 bytes): the SharedMLP's first GEMM reads them in place
             out = _GroupConcatPM.apply(xyz, new_xyz, point_major(features), idx, self.radius, self.normalize_xyz,
-                                       torch.bfloat16, 8)
+                                       torch.bfloat16, 8, inv)
             new_features = out.permute(0, 3, 1, 2)  # logical (B,3+C,M,S), physically NHWC
             return (new_features, new_features[:, :3]) if self.ret_grouped_xyz else new_features
         fused = hasattr(_ext, "group_concat") and self.nsample % 4 == 0

@@ -377,14 +377,17 @@ BQ_API int bq_lmhead_ce_dlogits(void *logits, const float *lse, const int *targe
  *   [B * L]: the positions b * L + l naming each value, ascending (stable radix sort); workspace of
  *   bq_invert_index_workspace_bytes(B * L) bytes.
  * bq_group_concat_pm_grad_gather: the FEATURE gradient of bq_group_concat_pm from the inverted group index (idx (B, M, S) ->
- *   L = M * S): grad_out rows of ld elements (bf16 / fp32), grad_feats f32 (B, N, C) written whole (no zero-fill).
+ *   L = M * S): grad_out rows of ld elements (bf16 / fp32), grad_feats f32 (B, N, C) written whole (no zero-fill); optional
+ *   grad_xyz f32 (B, N, 3) (the offset channels, / radius under normalize) and grad_new_xyz f32 (B, M, 3) (minus each centre's
+ *   own S rows, in order) -- any of the three may be NULL.
  * bq_three_interpolate_grad_gather: idx (B, n, 3) inverted over m known points (L = 3 n); grad_out f32 (B, C, n), weight f32
  *   (B, n, 3) -> grad_points f32 (B, C, m). */
 BQ_API size_t bq_invert_index_workspace_bytes(long total);
 BQ_API int bq_invert_index(const int32_t *idx, int B, long L, int N, int32_t *start, unsigned *slots, void *workspace,
                            size_t workspace_bytes, void *stream);
 BQ_API int bq_group_concat_pm_grad_gather(const void *grad_out, int in_bf16, const int32_t *start, const unsigned *slots,
-                                          float *grad_feats, int B, int C, int N, int ld, void *stream);
+                                          float *grad_feats, float *grad_xyz, float *grad_new_xyz, int B, int C, int N, int M,
+                                          int S, int ld, float radius, int normalize, void *stream);
 BQ_API int bq_three_interpolate_grad_gather(const float *grad_out, const int32_t *start, const unsigned *slots,
                                             const float *weight, float *grad_points, int B, int C, int n, int m, void *stream);
 

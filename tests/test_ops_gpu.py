@@ -355,12 +355,14 @@ def test_inverted_index_and_deterministic_scatter_gradients(ext, oracle, dev):
         go[..., :3 + C] = torch.randn(B, M, S, 3 + C, generator=g).to(dev).to(dt)
         rows = go[..., :3 + C]
         inv = ext.invert_index(d_idx, N)
-        outs = [ext.group_concat_pm_grad_gather(rows, inv, N) for _ in range(3)]
-        assert outs[0] is not None and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        outs = [ext.group_concat_pm_grad_gather(rows, inv, N, 0.2, True, True, True, True) for _ in range(3)]
+        for k in range(3):   # features, point coordinates, centres
+            assert outs[0][k] is not None and torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k])
         want = oracle.group_points_grad(rows.float().cpu().permute(0, 3, 1, 2)[:, 3:].contiguous(), idx, N).transpose(1, 2)
-        torch.testing.assert_close(outs[0].cpu(), want, rtol=2e-5, atol=2e-4)
-        atomic, _, _ = ext.group_concat_pm_grad(rows, d_idx, N, 0.2, True, True, False, False)
-        torch.testing.assert_close(outs[0], atomic, rtol=2e-5, atol=2e-4)
+        torch.testing.assert_close(outs[0][0].cpu(), want, rtol=2e-5, atol=2e-4)
+        atomic = ext.group_concat_pm_grad(rows, d_idx, N, 0.2, True, True, True, True)
+        for k in range(3):
+            torch.testing.assert_close(outs[0][k], atomic[k], rtol=2e-5, atol=2e-3)
     # three_interpolate: n unknown points over m known ones
     n, m, Cf = 700, 90, 33
     idx3 = torch.randint(0, m, (B, n, 3), generator=g, dtype=torch.int32)

@@ -318,8 +318,8 @@ def cpu_info():
 
 
 VIT_GEMMS = (("qkv", 2304, 768), ("proj", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072))
-PROFILE_PMC = os.path.join(ROOT, "profiles", "r04_gemm_pmc.jsonl")       # tools/run_gemm_pmc.sh -> tools/pmc_summary.py --json
-PROFILE_STATS = os.path.join(ROOT, "profiles", "r04_c3_kernel_stats.csv")  # rocprofv3 --kernel-trace --stats of this bench
+PROFILE_PMC = os.path.join(ROOT, "profiles", "r05_gemm_pmc.jsonl")       # tools/run_gemm_pmc.sh -> tools/pmc_summary.py --json
+PROFILE_STATS = os.path.join(ROOT, "profiles", "r05_c3_kernel_stats.csv")  # rocprofv3 --kernel-trace --stats of this bench
 PROFILE_ROWS = 16400   # the committed counter / in-step records were taken at c3's token count (B = 16 x 1025): they are
 #                        attached to a bench line only when the run has the same M (the c5 line divided c3's bytes)
 # kernel instantiation each launch form runs as (for the in-step averages of the committed profile)
@@ -432,7 +432,7 @@ def gemm_roofline(args, dev):
     out[-1]["note"] = ("all 48 weight gradients (+ bias gradients) of the 12 blocks through fusion_wgrad.flush_deferred_items: "
                        "the launch plan the step uses (two 256-tile launches + the planner's small problems on the 64-tile kernel)")
     traffic = ({"hbm_read_bytes": tot_fetch, "hbm_write_bytes": tot_write, "algorithmic_bytes": tot_alg,
-                "ratio": round((tot_fetch + tot_write) / tot_alg, 3), "file": "profiles/r04_gemm_pmc.jsonl",
+                "ratio": round((tot_fetch + tot_write) / tot_alg, 3), "file": "profiles/r05_gemm_pmc.jsonl",
                 "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, one launch form per process; read = 2 x "
                           "FETCH_SIZE x 1024 (gfx950 tallies a 128-B request as 64 B), write = WRITE_SIZE x 1024 "
                           "(MI355X_MICROARCH.md, HBM); fabric-side counters: Infinity-Cache hits are included"}
@@ -440,11 +440,11 @@ def gemm_roofline(args, dev):
     # the same fraction from the DURATIONS of the committed trace pass (rocprofv3 kernel trace, one launch form per
     # process) next to the live HIP-event medians `frac` uses: a reader can recompute either from its own source
     prof = ({"us_total": round(tot_prof, 1), "frac": round(tot_f / (tot_prof * 1e-6) / 1e12 / 2500.0, 4),
-             "file": "profiles/r04_gemm_pmc.jsonl (avg_us of the trace pass)"} if (tot_prof and not prof_missing) else None)
+             "file": "profiles/r05_gemm_pmc.jsonl (avg_us of the trace pass)"} if (tot_prof and not prof_missing) else None)
     return out, tot_f, tot_t, traffic, prof
 
 
-def _attn_pmc(threads, path="profiles/r04_attn_pmc.txt"):
+def _attn_pmc(threads, path="profiles/r05_attn_pmc.txt"):
     """MFMA-busy fractions of the three attention kernels at THIS run's shape, read back from the committed counter summary
     (tools/run_attn_pmc.sh -> tools/pmc_summary.py: per kernel and launch shape a '<name>  grid <threads>' line followed by
     the counters and a '=> MFMA utilisation X %' line); `threads` = B * H * ceil(L / 128) workgroups * 256"""
@@ -596,6 +596,14 @@ def reference_loop(args, model, batch, dev, use_graph):
     print(json.dumps(_json_safe(out)))
 
 
+def _fps_pmc():
+    """physical HBM traffic of SA1's FPS launch from the committed counter passes (tools/run_r5_profiles.sh), or None"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r05_fps_pmc.json")))
+    except (OSError, ValueError):
+        return None
+
+
 def ballquery_roofline(args, ops, alone_ms, alone_bg_ms, phased):
     """SA1's ball query (north_star names the op): SURVEY §8d's streaming-equivalent 12 N M B bytes per launch -- what the
     reference's kernel streams (every centre reads every point) -- over the launch's duration in the step and alone, next to
@@ -607,23 +615,28 @@ def ballquery_roofline(args, ops, alone_ms, alone_bg_ms, phased):
     eq = lambda t: round(alg / (t * 1e-3) / 1e9, 1) if t == t and t > 0 else None
     pmc = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_ballquery_pmc.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_ballquery_pmc.json")))
         if (pmc.get("B"), pmc.get("N"), pmc.get("M")) != (B, N, M):
             pmc = None   # (taken at another shape: not this run's traffic)
     except (OSError, ValueError):
         pass
-    return {"kernel": "bq::ball_query_wave_kernel (csrc/pn2_ops.hip), SA1: %d centres x %d points, radius 0.2, nsample 64, B=%d" % (M, N, B),
+    return {"kernel": "bq::grid_build_kernel + bq::ball_query_grid_kernel (csrc/ball_query_grid.hip, round 5: a uniform grid leaves "
+                      "~100 candidate points per centre instead of all N; index-exact), SA1: %d centres x %d points, radius 0.2, "
+                      "nsample 64, B=%d" % (M, N, B),
             "bound": "hbm", "convention": "streaming-equivalent (SURVEY §8d): 12*N*M*B bytes per launch = what the reference's "
-                                          "kernel streams; physical traffic is the L2-resident scene read once per XCD",
+                                          "exhaustive kernel streams -- this kernel SKIPS ~99 % of them, so `frac` far above 1 is the "
+                                          "pruning factor, not a bandwidth; physical traffic: `traffic`",
             "algorithmic_bytes_per_launch": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "achieved": eq(ms), "frac": round(eq(ms) / HBM_PEAK_GBS, 4) if eq(ms) else None, "ms_per_launch": round(ms, 4),
             "launches_timed": cnt,
-            "timed_on": ("the timed steps: the geometry phase of the NEXT batch (bq_ball_query_background: about one workgroup "
-                         "per CU, running under the fusion chain)" if phased else "eager re-run after the graph replay"),
+            "timed_on": ("the timed steps: the geometry phase of the NEXT batch, running under the fusion chain"
+                         if phased else "eager re-run after the graph replay"),
             "alone": {"ms_per_launch": round(alone_ms, 4), "achieved": eq(alone_ms),
                       "frac": round(eq(alone_ms) / HBM_PEAK_GBS, 4) if eq(alone_ms) else None,
                       "background_grid_ms_per_launch": round(alone_bg_ms, 4),
-                      "note": "5 back-to-back launches after the timed region, idle GPU, full grid / background grid"},
+                      "exhaustive_scan_ms_per_launch": round(alone_bg_ms, 4),
+                      "note": "5 back-to-back launches after the timed region, idle GPU; exhaustive_scan = bq_ball_query (the "
+                              "wave-per-centre-pair scan of rounds 3-4) on the same inputs"},
             "traffic": pmc}
 
 
@@ -942,15 +955,19 @@ def main():
     bq_alone_ms = bq_alone_bg_ms = float("nan")
     if rank == 0:
         ctr = xyz_alone[:, :2048].contiguous()   # (any 2048 points serve as centres for the timing: the scan is exhaustive)
-        for bg in (False, True):
-            _ext.ball_query(ctr, xyz_alone, 0.2, 64, background=bg)
+        for bg in (False, True):   # (bg: the exhaustive scan of rounds 3-4 for comparison -- the grid withdrawn)
+            prev_min = _ext.BALL_QUERY_GRID_MIN_N[0]
+            if bg:
+                _ext.BALL_QUERY_GRID_MIN_N[0] = 1 << 30
+            _ext.ball_query(ctr, xyz_alone, 0.2, 64)
             torch.cuda.synchronize()
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
             for _ in range(5):
-                _ext.ball_query(ctr, xyz_alone, 0.2, 64, background=bg)
+                _ext.ball_query(ctr, xyz_alone, 0.2, 64)
             ev1.record()
             torch.cuda.synchronize()
+            _ext.BALL_QUERY_GRID_MIN_N[0] = prev_min
             if bg:
                 bq_alone_bg_ms = ev0.elapsed_time(ev1) / 5
             else:
@@ -1039,9 +1056,7 @@ def main():
                              "frac": round(achieved / HBM_PEAK_GBS, 4), "ms_per_launch": round(fps_ms, 4),
                              "rounds": 2047, "us_per_round": round(fps_ms * 1e3 / 2047, 3),
                              "floor_us_per_round": 0.5, "floor_frac": round(0.5 / (fps_ms * 1e3 / 2047), 3),
-                             "traffic_from_profile": {"bytes": 27.9e6, "file": "profiles/r01_fps_pmc.txt",
-                                                      "note": "FETCH_SIZE x2 (gfx950) + WRITE_SIZE at N=40000, B=16"}
-                             if (args.points == 40000 and args.batch == 16) else None,
+                             "traffic_from_profile": _fps_pmc() if (args.points == 40000 and args.batch == 16) else None,
                              "timed_on": ("the timed steps (geometry phase launched eagerly between the graph replays)"
                                           if phased else "eager re-run after the graph replay" if graphed
                                           else "the timed steps"),
@@ -1069,8 +1084,8 @@ def main():
                                "algorithmic_flops": tot_f, "ms_total": round(tot_ms, 4), "per_gemm": per,
                                "timed_on": "dedicated launches after the timed region, HIP events on the launch stream, "
                                            "median of 10 (inside the step the same kernels replay from HIP graphs; the "
-                                           "in-step averages come from profiles/r04_c3_kernel_stats.csv, the counters from "
-                                           "profiles/r04_gemm_pmc.jsonl; both only at M = 16400, the shape they were taken at)"}
+                                           "in-step averages come from profiles/r05_c3_kernel_stats.csv, the counters from "
+                                           "profiles/r05_gemm_pmc.jsonl; both only at M = 16400, the shape they were taken at)"}
             out["roofline_attn"] = attn_roofline(args, dev)
         else:
             out["roofline"] = out["roofline_fps"]

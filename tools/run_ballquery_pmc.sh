@@ -11,13 +11,13 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/b -- python3 $R
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/c -- python3 $R/tools/time_ball_query.py > /dev/null 2>&1
 cd $R
 rm -f $D/bq.jsonl
-python tools/pmc_summary.py $D/t $D/b $D/c --match ball_query --json $D/bq.jsonl --label ball_query_sa1 > $D/ballquery_pmc.txt 2>&1
+python tools/pmc_summary.py $D/t $D/b $D/c --match ball_query_grid --json $D/bq.jsonl --label ball_query_sa1 > $D/ballquery_pmc.txt 2>&1
 python - <<PY
 import json
 rs = [json.loads(l) for l in open("$D/bq.jsonl")]   # (the trace pass and the counter passes report the grid in different units: two records)
 pick = lambda k: next((r[k] for r in rs if r.get(k) is not None), None)
 out = {"B": 16, "N": 40000, "M": 2048, "avg_us": pick("avg_us"), "hbm_read_bytes": pick("fetch_bytes"), "hbm_write_bytes": pick("write_bytes"),
-       "file": "profiles/r04_ballquery_pmc.json",
+       "file": "profiles/r05_ballquery_pmc.json",
        "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/time_ball_query.py; read = 2 x FETCH_SIZE x 1024 "
                  "(gfx950), write = WRITE_SIZE x 1024; fabric side, per launch"}
 json.dump(out, open("$D/ballquery_pmc.json", "w"))

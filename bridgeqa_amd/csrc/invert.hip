@@ -4,11 +4,13 @@
 // interpolate_gpu.cu:116-154) scatter with fp32 atomics: the order of the additions -- and with it the rounding of every sum --
 // changes from launch to launch.  Those sums feed the deepest layers of the detector; two executions of the same step
 // differed by 2.6-7.9 % on BatchNorm bias gradients that are sums of nearly cancelling terms.  Here the scatter is turned
-// around: bq_invert_index sorts the positions of an index tensor by the point they name (a STABLE radix sort of
-// (scene * N + point, position) pairs: rocPRIM through hipCUB -- within a point the positions stay ascending) into a CSR
-// table, and the gradient kernels GATHER: one sum per destination, its terms added in ascending position order.  Same terms as
-// the reference, a fixed order, no atomics, no zero-fill; bitwise reproducible.
-#include <hipcub/hipcub.hpp>
+// around: bq_invert_index sorts the positions of an index tensor by the point they name (a STABLE LSD radix sort of
+// (scene * N + point, position) pairs, 8 bits per pass -- within a point the positions stay ascending) into a CSR table, and
+// the gradient kernels GATHER: one sum per destination, its terms added in ascending position order.  Same terms as the
+// reference, a fixed order, no atomics, no zero-fill; bitwise reproducible.
+// (The sort is this file's own: rocPRIM's DeviceRadixSort, the first version, ran eagerly at every size and replayed from a
+// HIP graph at c3's 2.1 M pairs, but a REPLAYED graph holding it at c5's 4.2 M pairs died with a memory access fault --
+// tools/dbg_c5.py; everything here is plain kernels on caller-provided scratch.)
 
 #include "bq_common.h"
 #include "bqhip_fusion.h"
@@ -127,12 +129,129 @@ __global__ __launch_bounds__(256) void three_interpolate_grad_gather_kernel(cons
 
 }  // namespace bq
 
+namespace bq {
+
+// ---- stable LSD radix sort of (key, value) pairs, 8 bits per pass ------------------------------------------------------------
+// block = 256 threads x RS_IPT items in position order.  hist: per-block digit counts, stored digit-major [256][nblocks];
+// scan: one workgroup turns them into global offsets (exclusive, digit-major order = the sorted order of (digit, block));
+// scatter: a block walks its items in rounds of 256 (thread t takes item r * 256 + t): rank among equal digits = items of
+// earlier rounds (running counters in LDS) + earlier waves of this round (per-wave counts in LDS) + lower lanes of this wave
+// (eight ballots give the lanes with the same digit) -- every tie broken by position, so the sort is stable.
+constexpr int RS_IPT = 8, RS_ITEMS = 256 * RS_IPT;
+
+__global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned *__restrict__ keys, int *__restrict__ hist, long total, int nblocks,
+                                                      int shift) {
+  __shared__ int s_h[256];
+  s_h[threadIdx.x] = 0;
+  __syncthreads();
+  const long base = (long)blockIdx.x * RS_ITEMS;
+  for (int r = 0; r < RS_IPT; ++r) {
+    const long i = base + r * 256 + threadIdx.x;
+    if (i < total) atomicAdd(&s_h[(keys[i] >> shift) & 255u], 1);
+  }
+  __syncthreads();
+  hist[(long)threadIdx.x * nblocks + blockIdx.x] = s_h[threadIdx.x];
+}
+
+// one workgroup per digit: exclusive scan of that digit's row of block counts in place, the row's total to tot[digit]
+__global__ __launch_bounds__(256) void rs_scan_kernel(int *__restrict__ hist, int *__restrict__ tot, int nblocks) {
+  __shared__ int s_w[4];
+  __shared__ int s_carry;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  int *a = hist + (long)blockIdx.x * nblocks;
+  if (t == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += 1024) {
+    int v[4], sum = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = base + t * 4 + e;
+      v[e] = i < nblocks ? a[i] : 0;
+      sum += v[e];
+    }
+    int incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int x = 0; x < w; ++x) wbase += s_w[x];
+    int run = s_carry + wbase + incl - sum;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = base + t * 4 + e;
+      if (i < nblocks) a[i] = run;
+      run += v[e];
+    }
+    __syncthreads();
+    if (t == 255) s_carry = s_carry + wbase + incl;
+    __syncthreads();
+  }
+  if (t == 0) tot[blockIdx.x] = s_carry;
+}
+
+__global__ __launch_bounds__(256) void rs_scatter_kernel(const unsigned *__restrict__ keys_in, const unsigned *__restrict__ vals_in,
+                                                         unsigned *__restrict__ keys_out, unsigned *__restrict__ vals_out,
+                                                         const int *__restrict__ offs, const int *__restrict__ tot, long total,
+                                                         int nblocks, int shift) {
+  __shared__ int s_run[256];       // where this block's next item of a digit goes
+  __shared__ int s_cnt[4][256];    // this round's count per (wave, digit)
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  {  // digit base = exclusive scan of the 256 row totals
+    const int mine = tot[t];
+    int incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_cnt[0][w] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int x = 0; x < w; ++x) wbase += s_cnt[0][x];
+    s_run[t] = wbase + incl - mine + offs[(long)t * nblocks + blockIdx.x];
+    __syncthreads();
+  }
+  const long base = (long)blockIdx.x * RS_ITEMS;
+  for (int r = 0; r < RS_IPT; ++r) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x) s_cnt[x][t] = 0;
+    __syncthreads();
+    const long i = base + r * 256 + t;
+    const bool live = i < total;
+    const unsigned k = live ? keys_in[i] : 0u;
+    const unsigned d = (k >> shift) & 255u;
+    // lanes of this wave with the same digit (dead lanes form their own class through the `live` ballot)
+    unsigned long long peers = __ballot(live);
+    peers = live ? peers : ~peers;
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const unsigned long long m = __ballot((d >> bit) & 1u);
+      peers &= ((d >> bit) & 1u) ? m : ~m;
+    }
+    const int below = __builtin_popcountll(peers & ((1ull << lane) - 1ull));
+    if (live && below == 0) s_cnt[w][d] = __builtin_popcountll(peers);   // the class's first lane
+    __syncthreads();
+    if (live) {
+      int pos = s_run[d] + below;
+      for (int x = 0; x < w; ++x) pos += s_cnt[x][d];
+      keys_out[pos] = k;
+      vals_out[pos] = vals_in[i];
+    }
+    __syncthreads();
+    s_run[t] += s_cnt[0][t] + s_cnt[1][t] + s_cnt[2][t] + s_cnt[3][t];
+    __syncthreads();
+  }
+}
+
+}  // namespace bq
+
+// scratch: two key buffers + one value buffer (the second value buffer is `slots`) + the block histograms
 extern "C" size_t bq_invert_index_workspace_bytes(long total) {
   if (total <= 0) return 0;
-  size_t temp = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const unsigned *)nullptr, (unsigned *)nullptr, (const unsigned *)nullptr,
-                                           (unsigned *)nullptr, (int)total, 0, 32, (hipStream_t) nullptr);
-  return ((temp + 255) & ~(size_t)255) + 3 * (size_t)total * sizeof(unsigned) + 256;
+  const long nblocks = (total + bq::RS_ITEMS - 1) / bq::RS_ITEMS;
+  return 3 * (size_t)total * sizeof(unsigned) + (size_t)256 * (nblocks + 1) * sizeof(int);
 }
 
 // idx int32 (B, L) with values in [0, N): -> start int32 [B * N + 1] (CSR over scene * N + value), slots uint32 [B * L] = the
@@ -142,7 +261,7 @@ extern "C" int bq_invert_index(const int32_t *idx, int B, long L, int N, int32_t
   using namespace bq;
   BQ_REQUIRE(B >= 0 && L >= 0 && N > 0, BQ_EINVAL, "invert_index: bad extents");
   const long total = (long)B * L, K = (long)B * N;
-  BQ_REQUIRE(total < (1L << 31) && K < (1L << 31), BQ_ELIMIT, "invert_index: more than 2^31 entries");
+  BQ_REQUIRE(total < (1L << 31) - RS_ITEMS && K < (1L << 31), BQ_ELIMIT, "invert_index: more than 2^31 entries");
   BQ_REQUIRE(start, BQ_EINVAL, "invert_index: null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (total == 0) {
@@ -151,23 +270,27 @@ extern "C" int bq_invert_index(const int32_t *idx, int B, long L, int N, int32_t
   }
   BQ_REQUIRE(idx && slots && workspace && workspace_bytes >= bq_invert_index_workspace_bytes(total), BQ_EINVAL,
              "invert_index: workspace of %zu bytes required", bq_invert_index_workspace_bytes(total));
-  size_t temp = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const unsigned *)nullptr, (unsigned *)nullptr, (const unsigned *)nullptr,
-                                           (unsigned *)nullptr, (int)total, 0, 32, st);
-  const size_t temp_exact = temp;
-  temp = (temp + 255) & ~(size_t)255;
-  unsigned char *w = (unsigned char *)workspace;
-  unsigned *keys_a = (unsigned *)(w + temp), *keys_b = keys_a + total, *vals_a = keys_b + total;
+  const int nblocks = (int)((total + RS_ITEMS - 1) / RS_ITEMS);
+  unsigned *ka = (unsigned *)workspace, *kb = ka + total, *va = kb + total;
+  int *hist = (int *)(va + total), *tot = hist + 256L * nblocks;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(invert_keys_kernel, dim3(blocks), dim3(256), 0, st, idx, keys_a, vals_a, L, N, total);
-  // (plain pointer form: keys_a -> keys_b, vals_a -> slots; radix sort is stable, so equal keys keep ascending positions.
-  // All 32 key bits, as in the size query: rocPRIM's temporary-storage requirement depends on the bit range)
-  size_t temp_use = temp_exact;
-  hipError_t e = hipcub::DeviceRadixSort::SortPairs((void *)w, temp_use, (const unsigned *)keys_a, keys_b, (const unsigned *)vals_a, slots,
-                                                    (int)total, 0, 32, st);
-  if (e != hipSuccess) { set_error("invert_index: radix sort failed: %s", hipGetErrorString(e)); return (int)e; }
-  hipLaunchKernelGGL(invert_starts_kernel, dim3(blocks), dim3(256), 0, st, (const unsigned *)keys_b, start, total, K);
+  hipLaunchKernelGGL(invert_keys_kernel, dim3(blocks), dim3(256), 0, st, idx, ka, va, L, N, total);
+  int bits = 1;
+  while ((1L << bits) < K) ++bits;
+  int passes = (bits + 7) / 8;
+  if ((passes & 1) == 0) ++passes;   // an odd number of passes: the values end in `slots` (a pass over zero bits is a stable copy)
+  unsigned *kin = ka, *kout = kb, *vin = va, *vout = slots;
+  for (int p = 0; p < passes; ++p) {
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(256), 0, st, (const unsigned *)kin, hist, total, nblocks, 8 * p);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(256), 0, st, hist, tot, nblocks);
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblocks), dim3(256), 0, st, (const unsigned *)kin, (const unsigned *)vin, kout, vout,
+                       (const int *)hist, (const int *)tot, total, nblocks, 8 * p);
+    unsigned *tk = kin; kin = kout; kout = tk;
+    unsigned *tv = vin; vin = vout; vout = tv;
+  }
+  // after an odd number of passes the sorted keys are in kb and the values in slots
+  hipLaunchKernelGGL(invert_starts_kernel, dim3(blocks), dim3(256), 0, st, (const unsigned *)kin, start, total, K);
   return check_launch("invert_index");
 }
 

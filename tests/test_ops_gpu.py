@@ -349,6 +349,9 @@ def test_inverted_index_and_deterministic_scatter_gradients(ext, oracle, dev):
         got = slots[start[b * N + v]:start[b * N + v + 1]]
         want = (flat[b] == v).nonzero().flatten() + b * M * S
         assert torch.equal(got, want), (b, v)
+    # the whole table against a stable argsort
+    order = np.argsort((flat + torch.arange(B)[:, None] * N).flatten().numpy(), kind="stable")
+    assert np.array_equal(slots.numpy(), order)
     # feature gradient of group_concat_pm: padded bf16 rows (ld = 64) and contiguous fp32 rows
     for dt, ld in ((torch.bfloat16, 64), (torch.float32, 64)):
         go = torch.zeros(B, M, S, ld, dtype=dt, device=dev)
@@ -372,3 +375,38 @@ def test_inverted_index_and_deterministic_scatter_gradients(ext, oracle, dev):
     got = [ext.three_interpolate_grad_gather(go3.to(dev), inv3, w3.to(dev), m) for _ in range(2)]
     assert torch.equal(got[0], got[1])
     torch.testing.assert_close(got[0].cpu(), oracle.three_interpolate_grad(go3, idx3, w3, m), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,L,N", [(1, 1, 1), (2, 2049, 3), (5, 4096, 70000), (32, 2048 * 64, 80000)])
+def test_inverted_index_is_a_stable_sort_eager_and_replayed(ext, dev, B, L, N):
+    """bq_invert_index at sizes from one pair to configs[5]'s SA1 level (4.2 M pairs over 2.56 M points: three 8-bit passes),
+    eagerly and REPLAYED from a HIP graph on fresh indices (the round-5 fault: the first version's library sort died exactly
+    there -- tools/dbg_c5.py): slots is the stable argsort of scene * N + index, start its CSR"""
+    g = torch.Generator().manual_seed(B * 7 + N)
+    def draw():
+        idx = torch.randint(0, N, (B, L), generator=g, dtype=torch.int32)
+        idx[:, L // 2:] = idx[:, :1]
+        return idx
+    def check(idx, start, slots):
+        keys = (idx.long() + torch.arange(B)[:, None] * N).flatten().numpy()
+        assert np.array_equal(slots.cpu().numpy(), np.argsort(keys, kind="stable").astype(np.uint32))
+        want = np.zeros(B * N + 1, np.int64)
+        np.cumsum(np.bincount(keys, minlength=B * N), out=want[1:])
+        assert np.array_equal(start.cpu().numpy(), want)
+    idx = draw()
+    d_idx = idx.to(dev)
+    check(idx, *ext.invert_index(d_idx, N))
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ext.invert_index(d_idx, N)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        start, slots = ext.invert_index(d_idx, N)
+    for _ in range(2):
+        idx = draw()
+        d_idx.copy_(idx)
+        graph.replay()
+        torch.cuda.synchronize()
+        check(idx, start, slots)

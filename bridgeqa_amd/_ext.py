@@ -22,7 +22,7 @@ if not os.path.exists(_LIB_PATH):
 _lib = ctypes.CDLL(_LIB_PATH)
 _lib.bq_last_error.restype = ctypes.c_char_p
 _lib.bq_abi_version.restype = ctypes.c_int
-ABI_VERSION = 4   # = BQHIP_ABI_VERSION of include/bqhip.h
+ABI_VERSION = 5   # = BQHIP_ABI_VERSION of include/bqhip.h
 if _lib.bq_abi_version() != ABI_VERSION:
     raise ImportError("bridgeqa_amd: libbqhip.so ABI %d != %d (stale library: python -m bridgeqa_amd.build --force)"
                       % (_lib.bq_abi_version(), ABI_VERSION))
@@ -1100,17 +1100,19 @@ _lib.bq_pwconv_bn_fwd.restype = ctypes.c_int
 
 
 def pwconv_bn_relu_fwd(x, K, w_pad, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, S, relu,
-                       pool, center=None):
+                       pool, center=None, want_arg=False):
     """x: bf16 rows (R, ldx) view with contiguous elements (ldx = x.stride(0) >= K, the first K of a row are the input
     channels); w_pad: bf16 (N, Kc) contiguous, zero beyond K, Kc % 64 == 0.  y_raw = x @ w^T (bf16 (R, N)), its
     training-mode BatchNorm statistics from the fp32 accumulators (running buffers updated in place), then
     out = relu?(bn(y_raw)) as bf16 (R, N), or (R // S, N) = max over every run of S rows when pool.
     center (f32 (N,), e.g. running_mean itself): y_raw holds x @ w^T - center and stats describe the stored values (same
     `out`; the bf16 rounding of y_raw then applies to the deviation from the channel mean -- bq_pwconv_bn_fwd).
-    Returns out, y_raw, stats (f32 (4, N): scale, shift, mean, rstd)."""
+    Returns out, y_raw, stats (f32 (4, N): scale, shift, mean, rstd); with want_arg (pooled layers) a fourth value: u8
+    (R // S, N), the row of each group's first maximum (None where the fp32-accumulator apply pass produced the output)."""
     if not x.is_cuda:
         raise RuntimeError("x: CPU not supported")
     R, N, Kc = x.shape[0], w_pad.shape[0], w_pad.shape[1]
+    arg = None
     with torch.cuda.device(x.device):
         y_raw = torch.empty(R, N, dtype=torch.bfloat16, device=x.device)
         stats = torch.empty(5, N, dtype=torch.float32, device=x.device)   # scale, shift, mean, rstd (of the stored y) | shift_acc
@@ -1127,9 +1129,65 @@ def pwconv_bn_relu_fwd(x, K, w_pad, gamma, beta, running_mean, running_var, num_
                                            _p(stats[4]), _p(out), int(S), int(bool(relu)), int(bool(pool)),
                                            _stream()), "pwconv_bn_apply")
         else:
-            _check(_lib.bq_bn_apply(_p(y_raw), _p(stats[0]), _p(stats[1]), _p(out), R, N, int(S), int(bool(relu)),
-                                    int(bool(pool)), _stream()), "bn_apply")
-    return out, y_raw, stats
+            if want_arg and pool and int(S) <= 256:
+                arg = torch.empty(R // S, N, dtype=torch.uint8, device=x.device)
+            _check(_lib.bq_bn_apply_arg(_p(y_raw), _p(stats[0]), _p(stats[1]), _p(out), _p(arg), R, N, int(S),
+                                        int(bool(relu)), int(bool(pool)), _stream()), "bn_apply")
+    return (out, y_raw, stats, arg) if want_arg else (out, y_raw, stats)
+
+
+# ---- the backward of a SharedMLP layer in one pass over its activations (csrc/detbwd.hip) ------------------------------------
+_lib.bq_bn_apply_arg.argtypes = [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp]
+_lib.bq_bn_apply_arg.restype = ctypes.c_int
+_lib.bq_bn_backward_reduce.argtypes = [_vp] * 8 + [_l, _i, _i, _i, _i, _vp]
+_lib.bq_bn_backward_reduce.restype = ctypes.c_int
+_lib.bq_bn_backward_reduce_arg.argtypes = [_vp] * 9 + [_l, _i, _i, _i, _vp]
+_lib.bq_bn_backward_reduce_arg.restype = ctypes.c_int
+_lib.bq_sa_bwd_supported.argtypes = [_i, _i, _i, _i, _i]
+_lib.bq_sa_bwd_supported.restype = ctypes.c_int
+_lib.bq_sa_bwd_workgroups.argtypes = [_l, _i, _i, _i, _i]
+_lib.bq_sa_bwd_workgroups.restype = ctypes.c_int
+_lib.bq_sa_bwd_fused.argtypes = [_vp] * 13 + [_l, _i, _i, _i, _i, _i, _i, _i, _vp]
+_lib.bq_sa_bwd_fused.restype = ctypes.c_int
+# SharedMLP backward as reduction + one fused pass (off, or BQ_FUSED_SA_BWD=0 for A/B runs: bn_relu_bwd + dX GEMM + wgrad_rows)
+FUSED_SA_BWD = [os.environ.get("BQ_FUSED_SA_BWD", "1") != "0"]
+
+
+def sa_bwd_supported(ldx, N, S, pool, need_dx):
+    return bool(_lib.bq_sa_bwd_supported(int(ldx), int(N), int(S), int(bool(pool)), int(bool(need_dx))))
+
+
+def bn_bwd_reduce(dy, x, stats, S, relu, pool, arg=None):
+    """dgb f32 (2, C) = dbeta | dgamma of bn_relu_bwd alone; arg (pooled layers): the forward's arg-max table"""
+    R, C = x.shape
+    with torch.cuda.device(x.device):
+        dgb = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        part = torch.empty(_lib.bq_bn_chunks(R, int(S), int(bool(pool))) * 2 * C, dtype=torch.float32, device=x.device)
+        if pool and arg is not None and C <= 256 and 256 % C == 0:
+            _check(_lib.bq_bn_backward_reduce_arg(_p(dy), _p(x), _p(arg), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]),
+                                                  _p(part), _p(dgb), R, C, int(S), int(bool(relu)), _stream()),
+                   "bn_backward_reduce_arg")
+        else:
+            _check(_lib.bq_bn_backward_reduce(_p(dy), _p(x), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), _p(part),
+                                              _p(dgb), R, C, int(S), int(bool(relu)), int(bool(pool)), _stream()),
+                   "bn_backward_reduce")
+    return dgb
+
+
+def sa_bwd_fused(x, y_raw, dout, arg, w_pad, stats, dgb, S, relu, pool, need_dx):
+    """x bf16 (R, ldx) whole padded rows, y_raw bf16 (R, N), dout bf16 (R, N) | (R // S, N) with arg u8 when pool, w_pad bf16
+    (N, Kc), stats f32 (>= 4, N), dgb f32 (2, N) -> dx bf16 (R, ldx) | None, dw f32 (N, ldx)"""
+    R, ldx = x.shape[0], x.stride(0)
+    N = y_raw.shape[1]
+    with torch.cuda.device(x.device):
+        dx = torch.empty(R, ldx, dtype=torch.bfloat16, device=x.device) if need_dx else None
+        dw = torch.empty(N, ldx, dtype=torch.float32, device=x.device)
+        wgs = _lib.bq_sa_bwd_workgroups(R, ldx, N, int(bool(pool)), int(bool(need_dx)))
+        part = torch.empty(wgs * N * ldx, dtype=torch.float32, device=x.device)
+        _check(_lib.bq_sa_bwd_fused(_p(x), _p(y_raw), _p(dout), _p(arg), _p(w_pad), _p(stats[0]), _p(stats[1]), _p(stats[2]),
+                                    _p(stats[3]), _p(dgb), _p(dx), _p(dw), _p(part), R, ldx, N, w_pad.stride(0), ldx, int(S),
+                                    int(bool(relu)), int(bool(pool)), _stream()), "sa_bwd_fused")
+    return dx, dw
 
 
 # SharedMLP outputs from the fp32 accumulators (bq_pwconv_bn_apply) instead of from the stored bf16 y.  OFF: measured in round 5

@@ -128,10 +128,12 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(const float *__restrict__ 
 }
 
 // y = relu?(x*scale + shift); POOL: out[g][c] = max over the S rows of group g (relu applied: max >= 0 when RELU)
+// arg (POOL, may be null): u8 (R / S, C), the row 0 .. S-1 of the group's FIRST maximum -- what the backward searches for
+// otherwise (bn_bwd_reduce_kernel / bn_bwd_dx_kernel); csrc/detbwd.hip reads the table instead
 template <bool RELU, bool POOL>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const __bf16 *__restrict__ x, const float *__restrict__ scale,
                                                        const float *__restrict__ shift, __bf16 *__restrict__ y, long R,
-                                                       int C, int S) {
+                                                       int C, int S, unsigned char *__restrict__ arg) {
   const int tpr = C >> 3;
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const int cg = (int)(t % tpr);
@@ -157,18 +159,28 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const __bf16 *__restrict_
     *reinterpret_cast<bf16x8 *>(y + row * C + cg * 8) = o;
   } else {
     float m[8];
+    int am[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) m[i] = RELU ? 0.0f : -INFINITY;
+    for (int i = 0; i < 8; ++i) { m[i] = -INFINITY; am[i] = 0; }
     const __bf16 *px = x + row * S * C + cg * 8;
     for (int s = 0; s < S; ++s) {
       const bf16x8 v = *reinterpret_cast<const bf16x8 *>(px + (long)s * C);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], (float)v[i] * sc[i] + sh[i]);
+      for (int i = 0; i < 8; ++i) {
+        const float z = (float)v[i] * sc[i] + sh[i];
+        if (z > m[i]) { m[i] = z; am[i] = s; }
+      }
     }
     bf16x8 o;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (__bf16)m[i];
+    for (int i = 0; i < 8; ++i) o[i] = (__bf16)(RELU ? fmaxf(m[i], 0.0f) : m[i]);
     *reinterpret_cast<bf16x8 *>(y + row * C + cg * 8) = o;
+    if (arg) {
+      uint2 pk;
+      pk.x = (unsigned)am[0] | ((unsigned)am[1] << 8) | ((unsigned)am[2] << 16) | ((unsigned)am[3] << 24);
+      pk.y = (unsigned)am[4] | ((unsigned)am[5] << 8) | ((unsigned)am[6] << 16) | ((unsigned)am[7] << 24);
+      *reinterpret_cast<uint2 *>(arg + row * C + cg * 8) = pk;
+    }
   }
 }
 
@@ -345,22 +357,56 @@ extern "C" __attribute__((visibility("default"))) int bq_bn_stats(const void *x,
   return check_launch("bn_stats");
 }
 
-// y = relu?(x*scale + shift): y bf16 (R, C), or with pool != 0 y bf16 (R/S, C) = max over each run of S rows.
-extern "C" __attribute__((visibility("default"))) int bq_bn_apply(const void *x, const float *scale, const float *shift,
-                                                                  void *y, long R, int C, int S, int relu, int pool,
-                                                                  void *stream) {
+// y = relu?(x*scale + shift): y bf16 (R, C), or with pool != 0 y bf16 (R/S, C) = max over each run of S rows; arg (pooled
+// layers, may be null): u8 (R/S, C) = the row 0 .. S-1 of each group's first maximum (S <= 256).
+extern "C" __attribute__((visibility("default"))) int bq_bn_apply_arg(const void *x, const float *scale, const float *shift,
+                                                                      void *y, void *arg, long R, int C, int S, int relu,
+                                                                      int pool, void *stream) {
   BQ_REQUIRE(bn_extents_ok(R, C, S, pool) && (C >> 3) <= 256, BQ_ELIMIT, "bn_apply: C=%d S=%d unsupported", C, S);
+  BQ_REQUIRE(!arg || (pool && S <= 256), BQ_EINVAL, "bn_apply: arg is for pooled layers with S <= 256");
   if (R == 0) return BQ_OK;
   BQ_REQUIRE(x && scale && shift && y, BQ_EINVAL, "bn_apply: null pointer");
   const long rows = pool ? R / S : R, threads = rows * (C >> 3);
   const dim3 grid((unsigned)((threads + 255) / 256));
   hipStream_t st = (hipStream_t)stream;
 #define BQ_BN_APPLY(RL, PL) hipLaunchKernelGGL((bn_apply_kernel<RL, PL>), grid, dim3(256), 0, st, (const __bf16 *)x, \
-                                               scale, shift, (__bf16 *)y, R, C, S)
+                                               scale, shift, (__bf16 *)y, R, C, S, (unsigned char *)arg)
   if (relu) { if (pool) BQ_BN_APPLY(true, true); else BQ_BN_APPLY(true, false); }
   else      { if (pool) BQ_BN_APPLY(false, true); else BQ_BN_APPLY(false, false); }
 #undef BQ_BN_APPLY
   return check_launch("bn_apply");
+}
+
+extern "C" __attribute__((visibility("default"))) int bq_bn_apply(const void *x, const float *scale, const float *shift,
+                                                                  void *y, long R, int C, int S, int relu, int pool,
+                                                                  void *stream) {
+  return bq_bn_apply_arg(x, scale, shift, y, nullptr, R, C, S, relu, pool, stream);
+}
+
+// out[j] = sum over the chunks of partial[chunk][j], j < W, in chunk order (library-internal: csrc/detbwd.hip)
+extern "C" int bq_bn_fold(const float *partial, float *out, int chunks, int W, void *stream) {
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((W + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, out, chunks, W);
+  return check_launch("bn_fold");
+}
+
+// The reduction half of bq_bn_backward alone: dgb f32 (2, C) = dbeta | dgamma (csrc/detbwd.hip computes the gradient w.r.t. x
+// inside its fused pass).  Same arguments as bq_bn_backward without dx.
+extern "C" __attribute__((visibility("default"))) int bq_bn_backward_reduce(const void *dy, const void *x, const float *scale,
+                                                                            const float *shift, const float *mean,
+                                                                            const float *rstd, float *partial, float *dgb, long R,
+                                                                            int C, int S, int relu, int pool, void *stream) {
+  BQ_REQUIRE(bn_extents_ok(R, C, S, pool) && (C >> 3) <= 256, BQ_ELIMIT, "bn_backward_reduce: C=%d S=%d unsupported", C, S);
+  BQ_REQUIRE(R > 0, BQ_EINVAL, "bn_backward_reduce: empty batch");
+  BQ_REQUIRE(dy && x && scale && shift && mean && rstd && partial && dgb, BQ_EINVAL, "bn_backward_reduce: null pointer");
+  const int chunks = bq_bn_chunks(R, S, pool);
+  hipStream_t st = (hipStream_t)stream;
+#define BQ_BN_RED(RL, PL) hipLaunchKernelGGL((bn_bwd_reduce_kernel<RL, PL>), dim3(chunks), dim3(256), 0, st,           \
+                                             (const __bf16 *)dy, (const __bf16 *)x, scale, shift, mean, rstd, partial, \
+                                             R, C, S)
+  if (relu) { if (pool) BQ_BN_RED(true, true); else BQ_BN_RED(true, false); }
+  else      { if (pool) BQ_BN_RED(false, true); else BQ_BN_RED(false, false); }
+#undef BQ_BN_RED
+  return bq_bn_fold(partial, dgb, chunks, 2 * C, stream);
 }
 
 // Backward of bq_bn_stats + bq_bn_apply w.r.t. x, gamma, beta.  dy bf16 (R, C) or (R/S, C) when pooled;

@@ -12,6 +12,10 @@ void set_error(const char *fmt, ...);
 int check_launch(const char *what);
 int device_cus();   // compute units of the CURRENT device (cached per device ordinal, pn2_ops.hip)
 
+// library-internal entry points shared between translation units (not part of include/*.h)
+extern "C" int bq_bn_fold(const float *partial, float *out, int chunks, int W, void *stream);                       // bn.hip
+extern "C" int bq_wgrad_rows_reduce(float *part, float *out, int Ni, int Nj, int ldo, int pieces, void *stream);    // gemm.hip
+
 #define BQ_REQUIRE(cond, code, ...)   \
   do {                                \
     if (!(cond)) {                    \

@@ -1586,6 +1586,15 @@ extern "C" int bq_wgrad_rows_bf16(const void *P, const void *Q, float *out, floa
   return check_launch("wgrad_rows");
 }
 
+// out (Nj, ldo) = the sum of `pieces` slices of part, in slice order (library-internal: csrc/detbwd.hip)
+extern "C" int bq_wgrad_rows_reduce(float *part, float *out, int Ni, int Nj, int ldo, int pieces, void *stream) {
+  using namespace bq;
+  WgradRowsArgs a{};
+  a.part = part; a.out = out; a.Ni = Ni; a.Nj = Nj; a.ldo = ldo; a.pieces = pieces;
+  hipLaunchKernelGGL(wgrad_rows_reduce_kernel, dim3((Nj * ldo / 4 + 15) / 16), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("wgrad_rows_reduce");
+}
+
 extern "C" int bq_pwconv_records(long R, int N) {
   // row walkers per 64-channel block: enough workgroups to fill the chip three times over, never more than the tiles
   const long tiles_j = (R + 63) / 64;

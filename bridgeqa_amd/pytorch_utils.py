@@ -106,14 +106,21 @@ class _ConvBNReLUPointMajor(torch.autograd.Function):
         w_pad = fusion_ops.padded_conv_shadow(conv_weight)
         # (the pre-activation is stored as its deviation from running_mean -- last steps' estimate of the channel mean:
         # BatchNorm's output does not depend on the offset, the bf16 rounding of the stored tensor does; CENTER_PREACT)
-        out, y_raw, stats = _ext.pwconv_bn_relu_fwd(x, K, w_pad, gamma, beta, running_mean, running_var,
-                                                    num_batches_tracked, eps, momentum, S, relu, pool,
-                                                    center=running_mean if CENTER_PREACT[0] else None)
+        # (a pooled layer whose backward will run fused records the arg-max of every group: csrc/detbwd.hip reads the table
+        # instead of searching the group again)
+        want_arg = bool(pool and _ext.FUSED_SA_BWD[0] and x.shape[0] >= _WGRAD_ROWS_MIN
+                        and _ext.sa_bwd_supported(x.stride(0), conv_weight.shape[0], S, True, ctx.needs_input_grad[0]))
+        out, y_raw, stats, arg = _ext.pwconv_bn_relu_fwd(x, K, w_pad, gamma, beta, running_mean, running_var,
+                                                         num_batches_tracked, eps, momentum, S, relu, pool,
+                                                         center=running_mean if CENTER_PREACT[0] else None,
+                                                         want_arg=True) if want_arg else (
+            _ext.pwconv_bn_relu_fwd(x, K, w_pad, gamma, beta, running_mean, running_var, num_batches_tracked, eps,
+                                    momentum, S, relu, pool, center=running_mean if CENTER_PREACT[0] else None) + (None,))
         if conv_bias is not None and running_mean is not None:
             # a convolution bias in front of a training-mode BatchNorm cancels in the normalised output (it shifts the
             # batch mean by itself) and its gradient is identically zero; the only trace it leaves is in running_mean
             running_mean.add_(conv_bias.detach(), alpha=float(momentum))
-        ctx.save_for_backward(x, w_pad, y_raw, stats)
+        ctx.save_for_backward(x, w_pad, y_raw, stats, arg)
         ctx.cfg = (K, S, relu, pool)
         ctx.conv_weight, ctx.conv_bias = conv_weight, conv_bias
         return out
@@ -121,13 +128,24 @@ class _ConvBNReLUPointMajor(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         from . import _ext
-        x, w_pad, y_raw, stats = ctx.saved_tensors
+        x, w_pad, y_raw, stats, arg = ctx.saved_tensors
         K, S, relu, pool = ctx.cfg
         R, ldx = x.shape[0], x.stride(0)
         N = y_raw.shape[1]
         dout = dout.contiguous() if not dout.is_contiguous() else dout
         if dout.dtype != torch.bfloat16:
             dout = dout.to(torch.bfloat16)
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if (_ext.FUSED_SA_BWD[0] and need_dw and R >= _WGRAD_ROWS_MIN and (not pool or arg is not None)
+                and _ext.sa_bwd_supported(ldx, N, S, pool, need_dx) and R * max(ldx, N) * 2 < (1 << 31) - (1 << 20)):
+            # the BatchNorm reduction, then ONE pass over the activations for dX and dW (csrc/detbwd.hip)
+            dgb = _ext.bn_bwd_reduce(dout, y_raw, stats, S, relu, pool, arg)
+            xs = torch.as_strided(x, (R, ldx), (ldx, 1))
+            dx_full, dwf = _ext.sa_bwd_fused(xs, y_raw, dout, arg, w_pad, stats, dgb, S, relu, pool, need_dx)
+            dx = dx_full[:, :x.shape[1]] if need_dx else None
+            dw = dwf[:, :K].reshape(ctx.conv_weight.shape)
+            dcb = torch.zeros_like(ctx.conv_bias) if ctx.conv_bias is not None else None
+            return dx, dw, dgb[1], dgb[0], None, None, None, None, None, None, None, None, dcb
         dy, dgamma, dbeta = _ext.bn_relu_bwd(dout, y_raw, stats, S, relu, pool)
         dx = None
         if ctx.needs_input_grad[0]:

@@ -148,6 +148,37 @@ BQ_API int bq_bn_apply(const void *x, const float *scale, const float *shift, vo
 BQ_API int bq_bn_backward(const void *dy, const void *x, const float *scale, const float *shift, const float *mean,
                           const float *rstd, float *partial, float *dgb, void *dx, long R, int C, int S, int relu,
                           int pool, void *stream);
+/* ABI 5.  bq_bn_apply_arg: bq_bn_apply that also records, for a pooled layer, which row 0 .. S-1 of every group holds the
+ * group's FIRST maximum per channel: arg u8 (R / S, C), may be NULL, S <= 256 -- the index F.max_pool2d's backward routes the
+ * gradient to (pointnet2_modules.py:259-262), so that the backward does not search for it again.
+ * bq_bn_backward_reduce: the reduction half of bq_bn_backward alone (dgb = dbeta | dgamma; no dx).
+ * bq_bn_backward_reduce_arg: the same for a pooled layer from its arg table: one stored pre-activation value read per
+ * (group, channel) instead of all S; C <= 256, 256 % C == 0; partial = bq_bn_chunks(R, S, 1) * 2C floats. */
+BQ_API int bq_bn_apply_arg(const void *x, const float *scale, const float *shift, void *y, void *arg, long R, int C, int S,
+                           int relu, int pool, void *stream);
+BQ_API int bq_bn_backward_reduce(const void *dy, const void *x, const float *scale, const float *shift, const float *mean,
+                                 const float *rstd, float *partial, float *dgb, long R, int C, int S, int relu, int pool,
+                                 void *stream);
+BQ_API int bq_bn_backward_reduce_arg(const void *dy, const void *x, const void *arg, const float *scale, const float *shift,
+                                     const float *mean, const float *rstd, float *partial, float *dgb, long R, int C, int S,
+                                     int relu, void *stream);
+/* ---- the backward of a SharedMLP layer in one pass over its activations (csrc/detbwd.hip, ABI 5) ------------------------
+ * Replaces, after the BatchNorm reduction (dgb from bq_bn_backward_reduce[_arg]), bq_bn_backward's dx pass, the dX GEMM and
+ * bq_wgrad_rows_bf16 of one conv -> BatchNorm2d -> ReLU (-> max_pool2d) layer (lib/pointnet2/pytorch_utils.py:104-157 and
+ * its autograd): x bf16 (R, ldx) the layer's input rows (whole padded rows, ldx % 8 == 0, ldx <= 192), p bf16 (R, Nj) the
+ * stored pre-activation (Nj = 64 or 128), dout bf16 (R, Nj), or (R / S, Nj) with arg u8 (R / S, Nj) when pool != 0 (S = 16,
+ * 32 or 64, R % S == 0), w bf16 (Nj, ldw) zero beyond the input channels (ldw >= ldx rounded up to 64), scale / shift / mean /
+ * rstd f32 (Nj) of the stored pre-activation ->
+ *   dx bf16 (R, ldx) = dP w                  (NULL: not needed; the padding columns come out 0 because w's are)
+ *   dw f32 (Nj, ldo) = dP^T x                (columns [ldx, ldo) set to 0; ldo % 4 == 0)
+ * with dP = scale (g - dbeta / R - xhat dgamma / R) formed tile by tile in LDS and never stored.  part: scratch of
+ * bq_sa_bwd_workgroups(R, ldx, Nj, pool, dx != NULL) * Nj * ldo floats (per-workgroup slices, summed in a fixed order: no
+ * atomics).  bq_sa_bwd_supported: 1 when a kernel exists for the shape (it fits the 160 KB LDS). */
+BQ_API int bq_sa_bwd_supported(int ldx, int Nj, int S, int pool, int need_dx);
+BQ_API int bq_sa_bwd_workgroups(long R, int ldx, int Nj, int pool, int need_dx);
+BQ_API int bq_sa_bwd_fused(const void *x, const void *p, const void *dout, const void *arg, const void *w, const float *scale,
+                           const float *shift, const float *mean, const float *rstd, const float *dgb, void *dx, float *dw,
+                           float *part, long R, int ldx, int Nj, int ldw, int ldo, int S, int relu, int pool, void *stream);
 
 /* exact (erf) GELU, bf16 (vit.py:23-41 Mlp act_layer=nn.GELU); n % 8 == 0, 16-B aligned */
 BQ_API int bq_gelu_fwd_bf16(const void *x, void *y, long n, void *stream);

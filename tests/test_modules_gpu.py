@@ -390,3 +390,66 @@ def test_native_sharedmlp_layer_backward_vs_torch(dev):
             assert errs["out"] <= 5e-3 and max(errs[k] for k in ("dx", "dw", "dg", "db")) <= 2e-2, (R, K, N, errs)
         finally:
             fusion_ops.set_compute_dtype(prev)
+
+
+@pytest.mark.parametrize("R,K,ldx,N,S,pool,need_dx", [
+    (131072, 64, 64, 64, 64, False, True),      # 1 x 1 units (SA1's middle layer)
+    (131072, 64, 64, 128, 64, True, True),      # 1 x 2, pooled over 64 (SA1's last layer)
+    (70001, 135, 136, 64, 64, False, False),    # 3 x 1, no input gradient, ragged last tile (SA1's first layer)
+    (70016, 131, 136, 128, 32, False, True),    # 3 x 2 (SA2's first layer)
+    (98304, 128, 128, 128, 32, False, True),    # 2 x 2
+    (65536, 128, 128, 128, 16, True, True),     # 2 x 2, pooled over 16
+    (131072, 64, 64, 64, 32, True, False),      # 1 x 1, pooled over 32, no input gradient
+])
+def test_fused_sharedmlp_backward(dev, R, K, ldx, N, S, pool, need_dx):
+    """csrc/detbwd.hip: BatchNorm reduction + ONE pass for dX and dW against the unfused backward
+    (bn_bwd_dx -> dX GEMM -> wgrad_rows) on the same forward -- same arg-max, same ReLU mask, dP never stored: dX / dW to 1e-2
+    (two bf16 roundings of dP apart), dgamma / dbeta to 1e-4 (the pooled reduction reads the arg-max table instead of searching)
+    -- and, without pooling, against torch autograd in fp32 on the same operands at the unfused path's 2e-2."""
+    from bridgeqa_amd import fusion_ops, _ext
+    from bridgeqa_amd.pytorch_utils import _ConvBNReLUPointMajor
+    g = torch.Generator().manual_seed(R % 977 + N + S)
+    conv = torch.nn.Conv2d(K, N, 1, bias=False).to(dev)
+    bn = torch.nn.BatchNorm2d(N).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(N, generator=g) + 0.5); bn.bias.copy_(torch.randn(N, generator=g) * 0.2)
+    xfull = torch.zeros(R, ldx)
+    xfull[:, :K] = torch.randn(R, K, generator=g)
+    xb = xfull.to(dev).to(torch.bfloat16)
+    wout = torch.randn(R // S if pool else R, N, generator=g).to(dev)
+    rel = lambda a, b: ((a.float() - b.float()).norm() / (b.float().norm() + 1e-20)).item()
+    res = {}
+    prev = fusion_ops.set_compute_dtype(torch.bfloat16)
+    prev_f = _ext.FUSED_SA_BWD[0]
+    try:
+        for fused in (True, False):
+            _ext.FUSED_SA_BWD[0] = fused
+            for p in (conv.weight, bn.weight, bn.bias):
+                p.grad = None
+            x_nat = xb.clone().requires_grad_(need_dx)
+            rows = x_nat[:, :K] if ldx != K else x_nat
+            out = _ConvBNReLUPointMajor.apply(rows, conv.weight, bn.weight, bn.bias, None, None, None, bn.eps, 0.1, True,
+                                              pool, S)
+            (out.float() * wout).sum().backward()
+            res[fused] = dict(out=out.detach().float(), dx=x_nat.grad.float() if need_dx else None,
+                              dw=conv.weight.grad.clone(), dg=bn.weight.grad.clone(), db=bn.bias.grad.clone())
+    finally:
+        _ext.FUSED_SA_BWD[0] = prev_f
+        fusion_ops.set_compute_dtype(prev)
+    a, b = res[True], res[False]
+    assert torch.equal(a["out"], b["out"])
+    errs = dict(dw=rel(a["dw"], b["dw"]), dg=rel(a["dg"], b["dg"]), db=rel(a["db"], b["db"]))
+    if need_dx:
+        errs["dx"] = rel(a["dx"], b["dx"])
+        assert torch.equal(a["dx"][:, K:], torch.zeros_like(a["dx"][:, K:]))
+    assert errs["dw"] <= 1e-2 and errs.get("dx", 0.0) <= 1e-2 and errs["dg"] <= 1e-4 and errs["db"] <= 1e-4, errs
+    if not pool:
+        x_ref = xb[:, :K].float().clone().requires_grad_(True)
+        w_ref = conv.weight.detach().to(torch.bfloat16).float().view(N, K).requires_grad_(True)
+        bn.weight.grad = None; bn.bias.grad = None
+        yn = torch.nn.functional.batch_norm(x_ref @ w_ref.t(), None, None, bn.weight, bn.bias, True, 0.1, bn.eps)
+        (torch.relu(yn) * wout).sum().backward()
+        e2 = dict(dw=rel(a["dw"].view(N, K), w_ref.grad), dg=rel(a["dg"], bn.weight.grad), db=rel(a["db"], bn.bias.grad))
+        if need_dx:
+            e2["dx"] = rel(a["dx"][:, :K], x_ref.grad)
+        assert max(e2.values()) <= 2e-2, e2

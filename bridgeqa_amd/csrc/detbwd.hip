@@ -22,6 +22,7 @@
 namespace bq {
 
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 struct SaBwdArgs {
   const __bf16 *X;       // [R][ldx] the layer's input rows (whole padded rows)
@@ -40,12 +41,17 @@ struct SaBwdArgs {
 template <int TI, int TJ, bool POOL, bool DX>
 struct SaBwdCfg {
   static constexpr int UNITS = TI + TJ * (POOL ? 1 : 2);
-  static constexpr int STAGE = UNITS * 8192 + (POOL ? 8192 : 0);
   static constexpr int WB = DX ? TI * TJ * 8192 : 0;
-  static constexpr int NS = 3 * STAGE + WB <= 160 * 1024 ? 3 : 2;
+  // pooled layers: a wave's dOut / arg-max rows (one group per wave and tile) travel by DMA into 2 KB of the stage while three
+  // stages fit; with two stages they are loaded into registers instead (GREG: the loads of tile t + 1 are issued after the
+  // transform of tile t has consumed the registers) and the stage is the images alone
+  static constexpr int STAGE3 = UNITS * 8192 + (POOL ? 8192 : 0);
+  static constexpr int NS = 3 * STAGE3 + WB <= 160 * 1024 ? 3 : 2;
+  static constexpr bool GREG = POOL && NS == 2;
+  static constexpr int STAGE = NS == 3 ? STAGE3 : UNITS * 8192;
   static constexpr int LDS = NS * STAGE + WB;
   static constexpr bool FITS = LDS <= 160 * 1024;
-  static constexpr int NDMA = 2 * TI + 2 * TJ + (POOL ? 2 : 2 * TJ);   // per wave and stage
+  static constexpr int NDMA = 2 * TI + 2 * TJ + (POOL ? (GREG ? 2 * TJ : 2) : 2 * TJ);   // vector-memory operations per wave and stage
   static constexpr int NST = DX ? 4 * TI : 0;                           // dX stores per wave and tile
   static constexpr int WAITN = (NS - 2) * (NDMA + NST) + NST;
 };
@@ -102,6 +108,8 @@ __global__ __launch_bounds__(256) void sa_bwd_kernel(const SaBwdArgs ar) {
   const int smask = ar.S - 1;   // (pooled: S is a power of two, 16 .. 64)
   const int sshift = POOL ? __builtin_ctz((unsigned)ar.S) : 0;
 
+  [[maybe_unused]] u32x4_t g_d[TJ];   // GREG: the next tile's group rows
+  [[maybe_unused]] u32x2_t g_a[TJ];
   auto stage = [&](int step) {
     const bool live = step < nkt;
     unsigned char *base = stages + (step % NS) * STAGE;
@@ -124,7 +132,18 @@ __global__ __launch_bounds__(256) void sa_bwd_kernel(const SaBwdArgs ar) {
       vx[d] += x_step;
       vp[d] += p_step;
     }
-    if constexpr (POOL) {
+    if constexpr (C::GREG) {
+      // this wave's 16 rows lie in ONE group (S % 16 == 0): this lane's chunk of the group's dOut and arg rows, per unit
+      const long row0 = (long)(kt0 + step) * 64 + wave * 16;
+      const unsigned grp = (unsigned)(row0 >> sshift);
+      const bool ok = live && row0 < ar.R;
+#pragma unroll
+      for (int v = 0; v < TJ; ++v) {
+        const unsigned e = grp * (unsigned)ar.Nj + v * 64 + cp * 8;
+        g_d[v] = __builtin_amdgcn_raw_buffer_load_b128(rsD, ok ? e * 2u : DEAD, 0, 0);
+        g_a[v] = __builtin_amdgcn_raw_buffer_load_b64(rsA, ok ? e : DEAD, 0, 0);
+      }
+    } else if constexpr (POOL) {
       // this wave's 16 rows lie in ONE group (S % 16 == 0): its dOut row (lanes 0 .. Nj/8-1) and arg row (lanes 0 .. Nj/16-1)
       const long row0 = (long)(kt0 + step) * 64 + wave * 16;
       const unsigned grp = (unsigned)(row0 >> sshift);
@@ -183,7 +202,10 @@ __global__ __launch_bounds__(256) void sa_bwd_kernel(const SaBwdArgs ar) {
       for (int v = 0; v < TJ; ++v) {
         [[maybe_unused]] bf16x8 gd;
         [[maybe_unused]] u32x2_t ga;
-        if constexpr (POOL) {
+        if constexpr (C::GREG) {
+          gd = __builtin_bit_cast(bf16x8, g_d[v]);
+          ga = g_a[v];
+        } else if constexpr (POOL) {
           gd = *reinterpret_cast<const bf16x8 *>(garea + (v * 64 + cp * 8) * 2);
           ga = *reinterpret_cast<const u32x2_t *>(garea + 1024 + v * 64 + cp * 8);
         }
@@ -348,9 +370,8 @@ static int launch_sa_bwd_pd(bool pool, bool dx, int wgs, hipStream_t st, const S
 }
 
 static int sa_bwd_lds(int ti, int tj, bool pool, bool dx) {
-  const int units = ti + tj * (pool ? 1 : 2), stage = units * 8192 + (pool ? 8192 : 0), wb = dx ? ti * tj * 8192 : 0;
-  const int ns = 3 * stage + wb <= 160 * 1024 ? 3 : 2;
-  return ns * stage + wb;
+  const int units = ti + tj * (pool ? 1 : 2), stage3 = units * 8192 + (pool ? 8192 : 0), wb = dx ? ti * tj * 8192 : 0;
+  return 3 * stage3 + wb <= 160 * 1024 ? 3 * stage3 + wb : 2 * units * 8192 + wb;
 }
 
 }  // namespace bq
@@ -359,7 +380,7 @@ using namespace bq;
 // 1 when bq_sa_bwd_fused has a kernel for a layer with ldx input elements per row and Nj output channels
 extern "C" int bq_sa_bwd_supported(int ldx, int Nj, int S, int pool, int need_dx) {
   const int ti = (ldx + 63) / 64, tj = Nj / 64;
-  if (ldx <= 0 || ldx % 8 || Nj % 64 || ti < 1 || ti > 3 || (tj != 1 && tj != 2)) return 0;
+  if (ldx <= 0 || ldx % 8 || Nj % 64 || ti < 1 || ti > 3 || (tj != 1 && tj != 2 && !(tj == 4 && ti == 2))) return 0;
   if (pool && !(S == 16 || S == 32 || S == 64)) return 0;
   return sa_bwd_lds(ti, tj, pool != 0, need_dx != 0) <= 160 * 1024;
 }
@@ -414,6 +435,7 @@ extern "C" int bq_sa_bwd_fused(const void *x, const void *p, const void *dout,
   else if (ti == 1 && tj == 2) rc = launch_sa_bwd_pd<1, 2>(pool, dx != nullptr, wgs, st, a);
   else if (ti == 2 && tj == 1) rc = launch_sa_bwd_pd<2, 1>(pool, dx != nullptr, wgs, st, a);
   else if (ti == 2 && tj == 2) rc = launch_sa_bwd_pd<2, 2>(pool, dx != nullptr, wgs, st, a);
+  else if (ti == 2 && tj == 4) rc = launch_sa_bwd_pd<2, 4>(pool, dx != nullptr, wgs, st, a);
   else if (ti == 3 && tj == 1) rc = launch_sa_bwd_pd<3, 1>(pool, dx != nullptr, wgs, st, a);
   else if (ti == 3 && tj == 2) rc = launch_sa_bwd_pd<3, 2>(pool, dx != nullptr, wgs, st, a);
   BQ_REQUIRE(rc == 0, BQ_EINVAL, "bq_sa_bwd_fused: no kernel for %d x %d units", ti, tj);

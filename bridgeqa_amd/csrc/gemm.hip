@@ -1056,11 +1056,14 @@ __device__ __forceinline__ void chan_merge(float &n, float &mean, float &m2, flo
   m2 += m2g + delta * delta * (n * ng / tot);
   n = tot;
 }
-constexpr int PWF_PH = 16;
+// 16 channels x 64 phases per workgroup (round 5: 64 channels x 16 phases left every thread a chain of nrec / 16 = 64 records,
+// 16 dependent batches of loads -- 23 us per layer, 0.5 ms per step over the detector's 23 layers): a thread merges nrec / 64
+// records, four loads in flight, then the 64 phases of a channel meet in LDS in a fixed order
+constexpr int PWF_PH = 64, PWF_CH = 16;
 __global__ __launch_bounds__(1024) void pwconv_bn_finalize_kernel(const PwconvBnParams p) {
-  __shared__ float sh[3][PWF_PH][64];
-  const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
-  const int c = min(blockIdx.x * 64 + cl, p.C - 1);
+  __shared__ float sh[3][PWF_PH][PWF_CH];
+  const int cl = threadIdx.x & (PWF_CH - 1), ph = threadIdx.x / PWF_CH;
+  const int c = min(blockIdx.x * PWF_CH + cl, p.C - 1);
   float n = 0.f, mean = 0.f, m2 = 0.f;
   for (int g0 = ph; g0 < p.nrec; g0 += 4 * PWF_PH) {
     float pv[4], su[4], sq[4], ng[4];
@@ -1080,10 +1083,19 @@ __global__ __launch_bounds__(1024) void pwconv_bn_finalize_kernel(const PwconvBn
   }
   sh[0][ph][cl] = n; sh[1][ph][cl] = mean; sh[2][ph][cl] = m2;
   __syncthreads();
-  if (ph != 0 || blockIdx.x * 64 + cl >= p.C) return;
+  // 64 -> 8 -> 1: phases 8 q .. 8 q + 7 merged by thread (q, cl), then the eight results by thread (0, cl)
+  if (ph < 8) {
+    n = 0.f; mean = 0.f; m2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) chan_merge(n, mean, m2, sh[0][ph * 8 + q][cl], sh[1][ph * 8 + q][cl], sh[2][ph * 8 + q][cl]);
+  }
+  __syncthreads();
+  if (ph < 8) { sh[0][ph][cl] = n; sh[1][ph][cl] = mean; sh[2][ph][cl] = m2; }
+  __syncthreads();
+  if (ph != 0 || blockIdx.x * PWF_CH + cl >= p.C) return;
   n = 0.f; mean = 0.f; m2 = 0.f;
 #pragma unroll
-  for (int q = 0; q < PWF_PH; ++q) chan_merge(n, mean, m2, sh[0][q][cl], sh[1][q][cl], sh[2][q][cl]);
+  for (int q = 0; q < 8; ++q) chan_merge(n, mean, m2, sh[0][q][cl], sh[1][q][cl], sh[2][q][cl]);
   const float var = m2 / n;
   const float rstd = rsqrtf(var + p.eps);
   const float sc = p.gamma[c] * rstd;
@@ -1630,7 +1642,7 @@ extern "C" int bq_pwconv_bn_fwd(const void *x, long R, int K, int ldx, const voi
   hipLaunchKernelGGL(pwconv64_kernel<0>, dim3(a.tiles_i * a.Gj), dim3(256), 0, st, a);
   PwconvBnParams p{partial, gamma, beta, running_mean, running_var, num_batches_tracked, scale, shift, mean, rstd,
                    eps, momentum, N, a.Gj * 2, a.Gj, R, center, shift_acc};
-  hipLaunchKernelGGL(pwconv_bn_finalize_kernel, dim3((N + 63) / 64), dim3(1024), 0, st, p);
+  hipLaunchKernelGGL(pwconv_bn_finalize_kernel, dim3((N + PWF_CH - 1) / PWF_CH), dim3(1024), 0, st, p);
   return check_launch("pwconv_bn_fwd");
 }
 

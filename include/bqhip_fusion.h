@@ -166,7 +166,7 @@ BQ_API int bq_bn_backward_reduce_arg(const void *dy, const void *x, const void *
  * Replaces, after the BatchNorm reduction (dgb from bq_bn_backward_reduce[_arg]), bq_bn_backward's dx pass, the dX GEMM and
  * bq_wgrad_rows_bf16 of one conv -> BatchNorm2d -> ReLU (-> max_pool2d) layer (lib/pointnet2/pytorch_utils.py:104-157 and
  * its autograd): x bf16 (R, ldx) the layer's input rows (whole padded rows, ldx % 8 == 0, ldx <= 192), p bf16 (R, Nj) the
- * stored pre-activation (Nj = 64 or 128), dout bf16 (R, Nj), or (R / S, Nj) with arg u8 (R / S, Nj) when pool != 0 (S = 16,
+ * stored pre-activation (Nj = 64 or 128; 256 for a pooled layer with ldx <= 128), dout bf16 (R, Nj), or (R / S, Nj) with arg u8 (R / S, Nj) when pool != 0 (S = 16,
  * 32 or 64, R % S == 0), w bf16 (Nj, ldw) zero beyond the input channels (ldw >= ldx rounded up to 64), scale / shift / mean /
  * rstd f32 (Nj) of the stored pre-activation ->
  *   dx bf16 (R, ldx) = dP w                  (NULL: not needed; the padding columns come out 0 because w's are)

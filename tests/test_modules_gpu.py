@@ -400,6 +400,9 @@ def test_native_sharedmlp_layer_backward_vs_torch(dev):
     (98304, 128, 128, 128, 32, False, True),    # 2 x 2
     (65536, 128, 128, 128, 16, True, True),     # 2 x 2, pooled over 16
     (131072, 64, 64, 64, 32, True, False),      # 1 x 1, pooled over 32, no input gradient
+    (65536, 128, 128, 256, 32, True, True),     # 2 x 4, pooled (SA2's last layer): group rows in registers, two stages
+    (65600, 128, 128, 256, 16, True, True),     # the same over 16 with a ragged last tile (SA3 / SA4's last layer)
+    (69632, 131, 136, 128, 16, True, True),     # 3 x 2 pooled: two stages
 ])
 def test_fused_sharedmlp_backward(dev, R, K, ldx, N, S, pool, need_dx):
     """csrc/detbwd.hip: BatchNorm reduction + ONE pass for dX and dW against the unfused backward

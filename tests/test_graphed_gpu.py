@@ -2,10 +2,13 @@
 model(data_dict) -> get_loss -> zero_grad -> backward -> optimizer.step) against the same loop run kernel by kernel and
 against pipeline.PhasedTrainStep.
 
-Tolerances: the three executions run the same kernels on the same inputs, but the detector's scatter gradients use fp32
-atomics (order-dependent rounding) and AdamW turns a gradient into a step of size ~lr whatever its magnitude, so after a few
-steps parameters agree to a small multiple of lr on a few elements, not to 1e-6: compared are the loss sequences (2e-3
-relative) and the parameter UPDATES (rel-L2 <= 5e-2 per tensor family, the whole update vector <= 2e-2)."""
+Tolerances: the three executions run the same kernels on the same inputs and, since round 5, without fp32 atomics on the
+detector's data path: one forward + backward agrees to 1e-4 on every parameter's gradient (measured < 1e-6).  A few optimizer
+steps do NOT stay that close: parameters whose true gradient is zero (attention key biases -- softmax is shift-invariant; a
+BatchNorm bias in front of another training-mode BatchNorm) receive rounding noise as their gradient, AdamW's first steps turn
+it into steps of size ~lr in noise-determined directions, and the detection loss amplifies the resulting rounding changes
+(tools/dbg_graphed_step2.py: gradients of those parameters 70 % apart at step 0, the second loss 2.4 % apart, two EAGER
+executions 63 against 74 at the fourth step)."""
 import pytest
 import torch
 
@@ -61,22 +64,21 @@ def test_gradients_behind_the_plain_loop_equal_the_eager_loop(dev):
     prev = ops.set_compute_dtype(torch.bfloat16)
     try:
         want, want_loss = _grads_once(dev, "eager")
-        again, _ = _grads_once(dev, "eager")   # CONTROL: the detector's scatter gradients use fp32 atomics -- two eager
-        #                                        executions already differ by 2-3 % on the deep BatchNorm biases
-        for mode in ("graphed", "wrapped"):
+        for mode in ("eager", "graphed", "wrapped"):   # ("eager": a second eager execution -- the run-to-run control)
             got, got_loss = _grads_once(dev, mode)
-            assert abs(got_loss - want_loss) <= 1e-4 * abs(want_loss), (mode, got_loss, want_loss)
+            assert abs(got_loss - want_loss) <= 1e-6 * abs(want_loss), (mode, got_loss, want_loss)
             assert set(got) == set(want), mode
 
             def err(n, x):   # (a key bias' gradient is exactly zero in exact arithmetic: compared on the value bias' scale)
                 ref = want[n.replace(".key.bias", ".value.bias")] if n.endswith(".key.bias") else want[n]
                 return ((x[n] - want[n]).norm() / (ref.norm() + 1e-12)).item()
-            # beyond twice the run-to-run difference of the eager loop: 2e-2 for the fusion / image side (deterministic
-            # kernels), 6e-2 for the detector (fp32 atomics in its scatter gradients: ONE control execution does not bound
-            # the next -- a deep BatchNorm bias came out 2.6 % apart between two eager runs and 7.9 % in a replayed one)
-            bound = lambda n: 2e-2 if n.startswith("blip_model.") else 6e-2
-            worst = sorted(((err(n, got) - 2.0 * err(n, again) - bound(n), n, err(n, got)) for n in want), reverse=True)[:3]
-            assert worst[0][0] < 0.0, (mode, worst)
+            # Round 5: the detector's scatter gradients are gathers over an inverted index (csrc/invert.hip) and its SharedMLP
+            # backward sums per-workgroup slices in a fixed order (csrc/detbwd.hip) -- no fp32 atomics on the data path any more.
+            # Measured: every parameter below 1e-6 in all three executions (tools/dbg_graphed_tol.py); round 4 needed 6e-2
+            # beyond twice an eager control here.  What is left are weight-gradient column sums and cut contractions that end
+            # in fp32 atomics (last-bit differences).
+            worst = sorted(((err(n, got), n) for n in want), reverse=True)[:3]
+            assert worst[0][0] < 1e-4, (mode, worst)
     finally:
         ops.set_compute_dtype(prev)
 
@@ -131,9 +133,9 @@ def test_the_plain_loop_trains_under_replay_like_the_eager_loop_and_the_phased_s
     for mode, l in res.items():
         assert all(x == x for x in l) and l[-1] < 0.9 * l[0], (mode, l)
         assert abs(l[0] - res["eager"][0]) <= 1e-4 * abs(l[0]), (mode, l, res["eager"])
-        # (no tighter: two EAGER executions of this loop end 56 and 76 apart at the fourth step -- fp32 atomics in the
-        # detector's gradients under Adam's sign-like first steps; what this test guards is that a replayed step trains
-        # at all: updated weights reach the next replay, the static loss is this step's)
+        # (no tighter: two EAGER executions of this loop end 63 and 74 at the fourth step -- zero-true-gradient parameters
+        # under Adam's sign-like first steps, see the module docstring; what this test guards is that a replayed step
+        # trains at all: updated weights reach the next replay, the static loss is this step's)
         for a, b in zip(l, res["eager"]):
             assert 0.5 * abs(b) <= abs(a) <= 2.0 * abs(b), (mode, l, res["eager"])
 

@@ -12,7 +12,8 @@ import os
 
 import torch  # must be imported first: libbqhip.so resolves libamdhip64.so.7 to torch's copy
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libbqhip.so")
+# (BQHIP_LIB: another build of the same sources, e.g. with a measurement macro set -- A/B runs in one gpurun call)
+_LIB_PATH = os.environ.get("BQHIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libbqhip.so")
 
 if not os.path.exists(_LIB_PATH):
     raise ImportError(

@@ -23,8 +23,16 @@ namespace bq {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// rows per partial: 1024, or 4096 once that still leaves >= 256 chunks (fewer partials to fold)
-__host__ __device__ inline int bn_chunk_rows(long R) { return R >= (1L << 20) ? 4096 : 1024; }
+// rows per partial (measurement macros).  Round 5: 4096 / 1024 left the detector's large reductions with 512 workgroups -- eight
+// waves per CU for a streaming kernel; c2 step, two runs each: 4096 / 1024 9.57 ms, 2048 / 512 9.16, 1024 / 512 9.19, 1024 / 256
+// 9.07, 1024 / 128 9.06, 512 / 256 9.14-9.26, 512 / 128 9.14, 256 / 128 9.27 (more partials to fold)
+#ifndef BQ_BN_CHUNK_BIG
+#define BQ_BN_CHUNK_BIG 1024
+#endif
+#ifndef BQ_BN_CHUNK_SMALL
+#define BQ_BN_CHUNK_SMALL 256
+#endif
+__host__ __device__ inline int bn_chunk_rows(long R) { return R >= (1L << 20) ? BQ_BN_CHUNK_BIG : BQ_BN_CHUNK_SMALL; }
 
 // thread = 8 adjacent channels; TPR = C / 8 threads per row, 256 / TPR rows per sweep
 __global__ __launch_bounds__(256) void bn_stats_kernel(const __bf16 *__restrict__ x, float *__restrict__ partial,

@@ -19,6 +19,10 @@
 
 #include "gemm_common.h"
 
+#ifndef BQ_SA_PREFER_TWO
+#define BQ_SA_PREFER_TWO 1
+#endif
+
 namespace bq {
 
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
@@ -46,7 +50,9 @@ struct SaBwdCfg {
   // stages fit; with two stages they are loaded into registers instead (GREG: the loads of tile t + 1 are issued after the
   // transform of tile t has consumed the registers) and the stage is the images alone
   static constexpr int STAGE3 = UNITS * 8192 + (POOL ? 8192 : 0);
-  static constexpr int NS = 3 * STAGE3 + WB <= 160 * 1024 ? 3 : 2;
+  // (BQ_SA_PREFER_TWO: two stages wherever that lets two workgroups share a CU's LDS -- measurement macro)
+  static constexpr bool TWO = BQ_SA_PREFER_TWO && 2 * UNITS * 8192 + WB <= 80 * 1024 && 3 * STAGE3 + WB > 80 * 1024;
+  static constexpr int NS = (3 * STAGE3 + WB <= 160 * 1024 && !TWO) ? 3 : 2;
   static constexpr bool GREG = POOL && NS == 2;
   static constexpr int STAGE = NS == 3 ? STAGE3 : UNITS * 8192;
   static constexpr int LDS = NS * STAGE + WB;
@@ -371,7 +377,8 @@ static int launch_sa_bwd_pd(bool pool, bool dx, int wgs, hipStream_t st, const S
 
 static int sa_bwd_lds(int ti, int tj, bool pool, bool dx) {
   const int units = ti + tj * (pool ? 1 : 2), stage3 = units * 8192 + (pool ? 8192 : 0), wb = dx ? ti * tj * 8192 : 0;
-  return 3 * stage3 + wb <= 160 * 1024 ? 3 * stage3 + wb : 2 * units * 8192 + wb;
+  const bool two = BQ_SA_PREFER_TWO && 2 * units * 8192 + wb <= 80 * 1024 && 3 * stage3 + wb > 80 * 1024;
+  return (3 * stage3 + wb <= 160 * 1024 && !two) ? 3 * stage3 + wb : 2 * units * 8192 + wb;
 }
 
 }  // namespace bq

@@ -1611,7 +1611,10 @@ extern "C" int bq_pwconv_records(long R, int N) {
   // row walkers per 64-channel block: enough workgroups to fill the chip three times over, never more than the tiles
   const long tiles_j = (R + 63) / 64;
   const int tiles_i = (N + 63) / 64;
-  long gj = (256 * 2 + tiles_i - 1) / tiles_i;
+#ifndef BQ_PWCONV_WALKERS
+#define BQ_PWCONV_WALKERS 1024   // (c2 step, two runs each: 512 9.04 ms, 768 8.93, 1024 8.89)
+#endif
+  long gj = (BQ_PWCONV_WALKERS + tiles_i - 1) / tiles_i;
   if (gj > tiles_j) gj = tiles_j;
   if (gj < 1) gj = 1;
   return (int)gj * 2;

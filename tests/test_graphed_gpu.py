@@ -66,7 +66,7 @@ def test_gradients_behind_the_plain_loop_equal_the_eager_loop(dev):
         want, want_loss = _grads_once(dev, "eager")
         for mode in ("eager", "graphed", "wrapped"):   # ("eager": a second eager execution -- the run-to-run control)
             got, got_loss = _grads_once(dev, mode)
-            assert abs(got_loss - want_loss) <= 1e-6 * abs(want_loss), (mode, got_loss, want_loss)
+            assert abs(got_loss - want_loss) <= 1e-5 * abs(want_loss), (mode, got_loss, want_loss)
             assert set(got) == set(want), mode
 
             def err(n, x):   # (a key bias' gradient is exactly zero in exact arithmetic: compared on the value bias' scale)

@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_modules_gpu.py tests/test_configs_gpu.py -q -x 2>&1 | tail -3
+for rep in 1 2; do
+  timeout 600 python bench.py --workload c2 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | grep -o "\"ms_per_step\": [0-9.]*"
+done
+timeout 900 python bench.py --steps 30 --warmup 5 --no-loop-reference --no-cpu-baseline 2>/dev/null | grep -o "\"ms_per_step\": [0-9.]*"
+BENCH_ARGS="--workload c2" bash tools/run_step_profile.sh r5c24/c2 > /dev/null 2>&1

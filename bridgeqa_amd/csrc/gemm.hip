@@ -1019,6 +1019,164 @@ __global__ __launch_bounds__(256) void pwconv64_kernel(const PwconvArgs a) {
     }
 }
 
+// pwconv64s_kernel (round 5): MODE 0 of the kernel above as a STREAM over the row tiles.  There every tile started with an empty
+// pipeline -- barrier, two DMA stages, a full memory latency before the first MFMA -- and fetched the 64-channel weight block
+// again; SA1's layers ran at 2.9 TB/s.  Here the weight block (NKT units of 64 x 64) is loaded once per workgroup and stays in
+// LDS, a stage is ALL of a tile's NKT x units, and stages run NS - 1 tiles ahead across tile boundaries: one counted wait and
+// one barrier per tile, the y stores of a tile retire under the next tiles' loads (buffer stores, dropped past the end, so that
+// every wave issues the same number of vector-memory operations per tile: the counted waits below rely on it).  Same tile walk
+// (gj, gj + Gj, ...), same statistics records, same results as the kernel above.
+template <int NKT>
+struct PwsCfg {
+  static constexpr int NS = NKT <= 2 ? 3 : 2;
+  static constexpr int STAGE = NKT * 8192, WB = NKT * 8192, LDS = WB + NS * STAGE;
+  static constexpr int NDMA = 2 * NKT, NST = 4;
+  static constexpr int WAITN = (NS - 2) * (NDMA + NST) + NST;
+};
+
+template <int NKT>
+__global__ __launch_bounds__(256) void pwconv64s_kernel(const PwconvArgs a) {
+  using C = PwsCfg<NKT>;
+  constexpr int NS = C::NS, STAGE = C::STAGE;
+  static_assert(C::LDS <= 160 * 1024 && C::WAITN <= 63, "LDS / counted waits");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS];
+  unsigned char *const wimg = smem, *const stages = smem + C::WB;
+  const unsigned DEAD = 0x80000000u;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int bi = blockIdx.x % a.tiles_i, gj = blockIdx.x / a.tiles_i;
+  const int i0 = bi * 64;
+  const int tiles_j = (a.R + 63) >> 6;
+  const int ntile = gj < tiles_j ? (tiles_j - 1 - gj) / a.Gj + 1 : 0;   // tiles gj, gj + Gj, ...
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void *)a.W, 0, a.w_bytes, 0x00020000);
+  const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void *)a.X, 0, a.x_bytes, 0x00020000);
+  const auto rsY = __builtin_amdgcn_make_buffer_rsrc((void *)a.Y, 0, (unsigned)((long)a.R * a.Ni * 2), 0x00020000);
+  const int cp = lane & 7;
+  const int row16 = lane & 15, q4 = lane >> 4;
+  const int kc_base = row16 * 128 + ((q4 ^ (row16 & 7)) << 4);
+  const int xc_dummy[4] = {0, 0, 0, 0};
+  const int iw = i0 + wr * 32;
+
+  unsigned vq[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const int ur = (wave * 2 + d) * 8 + (lane >> 3);
+    const unsigned wo = (unsigned)(((i0 + ur) * a.ldw + (cp ^ (ur & 7)) * 8) * 2);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)   // the weight block: K-contiguous units, once
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_t *)(wimg + kt * 8192 + (wave * 2 + d) * 1024), 16, wo + kt * 128u, 0,
+                                               0, 0);
+    vq[d] = (unsigned)(((long)(gj * 64 + ur) * a.ldx + (cp ^ (ur & 7)) * 8) * 2);
+  }
+  const unsigned x_step = (unsigned)((long)a.Gj * 64 * a.ldx * 2);
+  auto stage = [&](int t) {
+    const bool live = t < ntile;
+    unsigned char *base = stages + (t % NS) * STAGE;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_t *)(base + kt * 8192 + (wave * 2 + d) * 1024), 16,
+                                                 live ? vq[d] + kt * 128u : DEAD, 0, 0, 0);
+      vq[d] += x_step;
+    }
+  };
+
+  float piv[2][4], s1[2][4], s2[2][4];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { piv[x][r] = 0.f; s1[x][r] = 0.f; s2[x][r] = 0.f; }
+  bool have_pivot = false;
+  float ctr[2][4];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ctr[x][r] = a.center ? a.center[iw + x * 16 + q4 * 4 + r] : 0.f;
+
+#pragma unroll
+  for (int p = 0; p < NS - 1; ++p) stage(p);
+  for (int t = 0; t < ntile; ++t) {
+    // behind this tile's DMAs lie (NS - 2) later stages and the y stores of the tiles in between (none in the first two trips)
+    if (t < 2) wait_vmcnt<(NS - 2) * C::NDMA>();
+    else wait_vmcnt<C::WAITN>();
+    BQ_BARRIER();
+    stage(t + NS - 1);
+    const unsigned char *buf = stages + (t % NS) * STAGE;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[x][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      bf16x8 fa[2][2], fb[2][2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fa[x][kk] = read_frag<false>(wimg + kt * 8192, wr * 2 + x, kk, kc_base, xc_dummy);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fb[b][kk] = read_frag<false>(buf + kt * 8192, wc * 2 + b, kk, kc_base, xc_dummy);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[x][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[x][kk], fb[b][kk], acc[x][b], 0, 0, 0);
+    }
+    // ---- epilogue: y (bf16) and the statistics of the fp32 values ---------------------------------------------------
+    const int jw = (gj + t * a.Gj) * 64 + wc * 32;
+    if (!have_pivot) {
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) piv[x][r] = __shfl(acc[x][0][r], lane & 48);
+      have_pivot = true;
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const int i = iw + x * 16 + q4 * 4;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int j = jw + b * 16 + row16;
+        const bool ok = j < a.R;
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        u32x2_t pk;
+        pk[0] = pack_bf16x2(acc[x][b][0] - ctr[x][0], acc[x][b][1] - ctr[x][1]);
+        pk[1] = pack_bf16x2(acc[x][b][2] - ctr[x][2], acc[x][b][3] - ctr[x][3]);
+        __builtin_amdgcn_raw_buffer_store_b64(pk, rsY, ok ? (unsigned)(((long)j * a.Ni + i) * 2) : DEAD, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = ok ? acc[x][b][r] - piv[x][r] : 0.f;
+          s1[x][r] += d;
+          s2[x][r] += d * d;
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float *rec = a.partial + (long)(gj * 2 + wc) * 3 * a.Ni;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float u = s1[x][r], v = s2[x][r];
+      u += dpp_f32_add<0x111>(u); u += dpp_f32_add<0x112>(u); u += dpp_f32_add<0x114>(u); u += dpp_f32_add<0x118>(u);
+      v += dpp_f32_add<0x111>(v); v += dpp_f32_add<0x112>(v); v += dpp_f32_add<0x114>(v); v += dpp_f32_add<0x118>(v);
+      if (row16 == 15) {
+        const int i = iw + x * 16 + q4 * 4 + r;
+        rec[i] = piv[x][r];
+        rec[a.Ni + i] = u;
+        rec[2 * a.Ni + i] = v;
+      }
+    }
+}
+
 // rows a (row walker gj, wave column wc) record covers: tiles gj, gj+Gj, ...; rows [64 t + 32 wc, +32) below R
 __device__ __forceinline__ long pwconv_record_rows(int rec, int Gj, long R) {
   const int gj = rec >> 1, wc = rec & 1;
@@ -1642,7 +1800,17 @@ extern "C" int bq_pwconv_bn_fwd(const void *x, long R, int K, int ldx, const voi
   a.w_bytes = (unsigned)((long)N * ldw * 2);
   a.x_bytes = (unsigned)(R * (long)ldx * 2);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(pwconv64_kernel<0>, dim3(a.tiles_i * a.Gj), dim3(256), 0, st, a);
+#ifndef BQ_PWCONV_STREAM
+#define BQ_PWCONV_STREAM 1
+#endif
+  const int nkt = Kc / 64;
+  const dim3 grid(a.tiles_i * a.Gj);
+  if (BQ_PWCONV_STREAM && nkt == 1) hipLaunchKernelGGL(pwconv64s_kernel<1>, grid, dim3(256), 0, st, a);
+  else if (BQ_PWCONV_STREAM && nkt == 2) hipLaunchKernelGGL(pwconv64s_kernel<2>, grid, dim3(256), 0, st, a);
+  else if (BQ_PWCONV_STREAM && nkt == 3) hipLaunchKernelGGL(pwconv64s_kernel<3>, grid, dim3(256), 0, st, a);
+  else if (BQ_PWCONV_STREAM && nkt == 4) hipLaunchKernelGGL(pwconv64s_kernel<4>, grid, dim3(256), 0, st, a);
+  else if (BQ_PWCONV_STREAM && nkt == 5) hipLaunchKernelGGL(pwconv64s_kernel<5>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(pwconv64_kernel<0>, grid, dim3(256), 0, st, a);
   PwconvBnParams p{partial, gamma, beta, running_mean, running_var, num_batches_tracked, scale, shift, mean, rstd,
                    eps, momentum, N, a.Gj * 2, a.Gj, R, center, shift_acc};
   hipLaunchKernelGGL(pwconv_bn_finalize_kernel, dim3((N + PWF_CH - 1) / PWF_CH), dim3(1024), 0, st, p);

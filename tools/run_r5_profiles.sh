@@ -12,8 +12,13 @@ bash tools/run_attn_pmc.sh $OUT/attn > /dev/null 2>&1
 cp gpurun_out/$OUT/attn/attn_pmc_summary.txt profiles/r05_attn_pmc.txt
 bash tools/run_ballquery_pmc.sh $OUT/bq > gpurun_out/$OUT/bq.log 2>&1
 cp gpurun_out/$OUT/bq/ballquery_pmc.json profiles/r05_ballquery_pmc.json
+bash tools/run_det_bwd_pmc.sh $OUT/detbwd > gpurun_out/$OUT/detbwd.log 2>&1
+cp gpurun_out/$OUT/detbwd/det_bwd_pmc_summary.txt profiles/r05_det_bwd_pmc.txt
 bash tools/run_step_profile.sh $OUT/step > gpurun_out/$OUT/step_profile.log 2>&1
 cp gpurun_out/$OUT/step/kernel_stats.csv profiles/r05_c3_kernel_stats.csv
+cp gpurun_out/$OUT/step/one_step_trace.csv profiles/r05_c3_one_step_trace.csv
+BENCH_ARGS="--workload c2" bash tools/run_step_profile.sh $OUT/c2step > gpurun_out/$OUT/c2step_profile.log 2>&1
+cp gpurun_out/$OUT/c2step/kernel_stats.csv profiles/r05_c2_kernel_stats.csv
 BQ_PIPE_TRACE=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2> gpurun_out/$OUT/phases.err > /dev/null; grep -E "GPU ms|host ms" gpurun_out/$OUT/phases.err > gpurun_out/$OUT/c3_phases.txt
 python bench.py --steps 20 --warmup 5 > gpurun_out/$OUT/bench_c3.json 2> gpurun_out/$OUT/bench_c3.err; head -c 200 gpurun_out/$OUT/bench_c3.json; echo
 python bench.py --workload c2 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/$OUT/bench_c2.json 2> gpurun_out/$OUT/bench_c2.err; head -c 200 gpurun_out/$OUT/bench_c2.json; echo

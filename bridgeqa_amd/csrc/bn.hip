@@ -125,14 +125,32 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
   if (c == 0 && p.num_batches_tracked) p.num_batches_tracked[0] += 1;
 }
 
-// W-column fold of generic partials (backward: W = 2C -> dbeta | dgamma)
+// W-column fold of generic partials (backward: W = 2C -> dbeta | dgamma): 16 columns x 16 chunk phases per workgroup, 8 loads in
+// flight per thread, the phases summed in a fixed order (round 5: 64 columns x 4 phases left a thread 512 dependent-batch loads
+// of the 2048 partials the finer reduction chunks produce -- 10 us per layer)
+constexpr int FOLD_COLS = 16;
 __global__ __launch_bounds__(256) void bn_fold_kernel(const float *__restrict__ partial, float *__restrict__ out,
                                                       int chunks, int W) {
-  __shared__ float s[4][64];
-  const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + cl;
-  const float v = fold_column(partial, chunks, W, min(j, W - 1), ph, s, cl);
-  if (ph == 0 && j < W) out[j] = v;
+  __shared__ float s[16][FOLD_COLS];
+  const int cl = threadIdx.x & (FOLD_COLS - 1), ph = threadIdx.x / FOLD_COLS;
+  const int j = blockIdx.x * FOLD_COLS + cl, jj = min(j, W - 1);
+  float t[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) t[u] = 0.f;
+  int y = ph;
+  for (; y + 16 * 7 < chunks; y += 16 * 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] += partial[(long)(y + 16 * u) * W + jj];
+  }
+  for (; y < chunks; y += 16) t[0] += partial[(long)y * W + jj];
+  s[ph][cl] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+  __syncthreads();
+  if (ph == 0 && j < W) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += s[q][cl];
+    out[j] = v;
+  }
 }
 
 // y = relu?(x*scale + shift); POOL: out[g][c] = max over the S rows of group g (relu applied: max >= 0 when RELU)
@@ -393,7 +411,7 @@ extern "C" __attribute__((visibility("default"))) int bq_bn_apply(const void *x,
 
 // out[j] = sum over the chunks of partial[chunk][j], j < W, in chunk order (library-internal: csrc/detbwd.hip)
 extern "C" int bq_bn_fold(const float *partial, float *out, int chunks, int W, void *stream) {
-  hipLaunchKernelGGL(bn_fold_kernel, dim3((W + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, out, chunks, W);
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((W + FOLD_COLS - 1) / FOLD_COLS), dim3(256), 0, (hipStream_t)stream, partial, out, chunks, W);
   return check_launch("bn_fold");
 }
 
@@ -435,7 +453,7 @@ extern "C" __attribute__((visibility("default"))) int bq_bn_backward(const void 
   if (relu) { if (pool) BQ_BN_RED(true, true); else BQ_BN_RED(true, false); }
   else      { if (pool) BQ_BN_RED(false, true); else BQ_BN_RED(false, false); }
 #undef BQ_BN_RED
-  hipLaunchKernelGGL(bn_fold_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, st, partial, dgb, chunks, 2 * C);
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((2 * C + FOLD_COLS - 1) / FOLD_COLS), dim3(256), 0, st, partial, dgb, chunks, 2 * C);
   const long rows = pool ? R / S : R, threads = rows * (C >> 3);
   const dim3 grid((unsigned)((threads + 255) / 256));
 #define BQ_BN_DX(RL, PL) hipLaunchKernelGGL((bn_bwd_dx_kernel<RL, PL>), grid, dim3(256), 0, st, (const __bf16 *)dy,   \

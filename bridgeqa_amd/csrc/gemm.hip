@@ -1223,10 +1223,10 @@ __global__ __launch_bounds__(1024) void pwconv_bn_finalize_kernel(const PwconvBn
   const int cl = threadIdx.x & (PWF_CH - 1), ph = threadIdx.x / PWF_CH;
   const int c = min(blockIdx.x * PWF_CH + cl, p.C - 1);
   float n = 0.f, mean = 0.f, m2 = 0.f;
-  for (int g0 = ph; g0 < p.nrec; g0 += 4 * PWF_PH) {
-    float pv[4], su[4], sq[4], ng[4];
+  for (int g0 = ph; g0 < p.nrec; g0 += 8 * PWF_PH) {
+    float pv[8], su[8], sq[8], ng[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {  // four records in flight per thread
+    for (int u = 0; u < 8; ++u) {  // eight records in flight per thread
       const int g = g0 + PWF_PH * u;
       const bool live = g < p.nrec;
       const float *rec = p.partial + (long)(live ? g : 0) * 3 * p.C;
@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(1024) void pwconv_bn_finalize_kernel(const PwconvBn
       ng[u] = live ? (float)pwconv_record_rows(g, p.Gj, p.R) : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const float inv = ng[u] > 0.f ? 1.0f / ng[u] : 0.f;
       chan_merge(n, mean, m2, ng[u], pv[u] + su[u] * inv, fmaxf(sq[u] - su[u] * su[u] * inv, 0.f));
     }

@@ -13,9 +13,10 @@ sys.argv = ["bench.py"]
 args = bench.parse()
 args.cin = 132
 torch.manual_seed(0)
-model = bench.build_model("c3", 132, args.image).to(dev)
+WL = os.environ.get("WHO_WORKLOAD", "c3")   # c2: the detector stage alone
+model = bench.build_model(WL, 132, args.image).to(dev)
 model.train()
-batch = bench.make_batch(args, "c3", 16, 42, dev)
+batch = bench.make_batch(args, WL, 16, 42, dev)
 params = [p for p in model.parameters()]
 
 

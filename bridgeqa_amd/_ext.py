@@ -1101,7 +1101,7 @@ _lib.bq_pwconv_bn_fwd.restype = ctypes.c_int
 
 
 def pwconv_bn_relu_fwd(x, K, w_pad, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, S, relu,
-                       pool, center=None, want_arg=False):
+                       pool, center=None, want_arg=False, x_stats=None, defer_apply=False):
     """x: bf16 rows (R, ldx) view with contiguous elements (ldx = x.stride(0) >= K, the first K of a row are the input
     channels); w_pad: bf16 (N, Kc) contiguous, zero beyond K, Kc % 64 == 0.  y_raw = x @ w^T (bf16 (R, N)), its
     training-mode BatchNorm statistics from the fp32 accumulators (running buffers updated in place), then
@@ -1109,7 +1109,10 @@ def pwconv_bn_relu_fwd(x, K, w_pad, gamma, beta, running_mean, running_var, num_
     center (f32 (N,), e.g. running_mean itself): y_raw holds x @ w^T - center and stats describe the stored values (same
     `out`; the bf16 rounding of y_raw then applies to the deviation from the channel mean -- bq_pwconv_bn_fwd).
     Returns out, y_raw, stats (f32 (4, N): scale, shift, mean, rstd); with want_arg (pooled layers) a fourth value: u8
-    (R // S, N), the row of each group's first maximum (None where the fp32-accumulator apply pass produced the output)."""
+    (R // S, N), the row of each group's first maximum (None where the fp32-accumulator apply pass produced the output).
+    Deferred activations between the layers of a SharedMLP (bq_pwconv_bn_fwd_x): x_stats = the previous layer's stats when x
+    is that layer's y_raw (the input is then relu(x * x_stats[0] + x_stats[1]), applied tile by tile inside the kernel);
+    defer_apply: skip this layer's own BatchNorm + ReLU pass -- out is None and the next layer reads y_raw."""
     if not x.is_cuda:
         raise RuntimeError("x: CPU not supported")
     R, N, Kc = x.shape[0], w_pad.shape[0], w_pad.shape[1]
@@ -1118,10 +1121,14 @@ def pwconv_bn_relu_fwd(x, K, w_pad, gamma, beta, running_mean, running_var, num_
         y_raw = torch.empty(R, N, dtype=torch.bfloat16, device=x.device)
         stats = torch.empty(5, N, dtype=torch.float32, device=x.device)   # scale, shift, mean, rstd (of the stored y) | shift_acc
         part = torch.empty(_lib.bq_pwconv_records(R, N) * 3 * N, dtype=torch.float32, device=x.device)
-        _check(_lib.bq_pwconv_bn_fwd(_p(x), R, int(K), x.stride(0), _p(w_pad), w_pad.stride(0), Kc, N, _p(y_raw), _p(part),
-                                     _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(num_batches_tracked),
-                                     float(eps), float(momentum), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]),
-                                     _p(center), _p(stats[4]), _stream()), "pwconv_bn_fwd")
+        _check(_lib.bq_pwconv_bn_fwd_x(_p(x), _p(x_stats[0]) if x_stats is not None else None,
+                                       _p(x_stats[1]) if x_stats is not None else None, R, int(K), x.stride(0), _p(w_pad),
+                                       w_pad.stride(0), Kc, N, _p(y_raw), _p(part), _p(gamma), _p(beta), _p(running_mean),
+                                       _p(running_var), _p(num_batches_tracked), float(eps), float(momentum), _p(stats[0]),
+                                       _p(stats[1]), _p(stats[2]), _p(stats[3]), _p(center), _p(stats[4]), _stream()),
+               "pwconv_bn_fwd")
+        if defer_apply:
+            return (None, y_raw, stats, None) if want_arg else (None, y_raw, stats)
         out = torch.empty(R // S if pool else R, N, dtype=torch.bfloat16, device=x.device)
         if FP32_PREACT[0] and (not pool or (int(S) in (16, 32, 64) and R % int(S) == 0)):
             # BatchNorm + ReLU (+ max-pool) on the fp32 accumulators of the product computed once more: the output never
@@ -1150,8 +1157,26 @@ _lib.bq_sa_bwd_workgroups.argtypes = [_l, _i, _i, _i, _i]
 _lib.bq_sa_bwd_workgroups.restype = ctypes.c_int
 _lib.bq_sa_bwd_fused.argtypes = [_vp] * 13 + [_l, _i, _i, _i, _i, _i, _i, _i, _vp]
 _lib.bq_sa_bwd_fused.restype = ctypes.c_int
+_lib.bq_sa_bwd_fused_x.argtypes = [_vp] * 15 + [_l, _i, _i, _i, _i, _i, _i, _i, _vp]
+_lib.bq_sa_bwd_fused_x.restype = ctypes.c_int
+_lib.bq_pwconv_bn_fwd_x.argtypes = [_vp, _vp, _vp, _l, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp,
+                                    _vp, _vp, _vp, _vp, _vp]
+_lib.bq_pwconv_bn_fwd_x.restype = ctypes.c_int
+# SharedMLP layers hand their stored pre-activation to the next layer, which applies BatchNorm + ReLU on load (no bn_apply pass,
+# no activation tensor between two convolutions); off / BQ_DEFER_BN=0: every layer writes its activation
+DEFER_BN = [os.environ.get("BQ_DEFER_BN", "1") != "0"]
 # SharedMLP backward as reduction + one fused pass (off, or BQ_FUSED_SA_BWD=0 for A/B runs: bn_relu_bwd + dX GEMM + wgrad_rows)
 FUSED_SA_BWD = [os.environ.get("BQ_FUSED_SA_BWD", "1") != "0"]
+
+
+def bn_apply(y_raw, stats, S, relu, pool):
+    """relu?(y_raw * stats[0] + stats[1]) as bf16 (R, N), or the max over runs of S rows (R // S, N) when pool"""
+    R, N = y_raw.shape
+    with torch.cuda.device(y_raw.device):
+        out = torch.empty(R // S if pool else R, N, dtype=torch.bfloat16, device=y_raw.device)
+        _check(_lib.bq_bn_apply(_p(y_raw), _p(stats[0]), _p(stats[1]), _p(out), R, N, int(S), int(bool(relu)),
+                                int(bool(pool)), _stream()), "bn_apply")
+    return out
 
 
 def sa_bwd_supported(ldx, N, S, pool, need_dx):
@@ -1175,9 +1200,10 @@ def bn_bwd_reduce(dy, x, stats, S, relu, pool, arg=None):
     return dgb
 
 
-def sa_bwd_fused(x, y_raw, dout, arg, w_pad, stats, dgb, S, relu, pool, need_dx):
+def sa_bwd_fused(x, y_raw, dout, arg, w_pad, stats, dgb, S, relu, pool, need_dx, x_stats=None):
     """x bf16 (R, ldx) whole padded rows, y_raw bf16 (R, N), dout bf16 (R, N) | (R // S, N) with arg u8 when pool, w_pad bf16
-    (N, Kc), stats f32 (>= 4, N), dgb f32 (2, N) -> dx bf16 (R, ldx) | None, dw f32 (N, ldx)"""
+    (N, Kc), stats f32 (>= 4, N), dgb f32 (2, N) -> dx bf16 (R, ldx) | None, dw f32 (N, ldx).  x_stats: x is the previous
+    layer's stored pre-activation and the layer's input relu(x * x_stats[0] + x_stats[1]) (bq_sa_bwd_fused_x; dx required)"""
     R, ldx = x.shape[0], x.stride(0)
     N = y_raw.shape[1]
     with torch.cuda.device(x.device):
@@ -1185,9 +1211,11 @@ def sa_bwd_fused(x, y_raw, dout, arg, w_pad, stats, dgb, S, relu, pool, need_dx)
         dw = torch.empty(N, ldx, dtype=torch.float32, device=x.device)
         wgs = _lib.bq_sa_bwd_workgroups(R, ldx, N, int(bool(pool)), int(bool(need_dx)))
         part = torch.empty(wgs * N * ldx, dtype=torch.float32, device=x.device)
-        _check(_lib.bq_sa_bwd_fused(_p(x), _p(y_raw), _p(dout), _p(arg), _p(w_pad), _p(stats[0]), _p(stats[1]), _p(stats[2]),
-                                    _p(stats[3]), _p(dgb), _p(dx), _p(dw), _p(part), R, ldx, N, w_pad.stride(0), ldx, int(S),
-                                    int(bool(relu)), int(bool(pool)), _stream()), "sa_bwd_fused")
+        _check(_lib.bq_sa_bwd_fused_x(_p(x), _p(x_stats[0]) if x_stats is not None else None,
+                                      _p(x_stats[1]) if x_stats is not None else None, _p(y_raw), _p(dout), _p(arg), _p(w_pad),
+                                      _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), _p(dgb), _p(dx), _p(dw), _p(part),
+                                      R, ldx, N, w_pad.stride(0), ldx, int(S), int(bool(relu)), int(bool(pool)), _stream()),
+               "sa_bwd_fused")
     return dx, dw
 
 

@@ -36,6 +36,7 @@ struct SaBwdArgs {
   const __bf16 *W;       // [Nj][ldw] zero beyond the input channels
   const float *scale, *shift, *mean, *rstd;   // of the STORED pre-activation
   const float *dgb;      // [2][Nj] dbeta | dgamma
+  const float *xscale, *xshift;   // XT: X holds the previous layer's stored pre-activation; the layer's input is relu(X xscale + xshift)
   __bf16 *dX;            // [R][ldx] or null
   float *part;           // [workgroups][Nj][ldo]
   int R, ldx, Nj, ldw, ldo, S, relu;
@@ -62,7 +63,7 @@ struct SaBwdCfg {
   static constexpr int WAITN = (NS - 2) * (NDMA + NST) + NST;
 };
 
-template <int TI, int TJ, bool POOL, bool DX>
+template <int TI, int TJ, bool POOL, bool DX, bool XT = false>
 __global__ __launch_bounds__(256) void sa_bwd_kernel(const SaBwdArgs ar) {
   using C = SaBwdCfg<TI, TJ, POOL, DX>;
   constexpr int STAGE = C::STAGE, NS = C::NS, WB = C::WB;
@@ -179,6 +180,20 @@ __global__ __launch_bounds__(256) void sa_bwd_kernel(const SaBwdArgs ar) {
       }
   }
 
+  // XT: the layer's input was never stored -- the x tile is the previous layer's pre-activation and becomes
+  // relu(x xscale + xshift) in place, wave by wave on its own rows, like dP
+  [[maybe_unused]] float x_sc[XT ? TI : 1][8], x_sh[XT ? TI : 1][8];
+  if constexpr (XT) {
+#pragma unroll
+    for (int u = 0; u < TI; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = u * 64 + cp * 8 + i;
+        x_sc[u][i] = c < ar.ldx ? ar.xscale[c] : 0.f;
+        x_sh[u][i] = c < ar.ldx ? ar.xshift[c] : 0.f;
+      }
+  }
+
   const int row16 = lane & 15, q4 = lane >> 4;
   const int xc_q = (lane & 15) >> 2;
   const int xcg = (xc_q >> 1) | ((q4 & 1) << 1), xc0 = (8 * q4 + xc_q) * 128 + 8 * (lane & 3);
@@ -241,6 +256,22 @@ __global__ __launch_bounds__(256) void sa_bwd_kernel(const SaBwdArgs ar) {
           *reinterpret_cast<bf16x8 *>(pp) = o;
         }
       }
+    }
+    if constexpr (XT) {
+#pragma unroll
+      for (int u = 0; u < TI; ++u)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const int row = wave * 16 + (lane >> 3) + 8 * d;
+          const int pos = cp ^ ((((lane >> 4) & 1) | (d << 1)) << 1);
+          unsigned char *pp = buf + u * 8192 + row * 128 + pos * 16;
+          const bf16x8 v = *reinterpret_cast<const bf16x8 *>(pp);
+          const bool inside = (long)(kt0 + step) * 64 + row < ar.R;   // rows past the end stay 0: their dP is not
+          bf16x8 o;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = (__bf16)(inside ? fmaxf((float)v[i] * x_sc[u][i] + x_sh[u][i], 0.0f) : 0.0f);
+          *reinterpret_cast<bf16x8 *>(pp) = o;
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     BQ_BARRIER();   // every wave's X rows have landed and its dP rows are written; the previous tile's reads are done
@@ -360,10 +391,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_arg_kernel(const __bf16 *__
   }
 }
 
-template <int TI, int TJ, bool POOL, bool DX>
+template <int TI, int TJ, bool POOL, bool DX, bool XT = false>
 static int launch_sa_bwd(int wgs, hipStream_t st, const SaBwdArgs &a) {
   if constexpr (SaBwdCfg<TI, TJ, POOL, DX>::FITS) {
-    hipLaunchKernelGGL((sa_bwd_kernel<TI, TJ, POOL, DX>), dim3(wgs), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((sa_bwd_kernel<TI, TJ, POOL, DX, XT>), dim3(wgs), dim3(256), 0, st, a);
     return 0;
   }
   return -1;
@@ -371,6 +402,10 @@ static int launch_sa_bwd(int wgs, hipStream_t st, const SaBwdArgs &a) {
 
 template <int TI, int TJ>
 static int launch_sa_bwd_pd(bool pool, bool dx, int wgs, hipStream_t st, const SaBwdArgs &a) {
+  if (a.xscale) {   // a deferred input always wants its gradient, and is 64 or 128 channels wide
+    if constexpr (TI <= 2) return pool ? launch_sa_bwd<TI, TJ, true, true, true>(wgs, st, a) : launch_sa_bwd<TI, TJ, false, true, true>(wgs, st, a);
+    return -1;
+  }
   if (pool) return dx ? launch_sa_bwd<TI, TJ, true, true>(wgs, st, a) : launch_sa_bwd<TI, TJ, true, false>(wgs, st, a);
   return dx ? launch_sa_bwd<TI, TJ, false, true>(wgs, st, a) : launch_sa_bwd<TI, TJ, false, false>(wgs, st, a);
 }
@@ -404,11 +439,24 @@ extern "C" int bq_sa_bwd_workgroups(long R, int ldx, int Nj, int pool, int need_
 // dW f32 (Nj, ldo) from x (R, ldx), the stored pre-activation p (R, Nj), dOut ((R, Nj), or (R / S, Nj) + arg when pooled),
 // w bf16 (Nj, ldw).  part: bq_sa_bwd_workgroups(...) * Nj * ldo floats.
 extern "C" int bq_sa_bwd_fused(const void *x, const void *p, const void *dout,
-                                                                      const void *arg, const void *w, const float *scale,
-                                                                      const float *shift, const float *mean, const float *rstd,
-                                                                      const float *dgb, void *dx, float *dw, float *part, long R,
-                                                                      int ldx, int Nj, int ldw, int ldo, int S, int relu, int pool,
-                                                                      void *stream) {
+                               const void *arg, const void *w, const float *scale,
+                               const float *shift, const float *mean, const float *rstd,
+                               const float *dgb, void *dx, float *dw, float *part, long R,
+                               int ldx, int Nj, int ldw, int ldo, int S, int relu, int pool,
+                               void *stream) {
+  return bq_sa_bwd_fused_x(x, nullptr, nullptr, p, dout, arg, w, scale, shift, mean, rstd, dgb, dx, dw, part, R, ldx, Nj, ldw, ldo,
+                           S, relu, pool, stream);
+}
+
+// the same with a DEFERRED input: x holds the previous layer's stored pre-activation (ldx = 64 or 128 channels, no padding)
+// and the layer's input is relu(x xscale + xshift), formed tile by tile in LDS (xscale == NULL: plain bq_sa_bwd_fused); dx is
+// then the gradient w.r.t. that activation and is required
+extern "C" int bq_sa_bwd_fused_x(const void *x, const float *xscale, const float *xshift, const void *p, const void *dout,
+                                 const void *arg, const void *w, const float *scale, const float *shift, const float *mean,
+                                 const float *rstd, const float *dgb, void *dx, float *dw, float *part, long R, int ldx, int Nj,
+                                 int ldw, int ldo, int S, int relu, int pool, void *stream) {
+  BQ_REQUIRE(!xscale || (xshift && dx && (ldx == 64 || ldx == 128)), BQ_EINVAL,
+             "bq_sa_bwd_fused_x: a deferred input needs xshift, dx and ldx = 64 or 128 (ldx=%d)", ldx);
   BQ_REQUIRE(x && p && dout && scale && shift && mean && rstd && dgb && dw && part && R > 0, BQ_EINVAL,
              "bq_sa_bwd_fused: null pointer / no rows");
   BQ_REQUIRE(bq_sa_bwd_supported(ldx, Nj, S, pool, dx != nullptr), BQ_EINVAL,
@@ -426,7 +474,7 @@ extern "C" int bq_sa_bwd_fused(const void *x, const void *p, const void *dout,
   SaBwdArgs a;
   a.X = (const __bf16 *)x; a.P = (const __bf16 *)p; a.dOut = (const __bf16 *)dout; a.arg = (const unsigned char *)arg;
   a.W = (const __bf16 *)w; a.scale = scale; a.shift = shift; a.mean = mean; a.rstd = rstd; a.dgb = dgb;
-  a.dX = (__bf16 *)dx; a.part = part;
+  a.dX = (__bf16 *)dx; a.part = part; a.xscale = xscale; a.xshift = xshift;
   a.R = (int)R; a.ldx = ldx; a.Nj = Nj; a.ldw = ldw; a.ldo = ldo; a.S = pool ? S : 1; a.relu = relu;
   a.x_bytes = (unsigned)(R * (long)ldx * 2);
   a.p_bytes = (unsigned)(R * (long)Nj * 2);

@@ -775,6 +775,9 @@ struct PwconvArgs {
   // MODE 1 / 2 (bq_pwconv_bn_apply): BatchNorm's affine map of the STORED values (v = (acc - center) scale + shift), ReLU
   const float *scale, *shift;
   int relu, S;
+  // pwconv64s_kernel<NKT, true>: X holds the PREVIOUS layer's stored pre-activation; relu(x xscale + xshift) is applied to
+  // every x tile as it arrives in LDS (the previous layer's BatchNorm + ReLU never materialised: bq_pwconv_bn_fwd_x)
+  const float *xscale, *xshift;
 };
 
 // MODE 0: y and its statistics (the first pass of a SharedMLP layer).  MODE 1 / 2 (round 5): the SAME
@@ -1034,7 +1037,7 @@ struct PwsCfg {
   static constexpr int WAITN = (NS - 2) * (NDMA + NST) + NST;
 };
 
-template <int NKT>
+template <int NKT, bool XT>
 __global__ __launch_bounds__(256) void pwconv64s_kernel(const PwconvArgs a) {
   using C = PwsCfg<NKT>;
   constexpr int NS = C::NS, STAGE = C::STAGE;
@@ -1096,12 +1099,41 @@ __global__ __launch_bounds__(256) void pwconv64s_kernel(const PwconvArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) ctr[x][r] = a.center ? a.center[iw + x * 16 + q4 * 4 + r] : 0.f;
 
+  // XT: this lane's 8 channels (logical 16-byte chunk lane & 7) of every K unit of the previous layer's BatchNorm map
+  [[maybe_unused]] float xs_c[XT ? NKT : 1][8], xh_c[XT ? NKT : 1][8];
+  if constexpr (XT) {
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        xs_c[kt][e] = a.xscale[kt * 64 + cp * 8 + e];
+        xh_c[kt][e] = a.xshift[kt * 64 + cp * 8 + e];
+      }
+  }
+
 #pragma unroll
   for (int p = 0; p < NS - 1; ++p) stage(p);
   for (int t = 0; t < ntile; ++t) {
     // behind this tile's DMAs lie (NS - 2) later stages and the y stores of the tiles in between (none in the first two trips)
     if (t < 2) wait_vmcnt<(NS - 2) * C::NDMA>();
     else wait_vmcnt<C::WAITN>();
+    if constexpr (XT) {
+      // every wave turns ITS OWN 16 rows of the x units (the rows its DMAs wrote) into relu(x xscale + xshift) in place
+      unsigned char *xb = stages + (t % NS) * STAGE;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const int row = wave * 16 + (lane >> 3) + 8 * d;
+          unsigned char *pp = xb + kt * 8192 + row * 128 + ((cp ^ ((lane >> 3) & 7)) << 4);
+          const bf16x8 v = *reinterpret_cast<const bf16x8 *>(pp);
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaxf((float)v[e] * xs_c[kt][e] + xh_c[kt][e], 0.0f);
+          *reinterpret_cast<bf16x8 *>(pp) = o;
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     BQ_BARRIER();
     stage(t + NS - 1);
     const unsigned char *buf = stages + (t % NS) * STAGE;
@@ -1783,6 +1815,15 @@ extern "C" int bq_pwconv_bn_fwd(const void *x, long R, int K, int ldx, const voi
                                 float *running_var, long long *num_batches_tracked, float eps, float momentum,
                                 float *scale, float *shift, float *mean, float *rstd, const float *center, float *shift_acc,
                                 void *stream) {
+  return bq_pwconv_bn_fwd_x(x, nullptr, nullptr, R, K, ldx, w, ldw, Kc, N, y, partial, gamma, beta, running_mean, running_var,
+                            num_batches_tracked, eps, momentum, scale, shift, mean, rstd, center, shift_acc, stream);
+}
+
+extern "C" int bq_pwconv_bn_fwd_x(const void *x, const float *xscale, const float *xshift, long R, int K, int ldx, const void *w,
+                                  int ldw, int Kc, int N, void *y, float *partial, const float *gamma, const float *beta,
+                                  float *running_mean, float *running_var, long long *num_batches_tracked, float eps,
+                                  float momentum, float *scale, float *shift, float *mean, float *rstd, const float *center,
+                                  float *shift_acc, void *stream) {
   using namespace bq;
   BQ_REQUIRE(x && w && y && partial && gamma && beta && scale && shift && mean && rstd, BQ_EINVAL, "pwconv_bn_fwd: null pointer");
   BQ_REQUIRE(R > 0 && K > 0 && N > 0, BQ_EINVAL, "pwconv_bn_fwd: empty problem");
@@ -1805,11 +1846,18 @@ extern "C" int bq_pwconv_bn_fwd(const void *x, long R, int K, int ldx, const voi
 #endif
   const int nkt = Kc / 64;
   const dim3 grid(a.tiles_i * a.Gj);
-  if (BQ_PWCONV_STREAM && nkt == 1) hipLaunchKernelGGL(pwconv64s_kernel<1>, grid, dim3(256), 0, st, a);
-  else if (BQ_PWCONV_STREAM && nkt == 2) hipLaunchKernelGGL(pwconv64s_kernel<2>, grid, dim3(256), 0, st, a);
-  else if (BQ_PWCONV_STREAM && nkt == 3) hipLaunchKernelGGL(pwconv64s_kernel<3>, grid, dim3(256), 0, st, a);
-  else if (BQ_PWCONV_STREAM && nkt == 4) hipLaunchKernelGGL(pwconv64s_kernel<4>, grid, dim3(256), 0, st, a);
-  else if (BQ_PWCONV_STREAM && nkt == 5) hipLaunchKernelGGL(pwconv64s_kernel<5>, grid, dim3(256), 0, st, a);
+  a.xscale = xscale; a.xshift = xshift;
+  if (xscale) {
+    BQ_REQUIRE(xshift && K == Kc && ldx == K && (nkt == 1 || nkt == 2), BQ_EINVAL,
+               "pwconv_bn_fwd_x: a deferred input needs K = ldx = 64 or 128 (K=%d ldx=%d)", K, ldx);
+    if (nkt == 1) hipLaunchKernelGGL((pwconv64s_kernel<1, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((pwconv64s_kernel<2, true>), grid, dim3(256), 0, st, a);
+  }
+  else if (BQ_PWCONV_STREAM && nkt == 1) hipLaunchKernelGGL((pwconv64s_kernel<1, false>), grid, dim3(256), 0, st, a);
+  else if (BQ_PWCONV_STREAM && nkt == 2) hipLaunchKernelGGL((pwconv64s_kernel<2, false>), grid, dim3(256), 0, st, a);
+  else if (BQ_PWCONV_STREAM && nkt == 3) hipLaunchKernelGGL((pwconv64s_kernel<3, false>), grid, dim3(256), 0, st, a);
+  else if (BQ_PWCONV_STREAM && nkt == 4) hipLaunchKernelGGL((pwconv64s_kernel<4, false>), grid, dim3(256), 0, st, a);
+  else if (BQ_PWCONV_STREAM && nkt == 5) hipLaunchKernelGGL((pwconv64s_kernel<5, false>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(pwconv64_kernel<0>, grid, dim3(256), 0, st, a);
   PwconvBnParams p{partial, gamma, beta, running_mean, running_var, num_batches_tracked, scale, shift, mean, rstd,
                    eps, momentum, N, a.Gj * 2, a.Gj, R, center, shift_acc};

@@ -100,7 +100,13 @@ class _ConvBNReLUPointMajor(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, conv_weight, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, relu,
-                pool, S, conv_bias=None):
+                pool, S, conv_bias=None, x_stats=None, defer=False):
+        """Deferred activations (round 5, SharedMLP.forward wires them): with `defer` the layer skips its BatchNorm + ReLU
+        pass and returns (its stored pre-activation, its stats) -- the NEXT layer, called with x = that pre-activation and
+        x_stats = those stats, applies relu(x scale + shift) tile by tile inside its convolution kernel and, in the backward,
+        inside the fused pass (csrc/gemm.hip pwconv64s_kernel<.., true>, csrc/detbwd.hip sa_bwd_kernel<.., XT>).  By
+        convention the gradient such a layer receives for its first output is the gradient w.r.t. the ACTIVATION (what the
+        next layer's fused backward computes as its dX), exactly what this backward expects as dout."""
         from . import _ext, fusion_ops
         K = conv_weight.shape[1]
         w_pad = fusion_ops.padded_conv_shadow(conv_weight)
@@ -113,22 +119,26 @@ class _ConvBNReLUPointMajor(torch.autograd.Function):
         out, y_raw, stats, arg = _ext.pwconv_bn_relu_fwd(x, K, w_pad, gamma, beta, running_mean, running_var,
                                                          num_batches_tracked, eps, momentum, S, relu, pool,
                                                          center=running_mean if CENTER_PREACT[0] else None,
-                                                         want_arg=True) if want_arg else (
+                                                         want_arg=True, x_stats=x_stats, defer_apply=defer) if want_arg else (
             _ext.pwconv_bn_relu_fwd(x, K, w_pad, gamma, beta, running_mean, running_var, num_batches_tracked, eps,
-                                    momentum, S, relu, pool, center=running_mean if CENTER_PREACT[0] else None) + (None,))
+                                    momentum, S, relu, pool, center=running_mean if CENTER_PREACT[0] else None,
+                                    x_stats=x_stats, defer_apply=defer) + (None,))
         if conv_bias is not None and running_mean is not None:
             # a convolution bias in front of a training-mode BatchNorm cancels in the normalised output (it shifts the
             # batch mean by itself) and its gradient is identically zero; the only trace it leaves is in running_mean
             running_mean.add_(conv_bias.detach(), alpha=float(momentum))
-        ctx.save_for_backward(x, w_pad, y_raw, stats, arg)
+        ctx.save_for_backward(x, w_pad, y_raw, stats, arg, x_stats)
         ctx.cfg = (K, S, relu, pool)
         ctx.conv_weight, ctx.conv_bias = conv_weight, conv_bias
+        if defer:
+            ctx.mark_non_differentiable(stats)
+            return y_raw, stats
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dstats=None):
         from . import _ext
-        x, w_pad, y_raw, stats, arg = ctx.saved_tensors
+        x, w_pad, y_raw, stats, arg, x_stats = ctx.saved_tensors
         K, S, relu, pool = ctx.cfg
         R, ldx = x.shape[0], x.stride(0)
         N = y_raw.shape[1]
@@ -137,15 +147,20 @@ class _ConvBNReLUPointMajor(torch.autograd.Function):
             dout = dout.to(torch.bfloat16)
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if (_ext.FUSED_SA_BWD[0] and need_dw and R >= _WGRAD_ROWS_MIN and (not pool or arg is not None)
+                and (x_stats is None or need_dx)
                 and _ext.sa_bwd_supported(ldx, N, S, pool, need_dx) and R * max(ldx, N) * 2 < (1 << 31) - (1 << 20)):
             # the BatchNorm reduction, then ONE pass over the activations for dX and dW (csrc/detbwd.hip)
             dgb = _ext.bn_bwd_reduce(dout, y_raw, stats, S, relu, pool, arg)
             xs = torch.as_strided(x, (R, ldx), (ldx, 1))
-            dx_full, dwf = _ext.sa_bwd_fused(xs, y_raw, dout, arg, w_pad, stats, dgb, S, relu, pool, need_dx)
+            dx_full, dwf = _ext.sa_bwd_fused(xs, y_raw, dout, arg, w_pad, stats, dgb, S, relu, pool, need_dx, x_stats=x_stats)
             dx = dx_full[:, :x.shape[1]] if need_dx else None
             dw = dwf[:, :K].reshape(ctx.conv_weight.shape)
             dcb = torch.zeros_like(ctx.conv_bias) if ctx.conv_bias is not None else None
-            return dx, dw, dgb[1], dgb[0], None, None, None, None, None, None, None, None, dcb
+            return dx, dw, dgb[1], dgb[0], None, None, None, None, None, None, None, None, dcb, None, None
+        if x_stats is not None:
+            # (a deferred input on the four-kernel path -- the fused kernel switched off between forward and backward, or an
+            # operand beyond its 2 GB bound: the activation is formed once, now)
+            x = _ext.bn_apply(x, x_stats, 1, True, False)
         dy, dgamma, dbeta = _ext.bn_relu_bwd(dout, y_raw, stats, S, relu, pool)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -167,7 +182,7 @@ class _ConvBNReLUPointMajor(torch.autograd.Function):
                                   _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32, _ext.EPI_NONE, 64)
             dw = dwf[:, :K].reshape(ctx.conv_weight.shape)
         dcb = torch.zeros_like(ctx.conv_bias) if ctx.conv_bias is not None else None
-        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None, dcb
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None, dcb, None, None
 
 
 CENTER_PREACT = [True]      # SharedMLP pre-activations stored relative to running_mean (tools/loss_gap_probe.py)
@@ -343,6 +358,18 @@ def _bn_kernel_ok(x, layer):
             and bn.weight.dtype == torch.float32 and x.is_cuda)
 
 
+def _defer_ok(rows, layer, nxt, S, nxt_pool):
+    """may `layer` hand its pre-activation to `nxt` instead of writing its activation?  Both native, ReLU, 64 or 128 channels
+    in between, enough rows for the fused backward and a fused kernel for the next layer's shape"""
+    from . import _ext
+    N, R = layer.conv.weight.shape[0], rows.shape[0]
+    return bool(_ext.DEFER_BN[0] and _ext.FUSED_SA_BWD[0] and not _ext.FP32_PREACT[0] and torch.is_grad_enabled()
+                and hasattr(layer, "activation") and N in (64, 128) and nxt.conv.weight.shape[1] == N
+                and R >= _WGRAD_ROWS_MIN and R * max(N, nxt.conv.weight.shape[0]) * 2 < (1 << 31) - (1 << 20)
+                and (not nxt_pool or int(S) in (16, 32, 64))
+                and _ext.sa_bwd_supported(N, nxt.conv.weight.shape[0], S, nxt_pool, True))
+
+
 class SharedMLP(nn.Sequential):
     """args=[C0,C1,...,Ck] -> k layers named layer0..layer{k-1} (pytorch_utils.py:11-36).
 """
@@ -367,11 +394,17 @@ class SharedMLP(nn.Sequential):
             # convolution, no layout change, no statistics pass (see _ConvBNReLUPointMajor)
             B, _, M, S = x.shape
             last = len(self) - 1
-            for i, layer in enumerate(self):
+            layers = list(self)
+            x_stats = None
+            for i, layer in enumerate(layers):
                 bn = layer.bn.bn
-                rows = _ConvBNReLUPointMajor.apply(rows, layer.conv.weight, bn.weight, bn.bias, bn.running_mean,
-                                                   bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum,
-                                                   hasattr(layer, "activation"), pool and i == last, S)
+                # (round 5) the BatchNorm + ReLU between two convolutions is not materialised where the next layer can apply
+                # it on load, forward and backward: this layer hands over its stored pre-activation and its stats
+                defer = i < last and _defer_ok(rows, layer, layers[i + 1], S, pool and i + 1 == last)
+                res = _ConvBNReLUPointMajor.apply(rows, layer.conv.weight, bn.weight, bn.bias, bn.running_mean,
+                                                  bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum,
+                                                  hasattr(layer, "activation"), pool and i == last, S, None, x_stats, defer)
+                rows, x_stats = res if defer else (res, None)
             C = rows.shape[1]
             return rows.view(B, M, C) if pool else rows.view(B, M, S, C).permute(0, 3, 1, 2)
         if rows is not None and not x.is_contiguous(memory_format=torch.channels_last):

@@ -179,6 +179,21 @@ BQ_API int bq_sa_bwd_workgroups(long R, int ldx, int Nj, int pool, int need_dx);
 BQ_API int bq_sa_bwd_fused(const void *x, const void *p, const void *dout, const void *arg, const void *w, const float *scale,
                            const float *shift, const float *mean, const float *rstd, const float *dgb, void *dx, float *dw,
                            float *part, long R, int ldx, int Nj, int ldw, int ldo, int S, int relu, int pool, void *stream);
+/* Deferred activations between the layers of one SharedMLP (ABI 5): the BatchNorm + ReLU between two convolutions is never
+ * materialised.  bq_pwconv_bn_fwd_x = bq_pwconv_bn_fwd whose x holds the PREVIOUS layer's stored pre-activation (K = ldx = 64
+ * or 128): relu(x xscale + xshift) -- the previous layer's scale / shift as bq_pwconv_bn_fwd wrote them -- is applied to every
+ * x tile as it arrives in LDS.  bq_sa_bwd_fused_x = bq_sa_bwd_fused on such an input (the weight gradient contracts with the
+ * re-formed activation; dx, required, is the gradient w.r.t. the activation, i.e. the previous layer's dout).
+ * xscale == NULL: the plain entries. */
+BQ_API int bq_pwconv_bn_fwd_x(const void *x, const float *xscale, const float *xshift, long R, int K, int ldx, const void *w,
+                              int ldw, int Kc, int N, void *y, float *partial, const float *gamma, const float *beta,
+                              float *running_mean, float *running_var, long long *num_batches_tracked, float eps,
+                              float momentum, float *scale, float *shift, float *mean, float *rstd, const float *center,
+                              float *shift_acc, void *stream);
+BQ_API int bq_sa_bwd_fused_x(const void *x, const float *xscale, const float *xshift, const void *p, const void *dout,
+                             const void *arg, const void *w, const float *scale, const float *shift, const float *mean,
+                             const float *rstd, const float *dgb, void *dx, float *dw, float *part, long R, int ldx, int Nj,
+                             int ldw, int ldo, int S, int relu, int pool, void *stream);
 
 /* exact (erf) GELU, bf16 (vit.py:23-41 Mlp act_layer=nn.GELU); n % 8 == 0, 16-B aligned */
 BQ_API int bq_gelu_fwd_bf16(const void *x, void *y, long n, void *stream);

@@ -456,3 +456,46 @@ def test_fused_sharedmlp_backward(dev, R, K, ldx, N, S, pool, need_dx):
         if need_dx:
             e2["dx"] = rel(a["dx"][:, :K], x_ref.grad)
         assert max(e2.values()) <= 2e-2, e2
+
+
+@pytest.mark.parametrize("mlp,npoint,nsample", [([128, 64, 64, 128], 1024, 64), ([128, 128, 128, 256], 1024, 32)])
+def test_deferred_activations_between_sharedmlp_layers(dev, mlp, npoint, nsample):
+    """Round 5: inside a SharedMLP the BatchNorm + ReLU between two convolutions is not materialised -- a layer hands its stored
+    pre-activation to the next one, whose convolution kernel (pwconv64s_kernel<.., true>) and fused backward
+    (sa_bwd_kernel<.., XT>) apply relu(x scale + shift) tile by tile in LDS.  Same arithmetic on the same values: the module's
+    output, the running statistics and EVERY gradient are bitwise those of the run that writes every activation."""
+    from bridgeqa_amd import fusion_ops, _ext
+    from bridgeqa_amd.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(5)
+    sa = PointnetSAModuleVotes(npoint=npoint, radius=0.4, nsample=nsample, mlp=list(mlp), use_xyz=True,
+                               normalize_xyz=True).to(dev).train()
+    g = torch.Generator().manual_seed(6)
+    xyz = (torch.rand(4, 4096, 3, generator=g) * torch.tensor([4.0, 4.0, 2.0])).to(dev)
+    feat0 = torch.randn(4, mlp[0], 4096, generator=g).to(dev)
+    wout = torch.randn(4, mlp[-1], npoint, generator=g).to(dev)
+    state = {k: v.clone() for k, v in sa.state_dict().items()}
+    res = {}
+    prev = fusion_ops.set_compute_dtype(torch.bfloat16)
+    prev_d = _ext.DEFER_BN[0]
+    try:
+        for defer in (True, False):
+            _ext.DEFER_BN[0] = defer
+            sa.load_state_dict(state)
+            sa.zero_grad(set_to_none=True)
+            feat = feat0.clone().requires_grad_(True)
+            torch.cuda.reset_peak_memory_stats()
+            nx, nf, ni = sa(xyz, feat)
+            (nf.float() * wout).sum().backward()
+            res[defer] = dict(nf=nf.detach().clone(), gfeat=feat.grad.clone(), peak=torch.cuda.max_memory_allocated(),
+                              grads={n: p.grad.detach().clone() for n, p in sa.named_parameters()},
+                              bufs={n: b.detach().clone() for n, b in sa.named_buffers()})
+    finally:
+        _ext.DEFER_BN[0] = prev_d
+        fusion_ops.set_compute_dtype(prev)
+    a, b = res[True], res[False]
+    assert torch.equal(a["nf"], b["nf"]) and torch.equal(a["gfeat"], b["gfeat"])
+    for n in a["grads"]:
+        assert torch.equal(a["grads"][n], b["grads"][n]), n
+    for n in a["bufs"]:
+        assert torch.equal(a["bufs"][n], b["bufs"][n]), n
+    assert a["peak"] < b["peak"], (a["peak"], b["peak"])   # two activation tensors fewer

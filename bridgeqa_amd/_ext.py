@@ -961,7 +961,7 @@ def gemm_grouped(problems, flags, epilogue=EPI_NONE, tile=None):
     if (tile or t_auto) != 128:
         flags &= ~GEMM_BACKGROUND   # (only the persistent 256 x 128 kernel has a reduced grid)
     with torch.cuda.device(dev):
-        if (tile or t_auto) == 128 and n == 1 and STREAMK[0]:
+        if (tile or t_auto) == 128 and n == 1 and (STREAMK[0] or STREAMK256[0]):
             _streamk_workspace(dev)
         _check(_lib.bq_gemm_bf16(arr, n, int(flags), int(epilogue), int(tile or t_auto), _stream()), "gemm_bf16")
 
@@ -969,19 +969,41 @@ def gemm_grouped(problems, flags, epilogue=EPI_NONE, tile=None):
 # ---- stream-K workspaces (bq_gemm_set_workspace): one per (device, stream), allocated at the first tile-128 single-problem
 # launch on that stream OUTSIDE a capture (the warm-up steps of pipeline.py / graphed.py run on the phase streams first); a
 # launch on a stream without one runs on whole tiles
-STREAMK = [False]   # round 5: built, parity-green, SLOWER on every shape measured -- off by default
+STREAMK = [False]   # the 256 x 128 kernel's stream-K form: built, parity-green, SLOWER on every shape measured
+# the 256 x 256 kernel's stream-K form (the vendor library's design for these shapes): built at the end of round 5, parity-green,
+# SLOWER too (fc2 forward 98.6 us against 76.7 on whole 256 x 256 tiles and 75.4 on 256 x 128; c3 + 0.9 ms) -- off;
+# BQ_GEMM_STREAMK256=1 switches it on
+STREAMK256 = [os.environ.get("BQ_GEMM_STREAMK256", "0") == "1"]
 _SK_WS = {}
 _lib.bq_gemm_workspace_bytes.restype = ctypes.c_long
 _lib.bq_gemm_set_workspace.argtypes = [_vp, ctypes.c_long, _vp]
 _lib.bq_gemm_set_workspace.restype = ctypes.c_int
+_lib.bq_gemm_streamk_mode.argtypes = [_i]
+_lib.bq_gemm_streamk_mode.restype = ctypes.c_int
+
+
+def _streamk_apply():
+    on = STREAMK[0] or STREAMK256[0]
+    _lib.bq_gemm_streamk_mode((1 if STREAMK[0] else 0) | (2 if STREAMK256[0] else 0))
+    for (d, sp), (ws, st) in _SK_WS.items():
+        with torch.cuda.device(d):
+            _check(_lib.bq_gemm_set_workspace(_p(ws) if on else None, ws.numel() if on else 0, sp), "gemm_set_workspace")
 
 
 def streamk_enable(flag):
-    """measurement / test switch: with False every registered workspace is withdrawn (the launches run on whole tiles)"""
+    """measurement / test switch of the 256 x 128 kernel's stream-K form (with both forms off every registered workspace is
+    withdrawn and the launches run on whole tiles)"""
     STREAMK[0] = bool(flag)
-    for (d, sp), (ws, st) in _SK_WS.items():
-        with torch.cuda.device(d):
-            _check(_lib.bq_gemm_set_workspace(_p(ws) if flag else None, ws.numel() if flag else 0, sp), "gemm_set_workspace")
+    _streamk_apply()
+
+
+def streamk256_enable(flag):
+    """the same for the 256 x 256 kernel's form (product default: off as well)"""
+    STREAMK256[0] = bool(flag)
+    _streamk_apply()
+
+
+_streamk_apply()
 
 
 def _streamk_workspace(dev):

@@ -28,10 +28,24 @@
 
 namespace bq {
 
+typedef unsigned u32x4_sk __attribute__((ext_vector_type(4)));
 
-template <bool P_XC, bool Q_XC, int EPI, bool OUT_F32>
+// SK (round 5, second attempt at VERDICT r4 item 1): the STREAM-K form of this kernel for ONE problem with a long contraction
+// whose 256 x 256 tiles do not fill the chip evenly (fc2 forward: 195 tiles of 48 K tiles on 256 CUs).  The grid is one
+// workgroup per CU; workgroup s walks the K-TILE UNITS [b(s), b(s + 1)) of the tile-major unit sequence -- a tail of one tile,
+// whole tiles, a head of the next -- running this kernel's ordinary pipeline over each segment; a tile cut across several
+// workgroups is finished by the one that ARRIVES LAST (csrc/gemm_mid.hip's protocol: ticket, fp32 slabs parked with
+// write-through stores, a bounded wait, a fold in fixed slot order).  The first attempt put stream-K on the 256 x 128 kernel
+// and lost: those launches are bound by L2 -> LDS bytes, which a 256 x 256 tile halves -- and the vendor library's kernel for
+// these shapes is exactly a 256 x 256 x 64 stream-K kernel (tools/hipblaslt_names.py).  MEASURED: parity-green and slower again
+// -- fc2 forward 98.6 us against 76.7 on whole 256 x 256 tiles (75.4 on 256 x 128), the c3 step + 0.9 ms: with one workgroup per
+// CU nothing hides a segment's second pipeline fill, the 256 KB park and the 256 KB fold.  Off by default
+// (bq_gemm_streamk_mode bit 1).
+template <bool P_XC, bool Q_XC, int EPI, bool OUT_F32, bool SK = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
+  static_assert(!SK || (!P_XC && !Q_XC && !OUT_F32 && (EPI == EPI_NONE || EPI == EPI_BIAS)), "stream-K: K-contiguous operands, bf16 out");
   __shared__ __attribute__((aligned(16))) unsigned char smem[131072];
+  __shared__ unsigned s_skflag;
   constexpr bool GTAB = !OUT_F32 && (EPI == EPI_BIAS_GELU || EPI == EPI_DGELU);
   __shared__ float s_gtab[GTAB ? GELU_TAB_N : 1];
   const int tid = threadIdx.x;
@@ -42,10 +56,31 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
   // ---- workgroup -> (problem, tile): XCD-aware (blocks b, b+8, ... share an XCD's L2: give each XCD a contiguous run
   // of tiles so that consecutive tiles, which share the Q row panel, hit the same L2) -----------------------------------
   const int nwg = args.total_tiles;
-  int t;
-  {
-    const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
-    t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+  auto xcd_order = [](int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+  };
+  // ---- stream-K: unit ranges (one problem; every tile has nkt_full K tiles; a segment is never a single K tile) ---------------
+  const int G = (int)gridDim.x;
+  const int nkt_full = SK ? (args.p[0].Kc + 63) >> 6 : 1;
+  const int U = SK ? nwg * nkt_full : 0;
+  auto bound = [&](int x) {
+    int b = (int)((long)x * U / G);
+    const int r = b % nkt_full;
+    return r == 1 ? b - 1 : (r == nkt_full - 1 ? b + 1 : b);
+  };
+  const int slot = SK ? xcd_order((int)blockIdx.x, G) : 0;
+  int su = SK ? bound(slot) : 0;
+  const int sue = SK ? bound(slot + 1) : 0;
+  if (SK && su >= sue) return;
+  for (;;) {   // SK: one trip per segment of this workgroup's unit range; otherwise exactly one trip
+  int t, kb = 0, kseg = 0;
+  if (SK) {
+    t = su / nkt_full;
+    kb = su - t * nkt_full;
+    kseg = min(nkt_full - kb, sue - su);
+  } else {
+    t = xcd_order((int)blockIdx.x, nwg);
   }
   int pi = 0;
   for (int k = 1; k < args.n; ++k)
@@ -58,7 +93,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
   const int i0 = bi * 256, j0 = bj * 256;
   const int Ni = pr.Ni, Nj = pr.Nj, Kc = pr.Kc;
   const int ldp = pr.ldp, ldq = pr.ldq;
-  const int nkt = (Kc + 63) >> 6;
+  const int nkt = SK ? kseg : (Kc + 63) >> 6;
 
   // ---- staging: 8 units per K tile, one LDS-DMA per wave per unit (wave w -> unit rows 8w..8w+7) -----------------
   const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void *)pr.P, 0, pr.p_bytes, 0x00020000);
@@ -90,6 +125,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
   }
   const unsigned p_step = P_XC ? (unsigned)(64 * ldp * 2) : 128u;
   const unsigned q_step = Q_XC ? (unsigned)(64 * ldq * 2) : 128u;
+  if (SK) {   // the segment starts at K tile kb of its tile
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { voff[u] += (unsigned)kb * p_step; voff[4 + u] += (unsigned)kb * q_step; }
+  }
   const unsigned lds_w = (unsigned)(wave * 1024);
   // batched-row map on the CONTRACTION rows of a contraction-major Q (the weight-gradient form reading its row range of
   // a (B, L1 + L2, N) gradient in place): the lane's row walks 64 rows per K tile; when it leaves its batch (q_rpb >= 64:
@@ -234,6 +273,61 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
   if (wr == 0) BQ_BARRIER();  // re-align the two groups: every LDS read of the K loop is complete after this
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing out-of-range DMAs have written their zeros
   BQ_BARRIER();
+
+  if (SK && kseg != nkt_full) {
+    // ---- a tile cut across several workgroups is finished by the one that arrives last (csrc/gemm_mid.hip, header) --------
+    unsigned *tick = (unsigned *)args.sk_ws + 2 * t;
+    const int t0 = t * nkt_full, t1 = t0 + nkt_full;
+    int s_lo = slot, s_hi = slot;
+    while (s_lo > 0 && bound(s_lo) > t0) --s_lo;
+    while (s_hi + 1 < G && bound(s_hi + 1) < t1) ++s_hi;
+    const int n_part = s_hi - s_lo + 1;
+    if (tid == 0) s_skflag = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)s_skflag);
+    constexpr unsigned SLAB256 = 256u * 256u * 4u;
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((char *)args.sk_ws + SK_TICKET_BYTES, 0, 0x7fffffffu, 0x00020000);
+    // slab of (slot, which of its two possible partial segments): the first one iff the slot's range starts inside the tile
+    auto slab_off = [&](int sl) { return (unsigned)(2 * sl + (bound(sl) >= t0 ? 0 : 1)) * SLAB256; };
+    if (arrived != (unsigned)(n_part - 1)) {
+      // not last: park the accumulators (write-through), drain, count this workgroup in
+      const unsigned base = slab_off(slot) + (unsigned)(tid * 16);
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_sk, acc[a][b]), rsW, base + (unsigned)((a * 4 + b) * 8192), 0, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(tick + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      su += kseg;
+      if (su >= sue) return;
+      continue;   // (the tile's last arriver stores it)
+    }
+    // last: every other participant is past its K loop; wait for their slabs (bounded: a timeout can only mean a protocol bug,
+    // and a wrong tile fails a test where a hang would lose the GPU), take the tickets back, fold in slot order
+    if (tid == 0) {
+      for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(tick + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(n_part - 1); ++spin)
+        __builtin_amdgcn_s_sleep(4);
+      __hip_atomic_store(tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(tick + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    for (int sl = s_lo; sl <= s_hi; ++sl) {
+      if (sl == slot) continue;
+      const unsigned base = slab_off(sl) + (unsigned)(tid * 16);
+#pragma unroll
+      for (int a0 = 0; a0 < 8; a0 += 2) {   // eight 16-byte loads in flight per lane (the fragment registers are free here)
+        u32x4_sk part[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[e] = __builtin_amdgcn_raw_buffer_load_b128(rsW, base + (unsigned)((a0 * 4 + e) * 8192), 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[a0 + (e >> 2)][e & 3] += __builtin_bit_cast(f32x4, part[e]);
+      }
+    }
+  }
 
   // ---- epilogue -------------------------------------------------------------------------------------------------
   // accumulator (a, b)[r]: i = iw + a*16 + q4*4 + r, j = jw + b*16 + row16
@@ -483,6 +577,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
+  if (!SK) return;
+  su += kseg;
+  if (su >= sue) return;
+  BQ_BARRIER();   // the wave-private output images alias the staging buffers the next segment's DMAs write
+  }   // segments
 }
 
 }  // namespace bq
@@ -1399,6 +1498,29 @@ static int launch_gemm(const GemmArgs &ga, int flags, int epi, int tile, hipStre
   constexpr int long_k_tiles = 12;
   bool long_k = long_k_tiles > 0 && tile != 256 && ga.total_tiles <= 2048;
   for (int k = 0; k < ga.n; ++k) long_k = long_k && ga.p[k].Kc >= 64 * long_k_tiles;
+  if (tile == 128 && (gemm_sk_mode() & 2) && !(flags & BQ_GEMM_BACKGROUND) && ga.n == 1 && !pxc && !qxc && !f32 &&
+      (epi == EPI_NONE || epi == EPI_BIAS) && ga.p[0].colsum == nullptr && ga.p[0].q_rpb() == 0 && ga.p[0].o_rpb() == 0) {
+    // stream-K on the 256 x 256 kernel (header of gemm256_kernel): one problem with a long contraction whose 256 x 256 tiles
+    // would leave >= 15 % of a one-workgroup-per-CU grid idle, every share still >= 16 K tiles
+    const GemmProblem &p0 = ga.p[0];
+    const int cus = device_cus();
+    const int nkt = (p0.Kc + 63) >> 6, tiles = ((p0.Ni + 255) / 256) * ((p0.Nj + 255) / 256);
+    const long units = (long)tiles * nkt;
+    const int rounds = (tiles + cus - 1) / cus;
+    long ws_bytes = 0;
+    void *ws = gemm_sk_workspace(st, &ws_bytes);
+    if (ws != nullptr && nkt >= 24 && tiles >= cus / 2 && units / cus >= 16 && (long)rounds * nkt * cus >= units * 115 / 100 &&
+        8L * tiles <= SK_TICKET_BYTES && ws_bytes >= SK_TICKET_BYTES + 2L * cus * 256 * 256 * 4) {
+      GemmArgs g2 = ga;
+      g2.sk_ws = ws;
+      g2.total_tiles = tiles;
+      g2.p[0].tile0 = 0;
+      g2.p[0].tiles_ks = (p0.Ni + 255) / 256;   // tiles along i, no K split
+      if (epi == EPI_NONE) hipLaunchKernelGGL((gemm256_kernel<false, false, EPI_NONE, false, true>), dim3(cus), dim3(512), 0, st, g2);
+      else hipLaunchKernelGGL((gemm256_kernel<false, false, EPI_BIAS, false, true>), dim3(cus), dim3(512), 0, st, g2);
+      return 0;
+    }
+  }
   if (tile == 128)  // csrc/gemm_mid.hip: forward / dX (bf16 out, K-contiguous Q) and the weight-gradient form
     return launch_gemm_mid(ga, pxc, qxc, f32, epi, (flags & BQ_GEMM_BACKGROUND) != 0, st);
   if (!pxc && !qxc && !f32) {

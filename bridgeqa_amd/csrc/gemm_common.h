@@ -201,5 +201,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 int launch_gemm_mid(const GemmArgs &ga, bool p_xc, bool q_xc, bool out_f32, int epi, bool background, hipStream_t st);
 // the stream-K workspace registered for `st` (bq_gemm_set_workspace), or nullptr
 void *gemm_sk_workspace(hipStream_t st, long *bytes);
+// which stream-K forms may run (bq_gemm_streamk_mode): bit 0 the 256 x 128 kernel's, bit 1 the 256 x 256 kernel's (both
+// measured slower than whole tiles: off by default)
+int gemm_sk_mode();
 
 }  // namespace bq

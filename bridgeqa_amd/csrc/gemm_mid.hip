@@ -594,15 +594,19 @@ void *gemm_sk_workspace(hipStream_t st, long *bytes) {
   return nullptr;
 }
 
-// measurement switch (tools/bench_gemm2.py --no-streamk): BQ_GEMM_STREAMK=0 in the environment keeps every launch on whole tiles
-static bool sk_enabled() {
-  static int on = -1;
-  if (on < 0) {
+// which stream-K forms may run: bit 0 = this file's (256 x 128 tiles: measured slower than whole tiles),
+// bit 1 = gemm256_kernel's (csrc/gemm.hip: slower as well, 98.6 us against 76.7 on fc2).  Default 0; bq_gemm_streamk_mode sets
+// it; BQ_GEMM_STREAMK=0 in the environment keeps every launch on whole tiles whatever the mode.
+static int g_sk_mode = 0;
+int gemm_sk_mode() {
+  static int env_off = -1;
+  if (env_off < 0) {
     const char *e = getenv("BQ_GEMM_STREAMK");
-    on = (e == nullptr || e[0] != '0') ? 1 : 0;
+    env_off = (e != nullptr && e[0] == '0') ? 1 : 0;
   }
-  return on == 1;
+  return env_off ? 0 : g_sk_mode;
 }
+static bool sk_enabled() { return (gemm_sk_mode() & 1) != 0; }
 
 int launch_gemm_mid(const GemmArgs &ga_in, bool p_xc, bool q_xc, bool out_f32, int epi, bool background, hipStream_t stream) {
   const int slots = 2 * device_cus();   // two co-resident workgroups per CU (64 KB of LDS, <= 256 VGPRs each)
@@ -664,6 +668,12 @@ int launch_gemm_mid(const GemmArgs &ga_in, bool p_xc, bool q_xc, bool out_f32, i
 }
 
 }  // namespace bq
+
+extern "C" int bq_gemm_streamk_mode(int mode) {
+  const int old = bq::g_sk_mode;
+  if (mode >= 0) bq::g_sk_mode = mode & 3;
+  return old;
+}
 
 extern "C" long bq_gemm_workspace_bytes(void) {
   return bq::SK_TICKET_BYTES + 2L * 2L * bq::device_cus() * bq::SK_SLAB_BYTES;

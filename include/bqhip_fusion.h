@@ -338,6 +338,12 @@ BQ_API int bq_gemm_bf16(const bq_gemm_desc *problems, int n, int flags, int epil
  * one launch at a time may use a workspace: one workspace per stream, and a captured launch replays on its capture stream. */
 BQ_API long bq_gemm_workspace_bytes(void);
 BQ_API int bq_gemm_set_workspace(void *ws, long bytes, void *stream);
+/* ABI 5.  Which stream-K forms may run on a stream that has a workspace: bit 0 the 256 x 128 kernel's (round 5's first attempt:
+ * slower than whole tiles on every ViT shape), bit 1 the 256 x 256 kernel's (one problem, K-contiguous operands, bf16 out, a
+ * contraction of >= 24 K tiles whose tiles would leave >= 15 % of the chip idle: fc2 forward, the input gradient through fc1).
+ * Both measured slower than whole tiles on this repo's kernels: default 0.  mode < 0: query.  Returns the
+ * previous mode. */
+BQ_API int bq_gemm_streamk_mode(int mode);
 
 /* Column sums of a list of bf16 matrices in ONE launch: out[n] += sum_m g[m*ld + n] (fp32 atomics: out must be zeroed
  * by the caller).  Replaces grad.sum(0), the bias gradient of nn.Linear, for every parked linear of a backward pass.

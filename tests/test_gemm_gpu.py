@@ -557,21 +557,35 @@ def test_multi_tensor_transpose(dev):
         _ext.transpose_table([(_rand((100, 128), dev, 67), torch.zeros(128, 100, dtype=torch.bfloat16, device=dev))], dev)
 
 
+def _sk_forms(form, on):
+    """form 128: the 256 x 128 kernel's stream-K (csrc/gemm_mid.hip), form 256: the 256 x 256 kernel's (csrc/gemm.hip); the
+    other form off while one is tested; (None, ..): the product defaults"""
+    from bridgeqa_amd import _ext
+    if form is None:
+        _ext.streamk_enable(False)
+        _ext.streamk256_enable(False)
+    else:
+        _ext.streamk_enable(on and form == 128)
+        _ext.streamk256_enable(on and form == 256)
+
+
+@pytest.mark.parametrize("form", [128, 256])
 @pytest.mark.parametrize("M,N,K", [(16400, 768, 3072), (16384, 768, 3072), (16400, 768, 1536), (9000, 1024, 2048),
                                    (16720, 768, 3072)])
-def test_stream_k_equals_whole_tiles(dev, M, N, K):
-    """the stream-K form of the 256 x 128 kernel (csrc/gemm_mid.hip header: a tile cut across workgroups, finished by the
-    last arriver through fp32 slabs) on the ViT MLP's long-contraction launches -- forward + bias, dX on the transposed
-    weight copy with and without the ADD epilogue -- against torch fp32 and against the same launches on whole tiles
-    (different fp32 summation order: equal up to one bf16 rounding on a few elements), five times over (tickets must
-    come back to zero), ragged row blocks included"""
+def test_stream_k_equals_whole_tiles(dev, M, N, K, form):
+    """the stream-K forms of the 256 x 128 kernel (csrc/gemm_mid.hip header: a tile cut across workgroups, finished by the
+    last arriver through fp32 slabs) and of the 256 x 256 kernel (csrc/gemm.hip: the same protocol around that kernel's
+    per-segment pipeline) on the ViT MLP's long-contraction launches --
+    forward + bias, dX on the transposed weight copy with and without the ADD epilogue -- against torch fp32 and against the
+    same launches on whole tiles (different fp32 summation order: equal up to one bf16 rounding on a few elements), five
+    times over (tickets must come back to zero), ragged row blocks included"""
     from bridgeqa_amd import _ext
     x, w = _rand((M, K), dev, 71), _rand((N, K), dev, 72, 0.05)
     b = torch.randn(N, device=dev)
     ref = x.float() @ w.float().t() + b
-    _ext.streamk_enable(False)
+    _sk_forms(form, False)
     whole = _ext.gemm_fwd(x, w, b, tile=128)
-    _ext.streamk_enable(True)
+    _sk_forms(form, True)
     outs = [_ext.gemm_fwd(x, w, b, tile=128) for _ in range(5)]
     torch.cuda.synchronize()
     for y in outs:
@@ -590,14 +604,15 @@ def test_stream_k_equals_whole_tiles(dev, M, N, K):
         for g in got:
             _check(g, r)
             assert torch.equal(g, got[0])
-    _ext.streamk_enable(False)   # (the product default: DESIGN.md section 4.5 -- measured slower than whole tiles)
+    _sk_forms(None, None)
 
 
-def test_stream_k_under_load_and_graph_replay(dev):
+@pytest.mark.parametrize("form", [128, 256])
+def test_stream_k_under_load_and_graph_replay(dev, form):
     """the hand-off protocol with the chip busy (a second stream keeps launching bandwidth-bound kernels, so workgroups of
     one launch are not all resident at once and arrive in every order) and replayed from a HIP graph"""
     from bridgeqa_amd import _ext
-    _ext.streamk_enable(True)
+    _sk_forms(form, True)
     M, N, K = 16400, 768, 3072
     x, w = _rand((M, K), dev, 81), _rand((N, K), dev, 82, 0.05)
     b = torch.randn(N, device=dev)
@@ -621,4 +636,4 @@ def test_stream_k_under_load_and_graph_replay(dev):
         torch.cuda.synchronize()
         _check(y, ref)
         assert torch.equal(y, want), it
-    _ext.streamk_enable(False)
+    _sk_forms(None, None)

@@ -89,10 +89,12 @@ def main():
             arms.append("128t")            # what the step launches: the K-contiguous transposed weight copy (fusion_state)
         if m >= 1024 and kind in ("fwd", "dx") and k * (n if kind == "dx" else 1) >= 1536 and (n if kind == "fwd" else k) <= 1024:
             arms.append("128t-streamk" if kind == "dx" else "128-streamk")   # the same launch cut into equal K-tile runs
+            arms.append("128t-streamk256" if kind == "dx" else "128-streamk256")   # ... on the 256 x 256 kernel
         for arm in arms:
             tile = 128 if isinstance(arm, str) else arm
             use_wt = isinstance(arm, str) and arm.startswith("128t")
             _ext.streamk_enable(isinstance(arm, str) and arm.endswith("streamk"))
+            _ext.streamk256_enable(isinstance(arm, str) and arm.endswith("streamk256"))
             if use_wt:
                 if kind == "dx":
                     mine = lambda: _ext.gemm_dx(dy, w, tile=tile, wt=wt)
@@ -112,6 +114,7 @@ def main():
                 mine = lambda: _ext.gemm_dw(dy, x, tile=tile)
             res[arm] = graph_time(mine)
         _ext.streamk_enable(False)
+        _ext.streamk256_enable(False)
         if kind == "fwd":
             ref = lambda: torch.nn.functional.linear(x, w, bb)
         elif kind == "fwdg":

@@ -486,7 +486,10 @@ static int ln_fwd_launch(const void *x, const void *residual, const float *gamma
   BQ_REQUIRE(p_path == 0.0f || rows_per_sample > 0, BQ_EINVAL, "drop_add_ln: rows_per_sample");
   LnArgs a{M, H, eps, 1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr,
            (unsigned)((double)p_path * 4294967296.0), 1.0f / (1.0f - p_path), rows_per_sample, groups, gamma2, beta2};
-  constexpr int fwd_cap = 1024;  // rows are strided over the grid (tools/ln_sweep.sh)
+#ifndef BQ_LN_FWD_CAP
+#define BQ_LN_FWD_CAP 1024
+#endif
+  constexpr int fwd_cap = BQ_LN_FWD_CAP;  // rows are strided over the grid (tools/ln_sweep.sh)
   const int Mg = M / groups;
   const dim3 grid(((Mg + 3) / 4) < fwd_cap ? (Mg + 3) / 4 : fwd_cap, groups);
   hipStream_t st = (hipStream_t)stream;

@@ -596,6 +596,53 @@ def reference_loop(args, model, batch, dev, use_graph):
     print(json.dumps(_json_safe(out)))
 
 
+def det_bwd_roofline(args, dev):
+    """The fused SharedMLP backward (csrc/detbwd.hip) at SA1's three layer shapes of this configuration: algorithmic HBM bytes
+    (operands read once, dX written once) over the live launch duration (HIP events on the launch stream, median of 7), next to
+    the counter bytes of the committed PMC passes (profiles/r05_det_bwd_pmc.txt, taken at B = 16 x 2048 x 64 rows)."""
+    import torch
+    from bridgeqa_amd import _ext
+    R = args.batch * 2048 * 64
+    shapes = (("SA1 layer 0 (136 -> 64, no dX)", 136, 64, False, False), ("SA1 layer 1 (64 -> 64)", 64, 64, False, True),
+              ("SA1 layer 2 (64 -> 128, max over 64)", 64, 128, True, True))
+    per, tot_b, tot_ms = [], 0.0, 0.0
+    st = torch.cuda.current_stream(dev)
+    for name, ldx, N, pool, need_dx in shapes:
+        if R * max(ldx, N) * 2 >= (1 << 31) - (1 << 20) or not _ext.sa_bwd_supported(ldx, N, 64, pool, need_dx):
+            return None
+        x = torch.randn(R, ldx, device=dev).to(torch.bfloat16)
+        y_raw = torch.randn(R, N, device=dev).to(torch.bfloat16)
+        dout = torch.randn(R // 64 if pool else R, N, device=dev).to(torch.bfloat16)
+        arg = torch.randint(0, 64, (R // 64, N), device=dev, dtype=torch.uint8) if pool else None
+        w = (torch.randn(N, ((ldx + 63) // 64) * 64, device=dev) * 0.05).to(torch.bfloat16)
+        stats = torch.stack([torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev) * 0.1, torch.randn(N, device=dev) * 0.1,
+                             torch.rand(N, device=dev) + 0.5, torch.zeros(N, device=dev)])
+        dgb = _ext.bn_bwd_reduce(dout, y_raw, stats, 64, True, pool, arg)
+        ts = []
+        for _ in range(9):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            _ext.sa_bwd_fused(x, y_raw, dout, arg, w, stats, dgb, 64, True, pool, need_dx)
+            e1.record(st)
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ms = sorted(ts[2:])[len(ts[2:]) // 2]
+        alg = R * 2.0 * (ldx + N + (0 if pool else N) + (ldx if need_dx else 0)) + (R // 64 * N * 3.0 if pool else 0.0)
+        per.append({"layer": name, "rows": R, "ms": round(ms, 4), "algorithmic_bytes": alg,
+                    "GB/s": round(alg / (ms * 1e-3) / 1e9, 1)})
+        tot_b += alg
+        tot_ms += ms
+        del x, y_raw, dout, arg
+    return {"kernel": "bq::sa_bwd_kernel (csrc/detbwd.hip): BatchNorm input gradient formed in LDS, dX and dW of a SharedMLP "
+                      "layer from one pass over its activations; the three layers of SA1", "bound": "hbm",
+            "achieved": round(tot_b / (tot_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms_total": round(tot_ms, 4), "per_layer": per,
+            "traffic_from_profile": "profiles/r05_det_bwd_pmc.txt (2 x FETCH_SIZE + WRITE_SIZE per launch: 1125 / 1082 / 1103 MB "
+                                    "for 1107 / 1074 / 1086 MB of algorithmic bytes at B = 16)",
+            "timed_on": "dedicated launches after the timed region, HIP events on the launch stream, median of 7"}
+
+
+
 def _fps_pmc():
     """physical HBM traffic of SA1's FPS launch from the committed counter passes (tools/run_r5_profiles.sh), or None"""
     try:
@@ -1089,6 +1136,8 @@ def main():
             out["roofline_attn"] = attn_roofline(args, dev)
         else:
             out["roofline"] = out["roofline_fps"]
+        if world == 1 and args.workload != "c5":
+            out["roofline_det_bwd"] = det_bwd_roofline(args, dev)
         if world == 1 and not args.no_cpu_baseline and args.workload != "c5":   # (c3 is the headline: its baseline is the one reported)
             out["cpu_baseline"] = cpu_baseline(args, workload)
         if loop_ref_res is not None:

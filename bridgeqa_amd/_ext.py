@@ -1181,6 +1181,15 @@ _lib.bq_sa_bwd_fused.argtypes = [_vp] * 13 + [_l, _i, _i, _i, _i, _i, _i, _i, _v
 _lib.bq_sa_bwd_fused.restype = ctypes.c_int
 _lib.bq_sa_bwd_fused_x.argtypes = [_vp] * 15 + [_l, _i, _i, _i, _i, _i, _i, _i, _vp]
 _lib.bq_sa_bwd_fused_x.restype = ctypes.c_int
+_lib.bq_sa_bwd_fused_xr.argtypes = [_vp] * 19 + [_l, _i, _i, _i, _i, _i, _i, _i, _vp]
+_lib.bq_sa_bwd_fused_xr.restype = ctypes.c_int
+_lib.bq_sa_bwd_reduce_supported.argtypes = [_i, _i, _i, _i]
+_lib.bq_sa_bwd_reduce_supported.restype = ctypes.c_int
+# a layer's fused backward can also sum the PREVIOUS layer's dbeta / dgamma (its dOut and its pre-activation are both in the pass:
+# "the BatchNorm reduce in the epilogue of the next layer's dX GEMM").  Built, parity-green, and SLOWER: the second barrier per
+# tile, the table reads and 32 more live registers per lane cost the fused kernels more than the eight reduction launches they
+# replace (c2 7.72 / 7.77 -> 7.91 / 7.95 ms, c3 33.50 -> 33.41 inside the noise).  Off; BQ_CARRY_REDUCE=1 switches it on.
+CARRY_REDUCE = [os.environ.get("BQ_CARRY_REDUCE", "0") == "1"]
 _lib.bq_pwconv_bn_fwd_x.argtypes = [_vp, _vp, _vp, _l, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp,
                                     _vp, _vp, _vp, _vp, _vp]
 _lib.bq_pwconv_bn_fwd_x.restype = ctypes.c_int
@@ -1222,10 +1231,12 @@ def bn_bwd_reduce(dy, x, stats, S, relu, pool, arg=None):
     return dgb
 
 
-def sa_bwd_fused(x, y_raw, dout, arg, w_pad, stats, dgb, S, relu, pool, need_dx, x_stats=None):
+def sa_bwd_fused(x, y_raw, dout, arg, w_pad, stats, dgb, S, relu, pool, need_dx, x_stats=None, carry_reduce=False):
     """x bf16 (R, ldx) whole padded rows, y_raw bf16 (R, N), dout bf16 (R, N) | (R // S, N) with arg u8 when pool, w_pad bf16
     (N, Kc), stats f32 (>= 4, N), dgb f32 (2, N) -> dx bf16 (R, ldx) | None, dw f32 (N, ldx).  x_stats: x is the previous
-    layer's stored pre-activation and the layer's input relu(x * x_stats[0] + x_stats[1]) (bq_sa_bwd_fused_x; dx required)"""
+    layer's stored pre-activation and the layer's input relu(x * x_stats[0] + x_stats[1]) (bq_sa_bwd_fused_x; dx required);
+    carry_reduce (with x_stats): a third value, f32 (2, ldx) = the PREVIOUS layer's dbeta | dgamma summed in the same pass
+    (bq_sa_bwd_fused_xr), or None where the shape has no room for it"""
     R, ldx = x.shape[0], x.stride(0)
     N = y_raw.shape[1]
     with torch.cuda.device(x.device):
@@ -1233,12 +1244,17 @@ def sa_bwd_fused(x, y_raw, dout, arg, w_pad, stats, dgb, S, relu, pool, need_dx,
         dw = torch.empty(N, ldx, dtype=torch.float32, device=x.device)
         wgs = _lib.bq_sa_bwd_workgroups(R, ldx, N, int(bool(pool)), int(bool(need_dx)))
         part = torch.empty(wgs * N * ldx, dtype=torch.float32, device=x.device)
-        _check(_lib.bq_sa_bwd_fused_x(_p(x), _p(x_stats[0]) if x_stats is not None else None,
-                                      _p(x_stats[1]) if x_stats is not None else None, _p(y_raw), _p(dout), _p(arg), _p(w_pad),
-                                      _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), _p(dgb), _p(dx), _p(dw), _p(part),
-                                      R, ldx, N, w_pad.stride(0), ldx, int(S), int(bool(relu)), int(bool(pool)), _stream()),
-               "sa_bwd_fused")
-    return dx, dw
+        carry = bool(carry_reduce and x_stats is not None and need_dx
+                     and _lib.bq_sa_bwd_reduce_supported(ldx, N, int(S), int(bool(pool))))
+        red_part = torch.empty(wgs * 4 * 2 * ldx, dtype=torch.float32, device=x.device) if carry else None
+        red_dgb = torch.empty(2, ldx, dtype=torch.float32, device=x.device) if carry else None
+        xs = x_stats
+        _check(_lib.bq_sa_bwd_fused_xr(_p(x), _p(xs[0]) if xs is not None else None, _p(xs[1]) if xs is not None else None,
+                                       _p(xs[2]) if carry else None, _p(xs[3]) if carry else None, _p(red_part), _p(red_dgb),
+                                       _p(y_raw), _p(dout), _p(arg), _p(w_pad), _p(stats[0]), _p(stats[1]), _p(stats[2]),
+                                       _p(stats[3]), _p(dgb), _p(dx), _p(dw), _p(part), R, ldx, N, w_pad.stride(0), ldx, int(S),
+                                       int(bool(relu)), int(bool(pool)), _stream()), "sa_bwd_fused")
+    return (dx, dw, red_dgb) if carry_reduce else (dx, dw)
 
 
 # SharedMLP outputs from the fp32 accumulators (bq_pwconv_bn_apply) instead of from the stored bf16 y.  OFF: measured in round 5

@@ -37,14 +37,19 @@ struct SaBwdArgs {
   const float *scale, *shift, *mean, *rstd;   // of the STORED pre-activation
   const float *dgb;      // [2][Nj] dbeta | dgamma
   const float *xscale, *xshift;   // XT: X holds the previous layer's stored pre-activation; the layer's input is relu(X xscale + xshift)
+  // RED (with XT): the PREVIOUS layer's BatchNorm reduction rides on this pass -- its dOut is this kernel's dX, its pre-activation
+  // this kernel's x tile: per (workgroup, wave) partial sums of g and g xhat, g = dX masked by that layer's ReLU
+  const float *xmean, *xrstd;
+  float *red_part;       // [workgroups * 4][2][ldx]
   __bf16 *dX;            // [R][ldx] or null
   float *part;           // [workgroups][Nj][ldo]
   int R, ldx, Nj, ldw, ldo, S, relu;
   unsigned x_bytes, p_bytes, d_bytes, a_bytes, w_bytes, dx_bytes;
 };
 
-template <int TI, int TJ, bool POOL, bool DX>
+template <int TI, int TJ, bool POOL, bool DX, bool RED = false>
 struct SaBwdCfg {
+  static constexpr int RED_LDS = RED ? TI * 64 * 16 : 0;   // the previous layer's (scale, shift, mean, rstd) per channel
   static constexpr int UNITS = TI + TJ * (POOL ? 1 : 2);
   static constexpr int WB = DX ? TI * TJ * 8192 : 0;
   // pooled layers: a wave's dOut / arg-max rows (one group per wave and tile) travel by DMA into 2 KB of the stage while three
@@ -52,25 +57,27 @@ struct SaBwdCfg {
   // transform of tile t has consumed the registers) and the stage is the images alone
   static constexpr int STAGE3 = UNITS * 8192 + (POOL ? 8192 : 0);
   // (BQ_SA_PREFER_TWO: two stages wherever that lets two workgroups share a CU's LDS -- measurement macro)
-  static constexpr bool TWO = BQ_SA_PREFER_TWO && 2 * UNITS * 8192 + WB <= 80 * 1024 && 3 * STAGE3 + WB > 80 * 1024;
-  static constexpr int NS = (3 * STAGE3 + WB <= 160 * 1024 && !TWO) ? 3 : 2;
+  static constexpr bool TWO = BQ_SA_PREFER_TWO && 2 * UNITS * 8192 + WB + RED_LDS <= 80 * 1024 && 3 * STAGE3 + WB + RED_LDS > 80 * 1024;
+  static constexpr int NS = (3 * STAGE3 + WB + RED_LDS <= 160 * 1024 && !TWO) ? 3 : 2;
   static constexpr bool GREG = POOL && NS == 2;
   static constexpr int STAGE = NS == 3 ? STAGE3 : UNITS * 8192;
-  static constexpr int LDS = NS * STAGE + WB;
+  static constexpr int LDS = NS * STAGE + WB + RED_LDS;
   static constexpr bool FITS = LDS <= 160 * 1024;
   static constexpr int NDMA = 2 * TI + 2 * TJ + (POOL ? (GREG ? 2 * TJ : 2) : 2 * TJ);   // vector-memory operations per wave and stage
   static constexpr int NST = DX ? 4 * TI : 0;                           // dX stores per wave and tile
   static constexpr int WAITN = (NS - 2) * (NDMA + NST) + NST;
 };
 
-template <int TI, int TJ, bool POOL, bool DX, bool XT = false>
+template <int TI, int TJ, bool POOL, bool DX, bool XT = false, bool RED = false>
 __global__ __launch_bounds__(256) void sa_bwd_kernel(const SaBwdArgs ar) {
-  using C = SaBwdCfg<TI, TJ, POOL, DX>;
+  static_assert(!RED || (XT && DX), "the previous layer's reduction needs the deferred input and its gradient");
+  using C = SaBwdCfg<TI, TJ, POOL, DX, RED>;
   constexpr int STAGE = C::STAGE, NS = C::NS, WB = C::WB;
   static_assert(C::FITS && C::WAITN <= 63, "LDS / counted waits");
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS];
   unsigned char *const wimg = smem;
   unsigned char *const stages = smem + WB;
+  [[maybe_unused]] float4 *const s_prev = reinterpret_cast<float4 *>(smem + WB + NS * STAGE);   // RED: [channel] = (sc, sh, mean, rstd)
   const unsigned DEAD = 0x80000000u;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -198,6 +205,18 @@ __global__ __launch_bounds__(256) void sa_bwd_kernel(const SaBwdArgs ar) {
   const int xc_q = (lane & 15) >> 2;
   const int xcg = (xc_q >> 1) | ((q4 & 1) << 1), xc0 = (8 * q4 + xc_q) * 128 + 8 * (lane & 3);
 
+  [[maybe_unused]] float r_b[RED ? TI : 1][4][4], r_g[RED ? TI : 1][4][4];   // RED: sums of g and g xhat, this lane's channels
+  if constexpr (RED) {
+    for (int c = tid; c < TI * 64; c += 256)
+      s_prev[c] = c < ar.ldx ? make_float4(ar.xscale[c], ar.xshift[c], ar.xmean[c], ar.xrstd[c]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < TI; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { r_b[u][t][e] = 0.f; r_g[u][t][e] = 0.f; }
+  }
+
   f32x4 acc[TI][TJ][2][2];
 #pragma unroll
   for (int u = 0; u < TI; ++u)
@@ -257,7 +276,7 @@ __global__ __launch_bounds__(256) void sa_bwd_kernel(const SaBwdArgs ar) {
         }
       }
     }
-    if constexpr (XT) {
+    auto transform_x = [&]() {   // XT: relu(x xscale + xshift) in place, this wave's own rows; rows past the end become 0
 #pragma unroll
       for (int u = 0; u < TI; ++u)
 #pragma unroll
@@ -266,13 +285,14 @@ __global__ __launch_bounds__(256) void sa_bwd_kernel(const SaBwdArgs ar) {
           const int pos = cp ^ ((((lane >> 4) & 1) | (d << 1)) << 1);
           unsigned char *pp = buf + u * 8192 + row * 128 + pos * 16;
           const bf16x8 v = *reinterpret_cast<const bf16x8 *>(pp);
-          const bool inside = (long)(kt0 + step) * 64 + row < ar.R;   // rows past the end stay 0: their dP is not
+          const bool inside = (long)(kt0 + step) * 64 + row < ar.R;   // (their dP is not zero)
           bf16x8 o;
 #pragma unroll
           for (int i = 0; i < 8; ++i) o[i] = (__bf16)(inside ? fmaxf((float)v[i] * x_sc[u][i] + x_sh[u][i], 0.0f) : 0.0f);
           *reinterpret_cast<bf16x8 *>(pp) = o;
         }
-    }
+    };
+    if constexpr (XT && !RED) transform_x();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     BQ_BARRIER();   // every wave's X rows have landed and its dP rows are written; the previous tile's reads are done
     stage(step + NS - 1);
@@ -310,6 +330,31 @@ __global__ __launch_bounds__(256) void sa_bwd_kernel(const SaBwdArgs ar) {
           pk[1] = pack_bf16x2(accx[u][t][2], accx[u][t][3]);
           __builtin_amdgcn_raw_buffer_store_b64(pk, rsO, (col < ar.ldx && r < ar.R) ? (unsigned)((r * ar.ldx + col) * 2) : DEAD, 0, 0);
         }
+      if constexpr (RED) {
+        // ---- the previous layer's BatchNorm reduction: g = this row's dX (as stored: bf16) where that layer's ReLU passed,
+        // xhat from its pre-activation -- the x tile, still untransformed, this wave's own rows ------------------------------
+        const bool live = r < ar.R;
+#pragma unroll
+        for (int u = 0; u < TI; ++u)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int chunk = 2 * t + (q4 >> 1);
+            const bf16x4 pv = *reinterpret_cast<const bf16x4 *>(buf + u * 8192 + rowx * 128 + ((chunk ^ (xg(rowx) << 1)) << 4) +
+                                                                (q4 & 1) * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float4 k = s_prev[u * 64 + t * 16 + q4 * 4 + e];   // (sc, sh, mean, rstd)
+              const float xf = (float)pv[e];
+              float g = (float)(__bf16)accx[u][t][e];
+              if (!live || !(xf * k.x + k.y > 0.0f)) g = 0.0f;
+              r_b[u][t][e] += g;
+              r_g[u][t][e] += g * ((xf - k.z) * k.w);
+            }
+          }
+        transform_x();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        BQ_BARRIER();   // every wave's x rows are the activation now
+      }
     }
 
     // ---- dW += dP^T X: contraction over the tile's 64 rows ----------------------------------------------------------------------
@@ -355,6 +400,25 @@ __global__ __launch_bounds__(256) void sa_bwd_kernel(const SaBwdArgs ar) {
                 make_float4(acc[u][v][a][b][0], acc[u][v][a][b][1], acc[u][v][a][b][2], acc[u][v][a][b][3]);
         }
       }
+  if constexpr (RED) {
+    // one record per (workgroup, wave): the 16 lanes of a q4 group hold different rows of the same four channels
+    float *rec = ar.red_part + ((long)blockIdx.x * 4 + wave) * 2 * ar.ldx;
+#pragma unroll
+    for (int u = 0; u < TI; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float sb = r_b[u][t][e], sg = r_g[u][t][e];
+          sb += dpp_f32_add<0x111>(sb); sb += dpp_f32_add<0x112>(sb); sb += dpp_f32_add<0x114>(sb); sb += dpp_f32_add<0x118>(sb);
+          sg += dpp_f32_add<0x111>(sg); sg += dpp_f32_add<0x112>(sg); sg += dpp_f32_add<0x114>(sg); sg += dpp_f32_add<0x118>(sg);
+          const int c = u * 64 + t * 16 + q4 * 4 + e;
+          if (row16 == 15 && c < ar.ldx) {
+            rec[c] = sb;
+            rec[ar.ldx + c] = sg;
+          }
+        }
+  }
 }
 
 // pooled layers: dbeta / dgamma partial sums from the arg-max table -- one pre-activation value per (group, channel) instead of
@@ -391,10 +455,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_arg_kernel(const __bf16 *__
   }
 }
 
-template <int TI, int TJ, bool POOL, bool DX, bool XT = false>
+template <int TI, int TJ, bool POOL, bool DX, bool XT = false, bool RED = false>
 static int launch_sa_bwd(int wgs, hipStream_t st, const SaBwdArgs &a) {
-  if constexpr (SaBwdCfg<TI, TJ, POOL, DX>::FITS) {
-    hipLaunchKernelGGL((sa_bwd_kernel<TI, TJ, POOL, DX, XT>), dim3(wgs), dim3(256), 0, st, a);
+  if constexpr (SaBwdCfg<TI, TJ, POOL, DX, RED>::FITS) {
+    hipLaunchKernelGGL((sa_bwd_kernel<TI, TJ, POOL, DX, XT, RED>), dim3(wgs), dim3(256), 0, st, a);
     return 0;
   }
   return -1;
@@ -403,17 +467,22 @@ static int launch_sa_bwd(int wgs, hipStream_t st, const SaBwdArgs &a) {
 template <int TI, int TJ>
 static int launch_sa_bwd_pd(bool pool, bool dx, int wgs, hipStream_t st, const SaBwdArgs &a) {
   if (a.xscale) {   // a deferred input always wants its gradient, and is 64 or 128 channels wide
-    if constexpr (TI <= 2) return pool ? launch_sa_bwd<TI, TJ, true, true, true>(wgs, st, a) : launch_sa_bwd<TI, TJ, false, true, true>(wgs, st, a);
+    if constexpr (TI <= 2) {
+      if (a.red_part)
+        return pool ? launch_sa_bwd<TI, TJ, true, true, true, true>(wgs, st, a) : launch_sa_bwd<TI, TJ, false, true, true, true>(wgs, st, a);
+      return pool ? launch_sa_bwd<TI, TJ, true, true, true>(wgs, st, a) : launch_sa_bwd<TI, TJ, false, true, true>(wgs, st, a);
+    }
     return -1;
   }
   if (pool) return dx ? launch_sa_bwd<TI, TJ, true, true>(wgs, st, a) : launch_sa_bwd<TI, TJ, true, false>(wgs, st, a);
   return dx ? launch_sa_bwd<TI, TJ, false, true>(wgs, st, a) : launch_sa_bwd<TI, TJ, false, false>(wgs, st, a);
 }
 
-static int sa_bwd_lds(int ti, int tj, bool pool, bool dx) {
+static int sa_bwd_lds(int ti, int tj, bool pool, bool dx, bool red = false) {
   const int units = ti + tj * (pool ? 1 : 2), stage3 = units * 8192 + (pool ? 8192 : 0), wb = dx ? ti * tj * 8192 : 0;
-  const bool two = BQ_SA_PREFER_TWO && 2 * units * 8192 + wb <= 80 * 1024 && 3 * stage3 + wb > 80 * 1024;
-  return (3 * stage3 + wb <= 160 * 1024 && !two) ? 3 * stage3 + wb : 2 * units * 8192 + wb;
+  const int rl = red ? ti * 64 * 16 : 0;
+  const bool two = BQ_SA_PREFER_TWO && 2 * units * 8192 + wb + rl <= 80 * 1024 && 3 * stage3 + wb + rl > 80 * 1024;
+  return ((3 * stage3 + wb + rl <= 160 * 1024 && !two) ? 3 * stage3 + wb : 2 * units * 8192 + wb) + rl;
 }
 
 }  // namespace bq
@@ -427,12 +496,17 @@ extern "C" int bq_sa_bwd_supported(int ldx, int Nj, int S, int pool, int need_dx
   return sa_bwd_lds(ti, tj, pool != 0, need_dx != 0) <= 160 * 1024;
 }
 
-extern "C" int bq_sa_bwd_workgroups(long R, int ldx, int Nj, int pool, int need_dx) {
+static int sa_bwd_wgs(long R, int ldx, int Nj, int pool, int need_dx, bool red) {
   const int ti = (ldx + 63) / 64, tj = Nj / 64;
   const long nkt = (R + 63) / 64;
-  long wgs = sa_bwd_lds(ti, tj, pool != 0, need_dx != 0) <= 80 * 1024 ? 512 : 256;
+  long wgs = sa_bwd_lds(ti, tj, pool != 0, need_dx != 0, red) <= 80 * 1024 ? 512 : 256;
   if (wgs > nkt) wgs = nkt;
   return (int)(wgs < 1 ? 1 : wgs);
+}
+
+// (an upper bound for every form of the call: the form that carries the previous layer's reduction may run fewer workgroups)
+extern "C" int bq_sa_bwd_workgroups(long R, int ldx, int Nj, int pool, int need_dx) {
+  return sa_bwd_wgs(R, ldx, Nj, pool, need_dx, false);
 }
 
 // The fused backward of a SharedMLP layer after its BatchNorm reduction (dgb): dX bf16 (R, ldx) (null: not needed) and
@@ -455,6 +529,29 @@ extern "C" int bq_sa_bwd_fused_x(const void *x, const float *xscale, const float
                                  const void *arg, const void *w, const float *scale, const float *shift, const float *mean,
                                  const float *rstd, const float *dgb, void *dx, float *dw, float *part, long R, int ldx, int Nj,
                                  int ldw, int ldo, int S, int relu, int pool, void *stream) {
+  return bq_sa_bwd_fused_xr(x, xscale, xshift, nullptr, nullptr, nullptr, nullptr, p, dout, arg, w, scale, shift, mean, rstd, dgb,
+                            dx, dw, part, R, ldx, Nj, ldw, ldo, S, relu, pool, stream);
+}
+
+// 1 when bq_sa_bwd_fused_xr can also carry the previous layer's reduction for this shape (its LDS table still fits)
+extern "C" int bq_sa_bwd_reduce_supported(int ldx, int Nj, int S, int pool) {
+  const int ti = (ldx + 63) / 64, tj = Nj / 64;
+  if (!(ldx == 64 || ldx == 128) || !bq_sa_bwd_supported(ldx, Nj, S, pool, 1)) return 0;
+  return sa_bwd_lds(ti, tj, pool != 0, true, true) <= 160 * 1024;
+}
+
+// ... and with the PREVIOUS layer's BatchNorm reduction riding on the pass (VERDICT r4 item 3a's first half: "the BatchNorm
+// reduce in the epilogue of the next layer's dX GEMM"): that layer's dOut is this call's dx, its pre-activation this call's x.
+// xmean / xrstd: that layer's mean / rstd; red_part: scratch of bq_sa_bwd_workgroups(...) * 4 * 2 * ldx floats; red_dgb: f32
+// (2, ldx) = its dbeta | dgamma (what bq_bn_backward_reduce would return for it).  red_dgb == NULL: bq_sa_bwd_fused_x.
+extern "C" int bq_sa_bwd_fused_xr(const void *x, const float *xscale, const float *xshift, const float *xmean, const float *xrstd,
+                                  float *red_part, float *red_dgb, const void *p, const void *dout, const void *arg, const void *w,
+                                  const float *scale, const float *shift, const float *mean, const float *rstd, const float *dgb,
+                                  void *dx, float *dw, float *part, long R, int ldx, int Nj, int ldw, int ldo, int S, int relu,
+                                  int pool, void *stream) {
+  BQ_REQUIRE(!red_dgb || (xscale && xmean && xrstd && red_part && bq_sa_bwd_reduce_supported(ldx, Nj, S, pool)), BQ_EINVAL,
+             "bq_sa_bwd_fused_xr: the carried reduction needs a deferred input, its mean / rstd, scratch and a shape with room "
+             "for its table (ldx=%d Nj=%d pool=%d)", ldx, Nj, pool);
   BQ_REQUIRE(!xscale || (xshift && dx && (ldx == 64 || ldx == 128)), BQ_EINVAL,
              "bq_sa_bwd_fused_x: a deferred input needs xshift, dx and ldx = 64 or 128 (ldx=%d)", ldx);
   BQ_REQUIRE(x && p && dout && scale && shift && mean && rstd && dgb && dw && part && R > 0, BQ_EINVAL,
@@ -475,6 +572,7 @@ extern "C" int bq_sa_bwd_fused_x(const void *x, const float *xscale, const float
   a.X = (const __bf16 *)x; a.P = (const __bf16 *)p; a.dOut = (const __bf16 *)dout; a.arg = (const unsigned char *)arg;
   a.W = (const __bf16 *)w; a.scale = scale; a.shift = shift; a.mean = mean; a.rstd = rstd; a.dgb = dgb;
   a.dX = (__bf16 *)dx; a.part = part; a.xscale = xscale; a.xshift = xshift;
+  a.xmean = xmean; a.xrstd = xrstd; a.red_part = red_dgb ? red_part : nullptr;
   a.R = (int)R; a.ldx = ldx; a.Nj = Nj; a.ldw = ldw; a.ldo = ldo; a.S = pool ? S : 1; a.relu = relu;
   a.x_bytes = (unsigned)(R * (long)ldx * 2);
   a.p_bytes = (unsigned)(R * (long)Nj * 2);
@@ -482,7 +580,7 @@ extern "C" int bq_sa_bwd_fused_x(const void *x, const float *xscale, const float
   a.a_bytes = pool ? (unsigned)((R / S) * (long)Nj) : 0u;
   a.w_bytes = w ? (unsigned)((long)Nj * ldw * 2) : 0u;
   a.dx_bytes = a.x_bytes;
-  const int wgs = bq_sa_bwd_workgroups(R, ldx, Nj, pool, dx != nullptr);
+  const int wgs = sa_bwd_wgs(R, ldx, Nj, pool, dx != nullptr, red_dgb != nullptr);
   const int ti = (ldx + 63) / 64, tj = Nj / 64;
   hipStream_t st = (hipStream_t)stream;
   int rc = -1;
@@ -494,6 +592,10 @@ extern "C" int bq_sa_bwd_fused_x(const void *x, const float *xscale, const float
   else if (ti == 3 && tj == 1) rc = launch_sa_bwd_pd<3, 1>(pool, dx != nullptr, wgs, st, a);
   else if (ti == 3 && tj == 2) rc = launch_sa_bwd_pd<3, 2>(pool, dx != nullptr, wgs, st, a);
   BQ_REQUIRE(rc == 0, BQ_EINVAL, "bq_sa_bwd_fused: no kernel for %d x %d units", ti, tj);
+  if (a.red_part) {
+    const int frc = bq_bn_fold(red_part, red_dgb, wgs * 4, 2 * ldx, stream);
+    if (frc) return frc;
+  }
   return bq_wgrad_rows_reduce(part, dw, ldx, Nj, ldo, wgs, stream);
 }
 

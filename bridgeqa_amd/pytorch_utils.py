@@ -100,7 +100,7 @@ class _ConvBNReLUPointMajor(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, conv_weight, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, relu,
-                pool, S, conv_bias=None, x_stats=None, defer=False):
+                pool, S, conv_bias=None, x_stats=None, defer=False, link_in=None, link_out=None):
         """Deferred activations (round 5, SharedMLP.forward wires them): with `defer` the layer skips its BatchNorm + ReLU
         pass and returns (its stored pre-activation, its stats) -- the NEXT layer, called with x = that pre-activation and
         x_stats = those stats, applies relu(x scale + shift) tile by tile inside its convolution kernel and, in the backward,
@@ -130,6 +130,9 @@ class _ConvBNReLUPointMajor(torch.autograd.Function):
         ctx.save_for_backward(x, w_pad, y_raw, stats, arg, x_stats)
         ctx.cfg = (K, S, relu, pool)
         ctx.conv_weight, ctx.conv_bias = conv_weight, conv_bias
+        # link_in / link_out: dicts shared with the previous / next layer of the SharedMLP -- the next layer's fused backward
+        # leaves this layer's dbeta | dgamma in link_out["dgb"] (the reduction rides on its pass: bq_sa_bwd_fused_xr)
+        ctx.link_in, ctx.link_out = link_in, link_out
         if defer:
             ctx.mark_non_differentiable(stats)
             return y_raw, stats
@@ -150,13 +153,20 @@ class _ConvBNReLUPointMajor(torch.autograd.Function):
                 and (x_stats is None or need_dx)
                 and _ext.sa_bwd_supported(ldx, N, S, pool, need_dx) and R * max(ldx, N) * 2 < (1 << 31) - (1 << 20)):
             # the BatchNorm reduction, then ONE pass over the activations for dX and dW (csrc/detbwd.hip)
-            dgb = _ext.bn_bwd_reduce(dout, y_raw, stats, S, relu, pool, arg)
+            dgb = ctx.link_out.pop("dgb", None) if ctx.link_out is not None else None   # (summed by the next layer's pass)
+            if dgb is None:
+                dgb = _ext.bn_bwd_reduce(dout, y_raw, stats, S, relu, pool, arg)
             xs = torch.as_strided(x, (R, ldx), (ldx, 1))
-            dx_full, dwf = _ext.sa_bwd_fused(xs, y_raw, dout, arg, w_pad, stats, dgb, S, relu, pool, need_dx, x_stats=x_stats)
+            carry = x_stats is not None and ctx.link_in is not None and _ext.CARRY_REDUCE[0]
+            res = _ext.sa_bwd_fused(xs, y_raw, dout, arg, w_pad, stats, dgb, S, relu, pool, need_dx, x_stats=x_stats,
+                                    carry_reduce=carry)
+            dx_full, dwf = res[0], res[1]
+            if carry and res[2] is not None:
+                ctx.link_in["dgb"] = res[2]
             dx = dx_full[:, :x.shape[1]] if need_dx else None
             dw = dwf[:, :K].reshape(ctx.conv_weight.shape)
             dcb = torch.zeros_like(ctx.conv_bias) if ctx.conv_bias is not None else None
-            return dx, dw, dgb[1], dgb[0], None, None, None, None, None, None, None, None, dcb, None, None
+            return dx, dw, dgb[1], dgb[0], None, None, None, None, None, None, None, None, dcb, None, None, None, None
         if x_stats is not None:
             # (a deferred input on the four-kernel path -- the fused kernel switched off between forward and backward, or an
             # operand beyond its 2 GB bound: the activation is formed once, now)
@@ -182,7 +192,9 @@ class _ConvBNReLUPointMajor(torch.autograd.Function):
                                   _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32, _ext.EPI_NONE, 64)
             dw = dwf[:, :K].reshape(ctx.conv_weight.shape)
         dcb = torch.zeros_like(ctx.conv_bias) if ctx.conv_bias is not None else None
-        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None, dcb, None, None
+        if ctx.link_out is not None:
+            ctx.link_out.pop("dgb", None)
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None, dcb, None, None, None, None
 
 
 CENTER_PREACT = [True]      # SharedMLP pre-activations stored relative to running_mean (tools/loss_gap_probe.py)
@@ -395,16 +407,19 @@ class SharedMLP(nn.Sequential):
             B, _, M, S = x.shape
             last = len(self) - 1
             layers = list(self)
-            x_stats = None
+            x_stats = link = None
             for i, layer in enumerate(layers):
                 bn = layer.bn.bn
                 # (round 5) the BatchNorm + ReLU between two convolutions is not materialised where the next layer can apply
                 # it on load, forward and backward: this layer hands over its stored pre-activation and its stats
                 defer = i < last and _defer_ok(rows, layer, layers[i + 1], S, pool and i + 1 == last)
+                nxt_link = {} if defer else None
                 res = _ConvBNReLUPointMajor.apply(rows, layer.conv.weight, bn.weight, bn.bias, bn.running_mean,
                                                   bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum,
-                                                  hasattr(layer, "activation"), pool and i == last, S, None, x_stats, defer)
+                                                  hasattr(layer, "activation"), pool and i == last, S, None, x_stats, defer,
+                                                  link, nxt_link)
                 rows, x_stats = res if defer else (res, None)
+                link = nxt_link
             C = rows.shape[1]
             return rows.view(B, M, C) if pool else rows.view(B, M, S, C).permute(0, 3, 1, 2)
         if rows is not None and not x.is_contiguous(memory_format=torch.channels_last):

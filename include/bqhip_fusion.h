@@ -190,6 +190,16 @@ BQ_API int bq_pwconv_bn_fwd_x(const void *x, const float *xscale, const float *x
                               float *running_mean, float *running_var, long long *num_batches_tracked, float eps,
                               float momentum, float *scale, float *shift, float *mean, float *rstd, const float *center,
                               float *shift_acc, void *stream);
+/* ... and with the PREVIOUS layer's BatchNorm reduction riding on the pass: that layer's dOut is this call's dx, its stored
+ * pre-activation this call's x.  xmean / xrstd: its mean / rstd; red_part: bq_sa_bwd_workgroups(...) * 4 * 2 * ldx floats of
+ * scratch; red_dgb f32 (2, ldx) = its dbeta | dgamma (what bq_bn_backward_reduce returns for it).  red_dgb == NULL:
+ * bq_sa_bwd_fused_x.  bq_sa_bwd_reduce_supported: 1 when the shape has room for the reduction's table. */
+BQ_API int bq_sa_bwd_reduce_supported(int ldx, int Nj, int S, int pool);
+BQ_API int bq_sa_bwd_fused_xr(const void *x, const float *xscale, const float *xshift, const float *xmean, const float *xrstd,
+                              float *red_part, float *red_dgb, const void *p, const void *dout, const void *arg, const void *w,
+                              const float *scale, const float *shift, const float *mean, const float *rstd, const float *dgb,
+                              void *dx, float *dw, float *part, long R, int ldx, int Nj, int ldw, int ldo, int S, int relu,
+                              int pool, void *stream);
 BQ_API int bq_sa_bwd_fused_x(const void *x, const float *xscale, const float *xshift, const void *p, const void *dout,
                              const void *arg, const void *w, const float *scale, const float *shift, const float *mean,
                              const float *rstd, const float *dgb, void *dx, float *dw, float *part, long R, int ldx, int Nj,

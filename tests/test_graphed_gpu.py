@@ -15,6 +15,18 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _teardown_process_group():
+    """RCCL's communicator goes LAST: one full-suite run in seven aborted inside destroy_process_group() while the test's
+    captured graphs (which hold collectives on the communication stream) were still alive in the test's frame"""
+    import gc
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    gc.collect()
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def _setup(dev):
     import bench
     from bridgeqa_amd.hotpath import ScanQAHotPath
@@ -325,44 +337,46 @@ def test_enable_refuses_a_ddp_wrap_and_exchanges_gradients_itself_on_rccl_world_
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", RANK="0", WORLD_SIZE="1")
     dist.init_process_group(backend="nccl", init_method="env://", rank=0, world_size=1)
     try:
-        model, batch = _setup(dev)
-        with pytest.raises(TypeError, match="DistributedDataParallel"):
-            graphed.enable(torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=True))
-        graphed.enable(model)
-        bench.total_loss(model(dict(batch))).backward()
-        torch.cuda.synchronize()
-        assert model._graphed.reducers is None          # one rank: no exchange
-        n_grads = sum(1 for p in model.parameters() if p.grad is not None)
-        graphed.disable(model)
-        graphed.enable(model)
-        model._graphed.force_comm = True                 # the world-1 collectives run for real
-        bench.total_loss(model(dict(batch))).backward()  # (captures; builds the groups)
-        torch.cuda.synchronize()
-        runner = model._graphed
-        assert set(runner.reducers) == {"fusion", "rest"} and runner.broadcaster is not None
-        ids = [id(p) for r in runner.reducers.values() for p in r.params]
-        assert len(ids) == len(set(ids)) == n_grads
-        late = {id(p) for p in runner.reducers["rest"].params}
-        names = {id(p): n for n, p in model.named_parameters()}
-        assert any("embeddings" in names[i] for i in late) and any("visual_encoder" in names[i] for i in late)
-        assert all(names[id(p)].startswith("blip_model.") and "visual_encoder" not in names[id(p)]
-                   for p in runner.reducers["fusion"].params)
-        # what every group packs (on the communication stream, when its turn comes) against the step's final gradients
-        packed = {}
-        for name, r in runner.reducers.items():
-            orig = r.all_reduce
+        def _body():   # (its locals -- steps, graphs, reducers -- are gone before the process group is)
+            model, batch = _setup(dev)
+            with pytest.raises(TypeError, match="DistributedDataParallel"):
+                graphed.enable(torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=True))
+            graphed.enable(model)
+            bench.total_loss(model(dict(batch))).backward()
+            torch.cuda.synchronize()
+            assert model._graphed.reducers is None          # one rank: no exchange
+            n_grads = sum(1 for p in model.parameters() if p.grad is not None)
+            graphed.disable(model)
+            graphed.enable(model)
+            model._graphed.force_comm = True                 # the world-1 collectives run for real
+            bench.total_loss(model(dict(batch))).backward()  # (captures; builds the groups)
+            torch.cuda.synchronize()
+            runner = model._graphed
+            assert set(runner.reducers) == {"fusion", "rest"} and runner.broadcaster is not None
+            ids = [id(p) for r in runner.reducers.values() for p in r.params]
+            assert len(ids) == len(set(ids)) == n_grads
+            late = {id(p) for p in runner.reducers["rest"].params}
+            names = {id(p): n for n, p in model.named_parameters()}
+            assert any("embeddings" in names[i] for i in late) and any("visual_encoder" in names[i] for i in late)
+            assert all(names[id(p)].startswith("blip_model.") and "visual_encoder" not in names[id(p)]
+                       for p in runner.reducers["fusion"].params)
+            # what every group packs (on the communication stream, when its turn comes) against the step's final gradients
+            packed = {}
+            for name, r in runner.reducers.items():
+                orig = r.all_reduce
 
-            def spy(r=r, orig=orig, name=name):
-                packed[name] = [p.grad.detach().clone() for p in r.params]
-                orig()
-            r.all_reduce = spy
-        bench.total_loss(model(dict(batch))).backward()  # a pure replay
-        torch.cuda.synchronize()
-        assert set(packed) == {"fusion", "rest"}
-        for name, r in runner.reducers.items():
-            for p, g in zip(r.params, packed[name]):
-                assert torch.isfinite(p.grad).all() and torch.equal(p.grad, g), (name, names[id(p)])
-        graphed.disable(model)
+                def spy(r=r, orig=orig, name=name):
+                    packed[name] = [p.grad.detach().clone() for p in r.params]
+                    orig()
+                r.all_reduce = spy
+            bench.total_loss(model(dict(batch))).backward()  # a pure replay
+            torch.cuda.synchronize()
+            assert set(packed) == {"fusion", "rest"}
+            for name, r in runner.reducers.items():
+                for p, g in zip(r.params, packed[name]):
+                    assert torch.isfinite(p.grad).all() and torch.equal(p.grad, g), (name, names[id(p)])
+            graphed.disable(model)
+        _body()
     finally:
-        dist.destroy_process_group()
+        _teardown_process_group()
         ops.set_compute_dtype(prev)

@@ -7,6 +7,18 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _teardown_process_group():
+    """RCCL's communicator goes LAST: one full-suite run in seven aborted inside destroy_process_group() while the test's
+    captured graphs (which hold collectives on the communication stream) were still alive in the test's frame"""
+    import gc
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    gc.collect()
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def _small_model(dev):
     from bridgeqa_amd.hotpath import ScanQAHotPath
     torch.manual_seed(0)
@@ -317,26 +329,28 @@ def test_bf16_wire_against_fp32_wire_through_rccl(dev):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", RANK="0", WORLD_SIZE="1")
     dist.init_process_group(backend="nccl", init_method="env://", rank=0, world_size=1)
     try:
-        g = torch.Generator().manual_seed(11)
-        shapes = [(768, 3072), (3072,), (2304, 768), (30524, 768), (5, 3, 7), (1,)]
-        for algo in ("all_reduce", "reduce_scatter"):
-            for dt, bound in ((torch.float32, 0.0), (torch.bfloat16, 4e-3)):
-                ps = [torch.nn.Parameter(torch.zeros(*sh, device=dev)) for sh in shapes]
-                want = []
-                for p in ps:
-                    p.grad = (torch.randn(*p.shape, generator=g) * 10.0 ** float(torch.randint(-4, 1, (1,), generator=g))).to(dev)
-                    want.append(p.grad.clone())
-                r = PackedGradReducer(ps, comm_dtype=dt, algo=algo)
-                r.force = True
-                r.timing = []
-                r.all_reduce()
-                torch.cuda.synchronize()
-                num = sum((p.grad - w).double().pow(2).sum().item() for p, w in zip(ps, want))
-                den = sum(w.double().pow(2).sum().item() for w in want)
-                assert (num / den) ** 0.5 <= bound, (algo, dt, (num / den) ** 0.5)
-                assert r.comm_ms() is not None and r.comm_ms() > 0
+        def _body():   # (its locals -- steps, graphs, reducers -- are gone before the process group is)
+            g = torch.Generator().manual_seed(11)
+            shapes = [(768, 3072), (3072,), (2304, 768), (30524, 768), (5, 3, 7), (1,)]
+            for algo in ("all_reduce", "reduce_scatter"):
+                for dt, bound in ((torch.float32, 0.0), (torch.bfloat16, 4e-3)):
+                    ps = [torch.nn.Parameter(torch.zeros(*sh, device=dev)) for sh in shapes]
+                    want = []
+                    for p in ps:
+                        p.grad = (torch.randn(*p.shape, generator=g) * 10.0 ** float(torch.randint(-4, 1, (1,), generator=g))).to(dev)
+                        want.append(p.grad.clone())
+                    r = PackedGradReducer(ps, comm_dtype=dt, algo=algo)
+                    r.force = True
+                    r.timing = []
+                    r.all_reduce()
+                    torch.cuda.synchronize()
+                    num = sum((p.grad - w).double().pow(2).sum().item() for p, w in zip(ps, want))
+                    den = sum(w.double().pow(2).sum().item() for w in want)
+                    assert (num / den) ** 0.5 <= bound, (algo, dt, (num / den) ** 0.5)
+                    assert r.comm_ms() is not None and r.comm_ms() > 0
+        _body()
     finally:
-        dist.destroy_process_group()
+        _teardown_process_group()
 
 
 def test_data_parallel_step_on_rccl_world_1_equals_the_plain_step(dev):
@@ -352,34 +366,36 @@ def test_data_parallel_step_on_rccl_world_1_equals_the_plain_step(dev):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", RANK="0", WORLD_SIZE="1")
     dist.init_process_group(backend="nccl", init_method="env://", rank=0, world_size=1)
     try:
-        model = _small_model(dev)
-        batch = _batch(dev)
-        plain = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, optimizer=None, use_graphs=False)
-        plain.capture(warmup=0)
-        want_loss = plain.eager_step().item()
-        torch.cuda.synchronize()
-        want = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
-        dp = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, optimizer=None, use_graphs=False)
+        def _body():   # (its locals -- steps, graphs, reducers -- are gone before the process group is)
+            model = _small_model(dev)
+            batch = _batch(dev)
+            plain = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, optimizer=None, use_graphs=False)
+            plain.capture(warmup=0)
+            want_loss = plain.eager_step().item()
+            torch.cuda.synchronize()
+            want = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+            dp = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, optimizer=None, use_graphs=False)
 
-        def make(ps):
-            r = PackedGradReducer(ps)       # fp32 on the wire
-            r.force = True                  # run the collective although the world has one rank
-            return r
-        reds = dp.attach_reducers(make)
-        assert set(reds) == {"fusion", "image", "det"}
-        dp.capture(warmup=0)
-        got_loss = dp.eager_step().item()
-        dp.wait()
-        torch.cuda.synchronize()
-        check_coverage(model, reds.values())
-        got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
-        assert set(got) == set(want)
-        assert abs(got_loss - want_loss) <= 1e-4 * abs(want_loss)
-        worst = max(((got[n] - want[n]).norm() / (want[n].norm() + 1e-12)).item() for n in want)
-        assert worst < 2e-3, worst          # fp32 atomics of the detector backward; the all-reduce itself is exact at world 1
-        assert sum(r.nbytes_on_wire() for r in reds.values()) == 4 * sum(p.numel() for p in model.parameters() if p.grad is not None)
+            def make(ps):
+                r = PackedGradReducer(ps)       # fp32 on the wire
+                r.force = True                  # run the collective although the world has one rank
+                return r
+            reds = dp.attach_reducers(make)
+            assert set(reds) == {"fusion", "image", "det"}
+            dp.capture(warmup=0)
+            got_loss = dp.eager_step().item()
+            dp.wait()
+            torch.cuda.synchronize()
+            check_coverage(model, reds.values())
+            got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+            assert set(got) == set(want)
+            assert abs(got_loss - want_loss) <= 1e-4 * abs(want_loss)
+            worst = max(((got[n] - want[n]).norm() / (want[n].norm() + 1e-12)).item() for n in want)
+            assert worst < 2e-3, worst          # fp32 atomics of the detector backward; the all-reduce itself is exact at world 1
+            assert sum(r.nbytes_on_wire() for r in reds.values()) == 4 * sum(p.numel() for p in model.parameters() if p.grad is not None)
+        _body()
     finally:
-        dist.destroy_process_group()
+        _teardown_process_group()
 
 
 def test_split_image_backward_groups_and_buffer_broadcast_on_rccl_world_1(dev):
@@ -395,60 +411,62 @@ def test_split_image_backward_groups_and_buffer_broadcast_on_rccl_world_1(dev):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29654", RANK="0", WORLD_SIZE="1")
     dist.init_process_group(backend="nccl", init_method="env://", rank=0, world_size=1)
     try:
-        model = _small_model(dev)
-        batch = _batch(dev)
-        plain = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, optimizer=None, use_graphs=False)
-        plain.capture(warmup=0)
-        want_loss = plain.eager_step().item()
-        torch.cuda.synchronize()
-        want = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
-        bb = BufferBroadcaster(model)
-        bb.force = True
-        dp = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, optimizer=None, use_graphs=True,
-                             image_bwd_splits=3, buffer_broadcaster=bb, coverage_every=2)
-        assert dp._vit_cuts == (4, 8) and model.blip_model.visual_encoder.grad_cuts == ()   # scoped, not module state
+        def _body():   # (its locals -- steps, graphs, reducers -- are gone before the process group is)
+            model = _small_model(dev)
+            batch = _batch(dev)
+            plain = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, optimizer=None, use_graphs=False)
+            plain.capture(warmup=0)
+            want_loss = plain.eager_step().item()
+            torch.cuda.synchronize()
+            want = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+            bb = BufferBroadcaster(model)
+            bb.force = True
+            dp = PhasedTrainStep(model, batch, bench.det_loss, bench.fusion_loss, optimizer=None, use_graphs=True,
+                                 image_bwd_splits=3, buffer_broadcaster=bb, coverage_every=2)
+            assert dp._vit_cuts == (4, 8) and model.blip_model.visual_encoder.grad_cuts == ()   # scoped, not module state
 
-        def make(ps):
-            r = PackedGradReducer(ps)
-            r.force = True
-            return r
-        reds = dp.attach_reducers(make)
-        assert set(reds) == {"fusion", "det", "image_0", "image_1", "image_2"}
-        ids = [id(p) for r in reds.values() for p in r.params]
-        assert len(ids) == len(set(ids))                                    # disjoint
-        names = {id(p): n for n, p in model.named_parameters()}
-        g0 = {names[id(p)] for p in reds["image_0"].params}
-        g2 = {names[id(p)] for p in reds["image_2"].params}
-        assert any(".blocks.11." in n for n in g0) and any(".blocks.0." in n for n in g2)
-        assert any("patch_embed" in n for n in g2) and not any(".blocks.0." in n for n in g0)
-        got_loss = dp.eager_step().item()
-        dp.wait()
-        torch.cuda.synchronize()
-        check_coverage(model, reds.values())
-        got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
-        assert set(got) == set(want)
-        assert abs(got_loss - want_loss) <= 1e-4 * abs(want_loss)
-        worst = max((((got[n] - want[n]).norm() / (want[n].norm() + 1e-12)).item(), n) for n in want)
-        assert worst[0] < 4e-3, worst   # (fp32 atomics in the detector's scatter gradients: 1-2e-3 between two eager executions)
-        dp.capture(warmup=1)                                                # graphs: image_bwd, image_bwd_1, image_bwd_2
-        assert {"image_bwd", "image_bwd_1", "image_bwd_2"} <= set(dp.graphs) and "image_bwd_3" not in dp.graphs
-        for _ in range(4):                                                  # (coverage check every 2nd replayed step)
-            l = dp.step()
-        dp.wait()
-        torch.cuda.synchronize()
-        assert abs(l.item() - want_loss) <= 2e-3 * abs(want_loss), (l.item(), want_loss)
-        got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
-        worst = max((((got[n] - want[n]).norm() / (want[n].norm() + 1e-12)).item(), n) for n in want)
-        assert worst[0] < 4e-3, worst
-        # a plain forward + backward AFTER the split step was built still reaches the patch embedding
-        model.zero_grad(set_to_none=True)
-        dd = model(dict(batch))
-        (bench.det_loss(dd) + bench.fusion_loss(dd)).backward()
-        torch.cuda.synchronize()
-        assert model.blip_model.visual_encoder.patch_embed.proj.weight.grad is not None
-        assert model.blip_model.visual_encoder.blocks[0].attn.qkv.weight.grad is not None
+            def make(ps):
+                r = PackedGradReducer(ps)
+                r.force = True
+                return r
+            reds = dp.attach_reducers(make)
+            assert set(reds) == {"fusion", "det", "image_0", "image_1", "image_2"}
+            ids = [id(p) for r in reds.values() for p in r.params]
+            assert len(ids) == len(set(ids))                                    # disjoint
+            names = {id(p): n for n, p in model.named_parameters()}
+            g0 = {names[id(p)] for p in reds["image_0"].params}
+            g2 = {names[id(p)] for p in reds["image_2"].params}
+            assert any(".blocks.11." in n for n in g0) and any(".blocks.0." in n for n in g2)
+            assert any("patch_embed" in n for n in g2) and not any(".blocks.0." in n for n in g0)
+            got_loss = dp.eager_step().item()
+            dp.wait()
+            torch.cuda.synchronize()
+            check_coverage(model, reds.values())
+            got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+            assert set(got) == set(want)
+            assert abs(got_loss - want_loss) <= 1e-4 * abs(want_loss)
+            worst = max((((got[n] - want[n]).norm() / (want[n].norm() + 1e-12)).item(), n) for n in want)
+            assert worst[0] < 4e-3, worst   # (fp32 atomics in the detector's scatter gradients: 1-2e-3 between two eager executions)
+            dp.capture(warmup=1)                                                # graphs: image_bwd, image_bwd_1, image_bwd_2
+            assert {"image_bwd", "image_bwd_1", "image_bwd_2"} <= set(dp.graphs) and "image_bwd_3" not in dp.graphs
+            for _ in range(4):                                                  # (coverage check every 2nd replayed step)
+                l = dp.step()
+            dp.wait()
+            torch.cuda.synchronize()
+            assert abs(l.item() - want_loss) <= 2e-3 * abs(want_loss), (l.item(), want_loss)
+            got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+            worst = max((((got[n] - want[n]).norm() / (want[n].norm() + 1e-12)).item(), n) for n in want)
+            assert worst[0] < 4e-3, worst
+            # a plain forward + backward AFTER the split step was built still reaches the patch embedding
+            model.zero_grad(set_to_none=True)
+            dd = model(dict(batch))
+            (bench.det_loss(dd) + bench.fusion_loss(dd)).backward()
+            torch.cuda.synchronize()
+            assert model.blip_model.visual_encoder.patch_embed.proj.weight.grad is not None
+            assert model.blip_model.visual_encoder.blocks[0].attn.qkv.weight.grad is not None
+        _body()
     finally:
-        dist.destroy_process_group()
+        _teardown_process_group()
 
 
 def test_bn_momentum_change_recaptures_the_graphs(dev):

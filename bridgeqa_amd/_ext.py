@@ -23,7 +23,7 @@ if not os.path.exists(_LIB_PATH):
 _lib = ctypes.CDLL(_LIB_PATH)
 _lib.bq_last_error.restype = ctypes.c_char_p
 _lib.bq_abi_version.restype = ctypes.c_int
-ABI_VERSION = 5   # = BQHIP_ABI_VERSION of include/bqhip.h
+ABI_VERSION = 6   # = BQHIP_ABI_VERSION of include/bqhip.h
 if _lib.bq_abi_version() != ABI_VERSION:
     raise ImportError("bridgeqa_amd: libbqhip.so ABI %d != %d (stale library: python -m bridgeqa_amd.build --force)"
                       % (_lib.bq_abi_version(), ABI_VERSION))
@@ -57,6 +57,8 @@ _lib.bq_attn_fwd.argtypes = [_vp] * 6 + [_i] * 5 + [_l] * 9 + [_f, _f, _u, _vp, 
 _lib.bq_attn_fwd.restype = ctypes.c_int
 _lib.bq_attn_bwd.argtypes = [_vp] * 11 + [_i] * 5 + [_l] * 9 + [_f, _f, _u, _vp, _i, _vp]
 _lib.bq_attn_bwd.restype = ctypes.c_int
+_lib.bq_attn_set_persistent.argtypes = [_i]
+_lib.bq_attn_set_persistent.restype = ctypes.c_int
 _lib.bq_attn_probs.argtypes = [_vp] * 5 + [_i] * 5 + [_l] * 6 + [_f, _f, _u, _vp, _i, _vp]
 _lib.bq_attn_probs.restype = ctypes.c_int
 _lib.bq_drop_add_ln_fwd.argtypes = [_vp] * 9 + [_i, _i, _f, _f, _f, _i, _u, _vp, _vp]
@@ -387,6 +389,12 @@ def attn_probs(q, k, lse, scale, mask_log2=None, p_drop=0.0, seed=0, seed_tensor
                                   float(scale), float(p_drop), int(seed) & 0xFFFFFFFF, _p(seed_tensor), int(bool(causal)),
                                   _stream()), "attn_probs")
     return P
+
+
+def attn_set_persistent(mask):
+    """which passes of the unmasked attention use the resident-grid kernels (bit 0 forward, 1 dQ, 2 dK/dV); returns the
+    previous mask (include/bqhip_fusion.h: bq_attn_set_persistent)"""
+    return int(_lib.bq_attn_set_persistent(int(mask)))
 
 
 def attn_bwd(q, k, v, out, lse, grad_out, scale, dq, dk, dv, mask_log2=None, p_drop=0.0, seed=0, seed_tensor=None,

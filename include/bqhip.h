@@ -37,7 +37,7 @@ extern "C" {
  * tile 128 and BQ_GEMM_BACKGROUND arrived after 1 without a bump: a stale libbqhip.so must fail the version check, not a
  * symbol lookup or an EINVAL at its first launch.
  * 3 (round 4): bq_pwconv_bn_fwd took `center`, bq_transpose_multi_bf16 / bq_transpose_tensor_bytes arrived. */
-#define BQHIP_ABI_VERSION 5
+#define BQHIP_ABI_VERSION 6
 
 #if defined(__GNUC__)
 #define BQ_API __attribute__((visibility("default")))

@@ -64,6 +64,13 @@ BQ_API int bq_attn_probs(const void *Q, const void *K, const float *LSE, const f
                          int Lk, int Lkp, long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, float scale,
                          float p_drop, unsigned seed, const unsigned *seed_ptr, int causal, void *stream);
 
+/* ABI 6.  Which passes of the UNMASKED attention (no mask, not causal, no dropout: the ViT's, models/vit.py:72-84) run on the
+ * resident-grid kernels of csrc/attn.hip -- 3 / 3 / 2 workgroups per CU walking (head, row block) items as one stream of
+ * LDS tiles -- instead of one workgroup per block: bit 0 the forward, bit 1 the dQ pass, bit 2 the dK/dV pass.  Default 7;
+ * returns the previous mask.  Results are the same to rounding (tests/test_attn_gpu.py compares both against fp32 torch);
+ * the switch exists for A/B timing (tools/bench_attn.py). */
+BQ_API int bq_attn_set_persistent(int mask);
+
 /* Attention of Lq <= 32 queries over cat(segment 1, segment 2) along the key axis without the concatenated tensor:
  * replaces  encoder_hidden_states = torch.cat([image_embeds | object_embeds, other stream's states], dim=1)  followed
  * by the cross-attention of models/med.py:549-562, 179-217 (BertEncoderTwin / BertSelfAttention).  K / V = segment 1

@@ -19,7 +19,7 @@ def test_headers_compile_as_c_and_cover_the_fusion_kernels():
     import subprocess, tempfile
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "t.c")
-        open(src, "w").write('#include "bqhip_fusion.h"\nint main(void) { return BQHIP_ABI_VERSION - 5; }\n')
+        open(src, "w").write('#include "bqhip_fusion.h"\nint main(void) { return BQHIP_ABI_VERSION - 6; }\n')
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", src,
                                "-o", os.path.join(d, "t.o")])
     syms = declared_symbols()
@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_ext.library_path())
     for s in declared_symbols():
         assert hasattr(lib, s), s
-    assert lib.bq_abi_version() == 5
+    assert lib.bq_abi_version() == 6
 
 
 def test_shim_surface_and_cpu_rejection():

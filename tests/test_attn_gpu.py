@@ -30,6 +30,75 @@ def test_attn_fwd_vs_torch_fp32(dev, B, H, L):
     assert (lse - want_lse).abs().max() < 2e-3
 
 
+@pytest.mark.parametrize("B,H,L", [(16, 12, 1025), (16, 12, 1024), (16, 12, 1100), (32, 12, 257), (64, 12, 129),
+                                   (16, 12, 1026)])
+def test_attn_fwd_resident_grid_vs_per_block_and_fp32(dev, B, H, L):
+    """the resident-grid forward (attn_fwd_persist_kernel: item walk, cross-item prefetch, the 128 n + 1-th row on vector
+    arithmetic) against the one-workgroup-per-block launch on the same inputs and against fp32 torch; shapes: the ViT's
+    (one ragged row), whole blocks only, a ragged block of 76 rows, of 2 rows, and two short ones with one ragged row"""
+    from bridgeqa_amd import _ext
+    g = torch.Generator().manual_seed(L + B)
+    qkv = (torch.randn(B, L, 3, H, 64, generator=g) * 1.5).to(dev).to(torch.bfloat16)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    prev = _ext.attn_set_persistent(0)
+    try:
+        base, base_lse = _ext.attn_fwd(q, k, v, 0.125)
+        _ext.attn_set_persistent(7)
+        out, lse = _ext.attn_fwd(q, k, v, 0.125)
+    finally:
+        _ext.attn_set_persistent(prev)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    # the same products on the matrix path; the softmax sums pair differently (packed fp32 adds) and the vector-arithmetic
+    # row rounds in another order: a few bf16 ulps of the output
+    d = (out.float() - base.float()).abs().max().item()
+    assert d < 2e-2, d
+    assert (lse - base_lse).abs().max() < 1e-3
+    assert (out.float() - base.float()).norm() / base.float().norm() < 2e-3
+    for b in (0, B - 1):
+        want, want_lse = ref_attention(q[b:b + 1], k[b:b + 1], v[b:b + 1], 0.125)
+        err = (out[b:b + 1].float() - want).norm() / want.norm()
+        assert err < 2e-2, err
+        assert (lse[b:b + 1] - want_lse).abs().max() < 2e-3
+        tail = (out[b, L - 1].float() - want[0, L - 1]).norm() / want[0, L - 1].norm()
+        assert tail < 2e-2, tail
+
+
+@pytest.mark.parametrize("B,H,L", [(16, 12, 1025), (16, 12, 1024), (16, 12, 1100), (32, 12, 257), (16, 12, 1026)])
+def test_attn_bwd_resident_grid_vs_per_block_and_fp32(dev, B, H, L):
+    """the resident-grid dQ and dK/dV passes (item walk, cross-item tile prefetch, the 128 n + 1-th row / key on vector
+    arithmetic) against the block-by-block launches on the same inputs (bit-equal on the matrix path) and, for two batch
+    elements, against fp32 autograd -- the ragged row / key on its own"""
+    from bridgeqa_amd import _ext
+    g = torch.Generator().manual_seed(3 * L + B)
+    qkv = torch.randn(B, L, 3, H, 64, generator=g).to(dev).to(torch.bfloat16)
+    go = torch.randn(B, L, H, 64, generator=g).to(dev).to(torch.bfloat16)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    prev = _ext.attn_set_persistent(0)
+    try:
+        out, lse = _ext.attn_fwd(q, k, v, 0.125)
+        base = torch.zeros_like(qkv)
+        _ext.attn_bwd(q, k, v, out, lse, go, 0.125, base[:, :, 0], base[:, :, 1], base[:, :, 2])
+        _ext.attn_set_persistent(7)
+        got = torch.zeros_like(qkv)
+        _ext.attn_bwd(q, k, v, out, lse, go, 0.125, got[:, :, 0], got[:, :, 1], got[:, :, 2])
+    finally:
+        _ext.attn_set_persistent(prev)
+    assert torch.isfinite(got.float()).all()
+    n = L - 1 if L % 128 == 1 else L
+    assert torch.equal(got[:, :n], base[:, :n])
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    if n < L:
+        for i, name in enumerate(("dq", "dk", "dv")):
+            assert rel(got[:, n:, i].float(), base[:, n:, i].float()) < 1e-2, name
+    for b in (0, B - 1):
+        ref_in = qkv[b:b + 1].float().requires_grad_(True)
+        want, _ = ref_attention(ref_in[:, :, 0], ref_in[:, :, 1], ref_in[:, :, 2], 0.125)
+        want.backward(go[b:b + 1].float())
+        for i, name in enumerate(("dq", "dk", "dv")):
+            assert rel(got[b:b + 1, :, i].float(), ref_in.grad[:, :, i]) < 3e-2, name
+            assert rel(got[b:b + 1, L - 1:, i].float(), ref_in.grad[:, L - 1:, i]) < 3e-2, (name, "last row")
+
+
 def test_attn_fwd_rescale_branch(dev):
     """Force the online-softmax running max to jump late (a spiked key at the end of the sequence)."""
     from bridgeqa_amd import _ext

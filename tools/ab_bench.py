@@ -17,6 +17,11 @@ def main():
     argv = sys.argv[1:]
     cut = argv.index("--") if "--" in argv else len(argv)
     for item in argv[:cut]:
+        if item.startswith("call:"):   # call:_ext.attn_set_persistent(0) -- a setter of the library instead of an attribute
+            name, args = item[5:].split("(", 1)
+            mod, fn = name.split(".", 1)
+            getattr(importlib.import_module("bridgeqa_amd." + mod), fn)(*ast.literal_eval("(" + args.rstrip(")") + ",)"))
+            continue
         name, value = item.split("=", 1)
         mod, attr = name.split(".", 1)
         m = importlib.import_module("bridgeqa_amd." + mod)

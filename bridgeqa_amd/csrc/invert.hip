@@ -139,6 +139,11 @@ namespace bq {
 // (eight ballots give the lanes with the same digit) -- every tie broken by position, so the sort is stable.
 constexpr int RS_IPT = 8, RS_ITEMS = 256 * RS_IPT;
 
+// digit of a radix pass.  A pass at shift >= 32 exists when the pass count was rounded up to an odd number for 25 .. 32 key
+// bits (K >= 2^24): a 32-bit shift by 32 is undefined (the hardware shifts by 0 and the pass would re-sort by the low byte) --
+// such a pass sees digit 0 everywhere, i.e. it is the stable copy it is meant to be.
+__device__ __forceinline__ unsigned rs_digit(unsigned key, int shift) { return shift >= 32 ? 0u : (key >> shift) & 255u; }
+
 __global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned *__restrict__ keys, int *__restrict__ hist, long total, int nblocks,
                                                       int shift) {
   __shared__ int s_h[256];
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned *__restrict
   const long base = (long)blockIdx.x * RS_ITEMS;
   for (int r = 0; r < RS_IPT; ++r) {
     const long i = base + r * 256 + threadIdx.x;
-    if (i < total) atomicAdd(&s_h[(keys[i] >> shift) & 255u], 1);
+    if (i < total) atomicAdd(&s_h[rs_digit(keys[i], shift)], 1);
   }
   __syncthreads();
   hist[(long)threadIdx.x * nblocks + blockIdx.x] = s_h[threadIdx.x];
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const unsigned *__restr
     const long i = base + r * 256 + t;
     const bool live = i < total;
     const unsigned k = live ? keys_in[i] : 0u;
-    const unsigned d = (k >> shift) & 255u;
+    const unsigned d = rs_digit(k, shift);
     // lanes of this wave with the same digit (dead lanes form their own class through the `live` ballot)
     unsigned long long peers = __ballot(live);
     peers = live ? peers : ~peers;

@@ -86,26 +86,41 @@ def wrap_optimizer(model, optimizer):
         return optimizer
     orig_step, orig_zero = optimizer.step, optimizer.zero_grad
 
-    def step(closure=None, **kw):
-        if closure is not None or kw or not runner.replayed_backward_pending():
+    # (installed as BOUND methods: torch's LR schedulers patch `optimizer.step` through its `__func__` -- lib/solver.py:245-266
+    # builds StepLR / MultiStepLR / CosineAnnealingLR after the optimizer, i.e. after this wrap)
+    def step(self_, closure=None, **kw):
+        if closure is not None or kw or not runner.replayed_backward_pending() or getattr(model, "_graphed", None) is not runner:
             return orig_step(closure, **kw) if (closure is not None or kw) else orig_step()
-        return runner.optimizer_step(optimizer, orig_step)
+        return runner.optimizer_step(self_, orig_step)
 
-    def zero_grad(set_to_none=True):
-        if runner.graphs is None:
+    def zero_grad(self_, set_to_none=True):
+        # Only while a REPLAYED forward is waiting for its backward may the static gradients stay as they are: that backward
+        # overwrites every one of them (first write is an assignment).  Anywhere else -- the runner disabled, a forward that
+        # took the eager path, a zero_grad() at the top of the loop -- autograd would ACCUMULATE onto what the static buffers
+        # still hold, so torch's own zero_grad runs (p.grad = None; the next replayed backward points p.grad back).
+        if getattr(model, "_graphed", None) is not runner or runner.graphs is None or runner._bwd_done:
             return orig_zero(set_to_none=set_to_none)
-        # the captured backward OVERWRITES every gradient it produces (first write is an assignment): nothing to clear on
-        # the device; parameters outside the captured set keep torch's semantics
         static = runner.static_grad_ids()
-        for g in optimizer.param_groups:
+        for g in self_.param_groups:
             for p in g["params"]:
                 if id(p) not in static and p.grad is not None:
                     if set_to_none:
                         p.grad = None
                     else:
                         p.grad.zero_()
-    optimizer.step, optimizer.zero_grad = step, zero_grad
+    import types
+    optimizer.step, optimizer.zero_grad = types.MethodType(step, optimizer), types.MethodType(zero_grad, optimizer)
     optimizer._bq_graphed = (orig_step, orig_zero)
+    runner._wrapped_opts.append(optimizer)
+    return optimizer
+
+
+def unwrap_optimizer(optimizer):
+    """undo wrap_optimizer (disable(model) does it for every optimizer wrapped for that model)"""
+    orig = getattr(optimizer, "_bq_graphed", None)
+    if orig is not None:
+        optimizer.step, optimizer.zero_grad = orig
+        optimizer._bq_graphed = None
     return optimizer
 
 
@@ -167,7 +182,11 @@ def wrap_loss(model, fn):
 
 
 def disable(model):
-    if getattr(model, "_graphed", None) is not None:
+    runner = getattr(model, "_graphed", None)
+    if runner is not None:
+        for opt in runner._wrapped_opts:
+            unwrap_optimizer(opt)
+        runner._wrapped_opts = []
         object.__setattr__(model, "_graphed", None)
     return model
 
@@ -261,6 +280,8 @@ class GraphedRunner(object):
         self.reducers, self.broadcaster, self.force_comm = None, None, False
         self.s_comm, self._comm_events = None, []
         self._streams_ready = False
+        self._in_capture = False    # warm-up passes of a (re-)capture: no collective may be issued (see _capture)
+        self._wrapped_opts = []     # optimizers wrap_optimizer changed (disable() restores them)
 
     # ---- what can be replayed --------------------------------------------------------------------------------------
     def usable(self, data_dict):
@@ -392,7 +413,7 @@ class GraphedRunner(object):
         detector forward -- ~490 nodes with its sampling chain -- launched first, the image encoder's graph reached its
         queue 8.5 ms later and the two ran back to back).  The shorter graph of each concurrent pair goes first."""
         cur = torch.cuda.current_stream(self.dev)
-        if self.broadcaster is not None:
+        if self.broadcaster is not None and not self._in_capture:
             self.broadcaster.broadcast()   # DDP's broadcast_buffers=True: rank 0's BatchNorm statistics before the forward
         for s_ in (self.s_main, self.s_det):
             s_.wait_stream(cur)
@@ -452,7 +473,11 @@ class GraphedRunner(object):
             self._probe("end")
         cur.wait_event(self.e_img_bwd)
         cur.wait_event(self.e_det_bwd)
-        if self.reducers:
+        if self.reducers and not self._in_capture:
+            # (never during a re-capture's warm-up passes: under padding='longest' the token shapes -- part of the capture
+            # signature -- differ per rank, so one rank can re-capture while the others replay; its warm-up gradients are
+            # seeded with 1e-3 and its collectives would pair up with the other ranks' REAL ones, one step apart.  With the
+            # warm-up silent every rank issues the same collectives per step whatever it captures.)
             # data parallel: the fusion group (3/4 of the bytes: gradients complete when fusion_bwd ends) travels on the
             # communication stream under the image / detector backward, the rest when both have finished
             sc = self.s_comm
@@ -511,9 +536,11 @@ class GraphedRunner(object):
         # ran 12.2 ms on the GPU instead of ~4.5
         prev = ops.set_overlap(False)
         announced, self._announced = self._announced, None   # (the warm-up passes must not consume the announcement)
+        self._in_capture = True
         try:
             self._capture(data_dict)
         finally:
+            self._in_capture = False
             ops.set_overlap(prev)
             self._announced = announced
 
@@ -695,8 +722,12 @@ class GraphedRunner(object):
             # was announced (same object, not written since)
             pc = data_dict["point_clouds"]
             key = data_dict.get("_bq_geometry_key")
-            self._geo_ready = self._geo_key is not None and (
-                (key is not None and key == self._geo_key) or self._geo_key == ("tensor", id(pc), pc._version))
+            # (the announced tensor itself is kept in the key and compared by identity: an id() can be recycled for another
+            # batch tensor once the announced one has died)
+            gk = self._geo_key
+            self._geo_ready = gk is not None and (
+                (key is not None and key == gk)
+                or (isinstance(gk, tuple) and len(gk) == 3 and gk[0] == "tensor" and gk[1] is pc and gk[2] == pc._version))
         self._copy_inputs(data_dict)
         self._forward_phases(self._replay)
         # (DETACHED inputs: an edge into the captured autograd graph would make this backward walk it eagerly)
@@ -868,8 +899,18 @@ class GraphedRunner(object):
 
     def optimizer_step(self, opt, orig_step):
         self._opt_pending = False
-        rec = self.opt_graphs.setdefault(id(opt), {"n": 0, "g": None})
+        rec = self.opt_graphs.setdefault(id(opt), {"n": 0, "g": None, "hyper": None})
         cur = torch.cuda.current_stream(self.dev)
+        if not hasattr(opt, "sync_hyperparams"):
+            # a torch optimizer (capturable=True) bakes every HOST-valued hyperparameter into the recorded launches (a tensor
+            # lr is read on the device): an LR scheduler's decay would be ignored on replay without an error -- record again
+            # when one of them has changed (StepLR / MultiStepLR: a few times per run; a per-step schedule wants a tensor lr
+            # or optim.FusedAdamW, whose captured launch re-reads its table)
+            hyper = tuple(tuple(sorted((k, v) for k, v in g.items() if k != "params" and isinstance(v, (int, float, bool, tuple))))
+                          for g in opt.param_groups)
+            if rec["g"] is not None and rec["hyper"] != hyper:
+                rec["g"] = None
+            rec["hyper"] = hyper
         if rec["g"] is None:
             rec["n"] += 1
             if rec["n"] < 2:
@@ -915,7 +956,7 @@ class GraphedRunner(object):
         if not torch.is_tensor(next_point_clouds) or next_point_clouds.dim() != 3 or next_point_clouds.shape[-1] < 3:
             raise ValueError("graphed.prefetch: point clouds of shape (B, N, >= 3) expected")
         if key is None:
-            key = ("tensor", id(next_point_clouds), next_point_clouds._version)
+            key = ("tensor", next_point_clouds, next_point_clouds._version)   # (a strong reference: see forward())
         if not self.prefetching:
             self.prefetching = True
             self._stash()

@@ -122,7 +122,7 @@ def _run_loop(dev, mode, steps=4):
             opt.step()
             losses.append(loss.detach().clone())
     torch.cuda.synchronize()
-    out = [l.item() for l in losses]
+    out = [l.item() for l in losses], torch.cat([p.detach().float().flatten() for p in model.parameters()])
     graphed.disable(model)           # (runner <-> model reference cycle: let this execution's graphs and pools go)
     del model, opt, batch
     import gc
@@ -132,24 +132,30 @@ def _run_loop(dev, mode, steps=4):
 
 
 def test_the_plain_loop_trains_under_replay_like_the_eager_loop_and_the_phased_step(dev):
-    """a few optimizer steps of the unchanged loop: first loss identical, every execution goes down, and they stay within a
-    factor of two of each other (AdamW's first steps move every element by ~lr whatever its gradient's size, so
-    rounding-level differences in near-zero gradients do move the curve -- 17 % at the second step of one execution, 35 % at
-    the fourth of another; the gradient test above is the parity check)"""
+    """four optimizer steps of the unchanged loop, eager / graph-replayed / as pipeline.PhasedTrainStep, from one initial state
+    on one batch: the first loss is identical, every execution goes down, and the PARAMETERS the three executions end with
+    agree to 3e-4 rel-L2 over the whole parameter vector (VERDICT r5 item 5 asked for 1e-4; measured 1.1e-4 graphed vs eager,
+    max element 1.5e-4 = 1.5 lr, with the first THREE losses equal to the last digit).  Why not tighter: AdamW's first steps
+    move every element by +-lr whatever its gradient's size, so a last-bit difference in a near-zero gradient (fp32 atomics of
+    the library BatchNorm / column sums) becomes a 2 lr difference in that element, and the bf16 gradient tensors of the
+    detector amplify last-bit differences level by level (1e-7 at FP2 -> 8e-3 at SA1 in one backward,
+    tools/calls/bisect_graphed.py); all elements flipped would be 4e-2.  The loss curves stay within 25 % of the eager one
+    (those parameters feed a discontinuous detection loss: the fourth losses were 68.1 and 77.6)."""
     from bridgeqa_amd import fusion_ops as ops
     prev = ops.set_compute_dtype(torch.bfloat16)
     try:
         res = {mode: _run_loop(dev, mode) for mode in ("eager", "graphed", "phased")}
     finally:
         ops.set_compute_dtype(prev)
-    for mode, l in res.items():
+    ref_l, ref_p = res["eager"]
+    for mode, (l, pvec) in res.items():
         assert all(x == x for x in l) and l[-1] < 0.9 * l[0], (mode, l)
-        assert abs(l[0] - res["eager"][0]) <= 1e-4 * abs(l[0]), (mode, l, res["eager"])
-        # (no tighter: two EAGER executions of this loop end 63 and 74 at the fourth step -- zero-true-gradient parameters
-        # under Adam's sign-like first steps, see the module docstring; what this test guards is that a replayed step
-        # trains at all: updated weights reach the next replay, the static loss is this step's)
-        for a, b in zip(l, res["eager"]):
-            assert 0.5 * abs(b) <= abs(a) <= 2.0 * abs(b), (mode, l, res["eager"])
+        assert abs(l[0] - ref_l[0]) <= 1e-4 * abs(l[0]), (mode, l, ref_l)
+        d = ((pvec - ref_p).norm() / ref_p.norm()).item()
+        print("parameters after 4 steps, %s vs eager: rel-L2 %.3e, max abs %.3e; losses %s" % (mode, d, (pvec - ref_p).abs().max().item(), l))
+        assert d <= 3e-4, (mode, d)
+        for a, b in zip(l, ref_l):
+            assert abs(a - b) <= 0.25 * abs(b), (mode, l, ref_l)
 
 
 def test_graphed_forward_keeps_the_module_api(dev):
@@ -312,11 +318,31 @@ def test_wrapped_optimizer_replays_the_same_update(dev):
         torch.cuda.synchronize()
         for p, g in zip(params, got):
             assert torch.equal(p.detach(), g)
-        # zero_grad under replay: nothing launched, static gradients stay attached
+        # zero_grad between a replayed forward and its backward: nothing launched, static gradients stay attached ...
         gid = [id(p.grad) for p in params]
+        loss = loss_fn(model(dict(batch)))
         opt.zero_grad(set_to_none=True)
         assert [id(p.grad) for p in params] == gid
+        loss.backward()
+        opt.step()
+        # ... anywhere else it is torch's own: after the step nothing is pending, the gradients are dropped, and
+        # the next replayed backward points p.grad at the static buffers again
+        opt.zero_grad(set_to_none=True)
+        assert all(p.grad is None for p in params)
+        fwd_bwd()
+        assert [id(p.grad) for p in params] == gid
+        # an LR scheduler built AFTER the wrap (lib/solver.py:245-266 builds it after the optimizer) can patch step()
+        sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.5)
+        opt.step(); sched.step()
+        assert abs(opt.param_groups[0]["lr"] - 5e-4) < 1e-12
+        # disable() hands the optimizer back: eager steps accumulate into gradients that zero_grad really clears
         graphed.disable(model)
+        assert opt._bq_graphed is None and model._graphed is None
+        for p in model.parameters():
+            p.grad = None
+        bench.total_loss(model(dict(batch))).backward()
+        opt.zero_grad(set_to_none=True)
+        assert all(p.grad is None for p in model.parameters())
     finally:
         ops.set_compute_dtype(prev)
 
@@ -375,6 +401,29 @@ def test_enable_refuses_a_ddp_wrap_and_exchanges_gradients_itself_on_rccl_world_
             for name, r in runner.reducers.items():
                 for p, g in zip(r.params, packed[name]):
                     assert torch.isfinite(p.grad).all() and torch.equal(p.grad, g), (name, names[id(p)])
+            # a RE-capture (new token length = new signature; under padding='longest' it happens on one
+            # rank while the others replay) must not issue a single collective in its warm-up passes -- they would pair up
+            # with the other ranks' real ones, one step apart; the step that follows issues exactly one set again
+            calls = {"bcast": 0, "fusion": 0, "rest": 0}
+            ob = runner.broadcaster.broadcast
+            runner.broadcaster.broadcast = lambda: (calls.__setitem__("bcast", calls["bcast"] + 1), ob())[1]
+            for name, r in runner.reducers.items():
+                def spy2(orig=r.all_reduce, name=name):
+                    calls[name] += 1
+                    orig()
+                r.all_reduce = spy2
+            longer = dict(batch)
+            for k in ("question",):
+                longer[k] = {kk: (torch.cat((t, torch.zeros_like(t[:, :3])), dim=1) if torch.is_tensor(t) and t.dim() == 2 else t)
+                             for kk, t in batch[k].items()}
+            before = runner.captures
+            bench.total_loss(model(longer)).backward()       # captures the new signature, then replays it once
+            torch.cuda.synchronize()
+            assert runner.captures == before + 1
+            assert calls == {"bcast": 1, "fusion": 1, "rest": 1}, calls
+            bench.total_loss(model(dict(batch))).backward()  # back to the cached set: a replay, one set of collectives
+            torch.cuda.synchronize()
+            assert runner.captures == before + 1 and calls == {"bcast": 2, "fusion": 2, "rest": 2}, calls
             graphed.disable(model)
         _body()
     finally:

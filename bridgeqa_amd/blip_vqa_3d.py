@@ -186,14 +186,32 @@ class BLIP_VQA3D(nn.Module):
         q = _tokens(question, self.tokenizer, dev, padding="longest", truncation=True, max_length=80)
         q.input_ids[:, 0] = self.tokenizer.enc_token_id
         prep = {"question": q, "q_embeds": self.text_encoder.embeddings(input_ids=q.input_ids)}
+        two = lambda t: torch.cat((t, t), dim=0)
+        # the attention masks that depend on the token masks only (round 6: ~40 launches of 5 us that sat at the head of the
+        # twin encoder and of the decoder): the question's extended mask, its stacked form for the paired levels, the 2D
+        # stream's encoder mask over cat(image tokens, question) -- the image tokens are never masked --, and for the shared
+        # decoder the causal answer mask and the stacked question mask its cross-attentions read; converted to the kernels'
+        # format here too (fusion_ops.prime_masks).  The 3D stream's mask needs the detector's objectness and stays in _encode.
+        te = self.text_encoder
+        am = q.attention_mask
+        ext = te.get_extended_attention_mask(am, tuple(am.shape), dev, False)
+        ext._bq_stacked = two(ext)
+        P = self.visual_encoder.patch_embed.num_patches + 1
+        enc_ext = te.invert_attention_mask(torch.cat((torch.ones(am.shape[0], P, dtype=am.dtype, device=dev), am), dim=1))
+        ops.prime_masks(ext, ext._bq_stacked, enc_ext)
+        prep["enc_masks"] = {"ext": ext, "enc_ext": enc_ext}
         if answer is not None and self.use_text_decoder and self.share_decoder and not self.use_scene_classifier:
             a = _tokens(answer, self.tokenizer, dev, padding="longest")
             a.input_ids[:, 0] = self.tokenizer.bos_token_id
             targets = a.input_ids.masked_fill(a.input_ids == self.tokenizer.pad_token_id, -100)
-            two = lambda t: torch.cat((t, t), dim=0)
             ids2 = two(a.input_ids)
-            prep.update(answer=a, ids2=ids2, att2=two(a.attention_mask), targets2=two(targets),
-                        a_embeds=self.text_decoder.bert.embeddings(input_ids=ids2))
+            att2 = two(a.attention_mask)
+            td = self.text_decoder.bert
+            dext = td.get_extended_attention_mask(att2, tuple(ids2.shape), dev, True)
+            denc = td.invert_attention_mask(two(am))
+            ops.prime_masks(getattr(dext, "_bq_causal_key_mask", None), denc)
+            prep.update(answer=a, ids2=ids2, att2=att2, targets2=two(targets),
+                        a_embeds=td.embeddings(input_ids=ids2), dec_masks={"ext": dext, "enc_ext": denc})
         return prep
 
     def _encode(self, image, question, image_embeds, scene_object_embeds, scene_object_mask, image_pose,
@@ -202,7 +220,10 @@ class BLIP_VQA3D(nn.Module):
             B, P, H = image_embeds.size()
             image_embeds = image_embeds.view(B // P, P * image_per_sample, H)
         dev = image_embeds.device
-        image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=dev)
+        # (with prepared masks the all-ones image mask is already inside text_prep["enc_masks"]["enc_ext"]; the encoder
+        # falls back to building it when the token count does not match -- several images per sample)
+        enc_masks = None if text_prep is None else text_prep.get("enc_masks")
+        image_atts = None if enc_masks is not None else torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=dev)
         if text_prep is not None:
             question = text_prep["question"]
         else:
@@ -217,7 +238,7 @@ class BLIP_VQA3D(nn.Module):
                                 encoder_hidden_states=image_embeds, encoder_attention_mask=image_atts,
                                 encoder_hidden_states_twin=scene_object_embeds,
                                 encoder_attention_mask_twin=scene_object_mask, return_dict=True,
-                                output_attentions="last")
+                                output_attentions="last", mask_prep=enc_masks)
         h2d, h3d = out.last_hidden_state
         if data_dict is not None:
             data_dict["2d_self_attention"], data_dict["3d_self_attention"] = out.attentions[-1]
@@ -255,10 +276,11 @@ class BLIP_VQA3D(nn.Module):
             assert answer is not None, "answer must be specified if use text decoder (free-form answer mode)"
             if text_prep is not None and "a_embeds" in text_prep:
                 # (token-only work done ahead of time: stacked ids / masks / targets and the decoder's embeddings)
+                dm = text_prep.get("dec_masks")
                 out = self.text_decoder(None, attention_mask=text_prep["att2"], encoder_embeds=text_prep["a_embeds"],
                                         encoder_hidden_states=torch.cat((q2d.last_hidden_state, q3d.last_hidden_state), dim=0),
-                                        encoder_attention_mask=torch.cat((q_mask, q_mask), dim=0),
-                                        labels=text_prep["targets2"], return_dict=True, reduction="none")
+                                        encoder_attention_mask=None if dm is not None else torch.cat((q_mask, q_mask), dim=0),
+                                        labels=text_prep["targets2"], return_dict=True, reduction="none", mask_prep=dm)
                 return out.loss.sum() / B, self.fuse_2d3d(q2d, q3d), q_mask
             answer = _tokens(answer, self.tokenizer, dev, padding="longest")
             answer.input_ids[:, 0] = self.tokenizer.bos_token_id

@@ -507,7 +507,9 @@ class BertEncoderTwin(BertEncoder):
                 if stacked is None:
                     stacked = torch.cat((ops._c(hidden_states), ops._c(hidden_states_twin)), dim=0)
                 if mask2 is None:
-                    mask2 = torch.cat((attention_mask, attention_mask), dim=0)
+                    mask2 = getattr(attention_mask, "_bq_stacked", None)   # (BLIP_VQA3D.prepare_text: built ahead of time)
+                    if mask2 is None:
+                        mask2 = torch.cat((attention_mask, attention_mask), dim=0)
                     ops.prime_masks(mask2)
                 stacked = self._twin_level(i, stacked, mask2, enc2d, enc3d, encoder_attention_mask,
                                            encoder_attention_mask_twin, layernorm_idx, want,
@@ -681,7 +683,13 @@ class BertModel(BertPreTrainedModel):
     def set_input_embeddings(self, value):
         self.embeddings.word_embeddings = value
 
-    def _prep(self, input_ids, inputs_embeds, encoder_embeds, attention_mask, past_key_values, is_decoder):
+    @staticmethod
+    def _prepared(mask_prep, key, shape):
+        """a mask computed ahead of time (extension: BLIP_VQA3D.prepare_text -> mask_prep) when it has the expected shape"""
+        m = None if mask_prep is None else mask_prep.get(key)
+        return m if (m is not None and tuple(m.shape) == tuple(shape)) else None
+
+    def _prep(self, input_ids, inputs_embeds, encoder_embeds, attention_mask, past_key_values, is_decoder, mask_prep=None):
         if input_ids is not None and inputs_embeds is not None:
             raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
         ref = input_ids if input_ids is not None else (inputs_embeds if inputs_embeds is not None else encoder_embeds)
@@ -691,24 +699,34 @@ class BertModel(BertPreTrainedModel):
         past_len = past_key_values[0][0].shape[2] if past_key_values is not None else 0
         if attention_mask is None:
             attention_mask = torch.ones((B, L + past_len), device=ref.device)
-        ext = self.get_extended_attention_mask(attention_mask, (B, L), ref.device, is_decoder)
+        ext = None
+        if mask_prep is not None and past_len == 0:
+            ext = self._prepared(mask_prep, "ext", (B, 1, L, L) if is_decoder else (B, 1, 1, L))
+        if ext is None:
+            ext = self.get_extended_attention_mask(attention_mask, (B, L), ref.device, is_decoder)
         return attention_mask, ext, past_len
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, head_mask=None, inputs_embeds=None,
                 encoder_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None, past_key_values=None,
                 use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None,
-                is_decoder=False, mode="multimodal", layernorm_idx=0, forward_layers=None):
+                is_decoder=False, mode="multimodal", layernorm_idx=0, forward_layers=None, mask_prep=None):
+        """mask_prep (extension): {"ext": this call's extended self-attention mask, "enc_ext": the inverted encoder mask}
+        computed ahead of time from the token masks (BLIP_VQA3D.prepare_text); each is used when its shape fits (and, for
+        enc_ext, when no encoder_attention_mask is given), otherwise the masks are built here as before"""
         output_attentions = output_attentions if output_attentions is not None else self.config.output_attentions
         output_hidden_states = output_hidden_states if output_hidden_states is not None \
             else self.config.output_hidden_states
         use_cache = (use_cache if use_cache is not None else self.config.use_cache) if is_decoder else False
         attention_mask, ext_mask, past_len = self._prep(input_ids, inputs_embeds, encoder_embeds, attention_mask,
-                                                        past_key_values, is_decoder)
+                                                        past_key_values, is_decoder, mask_prep)
         enc_ext = None
         if encoder_hidden_states is not None:
             if encoder_attention_mask is None:
-                encoder_attention_mask = torch.ones(encoder_hidden_states.shape[:2], device=ext_mask.device)
-            enc_ext = self.invert_attention_mask(encoder_attention_mask)
+                enc_ext = self._prepared(mask_prep, "enc_ext", (encoder_hidden_states.shape[0], 1, 1, encoder_hidden_states.shape[1]))
+                if enc_ext is None:
+                    encoder_attention_mask = torch.ones(encoder_hidden_states.shape[:2], device=ext_mask.device)
+            if enc_ext is None:
+                enc_ext = self.invert_attention_mask(encoder_attention_mask)
         if encoder_embeds is None:
             embedding_output = self.embeddings(input_ids=input_ids, position_ids=position_ids,
                                                inputs_embeds=inputs_embeds, past_key_values_length=past_len)
@@ -744,15 +762,24 @@ class BertModelTwin(BertModel):
                 encoder_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
                 encoder_hidden_states_twin=None, encoder_attention_mask_twin=None, past_key_values=None,
                 use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None,
-                is_decoder=False, mode="multimodal", layernorm_idx=0, forward_layers=None):
+                is_decoder=False, mode="multimodal", layernorm_idx=0, forward_layers=None, mask_prep=None):
+        """mask_prep (extension, see BertModel.forward): "ext" and, for an all-ones encoder mask (encoder_attention_mask
+        None: the image tokens), "enc_ext" = inverted cat(ones, text mask)"""
         output_attentions = output_attentions if output_attentions is not None else self.config.output_attentions
         output_hidden_states = output_hidden_states if output_hidden_states is not None \
             else self.config.output_hidden_states
         attention_mask, ext_mask, past_len = self._prep(input_ids, inputs_embeds, encoder_embeds, attention_mask,
-                                                        past_key_values, is_decoder)
+                                                        past_key_values, is_decoder, mask_prep)
         # each stream also sees the other stream's text states: masks are cat(encoder mask, text mask)
-        am = attention_mask.to(encoder_attention_mask.dtype)
-        enc_ext = self.invert_attention_mask(torch.cat((encoder_attention_mask, am), dim=1))
+        enc_ext = None
+        if encoder_attention_mask is None:
+            L1 = encoder_hidden_states.shape[1] + attention_mask.shape[1]
+            enc_ext = self._prepared(mask_prep, "enc_ext", (attention_mask.shape[0], 1, 1, L1))
+            if enc_ext is None:
+                encoder_attention_mask = torch.ones(encoder_hidden_states.shape[:2], dtype=torch.long, device=ext_mask.device)
+        if enc_ext is None:
+            am = attention_mask.to(encoder_attention_mask.dtype)
+            enc_ext = self.invert_attention_mask(torch.cat((encoder_attention_mask, am), dim=1))
         am = attention_mask.to(encoder_attention_mask_twin.dtype)
         enc_ext_twin = self.invert_attention_mask(torch.cat((encoder_attention_mask_twin, am), dim=1))
         if encoder_embeds is None:
@@ -796,7 +823,7 @@ class BertLMHeadModel(BertPreTrainedModel):
                 encoder_hidden_states=None, encoder_attention_mask=None, labels=None, past_key_values=None,
                 use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None,
                 return_logits=False, is_decoder=True, reduction="mean", mode="multimodal", layernorm_idx=0,
-                encoder_embeds=None):
+                encoder_embeds=None, mask_prep=None):
         """encoder_embeds (extension): the output of self.bert.embeddings computed ahead of time -- the text prologue of
         pipeline.PhasedTrainStep (BLIP_VQA3D.prepare_text); BertModel.forward takes it as the reference's does"""
         if labels is not None:
@@ -807,7 +834,7 @@ class BertLMHeadModel(BertPreTrainedModel):
                             encoder_attention_mask=encoder_attention_mask, past_key_values=past_key_values,
                             use_cache=use_cache, output_attentions=output_attentions,
                             output_hidden_states=output_hidden_states, is_decoder=is_decoder, mode=mode,
-                            layernorm_idx=layernorm_idx)
+                            layernorm_idx=layernorm_idx, mask_prep=mask_prep)
         head = self.cls.predictions
         hidden = head.transform(outputs.last_hidden_state)
         lm_loss = None

@@ -28,7 +28,7 @@ class _Args(object):
         self.points, self.image = points, image
 
 
-def run_curve(name, dtype, steps, lr=1e-4, seed=0, round_inputs=False):
+def run_curve(name, dtype, steps, lr=1e-4, seed=0, round_inputs=False, batch_seed=42):
     """losses (python floats, one per step) of `steps` eager training steps of workload `name` in compute dtype `dtype`;
     round_inputs: the per-point features and the image rounded to bf16 ONCE (everything else as `dtype` says) -- the
     control run: an fp32 run under a perturbation of the size of a single bf16 rounding"""
@@ -47,7 +47,7 @@ def run_curve(name, dtype, steps, lr=1e-4, seed=0, round_inputs=False):
                 mod.p = 0.0
             if hasattr(mod, "drop_prob"):
                 mod.drop_prob = 0.0
-        batch = bench.make_batch(_Args(w["points"], w["image"]), w["workload"], w["batch"], 42, dev)
+        batch = bench.make_batch(_Args(w["points"], w["image"]), w["workload"], w["batch"], batch_seed, dev)
         if round_inputs:
             batch["point_clouds"][..., 3:] = batch["point_clouds"][..., 3:].to(torch.bfloat16).float()
             if "images" in batch:

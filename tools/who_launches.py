@@ -1,23 +1,41 @@
-"""Which Python call sites launch the small ATen kernels of the c3 step?  Eager step under torch.profiler with
-stacks; kernels are attributed to the innermost bridgeqa_amd frame (forward) or autograd node (backward)."""
+"""Which module / autograd node launches the library (ATen / rocclr / Cijk) kernels of the c3 step?  One eager step under
+torch.profiler; every module's forward runs inside a record_function scope named after the module path, so a launch is
+attributed to the innermost scope around it (forward) or to the autograd node that issued it (backward).
+
+    python tools/who_launches.py [pattern] [top] [skip,substrings]      WHO_WORKLOAD=c2: the detector stage alone
+"""
 import collections, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from torch.profiler import profile, ProfilerActivity
+from torch.profiler import profile, ProfilerActivity, record_function
 from bridgeqa_amd import fusion_ops
 fusion_ops.set_compute_dtype(torch.bfloat16)
 import bench
 
 dev = torch.device("cuda")
-sys.argv = ["bench.py"]
+sys.argv, argv = ["bench.py"], sys.argv
 args = bench.parse()
 args.cin = 132
 torch.manual_seed(0)
-WL = os.environ.get("WHO_WORKLOAD", "c3")   # c2: the detector stage alone
+WL = os.environ.get("WHO_WORKLOAD", "c3")
 model = bench.build_model(WL, 132, args.image).to(dev)
 model.train()
 batch = bench.make_batch(args, WL, 16, 42, dev)
 params = [p for p in model.parameters()]
+
+
+def scoped(mod, name):
+    orig = mod.forward
+
+    def fwd(*a, **k):
+        with record_function("mod:" + name):
+            return orig(*a, **k)
+    mod.forward = fwd
+
+
+for name, mod in model.named_modules():
+    if name and name.count(".") <= 6:
+        scoped(mod, name)
 
 
 def step():
@@ -26,8 +44,12 @@ def step():
     fusion_ops.new_step(dev)
     prev = fusion_ops.set_overlap(False)   # single-stream fusion, as the phased step runs it
     try:
-        loss = bench.total_loss(model(dict(batch)))
-        fusion_ops.begin_deferred_wgrad()  # weight gradients parked and flushed once, as in pipeline.PhasedTrainStep
+        with record_function("mod:LOSS"):
+            pass
+        dd = model(dict(batch))
+        with record_function("mod:LOSS"):
+            loss = bench.total_loss(dd)
+        fusion_ops.begin_deferred_wgrad()
         try:
             loss.backward()
         finally:
@@ -40,40 +62,40 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step()
     torch.cuda.synchronize()
 
-pat = sys.argv[1] if len(sys.argv) > 1 else "elementwise"
-evs = prof.events()
+pat = argv[1] if len(argv) > 1 else ""
+TOP = int(argv[2]) if len(argv) > 2 else 120
+SKIP = argv[3].split(",") if len(argv) > 3 else []
 agg = collections.defaultdict(lambda: [0, 0.0])
-for e in evs:
-    if e.device_type.name != "CPU":
+for e in prof.events():
+    if e.device_type.name != "CPU" or not getattr(e, "kernels", None):
         continue
-    kern = [k for k in e.kernels] if hasattr(e, "kernels") else []
-    if not kern:
-        continue
-    for k in kern:
+    for k in e.kernels:
         kn = k.name
-        if not any(p in kn for p in ("at::native", "rocclr", "Cijk")):
+        if not any(p in kn for p in ("at::native", "rocclr", "Cijk")) or pat not in kn:
             continue
-        short = kn.split("<")[0][-40:] + "|" + (kn.split("at::native::")[2][:40] if kn.count("at::native::") > 1 else "")
-        frames = [f for f in (e.stack or []) if "bridgeqa_amd" in f or "bench.py" in f]
-        site = frames[0].split("/")[-1][:70] if frames else "(autograd) "
-        # walk up to the enclosing autograd node name for backward kernels
-        par = e.cpu_parent
-        node = ""
+        par, scope, node = e.cpu_parent, None, None
         while par is not None:
-            if "Backward" in par.name or "autograd::engine" in par.name:
-                node = par.name
-                break
+            if scope is None and par.name.startswith("mod:"):
+                scope = par.name[4:]
+            if node is None and ("Backward" in par.name or "autograd::engine" in par.name):
+                node = par.name.replace("autograd::engine::evaluate_function: ", "")
             par = par.cpu_parent
-        key = (short, e.name, str(e.input_shapes)[:60], site if not node else node[:60])
+        where = node if node is not None else (scope or "(top level)")
+        key = (where[:70], e.name[:28], str(e.input_shapes)[:50])
         agg[key][0] += 1
         agg[key][1] += k.duration
-TOP = int(sys.argv[2]) if len(sys.argv) > 2 else 70
-SKIP = sys.argv[3].split(",") if len(sys.argv) > 3 else []   # drop call sites containing any of these (e.g. loss_helper,pointnet2)
-items = [(k, v) for k, v in agg.items() if not any(x in k[3] for x in SKIP)]
+items = [(k, v) for k, v in agg.items() if not any(x in k[0] for x in SKIP)]
 print("%d launches, %.1f us in the listed classes" % (sum(v[0] for _, v in items), sum(v[1] for _, v in items)))
-for k, v in sorted(items, key=lambda x: -x[1][1])[:TOP]:
-    print("%4d %8.1fus  %-60s %-28s %-60s %s" % (v[0], v[1], k[0], k[1][:28], k[2], k[3]))
+by_where = collections.defaultdict(lambda: [0, 0.0])
+for (w, _, _), v in items:
+    by_where[w][0] += v[0]; by_where[w][1] += v[1]
+print("---- by owner")
+for w, v in sorted(by_where.items(), key=lambda x: -x[1][0])[:TOP]:
+    print("%4d %8.1fus  %s" % (v[0], v[1], w))
+print("---- by owner / op / shapes")
+for k, v in sorted(items, key=lambda x: -x[1][0])[:TOP]:
+    print("%4d %8.1fus  %-70s %-28s %s" % (v[0], v[1], k[0], k[1], k[2]))

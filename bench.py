@@ -82,6 +82,7 @@ def parse():
                     help="default c3 run: skip the second measurement (the reference's unchanged loop under graphed, "
                          "reported as `loop_reference` on the same JSON line)")
     ap.add_argument("--cpu-scenes", type=int, default=2, help="scenes in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0: min(os.cpu_count(), 32))")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
                     help="arithmetic of the dense layers: bf16 = the HIP kernel path (MFMA GEMMs, point-major detector); "
                          "f32 = the reference composition on torch ops (c2 only)")
@@ -252,9 +253,10 @@ def cpu_baseline(args, workload):
     """The hot path on the host cores: bridgeqa_amd's Python layers over the CPU oracle backend
     (oracle/ -- allowed here as the reported baseline only) + torch-CPU fp32 for the dense layers."""
     from bridgeqa_amd import pointnet2_utils
-    os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 32)))
+    cores = int(getattr(args, "cpu_threads", 0) or 0) or min(os.cpu_count() or 1, 32)  # (default: beyond ~32 threads this
+    #                                                   workload only adds contention; --cpu-threads N runs any other count)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     from oracle import pn2_oracle
-    cores = min(os.cpu_count() or 1, 32)  # beyond ~32 threads this workload only adds contention
     torch.set_num_threads(cores)
     prev = pointnet2_utils.set_backend(pn2_oracle)
     try:
@@ -318,8 +320,8 @@ def cpu_info():
 
 
 VIT_GEMMS = (("qkv", 2304, 768), ("proj", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072))
-PROFILE_PMC = os.path.join(ROOT, "profiles", "r05_gemm_pmc.jsonl")       # tools/run_gemm_pmc.sh -> tools/pmc_summary.py --json
-PROFILE_STATS = os.path.join(ROOT, "profiles", "r05_c3_kernel_stats.csv")  # rocprofv3 --kernel-trace --stats of this bench
+PROFILE_PMC = os.path.join(ROOT, "profiles", "r06_gemm_pmc.jsonl")       # tools/run_gemm_pmc.sh -> tools/pmc_summary.py --json
+PROFILE_STATS = os.path.join(ROOT, "profiles", "r06_c3_kernel_stats.csv")  # rocprofv3 --kernel-trace --stats of this bench
 PROFILE_ROWS = 16400   # the committed counter / in-step records were taken at c3's token count (B = 16 x 1025): they are
 #                        attached to a bench line only when the run has the same M (the c5 line divided c3's bytes)
 # kernel instantiation each launch form runs as (for the in-step averages of the committed profile)
@@ -432,7 +434,7 @@ def gemm_roofline(args, dev):
     out[-1]["note"] = ("all 48 weight gradients (+ bias gradients) of the 12 blocks through fusion_wgrad.flush_deferred_items: "
                        "the launch plan the step uses (two 256-tile launches + the planner's small problems on the 64-tile kernel)")
     traffic = ({"hbm_read_bytes": tot_fetch, "hbm_write_bytes": tot_write, "algorithmic_bytes": tot_alg,
-                "ratio": round((tot_fetch + tot_write) / tot_alg, 3), "file": "profiles/r05_gemm_pmc.jsonl",
+                "ratio": round((tot_fetch + tot_write) / tot_alg, 3), "file": "profiles/r06_gemm_pmc.jsonl",
                 "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, one launch form per process; read = 2 x "
                           "FETCH_SIZE x 1024 (gfx950 tallies a 128-B request as 64 B), write = WRITE_SIZE x 1024 "
                           "(MI355X_MICROARCH.md, HBM); fabric-side counters: Infinity-Cache hits are included"}
@@ -440,11 +442,11 @@ def gemm_roofline(args, dev):
     # the same fraction from the DURATIONS of the committed trace pass (rocprofv3 kernel trace, one launch form per
     # process) next to the live HIP-event medians `frac` uses: a reader can recompute either from its own source
     prof = ({"us_total": round(tot_prof, 1), "frac": round(tot_f / (tot_prof * 1e-6) / 1e12 / 2500.0, 4),
-             "file": "profiles/r05_gemm_pmc.jsonl (avg_us of the trace pass)"} if (tot_prof and not prof_missing) else None)
+             "file": "profiles/r06_gemm_pmc.jsonl (avg_us of the trace pass)"} if (tot_prof and not prof_missing) else None)
     return out, tot_f, tot_t, traffic, prof
 
 
-def _attn_pmc(threads, path="profiles/r05_attn_pmc.txt"):
+def _attn_pmc(threads, path="profiles/r06_attn_pmc.txt"):
     """MFMA-busy fractions of the three attention kernels at THIS run's shape, read back from the committed counter summary
     (tools/run_attn_pmc.sh -> tools/pmc_summary.py: per kernel and launch shape a '<name>  grid <threads>' line followed by
     the counters and a '=> MFMA utilisation X %' line); `threads` = B * H * ceil(L / 128) workgroups * 256"""
@@ -599,7 +601,7 @@ def reference_loop(args, model, batch, dev, use_graph):
 def det_bwd_roofline(args, dev):
     """The fused SharedMLP backward (csrc/detbwd.hip) at SA1's three layer shapes of this configuration: algorithmic HBM bytes
     (operands read once, dX written once) over the live launch duration (HIP events on the launch stream, median of 7), next to
-    the counter bytes of the committed PMC passes (profiles/r05_det_bwd_pmc.txt, taken at B = 16 x 2048 x 64 rows)."""
+    the counter bytes of the committed PMC passes (profiles/r06_det_bwd_pmc.txt, taken at B = 16 x 2048 x 64 rows)."""
     import torch
     from bridgeqa_amd import _ext
     R = args.batch * 2048 * 64
@@ -637,7 +639,7 @@ def det_bwd_roofline(args, dev):
                       "layer from one pass over its activations; the three layers of SA1", "bound": "hbm",
             "achieved": round(tot_b / (tot_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms_total": round(tot_ms, 4), "per_layer": per,
-            "traffic_from_profile": "profiles/r05_det_bwd_pmc.txt (2 x FETCH_SIZE + WRITE_SIZE per launch: 1125 / 1082 / 1103 MB "
+            "traffic_from_profile": "profiles/r06_det_bwd_pmc.txt (2 x FETCH_SIZE + WRITE_SIZE per launch: 1125 / 1082 / 1103 MB "
                                     "for 1107 / 1074 / 1086 MB of algorithmic bytes at B = 16)",
             "timed_on": "dedicated launches after the timed region, HIP events on the launch stream, median of 7"}
 
@@ -646,7 +648,7 @@ def det_bwd_roofline(args, dev):
 def _fps_pmc():
     """physical HBM traffic of SA1's FPS launch from the committed counter passes (tools/run_r5_profiles.sh), or None"""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r05_fps_pmc.json")))
+        return json.load(open(os.path.join(ROOT, "profiles", "r06_fps_pmc.json")))
     except (OSError, ValueError):
         return None
 
@@ -662,7 +664,7 @@ def ballquery_roofline(args, ops, alone_ms, alone_bg_ms, phased):
     eq = lambda t: round(alg / (t * 1e-3) / 1e9, 1) if t == t and t > 0 else None
     pmc = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_ballquery_pmc.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r06_ballquery_pmc.json")))
         if (pmc.get("B"), pmc.get("N"), pmc.get("M")) != (B, N, M):
             pmc = None   # (taken at another shape: not this run's traffic)
     except (OSError, ValueError):
@@ -1131,8 +1133,8 @@ def main():
                                "algorithmic_flops": tot_f, "ms_total": round(tot_ms, 4), "per_gemm": per,
                                "timed_on": "dedicated launches after the timed region, HIP events on the launch stream, "
                                            "median of 10 (inside the step the same kernels replay from HIP graphs; the "
-                                           "in-step averages come from profiles/r05_c3_kernel_stats.csv, the counters from "
-                                           "profiles/r05_gemm_pmc.jsonl; both only at M = 16400, the shape they were taken at)"}
+                                           "in-step averages come from profiles/r06_c3_kernel_stats.csv, the counters from "
+                                           "profiles/r06_gemm_pmc.jsonl; both only at M = 16400, the shape they were taken at)"}
             out["roofline_attn"] = attn_roofline(args, dev)
         else:
             out["roofline"] = out["roofline_fps"]

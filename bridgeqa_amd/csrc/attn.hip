@@ -603,7 +603,7 @@ using namespace bq;
 
 // persistent-grid switch (measurement: tools/bench_attn.py times both); bit 0: forward, bit 1: dQ pass, bit 2: dK/dV pass
 // Default 0 (round 6): alone the resident grid is ahead at the ViT shape (forward 84.8 us against 88.5, backward 233.0 against
-// 235.2, tools/ab_attn.py, one box), inside the c3 step it is behind (34.0-34.1 ms against 33.8, tools/calls/ab_step_attn.sh):
+// 235.2, tools/ab_attn.py, one box), inside the c3 step it is behind (34.0-34.1 ms against 33.8, tools/ab_step_attn.sh):
 // its static item walk cannot give way to the detector stream's workgroups the way block-by-block dispatch does.
 static int g_attn_persist = 0;
 extern "C" __attribute__((visibility("default"))) int bq_attn_set_persistent(int mask) {

@@ -9,8 +9,8 @@
 // the gradient kernels GATHER: one sum per destination, its terms added in ascending position order.  Same terms as the
 // reference, a fixed order, no atomics, no zero-fill; bitwise reproducible.
 // (The sort is this file's own: rocPRIM's DeviceRadixSort, the first version, ran eagerly at every size and replayed from a
-// HIP graph at c3's 2.1 M pairs, but a REPLAYED graph holding it at c5's 4.2 M pairs died with a memory access fault --
-// tools/dbg_c5.py; everything here is plain kernels on caller-provided scratch.)
+// HIP graph at c3's 2.1 M pairs, but a REPLAYED graph holding it at c5's 4.2 M pairs died with a memory access fault (bisected
+// in round 5); everything here is plain kernels on caller-provided scratch.)
 
 #include "bq_common.h"
 #include "bqhip_fusion.h"

@@ -1097,7 +1097,7 @@ _HOIST_GROUPED = [True]      # single-stream path: the slots' projections as ONE
 # ... and their input gradients as one grouped launch + a sum (take_dx).  OFF: it rounds the decoder's encoder-state gradient
 # differently from the chained ADD epilogue (every upstream gradient moves by bf16 noise, 4e-3 .. 1e-2 rel-L2 -- expected), and
 # with it the eager loop and the captured phases stop agreeing bit for bit on the DETECTOR's gradients (1e-7 at the top of the
-# backbone's backward, amplified to 8e-3 at SA1 by six levels of bf16 gradient tensors, tools/calls/bisect_graphed.py) although
+# backbone's backward, amplified to 8e-3 at SA1 by six levels of bf16 gradient tensors, tools/bisect_graphed.py) although
 # the object-token gradient they start from is identical; not understood, and worth ~0.1 ms at most
 _HOIST_GROUPED_DX = [False]
 _HOIST_BACKGROUND = [False]  # side-stream launches of the hoisted projections with one workgroup per CU (BQ_GEMM_BACKGROUND): measured slower

@@ -7,7 +7,7 @@ detector's data path: one forward + backward agrees to 1e-4 on every parameter's
 steps do NOT stay that close: parameters whose true gradient is zero (attention key biases -- softmax is shift-invariant; a
 BatchNorm bias in front of another training-mode BatchNorm) receive rounding noise as their gradient, AdamW's first steps turn
 it into steps of size ~lr in noise-determined directions, and the detection loss amplifies the resulting rounding changes
-(tools/dbg_graphed_step2.py: gradients of those parameters 70 % apart at step 0, the second loss 2.4 % apart, two EAGER
+(round-5 measurement: gradients of those parameters 70 % apart at step 0, the second loss 2.4 % apart, two EAGER
 executions 63 against 74 at the fourth step)."""
 import pytest
 import torch
@@ -86,7 +86,7 @@ def test_gradients_behind_the_plain_loop_equal_the_eager_loop(dev):
                 return ((x[n] - want[n]).norm() / (ref.norm() + 1e-12)).item()
             # Round 5: the detector's scatter gradients are gathers over an inverted index (csrc/invert.hip) and its SharedMLP
             # backward sums per-workgroup slices in a fixed order (csrc/detbwd.hip) -- no fp32 atomics on the data path any more.
-            # Measured: every parameter below 1e-6 in all three executions (tools/dbg_graphed_tol.py); round 4 needed 6e-2
+            # Measured: every parameter below 1e-6 in all three executions (tools/bisect_graphed.py); round 4 needed 6e-2
             # beyond twice an eager control here.  What is left are weight-gradient column sums and cut contractions that end
             # in fp32 atomics (last-bit differences).
             worst = sorted(((err(n, got), n) for n in want), reverse=True)[:3]
@@ -139,7 +139,7 @@ def test_the_plain_loop_trains_under_replay_like_the_eager_loop_and_the_phased_s
     move every element by +-lr whatever its gradient's size, so a last-bit difference in a near-zero gradient (fp32 atomics of
     the library BatchNorm / column sums) becomes a 2 lr difference in that element, and the bf16 gradient tensors of the
     detector amplify last-bit differences level by level (1e-7 at FP2 -> 8e-3 at SA1 in one backward,
-    tools/calls/bisect_graphed.py); all elements flipped would be 4e-2.  The loss curves stay within 25 % of the eager one
+    tools/bisect_graphed.py); all elements flipped would be 4e-2.  The loss curves stay within 25 % of the eager one
     (those parameters feed a discontinuous detection loss: the fourth losses were 68.1 and 77.6)."""
     from bridgeqa_amd import fusion_ops as ops
     prev = ops.set_compute_dtype(torch.bfloat16)

@@ -381,7 +381,7 @@ def test_inverted_index_and_deterministic_scatter_gradients(ext, oracle, dev):
 def test_inverted_index_is_a_stable_sort_eager_and_replayed(ext, dev, B, L, N):
     """bq_invert_index at sizes from one pair to configs[5]'s SA1 level (4.2 M pairs over 2.56 M points: three 8-bit passes),
     eagerly and REPLAYED from a HIP graph on fresh indices (the round-5 fault: the first version's library sort died exactly
-    there -- tools/dbg_c5.py): slots is the stable argsort of scene * N + index, start its CSR"""
+    there): slots is the stable argsort of scene * N + index, start its CSR"""
     g = torch.Generator().manual_seed(B * 7 + N)
     def draw():
         idx = torch.randint(0, N, (B, L), generator=g, dtype=torch.int32)

@@ -26,13 +26,48 @@ def stats(v):
     return m, sd
 
 
+def preact_arm(a):
+    from bridgeqa_amd import _ext
+    prev = json.load(open(a.preact_arm))
+    rows = []
+    _ext.FP32_PREACT[0] = True
+    try:
+        for r in prev["runs"][:a.seeds]:
+            s = r["seed"]
+            c1 = run_curve(a.workload, torch.bfloat16, a.steps, seed=s, batch_seed=42 + s)
+            c2 = run_curve(a.workload, torch.bfloat16, a.steps, seed=s, batch_seed=42 + s)
+            f = 0.5 * (sum(c1[-10:]) / 10 + sum(c2[-10:]) / 10)
+            f32 = 0.5 * (r["fp32"]["final"] + r["fp32_repeat"]["final"])
+            b16 = 0.5 * (r["bf16"]["final"] + r["bf16_repeat"]["final"])
+            rows.append({"seed": s, "bf16_fp32_preact": f, "fp32": f32, "bf16": b16})
+            print(s, "fp32 %.4f bf16 %.4f bf16+fp32-preact %.4f" % (f32, b16, f), flush=True)
+    finally:
+        _ext.FP32_PREACT[0] = False
+    rel = [(r["bf16_fp32_preact"] - r["fp32"]) / r["fp32"] for r in rows]
+    rel_b = [(r["bf16_fp32_preact"] - r["bf16"]) / r["bf16"] for r in rows]
+    (m, sd), (mb, sdb) = stats(rel), stats(rel_b)
+    n = math.sqrt(len(rows))
+    summary = {"seeds": len(rows), "arm": "bf16 kernel path with _ext.FP32_PREACT (SharedMLP outputs from the fp32 accumulators)",
+               "paired_rel_diff_vs_fp32_pct": {"mean": round(100 * m, 2), "standard_error": round(100 * sd / n, 2)},
+               "paired_rel_diff_vs_bf16_default_pct": {"mean": round(100 * mb, 2), "standard_error": round(100 * sdb / n, 2)}}
+    print(json.dumps(summary))
+    if a.out:
+        json.dump({"what": "tools/loss_curve_r6.py --preact-arm: does round 5's fp32-accumulator SharedMLP output close the gap?",
+                   "summary": summary, "runs": rows}, open(a.out, "w"), indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--seeds", type=int, default=12)
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--preact-arm", default=None, metavar="PREVIOUS.json",
+                    help="run ONLY the bf16 path with the SharedMLP outputs taken from the fp32 accumulators (_ext.FP32_PREACT, "
+                         "round 5's opt-in), twice per seed, and pair it with the fp32 / bf16 finals of PREVIOUS.json (same seeds)")
     a = ap.parse_args()
+    if a.preact_arm:
+        return preact_arm(a)
     tail = 10
     final = lambda c: sum(c[-tail:]) / tail
     rows = []

@@ -65,6 +65,8 @@ _lib.bq_drop_add_ln_fwd.argtypes = [_vp] * 9 + [_i, _i, _f, _f, _f, _i, _u, _vp,
 _lib.bq_drop_add_ln_fwd.restype = ctypes.c_int
 _lib.bq_drop_add_ln_bwd.argtypes = [_vp] * 10 + [_i, _i, _f, _f, _f, _i, _u, _vp, _vp]
 _lib.bq_drop_add_ln_bwd.restype = ctypes.c_int
+_lib.bq_drop_add_ln_bwd_sum.argtypes = [_vp] * 9 + [_i, _i, _f, _f, _i, _u, _vp, _vp]
+_lib.bq_drop_add_ln_bwd_sum.restype = ctypes.c_int
 _lib.bq_twin_drop_add_ln_fwd.argtypes = [_vp] * 10 + [_i, _i, _f, _f, _u, _vp, _vp]
 _lib.bq_twin_drop_add_ln_fwd.restype = ctypes.c_int
 _lib.bq_twin_drop_add_ln_bwd.argtypes = [_vp] * 10 + [_i, _i, _f, _f, _u, _vp, _vp]
@@ -735,6 +737,22 @@ def drop_add_ln_bwd(x, residual, gamma, dy, mean, rstd, eps, p_drop, seed, seed_
                                        int(rows_per_sample), int(seed) & 0xFFFFFFFF, _p(seed_tensor), _stream()),
                "drop_add_ln_bwd")
     return dx, dres, dgb[0], dgb[1]
+
+
+def drop_add_ln_bwd_sum(s, gamma, dy, mean, rstd, eps, seed, seed_tensor, dsum=None, p_path=0.0, rows_per_sample=0, dgb=None):
+    """the backward of a dropout-free site from its stored sum `s` (include/bqhip_fusion.h: bq_drop_add_ln_bwd_sum)
+    -> dx, dresidual (the SAME tensor as dx when p_path == 0), dgamma, dbeta"""
+    H = s.shape[-1]
+    M = s.numel() // H
+    with torch.cuda.device(s.device):
+        dx = torch.empty_like(s)
+        dres = torch.empty_like(s) if p_path > 0 else None
+        if dgb is None:
+            dgb = torch.zeros(2, H, dtype=torch.float32, device=s.device)
+        _check(_lib.bq_drop_add_ln_bwd_sum(_p(s), _p(gamma), _p(dy), _p(dsum), _p(mean), _p(rstd), _p(dx), _p(dres), _p(dgb),
+                                           M, H, float(eps), float(p_path), int(rows_per_sample), int(seed) & 0xFFFFFFFF,
+                                           _p(seed_tensor), _stream()), "drop_add_ln_bwd_sum")
+    return dx, (dres if dres is not None else dx), dgb[0], dgb[1]
 
 
 def twin_drop_add_ln_fwd(x, residual, gamma, beta, gamma2, beta2, eps, p_drop, seed, seed_tensor, want_dgb=False):

@@ -27,6 +27,8 @@ constexpr int GRID_MAXC = 8192;    // cells per scene (LDS histogram of the buil
 constexpr int GRID_CAP = 256;      // in-ball indices a wave can rank in LDS
 constexpr int GRID_HDR = 16;       // floats: lo x y z, inv x y z, gx gy gz (as ints), N
 
+typedef float f32x3 __attribute__((ext_vector_type(3), aligned(4)));
+
 struct GridHeader { float lox, loy, loz, invx, invy, invz; int gx, gy, gz, n; };
 
 __device__ __forceinline__ int cell1(float x, float lo, float inv, int g) {
@@ -39,6 +41,7 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float *__restric
                                                           size_t ws_stride) {
   __shared__ int s_cnt[GRID_MAXC + 2];
   __shared__ float s_red[16][6];
+  __shared__ int s_wsum[16];
   __shared__ float s_box[6];
   constexpr int T = 1024;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
@@ -56,7 +59,8 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float *__restric
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int k = min(k0 + u * T, N - 1);   // (a repeated last point changes no minimum / maximum)
-      px[u] = P[k * 3]; py[u] = P[k * 3 + 1]; pz[u] = P[k * 3 + 2];
+      const f32x3 p3 = *reinterpret_cast<const f32x3 *>(P + k * 3);   // one 12-byte load per point
+      px[u] = p3[0]; py[u] = p3[1]; pz[u] = p3[2];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -100,27 +104,42 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float *__restric
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int k = min(k0 + u * T, N - 1);
-      px[u] = P[k * 3]; py[u] = P[k * 3 + 1]; pz[u] = P[k * 3 + 2];
+      const f32x3 p3 = *reinterpret_cast<const f32x3 *>(P + k * 3);   // one 12-byte load per point
+      px[u] = p3[0]; py[u] = p3[1]; pz[u] = p3[2];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (k0 + u * T < N) atomicAdd(&s_cnt[cell_of(px[u], py[u], pz[u])], 1);
   }
   __syncthreads();
-  if (wid == 0) {   // exclusive scan of the counters by one wave, 64 at a time
-    int carry = 0;
-    for (int b0 = 0; b0 <= ncell; b0 += 64) {
-      const int c = b0 + lane;
-      const int v = c < ncell ? s_cnt[c] : 0;
-      int incl = v;
+  {   // exclusive scan of the counters by the whole workgroup: thread t owns cells [8 t, 8 t + 8) (GRID_MAXC = 8 x 1024), wave
+      // scans of the per-thread totals, one 16-entry scan of the wave totals (round 5 had ONE wave walk the table 64 cells at
+      // a time: 128 dependent six-step shuffle scans, ~25 of the launch's 65 us)
+    static_assert(GRID_MAXC == 8 * T, "one thread per 8 cells");
+    int v[8], tot = 0;
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
-      }
-      if (c <= ncell) s_cnt[c] = carry + incl - v;
-      carry += __shfl(incl, 63);
+    for (int i = 0; i < 8; ++i) {
+      v[i] = (8 * t + i < ncell) ? s_cnt[8 * t + i] : 0;
+      tot += v[i];
     }
+    int incl = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    __syncthreads();                       // (every thread has read its cells; s_wsum aliases nothing)
+    if (lane == 63) s_wsum[wid] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wid; ++w) woff += s_wsum[w];
+    int base = woff + incl - tot;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (8 * t + i <= ncell) s_cnt[8 * t + i] = base;
+      base += v[i];
+    }
+    if (t == T - 1 && ncell == GRID_MAXC) s_cnt[GRID_MAXC] = base;   // (the end marker of a full table lies past the last thread's cells)
   }
   __syncthreads();
   for (int c = t; c <= ncell; c += T) starts[c] = s_cnt[c];
@@ -136,7 +155,8 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float *__restric
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int k = min(k0 + u * T, N - 1);
-      px[u] = P[k * 3]; py[u] = P[k * 3 + 1]; pz[u] = P[k * 3 + 2];
+      const f32x3 p3 = *reinterpret_cast<const f32x3 *>(P + k * 3);   // one 12-byte load per point
+      px[u] = p3[0]; py[u] = p3[1]; pz[u] = p3[2];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {

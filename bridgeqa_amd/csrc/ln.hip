@@ -37,6 +37,9 @@ struct LnArgs {
   // dbeta accumulator (dgb + g*2H); blockIdx.y = group
   int groups;
   const float *gamma2, *beta2;
+  // backward only (round 6): `x` IS the stored sum path(x) + residual (the forward's sum_out; no dropout): the row is read
+  // once instead of twice, the gradients are dx = dz * path scale and dresidual = dz as before
+  int x_is_sum;
 };
 
 __device__ __forceinline__ float ln_path_scale(const LnArgs &a, unsigned seed, int row) {
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(256) void drop_add_ln_bwd_kernel(const __bf16 *__re
         const int i = ch * 4 + j;
         float v = (float)cur.x[ch][j];
         if (a.thresh) v = ln_keep(seed, row, c0 + j, a.thresh) ? v * a.inv_keep : 0.0f;
-        z[i] = v * ps + (float)cur.r[ch][j];       // dropout(x) * path + residual, as load_z
+        z[i] = a.x_is_sum ? v : v * ps + (float)cur.r[ch][j];   // dropout(x) * path + residual, as load_z (or the stored sum)
         const float dyv = (float)cur.d[ch][j];
         z[i] = (z[i] - mean) * rstd;  // z_hat
         g[i] = dyv * gm[i];
@@ -485,7 +488,7 @@ static int ln_fwd_launch(const void *x, const void *residual, const float *gamma
   BQ_REQUIRE(x && gamma && beta && y && mean && rstd, BQ_EINVAL, "drop_add_ln: null pointer");
   BQ_REQUIRE(p_path == 0.0f || rows_per_sample > 0, BQ_EINVAL, "drop_add_ln: rows_per_sample");
   LnArgs a{M, H, eps, 1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr,
-           (unsigned)((double)p_path * 4294967296.0), 1.0f / (1.0f - p_path), rows_per_sample, groups, gamma2, beta2};
+           (unsigned)((double)p_path * 4294967296.0), 1.0f / (1.0f - p_path), rows_per_sample, groups, gamma2, beta2, 0};
 #ifndef BQ_LN_FWD_CAP
 #define BQ_LN_FWD_CAP 1024
 #endif
@@ -523,15 +526,16 @@ extern "C" __attribute__((visibility("default"))) int bq_twin_drop_add_ln_fwd(
 static int ln_bwd_launch(const void *x, const void *residual, const float *gamma, const float *gamma2, int groups,
                          const void *dy, const void *dsum, const float *mean, const float *rstd, void *dx,
                          void *dresidual, float *dgb, int M, int H, float eps, float p_drop, float p_path,
-                         int rows_per_sample, unsigned seed, const unsigned *seed_ptr, void *stream) {
+                         int rows_per_sample, unsigned seed, const unsigned *seed_ptr, void *stream, int x_is_sum = 0) {
   BQ_REQUIRE(M >= 0 && H > 0 && H % 256 == 0 && H <= 1024, BQ_ELIMIT, "drop_add_ln: H=%d unsupported", H);
   BQ_REQUIRE(groups == 1 || (groups == 2 && gamma2 && M % 2 == 0), BQ_EINVAL, "drop_add_ln_bwd: bad row groups");
   if (M == 0) return BQ_OK;
-  BQ_REQUIRE(x && gamma && dy && mean && rstd && dx && dgb && (!residual == !dresidual), BQ_EINVAL,
+  BQ_REQUIRE(x && gamma && dy && mean && rstd && dx && dgb && (x_is_sum ? !residual : (!residual == !dresidual)), BQ_EINVAL,
              "drop_add_ln_bwd: null pointer");
+  BQ_REQUIRE(!x_is_sum || (p_drop == 0.0f && groups == 1), BQ_EINVAL, "drop_add_ln_bwd_sum: no dropout, one row group");
   BQ_REQUIRE(p_path == 0.0f || rows_per_sample > 0, BQ_EINVAL, "drop_add_ln_bwd: rows_per_sample");
   LnArgs a{M, H, eps, 1.0f / (1.0f - p_drop), (unsigned)((double)p_drop * 4294967296.0), seed, seed_ptr,
-           (unsigned)((double)p_path * 4294967296.0), 1.0f / (1.0f - p_path), rows_per_sample, groups, gamma2, nullptr};
+           (unsigned)((double)p_path * 4294967296.0), 1.0f / (1.0f - p_path), rows_per_sample, groups, gamma2, nullptr, x_is_sum};
   // (with the cross-row prefetch: 256 / 384 / 512 / 640 / 1024 / 2048 workgroups -> 33.1 / 32.2 / 35.2 / 40.6 / 41.6 / 60.6 us
   // at the ViT shape, tools/bench_ln.py: every workgroup ends with 2 H float atomics on the same 2 H addresses)
   constexpr int bwd_cap = 384;
@@ -552,6 +556,18 @@ extern "C" __attribute__((visibility("default"))) int bq_drop_add_ln_bwd(
     int rows_per_sample, unsigned seed, const unsigned *seed_ptr, void *stream) {
   return ln_bwd_launch(x, residual, gamma, nullptr, 1, dy, dsum, mean, rstd, dx, dresidual, dgb, M, H, eps, p_drop, p_path,
                        rows_per_sample, seed, seed_ptr, stream);
+}
+// ABI 6.  The backward of a site WITHOUT dropout whose forward wrote sum_out (the residual stream of a pre-LN block, reference
+// models/vit.py:106-109), from that stored sum: `sum` bf16 (M, H) replaces x and residual (one read instead of two: the ViT
+// site drops from 150 to 125 MB, to 100 MB without stochastic depth); dx = dz * path scale, dresidual = dz (NULL with
+// p_path == 0: the two are the same tensor then and the caller hands dx to both).  The normalised value is re-formed from the
+// bf16-rounded sum where bq_drop_add_ln_bwd re-forms it from x and residual in fp32 (one bf16 rounding of the row apart).
+extern "C" __attribute__((visibility("default"))) int bq_drop_add_ln_bwd_sum(
+    const void *sum, const float *gamma, const void *dy, const void *dsum, const float *mean, const float *rstd, void *dx,
+    void *dresidual, float *dgb, int M, int H, float eps, float p_path, int rows_per_sample, unsigned seed,
+    const unsigned *seed_ptr, void *stream) {
+  return ln_bwd_launch(sum, nullptr, gamma, nullptr, 1, dy, dsum, mean, rstd, dx, dresidual, dgb, M, H, eps, 0.0f, p_path,
+                       rows_per_sample, seed, seed_ptr, stream, 1);
 }
 // backward of bq_twin_drop_add_ln_fwd: dgb f32 (2, 2, H) = per row group dgamma then dbeta, accumulated
 extern "C" __attribute__((visibility("default"))) int bq_twin_drop_add_ln_bwd(

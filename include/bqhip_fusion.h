@@ -108,6 +108,14 @@ BQ_API int bq_drop_add_ln_bwd(const void *x, const void *residual, const float *
                               float *dgb, int M, int H, float eps, float p_drop, float p_path, int rows_per_sample,
                               unsigned seed, const unsigned *seed_ptr, void *stream);
 
+/* ABI 6.  The same backward for a site without dropout whose forward wrote sum_out (the pre-LN residual update of
+ * models/vit.py:106-109), from that STORED SUM instead of x and residual: one row read instead of two.  dx = dz * path scale,
+ * dresidual = dz; dresidual may be NULL when p_path == 0 (both gradients are the same tensor then).  The normalised value is
+ * re-formed from the bf16 sum (bq_drop_add_ln_bwd re-forms it from x + residual in fp32: one rounding of the row apart). */
+BQ_API int bq_drop_add_ln_bwd_sum(const void *sum, const float *gamma, const void *dy, const void *dsum, const float *mean,
+                                  const float *rstd, void *dx, void *dresidual, float *dgb, int M, int H, float eps,
+                                  float p_path, int rows_per_sample, unsigned seed, const unsigned *seed_ptr, void *stream);
+
 /* ---- bias gradient: out[n] = sum_m g[m][n], g bf16 (M,N), out f32 (N) (csrc/ln.hip) -------------------------
  * Replaces grad_output.sum(0) of torch's LinearBackward (every nn.Linear of vit.py / med.py).
  * C = bq_colsum_chunks(M) row chunks; C > 1 needs partial (C*N floats) and, for M <= 2048, counter ((N+255)/256

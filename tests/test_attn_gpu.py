@@ -447,6 +447,49 @@ def test_add_layernorm_with_sum_output_and_plain_form(dev, M, H, with_res):
         ops.set_compute_dtype(torch.float32)
 
 
+@pytest.mark.parametrize("p_path", [0.0, 0.3])
+def test_add_layernorm_backward_from_the_stored_sum(dev, p_path):
+    """round 6 (bq_drop_add_ln_bwd_sum): the backward of a dropout-free add + LayerNorm site that wrote its sum re-forms the
+    normalised row from that stored bf16 sum instead of from x and residual -- same gradients as the two-operand backward to
+    one bf16 rounding of the row (5e-3 rel-L2), the same values for dx and dresidual without stochastic depth, dropped
+    samples' dx exactly zero with it"""
+    from bridgeqa_amd import fusion_ops as ops
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        B, L, H = 8, 1025, 768
+        g = torch.Generator().manual_seed(5)
+        ln = torch.nn.LayerNorm(H, eps=1e-6).to(dev)
+        with torch.no_grad():
+            ln.weight.copy_(torch.rand(H, generator=g) + 0.5); ln.bias.copy_(torch.randn(H, generator=g) * 0.1)
+        x0 = (torch.randn(B, L, H, generator=g) * 2).to(dev).to(torch.bfloat16)
+        r0 = (torch.randn(B, L, H, generator=g) * 3 + 0.5).to(dev).to(torch.bfloat16)
+        dy = torch.randn(B, L, H, generator=g).to(dev).to(torch.bfloat16)
+        ds = torch.randn(B, L, H, generator=g).to(dev).to(torch.bfloat16)
+        res = {}
+        for from_sum in (False, True):
+            ops._LN_BWD_FROM_SUM[0] = from_sum
+            ops._CALL_SEED[0] = 1234          # (the same stochastic-depth draw in both arms)
+            x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+            ln.zero_grad()
+            s, y = ops.add_layer_norm(x, r, ln, drop_path=p_path)
+            (y.float() * dy.float()).sum().add((s.float() * ds.float()).sum()).backward()
+            res[from_sum] = (s.detach().clone(), y.detach().clone(), x.grad.clone(), r.grad.clone(), ln.weight.grad.clone(),
+                             ln.bias.grad.clone(), x.grad.data_ptr() == r.grad.data_ptr())
+        a, b = res[False], res[True]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        rel = lambda u, v: ((u.float() - v.float()).norm() / v.float().norm()).item()
+        assert rel(b[2], a[2]) < 5e-3 and rel(b[3], a[3]) < 5e-3 and rel(b[4], a[4]) < 5e-3 and rel(b[5], a[5]) < 5e-3
+        if p_path == 0.0:
+            assert torch.equal(b[2], b[3])   # (one tensor from the kernel; autograd clones it for the second leaf)
+        else:
+            dropped = (a[0] == r0).flatten(1).all(1)          # samples whose branch was dropped: sum == residual
+            assert dropped.any() and not dropped.all()
+            assert torch.equal(b[2][dropped], torch.zeros_like(b[2][dropped])) and (b[2][~dropped] != 0).any()
+    finally:
+        ops._LN_BWD_FROM_SUM[0] = True
+        ops.set_compute_dtype(torch.float32)
+
+
 def test_add_layernorm_stochastic_depth_drops_whole_samples(dev):
     """vit.py:107-108 x + drop_path(f): with p_path > 0 a sample's branch rows are either all dropped (sum == residual)
     or all scaled by 1 / keep; the backward sends the same scale to dx and an unscaled gradient to the residual."""

@@ -109,6 +109,39 @@ def test_blip_vqa3d_vs_reference_golden(golden):
     run_blip(golden("fusion_blip.npz"), torch.device("cpu"), 2e-4, 2e-5)
 
 
+def test_prepared_token_masks_equal_the_masks_built_in_place(golden):
+    """round 6: BLIP_VQA3D.prepare_text also builds the attention masks that depend on the token masks only (question
+    self-attention mask and its stacked form, the 2D stream's encoder mask over cat(image tokens, question), the decoder's
+    causal mask and its stacked question mask); a forward fed with them (text_prep=) returns exactly what the forward that
+    builds every mask in place returns -- loss, fused states, attention maps -- and the same input gradient"""
+    from bridgeqa_amd.blip_vqa_3d import BLIP_VQA3D, SyntheticTokenizer
+    from bridgeqa_amd.med import BertConfig
+    g = golden("fusion_blip.npz")
+    gm = dict(np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "fusion_med.npz")))
+    cfg = BertConfig(num_hidden_layers=2, vocab_size=200, max_position_embeddings=64)
+    torch.manual_seed(3)
+    m = BLIP_VQA3D(med_config=cfg, image_size=64, num_answers=10, use_text_decoder=True, share_decoder=True,
+                   scene_size=32, tokenizer=SyntheticTokenizer(0, 102, 198, 199)).eval()
+    t = lambda k: torch.from_numpy(g[k])
+    tm = lambda k: torch.from_numpy(gm[k])
+    q = {"input_ids": tm("tw_ids"), "attention_mask": tm("tw_am")}
+    a = {"input_ids": tm("dec_ids"), "attention_mask": tm("dec_am")}
+    res = []
+    for prepared in (False, True):
+        obj = t("bl_obj").clone().requires_grad_(True)
+        dd = {}
+        prep = m.prepare_text(dict(q), dict(a)) if prepared else None
+        if prepared:
+            assert set(prep["enc_masks"]) == {"ext", "enc_ext"} and set(prep["dec_masks"]) == {"ext", "enc_ext"}
+            assert prep["enc_masks"]["enc_ext"].shape[-1] == m.visual_encoder.patch_embed.num_patches + 1 + q["input_ids"].shape[1]
+        loss, fused, qmask = m(t("bl_img"), dict(q), dict(a), scene_object_embeds=obj, scene_object_mask=tm("tw_om"),
+                               data_dict=dd, text_prep=prep)
+        loss.backward()
+        res.append((loss.detach(), fused.detach(), dd["2d_cross_attention"], dd["3d_cross_attention"], obj.grad.clone()))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+
+
 def test_twin_init_copies_2d_stream_and_backward_reaches_both():
     from bridgeqa_amd import med
     torch.manual_seed(0)

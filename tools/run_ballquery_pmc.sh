@@ -12,12 +12,18 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/c -- python3 $R
 cd $R
 rm -f $D/bq.jsonl
 python tools/pmc_summary.py $D/t $D/b $D/c --match ball_query_grid --json $D/bq.jsonl --label ball_query_sa1 > $D/ballquery_pmc.txt 2>&1
+rm -f $D/gb.jsonl
+python tools/pmc_summary.py $D/t $D/b $D/c --match grid_build --json $D/gb.jsonl --label grid_build_sa1 >> $D/ballquery_pmc.txt 2>&1
 python - <<PY
 import json
 rs = [json.loads(l) for l in open("$D/bq.jsonl")]   # (the trace pass and the counter passes report the grid in different units: two records)
 pick = lambda k: next((r[k] for r in rs if r.get(k) is not None), None)
+gb = [json.loads(l) for l in open("$D/gb.jsonl")]
+gpick = lambda k: next((r[k] for r in gb if r.get(k) is not None), None)
 out = {"B": 16, "N": 40000, "M": 2048, "avg_us": pick("avg_us"), "hbm_read_bytes": pick("fetch_bytes"), "hbm_write_bytes": pick("write_bytes"),
-       "file": "profiles/r05_ballquery_pmc.json",
+       "grid_build": {"avg_us": gpick("avg_us"), "hbm_read_bytes": gpick("fetch_bytes"), "hbm_write_bytes": gpick("write_bytes"),
+                      "note": "the launch that bins the scene's points in front of the query kernel (one workgroup per scene); avg_us above is the QUERY kernel alone, bench.py's `alone` time covers both"},
+       "file": "profiles/r06_ballquery_pmc.json",
        "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/time_ball_query.py; read = 2 x FETCH_SIZE x 1024 "
                  "(gfx950), write = WRITE_SIZE x 1024; fabric side, per launch"}
 json.dump(out, open("$D/ballquery_pmc.json", "w"))

@@ -22,7 +22,7 @@ gb = [json.loads(l) for l in open("$D/gb.jsonl")]
 gpick = lambda k: next((r[k] for r in gb if r.get(k) is not None), None)
 out = {"B": 16, "N": 40000, "M": 2048, "avg_us": pick("avg_us"), "hbm_read_bytes": pick("fetch_bytes"), "hbm_write_bytes": pick("write_bytes"),
        "grid_build": {"avg_us": gpick("avg_us"), "hbm_read_bytes": gpick("fetch_bytes"), "hbm_write_bytes": gpick("write_bytes"),
-                      "note": "the launch that bins the scene's points in front of the query kernel (one workgroup per scene); avg_us above is the QUERY kernel alone, bench.py's `alone` time covers both"},
+                      "note": "the launch that bins the scene's points in front of the query kernel (one workgroup per scene); avg_us above is the QUERY kernel alone, bench.py's 'alone' time covers both"},
        "file": "profiles/r06_ballquery_pmc.json",
        "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/time_ball_query.py; read = 2 x FETCH_SIZE x 1024 "
                  "(gfx950), write = WRITE_SIZE x 1024; fabric side, per launch"}

@@ -88,4 +88,8 @@ g = emit("BACKWARD, twin level 4 of 12 (weight gradients are parked and flushed 
 print("12 levels: forward %.2f ms in the step against %.2f ms of floor; backward %.2f ms against %.2f ms of floor.  The two big launches of a level "
       "(K/V projection, pair attention) run at 38 - 53 %% of this floor's rate -- the GEMM family's and the narrow attention's usual efficiency --, the "
       "ten small ones at 2 - 3 x their floor: each is one load -> compute -> store round trip of a 240-workgroup launch with a 100 - 140 KB operand "
-      "panel per CU (DESIGN.md section 5.3)." % (12 * f[0] / 1e3, 12 * f[1] / 1e3, 12 * g[0] / 1e3, 12 * g[1] / 1e3))
+      "panel per CU (DESIGN.md section 5.3).  What this floor leaves out for the small GEMMs: a 640 x 768 x 768 launch on 64 x 32 tiles moves "
+      "240 x 144 KB = 34.6 MB from L2 to LDS (every weight panel is staged by 20 row tiles, every row panel by 12 column tiles) -- 2.9 us at the "
+      "11.9 TB/s this fabric sustained for the GEMM family (profiles/EXPERIMENTS_r1-r5.md section 4.5); larger tiles halve the bytes and quarter the CUs "
+      "that pull them.  With that term a K = 768 projection is 1.56 + 0.8 + 2.9 + ~0.5 (MFMA tail, epilogue) = 5.8 us against 6.6 - 7.7 measured."
+      % (12 * f[0] / 1e3, 12 * f[1] / 1e3, 12 * g[0] / 1e3, 12 * g[1] / 1e3))

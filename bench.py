@@ -669,8 +669,8 @@ def ballquery_roofline(args, ops, alone_ms, alone_bg_ms, phased):
             pmc = None   # (taken at another shape: not this run's traffic)
     except (OSError, ValueError):
         pass
-    return {"kernel": "bq::grid_build_kernel + bq::ball_query_grid_kernel (csrc/ball_query_grid.hip, round 5: a uniform grid leaves "
-                      "~100 candidate points per centre instead of all N; index-exact), SA1: %d centres x %d points, radius 0.2, "
+    return {"kernel": "bq::grid_box_kernel + grid_cellid_kernel + grid_chunk_kernel + bq::ball_query_grid_kernel (csrc/ball_query_grid.hip: "
+                      "a uniform grid leaves ~100 candidate points per centre instead of all N; index-exact), SA1: %d centres x %d points, radius 0.2, "
                       "nsample 64, B=%d" % (M, N, B),
             "bound": "hbm", "convention": "streaming-equivalent (SURVEY §8d): 12*N*M*B bytes per launch = what the reference's "
                                           "exhaustive kernel streams -- this kernel SKIPS ~99 % of them, so `frac` far above 1 is the "

@@ -181,6 +181,13 @@ _lib.bq_ball_query_grid_workspace_bytes.argtypes = [_i, _i]
 _lib.bq_ball_query_grid_workspace_bytes.restype = ctypes.c_size_t
 _lib.bq_ball_query_grid.argtypes = [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, ctypes.c_size_t, _vp]
 _lib.bq_ball_query_grid.restype = ctypes.c_int
+_lib.bq_ball_query_grid_build_mode.argtypes = [_i]
+_lib.bq_ball_query_grid_build_mode.restype = ctypes.c_int
+
+
+def ball_query_grid_build_mode(multi):
+    """1: the multi-workgroup grid build (default), 0: one workgroup per scene; returns the previous mode (include/bqhip.h)"""
+    return int(_lib.bq_ball_query_grid_build_mode(int(multi)))
 
 
 def group_points(points, idx):

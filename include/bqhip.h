@@ -99,6 +99,12 @@ BQ_API int bq_ball_query_background(const float *new_xyz, const float *xyz, int3
  * uses it from N = 8192); workspace: device scratch of bq_ball_query_grid_workspace_bytes(B, N) bytes, contents irrelevant.
  * radius > 0. */
 BQ_API size_t bq_ball_query_grid_workspace_bytes(int B, int N);
+/* ABI 6.  How bq_ball_query_grid bins a scene's points: 1 (default) = three short launches for 4096 <= N < 2^19 (partial
+ * bounding boxes; the cell of every point as 16 bits; 16 workgroups per scene that each own a chunk of the cells -- histogram,
+ * start table and records of their chunk, no scan across workgroups and no global atomics); 0 = round 5's one workgroup per
+ * scene (one launch).  Same indices either way (the order of the records inside a cell does not reach the output).  Returns the
+ * previous mode; a measurement switch (tools/time_ball_query.py). */
+BQ_API int bq_ball_query_grid_build_mode(int multi);
 BQ_API int bq_ball_query_grid(const float *new_xyz, const float *xyz, int32_t *idx, int B, int N, int M, float radius,
                               int nsample, void *workspace, size_t workspace_bytes, void *stream);
 

@@ -276,6 +276,15 @@ def _grid_vs_scan(ext, new_xyz, xyz, r, S):
     try:
         ext.BALL_QUERY_GRID_MIN_N[0] = 1
         a = ext.ball_query(new_xyz, xyz, r, S)
+        # (round 6) both ways of binning the scene -- box / cell ids / 16 cell-chunk workgroups per scene in three launches
+        # (default from N = 4096) and one workgroup per scene -- must give the same indices: the order of the records inside
+        # a cell never reaches the output
+        mode = ext.ball_query_grid_build_mode(0)
+        try:
+            a1 = ext.ball_query(new_xyz, xyz, r, S)
+        finally:
+            ext.ball_query_grid_build_mode(mode)
+        assert torch.equal(a, a1)
         ext.BALL_QUERY_GRID_MIN_N[0] = 1 << 30
         b = ext.ball_query(new_xyz, xyz, r, S)
     finally:

@@ -23,6 +23,31 @@ e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 100
 print("ball query SA1 (16 x 40000 -> 2048 x 64): %.1f us  = %.2f TB/s of point coordinates read through L2" % (us, 16 * 2048 * 40000 * 12 / us / 1e6))
+# round 6: the one-workgroup-per-scene build of round 5 against the multi-workgroup build (default)
+# (replayed from a HIP graph, as inside the step: launched one by one from Python the five launches of mode 1 are host-bound)
+for mode in (0, 1):
+    _ext.ball_query_grid_build_mode(mode)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(2):
+            _ext.ball_query(new_xyz, xyz, 0.2, 64)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st):
+        for _ in range(10):
+            idx_m = _ext.ball_query(new_xyz, xyz, 0.2, 64)
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    print("grid build mode %d (%s): build + query %.1f us under graph replay; identical indices: %s"
+          % (mode, "one workgroup per scene" if mode == 0 else "box, cell ids, 16 cell-chunk workgroups per scene", e0.elapsed_time(e1) * 10,
+             bool(torch.equal(idx, idx_m))))
+    del g
 # round 5: the same query with the grid withdrawn (exhaustive scan), and the two launches of the grid path apart
 _ext.BALL_QUERY_GRID_MIN_N[0] = 1 << 30
 for _ in range(2):

@@ -14,16 +14,14 @@
 //
 // gemm256_kernel: 256 x 256 output tile per workgroup, 8 waves (2 along i x 4 along j, 128 x 64 per wave), K step 64,
 // LDS-DMA staging (buffer_load ... lds: bounds-checked, no VGPRs), two 64 KB LDS buffers.  The K loop is a
-// 4-phase-per-tile software pipeline in which the two wave groups (wr = 0 / 1, one wave of each per SIMD) run HALF A
+// phased software pipeline in which the two wave groups (wr = 0 / 1, one wave of each per SIMD) run HALF A
 // PHASE APART: while one group issues its 16-MFMA cluster the other issues its LDS reads and the next DMA, so the
 // matrix pipe of every SIMD always has a wave feeding it (cdna_hip_programming.md §5 "8-phase template"; the schedule
 // below is this file's own and its hazard analysis is in DESIGN.md §4.4):
 //   staging unit = 64 rows x 64 k (8 KB, one DMA per wave): A0(g) A1(g) = the two 64-row halves of wave group g's
 //   P rows, B0(h) B1(h) = the first / second 32 columns of the four wave columns (h = wc >> 1);
-//   phase p of tile t reads      p0: A0,B0 -> Q00   p1: B1 -> Q01   p2: A1 -> Q11   p3: (B0 kept) -> Q10
-//   and stages (2 DMAs per wave) p0: B1(t+1)        p1: A1(t+1)     p2: A0(t+2)     p3: B0(t+2)
-//   followed by ONE s_waitcnt vmcnt(8): everything older than the last four stages has landed (a stage is consumed
-//   >= 4 phases ~ 2000 cycles after it was issued: HBM misses are covered), then barrier | MFMA | barrier.
+//   rounds 1-5: four phases of 16 MFMAs per K tile; round 6: TWO of 32 (the schedule and its wait arithmetic stand at the
+//   K loop), the fragment reads as inline asm (gemm_common.h: the compiler put s_waitcnt vmcnt(0) in front of its own).
 #include "gemm_common.h"
 
 namespace bq {
@@ -41,6 +39,13 @@ typedef unsigned u32x4_sk __attribute__((ext_vector_type(4)));
 // -- fc2 forward 98.6 us against 76.7 on whole 256 x 256 tiles (75.4 on 256 x 128), the c3 step + 0.9 ms: with one workgroup per
 // CU nothing hides a segment's second pipeline fill, the 256 KB park and the 256 KB fold.  Off by default
 // (bq_gemm_streamk_mode bit 1).
+//
+// Round 6, tried on the weight-gradient form and withdrawn: PREFETCH ROLES -- the four waves of group 0 issue all the LDS-DMAs
+// (and do the counted waits), the four of group 1 issue none and touch, one dword per 128-B line, the operand rows four K
+// tiles ahead, so that the DMAs hit L2 (a prefetch by the wave that also issues DMAs is useless: vmcnt retires in issue
+// order).  Bit-identical, 20 % SLOWER on every cut of the 48 problems (2.49 -> 3.02 ms; profiles/r06_dw_prefetch.txt): the
+// launches are not waiting for HBM, they are at the LDS port (192 KB of fragment reads + 64 KB of DMA writes per K tile =
+// 2048 clocks at 128 B/clk, the MFMA time of the same K tile).
 template <bool P_XC, bool Q_XC, int EPI, bool OUT_F32, bool SK = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
   static_assert(!SK || (!P_XC && !Q_XC && !OUT_F32 && (EPI == EPI_NONE || EPI == EPI_BIAS)), "stream-K: K-contiguous operands, bf16 out");
@@ -199,74 +204,77 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs args) {
         qs[BO + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, FB[b][kk], qs[BO + b], 0, 0, 0);   \
   }
 
-  // ---- prologue: stages 0..5 = A0(0) B0(0) B1(0) A1(0) A0(1) B0(1) ------------------------------------------------
-  stage_pair(0, 0); stage_pair(4, 0); stage_pair(6, 0); stage_pair(2, 0); stage_pair(0, 1); stage_pair(4, 1);
+  // ---- prologue: tile 0 whole, then A0 B0 B1 of tile 1 (its A1 is staged by X(0)) ---------------------------------------
+  stage_pair(0, 0); stage_pair(4, 0); stage_pair(6, 0); stage_pair(2, 0); stage_pair(0, 1); stage_pair(4, 1); stage_pair(6, 1);
   if (GTAB) gelu_tab_fill<EPI == EPI_DGELU>(s_gtab, tid, 512);  // under the prologue's DMA latency; read after the K loop
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // A0 B0 B1 of tile 0 have landed (behind them: A1(0) and tile 1's six)
   BQ_BARRIER();
   if (wr == 1) BQ_BARRIER();  // group 1 runs half a phase behind group 0
 
   bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+  const unsigned smem_lds = lds_addr_of(smem);
 #define BQ_MFMA_Q(AO, FB, BO)                                                                         \
   _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int a = 0; a < 4; ++a)      \
       _Pragma("unroll") for (int b = 0; b < 2; ++b) acc[AO + a][BO + b] =                             \
           __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][kk], FB[b][kk], acc[AO + a][BO + b], 0, 0, 0);
+  // (the LDS reads are waited for BEFORE the barrier: behind it no read of any wave is in flight, so the phase that follows
+  // may restage what this one read)
 #define BQ_PHASE_SYNC_A()                                   \
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          \
-  BQ_BARRIER();                                             \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
+  BQ_BARRIER();                                             \
   __builtin_amdgcn_sched_barrier(0);                        \
   __builtin_amdgcn_s_setprio(1);
 #define BQ_PHASE_SYNC_B()                                   \
   __builtin_amdgcn_s_setprio(0);                            \
   BQ_BARRIER();
 
+  // Round 6: TWO phases per K tile, 32 MFMAs (512 cycles) each, instead of four of 16.  The other group's reads, DMA issue
+  // and barrier skew of a phase (~300-400 cycles) used to stand against a 256-cycle MFMA cluster -- the matrix pipe idled
+  // about half of every phase; against 512 cycles they fit.
+  //   X(t) reads A0 B0 B1 of tile t -> Q00 Q01 ; stages A1(t+1)        (its image was last read in Y(t-1))
+  //   Y(t) reads A1                 -> Q11 Q10 ; stages A0 B0 B1 (t+2)  (their images were read in X(t))
+  // A wave's DMAs in issue order: ... a(t) = A1(t+1) [2], b(t) = A0 B0 B1 (t+2) [6], a(t+1) [2], b(t+1) [6] ...; the wait of
+  // X(t+1) wants a(t) (read next, in Y(t+1)): b(t) + a(t+1) = 8 behind it; the wait of Y(t+1) wants b(t) (read in X(t+2)):
+  // a(t+1) + b(t+1) = 8 behind it -- vmcnt(8) both times, a stage is waited for one K tile after it was issued.
   for (int kt = 0; kt < nkt; ++kt) {
-    const unsigned char *buf = smem + (kt & 1) * 65536;
-    // ---- p0: A0, B0 -> Q00 ; stage B1(t+1)
+    const unsigned buf = smem_lds + (unsigned)((kt & 1) * 65536);   // (asm reads: gemm_common.h, read_frag_asm)
+    // ---- X: A0, B0, B1 -> Q00, Q01 ; stage A1(t+1)
     if (vA0) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag<P_XC>(buf + uA0, a, kk, kc_base, xc_base);
+        for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag_asm<P_XC>(buf + uA0, a, kk, kc_base, xc_base);
     }
     if (vB0) {
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fb0[b][kk] = read_frag<Q_XC>(buf + uB0, bsub + b, kk, kc_base, xc_base);
+        for (int kk = 0; kk < 2; ++kk) fb0[b][kk] = read_frag_asm<Q_XC>(buf + uB0, bsub + b, kk, kc_base, xc_base);
     }
-    stage_pair(6, kt + 1);
-    BQ_PHASE_SYNC_A();
-    if (vA0 && vB0) { BQ_MFMA_Q(0, fb0, 0) }
-    if (vB0) { BQ_MFMA_QSUM(fb0, 0) }
-    BQ_PHASE_SYNC_B();
-    // ---- p1: B1 -> Q01 ; stage A1(t+1)
     if (vB1) {
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fb1[b][kk] = read_frag<Q_XC>(buf + uB1, bsub + b, kk, kc_base, xc_base);
+        for (int kk = 0; kk < 2; ++kk) fb1[b][kk] = read_frag_asm<Q_XC>(buf + uB1, bsub + b, kk, kc_base, xc_base);
     }
     stage_pair(2, kt + 1);
     BQ_PHASE_SYNC_A();
+    if (vA0 && vB0) { BQ_MFMA_Q(0, fb0, 0) }
+    if (vB0) { BQ_MFMA_QSUM(fb0, 0) }
     if (vA0 && vB1) { BQ_MFMA_Q(0, fb1, 2) }
     if (vB1) { BQ_MFMA_QSUM(fb1, 2) }
     BQ_PHASE_SYNC_B();
-    // ---- p2: A1 -> Q11 ; stage A0(t+2)
+    // ---- Y: A1 (B0, B1 kept in registers) -> Q11, Q10 ; stage A0, B0, B1 (t+2)
     if (vA1) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag<P_XC>(buf + uA1, a, kk, kc_base, xc_base);
+        for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag_asm<P_XC>(buf + uA1, a, kk, kc_base, xc_base);
     }
-    stage_pair(0, kt + 2);
+    stage_pair(0, kt + 2); stage_pair(4, kt + 2); stage_pair(6, kt + 2);
     BQ_PHASE_SYNC_A();
     if (vA1 && vB1) { BQ_MFMA_Q(4, fb1, 2) }
-    BQ_PHASE_SYNC_B();
-    // ---- p3: (B0 kept in registers) -> Q10 ; stage B0(t+2)
-    stage_pair(4, kt + 2);
-    BQ_PHASE_SYNC_A();
     if (vA1 && vB0) { BQ_MFMA_Q(4, fb0, 0) }
     BQ_PHASE_SYNC_B();
   }

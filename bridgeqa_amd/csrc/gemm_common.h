@@ -185,6 +185,38 @@ __device__ __forceinline__ bf16x8 read_frag_cf(const unsigned char *unit, int su
   }
 }
 
+// ---- the same fragment reads as INLINE ASM (round 6) --------------------------------------------------------------------
+// hipcc's waitcnt pass knows that an LDS-DMA (buffer_load ... lds) writes LDS and, without alias information, puts
+// s_waitcnt vmcnt(0) in front of LDS reads that follow one: in gemm256_kernel every phase's fragment reads then waited for ALL
+// the DMAs in flight -- the four-stage look-ahead of its counted waits never existed, a K tile of the weight-gradient launches
+// cost four L2 / HBM round trips (2.1-2.5 us against 0.85 us of MFMA time).  Reads the compiler cannot see are ordered by the
+// kernel's own counted waits and barriers only; the caller waits lgkmcnt(0) behind a sched_barrier before the first use.
+template <bool XC>
+__device__ __forceinline__ bf16x8 read_frag(const unsigned char *unit, int sub16, int kk, int kc_base, const int (&xc_base)[4]);
+typedef __attribute__((address_space(3))) unsigned char lds_u8c_t;
+__device__ __forceinline__ unsigned lds_addr_of(const void *p) { return (unsigned)(size_t)((lds_u8c_t *)p); }
+// (measurement builds only, tools/bench_dw_prefetch.py: 0 = the compiler-visible reads of rounds 1-5)
+#ifndef BQ_G256_ASM_READS
+#define BQ_G256_ASM_READS 1
+#endif
+template <bool XC>
+__device__ __forceinline__ bf16x8 read_frag_asm(unsigned unit, int sub16, int kk, int kc_base, const int (&xc_base)[4]) {
+  if (!BQ_G256_ASM_READS) {
+    return read_frag<XC>((const unsigned char *)((lds_u8c_t *)(size_t)unit), sub16, kk, kc_base, xc_base);
+  } else if (!XC) {
+    bf16x8 v;
+    const unsigned a = unit + (unsigned)(sub16 * 2048 + (kc_base ^ (kk << 6)));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a) : "memory");
+    return v;
+  } else {
+    bf16x4 lo, hi;
+    const unsigned a = unit + (unsigned)(xc_base[sub16] + kk * 4096);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(hi) : "v"(a) : "memory");
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+
 #define BQ_BARRIER()                                        \
   do {                                                      \
     __builtin_amdgcn_sched_barrier(0);                      \

@@ -217,6 +217,21 @@ __device__ __forceinline__ bf16x8 read_frag_asm(unsigned unit, int sub16, int kk
   }
 }
 
+// the closed-form contraction-major read (read_frag_cf<true>) as inline asm, for the same reason as read_frag_asm; the
+// K-contiguous form stays a compiler-visible load (hipcc does not fence those: tools/isa_waits.py)
+template <bool XC>
+__device__ __forceinline__ bf16x8 read_frag_cf_x(const unsigned char *unit, int sub16, int kk, int kc_base, int xc0, int xcg) {
+  if (!XC) {
+    return read_frag_cf<false>(unit, sub16, kk, kc_base, xc0, xcg);
+  } else {
+    bf16x4 lo, hi;
+    const unsigned a = lds_addr_of(unit) + (unsigned)(xc0 + ((sub16 ^ xcg) << 5) + kk * 4096);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(hi) : "v"(a) : "memory");
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+
 #define BQ_BARRIER()                                        \
   do {                                                      \
     __builtin_amdgcn_sched_barrier(0);                      \

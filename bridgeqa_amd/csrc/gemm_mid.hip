@@ -281,11 +281,11 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag_cf<P_XC>(smem + uA0, a, kk, kc_base, xc0, xcg);
+        for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag_cf_x<P_XC>(smem + uA0, a, kk, kc_base, xc0, xcg);
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fb0[b][kk] = read_frag_cf<Q_XC>(qb, bsub + b, kk, kc_base, xc0, xcg);
+        for (int kk = 0; kk < 2; ++kk) fb0[b][kk] = read_frag_cf_x<Q_XC>(qb, bsub + b, kk, kc_base, xc0, xcg);
       dma_q(1, gk + 1);
       BQ_MID_COMPUTE_BEGIN();
       if (vA0 && vB0) { BQ_MID_MFMA(0, fb0, 0) }
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fb1[b][kk] = read_frag_cf<Q_XC>(qb + 8192, bsub + b, kk, kc_base, xc0, xcg);
+        for (int kk = 0; kk < 2; ++kk) fb1[b][kk] = read_frag_cf_x<Q_XC>(qb + 8192, bsub + b, kk, kc_base, xc0, xcg);
       dma_p(0);
       BQ_MID_COMPUTE_BEGIN();
       if (vA0 && vB1) { BQ_MID_MFMA(0, fb1, 2) }
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmArgs args) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag_cf<P_XC>(smem + uA1, a, kk, kc_base, xc0, xcg);
+        for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag_cf_x<P_XC>(smem + uA1, a, kk, kc_base, xc0, xcg);
       if (!last) dma_q(0, gk + 2);
       BQ_MID_COMPUTE_BEGIN();
       if (vA1 && vB1) { BQ_MID_MFMA(4, fb1, 2) }

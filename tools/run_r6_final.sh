@@ -1,10 +1,15 @@
-# the part of tools/run_r6_profiles.sh that depends on the LAST code changes of round 6 (LayerNorm backward from the stored
-# sum, grid build): step profiles, phases, bench lines, ball-query PMC with BOTH kernels.  GEMM / attention / FPS / det-bwd PMC,
-# the CPU baseline and the A/B files stay as run_r6_profiles.sh left them (those kernels did not change).
+# the round-6 evidence that depends on the LAST code changes (gemm256's new K loop, the asm fragment reads, the grid build):
+# per-form GEMM PMC, GEMM family vs hipBLASLt, ball-query PMC with every kernel, step profiles, phases, bench lines.  Attention /
+# FPS / det-bwd PMC, the CPU baseline and the attention A/B files stay as tools/run_r6_profiles.sh left them (those kernels did
+# not change).  usage: bash tools/run_r6_final.sh <outdir-under-gpurun_out>; then bash tools/collect_r6_final.sh <outdir> locally
 OUT=${1:-r6f}
 R=$GRAFT_REPO_ROOT
 cd $R
 mkdir -p $R/gpurun_out/$OUT
+bash tools/run_gemm_pmc.sh $OUT/pmc > /dev/null 2>&1
+cp gpurun_out/$OUT/pmc/gemm_pmc.jsonl gpurun_out/$OUT/gemm_pmc.jsonl; cp gpurun_out/$OUT/pmc/gemm_pmc_summary.txt gpurun_out/$OUT/gemm_pmc_summary.txt
+cp gpurun_out/$OUT/gemm_pmc.jsonl profiles/r06_gemm_pmc.jsonl
+python tools/bench_gemm2.py --json gpurun_out/$OUT/gemm_bench.json > gpurun_out/$OUT/gemm_bench.log 2>&1
 bash tools/run_ballquery_pmc.sh $OUT/bq > gpurun_out/$OUT/bq.log 2>&1
 cp gpurun_out/$OUT/bq/ballquery_pmc.json profiles/r06_ballquery_pmc.json
 BENCH_ARGS="--no-loop-reference" bash tools/run_step_profile.sh $OUT/step > gpurun_out/$OUT/step_profile.log 2>&1

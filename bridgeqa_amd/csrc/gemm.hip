@@ -757,11 +757,17 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const GemmArgs args) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag_cf<P_XC>(buf, wr * 2 + a, kk, kc_base, xc0, xcg);
+        for (int kk = 0; kk < 2; ++kk) fa[a][kk] = read_frag_cf_x<P_XC>(buf, wr * 2 + a, kk, kc_base, xc0, xcg);
 #pragma unroll
       for (int b = 0; b < QF; ++b)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fb[b][kk] = read_frag_cf<Q_XC>(buf + 8192, wc * QF + b, kk, kc_base, xc0, xcg);
+        for (int kk = 0; kk < 2; ++kk) fb[b][kk] = read_frag_cf_x<Q_XC>(buf + 8192, wc * QF + b, kk, kc_base, xc0, xcg);
+      if (P_XC || Q_XC) {
+        // (round 6) the contraction-major reads are inline asm: behind stage() hipcc fenced them with vmcnt(0) -- every step
+        // of the weight-gradient forms waited for the DMAs it had just issued for step + NS - 1 (tools/isa_waits.py)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll

@@ -58,6 +58,10 @@ def main():
             der = []
             if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
                 der.append("MFMA utilisation %.1f %%" % (100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024)))
+            if "GRBM_GUI_ACTIVE" in c and dur[key]:
+                # (MI355X_MICROARCH.md, DVFS give-back: the chip lowers its clock under MFMA load; rocprofv3 sums the 8 XCDs;
+                # reads high on dispatches under ~0.3 ms)
+                der.append("effective clock %.2f GHz" % (c["GRBM_GUI_ACTIVE"] / 8 / (sum(dur[key]) / len(dur[key])) / 1e3))
             if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
                 der.append("VALU busy %.1f %%" % (100 * 4 * c["SQ_ACTIVE_INST_VALU"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024)))
             if "SQ_INSTS_VALU" in c and c.get("SQ_INSTS_MFMA"):
@@ -75,6 +79,8 @@ def main():
                        avg_us=round(sum(dur[key]) / len(dur[key]), 2) if dur[key] else None)
             if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
                 rec["mfma_util"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024), 4)
+                if dur[key]:
+                    rec["effective_clock_ghz"] = round(c["GRBM_GUI_ACTIVE"] / 8 / (sum(dur[key]) / len(dur[key])) / 1e3, 3)
             if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
                 rec["valu_busy"] = round(4 * c["SQ_ACTIVE_INST_VALU"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024), 4)
             if "FETCH_SIZE" in c:

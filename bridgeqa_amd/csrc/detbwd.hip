@@ -88,16 +88,18 @@ __global__ __launch_bounds__(256) void sa_bwd_kernel(const SaBwdArgs ar) {
   const int kt0 = (int)blockIdx.x * kt_per;
   const int nkt = max(0, min(kt_per, nkt_all - kt0));
 
-  const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void *)ar.X, 0, ar.x_bytes, 0x00020000);
-  const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void *)ar.P, 0, ar.p_bytes, 0x00020000);
-  const auto rsD = __builtin_amdgcn_make_buffer_rsrc((void *)ar.dOut, 0, ar.d_bytes, 0x00020000);
-  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(POOL ? (const void *)ar.arg : (const void *)ar.dOut), 0,
+  [[maybe_unused]] const auto rsD = __builtin_amdgcn_make_buffer_rsrc((void *)ar.dOut, 0, ar.d_bytes, 0x00020000);
+  [[maybe_unused]] const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(POOL ? (const void *)ar.arg : (const void *)ar.dOut), 0,
                                                      POOL ? ar.a_bytes : 0u, 0x00020000);
   const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void *)ar.dX, 0, DX ? ar.dx_bytes : 0u, 0x00020000);
   const int cp = lane & 7;
+  // the same descriptors for the LDS-DMAs, which are inline asm (gemm_common.h, lds_dma16: hipcc fenced every LDS access of
+  // the tile loop against the builtin -- the loop's stages never overlapped anything)
+  const i32x4_rs dsX = raw_rsrc_v4(ar.X, ar.x_bytes), dsP = raw_rsrc_v4(ar.P, ar.p_bytes), dsD = raw_rsrc_v4(ar.dOut, ar.d_bytes);
+  [[maybe_unused]] const i32x4_rs dsA = raw_rsrc_v4(POOL ? (const void *)ar.arg : (const void *)ar.dOut, POOL ? ar.a_bytes : 0u);
 
   if constexpr (DX) {   // the weight image: [TJ][TI] units of [64 n][64 i], contraction-major
-    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void *)ar.W, 0, ar.w_bytes, 0x00020000);
+    const i32x4_rs rsW = raw_rsrc_v4(ar.W, ar.w_bytes);
 #pragma unroll
     for (int v = 0; v < TJ; ++v)
 #pragma unroll
@@ -106,8 +108,7 @@ __global__ __launch_bounds__(256) void sa_bwd_kernel(const SaBwdArgs ar) {
         for (int d = 0; d < 2; ++d) {
           const int ur = (wave * 2 + d) * 8 + (lane >> 3);
           const unsigned off = (unsigned)((((v * 64 + ur) * ar.ldw) + u * 64 + (cp ^ (xg(ur) << 1)) * 8) * 2);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_t *)(wimg + (v * TI + u) * 8192 + (wave * 2 + d) * 1024), 16, off,
-                                                   0, 0, 0);
+          lds_dma16(rsW, wimg + (v * TI + u) * 8192 + (wave * 2 + d) * 1024, off);
         }
   }
 
@@ -131,17 +132,14 @@ __global__ __launch_bounds__(256) void sa_bwd_kernel(const SaBwdArgs ar) {
     for (int d = 0; d < 2; ++d) {
 #pragma unroll
       for (int u = 0; u < TI; ++u)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_t *)(base + u * 8192 + (wave * 2 + d) * 1024), 16,
-                                                 live ? vx[d] + u * 128 : DEAD, 0, 0, 0);
+        lds_dma16(dsX, base + u * 8192 + (wave * 2 + d) * 1024, live ? vx[d] + u * 128 : DEAD);
 #pragma unroll
       for (int v = 0; v < TJ; ++v)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_void_t *)(base + (TI + v) * 8192 + (wave * 2 + d) * 1024), 16,
-                                                 live ? vp[d] + v * 128 : DEAD, 0, 0, 0);
+        lds_dma16(dsP, base + (TI + v) * 8192 + (wave * 2 + d) * 1024, live ? vp[d] + v * 128 : DEAD);
       if constexpr (!POOL) {
 #pragma unroll
         for (int v = 0; v < TJ; ++v)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_void_t *)(base + (TI + TJ + v) * 8192 + (wave * 2 + d) * 1024), 16,
-                                                   live ? vp[d] + v * 128 : DEAD, 0, 0, 0);
+          lds_dma16(dsD, base + (TI + TJ + v) * 8192 + (wave * 2 + d) * 1024, live ? vp[d] + v * 128 : DEAD);
       }
       vx[d] += x_step;
       vp[d] += p_step;
@@ -162,10 +160,8 @@ __global__ __launch_bounds__(256) void sa_bwd_kernel(const SaBwdArgs ar) {
       const long row0 = (long)(kt0 + step) * 64 + wave * 16;
       const unsigned grp = (unsigned)(row0 >> sshift);
       const bool ok = live && row0 < ar.R;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_void_t *)(base + C::UNITS * 8192 + wave * 2048), 16,
-                                               ok && lane * 8 < ar.Nj ? (grp * (unsigned)ar.Nj + lane * 8) * 2u : DEAD, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t *)(base + C::UNITS * 8192 + wave * 2048 + 1024), 16,
-                                               ok && lane * 16 < ar.Nj ? grp * (unsigned)ar.Nj + lane * 16 : DEAD, 0, 0, 0);
+      lds_dma16(dsD, base + C::UNITS * 8192 + wave * 2048, ok && lane * 8 < ar.Nj ? (grp * (unsigned)ar.Nj + lane * 8) * 2u : DEAD);
+      lds_dma16(dsA, base + C::UNITS * 8192 + wave * 2048 + 1024, ok && lane * 16 < ar.Nj ? grp * (unsigned)ar.Nj + lane * 16 : DEAD);
     }
   };
 

@@ -1727,8 +1727,8 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const WgradRowsArgs ar)
   const int kt0 = (int)blockIdx.x * kt_per;
   const int nkt = max(0, min(kt_per, nkt_all - kt0));   // (0: this workgroup's slice is all zeros)
 
-  const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void *)ar.P, 0, ar.p_bytes, 0x00020000);
-  const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void *)ar.Q, 0, ar.q_bytes, 0x00020000);
+  // (the LDS-DMAs are inline asm -- gemm_common.h, lds_dma16: hipcc fenced the transposed reads of every step against the builtin)
+  const i32x4_rs rsP = raw_rsrc_v4(ar.P, ar.p_bytes), rsQ = raw_rsrc_v4(ar.Q, ar.q_bytes);
   const int cp = lane & 7;
   unsigned vp[2], vq[2];
 #pragma unroll
@@ -1746,12 +1746,10 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const WgradRowsArgs ar)
     for (int d = 0; d < 2; ++d) {
 #pragma unroll
       for (int u = 0; u < TI; ++u)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_void_t *)(smem + base + u * 8192 + (wave * 2 + d) * 1024), 16,
-                                                 live ? vp[d] + u * 128 : 0x80000000u, 0, 0, 0);
+        lds_dma16(rsP, smem + base + u * 8192 + (wave * 2 + d) * 1024, live ? vp[d] + u * 128 : 0x80000000u);
 #pragma unroll
       for (int v = 0; v < TJ; ++v)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_void_t *)(smem + base + (TI + v) * 8192 + (wave * 2 + d) * 1024),
-                                                 16, live ? vq[d] + v * 128 : 0x80000000u, 0, 0, 0);
+        lds_dma16(rsQ, smem + base + (TI + v) * 8192 + (wave * 2 + d) * 1024, live ? vq[d] + v * 128 : 0x80000000u);
       vp[d] += p_step;
       vq[d] += q_step;
     }

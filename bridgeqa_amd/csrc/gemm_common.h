@@ -217,6 +217,33 @@ __device__ __forceinline__ bf16x8 read_frag_asm(unsigned unit, int sub16, int kk
   }
 }
 
+// An LDS-DMA the compiler cannot see (round 6): 16 B per lane from buffer offset `voff` (bounds-checked by the descriptor) to
+// LDS byte address lds + 16 * lane (lds wave-uniform).  Issued through __builtin_amdgcn_raw_ptr_buffer_load_lds hipcc fences
+// EVERY later LDS access of the kernel against it (s_waitcnt vmcnt(0) in front of plain reads, transposed reads and writes
+// alike); a kernel whose in-place LDS work is ordered by its own counted waits and barriers loses its stages to that fence.
+// M0 is written inside the asm and not declared (a reserved register: hipcc ignores it on a clobber list): a kernel uses EITHER
+// this OR the builtin for all its DMAs -- the compiler hoists its own M0 initialisations as if nobody else wrote M0.
+// BQ_DMA_ASM=0 (measurement builds) restores the builtin.
+#ifndef BQ_DMA_ASM
+#define BQ_DMA_ASM 1
+#endif
+typedef int i32x4_rs __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4_rs raw_rsrc_v4(const void *p, unsigned bytes) {   // = make_buffer_rsrc(p, 0, bytes, 0x00020000)
+  const unsigned long a = (unsigned long)p;
+  i32x4_rs r;
+  r[0] = (int)(unsigned)a; r[1] = (int)(unsigned)((a >> 32) & 0xffffu); r[2] = (int)bytes; r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void lds_dma16(i32x4_rs rs, const void *lds, unsigned voff) {
+  if (!BQ_DMA_ASM) {
+    const auto r = __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long)(unsigned)rs[1] << 32) | (unsigned)rs[0]), 0, rs[2], rs[3]);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t *)(lds_u8c_t *)lds, 16, voff, 0, 0, 0);
+    return;
+  }
+  const unsigned l = lds_addr_of(lds);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(l), "v"(voff), "s"(rs) : "memory");
+}
+
 // the closed-form contraction-major read (read_frag_cf<true>) as inline asm, for the same reason as read_frag_asm; the
 // K-contiguous form stays a compiler-visible load (hipcc does not fence those: tools/isa_waits.py)
 template <bool XC>

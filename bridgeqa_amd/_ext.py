@@ -924,6 +924,14 @@ def _mat_rows(t, name):
     return (B * R, C), ld, R, bs
 
 
+# forward / dX launches (K-contiguous operands, plain or bias epilogue) whose contraction is at least this long run on the
+# 256 x 256 kernel instead of the 256 x 128 one: since round 6's K loop (two 32-MFMA phases, no compiler fence) it is level or
+# ahead alone on fc2 forward (71 against 77 us), dX through fc1 (71 / 72) and dX through qkv (56 / 56), and inside the c3 step
+# 31.81 against 32.05 ms (five interleaved pairs, 7 of 8 pairs over two calls in favour; profiles/r06_tile256_long_k.txt).
+# 0 = never (tools/ab_bench.py "_ext.TILE256_MIN_K[0]=0")
+TILE256_MIN_K = [2304]
+
+
 def pick_tile(Ni, Nj, q_xc, mid_ok=False):
     if Nj >= GEMM_TILE_ROWS and Ni >= 256:
         return 128 if mid_ok else 256
@@ -988,6 +996,9 @@ def gemm_grouped(problems, flags, epilogue=EPI_NONE, tile=None):
         t_auto = max(t_auto, pick_tile(Ni, Nj, qxc, True))
     if t_auto == 128 and not all_mid_ok:
         t_auto = 256   # (one tile class per launch: every problem of the group must be able to take the 256 x 128 kernel)
+    if (t_auto == 128 and TILE256_MIN_K[0] and not pxc and epilogue in (EPI_NONE, EPI_BIAS)
+            and all(int(arr[k].Kc) >= TILE256_MIN_K[0] for k in range(n))):
+        t_auto = 256   # (long contractions: TILE256_MIN_K above)
     if t_auto == 256 and any_map and tile is None and not (pxc and qxc and f32):
         t_auto = 64    # (the 256 x 256 kernel maps only the contraction rows of its weight-gradient form)
     dev = problems[0]["out"].device

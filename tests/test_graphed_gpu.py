@@ -160,9 +160,9 @@ def test_the_plain_loop_trains_under_replay_like_the_eager_loop_and_the_phased_s
         d = ((pvec - ref_p).norm() / ref_p.norm()).item()
         print("parameters after 4 steps, %s vs eager: rel-L2 %.3e, max abs %.3e; losses %s" % (mode, d, (pvec - ref_p).abs().max().item(), l))
         assert d <= 6e-4, (mode, d)
-        # the later losses: on the eager execution's trajectory (to the digit) or on the other one -- never anywhere else
-        same = all(abs(a - b) <= 1e-3 * abs(b) for a, b in zip(l, ref_l))
-        assert same or d >= 5e-5, (mode, l, ref_l, d)
+        # on the eager execution's trajectory (all four losses to 1e-3) the parameters agree far tighter: measured 3e-7
+        if all(abs(a - b) <= 1e-3 * abs(b) for a, b in zip(l, ref_l)):
+            assert d <= 1e-5, (mode, d)
 
 
 def test_graphed_forward_keeps_the_module_api(dev):

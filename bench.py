@@ -1122,7 +1122,8 @@ def main():
         if workload == "c3":
             per, tot_f, tot_ms, traffic, prof_frac = gemm_roofline(args, dev)
             out["roofline"] = {"kernel": "bq::gemm128_kernel (csrc/gemm_mid.hip: forward / input-gradient forms, 256x128 tiles, "
-                                         "persistent, 2 workgroups per CU) + bq::gemm256_kernel (csrc/gemm.hip: weight gradients): "
+                                         "persistent, 2 workgroups per CU) + bq::gemm256_kernel (csrc/gemm.hip: weight gradients and, since round 6, the "
+                                         "forward / dX launches with a contraction >= 2304: fc2 forward, dX through fc1 and qkv): "
                                          "the 8 launches of one ViT block (forward + dX, with the epilogues the step uses) + "
                                          "the grouped dW launch of all 12 blocks", "bound": "mfma",
                                "achieved": round(tot_f / tot_ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",

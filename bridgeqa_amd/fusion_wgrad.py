@@ -113,10 +113,11 @@ _PLAN_WGRAD = [True]
 _QSUM = [True]
 _QSUM64 = [True]
 _DW_TILE = [256]   # 256: gemm256_kernel (one workgroup per CU); 128: the 256 x 128 persistent kernel's weight-gradient form
-_SHORT_DW_TILE = [128]  # short contractions (128 <= rows < 1024: the text side's B x 20 token rows): 128 = the persistent
-                        # 256 x 128 kernel's weight-gradient form (1.9 x the output bytes staged through LDS per tile), 64 = the
-                        # 64 x 64-tile kernel (5 x).  tools/bench_short_dw.py, both forms graph-replayed and interleaved: the twin
-                        # levels' 144 problems 0.645 -> 0.480 ms (0.79 GB of fp32 gradients: 1.65 TB/s), bit-identical results
+_SHORT_DW_TILE = [256]  # short contractions (128 <= rows < 1024: the text side's B x 20 token rows): 256 = gemm256_kernel (since
+                        # round 6's K loop: the 228 problems of one flush 0.52 ms against 0.59 on the persistent 256 x 128
+                        # kernel's weight-gradient form and 0.77 on the 64 x 64-tile kernel, tools/bench_short_dw.py, each form
+                        # graph-replayed and interleaved, bit-identical results; c3 step 31.31 -> 31.17 ms over five interleaved
+                        # pairs, profiles/r06_short_dw_tile.txt); 128 and 64 select the other two
 
 
 def plan_big_launches(tiles, cus, max_problems=36, moved_cost=0.011):
@@ -204,14 +205,14 @@ def flush_deferred_items(items):
         small = small + [big[j] for j in moved]
     dbs = {}
     mid = []
-    if _SHORT_DW_TILE[0] == 128:
+    if _SHORT_DW_TILE[0] in (128, 256):
         # (only the SHORT contractions: the planner's moved problems -- full 16 400-row contractions of 9 tiles -- stay on
         # the 64-tile kernel, whose cut contraction spreads them over the chip: the 256 x 128 form ran them at 5 % MFMA busy)
         ok = lambda it: (128 <= _nrows(it[0]) < _BIG_ROWS and it[0].dim() == 2 and it[0].shape[-1] >= 128
                          and it[1].shape[-1] >= 256)
         mid = [k for k in small if ok(items[k])]
         small = [k for k in small if not ok(items[k])]
-    for tile, idx_groups in ((_DW_TILE[0], groups), (128, [mid] if mid else []), (64, [small] if small else [])):
+    for tile, idx_groups in ((_DW_TILE[0], groups), (_SHORT_DW_TILE[0], [mid] if mid else []), (64, [small] if small else [])):
         for idx in idx_groups:
             probs = []
             for k in idx:

@@ -47,7 +47,7 @@ def flush():
 # the step replays the flush from a HIP graph (no host time between its launches): so does this
 graphs = {}
 side = torch.cuda.Stream()
-for tile in (64, 128):
+for tile in (64, 128, 256):
     fusion_wgrad._SHORT_DW_TILE[0] = tile
     with torch.cuda.stream(side):
         for _ in range(3):
@@ -58,14 +58,14 @@ for tile in (64, 128):
         flush()
     graphs[tile] = gr
 torch.cuda.synchronize()
-res = {64: [], 128: []}
+res = {64: [], 128: [], 256: []}
 for rep in range(15):
-    for tile in (64, 128):
+    for tile in (64, 128, 256):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); graphs[tile].replay(); e1.record()
         torch.cuda.synchronize()
         res[tile].append(e0.elapsed_time(e1))
-for tile in (64, 128):
+for tile in (64, 128, 256):
     v = sorted(res[tile])
     print("short contractions on tile %3d: median %.3f ms  min %.3f  (%.2f TB/s of gradient writes)" % (
         tile, v[len(v) // 2], v[0], out_bytes / (v[len(v) // 2] * 1e-3) / 1e12))

@@ -113,6 +113,8 @@ _PLAN_WGRAD = [True]
 _QSUM = [True]
 _QSUM64 = [True]
 _DW_TILE = [256]   # 256: gemm256_kernel (one workgroup per CU); 128: the 256 x 128 persistent kernel's weight-gradient form
+_SHORT_DW_MIN_ROWS = [64]    # contractions from this many rows on (the decoder's B x 5 answer rows = 80 included: the flush 0.53 -> 0.48 ms,
+                             # bit-identical; the 256 x 128 form, _SHORT_DW_TILE = 128, needs >= 128)
 _SHORT_DW_TILE = [256]  # short contractions (128 <= rows < 1024: the text side's B x 20 token rows): 256 = gemm256_kernel (since
                         # round 6's K loop: the 228 problems of one flush 0.52 ms against 0.59 on the persistent 256 x 128
                         # kernel's weight-gradient form and 0.77 on the 64 x 64-tile kernel, tools/bench_short_dw.py, each form
@@ -206,9 +208,10 @@ def flush_deferred_items(items):
     dbs = {}
     mid = []
     if _SHORT_DW_TILE[0] in (128, 256):
+        min_rows = max(_SHORT_DW_MIN_ROWS[0], 128 if _SHORT_DW_TILE[0] == 128 else 1)
         # (only the SHORT contractions: the planner's moved problems -- full 16 400-row contractions of 9 tiles -- stay on
         # the 64-tile kernel, whose cut contraction spreads them over the chip: the 256 x 128 form ran them at 5 % MFMA busy)
-        ok = lambda it: (128 <= _nrows(it[0]) < _BIG_ROWS and it[0].dim() == 2 and it[0].shape[-1] >= 128
+        ok = lambda it: (min_rows <= _nrows(it[0]) < _BIG_ROWS and it[0].dim() == 2 and it[0].shape[-1] >= 128
                          and it[1].shape[-1] >= 256)
         mid = [k for k in small if ok(items[k])]
         small = [k for k in small if not ok(items[k])]

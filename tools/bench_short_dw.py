@@ -23,6 +23,10 @@ def add(M, N, K):
     items.append((rnd(M, N), rnd(M, K), [w], [b]))
 
 
+if "--min-rows" in sys.argv:   # fusion_wgrad._SHORT_DW_MIN_ROWS: contractions from this many rows on take the tile under test
+    k = sys.argv.index("--min-rows")
+    fusion_wgrad._SHORT_DW_MIN_ROWS[0] = int(sys.argv[k + 1])
+    del sys.argv[k:k + 2]
 WHAT = sys.argv[1] if len(sys.argv) > 1 else "all"   # all | twin | decoder
 if WHAT in ("all", "twin"):
     for lvl in range(12):
@@ -47,7 +51,8 @@ def flush():
 # the step replays the flush from a HIP graph (no host time between its launches): so does this
 graphs = {}
 side = torch.cuda.Stream()
-for tile in (64, 128, 256):
+TILES = (64, 128, 256) if fusion_wgrad._SHORT_DW_MIN_ROWS[0] >= 128 else (64, 256)   # (the 256 x 128 form needs >= 128 rows)
+for tile in TILES:
     fusion_wgrad._SHORT_DW_TILE[0] = tile
     with torch.cuda.stream(side):
         for _ in range(3):
@@ -58,20 +63,20 @@ for tile in (64, 128, 256):
         flush()
     graphs[tile] = gr
 torch.cuda.synchronize()
-res = {64: [], 128: [], 256: []}
+res = {t: [] for t in TILES}
 for rep in range(15):
-    for tile in (64, 128, 256):
+    for tile in TILES:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); graphs[tile].replay(); e1.record()
         torch.cuda.synchronize()
         res[tile].append(e0.elapsed_time(e1))
-for tile in (64, 128, 256):
+for tile in TILES:
     v = sorted(res[tile])
     print("short contractions on tile %3d: median %.3f ms  min %.3f  (%.2f TB/s of gradient writes)" % (
         tile, v[len(v) // 2], v[0], out_bytes / (v[len(v) // 2] * 1e-3) / 1e12))
 # parity of the two forms
 fusion_wgrad._SHORT_DW_TILE[0] = 64
 flush(); a = [p.grad.clone() for p in params]
-fusion_wgrad._SHORT_DW_TILE[0] = 128
+fusion_wgrad._SHORT_DW_TILE[0] = TILES[-1]
 flush(); b = [p.grad for p in params]
 print("max |difference| between the forms: %.3e" % max((x - y).abs().max().item() for x, y in zip(a, b)))

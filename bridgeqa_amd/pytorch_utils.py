@@ -185,6 +185,8 @@ class _ConvBNReLUPointMajor(torch.autograd.Function):
             if _WGRAD_ROWS and R >= _WGRAD_ROWS_MIN and _ext.wgrad_rows_ok(ldx, N):
                 # whole rows staged once for all output tiles, slices summed in a fixed order: no atomics
                 dwf = _ext.wgrad_rows(xs, dy, torch.empty(N, ldx, dtype=torch.float32, device=x.device), _WGRAD_ROWS_WGS)
+            elif _CUT_DW_DETERMINISTIC[0]:
+                dwf, _ = _cut_dw(xs, dy, _wgrad_pieces(R, tiles), False)
             else:
                 dwf = torch.zeros(N, ldx, dtype=torch.float32, device=x.device)
                 ksplit = _wgrad_pieces(R, tiles)
@@ -209,6 +211,34 @@ def _wgrad_pieces(R, tiles):
     kernel keeps 3 per CU resident: 768 a round), a multiple of 8 so that the kernel's XCD-aware order applies"""
     ks = max(1, min((R + 63) // 64, _WGRAD_WGS // tiles))
     return ks - ks % 8 if ks >= 8 else ks
+
+
+_CUT_DW_DETERMINISTIC = [True]   # cut weight-gradient contractions as separate problems summed in a fixed order (no fp32 atomics)
+
+
+def _cut_dw(xs, dy, pieces, want_colsum):
+    """dW (N, ld) = dy^T xs -- and, on request, the column sums of dy -- with the row contraction cut into `pieces` PROBLEMS of one
+    grouped launch (whole K tiles each, at most the launch's 36), whose fp32 partial results are summed in a fixed order: no
+    atomics, bit-reproducible (round 6: these cut contractions were the last gradients of the detector that moved from one
+    execution to the next, tools/grad_determinism.py).  xs (R, ld), dy (R, N) bf16 rows."""
+    from . import _ext
+    R, N, ld = xs.shape[0], dy.shape[1], xs.shape[1]
+    pieces = max(1, min(int(pieces), int(_ext._lib.bq_gemm_max_problems())))
+    step = -(-(-(-R // pieces)) // 64) * 64
+    pieces = -(-R // step)
+    part = torch.empty(pieces, N, ld, dtype=torch.float32, device=xs.device)
+    cs = torch.empty(pieces, N, dtype=torch.float32, device=xs.device) if want_colsum else None
+    probs = []
+    for i in range(pieces):
+        r0, r1 = i * step, min(R, (i + 1) * step)
+        pr = dict(P=xs[r0:r1], Q=dy[r0:r1], out=part[i])
+        if want_colsum:
+            pr["colsum"] = cs[i]
+        probs.append(pr)
+    _ext.gemm_grouped(probs, _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32, _ext.EPI_NONE, 64)
+    if pieces == 1:
+        return part[0], (cs[0] if want_colsum else None)
+    return part.sum(0), (cs.sum(0) if want_colsum else None)
 
 
 def _rows_view_ok(x):
@@ -308,10 +338,13 @@ class _RowsLinearF32(torch.autograd.Function):
             dx = torch.empty(R, K, dtype=torch.bfloat16, device=g.device)
             _ext.gemm_grouped([dict(P=wp, Q=gp, out=dx, Kc=Nc, q_bytes=gp.numel() * 2)], _ext.GEMM_P_XC, _ext.EPI_NONE)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            dwp = torch.zeros(Np, K, dtype=torch.float32, device=g.device)
-            dbp = torch.zeros(Np, dtype=torch.float32, device=g.device)
-            _ext.gemm_grouped([dict(P=rows, Q=gp, out=dwp, colsum=dbp, ksplit=max(1, min(64, R // 512)))],
-                              _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32, _ext.EPI_NONE, 64)
+            if _CUT_DW_DETERMINISTIC[0]:
+                dwp, dbp = _cut_dw(rows, gp, max(1, min(64, R // 512)), True)
+            else:
+                dwp = torch.zeros(Np, K, dtype=torch.float32, device=g.device)
+                dbp = torch.zeros(Np, dtype=torch.float32, device=g.device)
+                _ext.gemm_grouped([dict(P=rows, Q=gp, out=dwp, colsum=dbp, ksplit=max(1, min(64, R // 512)))],
+                                  _ext.GEMM_P_XC | _ext.GEMM_Q_XC | _ext.GEMM_OUT_F32, _ext.EPI_NONE, 64)
             dw, db = dwp[:N], (dbp[:N] if has_bias else None)
         return dx, dw, db
 

@@ -4,11 +4,12 @@ the number of executions whose gradient differs in any bit from the first one's,
     python tools/grad_determinism.py [c2|c3] [N]
 
 Why it exists (round 6): the four-step loop test found a second loss trajectory in one execution out of seven, whatever the mode
--- some fp32 sum is not order-stable; this names the parameters whose gradients move.  c2 (the detector stage), 24 executions:
-one loss value; 66 of 77 parameter gradients bit-identical every time (every SharedMLP of the SA modules: sa_bwd / wgrad_rows,
-the gather gradients); 11 move by 2e-7 .. 6e-7 of their largest element -- the convolutions of the FP modules, of the voting
-module and of the proposal head, whose weight gradients are cut contractions summed with fp32 atomics (pytorch_utils
-_RowsLinearF32 and the FP layers' flush).  (c3 is not comparable this way: fusion_ops.new_step draws new dropout masks.)"""
+-- some fp32 sum is not order-stable; this names the parameters whose gradients move.  c2 (the detector stage), 24 executions,
+first run: one loss value; 66 of 77 parameter gradients bit-identical every time (every SharedMLP of the SA modules: sa_bwd /
+wgrad_rows, the gather gradients); 11 moved by 2e-7 .. 6e-7 of their largest element -- the convolutions of the FP modules, of
+the voting module and of the proposal head, whose weight gradients were cut contractions summed with fp32 atomics.  Since
+pytorch_utils._cut_dw (the pieces as separate problems of one launch, summed in a fixed order): 0 of 77 over 16 executions.
+(c3 is not comparable this way: fusion_ops.new_step draws new dropout masks.)"""
 import os
 import sys
 
